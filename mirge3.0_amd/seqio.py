@@ -1,0 +1,157 @@
+"""Flat (ragged) sequence containers shared by the host code, the tests and the bench.
+
+A set of sequences is held as one ASCII byte array plus an int64 offsets array
+(``offsets[i]:offsets[i+1]`` is sequence ``i``).  That is the exact shape the C ABI takes
+(``include/mirge_native.h``), so nothing is re-laid-out between Python and the kernels.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Sequence
+
+import numpy as np
+
+
+@dataclass
+class FlatSeqs:
+    """Ragged ASCII sequences: ``data`` uint8, ``offsets`` int64 of length n+1."""
+    data: np.ndarray
+    offsets: np.ndarray
+
+    def __len__(self) -> int:
+        return int(self.offsets.shape[0] - 1)
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return np.diff(self.offsets)
+
+    def get(self, i: int) -> str:
+        return self.data[self.offsets[i]:self.offsets[i + 1]].tobytes().decode("ascii")
+
+    def to_list(self) -> List[str]:
+        buf = self.data.tobytes()
+        o = self.offsets
+        return [buf[o[i]:o[i + 1]].decode("ascii") for i in range(len(self))]
+
+    @staticmethod
+    def from_list(seqs: Sequence[str]) -> "FlatSeqs":
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+        offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        data = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).copy()
+        return FlatSeqs(data, offsets)
+
+    def take(self, idx: np.ndarray) -> "FlatSeqs":
+        idx = np.asarray(idx, dtype=np.int64)
+        lens = self.lengths[idx]
+        offsets = np.zeros(idx.shape[0] + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        total = int(offsets[-1])
+        # gather: position j of output belongs to row r = searchsorted(offsets, j)
+        rows = np.repeat(np.arange(idx.shape[0], dtype=np.int64), lens)
+        within = np.arange(total, dtype=np.int64) - offsets[:-1][rows]
+        data = self.data[self.offsets[:-1][idx][rows] + within]
+        return FlatSeqs(data, offsets)
+
+
+@dataclass
+class Library:
+    """One small-RNA reference library (what a bowtie index stands for in the reference,
+    ``mirge/libs/manifoldAlign.py:84,97-98``).
+
+    ``names`` are the SAM ``RNAME`` values bowtie would print, i.e. the FASTA header up to
+    the first whitespace; ``headers`` keep the full header line (``bowtie-inspect -n``
+    prints those, ``mirge/libs/summary.py:776-788``).
+    """
+    names: List[str]
+    seqs: FlatSeqs
+    headers: List[str] = field(default_factory=list)
+
+    def __post_init__(self):
+        if not self.headers:
+            self.headers = list(self.names)
+
+    def __len__(self) -> int:
+        return len(self.names)
+
+    @property
+    def total_len(self) -> int:
+        return int(self.seqs.offsets[-1])
+
+
+def read_fasta(path: str) -> Library:
+    names: List[str] = []
+    headers: List[str] = []
+    chunks: List[str] = []
+    cur: List[str] = []
+    with open(path, "r") as fh:
+        for line in fh:
+            line = line.rstrip("\r\n")
+            if not line:
+                continue
+            if line[0] == ">":
+                if headers:
+                    chunks.append("".join(cur))
+                    cur = []
+                headers.append(line[1:])
+                names.append(line[1:].split()[0] if line[1:].split() else "")
+            else:
+                cur.append(line.strip().upper().replace("U", "T"))
+    if headers:
+        chunks.append("".join(cur))
+    return Library(names, FlatSeqs.from_list(chunks), headers)
+
+
+def write_fasta(path: str, lib: Library) -> None:
+    seqs = lib.seqs.to_list()
+    with open(path, "w") as fh:
+        for h, s in zip(lib.headers, seqs):
+            fh.write(">" + h + "\n" + s + "\n")
+
+
+# Library keys in cascade order and the reference's index-name suffixes
+# (mirge/libs/manifoldAlign.py:84,97,115-117).  ``{db}`` is appended for the miRNA and
+# hairpin libraries only.
+LIB_KEYS = ["mirna", "hairpin", "mature_trna", "pre_trna", "snorna", "rrna",
+            "ncrna_others", "mrna", "spike-in"]
+_DB_SUFFIXED = {"mirna", "hairpin"}
+
+
+def index_basename(organism: str, key: str, ref_db: str) -> str:
+    return f"{organism}_{key}_{ref_db}" if key in _DB_SUFFIXED else f"{organism}_{key}"
+
+
+def load_library_dir(libraries_path: str, organism: str, ref_db: str,
+                     with_spike: bool = False) -> Dict[str, Library]:
+    """Load ``<lib>/<org>/index.Libs/<org>_<key>[_<db>].fa``.
+
+    The reference keeps only bowtie ``.ebwt`` indexes there; this build reads the FASTA the
+    index was made from, stored next to it under the same base name (hard
+    part 2: the ``.ebwt`` reader is a 'next' row).
+    """
+    base = os.path.join(libraries_path, organism, "index.Libs")
+    out: Dict[str, Library] = {}
+    for key in LIB_KEYS:
+        if key == "spike-in" and not with_spike:
+            continue
+        p = os.path.join(base, index_basename(organism, key, ref_db) + ".fa")
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"library FASTA missing: {p}")
+        out[key] = read_fasta(p)
+    return out
+
+
+def load_merges(libraries_path: str, organism: str, ref_db: str) -> List[List[str]]:
+    """``<org>_merges_<db>.csv``: first field merged name, rest members
+    (mirge/libs/summary.py:707-712).  Missing file -> no merges (``:713-714``)."""
+    p = os.path.join(libraries_path, organism, "annotation.Libs",
+                     f"{organism}_merges_{ref_db}.csv")
+    rows: List[List[str]] = []
+    try:
+        with open(p, "r") as fh:
+            for line in fh:
+                rows.append(line.strip().split(","))
+    except FileNotFoundError:
+        pass
+    return rows

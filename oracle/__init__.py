@@ -1,0 +1,237 @@
+"""oracle -- CPU restatement of the miRge3.0 hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; the product path (``mirge3.0_amd``) never does.
+
+PARITY STATUS -- "parity unpinned" for the alignment predicate: the cascade's arithmetic is
+bowtie 1.x (third-party, absent here, no golden vectors in the reference); see the header of
+``mirge_oracle.c``.  Pinned against the real reference code through ``tests/golden``:
+pass order / subsets / overwrite rule (``mirge/libs/manifoldAlign.py:12-146``), the collapse
+rule (``mirge/libs/digest.py:141-163``) and the whole count join (``mirge/libs/summary.py``).
+
+* ``mirge_oracle.c``: cascade (brute force + indexed) and collapse, plain C.
+* ``join`` below: the count join of ``summary.py:25-45,677-798,882-901,1223-1291`` in numpy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmirge_oracle.so")
+_SRC = os.path.join(_HERE, "mirge_oracle.c")
+
+
+def build(force: bool = False) -> str:
+    """gcc the C restatement into oracle/_build/ (git-ignored; travels to the GPU box)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-shared", "-fPIC", "-o", _SO, _SRC])
+    return _SO
+
+
+class _Policy(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "mode", "mm", "seedlen", "maxtotal", "trim5", "trim3", "ttail", "len_lt", "len_gt",
+        "need_unannotated")]
+
+
+class _Lib(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("offsets", C.c_void_p), ("n", C.c_int64)]
+
+
+# The ten passes: column written, library key, bowtie argument string
+# (mirge/libs/manifoldAlign.py:84-85) and the restated predicate.
+PASSES = [
+    # column,          lib key,        bowtie args (verbatim),                      policy
+    ("exact miRNA",   "mirna",        "-n 0 -f --norc -S",
+     dict(mode=0, mm=0, seedlen=28, maxtotal=2, len_lt=26)),
+    ("hairpin miRNA", "hairpin",      "-n 1 -f --norc -S",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2, len_gt=25)),
+    ("mature tRNA",   "mature_trna",  "-v 1 -f -a --best --strata --norc -S",
+     dict(mode=1, mm=1, seedlen=28, maxtotal=1, need_unannotated=1)),
+    ("primary tRNA",  "pre_trna",     "-v 0 -f -a --best --strata --norc -S",
+     dict(mode=1, mm=0, seedlen=28, maxtotal=0, ttail=1, need_unannotated=1)),
+    ("snoRNA",        "snorna",       "-n 1 -f --norc -S",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2, need_unannotated=1)),
+    ("rRNA",          "rrna",         "-n 1 -f --norc -S",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2, need_unannotated=1)),
+    ("ncrna others",  "ncrna_others", "-n 1 -f --norc -S",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2, need_unannotated=1)),
+    ("mRNA",          "mrna",         "-n 0 -f --norc -S",
+     dict(mode=0, mm=0, seedlen=28, maxtotal=2, need_unannotated=1)),
+    ("isomiR miRNA",  "mirna",        "-5 1 -3 2 -v 2 -f --norc --best -S",
+     dict(mode=1, mm=2, seedlen=28, maxtotal=2, trim5=1, trim3=2, need_unannotated=1)),
+    ("spike-in",      "spike-in",     "-n 0 -f --norc -S",
+     dict(mode=0, mm=0, seedlen=28, maxtotal=2, need_unannotated=1)),
+]
+
+
+def _lib():
+    so = C.CDLL(build())
+    so.oracle_cascade.restype = C.c_int
+    so.oracle_collapse.restype = C.c_int64
+    so.oracle_align_one.restype = C.c_int
+    return so
+
+
+def _policy(d: dict) -> _Policy:
+    p = _Policy()
+    for k, v in d.items():
+        setattr(p, k, v)
+    return p
+
+
+def cascade(data: np.ndarray, offsets: np.ndarray,
+            libs: Sequence[Optional[Tuple[np.ndarray, np.ndarray]]],
+            n_pass: int = 9, indexed: bool = False, threads: int = 0,
+            policies: Optional[Sequence[dict]] = None):
+    """Run the cascade.  ``libs[p]`` = (ascii uint8, int64 offsets) of the library of pass p
+    (or None to skip the pass).  Returns int32 arrays (pass, ref, off, mm), -1 = unannotated."""
+    so = _lib()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.shape[0] - 1
+    keep = []
+    arr = (_Lib * n_pass)()
+    for p in range(n_pass):
+        lp = libs[p]
+        if lp is None:
+            arr[p].n = 0
+            continue
+        d = np.ascontiguousarray(lp[0], dtype=np.uint8)
+        o = np.ascontiguousarray(lp[1], dtype=np.int64)
+        keep += [d, o]
+        arr[p].data, arr[p].offsets, arr[p].n = d.ctypes.data, o.ctypes.data, o.shape[0] - 1
+    pol = (_Policy * n_pass)(*[_policy((policies[p] if policies else PASSES[p][3])) for p in range(n_pass)])
+    out = [np.empty(max(n, 1), dtype=np.int32) for _ in range(4)]
+    so.oracle_cascade(C.c_void_p(data.ctypes.data), C.c_void_p(offsets.ctypes.data), C.c_int64(n),
+                      arr, pol, C.c_int32(n_pass), C.c_int32(1 if indexed else 0), C.c_int32(threads),
+                      *[C.c_void_p(a.ctypes.data) for a in out])
+    return tuple(a[:n] for a in out)
+
+
+def collapse(data: np.ndarray, offsets: np.ndarray):
+    """-> (first_index[U], count[U], inverse[n]); uniques in order of first appearance."""
+    so = _lib()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.shape[0] - 1
+    first = np.empty(max(n, 1), dtype=np.int64)
+    cnt = np.empty(max(n, 1), dtype=np.int64)
+    inv = np.empty(max(n, 1), dtype=np.int64)
+    U = so.oracle_collapse(C.c_void_p(data.ctypes.data), C.c_void_p(offsets.ctypes.data), C.c_int64(n),
+                           C.c_void_p(first.ctypes.data), C.c_void_p(cnt.ctypes.data),
+                           C.c_void_p(inv.ctypes.data))
+    return first[:U], cnt[:U], inv[:n]
+
+
+# --------------------------------------------------------------------------------------
+# count join (mirge/libs/summary.py)
+# --------------------------------------------------------------------------------------
+REPORT_CLASSES = [  # (report column, pass index)  summary.py:686-690,895-901
+    ("Hairpin miRNAs", 1), ("mature tRNA Reads", 2), ("primary tRNA Reads", 3),
+    ("snoRNA Reads", 4), ("rRNA Reads", 5), ("ncRNA others", 6), ("mRNA Reads", 7),
+]
+
+
+def _fmt_float(x: float) -> str:
+    return repr(float(x))
+
+
+def join(pass_: np.ndarray, ref: np.ndarray, counts: np.ndarray, mirna_names: List[str],
+         mirna_headers: List[str], merges: List[List[str]], samples: List[str],
+         sample_read_counts: Dict[str, int], trimmed_read_counts: Dict[str, int],
+         trimmed_unique: Dict[str, int], cr_threshold: float = 0.1, spike: bool = False):
+    """Restates summary.py: per-class sums (:686-698), exact/isomiR group-by (:749-752),
+    mirge_can (:25-45), merged-family renaming (:759-764), totals (:766-771,882-888), the
+    full name universe (:774-790) and the three CSV texts (:796-797,1281-1284)."""
+    S = len(samples)
+    counts = np.asarray(counts, dtype=np.int64).reshape(-1, S)
+    R = len(mirna_names)
+    class_sums = {}
+    classes = list(REPORT_CLASSES) + ([("Spike-in", 9)] if spike else [])
+    for col, p in classes:
+        class_sums[col] = counts[pass_ == p].sum(axis=0)
+    exact = np.zeros((R, S), dtype=np.int64)
+    iso = np.zeros((R, S), dtype=np.int64)
+    m0, m8 = pass_ == 0, pass_ == 8
+    np.add.at(exact, ref[m0], counts[m0])
+    np.add.at(iso, ref[m8], counts[m8])
+    all_mirna = counts[m0 | m8].sum(axis=0)  # 'All miRNA Reads' summary.py:769-771
+    has_exact = np.zeros(R, dtype=bool)
+    has_exact[ref[m0]] = True  # groupby keeps names that occur, even with zero counts
+    merged_of = {}
+    universe: Dict[str, int] = {}
+    for row in merges:
+        for item in row[1:]:
+            merged_of[item] = row[0]
+            universe[row[0]] = 1
+    # mirge_can per sample, over the names that have exact rows (left merge)
+    filt: Dict[str, np.ndarray] = {}
+    # pandas dtype flow of mirge_can: a sample column stays int64 only if every exact-name row
+    # passes the ratio test (no NaN is introduced at summary.py:41); one NaN makes it float64
+    col_all_pass = np.ones(S, dtype=bool)
+    for r in np.nonzero(has_exact)[0]:
+        x = exact[r].astype(np.float64)
+        y = iso[r].astype(np.float64)
+        low = x < 2
+        x = np.where(low, 0.0, x)
+        y = np.where(low, 0.0, y)
+        ratio = np.where(y > 0, x / np.where(y > 0, y, 1.0), x)
+        ok = ratio > cr_threshold
+        col_all_pass &= ok
+        val = np.where(ok, x + y, 0.0)
+        name = merged_of.get(mirna_names[r], mirna_names[r])
+        filt[name] = filt.get(name, 0.0) + val
+    names_sorted = sorted(filt)
+    table = np.array([filt[nm] for nm in names_sorted], dtype=np.float64).reshape(-1, S)
+    filtered = table.sum(axis=0) if len(names_sorted) else np.zeros(S)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rpm = np.round(table / table.sum(axis=0) * 1e6, 4) if len(names_sorted) else table
+    unique_mirnas = (table > 0).sum(axis=0) if len(names_sorted) else np.zeros(S, dtype=np.int64)
+    for h in mirna_headers:  # bowtie-inspect -n lines, summary.py:783-788
+        srow = h.split(" ")[0] if "segs:" in h else h
+        if srow not in merged_of:
+            universe[srow] = 1
+    all_names = sorted(set(universe) | set(names_sorted))
+    idx = {nm: i for i, nm in enumerate(names_sorted)}
+    outer_adds_nan = any(nm not in idx for nm in all_names)  # join(how='outer').fillna(0), :792
+
+    def table_csv(tab: np.ndarray, int_cols) -> str:
+        lines = ["miRNA," + ",".join(samples)]
+        for nm in all_names:
+            if nm in idx:
+                vals = [0.0 if np.isnan(v) else v for v in tab[idx[nm]]]
+            else:
+                vals = [0.0] * S
+            lines.append(nm + "," + ",".join(str(int(v)) if int_cols[j] else _fmt_float(v)
+                                             for j, v in enumerate(vals)))
+        return "\n".join(lines) + "\n"
+
+    counts_int = [bool(col_all_pass[j]) and not outer_adds_nan for j in range(S)]
+    cols = ["Total Input Reads", "Trimmed Reads (all)", "Trimmed Reads (unique)", "All miRNA Reads",
+            "Filtered miRNA Reads", "Unique miRNAs"] + [c for c, _ in classes] + ["Remaining Reads"]
+    rep_lines = ["Sample name(s)," + ",".join(cols)]
+    report = {}
+    for s, nm in enumerate(samples):
+        row = {
+            "Total Input Reads": int(sample_read_counts[nm]),
+            "Trimmed Reads (all)": int(trimmed_read_counts[nm]),
+            "Trimmed Reads (unique)": int(trimmed_unique[nm]),
+            "All miRNA Reads": int(all_mirna[s]),
+            "Filtered miRNA Reads": int(filtered[s]),
+            "Unique miRNAs": int(unique_mirnas[s]),
+        }
+        for c, _ in classes:
+            row[c] = int(class_sums[c][s])
+        row["Remaining Reads"] = row["Trimmed Reads (all)"] - (row["All miRNA Reads"] + sum(row[c] for c, _ in classes))
+        report[nm] = row
+        rep_lines.append(nm + "," + ",".join(str(row[c]) for c in cols))
+    return dict(class_sums=class_sums, exact=exact, iso=iso, names=names_sorted, table=table, rpm=rpm,
+                report=report, counts_csv=table_csv(table, counts_int), rpm_csv=table_csv(rpm, [False] * S),
+                report_csv="\n".join(rep_lines) + "\n")

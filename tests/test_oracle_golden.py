@@ -1,0 +1,52 @@
+"""The oracle against the golden vectors the REFERENCE produced (tests/golden/make_golden.py).
+
+Pins: pass order, subset rules, T-tail strip, overwrite rule (manifoldAlign.py:12-146) and the
+count join (summary.py) -- the reference's own code ran over the oracle's matcher to make these
+files.  Does not pin bowtie's predicate itself ("parity unpinned", see oracle/mirge_oracle.c).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import CASES, GoldenCase
+
+
+@pytest.fixture(scope="module", params=CASES)
+def case(request):
+    return GoldenCase(request.param)
+
+
+def test_cascade_matches_reference_harness(case):
+    for indexed in (False, True):
+        ps, ref, off, mm = oracle.cascade(case.reads.data, case.reads.offsets, case.oracle_libs(),
+                                          n_pass=case.n_pass, indexed=indexed)
+        exp = case.expected_annotation()
+        assert len(exp) == len(case.seqs)
+        for i, s in enumerate(case.seqs):
+            p = int(ps[i])
+            name = case.lib_of_pass(p).names[int(ref[i])] if p >= 0 else ""
+            assert (p, name) == exp[s], (s, indexed)
+
+
+def test_join_matches_reference_summarize(case):
+    ps, ref, off, mm = oracle.cascade(case.reads.data, case.reads.offsets, case.oracle_libs(),
+                                      n_pass=case.n_pass)
+    mir = case.libs["mirna"]
+    j = oracle.join(ps, ref, case.counts, mir.names, mir.headers, case.merges, case.samples,
+                    case.sample_read_counts, case.trimmed, case.trimmed_unique, spike=case.spike)
+    assert j["report_csv"] == case.text("annotation.report.csv")
+    assert j["counts_csv"] == case.text("miR.Counts.csv")
+    assert j["rpm_csv"] == case.text("miR.RPM.csv")
+
+
+def test_collapse_rule():
+    seqs = ["ACGT" * 5, "TTTTACGTACGTACGTAC", "ACGT" * 5, "ACGTACGTACGTACGTACGN", "ACGT" * 5,
+            "TTTTACGTACGTACGTAC", "ACGTACGTACGTACGTACG"]
+    from mirge3_amd.seqio import FlatSeqs
+    fs = FlatSeqs.from_list(seqs)
+    first, cnt, inv = oracle.collapse(fs.data, fs.offsets)
+    assert first.tolist() == [0, 1, 3, 6]
+    assert cnt.tolist() == [3, 2, 1, 1]
+    assert inv.tolist() == [0, 1, 0, 2, 0, 1, 3]
+    f0, c0, i0 = oracle.collapse(fs.data[:0], fs.offsets[:1])
+    assert len(f0) == 0 and len(i0) == 0
