@@ -1,0 +1,130 @@
+/*
+ * mirge_native.h -- C ABI of libmirge_native.so: the MI355X (gfx950) implementation of the
+ * miRge3.0 hot path (collapse -> annotation cascade -> count join).
+ *
+ * The reference (mhalushka/miRge3.0) has no FFI for this path: it is three Python call sites
+ * and one process boundary.  Each entry point below names what it replaces;
+ * INTEGRATION.md shows the ctypes stub a miRge3.0 maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on failure; mirge_last_error()
+ *     returns the message of the calling thread's last failure (the reference either raises
+ *     CalledProcessError from subprocess.run(check=True), manifoldAlign.py:19, or prints and
+ *     exits; the Python wrapper turns a non-zero code into RuntimeError);
+ *   - plain pointers and sizes only; "host" pointers are ordinary process memory (numpy
+ *     buffers), all device memory is owned by the opaque handles;
+ *   - sequences cross the boundary as one ASCII byte array plus int64 offsets[n+1];
+ *   - handles are created/destroyed by the library, the caller allocates every output array;
+ *   - one mirge_ctx = one GPU + one HIP stream; calls on one ctx are serialised by the caller,
+ *     different ctx (different GPUs) may be driven from different threads/processes.
+ */
+#ifndef MIRGE_NATIVE_H
+#define MIRGE_NATIVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mirge_ctx mirge_ctx;       /* device + stream + workspace pool              */
+typedef struct mirge_lib mirge_lib;       /* one reference library, packed + indexed in HBM */
+typedef struct mirge_reads mirge_reads;   /* device-resident packed read set (+ counts)     */
+typedef struct mirge_result mirge_result; /* device-resident per-read annotation            */
+
+/* One cascade pass = one of the ten bowtie argument strings of manifoldAlign.py:85, restated
+ * (SURVEY.md 8 table a8-P).  Same fields as oracle_policy minus the annotFlag test, which the
+ * cascade applies itself (manifoldAlign.py:120,129). */
+typedef struct mirge_policy {
+    int32_t mode;     /* 0: -n N (seeded), 1: -v V (end to end)                          */
+    int32_t mm;       /* N or V                                                          */
+    int32_t seedlen;  /* -l, bowtie default 28                                           */
+    int32_t maxtotal; /* -n: 2 (FASTA Q40 -> Maq-rounded 30, -e 70); -v: V               */
+    int32_t trim5;    /* -5                                                              */
+    int32_t trim3;    /* -3                                                              */
+    int32_t ttail;    /* 1: only reads matching T{3,}$, aligned without that run (:118-126) */
+    int32_t len_lt;   /* >0: only reads shorter than this (pass 0: 26, :93)              */
+    int32_t len_gt;   /* >0: only reads longer than this (pass 1: 25, :104)              */
+    int32_t reserved;
+} mirge_policy;
+
+#define MIRGE_MAX_PASSES 16
+#define MIRGE_NO_PASS (-1)
+
+const char* mirge_last_error(void);
+
+/* replaces: miRgeEssential.check_dependencies probing `bowtie --version` (miRgeEssential.py:6-34) */
+int mirge_device_count(void);
+/* hip_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private one */
+int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out);
+void mirge_ctx_destroy(mirge_ctx* ctx);
+int mirge_ctx_sync(mirge_ctx* ctx);
+
+/* ---- libraries: replaces `bowtie <index>` opening an .ebwt index (manifoldAlign.py:97-99)
+ * and `bowtie-build`.  seq_ascii/offsets: the reference sequences in library order.          */
+int mirge_lib_create(mirge_ctx* ctx, const char* seq_ascii, const int64_t* offsets, int64_t n_refs,
+                     mirge_lib** out);
+void mirge_lib_destroy(mirge_lib* lib);
+int64_t mirge_lib_n_refs(const mirge_lib* lib);
+int64_t mirge_lib_device_bytes(const mirge_lib* lib);
+/* build the k-mer table for probe length k now (otherwise built on first need) */
+int mirge_lib_prepare(mirge_lib* lib, int32_t k);
+
+/* ---- reads: replaces writing bwtInput.fasta (manifoldAlign.py:92-95) / dnaio parsing ---- */
+int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, int64_t n,
+                     mirge_reads** out);
+void mirge_reads_destroy(mirge_reads* reads);
+int64_t mirge_reads_count(const mirge_reads* reads);
+int64_t mirge_reads_total_bases(const mirge_reads* reads);
+int32_t mirge_reads_n_samples(const mirge_reads* reads);
+/* sequences back as ASCII: ascii_out[total_bases], offsets_out[n+1], in handle order */
+int mirge_reads_unpack(mirge_ctx* ctx, const mirge_reads* reads, char* ascii_out, int64_t* offsets_out);
+
+/* ---- collapse: replaces the dict merge of digest.py:141-163 and the sample matrix of
+ * digest.py:237-245.  sample_ids[n] (host, may be NULL when n_samples == 1) gives the sample
+ * of every raw read.  The result holds the U distinct sequences (short reads first, each
+ * width group in order of first appearance) and a U x n_samples count matrix.            */
+int mirge_collapse(mirge_ctx* ctx, const mirge_reads* raw, const int32_t* sample_ids,
+                   int32_t n_samples, mirge_reads** uniq, int64_t* n_uniq);
+/* counts_out[U * n_samples] (row-major), first_index_out[U] (index of the first raw read, may be NULL) */
+int mirge_collapse_fetch(mirge_ctx* ctx, const mirge_reads* uniq, uint32_t* counts_out,
+                         int64_t* first_index_out);
+/* attach a caller-made count matrix (U x n_samples, host) to a packed read set, e.g. after -rr */
+int mirge_reads_set_counts(mirge_ctx* ctx, mirge_reads* reads, const uint32_t* counts, int32_t n_samples);
+
+/* ---- cascade: replaces bwtAlign + alignPlusParse (manifoldAlign.py:12-146): the n_pass
+ * bowtie runs, their FASTA/SAM round trips and the DataFrame updates.  libs[p] == NULL skips
+ * pass p.  Result per read: pass index (or MIRGE_NO_PASS), reference index in libs[pass],
+ * 0-based offset in that reference, mismatches.                                            */
+int mirge_cascade_run(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib* const* libs,
+                      const mirge_policy* policies, int32_t n_pass, mirge_result** out);
+int mirge_result_fetch(mirge_ctx* ctx, const mirge_result* res, int8_t* pass_out, int32_t* ref_out,
+                       int32_t* off_out, int8_t* mm_out);
+void mirge_result_destroy(mirge_result* res);
+
+/* ---- count join: replaces the pandas sums of summary.py:686-698 (per-class), :749-752
+ * (exact / isomiR group-by) and :769-771.  class_sums[n_pass * S]; exact/iso[n_mirna * S]
+ * accumulate the counts of reads annotated in exact_pass / iso_pass per reference.          */
+int mirge_count_join(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res,
+                     int32_t exact_pass, int32_t iso_pass, int64_t n_mirna,
+                     int64_t* class_sums, int64_t* exact, int64_t* iso);
+
+/* same sums from host arrays (the reference's summarize() is handed a DataFrame, summary.py:677):
+ * pass[n] (MIRGE_NO_PASS = unannotated), ref[n], counts[n * S] row-major                   */
+int mirge_count_join_host(mirge_ctx* ctx, const int8_t* pass, const int32_t* ref, const uint32_t* counts,
+                          int64_t n, int32_t n_samples, int32_t n_pass, int32_t exact_pass, int32_t iso_pass,
+                          int64_t n_mirna, int64_t* class_sums, int64_t* exact, int64_t* iso);
+
+/* ---- measurement (bench.py): HIP events on the ctx stream ---- */
+int mirge_ctx_timer_start(mirge_ctx* ctx);
+int mirge_ctx_timer_stop(mirge_ctx* ctx, double* ms_out);
+int mirge_ctx_profile_enable(mirge_ctx* ctx, int32_t on);
+int mirge_ctx_profile_reset(mirge_ctx* ctx);
+int32_t mirge_ctx_profile_count(mirge_ctx* ctx);
+int mirge_ctx_profile_get(mirge_ctx* ctx, int32_t i, char* name_out, int32_t name_cap,
+                          int64_t* launches, double* total_ms, double* units);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,283 @@
+"""ctypes binding of ``csrc/libmirge_native.so`` (C ABI: ``include/mirge_native.h``).
+
+This is the whole boundary between the Python host code and the HIP kernels: plain pointers and
+sizes, numpy buffers in and out.  There is no fallback: if the shared library is missing, or no
+MI355X is visible, the first call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .seqio import FlatSeqs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libmirge_native.so")
+
+EXPORTS = [
+    "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
+    "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
+    "mirge_reads_pack", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
+    "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
+    "mirge_reads_set_counts", "mirge_cascade_run", "mirge_result_fetch", "mirge_result_destroy",
+    "mirge_count_join", "mirge_count_join_host", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
+    "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
+]
+
+
+class MirgePolicy(C.Structure):
+    """``mirge_policy`` of include/mirge_native.h."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "mode", "mm", "seedlen", "maxtotal", "trim5", "trim3", "ttail", "len_lt", "len_gt", "reserved")]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it was not built -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  mirge3.0_amd has no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    lib.mirge_last_error.restype = C.c_char_p
+    for name in ("mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_reads_count", "mirge_reads_total_bases"):
+        getattr(lib, name).restype = C.c_int64
+    for name in ("mirge_lib_destroy", "mirge_reads_destroy", "mirge_result_destroy", "mirge_ctx_destroy"):
+        getattr(lib, name).restype = None
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mirge_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def _p(a: Optional[np.ndarray]):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+class Context:
+    """One GPU + one HIP stream (``mirge_ctx``)."""
+
+    def __init__(self, device: int = 0, stream: int = 0):
+        lib = load()
+        if lib.mirge_device_count() <= 0:
+            raise RuntimeError("no HIP device visible: mirge3.0_amd needs an MI355X (no CPU fallback)")
+        self._h = C.c_void_p()
+        _check(lib.mirge_ctx_create(C.c_int(device), C.c_void_p(stream), C.byref(self._h)), "mirge_ctx_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            load().mirge_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(load().mirge_ctx_sync(self._h), "mirge_ctx_sync")
+
+    # ---- measurement
+    def timer_start(self):
+        _check(load().mirge_ctx_timer_start(self._h), "mirge_ctx_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_double()
+        _check(load().mirge_ctx_timer_stop(self._h, C.byref(ms)), "mirge_ctx_timer_stop")
+        return ms.value
+
+    def profile(self, on: bool):
+        _check(load().mirge_ctx_profile_enable(self._h, C.c_int32(1 if on else 0)), "profile_enable")
+
+    def profile_reset(self):
+        _check(load().mirge_ctx_profile_reset(self._h), "profile_reset")
+
+    def profile_records(self):
+        """[(kernel name, launches, total ms, units)]"""
+        lib = load()
+        out = []
+        for i in range(lib.mirge_ctx_profile_count(self._h)):
+            name = C.create_string_buffer(64)
+            launches, ms, units = C.c_int64(), C.c_double(), C.c_double()
+            _check(lib.mirge_ctx_profile_get(self._h, C.c_int32(i), name, C.c_int32(64), C.byref(launches),
+                                             C.byref(ms), C.byref(units)), "profile_get")
+            out.append((name.value.decode(), launches.value, ms.value, units.value))
+        return out
+
+
+class DeviceLibrary:
+    """A reference library packed and indexed in HBM (``mirge_lib``)."""
+
+    def __init__(self, ctx: Context, seqs: FlatSeqs):
+        self.ctx = ctx
+        data = np.ascontiguousarray(seqs.data, dtype=np.uint8)
+        off = np.ascontiguousarray(seqs.offsets, dtype=np.int64)
+        self._h = C.c_void_p()
+        _check(load().mirge_lib_create(ctx._h, _p(data), _p(off), C.c_int64(len(seqs)), C.byref(self._h)),
+               "mirge_lib_create")
+
+    @property
+    def n_refs(self) -> int:
+        return load().mirge_lib_n_refs(self._h)
+
+    @property
+    def device_bytes(self) -> int:
+        return load().mirge_lib_device_bytes(self._h)
+
+    def prepare(self, k: int):
+        _check(load().mirge_lib_prepare(self._h, C.c_int32(k)), "mirge_lib_prepare")
+
+    def close(self):
+        if self._h:
+            load().mirge_lib_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceReads:
+    """A device-resident packed read set (``mirge_reads``), optionally with a count matrix."""
+
+    def __init__(self, ctx: Context, handle: C.c_void_p):
+        self.ctx = ctx
+        self._h = handle
+
+    @staticmethod
+    def pack(ctx: Context, reads: FlatSeqs) -> "DeviceReads":
+        data = np.ascontiguousarray(reads.data, dtype=np.uint8)
+        off = np.ascontiguousarray(reads.offsets, dtype=np.int64)
+        h = C.c_void_p()
+        _check(load().mirge_reads_pack(ctx._h, _p(data), _p(off), C.c_int64(len(reads)), C.byref(h)),
+               "mirge_reads_pack")
+        return DeviceReads(ctx, h)
+
+    def __len__(self) -> int:
+        return load().mirge_reads_count(self._h)
+
+    @property
+    def n_samples(self) -> int:
+        return load().mirge_reads_n_samples(self._h)
+
+    def unpack(self) -> FlatSeqs:
+        n = len(self)
+        off = np.zeros(n + 1, dtype=np.int64)
+        data = np.empty(max(load().mirge_reads_total_bases(self._h), 1), dtype=np.uint8)
+        _check(load().mirge_reads_unpack(self.ctx._h, self._h, _p(data), _p(off)), "mirge_reads_unpack")
+        return FlatSeqs(data[:off[-1]].copy(), off)
+
+    def collapse(self, sample_ids: Optional[np.ndarray] = None, n_samples: int = 1) -> "DeviceReads":
+        sid = None if sample_ids is None else np.ascontiguousarray(sample_ids, dtype=np.int32)
+        h = C.c_void_p()
+        nu = C.c_int64()
+        _check(load().mirge_collapse(self.ctx._h, self._h, _p(sid), C.c_int32(n_samples), C.byref(h),
+                                     C.byref(nu)), "mirge_collapse")
+        return DeviceReads(self.ctx, h)
+
+    def counts(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(counts [U, S] uint32, first_index [U] int64) of a collapse result."""
+        n, S = len(self), self.n_samples
+        cnt = np.zeros((n, max(S, 1)), dtype=np.uint32)
+        first = np.zeros(n, dtype=np.int64)
+        _check(load().mirge_collapse_fetch(self.ctx._h, self._h, _p(cnt), _p(first)), "mirge_collapse_fetch")
+        return cnt, first
+
+    def set_counts(self, counts: np.ndarray):
+        counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(len(self), -1)
+        _check(load().mirge_reads_set_counts(self.ctx._h, self._h, _p(counts), C.c_int32(counts.shape[1])),
+               "mirge_reads_set_counts")
+
+    def close(self):
+        if self._h:
+            load().mirge_reads_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CascadeResult:
+    """Device-resident per-read annotation (``mirge_result``)."""
+
+    def __init__(self, ctx: Context, handle: C.c_void_p, reads: DeviceReads, n_pass: int):
+        self.ctx, self._h, self.reads, self.n_pass = ctx, handle, reads, n_pass
+
+    def fetch(self):
+        """(pass int8, ref int32, off int32, mm int8) in the read set's order; -1 = unannotated."""
+        n = len(self.reads)
+        ps = np.empty(n, dtype=np.int8)
+        ref = np.empty(n, dtype=np.int32)
+        off = np.empty(n, dtype=np.int32)
+        mm = np.empty(n, dtype=np.int8)
+        _check(load().mirge_result_fetch(self.ctx._h, self._h, _p(ps), _p(ref), _p(off), _p(mm)),
+               "mirge_result_fetch")
+        return ps, ref, off, mm
+
+    def close(self):
+        if self._h:
+            load().mirge_result_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cascade_run(ctx: Context, reads: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],
+                policies: Sequence[MirgePolicy]) -> CascadeResult:
+    n_pass = len(policies)
+    arr = (C.c_void_p * n_pass)(*[(lb._h if lb is not None else C.c_void_p(0)) for lb in libs])
+    pol = (MirgePolicy * n_pass)(*policies)
+    h = C.c_void_p()
+    _check(load().mirge_cascade_run(ctx._h, reads._h, arr, pol, C.c_int32(n_pass), C.byref(h)), "mirge_cascade_run")
+    return CascadeResult(ctx, h, reads, n_pass)
+
+
+def count_join(ctx: Context, uniq: DeviceReads, res: CascadeResult, exact_pass: int, iso_pass: int,
+               n_mirna: int):
+    """-> (class_sums [n_pass, S], exact [n_mirna, S], iso [n_mirna, S]) int64."""
+    S = uniq.n_samples
+    cls = np.zeros((res.n_pass, S), dtype=np.int64)
+    ex = np.zeros((max(n_mirna, 1), S), dtype=np.int64)
+    iso = np.zeros((max(n_mirna, 1), S), dtype=np.int64)
+    _check(load().mirge_count_join(ctx._h, uniq._h, res._h, C.c_int32(exact_pass), C.c_int32(iso_pass),
+                                   C.c_int64(n_mirna), _p(cls), _p(ex), _p(iso)), "mirge_count_join")
+    return cls, ex[:n_mirna], iso[:n_mirna]
+
+
+def count_join_host(ctx: Context, ps: np.ndarray, ref: np.ndarray, counts: np.ndarray, n_pass: int,
+                    exact_pass: int, iso_pass: int, n_mirna: int):
+    """``count_join`` from host arrays (pass int8 [n], ref int32 [n], counts uint32 [n, S])."""
+    ps = np.ascontiguousarray(ps, dtype=np.int8)
+    ref = np.ascontiguousarray(ref, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(ps.shape[0], -1)
+    S = counts.shape[1]
+    cls = np.zeros((n_pass, S), dtype=np.int64)
+    ex = np.zeros((max(n_mirna, 1), S), dtype=np.int64)
+    iso = np.zeros((max(n_mirna, 1), S), dtype=np.int64)
+    _check(load().mirge_count_join_host(ctx._h, _p(ps), _p(ref), _p(counts), C.c_int64(ps.shape[0]), C.c_int32(S),
+                                        C.c_int32(n_pass), C.c_int32(exact_pass), C.c_int32(iso_pass),
+                                        C.c_int64(n_mirna), _p(cls), _p(ex), _p(iso)), "mirge_count_join_host")
+    return cls, ex[:n_mirna], iso[:n_mirna]

@@ -1,0 +1,141 @@
+"""Annotation cascade -- host mirror of ``mirge/libs/manifoldAlign.py``.
+
+``bwt_align(args, pdDataFrame, workDir, ref_db)`` has the reference's signature and returns the
+same DataFrame (``annotFlag`` int, the nine/ten annotation columns as ``str``, sample columns),
+so the reference's ``summarize`` could consume it.  The ten bowtie runs, their FASTA temp files
+and the SAM parsing (``alignPlusParse``, manifoldAlign.py:12-64) are replaced by ONE call into
+the HIP kernels: ``mirge_cascade_run``.
+"""
+from __future__ import annotations
+
+import os
+import time
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import PASS_COLUMNS, _ffi
+from .seqio import FlatSeqs, Library, load_library_dir
+
+# (column written, library key, bowtie argument string it stands for, policy)
+# manifoldAlign.py:84-85 verbatim; predicate per SURVEY.md 8 table a8-P.
+PASSES = [
+    ("exact miRNA",   "mirna",        " -n 0 -f --norc -S --threads ",
+     dict(mode=0, mm=0, seedlen=28, maxtotal=2, len_lt=26)),                 # :93  len < 26
+    ("hairpin miRNA", "hairpin",      " -n 1 -f --norc -S --threads ",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2, len_gt=25)),                 # :104 len > 25
+    ("mature tRNA",   "mature_trna",  " -v 1 -f -a --best --strata --norc -S --threads ",
+     dict(mode=1, mm=1, seedlen=28, maxtotal=1)),
+    ("primary tRNA",  "pre_trna",     " -v 0 -f -a --best --strata --norc -S --threads ",
+     dict(mode=1, mm=0, seedlen=28, maxtotal=0, ttail=1)),                   # :118-126
+    ("snoRNA",        "snorna",       " -n 1 -f --norc -S --threads ",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2)),
+    ("rRNA",          "rrna",         " -n 1 -f --norc -S --threads ",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2)),
+    ("ncrna others",  "ncrna_others", " -n 1 -f --norc -S --threads ",
+     dict(mode=0, mm=1, seedlen=28, maxtotal=2)),
+    ("mRNA",          "mrna",         " -n 0 -f --norc -S --threads ",
+     dict(mode=0, mm=0, seedlen=28, maxtotal=2)),
+    ("isomiR miRNA",  "mirna",        " -5 1 -3 2 -v 2 -f --norc --best -S --threads ",
+     dict(mode=1, mm=2, seedlen=28, maxtotal=2, trim5=1, trim3=2)),
+    ("spike-in",      "spike-in",     " -n 0 -f --norc -S --threads ",
+     dict(mode=0, mm=0, seedlen=28, maxtotal=2)),
+]
+EXACT_PASS, ISO_PASS = 0, 8
+assert [p[0] for p in PASSES] == PASS_COLUMNS
+
+
+def policies(n_pass: int = 9) -> List[_ffi.MirgePolicy]:
+    out = []
+    for _, _, _, kw in PASSES[:n_pass]:
+        p = _ffi.MirgePolicy()
+        for k, v in kw.items():
+            setattr(p, k, v)
+        out.append(p)
+    return out
+
+
+class Cascade:
+    """The libraries of one organism resident on one GPU + the pass table."""
+
+    def __init__(self, ctx: _ffi.Context, libs: Dict[str, Library], spike_in: bool = False,
+                 n_pass: Optional[int] = None):
+        self.ctx = ctx
+        self.libs = libs
+        self.n_pass = n_pass if n_pass is not None else (10 if spike_in else 9)
+        self._dev: Dict[str, _ffi.DeviceLibrary] = {}
+        self.dev_libs: List[Optional[_ffi.DeviceLibrary]] = []
+        for _, key, _, _ in PASSES[:self.n_pass]:
+            if key not in libs:
+                self.dev_libs.append(None)
+                continue
+            if key not in self._dev:  # the miRNA library serves passes 0 and 8
+                self._dev[key] = _ffi.DeviceLibrary(ctx, libs[key].seqs)
+            self.dev_libs.append(self._dev[key])
+        self.policies = policies(self.n_pass)
+
+    def lib_of_pass(self, p: int) -> Library:
+        return self.libs[PASSES[p][1]]
+
+    def run(self, reads: _ffi.DeviceReads) -> _ffi.CascadeResult:
+        return _ffi.cascade_run(self.ctx, reads, self.dev_libs, self.policies)
+
+    def annotate(self, seqs: FlatSeqs):
+        """Convenience: host sequences in, (pass, ref, off, mm) numpy arrays out."""
+        dr = _ffi.DeviceReads.pack(self.ctx, seqs)
+        res = self.run(dr)
+        out = res.fetch()
+        res.close()
+        dr.close()
+        return out
+
+    def close(self):
+        for d in self._dev.values():
+            d.close()
+        self._dev.clear()
+
+
+_cascade_cache: Dict[tuple, Cascade] = {}
+
+
+def get_cascade(args, ref_db: str, device: int = 0) -> Cascade:
+    key = (os.path.abspath(str(args.libraries_path)), args.organism_name, ref_db, bool(args.spikeIn), device)
+    if key not in _cascade_cache:
+        libs = load_library_dir(str(args.libraries_path), args.organism_name, ref_db, with_spike=bool(args.spikeIn))
+        _cascade_cache[key] = Cascade(_ffi.Context(device), libs, spike_in=bool(args.spikeIn))
+    return _cascade_cache[key]
+
+
+def bwt_align(args, pdDataFrame, workDir, ref_db):
+    """Drop-in for ``bwtAlign`` (manifoldAlign.py:68-146)."""
+    begningTime = time.perf_counter()
+    runlogFile = Path(workDir) / "run.log"
+    outlog = open(str(runlogFile), "a+")
+    if not args.quiet:
+        print("Alignment in progress ...")
+    outlog.write("Alignment in progress ...\n")
+    casc = get_cascade(args, ref_db, getattr(args, "device", 0))
+    seqs = FlatSeqs.from_list([str(s) for s in pdDataFrame.index])
+    ps, ref, off, mm = casc.annotate(seqs)
+    colnames = list(pdDataFrame.columns)
+    flag = pdDataFrame[colnames[0]].to_numpy().copy()
+    for p in range(casc.n_pass):
+        sel = np.nonzero(ps == p)[0]
+        if sel.size == 0:
+            continue
+        names = np.asarray(casc.lib_of_pass(p).names, dtype=object)
+        col = pdDataFrame[colnames[1 + p]].to_numpy(dtype=object).copy()
+        col[sel] = names[ref[sel]]
+        pdDataFrame[colnames[1 + p]] = col
+        flag[sel] = 1
+    pdDataFrame[colnames[0]] = flag
+    finish = time.perf_counter()
+    if not args.spikeIn:
+        pdDataFrame = pdDataFrame.drop(columns=['spike-in'])
+    pdDataFrame = pdDataFrame.fillna('')
+    if not args.quiet:
+        print(f'Alignment completed in {round(finish-begningTime, 4)} second(s)\n')
+    outlog.write(f'Alignment completed in {round(finish-begningTime, 4)} second(s)\n')
+    outlog.close()
+    return pdDataFrame

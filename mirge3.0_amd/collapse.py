@@ -1,0 +1,137 @@
+"""Read collapse and the sample matrix -- host mirror of ``mirge/libs/digest.py:105-302``.
+
+``baking(args, inFileArray, inFileBaseArray, workDir)`` keeps the reference's signature and
+return value ``(DataFrame, sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique)``.
+The per-chunk dict counting (``cutadapt()``, digest.py:320-375), the dict merge (:141-163) and
+the pandas outer join of the samples (:237-245) are ONE ``mirge_collapse`` call on the GPU: all
+samples' reads go in together with a sample id and come back as the U distinct sequences plus a
+U x S count matrix.
+
+Scope: reads are taken as already trimmed (adapter/quality trimming is
+cutadapt's, third-party and upstream of the path).  Asking for adapter trimming raises instead of
+silently skipping it.  Only the length filter of digest.py:348,368 (``--minimum-length``) applies.
+"""
+from __future__ import annotations
+
+import gzip
+import time
+from pathlib import Path
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import PASS_COLUMNS, _ffi
+from .seqio import FlatSeqs
+
+
+def read_fastq_sequences(path: str) -> FlatSeqs:
+    """Sequence lines of a FASTQ (or FASTA, or one-sequence-per-line) file, plain or .gz."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rb") as fh:
+        buf = np.frombuffer(fh.read(), dtype=np.uint8)
+    if buf.size == 0:
+        return FlatSeqs(np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    nl = np.flatnonzero(buf == 10)
+    if buf[-1] != 10:
+        nl = np.append(nl, buf.size)
+    starts = np.concatenate(([0], nl[:-1] + 1))
+    ends = nl.copy()
+    # strip \r
+    cr = (ends > starts) & (buf[np.maximum(ends - 1, 0)] == 13)
+    ends = ends - cr
+    first = buf[0]
+    if first == ord("@"):
+        sel = slice(1, None, 4)
+    elif first == ord(">"):
+        sel = slice(1, None, 2)
+    else:
+        sel = slice(0, None, 1)
+    s, e = starts[sel], ends[sel]
+    lens = (e - s).astype(np.int64)
+    offsets = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    rows = np.repeat(np.arange(lens.shape[0], dtype=np.int64), lens)
+    within = np.arange(int(offsets[-1]), dtype=np.int64) - offsets[:-1][rows]
+    return FlatSeqs(buf[s[rows] + within], offsets)
+
+
+def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:
+    keep = np.flatnonzero(reads.lengths >= int(min_len))
+    if keep.shape[0] == len(reads):
+        return reads
+    return reads.take(keep)
+
+
+def collapse_samples(ctx: _ffi.Context, samples: Sequence[FlatSeqs]):
+    """-> (DeviceReads uniq (with counts), order) where ``order`` lists the unique rows in the
+    reference's row order: first appearance for one sample (dict order, digest.py:158-163),
+    lexicographic for several (pandas ``join(how='outer')`` sorts, digest.py:243)."""
+    S = len(samples)
+    if S == 1:
+        allr, sid = samples[0], None
+    else:
+        data = np.concatenate([s.data for s in samples])
+        lens = np.concatenate([s.lengths for s in samples])
+        off = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        allr = FlatSeqs(data, off)
+        sid = np.repeat(np.arange(S, dtype=np.int32), [len(s) for s in samples])
+    raw = _ffi.DeviceReads.pack(ctx, allr)
+    uniq = raw.collapse(sid, S)
+    raw.close()
+    return uniq
+
+
+def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None):
+    """Drop-in for ``baking`` (digest.py:105-302) on already-trimmed reads."""
+    import pandas as pd
+    if getattr(args, "adapters", None) or getattr(args, "front", None) or getattr(args, "uniq_mol_ids", None):
+        raise NotImplementedError(
+            "adapter / UMI trimming is outside the MI355X hot path (SURVEY.md 8f, N4): trim with cutadapt "
+            "first and pass the trimmed reads")
+    begningTime = time.perf_counter()
+    runlogFile = Path(workDir) / "run.log"
+    outlog = open(str(runlogFile), "a+")
+    ctx = ctx or _ffi.Context(getattr(args, "device", 0))
+    min_len = int(getattr(args, "minimum_length", 16))
+    sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
+    samples: List[FlatSeqs] = []
+    for FQfile, name in zip(inFileArray, inFileBaseArray):
+        start = time.perf_counter()
+        reads = read_fastq_sequences(str(FQfile))
+        sampleReadCounts[name] = len(reads)
+        reads = filter_min_length(reads, min_len)
+        trimmedReadCounts[name] = len(reads)
+        samples.append(reads)
+        finish2 = time.perf_counter()
+        if not args.quiet:
+            print(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)')
+        outlog.write(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)\n')
+    t0 = time.perf_counter()
+    uniq = collapse_samples(ctx, samples)
+    counts, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    uniq.close()
+    counts = counts.astype(np.int64)
+    for s, name in enumerate(inFileBaseArray):
+        trimmedReadCountsUnique[name] = int((counts[:, s] > 0).sum())
+    if len(inFileBaseArray) == 1:
+        order = np.argsort(first, kind="stable")  # dict insertion order
+    else:
+        order = np.argsort(np.asarray(seqs, dtype=object), kind="stable")  # outer join sorts the index
+    complete_set = pd.DataFrame(counts[order], columns=list(inFileBaseArray),
+                                index=pd.Index([seqs[i] for i in order], name='Sequence'))
+    t1 = time.perf_counter()
+    if not args.quiet:
+        print(f'Collapsing finished in {round(t1-t0, 4)} second(s)\n')
+    outlog.write(f'Collapsing finished in {round(t1-t0, 4)} second(s)\n')
+    complete_set = complete_set.assign(**dict.fromkeys(PASS_COLUMNS, ''))
+    complete_set = complete_set.assign(**dict.fromkeys(['annotFlag'], '0'))
+    complete_set = complete_set.reindex(columns=['annotFlag'] + PASS_COLUMNS + list(inFileBaseArray))
+    complete_set = complete_set.astype({"annotFlag": int})
+    EndTime = time.perf_counter()
+    if not args.quiet:
+        print(f'Data pre-processing completed in {round(EndTime-begningTime, 4)} second(s)\n')
+    outlog.write(f'\nData pre-processing completed in {round(EndTime-begningTime, 4)} second(s)\n\n')
+    outlog.close()
+    return (complete_set, sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique)

@@ -1,0 +1,155 @@
+"""Count join -- host mirror of ``mirge/libs/summary.py`` (:25-45, :677-798, :882-901, :1223-1291).
+
+The sums over the U collapsed rows (per-class sums :686-698, exact / isomiR group-by :749-752,
+'All miRNA Reads' :769-771) run on the GPU (``mirge_count_join``).  What is left is arithmetic on
+tables with one row per miRNA (a few thousand): ``mirge_can``, the merged-family renaming, RPM
+and writing ``miR.Counts.csv`` / ``miR.RPM.csv`` / ``annotation.report.csv``.  That tail is done
+with pandas the way the reference does it so that dtypes -- and therefore the printed numbers
+(``50`` vs ``50.0``) -- come out identical.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .cascade import EXACT_PASS, ISO_PASS, PASSES
+from .seqio import FlatSeqs, Library
+
+# report column <- pass index (summary.py:686-690, 895-901)
+REPORT_CLASSES = [("Hairpin miRNAs", 1), ("mature tRNA Reads", 2), ("primary tRNA Reads", 3),
+                  ("snoRNA Reads", 4), ("rRNA Reads", 5), ("ncRNA others", 6), ("mRNA Reads", 7)]
+
+
+def _group_by_name(tab: np.ndarray, names: Sequence[str]):
+    """Sum rows that carry the same reference name (pandas groupby on the name column)."""
+    uniq: Dict[str, int] = {}
+    idx = np.empty(len(names), dtype=np.int64)
+    for i, nm in enumerate(names):
+        idx[i] = uniq.setdefault(nm, len(uniq))
+    out = np.zeros((len(uniq), tab.shape[1]), dtype=np.int64)
+    np.add.at(out, idx, tab)
+    return list(uniq), out
+
+
+def finish_tables(class_sums: np.ndarray, exact: np.ndarray, iso: np.ndarray, mirna: Library,
+                  merges: List[List[str]], base_names: List[str], sampleReadCounts, trimmedReadCounts,
+                  trimmedReadCountsUnique, cr_threshold: float, spike_in: bool, workDir=None):
+    """summary.py:700-798 and :882-901,1223-1284 on the per-miRNA tables."""
+    import pandas as pd
+    S = len(base_names)
+    mirMergedNameDic, mirMergedDataframeDic = {}, {}
+    for row in merges:  # summary.py:707-712
+        for item in row[1:]:
+            mirMergedNameDic[item] = row[0]
+            mirMergedDataframeDic[row[0]] = "1"
+    names, ex = _group_by_name(exact, mirna.names)
+    _, iso_g = _group_by_name(iso, mirna.names)
+    present = ex.sum(axis=1) > 0  # a name has an 'exact miRNA' row iff some read hit it in pass 0
+    order = sorted(i for i in range(len(names)) if present[i])  # groupby sorts by name
+    order.sort(key=lambda i: names[i])
+    df = pd.DataFrame([names[i] for i in order], columns=['exact miRNA'])
+    for s, file_name in enumerate(base_names):  # mirge_can, summary.py:25-45
+        x = ex[order, s].astype(np.int64).copy()
+        y = iso_g[order, s].astype(np.int64).copy()
+        low = x < 2
+        x[low] = 0
+        y[low] = 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ratio = np.where(y > 0, x / np.where(y > 0, y, 1), x.astype(np.float64))
+        ok = ratio > cr_threshold
+        if ok.all():
+            df[file_name] = (x + y).astype(np.int64)
+        else:
+            df[file_name] = np.where(ok, (x + y).astype(np.float64), np.nan)
+    df['miRNA'] = df['exact miRNA'].map(mirMergedNameDic)
+    df = df.fillna(0)
+    df.loc[df.miRNA == 0, 'miRNA'] = df['exact miRNA']
+    df.set_index('miRNA', inplace=True)
+    df = df.groupby(['miRNA']).sum()[base_names]
+    Filtered_miRNA_Reads = df.sum(axis=0, skipna=True)[base_names].to_dict()
+    miR_RPM = (df.div(df.sum(axis=0)) * 1000000).round(4)
+    for h in mirna.headers:  # `bowtie-inspect -n`, summary.py:783-788
+        srow = h.split(" ")[0] if "segs:" in h else h
+        if srow not in mirMergedNameDic:
+            mirMergedDataframeDic[srow] = "1"
+    mirMerged_df = pd.DataFrame(list(mirMergedDataframeDic.keys()), columns=['miRNA'])
+    mirMerged_df.set_index('miRNA', inplace=True)
+    mirCounts_completeSet = mirMerged_df.join(df, how='outer').fillna(0)
+    mirRPM_completeSet = mirMerged_df.join(miR_RPM, how='outer').fillna(0)
+    miRNA_counts = {fn: int(df.index[df[fn] > 0].shape[0]) for fn in base_names}
+    classes = list(REPORT_CLASSES) + ([("Spike-in", 9)] if spike_in else [])
+    all_mirna = class_sums[EXACT_PASS] + class_sums[ISO_PASS]
+    pre_summary = {
+        'Total Input Reads': sampleReadCounts, 'Trimmed Reads (all)': trimmedReadCounts,
+        'Trimmed Reads (unique)': trimmedReadCountsUnique,
+        'All miRNA Reads': {fn: int(all_mirna[s]) for s, fn in enumerate(base_names)},
+        'Filtered miRNA Reads': Filtered_miRNA_Reads, 'Unique miRNAs': miRNA_counts,
+    }
+    for col, p in classes:
+        pre_summary[col] = {fn: int(class_sums[p][s]) for s, fn in enumerate(base_names)}
+    col_tosum = ['All miRNA Reads'] + [c for c, _ in classes]
+    colRearrange = ['Total Input Reads', 'Trimmed Reads (all)', 'Trimmed Reads (unique)', 'All miRNA Reads',
+                    'Filtered miRNA Reads', 'Unique miRNAs'] + [c for c, _ in classes] + ['Remaining Reads']
+    summary = pd.DataFrame.from_dict(pre_summary).fillna(0).astype(int)
+    summary['Remaining Reads'] = summary['Trimmed Reads (all)'] - (summary[col_tosum].sum(axis=1))
+    summary = summary.reindex(columns=colRearrange)
+    summary.index.name = "Sample name(s)"
+    out = dict(counts=mirCounts_completeSet, rpm=mirRPM_completeSet, summary=summary,
+               class_sums={c: class_sums[p] for c, p in classes})
+    if workDir is not None:
+        mirCounts_completeSet.to_csv(Path(workDir) / "miR.Counts.csv")
+        mirRPM_completeSet.to_csv(Path(workDir) / "miR.RPM.csv")
+        summary.to_csv(Path(workDir) / "annotation.report.csv")
+        html = summary.reset_index(level=['Sample name(s)'])
+        html.index += 1
+        with open(Path(workDir) / "annotation.report.html", 'w') as f:
+            f.write(html.to_html(index=False))
+    return out
+
+
+def summarize_device(ctx: _ffi.Context, uniq: _ffi.DeviceReads, res: _ffi.CascadeResult, mirna: Library,
+                     merges, base_names, sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique,
+                     cr_threshold: float = 0.1, spike_in: bool = False, workDir=None):
+    """Fast path: the annotation and the count matrix never leave the GPU before the join."""
+    cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS, len(mirna))
+    return finish_tables(cls, ex, iso, mirna, merges, list(base_names), sampleReadCounts, trimmedReadCounts,
+                         trimmedReadCountsUnique, cr_threshold, spike_in, workDir)
+
+
+def summarize(args, workDir, ref_db, base_names, pdMapped, sampleReadCounts, trimmedReadCounts,
+              trimmedReadCountsUnique):
+    """Drop-in for ``summarize`` (summary.py:677): takes the mapped rows of the DataFrame.
+
+    The name columns are turned back into (pass, reference index) arrays; those and the count
+    matrix go to the GPU and ``mirge_count_join_host`` does the sums.
+    """
+    from .cascade import get_cascade
+    from .seqio import load_merges
+    casc = get_cascade(args, ref_db, getattr(args, "device", 0))
+    ctx = casc.ctx
+    n = len(pdMapped)
+    ps = np.full(n, -1, dtype=np.int8)
+    ref = np.zeros(n, dtype=np.int32)
+    for p in range(casc.n_pass):
+        col = PASSES[p][0]
+        if col not in pdMapped.columns:
+            continue
+        v = pdMapped[col].to_numpy(dtype=object)
+        sel = np.nonzero(v.astype(bool))[0]
+        if sel.size == 0:
+            continue
+        lut = {}
+        for i, nm in enumerate(casc.lib_of_pass(p).names):
+            lut.setdefault(nm, i)
+        ps[sel] = p
+        ref[sel] = [lut[x] for x in v[sel]]
+    counts = pdMapped[list(base_names)].to_numpy(dtype=np.int64)
+    mirna = casc.libs["mirna"]
+    cls, ex, iso = _ffi.count_join_host(ctx, ps, ref, counts.astype(np.uint32), casc.n_pass, EXACT_PASS, ISO_PASS,
+                                        len(mirna))
+    return finish_tables(cls, ex, iso, mirna, load_merges(str(args.libraries_path), args.organism_name, ref_db),
+                         list(base_names), sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique,
+                         float(args.crThreshold), bool(args.spikeIn), workDir)

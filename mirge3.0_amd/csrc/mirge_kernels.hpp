@@ -1,0 +1,384 @@
+// mirge_kernels.hpp -- the gfx950 kernels of the hot path (included by mirge_native.hip).
+//
+// All of them are integer / indexing kernels: no MFMA, wave64, 256-thread workgroups,
+// grid-stride loops over a grid capped at CUs x 8 so that every launch fills the 256 CUs
+// and per-launch overhead stays constant.  Reads are structure-of-arrays so that lane i of a
+// wave loads word i of a contiguous 512-byte run (coalesced); everything that is random
+// access (k-mer buckets, text windows) goes to L2 / Infinity Cache / HBM by design.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mirge_core.hpp"
+
+#define MIRGE_BLOCK 256
+#define MIRGE_MAX_PASSES_K 16
+#define MIRGE_EMPTY 0xFFFFFFFFu
+
+template <int W>
+struct GroupView {
+    const uint64_t* seq;    // [W][n]
+    const uint8_t* len;     // [n]
+    const uint64_t* nmask;  // [W][n] or nullptr
+    uint32_t n;
+};
+
+template <int W>
+__device__ __forceinline__ void load_read(const GroupView<W>& g, uint32_t i, MirgeRead<W>& r) {
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        r.w[w] = g.seq[(size_t)w * g.n + i];
+        r.nm[w] = g.nmask ? g.nmask[(size_t)w * g.n + i] : 0ull;
+    }
+    r.len = g.len[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pack: ASCII -> 2-bit.  One thread per read; the read's bytes are contiguous in `ascii`.
+// flags[0] |= 1 if any N was seen, flags[1] |= 1 if a byte outside ACGTN (any case) was seen.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ offsets,
+                       const uint32_t* __restrict__ idx, uint32_t n, uint64_t* __restrict__ seq,
+                       uint8_t* __restrict__ len, uint64_t* __restrict__ nmask,
+                       uint32_t* __restrict__ flags) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t src = idx[j];
+        const int64_t b = offsets[src];
+        const int L = (int)(offsets[src + 1] - b);
+        uint64_t w[W], nm[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) { w[i] = 0; nm[i] = 0; }
+        uint32_t sawN = 0, bad = 0;
+        for (int p = 0; p < L; p++) {
+            uint8_t c = ascii[b + p] & 0xDF;  // upper-case
+            uint64_t code = 0, isn = 0;
+            switch (c) {
+                case 'A': code = 0; break;
+                case 'C': code = 1; break;
+                case 'G': code = 2; break;
+                case 'T': code = 3; break;
+                case 'U': code = 3; break;
+                case 'N': isn = 1; break;
+                default: isn = 1; bad = 1; break;
+            }
+            sawN |= (uint32_t)isn;
+#pragma unroll
+            for (int i = 0; i < W; i++)
+                if ((p >> 5) == i) { w[i] |= code << (2 * (p & 31)); nm[i] |= isn << (2 * (p & 31)); }
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            seq[(size_t)i * n + j] = w[i];
+            nmask[(size_t)i * n + j] = nm[i];
+        }
+        len[j] = (uint8_t)L;
+        if (sawN) atomicOr(&flags[0], 1u);
+        if (bad) atomicOr(&flags[1], 1u);
+    }
+}
+
+template <int W>
+__global__ void k_unpack(GroupView<W> g, const int64_t* __restrict__ out_off, uint32_t base,
+                         const uint32_t* __restrict__ orig, uint8_t* __restrict__ ascii_out) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g.n; j += gridDim.x * blockDim.x) {
+        MirgeRead<W> r;
+        load_read<W>(g, j, r);
+        const uint32_t dst = orig ? orig[j] : base + j;
+        uint8_t* o = ascii_out + out_off[dst];
+        for (int p = 0; p < r.len; p++) {
+            uint32_t code = (uint32_t)((r.w[p >> 5] >> (2 * (p & 31))) & 3ull);
+            uint32_t isn = (uint32_t)((r.nm[p >> 5] >> (2 * (p & 31))) & 1ull);
+            o[p] = isn ? 'N' : "ACGT"[code];
+        }
+    }
+}
+
+// lengths scattered to handle order (for unpack offsets / histograms)
+__global__ void k_scatter_len(const uint8_t* __restrict__ len, uint32_t n, uint32_t base,
+                              const uint32_t* __restrict__ orig, int32_t* __restrict__ out) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        out[orig ? orig[j] : base + j] = len[j];
+}
+
+// histogram of read lengths (which k-mer tables will the cascade ask for)
+__global__ void k_len_hist(const uint8_t* __restrict__ len, uint32_t n, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[MIRGE_MAX_READ_LEN + 1];
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        uint32_t L = len[j];
+        atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves of 64)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* lds4) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) lds4[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < MIRGE_BLOCK / 64; i++) {
+        uint32_t s = lds4[i];
+        if (i < wv) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// collapse (digest.py:141-163): open-addressing hash table of representative read indices.
+//   insert : slot claimed by atomicCAS on rep[]; a later equal read finds the slot by comparing
+//            its words with the representative's (the raw arrays are read-only during the kernel)
+//            and adds 1 to cnt[slot][sample]; firstj[slot] = min index (first appearance).
+//   heads  : read j is the head of its group iff firstj[slot_of[j]] == j; block sums of heads.
+//   scatter: exclusive scan of heads = rank in order of first appearance; heads copy their read
+//            and their slot's count row to the output.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ bool same_read(const GroupView<W>& g, uint32_t a, const MirgeRead<W>& r) {
+    if (g.len[a] != (uint8_t)r.len) return false;
+    bool eq = true;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        eq &= g.seq[(size_t)w * g.n + a] == r.w[w];
+        if (g.nmask) eq &= g.nmask[(size_t)w * g.n + a] == r.nm[w];
+    }
+    return eq;
+}
+
+template <int W>
+__global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, uint32_t* __restrict__ firstj,
+                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of,
+                                  uint32_t mask, const int32_t* __restrict__ sample_ids,
+                                  const uint32_t* __restrict__ orig, uint32_t base, int32_t S) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g.n; j += gridDim.x * blockDim.x) {
+        MirgeRead<W> r;
+        load_read<W>(g, j, r);
+        uint64_t h = mirge_mix64(r.w[0] ^ ((uint64_t)r.len << 56));
+#pragma unroll
+        for (int w = 1; w < W; w++) h = mirge_mix64(h ^ r.w[w]);
+#pragma unroll
+        for (int w = 0; w < W; w++) h ^= mirge_mix64(r.nm[w] + 0x9e3779b97f4a7c15ull * (w + 1));
+        uint32_t s = (uint32_t)(h >> 20) & mask;
+        while (true) {
+            uint32_t cur = rep[s];
+            if (cur == MIRGE_EMPTY) cur = atomicCAS(&rep[s], MIRGE_EMPTY, j);
+            if (cur == MIRGE_EMPTY || cur == j || same_read<W>(g, cur, r)) break;
+            s = (s + 1) & mask;
+        }
+        slot_of[j] = s;
+        atomicMin(&firstj[s], j);
+        const int32_t sid = sample_ids ? sample_ids[orig ? orig[j] : base + j] : 0;
+        atomicAdd(&cnt[(size_t)s * S + sid], 1u);
+    }
+}
+
+#define MIRGE_SCAN_ITEMS 8  // per thread -> 2048 per block
+__global__ void k_heads_blocksum(const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ firstj,
+                                 uint32_t n, uint32_t* __restrict__ blocksum) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * MIRGE_SCAN_ITEMS) + threadIdx.x * MIRGE_SCAN_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
+        uint32_t j = b0 + i;
+        if (j < n) c += (firstj[slot_of[j]] == j);
+    }
+    uint32_t total;
+    block_excl_scan(c, total, lds4);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of blocksum[0..nb) in place, total to *out_total
+__global__ void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb, uint32_t* __restrict__ out_total) {
+    __shared__ uint32_t lds4[4];
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < nb; b += MIRGE_BLOCK) {
+        uint32_t i = b + threadIdx.x;
+        uint32_t v = i < nb ? blocksum[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, total, lds4);
+        if (i < nb) blocksum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *out_total = carry;
+}
+
+template <int W>
+__global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ slot_of,
+                                   const uint32_t* __restrict__ firstj, const uint32_t* __restrict__ cnt,
+                                   const uint32_t* __restrict__ blockoff, const uint32_t* __restrict__ n_uniq_ptr,
+                                   const uint32_t* __restrict__ orig, uint32_t base, int32_t S,
+                                   uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
+                                   uint64_t* __restrict__ unmask, uint32_t* __restrict__ ucnt,
+                                   uint32_t* __restrict__ ufirst) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t U = *n_uniq_ptr;
+    const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * MIRGE_SCAN_ITEMS) + threadIdx.x * MIRGE_SCAN_ITEMS;
+    uint32_t heads = 0, c = 0;
+#pragma unroll
+    for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
+        uint32_t j = b0 + i;
+        if (j < g.n && firstj[slot_of[j]] == j) { heads |= 1u << i; c++; }
+    }
+    uint32_t total;
+    uint32_t rank = blockoff[blockIdx.x] + block_excl_scan(c, total, lds4);
+#pragma unroll
+    for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
+        if (heads & (1u << i)) {
+            const uint32_t j = b0 + i;
+            const uint32_t s = slot_of[j];
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                useq[(size_t)w * U + rank] = g.seq[(size_t)w * g.n + j];
+                if (unmask) unmask[(size_t)w * U + rank] = g.nmask ? g.nmask[(size_t)w * g.n + j] : 0ull;
+            }
+            ulen[rank] = g.len[j];
+            for (int32_t q = 0; q < S; q++) ucnt[(size_t)rank * S + q] = cnt[(size_t)s * S + q];
+            ufirst[rank] = orig ? orig[j] : base + j;
+            rank++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pass: one cascade pass over the still-unannotated reads of one width group.
+//   act_in == nullptr: all reads 0..n-1 (first pass); otherwise act_in[0 .. *n_in).
+//   A hit writes (pass, global position, mismatches) at the read's slot; every other read
+//   (not selected by the pass's subset rule, skipped by bowtie, or unaligned) is appended to
+//   act_out through one atomicAdd per wave (ballot + prefix popcount), so the next pass sees
+//   exactly the rows with annotFlag == 0 (manifoldAlign.py:120,129).
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(MIRGE_BLOCK)
+k_pass(MirgeLibView lib, MirgePolicy pol, GroupView<W> g, const uint32_t* __restrict__ act_in,
+       const uint32_t* __restrict__ n_in_ptr, uint32_t* __restrict__ act_out, uint32_t* __restrict__ n_out,
+       int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
+       int8_t* __restrict__ res_mm) {
+    const uint32_t n_in = act_in ? *n_in_ptr : g.n;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_in; base += stride) {
+        const uint32_t t = base + threadIdx.x;
+        const bool valid = t < n_in;
+        bool survivor = false;
+        uint32_t idx = 0;
+        if (valid) {
+            idx = act_in ? act_in[t] : t;
+            MirgeRead<W> r;
+            load_read<W>(g, idx, r);
+            survivor = true;
+            if (mirge_effective_read<W>(r, pol)) {
+                uint64_t best;
+                mirge_align_indexed<W>(lib, pol, r, best);
+                if (best != MIRGE_NO_HIT) {
+                    res_pass[idx] = (int8_t)pass_id;
+                    res_pos[idx] = (uint32_t)best;
+                    res_mm[idx] = (int8_t)(best >> 32);
+                    survivor = false;
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(survivor);
+        if (bal) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(n_out, (uint32_t)__popcll(bal));
+            wbase = __shfl(wbase, 0, 64);
+            if (survivor) act_out[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+        }
+    }
+}
+
+// global position -> (reference index, offset) by binary search in ref_start of the pass's library
+struct ResolveTable {
+    const uint32_t* ref_start[MIRGE_MAX_PASSES_K];
+    uint32_t n_refs[MIRGE_MAX_PASSES_K];
+};
+
+__global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, const uint32_t* __restrict__ res_pos,
+                          uint32_t n, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int p = res_pass[i];
+        int32_t ref = -1, off = -1;
+        if (p >= 0) {
+            const uint32_t g = res_pos[i];
+            const uint32_t* rs = nullptr;
+            uint32_t nr = 0;
+#pragma unroll
+            for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
+                if (q == p) { rs = tb.ref_start[q]; nr = tb.n_refs[q]; }
+            uint32_t lo = 0, hi = nr;  // last t with rs[t] <= g
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (rs[mid] <= g) lo = mid; else hi = mid;
+            }
+            ref = (int32_t)lo;
+            off = (int32_t)(g - rs[lo]);
+        }
+        res_ref[i] = ref;
+        res_off[i] = off;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_join: count join (summary.py:686-698,749-752): class_sums[pass][s] += counts[i][s],
+// exact/iso[ref][s] += counts[i][s] for the two miRNA passes.  Class sums are accumulated in LDS
+// per workgroup and flushed with one atomic per (pass, sample) cell.
+// ------------------------------------------------------------------------------------------
+#define MIRGE_JOIN_LDS 2048
+__global__ void k_join(const int8_t* __restrict__ res_pass, const int32_t* __restrict__ res_ref,
+                       const uint32_t* __restrict__ counts, uint32_t n, int32_t S, int32_t n_pass,
+                       int32_t exact_pass, int32_t iso_pass, unsigned long long* __restrict__ class_sums,
+                       unsigned long long* __restrict__ exact, unsigned long long* __restrict__ iso) {
+    __shared__ unsigned long long acc[MIRGE_JOIN_LDS];
+    const int cells = n_pass * S;
+    const bool use_lds = cells <= MIRGE_JOIN_LDS;
+    if (use_lds) {
+        for (int c = threadIdx.x; c < cells; c += blockDim.x) acc[c] = 0ull;
+        __syncthreads();
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int p = res_pass[i];
+        if (p < 0) continue;
+        const int32_t ref = res_ref[i];
+        for (int32_t s = 0; s < S; s++) {
+            const unsigned long long c = counts[(size_t)i * S + s];
+            if (!c) continue;
+            if (use_lds) atomicAdd(&acc[p * S + s], c);
+            else atomicAdd(&class_sums[p * S + s], c);
+            if (p == exact_pass) atomicAdd(&exact[(size_t)ref * S + s], c);
+            else if (p == iso_pass) atomicAdd(&iso[(size_t)ref * S + s], c);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < cells; c += blockDim.x)
+            if (acc[c]) atomicAdd(&class_sums[c], acc[c]);
+    }
+}
+
+// out[orig[j] or base+j] = in[j]
+template <typename T>
+__global__ void k_scatter_out(const T* __restrict__ in, uint32_t n, uint32_t base,
+                              const uint32_t* __restrict__ orig, T* __restrict__ out) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        out[orig ? orig[j] : base + j] = in[j];
+}
+
+template <typename T>
+__global__ void k_fill(T* __restrict__ p, size_t n, T v) {
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) p[j] = v;
+}

@@ -1,0 +1,97 @@
+// mirge_libbuild.hpp -- host-side construction of a library's device image: 2-bit text,
+// invalid bitmap, reference starts and the direct-addressed k-mer tables.  Plain C++ (no HIP) so
+// that it is compiled into libmirge_native.so and, for logic tests without a GPU, into
+// tests/hostsim.  It stands where `bowtie-build` stands for the reference.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mirge_core.hpp"
+
+struct MirgeHostLib {
+    int64_t n_refs = 0;
+    uint64_t total = 0;  // bases including one separator after every reference
+    int kmax = 8;
+    uint64_t valid_positions = 0;
+    std::vector<uint64_t> T;    // (total+31)/32 + 8 words, zero padded
+    std::vector<uint64_t> inv;  // (total+63)/64 + 4 words, padding = ones
+    std::vector<uint32_t> ref_start;  // n_refs + 1
+};
+
+static inline int mirge_base_code(char ch) {
+    switch (ch & 0xDF) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        case 'U': return 3;
+        default: return -1;  // N and every other IUPAC code: no window over it is a valid hit
+    }
+}
+
+static inline int mirge_hostlib_build(MirgeHostLib& L, const char* seq, const int64_t* off, int64_t n_refs,
+                                      std::string& err) {
+    L.n_refs = n_refs;
+    uint64_t total = 0;
+    for (int64_t t = 0; t < n_refs; t++) {
+        if (off[t + 1] < off[t]) { err = "offsets not monotone"; return -1; }
+        total += (uint64_t)(off[t + 1] - off[t]) + 1;
+    }
+    if (total >= 0xFFFFFFF0ull) { err = "library larger than 2^32 bases is not supported"; return -5; }
+    L.total = total;
+    L.T.assign((size_t)((total + 31) / 32) + 8, 0ull);
+    L.inv.assign((size_t)((total + 63) / 64) + 4, ~0ull);
+    L.ref_start.resize((size_t)n_refs + 1);
+    uint64_t g = 0;
+    L.valid_positions = 0;
+    for (int64_t t = 0; t < n_refs; t++) {
+        L.ref_start[(size_t)t] = (uint32_t)g;
+        for (int64_t i = off[t]; i < off[t + 1]; i++, g++) {
+            int code = mirge_base_code(seq[i]);
+            if (code >= 0) {
+                L.T[g >> 5] |= (uint64_t)code << (2 * (g & 31));
+                L.inv[g >> 6] &= ~(1ull << (g & 63));
+                L.valid_positions++;
+            }
+        }
+        g++;  // the separator stays invalid
+    }
+    L.ref_start[(size_t)n_refs] = (uint32_t)g;
+    // largest probe length: 4^k >= 4 x positions, clamped to [8, MIRGE_KMAX]
+    int k = 8;
+    while (k < MIRGE_KMAX && (1ull << (2 * k)) < 4ull * std::max<uint64_t>(L.valid_positions, 1)) k++;
+    L.kmax = k;
+    return 0;
+}
+
+// Every valid k-window, counting-sorted by its little-endian 2-bit value; positions ascend
+// inside a bucket (the early exit of mirge_align_indexed relies on that).
+static inline void mirge_hostlib_table(const MirgeHostLib& L, int k, std::vector<uint32_t>& bucket,
+                                       std::vector<uint32_t>& pos) {
+    const uint64_t nb = 1ull << (2 * k);
+    bucket.assign(nb + 1, 0u);
+    const uint64_t* T = L.T.data();
+    const uint64_t* inv = L.inv.data();
+    const int sh = 2 * (k - 1);
+    for (int phase = 0; phase < 2; phase++) {
+        if (phase == 1) {
+            uint32_t acc = 0;
+            for (uint64_t b = 0; b <= nb; b++) { uint32_t c = bucket[b]; bucket[b] = acc; acc += c; }
+            pos.assign(std::max<size_t>(acc, 1), 0u);
+        }
+        uint64_t key = 0;
+        int run = 0;
+        for (uint64_t g = 0; g < L.total; g++) {
+            if ((inv[g >> 6] >> (g & 63)) & 1ull) { run = 0; key = 0; continue; }
+            key = (key >> 2) | (((T[g >> 5] >> (2 * (g & 31))) & 3ull) << sh);  // window [g-k+1, g]
+            if (++run >= k) {
+                if (phase == 0) bucket[key]++;
+                else pos[bucket[key]++] = (uint32_t)(g - (uint64_t)k + 1);
+            }
+        }
+    }
+    for (uint64_t b = nb; b > 0; b--) bucket[b] = bucket[b - 1];
+    bucket[0] = 0;
+}

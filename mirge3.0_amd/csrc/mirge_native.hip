@@ -1,0 +1,867 @@
+// mirge_native.hip -- host runtime + C ABI of libmirge_native.so (include/mirge_native.h).
+//
+// Host side of the MI355X hot path: device context with a stream-ordered buffer pool (no
+// hipMalloc/hipFree once warm), library packing + k-mer table construction, and the launch
+// sequences for pack / collapse / cascade / count join.  Kernels: mirge_kernels.hpp.
+// There is no CPU implementation of any of the compute in this file or anywhere in the product.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mirge_native.h"
+#include "mirge_kernels.hpp"
+#include "mirge_libbuild.hpp"
+
+static_assert(sizeof(mirge_policy) == sizeof(MirgePolicy), "policy layout");
+static_assert(MIRGE_MAX_PASSES == MIRGE_MAX_PASSES_K, "pass cap");
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPOK(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+#define CHECK(expr)            \
+    do {                       \
+        int _c = (expr);       \
+        if (_c != 0) return _c; \
+    } while (0)
+
+extern "C" const char* mirge_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------
+// context: device, stream, pooled device memory, profiler
+// ------------------------------------------------------------------------------------------
+struct ProfRec {
+    std::string name;
+    int64_t launches = 0;
+    double total_ms = 0.0;
+    double units = 0.0;
+};
+struct PendingEvt {
+    int rec;
+    hipEvent_t a, b;
+};
+
+struct mirge_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    // pool
+    std::multimap<size_t, void*> free_blocks;
+    std::unordered_map<void*, size_t> sizes;
+    size_t pool_bytes = 0;
+    // profiler
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    std::unordered_map<std::string, int> rec_of;
+    std::vector<PendingEvt> pending;
+    std::vector<hipEvent_t> evt_pool;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // pinned scratch for small D2H
+    uint32_t* pinned = nullptr;
+
+    int alloc(void** out, size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes * 2 + (1u << 20)) {
+            *out = it->second;
+            free_blocks.erase(it);
+            return 0;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
+            for (auto& kv : free_blocks) { (void)hipFree(kv.second); pool_bytes -= kv.first; sizes.erase(kv.second); }
+            free_blocks.clear();
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return fail(-3, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+        }
+        sizes[p] = bytes;
+        pool_bytes += bytes;
+        *out = p;
+        return 0;
+    }
+    void release(void* p) {
+        if (!p) return;
+        auto it = sizes.find(p);
+        if (it == sizes.end()) return;
+        free_blocks.emplace(it->second, p);  // stream-ordered reuse: one stream per ctx
+    }
+    int rec_index(const char* name) {
+        auto it = rec_of.find(name);
+        if (it != rec_of.end()) return it->second;
+        recs.push_back(ProfRec{name});
+        rec_of[name] = (int)recs.size() - 1;
+        return (int)recs.size() - 1;
+    }
+    hipEvent_t get_evt() {
+        if (!evt_pool.empty()) { hipEvent_t e = evt_pool.back(); evt_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void drain() {  // resolve pending event pairs (caller has synchronised the stream)
+        for (auto& p : pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) recs[p.rec].total_ms += ms;
+            evt_pool.push_back(p.a);
+            evt_pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+
+template <typename T>
+static int dalloc(mirge_ctx* c, T** out, size_t count) { return c->alloc((void**)out, count * sizeof(T)); }
+
+// launch bracket: HIP events on the ctx stream around each kernel when profiling is on
+struct LaunchScope {
+    mirge_ctx* c; int rec = -1; hipEvent_t a = nullptr, b = nullptr;
+    LaunchScope(mirge_ctx* ctx, const char* name, double units) : c(ctx) {
+        if (!c->profiling) return;
+        rec = c->rec_index(name);
+        c->recs[rec].launches++;
+        c->recs[rec].units += units;
+        a = c->get_evt(); b = c->get_evt();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~LaunchScope() {
+        if (rec < 0) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back(PendingEvt{rec, a, b});
+    }
+};
+
+static inline int grid_for(const mirge_ctx* c, size_t n, int per_block = MIRGE_BLOCK) {
+    size_t blocks = (n + per_block - 1) / per_block;
+    size_t cap = (size_t)c->n_cu * 8;
+    return (int)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+extern "C" int mirge_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
+    if (!out) return fail(-1, "mirge_ctx_create: out is NULL");
+    int n = mirge_device_count();
+    if (n <= 0) return fail(-4, "no HIP device visible: the hot path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(-1, "device index out of range");
+    HIPOK(hipSetDevice(device));
+    auto c = std::make_unique<mirge_ctx>();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPOK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; }
+    else { HIPOK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIPOK(hipEventCreate(&c->t0));
+    HIPOK(hipEventCreate(&c->t1));
+    HIPOK(hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault));
+    *out = c.release();
+    return 0;
+}
+
+extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->drain();
+    for (auto& kv : c->sizes) (void)hipFree(kv.first);
+    for (auto e : c->evt_pool) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mirge_ctx_sync(mirge_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->drain();
+    return 0;
+}
+
+extern "C" int mirge_ctx_timer_start(mirge_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    HIPOK(hipEventRecord(c->t0, c->stream));
+    return 0;
+}
+extern "C" int mirge_ctx_timer_stop(mirge_ctx* c, double* ms_out) {
+    if (!c || !ms_out) return fail(-1, "NULL argument");
+    HIPOK(hipEventRecord(c->t1, c->stream));
+    HIPOK(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    HIPOK(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_out = ms;
+    return 0;
+}
+extern "C" int mirge_ctx_profile_enable(mirge_ctx* c, int32_t on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->profiling = on != 0;
+    return 0;
+}
+extern "C" int mirge_ctx_profile_reset(mirge_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    CHECK(mirge_ctx_sync(c));
+    c->recs.clear();
+    c->rec_of.clear();
+    return 0;
+}
+extern "C" int32_t mirge_ctx_profile_count(mirge_ctx* c) {
+    if (!c) return 0;
+    if (mirge_ctx_sync(c) != 0) return 0;
+    return (int32_t)c->recs.size();
+}
+extern "C" int mirge_ctx_profile_get(mirge_ctx* c, int32_t i, char* name_out, int32_t name_cap,
+                                     int64_t* launches, double* total_ms, double* units) {
+    if (!c || i < 0 || i >= (int32_t)c->recs.size()) return fail(-1, "profile index out of range");
+    const ProfRec& r = c->recs[i];
+    if (name_out && name_cap > 0) { std::snprintf(name_out, (size_t)name_cap, "%s", r.name.c_str()); }
+    if (launches) *launches = r.launches;
+    if (total_ms) *total_ms = r.total_ms;
+    if (units) *units = r.units;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// library: 2-bit text + invalid bitmap + per-k tables
+// ------------------------------------------------------------------------------------------
+struct mirge_lib {
+    mirge_ctx* ctx = nullptr;
+    MirgeHostLib h;  // host image (table construction)
+    // device
+    uint64_t* dT = nullptr;
+    uint64_t* dinv = nullptr;
+    uint32_t* dref_start = nullptr;
+    MirgeKTable* dtables = nullptr;
+    MirgeKTable htables[MIRGE_KMAX + 1];
+    size_t table_n[MIRGE_KMAX + 1];
+    size_t device_bytes = 0;
+    std::mutex mu;
+    int64_t n_refs = 0;
+    int kmax = 8;
+
+    MirgeLibView view() const {
+        MirgeLibView v;
+        v.T = dT; v.inv = dinv; v.ref_start = dref_start; v.tables = dtables;
+        v.total = h.total; v.n_refs = (uint32_t)n_refs; v.kmax = kmax;
+        return v;
+    }
+};
+
+extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* off, int64_t n_refs, mirge_lib** out) {
+    if (!c || !out || (!seq && n_refs > 0) || !off || n_refs < 0) return fail(-1, "mirge_lib_create: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    auto L = std::make_unique<mirge_lib>();
+    L->ctx = c;
+    std::string err;
+    int rc = mirge_hostlib_build(L->h, seq, off, n_refs, err);
+    if (rc) return fail(rc, "mirge_lib_create: " + err);
+    L->n_refs = n_refs;
+    L->kmax = L->h.kmax;
+    for (int i = 0; i <= MIRGE_KMAX; i++) { L->htables[i].bucket = nullptr; L->htables[i].pos = nullptr; L->table_n[i] = 0; }
+    const size_t nT = L->h.T.size() * 8, nI = L->h.inv.size() * 8, nR = ((size_t)n_refs + 1) * 4;
+    HIPOK(hipMalloc((void**)&L->dT, nT));
+    HIPOK(hipMalloc((void**)&L->dinv, nI));
+    HIPOK(hipMalloc((void**)&L->dref_start, nR));
+    HIPOK(hipMalloc((void**)&L->dtables, sizeof(MirgeKTable) * (MIRGE_KMAX + 1)));
+    HIPOK(hipMemcpy(L->dT, L->h.T.data(), nT, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(L->dinv, L->h.inv.data(), nI, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(L->dref_start, L->h.ref_start.data(), nR, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(L->dtables, L->htables, sizeof(MirgeKTable) * (MIRGE_KMAX + 1), hipMemcpyHostToDevice));
+    L->device_bytes = nT + nI + nR;
+    *out = L.release();
+    return 0;
+}
+
+extern "C" void mirge_lib_destroy(mirge_lib* L) {
+    if (!L) return;
+    (void)hipSetDevice(L->ctx->device);
+    (void)hipStreamSynchronize(L->ctx->stream);
+    (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dtables);
+    for (int k = 0; k <= MIRGE_KMAX; k++) { (void)hipFree((void*)L->htables[k].bucket); (void)hipFree((void*)L->htables[k].pos); }
+    delete L;
+}
+extern "C" int64_t mirge_lib_n_refs(const mirge_lib* L) { return L ? L->n_refs : -1; }
+extern "C" int64_t mirge_lib_device_bytes(const mirge_lib* L) { return L ? (int64_t)L->device_bytes : -1; }
+
+extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {
+    if (!L) return fail(-1, "lib is NULL");
+    if (k < 1 || k > MIRGE_KMAX) return fail(-1, "k out of range");
+    std::lock_guard<std::mutex> lk(L->mu);
+    if (L->htables[k].bucket) return 0;
+    HIPOK(hipSetDevice(L->ctx->device));
+    std::vector<uint32_t> bucket, pos;
+    mirge_hostlib_table(L->h, k, bucket, pos);
+    uint32_t* dbucket = nullptr; uint32_t* dpos = nullptr;
+    HIPOK(hipMalloc((void**)&dbucket, bucket.size() * 4));
+    HIPOK(hipMalloc((void**)&dpos, pos.size() * 4));
+    HIPOK(hipMemcpy(dbucket, bucket.data(), bucket.size() * 4, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(dpos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+    L->htables[k].bucket = dbucket;
+    L->htables[k].pos = dpos;
+    L->table_n[k] = pos.size();
+    L->device_bytes += bucket.size() * 4 + pos.size() * 4;
+    HIPOK(hipStreamSynchronize(L->ctx->stream));  // no kernel may be reading the table row being replaced
+    HIPOK(hipMemcpy(L->dtables, L->htables, sizeof(MirgeKTable) * (MIRGE_KMAX + 1), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// reads
+// ------------------------------------------------------------------------------------------
+static const int kGroupW[3] = {1, 2, 4};
+
+struct ReadGroup {
+    int W = 1;
+    uint32_t n = 0;
+    uint64_t* seq = nullptr;
+    uint8_t* len = nullptr;
+    uint64_t* nmask = nullptr;
+    uint32_t* orig = nullptr;    // handle-order index of each read (nullptr: base + j)
+    uint32_t base = 0;
+    uint32_t* counts = nullptr;  // [n][S]
+    uint32_t* first = nullptr;   // [n] raw index of first appearance (collapse output)
+};
+
+struct mirge_reads {
+    mirge_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int64_t total_bases = 0;
+    int32_t n_samples = 0;  // 0: no count matrix attached
+    ReadGroup g[3];
+    int32_t len_hist[MIRGE_MAX_READ_LEN + 1];  // lengths present (host), for table preparation
+    bool hist_valid = false;
+};
+
+template <int W>
+static GroupView<W> view_of(const ReadGroup& g) {
+    GroupView<W> v; v.seq = g.seq; v.len = g.len; v.nmask = g.nmask; v.n = g.n; return v;
+}
+
+extern "C" void mirge_reads_destroy(mirge_reads* r) {
+    if (!r) return;
+    for (auto& g : r->g) {
+        r->ctx->release(g.seq); r->ctx->release(g.len); r->ctx->release(g.nmask);
+        r->ctx->release(g.orig); r->ctx->release(g.counts); r->ctx->release(g.first);
+    }
+    delete r;
+}
+extern "C" int64_t mirge_reads_count(const mirge_reads* r) { return r ? r->n : -1; }
+extern "C" int64_t mirge_reads_total_bases(const mirge_reads* r) { return r ? r->total_bases : -1; }
+extern "C" int32_t mirge_reads_n_samples(const mirge_reads* r) { return r ? r->n_samples : -1; }
+
+template <int W>
+static void launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* doff, const uint32_t* didx,
+                        ReadGroup& g, uint32_t* dflags) {
+    LaunchScope ls(c, "k_pack", g.n);
+    hipLaunchKernelGGL(k_pack<W>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                       dascii, doff, didx, g.n, g.seq, g.len, g.nmask, dflags);
+}
+
+extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads** out) {
+    if (!c || !out || !off || n < 0 || (n > 0 && !ascii)) return fail(-1, "mirge_reads_pack: bad argument");
+    if (n >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
+    HIPOK(hipSetDevice(c->device));
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = n;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    std::vector<uint32_t> idx[3];
+    for (int64_t i = 0; i < n; i++) {
+        int64_t L = off[i + 1] - off[i];
+        if (L < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
+        if (L > MIRGE_MAX_READ_LEN)
+            return fail(-6, "read " + std::to_string(i) + " is " + std::to_string(L) + " nt; the limit is " +
+                            std::to_string(MIRGE_MAX_READ_LEN));
+        R->len_hist[L]++;
+        idx[L <= 32 ? 0 : (L <= 64 ? 1 : 2)].push_back((uint32_t)i);
+    }
+    R->hist_valid = true;
+    R->total_bases = n ? off[n] - off[0] : 0;
+    const int64_t nbytes = R->total_bases;
+    uint8_t* dascii = nullptr; int64_t* doff = nullptr; uint32_t* dflags = nullptr;
+    CHECK(dalloc(c, &dascii, (size_t)std::max<int64_t>(nbytes, 1)));
+    CHECK(dalloc(c, &doff, (size_t)n + 1));
+    CHECK(dalloc(c, &dflags, 8));
+    std::vector<int64_t> rel((size_t)n + 1);
+    for (int64_t i = 0; i <= n; i++) rel[(size_t)i] = off[i] - off[0];
+    if (nbytes) HIPOK(hipMemcpyAsync(dascii, ascii + off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(doff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemsetAsync(dflags, 0, 32, c->stream));
+    uint32_t* didx[3] = {nullptr, nullptr, nullptr};
+    for (int gi = 0; gi < 3; gi++) {
+        ReadGroup& g = R->g[gi];
+        g.W = kGroupW[gi];
+        g.n = (uint32_t)idx[gi].size();
+        if (!g.n) continue;
+        CHECK(dalloc(c, &g.seq, (size_t)g.W * g.n));
+        CHECK(dalloc(c, &g.nmask, (size_t)g.W * g.n));
+        CHECK(dalloc(c, &g.len, (size_t)g.n));
+        CHECK(dalloc(c, &g.orig, (size_t)g.n));
+        HIPOK(hipMemcpyAsync(g.orig, idx[gi].data(), (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream));
+        didx[gi] = g.orig;
+        if (gi == 0) launch_pack<1>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
+        else if (gi == 1) launch_pack<2>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
+        else launch_pack<4>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
+    }
+    HIPOK(hipMemcpyAsync(c->pinned, dflags, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));  // idx/rel host vectors are read by the async copies
+    c->release(dascii); c->release(doff); c->release(dflags);
+    for (int gi = 0; gi < 3; gi++) {
+        if (c->pinned[2 * gi + 1]) {
+            mirge_reads_destroy(R.release());
+            return fail(-7, "a read contains a character other than A/C/G/T/U/N");
+        }
+        if (!c->pinned[2 * gi] && R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
+    }
+    *out = R.release();
+    return 0;
+}
+
+extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* ascii_out, int64_t* off_out) {
+    if (!c || !R || !off_out || (R->total_bases > 0 && !ascii_out)) return fail(-1, "mirge_reads_unpack: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    const int64_t n = R->n;
+    int32_t* dlen = nullptr;
+    CHECK(dalloc(c, &dlen, (size_t)std::max<int64_t>(n, 1)));
+    for (int gi = 0; gi < 3; gi++) {
+        const ReadGroup& g = R->g[gi];
+        if (!g.n) continue;
+        LaunchScope ls(c, "k_scatter_len", g.n);
+        hipLaunchKernelGGL(k_scatter_len, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                           g.len, g.n, g.base, g.orig, dlen);
+    }
+    std::vector<int32_t> hlen((size_t)std::max<int64_t>(n, 1));
+    if (n) HIPOK(hipMemcpyAsync(hlen.data(), dlen, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    off_out[0] = 0;
+    for (int64_t i = 0; i < n; i++) off_out[i + 1] = off_out[i] + hlen[(size_t)i];
+    const int64_t total = off_out[n];
+    int64_t* doff = nullptr; uint8_t* dout = nullptr;
+    CHECK(dalloc(c, &doff, (size_t)n + 1));
+    CHECK(dalloc(c, &dout, (size_t)std::max<int64_t>(total, 1)));
+    HIPOK(hipMemcpyAsync(doff, off_out, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    for (int gi = 0; gi < 3; gi++) {
+        const ReadGroup& g = R->g[gi];
+        if (!g.n) continue;
+        LaunchScope ls(c, "k_unpack", g.n);
+        if (gi == 0) hipLaunchKernelGGL(k_unpack<1>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(g), doff, g.base, g.orig, dout);
+        else if (gi == 1) hipLaunchKernelGGL(k_unpack<2>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<2>(g), doff, g.base, g.orig, dout);
+        else hipLaunchKernelGGL(k_unpack<4>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<4>(g), doff, g.base, g.orig, dout);
+    }
+    if (total) HIPOK(hipMemcpyAsync(ascii_out, dout, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->release(dlen); c->release(doff); c->release(dout);
+    return 0;
+}
+
+extern "C" int mirge_reads_set_counts(mirge_ctx* c, mirge_reads* R, const uint32_t* counts, int32_t S) {
+    if (!c || !R || !counts || S < 1) return fail(-1, "mirge_reads_set_counts: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    // counts are in handle order; each group wants its rows contiguous -> gather on the host
+    // through the group's orig list (small: U x S)
+    for (int gi = 0; gi < 3; gi++) {
+        ReadGroup& g = R->g[gi];
+        if (!g.n) continue;
+        std::vector<uint32_t> horig(g.n);
+        if (g.orig) { HIPOK(hipMemcpyAsync(horig.data(), g.orig, (size_t)g.n * 4, hipMemcpyDeviceToHost, c->stream)); HIPOK(hipStreamSynchronize(c->stream)); }
+        else for (uint32_t j = 0; j < g.n; j++) horig[j] = g.base + j;
+        std::vector<uint32_t> rows((size_t)g.n * S);
+        for (uint32_t j = 0; j < g.n; j++)
+            std::memcpy(&rows[(size_t)j * S], &counts[(size_t)horig[j] * S], (size_t)S * 4);
+        c->release(g.counts); g.counts = nullptr;
+        CHECK(dalloc(c, &g.counts, (size_t)g.n * S));
+        HIPOK(hipMemcpyAsync(g.counts, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+    }
+    R->n_samples = S;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// collapse
+// ------------------------------------------------------------------------------------------
+template <int W>
+static int collapse_group(mirge_ctx* c, const ReadGroup& in, ReadGroup& out, const int32_t* dsample, int32_t S,
+                          uint32_t out_base, uint32_t* dhist) {
+    out.W = W; out.n = 0; out.base = out_base;
+    if (!in.n) return 0;
+    uint32_t tsize = 1024;
+    while (tsize < 2ull * in.n) tsize <<= 1;
+    uint32_t *rep = nullptr, *firstj = nullptr, *cnt = nullptr, *slot_of = nullptr, *blocksum = nullptr, *dU = nullptr;
+    CHECK(dalloc(c, &rep, tsize));
+    CHECK(dalloc(c, &firstj, tsize));
+    CHECK(dalloc(c, &cnt, (size_t)tsize * S));
+    CHECK(dalloc(c, &slot_of, in.n));
+    const uint32_t per_block = MIRGE_BLOCK * MIRGE_SCAN_ITEMS;
+    const uint32_t nb = (in.n + per_block - 1) / per_block;
+    CHECK(dalloc(c, &blocksum, nb));
+    CHECK(dalloc(c, &dU, 4));
+    HIPOK(hipMemsetAsync(rep, 0xFF, (size_t)tsize * 4, c->stream));
+    HIPOK(hipMemsetAsync(firstj, 0xFF, (size_t)tsize * 4, c->stream));
+    HIPOK(hipMemsetAsync(cnt, 0, (size_t)tsize * S * 4, c->stream));
+    GroupView<W> v = view_of<W>(in);
+    {
+        LaunchScope ls(c, "k_collapse_insert", in.n);
+        hipLaunchKernelGGL(k_collapse_insert<W>, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                           v, rep, firstj, cnt, slot_of, tsize - 1, dsample, in.orig, in.base, S);
+    }
+    {
+        LaunchScope ls(c, "k_heads_blocksum", in.n);
+        hipLaunchKernelGGL(k_heads_blocksum, dim3(nb), dim3(MIRGE_BLOCK), 0, c->stream, slot_of, firstj, in.n, blocksum);
+    }
+    {
+        LaunchScope ls(c, "k_scan_blocksums", nb);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->stream, blocksum, nb, dU);
+    }
+    HIPOK(hipMemcpyAsync(c->pinned, dU, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));  // U sizes the output arrays
+    const uint32_t U = c->pinned[0];
+    out.n = U;
+    CHECK(dalloc(c, &out.seq, (size_t)W * U));
+    CHECK(dalloc(c, &out.len, (size_t)U));
+    if (in.nmask) CHECK(dalloc(c, &out.nmask, (size_t)W * U));
+    CHECK(dalloc(c, &out.counts, (size_t)U * S));
+    CHECK(dalloc(c, &out.first, (size_t)U));
+    {
+        LaunchScope ls(c, "k_collapse_scatter", in.n);
+        hipLaunchKernelGGL(k_collapse_scatter<W>, dim3(nb), dim3(MIRGE_BLOCK), 0, c->stream, v, slot_of, firstj, cnt,
+                           blocksum, dU, in.orig, in.base, S, out.seq, out.len, out.nmask, out.counts, out.first);
+    }
+    if (U) {
+        LaunchScope ls(c, "k_len_hist", U);
+        hipLaunchKernelGGL(k_len_hist, dim3(grid_for(c, U)), dim3(MIRGE_BLOCK), 0, c->stream, out.len, U, dhist);
+    }
+    c->release(rep); c->release(firstj); c->release(cnt); c->release(slot_of); c->release(blocksum); c->release(dU);
+    return 0;
+}
+
+extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
+                              mirge_reads** uniq, int64_t* n_uniq) {
+    if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids)) return fail(-1, "mirge_collapse: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    int32_t* dsample = nullptr;
+    if (sample_ids && raw->n) {
+        for (int64_t i = 0; i < raw->n; i++)
+            if (sample_ids[i] < 0 || sample_ids[i] >= S) return fail(-1, "sample id out of range");
+        CHECK(dalloc(c, &dsample, (size_t)raw->n));
+        HIPOK(hipMemcpyAsync(dsample, sample_ids, (size_t)raw->n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n_samples = S;
+    uint32_t base = 0;
+    int rc = 0;
+    uint32_t* dhist = nullptr;
+    CHECK(dalloc(c, &dhist, MIRGE_MAX_READ_LEN + 1));
+    HIPOK(hipMemsetAsync(dhist, 0, (MIRGE_MAX_READ_LEN + 1) * 4, c->stream));
+    for (int gi = 0; gi < 3 && rc == 0; gi++) {
+        if (gi == 0) rc = collapse_group<1>(c, raw->g[gi], R->g[gi], dsample, S, base, dhist);
+        else if (gi == 1) rc = collapse_group<2>(c, raw->g[gi], R->g[gi], dsample, S, base, dhist);
+        else rc = collapse_group<4>(c, raw->g[gi], R->g[gi], dsample, S, base, dhist);
+        base += R->g[gi].n;
+    }
+    if (rc == 0) {
+        hipError_t e = hipMemcpyAsync(c->pinned, dhist, (MIRGE_MAX_READ_LEN + 1) * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(-2, std::string("length histogram: ") + hipGetErrorString(e));
+        else {
+            R->total_bases = 0;
+            for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
+                R->len_hist[L] = (int32_t)c->pinned[L];
+                R->total_bases += (int64_t)L * c->pinned[L];
+            }
+            R->hist_valid = true;
+        }
+    }
+    c->release(dsample); c->release(dhist);
+    if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    R->n = base;
+    *uniq = R.release();
+    if (n_uniq) *n_uniq = base;
+    return 0;
+}
+
+extern "C" int mirge_collapse_fetch(mirge_ctx* c, const mirge_reads* U, uint32_t* counts_out, int64_t* first_out) {
+    if (!c || !U || !counts_out) return fail(-1, "mirge_collapse_fetch: bad argument");
+    if (U->n_samples < 1) return fail(-1, "read set has no count matrix");
+    HIPOK(hipSetDevice(c->device));
+    const int32_t S = U->n_samples;
+    std::vector<uint32_t> tmp;
+    for (int gi = 0; gi < 3; gi++) {
+        const ReadGroup& g = U->g[gi];
+        if (!g.n) continue;
+        if (g.orig) return fail(-1, "mirge_collapse_fetch: handle is not a collapse result");
+        HIPOK(hipMemcpyAsync(counts_out + (size_t)g.base * S, g.counts, (size_t)g.n * S * 4, hipMemcpyDeviceToHost, c->stream));
+        if (first_out && g.first) {
+            tmp.resize(g.n);
+            HIPOK(hipMemcpyAsync(tmp.data(), g.first, (size_t)g.n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPOK(hipStreamSynchronize(c->stream));
+            for (uint32_t j = 0; j < g.n; j++) first_out[g.base + j] = tmp[j];
+        }
+    }
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// cascade
+// ------------------------------------------------------------------------------------------
+struct ResGroup {
+    uint32_t n = 0;
+    int8_t* pass = nullptr;
+    uint32_t* pos = nullptr;
+    int8_t* mm = nullptr;
+    int32_t* ref = nullptr;
+    int32_t* off = nullptr;
+};
+struct mirge_result {
+    mirge_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int32_t n_pass = 0;
+    ResGroup g[3];
+    const mirge_reads* reads = nullptr;  // borrowed: orig/base mapping (must outlive the fetch)
+};
+
+extern "C" void mirge_result_destroy(mirge_result* r) {
+    if (!r) return;
+    for (auto& g : r->g) {
+        r->ctx->release(g.pass); r->ctx->release(g.pos); r->ctx->release(g.mm);
+        r->ctx->release(g.ref); r->ctx->release(g.off);
+    }
+    delete r;
+}
+
+// which table lengths can pass `p` ask for, given the read lengths present
+static void needed_k(const mirge_policy& p, const int32_t* hist, int kmax, bool need[MIRGE_KMAX + 1]) {
+    for (int L = 1; L <= MIRGE_MAX_READ_LEN; L++) {
+        if (!hist[L]) continue;
+        if (p.len_lt > 0 && !(L < p.len_lt)) continue;
+        if (p.len_gt > 0 && !(L > p.len_gt)) continue;
+        int lo = L, hi = L;
+        if (p.ttail) { lo = 1; hi = L - 3; }  // any head length once the T run is gone
+        for (int l0 = lo; l0 <= hi; l0++) {
+            int l = l0 - p.trim5 - p.trim3;
+            if (l < 1 || l <= p.mm) continue;
+            int seed = p.mode == 0 ? std::min(l, p.seedlen) : l;
+            int h = seed / (p.mm + 1);
+            int k = std::min(h, kmax);
+            if (k >= 1) need[k] = true;
+        }
+    }
+}
+
+template <int W>
+static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const mirge_lib* const* libs,
+                         const mirge_policy* pol, int32_t n_pass, const ResolveTable& rt) {
+    out.n = rg.n;
+    if (!rg.n) return 0;
+    const uint32_t n = rg.n;
+    CHECK(dalloc(c, &out.pass, n));
+    CHECK(dalloc(c, &out.pos, n));
+    CHECK(dalloc(c, &out.mm, n));
+    CHECK(dalloc(c, &out.ref, n));
+    CHECK(dalloc(c, &out.off, n));
+    uint32_t *actA = nullptr, *actB = nullptr, *counters = nullptr;
+    CHECK(dalloc(c, &actA, n));
+    CHECK(dalloc(c, &actB, n));
+    CHECK(dalloc(c, &counters, MIRGE_MAX_PASSES + 2));
+    HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->stream));
+    HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->stream));
+    HIPOK(hipMemsetAsync(counters, 0, (MIRGE_MAX_PASSES + 2) * 4, c->stream));
+    GroupView<W> v = view_of<W>(rg);
+    const uint32_t* act_in = nullptr;
+    uint32_t* act_out = actA;
+    int stage = 0;
+    static const char* kname[MIRGE_MAX_PASSES] = {
+        "k_pass[0]", "k_pass[1]", "k_pass[2]", "k_pass[3]", "k_pass[4]", "k_pass[5]", "k_pass[6]", "k_pass[7]",
+        "k_pass[8]", "k_pass[9]", "k_pass[10]", "k_pass[11]", "k_pass[12]", "k_pass[13]", "k_pass[14]", "k_pass[15]"};
+    std::vector<std::pair<int, int>> stage_of_pass;  // (rec index, counter index) for unit accounting
+    for (int32_t p = 0; p < n_pass; p++) {
+        if (!libs[p]) continue;
+        MirgePolicy mp;
+        std::memcpy(&mp, &pol[p], sizeof(mp));
+        {
+            LaunchScope ls(c, kname[p], 0.0);
+            if (ls.rec >= 0) stage_of_pass.emplace_back(ls.rec, stage);
+            hipLaunchKernelGGL(k_pass<W>, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, libs[p]->view(), mp, v,
+                               act_in, counters + stage, act_out, counters + stage + 1, p, out.pass, out.pos, out.mm);
+        }
+        act_in = act_out;
+        act_out = (act_out == actA) ? actB : actA;
+        stage++;
+    }
+    {
+        LaunchScope ls(c, "k_resolve", n);
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, rt, out.pass, out.pos, n, out.ref, out.off);
+    }
+    if (c->profiling && !stage_of_pass.empty()) {  // units of each pass = reads it was handed
+        HIPOK(hipMemcpyAsync(c->pinned, counters, (MIRGE_MAX_PASSES + 2) * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+        for (auto& sp : stage_of_pass) c->recs[sp.first].units += sp.second == 0 ? (double)n : (double)c->pinned[sp.second];
+    }
+    c->release(actA); c->release(actB); c->release(counters);
+    return 0;
+}
+
+extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
+                                 const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
+    if (!c || !R || !libs || !pol || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
+        return fail(-1, "mirge_cascade_run: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    // read lengths present (host histogram from pack; a collapse result asks the device once)
+    int32_t hist[MIRGE_MAX_READ_LEN + 1];
+    if (R->hist_valid) std::memcpy(hist, R->len_hist, sizeof(hist));
+    else {
+        std::memset(hist, 0, sizeof(hist));
+        for (int gi = 0; gi < 3; gi++) {
+            const ReadGroup& g = R->g[gi];
+            if (!g.n) continue;
+            // conservative: every length the width group can hold is assumed present
+            int lo = gi == 0 ? 1 : (gi == 1 ? 33 : 65), hi = gi == 0 ? 32 : (gi == 1 ? 64 : 128);
+            for (int L = lo; L <= hi; L++) hist[L] = 1;
+        }
+    }
+    ResolveTable rt;
+    for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.n_refs[p] = 0; }
+    for (int32_t p = 0; p < n_pass; p++) {
+        if (!libs[p]) continue;
+        if (libs[p]->ctx->device != c->device) return fail(-1, "library lives on another device");
+        if (pol[p].mm < 0 || pol[p].mm > 3 || pol[p].trim5 < 0 || pol[p].trim5 > 31 || pol[p].trim3 < 0)
+            return fail(-1, "unsupported policy");
+        bool need[MIRGE_KMAX + 1] = {false};
+        needed_k(pol[p], hist, libs[p]->kmax, need);
+        for (int k = 1; k <= MIRGE_KMAX; k++)
+            if (need[k]) CHECK(mirge_lib_prepare(const_cast<mirge_lib*>(libs[p]), k));
+        rt.ref_start[p] = libs[p]->dref_start;
+        rt.n_refs[p] = (uint32_t)libs[p]->n_refs;
+    }
+    auto res = std::make_unique<mirge_result>();
+    res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
+    int rc = 0;
+    for (int gi = 0; gi < 3 && rc == 0; gi++) {
+        if (gi == 0) rc = cascade_group<1>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt);
+        else if (gi == 1) rc = cascade_group<2>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt);
+        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt);
+    }
+    if (rc) { mirge_result_destroy(res.release()); return rc; }
+    *out = res.release();
+    return 0;
+}
+
+template <typename T>
+static int fetch_field(mirge_ctx* c, const mirge_result* res, T* host_out, T* ResGroup::*field) {
+    if (!host_out || !res->n) return 0;
+    T* dfull = nullptr;
+    CHECK(dalloc(c, &dfull, (size_t)res->n));
+    for (int gi = 0; gi < 3; gi++) {
+        const ResGroup& g = res->g[gi];
+        const ReadGroup& rg = res->reads->g[gi];
+        if (!g.n) continue;
+        hipLaunchKernelGGL(k_scatter_out<T>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                           (const T*)(g.*field), g.n, rg.base, (const uint32_t*)rg.orig, dfull);
+    }
+    HIPOK(hipMemcpyAsync(host_out, dfull, (size_t)res->n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->release(dfull);
+    return 0;
+}
+
+extern "C" int mirge_result_fetch(mirge_ctx* c, const mirge_result* res, int8_t* pass_out, int32_t* ref_out,
+                                  int32_t* off_out, int8_t* mm_out) {
+    if (!c || !res) return fail(-1, "mirge_result_fetch: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    CHECK(fetch_field<int8_t>(c, res, pass_out, &ResGroup::pass));
+    CHECK(fetch_field<int32_t>(c, res, ref_out, &ResGroup::ref));
+    CHECK(fetch_field<int32_t>(c, res, off_out, &ResGroup::off));
+    CHECK(fetch_field<int8_t>(c, res, mm_out, &ResGroup::mm));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// count join
+// ------------------------------------------------------------------------------------------
+extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, int32_t exact_pass,
+                                int32_t iso_pass, int64_t n_mirna, int64_t* class_sums, int64_t* exact, int64_t* iso) {
+    if (!c || !U || !res || !class_sums || !exact || !iso || n_mirna < 0) return fail(-1, "mirge_count_join: bad argument");
+    if (U->n_samples < 1) return fail(-1, "read set has no count matrix (collapse it or mirge_reads_set_counts)");
+    if (res->n != U->n) return fail(-1, "result and read set differ in size");
+    HIPOK(hipSetDevice(c->device));
+    const int32_t S = U->n_samples, P = res->n_pass;
+    const size_t n_cls = (size_t)P * S, n_tab = (size_t)std::max<int64_t>(n_mirna, 1) * S;
+    unsigned long long* d = nullptr;
+    CHECK(dalloc(c, &d, n_cls + 2 * n_tab));
+    HIPOK(hipMemsetAsync(d, 0, (n_cls + 2 * n_tab) * 8, c->stream));
+    for (int gi = 0; gi < 3; gi++) {
+        const ResGroup& g = res->g[gi];
+        if (!g.n) continue;
+        LaunchScope ls(c, "k_join", g.n);
+        hipLaunchKernelGGL(k_join, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, g.pass, g.ref,
+                           U->g[gi].counts, g.n, S, P, exact_pass, iso_pass, d, d + n_cls, d + n_cls + n_tab);
+    }
+    HIPOK(hipMemcpyAsync(class_sums, d, n_cls * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_mirna) {
+        HIPOK(hipMemcpyAsync(exact, d + n_cls, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipMemcpyAsync(iso, d + n_cls + n_tab, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->drain();
+    c->release(d);
+    return 0;
+}
+
+extern "C" int mirge_count_join_host(mirge_ctx* c, const int8_t* pass, const int32_t* ref, const uint32_t* counts,
+                                     int64_t n, int32_t S, int32_t P, int32_t exact_pass, int32_t iso_pass,
+                                     int64_t n_mirna, int64_t* class_sums, int64_t* exact, int64_t* iso) {
+    if (!c || !class_sums || !exact || !iso || n < 0 || S < 1 || P < 1 || P > MIRGE_MAX_PASSES || n_mirna < 0 ||
+        (n > 0 && (!pass || !ref || !counts)))
+        return fail(-1, "mirge_count_join_host: bad argument");
+    if (n >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 rows");
+    HIPOK(hipSetDevice(c->device));
+    for (int64_t i = 0; i < n; i++) {
+        if (pass[i] >= P) return fail(-1, "pass index out of range");
+        if ((pass[i] == exact_pass || pass[i] == iso_pass) && (ref[i] < 0 || ref[i] >= n_mirna))
+            return fail(-1, "miRNA reference index out of range");
+    }
+    const size_t n_cls = (size_t)P * S, n_tab = (size_t)std::max<int64_t>(n_mirna, 1) * S;
+    unsigned long long* d = nullptr; int8_t* dp = nullptr; int32_t* dr = nullptr; uint32_t* dc = nullptr;
+    CHECK(dalloc(c, &d, n_cls + 2 * n_tab));
+    CHECK(dalloc(c, &dp, (size_t)std::max<int64_t>(n, 1)));
+    CHECK(dalloc(c, &dr, (size_t)std::max<int64_t>(n, 1)));
+    CHECK(dalloc(c, &dc, (size_t)std::max<int64_t>(n, 1) * S));
+    HIPOK(hipMemsetAsync(d, 0, (n_cls + 2 * n_tab) * 8, c->stream));
+    if (n) {
+        HIPOK(hipMemcpyAsync(dp, pass, (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipMemcpyAsync(dr, ref, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipMemcpyAsync(dc, counts, (size_t)n * S * 4, hipMemcpyHostToDevice, c->stream));
+        LaunchScope ls(c, "k_join", (double)n);
+        hipLaunchKernelGGL(k_join, dim3(grid_for(c, (size_t)n)), dim3(MIRGE_BLOCK), 0, c->stream, dp, dr, dc, (uint32_t)n,
+                           S, P, exact_pass, iso_pass, d, d + n_cls, d + n_cls + n_tab);
+    }
+    HIPOK(hipMemcpyAsync(class_sums, d, n_cls * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_mirna) {
+        HIPOK(hipMemcpyAsync(exact, d + n_cls, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipMemcpyAsync(iso, d + n_cls + n_tab, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->drain();
+    c->release(d); c->release(dp); c->release(dr); c->release(dc);
+    return 0;
+}

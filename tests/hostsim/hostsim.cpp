@@ -1,0 +1,94 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE ONLY, never linked into libmirge_native.so.
+//
+// This container has no GPU.  To debug the device arithmetic before spending GPU minutes, the
+// exact header the kernels are built from (mirge3.0_amd/csrc/mirge_core.hpp: packing, trimming,
+// window verification, pigeonhole probing) and the exact table builder (mirge_libbuild.hpp) are
+// compiled here with g++ and driven by a plain loop that does what k_pass does per thread.
+// tests/test_hostsim.py compares the outcome with the oracle.  It is not a product path and not
+// a fallback: the product fails loudly without the HIP library and a GPU.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../mirge3.0_amd/csrc/mirge_core.hpp"
+#include "../../mirge3.0_amd/csrc/mirge_libbuild.hpp"
+
+struct SimLib {
+    MirgeHostLib h;
+    std::vector<uint32_t> bucket[MIRGE_KMAX + 1], pos[MIRGE_KMAX + 1];
+    MirgeKTable tables[MIRGE_KMAX + 1];
+    MirgeLibView view() {
+        MirgeLibView v;
+        v.T = h.T.data(); v.inv = h.inv.data(); v.ref_start = h.ref_start.data(); v.tables = tables;
+        v.total = h.total; v.n_refs = (uint32_t)h.n_refs; v.kmax = h.kmax;
+        return v;
+    }
+};
+
+template <int W>
+static bool pack_read(const char* s, int L, MirgeRead<W>& r) {
+    for (int i = 0; i < W; i++) { r.w[i] = 0; r.nm[i] = 0; }
+    for (int p = 0; p < L; p++) {
+        int code = mirge_base_code(s[p]);
+        if (code < 0) r.nm[p >> 5] |= 1ull << (2 * (p & 31));
+        else r.w[p >> 5] |= (uint64_t)code << (2 * (p & 31));
+    }
+    r.len = L;
+    return true;
+}
+
+template <int W>
+static void sim_one(const char* s, int L, std::vector<SimLib>& libs, const std::vector<bool>& present,
+                    const MirgePolicy* pol, int n_pass, int8_t* o_pass, int32_t* o_ref, int32_t* o_off, int8_t* o_mm) {
+    *o_pass = -1; *o_ref = -1; *o_off = -1; *o_mm = -1;
+    for (int p = 0; p < n_pass; p++) {
+        if (!present[p]) continue;
+        MirgeRead<W> r;
+        pack_read<W>(s, L, r);
+        if (!mirge_effective_read<W>(r, pol[p])) continue;
+        // same table-on-demand rule as mirge_cascade_run
+        const int seed = pol[p].mode == 0 ? (r.len < pol[p].seedlen ? r.len : pol[p].seedlen) : r.len;
+        const int h = seed / (pol[p].mm + 1);
+        const int k = h < libs[p].h.kmax ? h : libs[p].h.kmax;
+        if (k >= 1 && !libs[p].tables[k].bucket) {
+            mirge_hostlib_table(libs[p].h, k, libs[p].bucket[k], libs[p].pos[k]);
+            libs[p].tables[k].bucket = libs[p].bucket[k].data();
+            libs[p].tables[k].pos = libs[p].pos[k].data();
+        }
+        uint64_t best;
+        MirgeLibView v = libs[p].view();
+        mirge_align_indexed<W>(v, pol[p], r, best);
+        if (best != MIRGE_NO_HIT) {
+            const uint32_t g = (uint32_t)best;
+            const std::vector<uint32_t>& rs = libs[p].h.ref_start;
+            uint32_t lo = 0, hi = (uint32_t)libs[p].h.n_refs;
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (rs[mid] <= g) lo = mid; else hi = mid; }
+            *o_pass = (int8_t)p; *o_ref = (int32_t)lo; *o_off = (int32_t)(g - rs[lo]); *o_mm = (int8_t)(best >> 32);
+            return;
+        }
+    }
+}
+
+extern "C" int hostsim_cascade(const char* reads, const int64_t* roff, int64_t n, const char* const* lib_seq,
+                               const int64_t* const* lib_off, const int64_t* lib_n, const MirgePolicy* pol,
+                               int32_t n_pass, int8_t* o_pass, int32_t* o_ref, int32_t* o_off, int8_t* o_mm) {
+    std::vector<SimLib> libs((size_t)n_pass);
+    std::vector<bool> present((size_t)n_pass, false);
+    for (int p = 0; p < n_pass; p++) {
+        for (int k = 0; k <= MIRGE_KMAX; k++) { libs[p].tables[k].bucket = nullptr; libs[p].tables[k].pos = nullptr; }
+        if (!lib_seq[p]) continue;
+        std::string err;
+        if (mirge_hostlib_build(libs[p].h, lib_seq[p], lib_off[p], lib_n[p], err)) return -1;
+        present[p] = true;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const char* s = reads + roff[i];
+        const int L = (int)(roff[i + 1] - roff[i]);
+        if (L > MIRGE_MAX_READ_LEN) return -6;
+        if (L <= 32) sim_one<1>(s, L, libs, present, pol, n_pass, o_pass + i, o_ref + i, o_off + i, o_mm + i);
+        else if (L <= 64) sim_one<2>(s, L, libs, present, pol, n_pass, o_pass + i, o_ref + i, o_off + i, o_mm + i);
+        else sim_one<4>(s, L, libs, present, pol, n_pass, o_pass + i, o_ref + i, o_off + i, o_mm + i);
+    }
+    return 0;
+}

@@ -1,0 +1,254 @@
+"""GPU parity tests: the HIP path, called through the C ABI (mirge3_amd._ffi), against the oracle
+on the same seeded inputs and against the golden vectors the reference produced.
+
+Bar: bit-exact.  Everything on this path is integer / index work; the only floating point is
+RPM (rounded to 4 decimals, summary.py:768) and it is compared as text against the reference's CSV.
+"""
+import csv
+import os
+from collections import Counter
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import CASES, GoldenCase, ORG, DB, PASS_COLS, oracle_libs_from
+import mirge3_amd  # noqa: F401
+from mirge3_amd import _ffi, synth
+from mirge3_amd.cascade import Cascade, PASSES, bwt_align
+from mirge3_amd.collapse import baking, collapse_samples
+from mirge3_amd.countjoin import summarize, summarize_device
+from mirge3_amd.seqio import FlatSeqs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _ffi.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ci_libs():
+    return synth.make_libraries(seed=77, scale="ci")
+
+
+@pytest.fixture(scope="module")
+def ci_cascade(ctx, ci_libs):
+    c = Cascade(ctx, ci_libs.libs)
+    yield c
+    c.close()
+
+
+def _assert_same(o, g):
+    for a, b, nm in zip(o, g, ("pass", "ref", "off", "mm")):
+        bad = np.nonzero(a.astype(np.int64) != b.astype(np.int64))[0]
+        assert bad.size == 0, (nm, bad[:5], a[bad[:5]], b[bad[:5]])
+
+
+# ---------------------------------------------------------------- golden vectors
+@pytest.mark.parametrize("name", CASES)
+def test_golden_cascade_and_join(ctx, name, tmp_path):
+    case = GoldenCase(name)
+    casc = Cascade(ctx, case.libs, spike_in=case.spike)
+    dr = _ffi.DeviceReads.pack(ctx, case.reads)
+    dr.set_counts(case.counts.astype(np.uint32))
+    res = casc.run(dr)
+    ps, ref, off, mm = res.fetch()
+    exp = case.expected_annotation()
+    for i, s in enumerate(case.seqs):
+        p = int(ps[i])
+        nm = case.lib_of_pass(p).names[int(ref[i])] if p >= 0 else ""
+        assert (p, nm) == exp[s], s
+    summarize_device(ctx, dr, res, case.libs["mirna"], case.merges, case.samples, case.sample_read_counts,
+                     case.trimmed, case.trimmed_unique, 0.1, case.spike, workDir=tmp_path)
+    for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+        assert (tmp_path / f).read_text() == case.text(f), f
+    # the packed reads survive a round trip
+    assert dr.unpack().to_list() == case.seqs
+    res.close(); dr.close(); casc.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_dropin_signatures(name, tmp_path):
+    """bwt_align / summarize with the reference's signatures on the golden library directory:
+    mapped.csv, unmapped.csv and the three tables must equal what the reference wrote."""
+    import pandas as pd
+    case = GoldenCase(name)
+    args = SimpleNamespace(threads=1, bowtie_path=None, bowtieVersion="True", quiet=True, bam_out=False,
+                           tRNA_frag=False, spikeIn=case.spike, organism_name=ORG, libraries_path=case.libdir,
+                           crThreshold="0.1", gff_out=False, isoform_entropy=False, AtoI=False)
+    df = pd.DataFrame(case.counts, columns=case.samples, index=pd.Index(case.seqs, name="Sequence"))
+    df = df.assign(**dict.fromkeys(PASS_COLS, ''))
+    df = df.assign(annotFlag=0).reindex(columns=['annotFlag'] + PASS_COLS + case.samples)
+    out = bwt_align(args, df, str(tmp_path), DB)
+    mapped, unmapped = out[out.annotFlag.eq(1)], out[out.annotFlag.eq(0)]
+    mapped.to_csv(tmp_path / "mapped.csv")
+    unmapped.to_csv(tmp_path / "unmapped.csv")
+    assert (tmp_path / "mapped.csv").read_text() == case.text("mapped.csv")
+    assert (tmp_path / "unmapped.csv").read_text() == case.text("unmapped.csv")
+    summarize(args, str(tmp_path), DB, case.samples, mapped, case.sample_read_counts, case.trimmed,
+              case.trimmed_unique)
+    for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+        assert (tmp_path / f).read_text() == case.text(f), f
+
+
+# ---------------------------------------------------------------- oracle on seeded inputs
+def test_cascade_vs_oracle_ci_scale(ctx, ci_libs, ci_cascade):
+    reads = synth.make_reads(ci_libs, 60000, seed=5, n_frac=0.01)
+    rng = np.random.default_rng(3)
+    extra = []  # W=2 / W=4 width groups incl. the 128-nt maximum
+    for key in ("mrna", "ncrna_others", "rrna"):
+        lib = ci_libs.libs[key]
+        for L in list(rng.integers(51, 129, size=80)) + [64, 65, 128]:
+            s = lib.seqs.get(int(rng.integers(0, len(lib))))
+            if len(s) <= L:
+                continue
+            a = int(rng.integers(0, len(s) - L))
+            x = list(s[a:a + int(L)])
+            for _ in range(int(rng.integers(0, 3))):
+                q = int(rng.integers(0, len(x)))
+                x[q] = "ACGT"[("ACGT".index(x[q]) + 1) % 4] if x[q] in "ACGT" else "A"
+            extra.append("".join(x))
+    allr = FlatSeqs.from_list(reads.to_list() + extra + ["T" * 16, "T" * 40, "A" * 16, "ACGTN" * 4])
+    g = ci_cascade.annotate(allr)
+    o = oracle.cascade(allr.data, allr.offsets, oracle_libs_from(ci_libs.libs), n_pass=9, indexed=True)
+    _assert_same(o, g)
+    assert (g[0] >= 0).mean() > 0.5
+
+
+def test_cascade_vs_bruteforce_oracle(ctx, ci_libs, ci_cascade):
+    reads = synth.make_reads(ci_libs, 3000, seed=17, n_frac=0.03)
+    g = ci_cascade.annotate(reads)
+    o = oracle.cascade(reads.data, reads.offsets, oracle_libs_from(ci_libs.libs), n_pass=9, indexed=False)
+    _assert_same(o, g)
+
+
+def test_collapse_vs_oracle(ctx, ci_libs):
+    reads = synth.make_reads(ci_libs, 200000, seed=8, n_frac=0.01, pool=20000)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq = raw.collapse()
+    counts, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    o_first, o_cnt, o_inv = oracle.collapse(reads.data, reads.offsets)
+    assert len(uniq) == len(o_first)
+    order = np.argsort(first, kind="stable")
+    assert np.array_equal(first[order], o_first)
+    assert np.array_equal(counts[order, 0].astype(np.int64), o_cnt)
+    allr = reads.to_list()
+    assert [seqs[i] for i in order] == [allr[i] for i in o_first]
+    assert int(counts.sum()) == len(reads)
+    raw.close(); uniq.close()
+
+
+def test_collapse_multi_sample(ctx, ci_libs):
+    samples = [synth.make_reads(ci_libs, 30000, seed=40 + s, pool=4000) for s in range(3)]
+    uniq = collapse_samples(ctx, samples)
+    counts, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    exp = [Counter(s.to_list()) for s in samples]
+    union = set().union(*[set(c) for c in exp])
+    assert set(seqs) == union and len(seqs) == len(union)
+    for i, s in enumerate(seqs):
+        assert [int(x) for x in counts[i]] == [c.get(s, 0) for c in exp]
+    uniq.close()
+
+
+def test_edge_cases(ctx, ci_libs, ci_cascade):
+    # empty set
+    empty = FlatSeqs(np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    dr = _ffi.DeviceReads.pack(ctx, empty)
+    u = dr.collapse()
+    assert len(u) == 0
+    res = ci_cascade.run(u)
+    assert res.fetch()[0].shape == (0,)
+    cls, ex, iso = _ffi.count_join(ctx, u, res, 0, 8, len(ci_libs.libs["mirna"]))
+    assert cls.sum() == 0 and ex.sum() == 0
+    res.close(); u.close(); dr.close()
+    # nothing annotated
+    rnd = FlatSeqs.from_list(["ACGTTGCAAGCTTGCAAGGC"[::-1] * 1, "GGGGGGGGGGGGGGGGGGGGGGGG"])
+    ps = ci_cascade.annotate(rnd)[0]
+    o = oracle.cascade(rnd.data, rnd.offsets, oracle_libs_from(ci_libs.libs), n_pass=9)
+    assert np.array_equal(ps.astype(np.int32), o[0])
+    # loud failures
+    with pytest.raises(RuntimeError, match="limit is 128"):
+        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["A" * 129]))
+    with pytest.raises(RuntimeError, match="character other than"):
+        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGTRYACGTACGTACGT"]))
+    # lower-case and U are accepted as their upper-case / T
+    a = ci_cascade.annotate(FlatSeqs.from_list([ci_libs.libs["mirna"].seqs.get(3).lower().replace("t", "u")]))
+    b = ci_cascade.annotate(FlatSeqs.from_list([ci_libs.libs["mirna"].seqs.get(3)]))
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[0][0] == 0
+
+
+def test_baking_dropin(ctx, ci_libs, tmp_path):
+    """FASTQ files in, the reference's DataFrame schema + counters out (digest.py:237-261,212-217)."""
+    names, files, exp = [], [], []
+    for s in range(2):
+        reads = synth.make_reads(ci_libs, 5000, seed=60 + s, pool=700).to_list() + ["ACGTACGT", "ACGTACGTACGTACG"]
+        p = tmp_path / f"S{s + 1}.fastq"
+        with open(p, "w") as fh:
+            for i, r in enumerate(reads):
+                fh.write(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n")
+        names.append(f"S{s + 1}"); files.append(str(p)); exp.append(reads)
+    args = SimpleNamespace(quiet=True, minimum_length=16, adapters=None, front=None, uniq_mol_ids=None)
+    df, src, trimmed, uniq = baking(args, files, names, str(tmp_path), ctx=ctx)
+    cnt = [Counter(r for r in e if len(r) >= 16) for e in exp]
+    union = sorted(set(cnt[0]) | set(cnt[1]))
+    assert list(df.index) == union and df.index.name == "Sequence"
+    assert list(df.columns) == ["annotFlag"] + PASS_COLS + names
+    for s, nm in enumerate(names):
+        assert df[nm].tolist() == [cnt[s].get(q, 0) for q in union]
+        assert src[nm] == len(exp[s]) and trimmed[nm] == sum(cnt[s].values()) and uniq[nm] == len(cnt[s])
+    assert (df.annotFlag == 0).all() and (df[PASS_COLS] == "").all().all()
+    # single sample keeps first-appearance order
+    df1, *_ = baking(args, files[:1], names[:1], str(tmp_path), ctx=ctx)
+    seen = list(dict.fromkeys(r for r in exp[0] if len(r) >= 16))
+    assert list(df1.index) == seen
+    with pytest.raises(NotImplementedError):
+        baking(SimpleNamespace(quiet=True, minimum_length=16, adapters=["x"], front=None, uniq_mol_ids=None),
+               files, names, str(tmp_path), ctx=ctx)
+
+
+# ---------------------------------------------------------------- size-independent properties
+def test_properties_at_scale(ctx):
+    """BASELINE configs C2/C3 shape (human-sized small libraries, millions of reads): invariants
+    that need no oracle, plus the indexed oracle on a random sample of the collapsed reads."""
+    sl = synth.make_libraries(seed=20260101, scale="small")
+    casc = Cascade(ctx, sl.libs)
+    reads = synth.make_reads_chunked(sl, 3_000_000, seed=11)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq = raw.collapse()
+    counts, first = uniq.counts()
+    assert int(counts.sum()) == len(reads)                      # collapse conserves reads
+    res = casc.run(uniq)
+    ps, ref, off, mm = res.fetch()
+    cls, ex, iso = _ffi.count_join(ctx, uniq, res, 0, 8, len(sl.libs["mirna"]))
+    c = counts[:, 0].astype(np.int64)
+    for p in range(9):                                           # a checksum of checksums
+        assert cls[p, 0] == c[ps == p].sum()
+    assert cls.sum() + c[ps < 0].sum() == len(reads)
+    assert ex.sum() == cls[0, 0] and iso.sum() == cls[8, 0]
+    useq = uniq.unpack()
+    lens = useq.lengths
+    assert (lens[ps == 0] < 26).all() and (lens[ps == 1] > 25).all()   # subset rules
+    # idempotence / order independence: a shuffled subset gets the same per-read answers
+    rng = np.random.default_rng(1)
+    pick = rng.permutation(len(uniq))[:200000]
+    sub = useq.take(pick)
+    g = casc.annotate(sub)
+    for a, b in zip(g, (ps, ref, off, mm)):
+        assert np.array_equal(a, b[pick])
+    # and the oracle agrees on a sample of it
+    o = oracle.cascade(sub.data[: sub.offsets[20000]], sub.offsets[:20001], oracle_libs_from(sl.libs), n_pass=9,
+                       indexed=True)
+    for a, b in zip(o, g):
+        assert np.array_equal(a.astype(np.int64), b[:20000].astype(np.int64))
+    # pass-0-only run (BASELINE config C2) equals the pass-0 part of the full cascade
+    c2 = Cascade(ctx, {"mirna": sl.libs["mirna"]}, n_pass=1)
+    p0 = c2.annotate(sub)
+    assert np.array_equal(p0[0] == 0, g[0] == 0) and np.array_equal(p0[1][p0[0] == 0], g[1][g[0] == 0])
+    res.close(); uniq.close(); raw.close(); casc.close(); c2.close()

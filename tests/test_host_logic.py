@@ -1,0 +1,119 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, the
+product fails loudly without a GPU, the count-join tail reproduces the reference's CSVs from
+per-miRNA tables, FASTQ parsing, and the oracle's two matchers agree."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import CASES, GoldenCase, PASS_COLS, oracle_libs_from
+import mirge3_amd  # noqa: F401
+from mirge3_amd import _ffi, synth
+from mirge3_amd.cascade import PASSES, policies
+from mirge3_amd.collapse import read_fastq_sequences, filter_min_length
+from mirge3_amd.countjoin import finish_tables
+from mirge3_amd.seqio import FlatSeqs
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_abi_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    hdr = open(os.path.join(ROOT, "include", "mirge_native.h")).read()
+    declared = set(re.findall(r"\b(mirge_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    lib = C.CDLL(_ffi.SO_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_policy_tables_agree_with_oracle():
+    # the product's table and the oracle's are written independently from manifoldAlign.py:84-85
+    for p, (col, key, args, kw) in enumerate(PASSES):
+        ocol, okey, oargs, okw = oracle.PASSES[p]
+        assert (col, key) == (ocol, okey)
+        assert args.replace("--threads", "").split() == oargs.split()
+        for f in ("mode", "mm", "seedlen", "maxtotal", "trim5", "trim3", "ttail", "len_lt", "len_gt"):
+            assert kw.get(f, 0) == okw.get(f, 0), (p, f)
+    assert C.sizeof(_ffi.MirgePolicy) == 40 and len(policies(10)) == 10
+
+
+@pytest.mark.skipif(_ffi.load().mirge_device_count() > 0, reason="GPU present")
+def test_product_fails_loudly_without_gpu():
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        _ffi.Context(0)
+    from mirge3_amd.cascade import Cascade
+    sl = synth.make_libraries(scale="tiny")
+    with pytest.raises(RuntimeError):
+        Cascade(_ffi.Context(0), sl.libs)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_count_join_tail_reproduces_reference_csvs(name, tmp_path):
+    """finish_tables (the pandas tail behind mirge_count_join) fed with sums computed in numpy
+    from the reference's mapped.csv must write the reference's three CSVs byte for byte."""
+    import csv
+    case = GoldenCase(name)
+    exp = case.expected_annotation()
+    mir = case.libs["mirna"]
+    lut = {}
+    for i, nm in enumerate(mir.names):
+        lut.setdefault(nm, i)
+    S = len(case.samples)
+    cls = np.zeros((case.n_pass, S), dtype=np.int64)
+    ex = np.zeros((len(mir), S), dtype=np.int64)
+    iso = np.zeros((len(mir), S), dtype=np.int64)
+    for s, row in zip(case.seqs, case.counts):
+        p, nm = exp[s]
+        if p < 0:
+            continue
+        cls[p] += row
+        if p == 0:
+            ex[lut[nm]] += row
+        if p == 8:
+            iso[lut[nm]] += row
+    finish_tables(cls, ex, iso, mir, case.merges, case.samples, case.sample_read_counts, case.trimmed,
+                  case.trimmed_unique, 0.1, case.spike, workDir=tmp_path)
+    for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+        assert (tmp_path / f).read_text() == case.text(f), f
+
+
+def test_fastq_parsing(tmp_path):
+    p = tmp_path / "x.fastq"
+    p.write_text("@r1\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\n@r2\nACGT\n+\nIIII\n@r3\nTTTTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n")
+    fs = read_fastq_sequences(str(p))
+    assert fs.to_list() == ["ACGTACGTACGTACGTAC", "ACGT", "TTTTACGTACGTACGTACGT"]
+    assert filter_min_length(fs, 16).to_list() == ["ACGTACGTACGTACGTAC", "TTTTACGTACGTACGTACGT"]
+    import gzip
+    with gzip.open(tmp_path / "y.fastq.gz", "wb") as fh:
+        fh.write(p.read_bytes())
+    assert read_fastq_sequences(str(tmp_path / "y.fastq.gz")).to_list() == fs.to_list()
+    (tmp_path / "e.fastq").write_text("")
+    assert len(read_fastq_sequences(str(tmp_path / "e.fastq"))) == 0
+
+
+def test_oracle_bruteforce_vs_indexed_ci_scale():
+    sl = synth.make_libraries(seed=21, scale="ci")
+    reads = synth.make_reads(sl, 4000, seed=2, n_frac=0.02)
+    libs = oracle_libs_from(sl.libs)
+    a = oracle.cascade(reads.data, reads.offsets, libs, n_pass=9, indexed=False)
+    b = oracle.cascade(reads.data, reads.offsets, libs, n_pass=9, indexed=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    # planted truth: most reads drawn from a library are annotated
+    assert (a[0] >= 0).mean() > 0.8
+
+
+def test_synthetic_generator_is_seeded():
+    a = synth.make_libraries(seed=3, scale="tiny")
+    b = synth.make_libraries(seed=3, scale="tiny")
+    for k in a.libs:
+        assert np.array_equal(a.libs[k].seqs.data, b.libs[k].seqs.data)
+    ra = synth.make_reads(a, 500, seed=4)
+    rb = synth.make_reads(b, 500, seed=4)
+    assert np.array_equal(ra.data, rb.data) and np.array_equal(ra.offsets, rb.offsets)
+    assert ra.lengths.min() >= 16 and len(set(ra.lengths.tolist())) > 3
