@@ -520,7 +520,7 @@ static int collapse_group(mirge_ctx* c, const ReadGroup& in, ReadGroup& out, con
     HIPOK(hipMemsetAsync(cnt, 0, (size_t)tsize * S * 4, c->stream));
     GroupView<W> v = view_of<W>(in);
     {
-        LaunchScope ls(c, "k_collapse_insert", in.n);
+        LaunchScope ls(c, W == 1 ? "k_collapse_insert.w1" : (W == 2 ? "k_collapse_insert.w2" : "k_collapse_insert.w4"), in.n);
         hipLaunchKernelGGL(k_collapse_insert<W>, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->stream,
                            v, rep, firstj, cnt, slot_of, tsize - 1, dsample, in.orig, in.base, S);
     }
@@ -542,7 +542,7 @@ static int collapse_group(mirge_ctx* c, const ReadGroup& in, ReadGroup& out, con
     CHECK(dalloc(c, &out.counts, (size_t)U * S));
     CHECK(dalloc(c, &out.first, (size_t)U));
     {
-        LaunchScope ls(c, "k_collapse_scatter", in.n);
+        LaunchScope ls(c, W == 1 ? "k_collapse_scatter.w1" : (W == 2 ? "k_collapse_scatter.w2" : "k_collapse_scatter.w4"), in.n);
         hipLaunchKernelGGL(k_collapse_scatter<W>, dim3(nb), dim3(MIRGE_BLOCK), 0, c->stream, v, slot_of, firstj, cnt,
                            blocksum, dU, in.orig, in.base, S, out.seq, out.len, out.nmask, out.counts, out.first);
     }
@@ -679,45 +679,54 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     CHECK(dalloc(c, &out.mm, n));
     CHECK(dalloc(c, &out.ref, n));
     CHECK(dalloc(c, &out.off, n));
-    uint32_t *actA = nullptr, *actB = nullptr, *counters = nullptr;
-    CHECK(dalloc(c, &actA, n));
-    CHECK(dalloc(c, &actB, n));
-    CHECK(dalloc(c, &counters, MIRGE_MAX_PASSES + 2));
+    // every workgroup keeps its own survivor segment through all passes: no global cursor
+    const uint32_t grid = (uint32_t)grid_for(c, n);
+    uint32_t cap = (n + grid - 1) / grid;
+    cap = (cap + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
+    uint32_t *actA = nullptr, *actB = nullptr, *seg_n = nullptr;
+    CHECK(dalloc(c, &actA, (size_t)grid * cap));
+    CHECK(dalloc(c, &actB, (size_t)grid * cap));
+    CHECK(dalloc(c, &seg_n, (size_t)grid * (MIRGE_MAX_PASSES + 1)));
     HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->stream));
     HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->stream));
-    HIPOK(hipMemsetAsync(counters, 0, (MIRGE_MAX_PASSES + 2) * 4, c->stream));
     GroupView<W> v = view_of<W>(rg);
     const uint32_t* act_in = nullptr;
     uint32_t* act_out = actA;
     int stage = 0;
-    static const char* kname[MIRGE_MAX_PASSES] = {
-        "k_pass[0]", "k_pass[1]", "k_pass[2]", "k_pass[3]", "k_pass[4]", "k_pass[5]", "k_pass[6]", "k_pass[7]",
-        "k_pass[8]", "k_pass[9]", "k_pass[10]", "k_pass[11]", "k_pass[12]", "k_pass[13]", "k_pass[14]", "k_pass[15]"};
-    std::vector<std::pair<int, int>> stage_of_pass;  // (rec index, counter index) for unit accounting
+    char name[32];
+    std::vector<std::pair<int, int>> stage_of_pass;  // (profile record, stage) for unit accounting
     for (int32_t p = 0; p < n_pass; p++) {
         if (!libs[p]) continue;
         MirgePolicy mp;
         std::memcpy(&mp, &pol[p], sizeof(mp));
         {
-            LaunchScope ls(c, kname[p], 0.0);
+            std::snprintf(name, sizeof(name), "k_pass[%d].w%d", (int)p, W);
+            LaunchScope ls(c, name, 0.0);
             if (ls.rec >= 0) stage_of_pass.emplace_back(ls.rec, stage);
-            hipLaunchKernelGGL(k_pass<W>, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, libs[p]->view(), mp, v,
-                               act_in, counters + stage, act_out, counters + stage + 1, p, out.pass, out.pos, out.mm);
+            hipLaunchKernelGGL(k_pass<W>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, libs[p]->view(), mp, v, act_in,
+                               seg_n + (size_t)grid * (stage > 0 ? stage - 1 : 0), act_out, seg_n + (size_t)grid * stage,
+                               cap, p, out.pass, out.pos, out.mm);
         }
         act_in = act_out;
         act_out = (act_out == actA) ? actB : actA;
         stage++;
     }
     {
-        LaunchScope ls(c, "k_resolve", n);
+        std::snprintf(name, sizeof(name), "k_resolve.w%d", W);
+        LaunchScope ls(c, name, n);
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, rt, out.pass, out.pos, n, out.ref, out.off);
     }
-    if (c->profiling && !stage_of_pass.empty()) {  // units of each pass = reads it was handed
-        HIPOK(hipMemcpyAsync(c->pinned, counters, (MIRGE_MAX_PASSES + 2) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->profiling && stage > 0) {  // units of a pass = reads it was handed = survivors of the stage before
+        std::vector<uint32_t> h((size_t)grid * stage);
+        HIPOK(hipMemcpyAsync(h.data(), seg_n, h.size() * 4, hipMemcpyDeviceToHost, c->stream));
         HIPOK(hipStreamSynchronize(c->stream));
-        for (auto& sp : stage_of_pass) c->recs[sp.first].units += sp.second == 0 ? (double)n : (double)c->pinned[sp.second];
+        for (auto& sp : stage_of_pass) {
+            double u = n;
+            if (sp.second > 0) { u = 0; for (uint32_t b = 0; b < grid; b++) u += h[(size_t)grid * (sp.second - 1) + b]; }
+            c->recs[sp.first].units += u;
+        }
     }
-    c->release(actA); c->release(actB); c->release(counters);
+    c->release(actA); c->release(actB); c->release(seg_n);
     return 0;
 }
 
