@@ -255,6 +255,98 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// align_hybrid: the device form of mirge_align_indexed (same probes, same verification, same
+// minimum) with the candidate lists balanced over the wave.
+//   A probe's bucket holds from 0 to thousands of candidate windows (a 16-nt read under -v 2 is
+//   probed with 4-mers: ~220 candidates per probe in a 57 kb library, while a 28-nt read sees ~1).
+//   Lane-serial evaluation makes the whole wave wait for its unluckiest lane and walks each list
+//   as a chain of dependent loads.  Here a lane verifies only short lists (<= MIRGE_LIGHT) itself;
+//   longer lists are taken one at a time by the whole wave: the owner's read is broadcast with
+//   v_readlane, the 64 lanes stride through the bucket (coalesced pos[] loads, 64 windows
+//   verified per step) and a 6-step xor-shuffle min hands the best candidate back to the owner.
+//   All 64 lanes of the wave must call this together (inactive lanes pass active = false).
+// ------------------------------------------------------------------------------------------
+#define MIRGE_LIGHT 4
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int W>
+__device__ __forceinline__ uint64_t eval_candidate(const MirgeLibView& lib, const MirgePolicy& pol,
+                                                   const MirgeRead<W>& r, uint32_t pz, int a) {
+    if (pz < (uint32_t)a) return MIRGE_NO_HIT;
+    const uint64_t g = (uint64_t)pz - (uint64_t)a;
+    const int m = mirge_window_mm<W>(lib.T, g, r, pol);
+    if (m < 0) return MIRGE_NO_HIT;
+    if (mirge_window_invalid(lib.inv, g, r.len)) return MIRGE_NO_HIT;
+    return ((uint64_t)m << 32) | g;
+}
+
+template <int W>
+__device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol,
+                                             const MirgeRead<W>& r, bool active, uint64_t& best) {
+    best = MIRGE_NO_HIT;
+    const int lane = threadIdx.x & 63;
+    const int L = r.len;
+    const int seed = pol.mode == 0 ? (L < pol.seedlen ? L : pol.seedlen) : L;
+    const int nseg = pol.mm + 1;  // wave-uniform
+    const int h = seed / nseg;
+    const int k = h < lib.kmax ? h : lib.kmax;
+    if (k < 1) active = false;
+    MirgeKTable tb;
+    tb.bucket = nullptr; tb.pos = nullptr;
+    if (active) tb = lib.tables[k];
+    for (int sg = 0; sg < nseg; sg++) {
+        const int a = sg * h;
+        uint32_t lo = 0, hi = 0;
+        if (active && !mirge_extract<W>(r.nm, a, k)) {  // an N inside the probe: cannot be exact
+            const uint64_t key = mirge_extract<W>(r.w, a, k);
+            lo = tb.bucket[key];
+            hi = tb.bucket[key + 1];
+        }
+        const bool heavy = (hi - lo) > MIRGE_LIGHT;
+        if (!heavy) {
+            for (uint32_t c = lo; c < hi; c++) {
+                const uint64_t cand = eval_candidate<W>(lib, pol, r, tb.pos[c], a);
+                if (cand < best) best = cand;
+            }
+        }
+        unsigned long long hb = __ballot(heavy);
+        while (hb) {
+            const int src = __ffsll(hb) - 1;
+            hb &= hb - 1;
+            MirgeRead<W> rr;
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                rr.w[w] = readlane_u64(r.w[w], src);
+                rr.nm[w] = readlane_u64(r.nm[w], src);
+            }
+            rr.len = __builtin_amdgcn_readlane(r.len, src);
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)lo, src);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, src);
+            const int ba = __builtin_amdgcn_readlane(a, src);
+            const uint32_t* bpos = (const uint32_t*)readlane_u64((uint64_t)tb.pos, src);
+            uint64_t lbest = MIRGE_NO_HIT;
+            for (uint32_t c = blo + lane; c < bhi; c += 64) {
+                const uint64_t cand = eval_candidate<W>(lib, pol, rr, bpos[c], ba);
+                if (cand < lbest) lbest = cand;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint64_t o = __shfl_xor(lbest, d, 64);
+                if (o < lbest) lbest = o;
+            }
+            if (lane == src && lbest < best) best = lbest;
+        }
+        // a 0-mismatch window is in segment 0's bucket: nothing later can beat it
+        if (sg == 0 && (best >> 32) == 0) active = false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_pass: one cascade pass over the still-unannotated reads of one width group.
 //   Every workgroup owns a fixed segment of `cap` slots.  First pass (act_in == nullptr):
 //   workgroup b takes the contiguous reads [b*cap, (b+1)*cap).  Later passes: workgroup b takes
@@ -287,19 +379,26 @@ k_pass(MirgeLibView lib, MirgePolicy pol, GroupView<W> g, const uint32_t* __rest
         uint32_t idx = 0;
         if (valid) {
             idx = act_in ? act_in[seg + t] : (uint32_t)seg + t;
-            MirgeRead<W> r;
-            load_read<W>(g, idx, r);
             survivor = true;
-            if (mirge_effective_read<W>(r, pol)) {
-                uint64_t best;
-                mirge_align_indexed<W>(lib, pol, r, best);
-                if (best != MIRGE_NO_HIT) {
-                    res_pass[idx] = (int8_t)pass_id;
-                    res_pos[idx] = (uint32_t)best;
-                    res_mm[idx] = (int8_t)(best >> 32);
-                    survivor = false;
-                }
-            }
+        }
+        // the wave aligns its 64 reads together (align_hybrid balances the candidate lists)
+        MirgeRead<W> r2;
+        bool elig = false;
+        if (valid) {
+            load_read<W>(g, idx, r2);
+            elig = mirge_effective_read<W>(r2, pol);
+        } else {
+#pragma unroll
+            for (int w = 0; w < W; w++) { r2.w[w] = 0; r2.nm[w] = 0; }
+            r2.len = 0;
+        }
+        uint64_t best;
+        align_hybrid<W>(lib, pol, r2, elig, best);
+        if (elig && best != MIRGE_NO_HIT) {
+            res_pass[idx] = (int8_t)pass_id;
+            res_pos[idx] = (uint32_t)best;
+            res_mm[idx] = (int8_t)(best >> 32);
+            survivor = false;
         }
         const unsigned long long bal = __ballot(survivor);
         if (bal) {
