@@ -263,7 +263,8 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
 //   as a chain of dependent loads.  Here a lane verifies only short lists (<= MIRGE_LIGHT) itself;
 //   longer lists are taken one at a time by the whole wave: the owner's read is broadcast with
 //   v_readlane, the 64 lanes stride through the bucket (coalesced pos[] loads, 64 windows
-//   verified per step) and a 6-step xor-shuffle min hands the best candidate back to the owner.
+//   verified per step); the few lanes that found a valid window are read back with v_readlane and
+//   their minimum goes to the owner.
 //   All 64 lanes of the wave must call this together (inactive lanes pass active = false).
 // ------------------------------------------------------------------------------------------
 #define MIRGE_LIGHT 4
@@ -334,12 +335,17 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
                 const uint64_t cand = eval_candidate<W>(lib, pol, rr, bpos[c], ba);
                 if (cand < lbest) lbest = cand;
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const uint64_t o = __shfl_xor(lbest, d, 64);
-                if (o < lbest) lbest = o;
+            // almost every candidate fails verification: instead of a shuffle tree, visit the few
+            // lanes that hold a hit (v_readlane -> scalar min)
+            unsigned long long hits = __ballot(lbest != MIRGE_NO_HIT);
+            uint64_t tbest = MIRGE_NO_HIT;
+            while (hits) {
+                const int hl = __ffsll(hits) - 1;
+                hits &= hits - 1;
+                const uint64_t v = readlane_u64(lbest, hl);
+                if (v < tbest) tbest = v;
             }
-            if (lane == src && lbest < best) best = lbest;
+            if (lane == src && tbest < best) best = tbest;
         }
         // a 0-mismatch window is in segment 0's bucket: nothing later can beat it
         if (sg == 0 && (best >> 32) == 0) active = false;
@@ -358,7 +364,9 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
 //   workgroup, one ds_add per wave (ballot + prefix popcount).  A single global cursor was
 //   measured at ~0.35 ms per pass for 2 M reads (33 k same-address returning atomics).
 // ------------------------------------------------------------------------------------------
-template <int W>
+// SLOT is the pass index and only names the symbol (k_pass<1,6> ...), so that rocprofv3's per-kernel
+// statistics separate the passes; the policy itself stays a run-time argument.
+template <int W, int SLOT>
 __global__ void __launch_bounds__(MIRGE_BLOCK)
 k_pass(MirgeLibView lib, MirgePolicy pol, GroupView<W> g, const uint32_t* __restrict__ act_in,
        const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,

@@ -703,9 +703,25 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
             std::snprintf(name, sizeof(name), "k_pass[%d].w%d", (int)p, W);
             LaunchScope ls(c, name, 0.0);
             if (ls.rec >= 0) stage_of_pass.emplace_back(ls.rec, stage);
-            hipLaunchKernelGGL(k_pass<W>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, libs[p]->view(), mp, v, act_in,
-                               seg_n + (size_t)grid * (stage > 0 ? stage - 1 : 0), act_out, seg_n + (size_t)grid * stage,
-                               cap, p, out.pass, out.pos, out.mm);
+            const uint32_t* sn_in = seg_n + (size_t)grid * (stage > 0 ? stage - 1 : 0);
+            uint32_t* sn_out = seg_n + (size_t)grid * stage;
+#define MIRGE_LAUNCH_PASS(SLOT)                                                                                   \
+    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, libs[p]->view(), mp, v, act_in, \
+                       sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm)
+            switch (p) {
+                case 0: MIRGE_LAUNCH_PASS(0); break;
+                case 1: MIRGE_LAUNCH_PASS(1); break;
+                case 2: MIRGE_LAUNCH_PASS(2); break;
+                case 3: MIRGE_LAUNCH_PASS(3); break;
+                case 4: MIRGE_LAUNCH_PASS(4); break;
+                case 5: MIRGE_LAUNCH_PASS(5); break;
+                case 6: MIRGE_LAUNCH_PASS(6); break;
+                case 7: MIRGE_LAUNCH_PASS(7); break;
+                case 8: MIRGE_LAUNCH_PASS(8); break;
+                case 9: MIRGE_LAUNCH_PASS(9); break;
+                default: MIRGE_LAUNCH_PASS(15); break;
+            }
+#undef MIRGE_LAUNCH_PASS
         }
         act_in = act_out;
         act_out = (act_out == actA) ? actB : actA;
