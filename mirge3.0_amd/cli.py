@@ -1,0 +1,115 @@
+"""Command line for the hot path only -- the part of ``mirge/__main__.py:24-173`` that is in scope.
+
+  python -m mirge3_amd.cli -s S1.fastq,S2.fastq -lib /path/Libs -on human -db miRBase -o out
+
+Same flag names as the reference (``mirge/libs/parse.py``) for what is implemented; flags of
+subsystems that are out of scope (novel miRNA, GFF, BAM, tRF, A-to-I, DESeq2, miREC, adapter
+trimming) are rejected instead of being ignored.  Writes the reference's files: ``run.log``,
+``mapped.csv``, ``unmapped.csv``, ``miR.Counts.csv``, ``miR.RPM.csv``, ``annotation.report.csv/html``.
+
+One process: all samples on one GPU, byte-compatible outputs.  Under ``torch.distributed.run`` with N
+ranks: samples are sharded one per GPU (multigpu.py), rank 0 writes the three tables; the per-read
+``mapped.csv``/``unmapped.csv`` are then written per sample (``mapped.<sample>.csv``) by the rank that
+owns it, because the cross-sample outer join of sequences is the only step that would need an
+exchange.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+DB_KEYS = {"mirbase": "miRBase", "mirgenedb": "MirGeneDB"}  # __main__.py:36
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(prog="miRge3.0-amd", description="miRge3.0 hot path on MI355X")
+    ap.add_argument("-s", "--samples", required=True, help="comma separated FASTQ/FASTA files (already trimmed)")
+    ap.add_argument("-o", "--outDir", default=None)
+    ap.add_argument("-dn", "--outDirName", dest="outDirName", default=None)
+    ap.add_argument("-lib", "--libraries-path", dest="libraries_path", required=True)
+    ap.add_argument("-on", "--organism-name", dest="organism_name", required=True)
+    ap.add_argument("-db", "--mir-DB", dest="mir_DB", default="miRBase")
+    ap.add_argument("-cr", "--crThreshold", dest="crThreshold", default="0.1")
+    ap.add_argument("-m", "--minimum-length", dest="minimum_length", type=int, default=16)
+    ap.add_argument("-spk", "--spikeIn", dest="spikeIn", action="store_true")
+    ap.add_argument("-q", "--quiet", action="store_true")
+    ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted, unused (GPU path)")
+    ap.add_argument("--device", type=int, default=None)
+    for flag in ("-a", "-g", "-umi", "-nmir", "-gff", "-bam", "-trf", "-ai", "-ie", "-mEC", "-dex"):
+        ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
+                        help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    for k, v in vars(args).items():
+        if k.startswith("oos_") and v is not None:
+            ap.error(f"-{k[4:]} belongs to a miRge3.0 subsystem outside the MI355X hot path (DESIGN.md section 0)")
+    args.adapters = args.front = args.uniq_mol_ids = None
+    return args
+
+
+def main(argv=None):
+    globalstart = time.perf_counter()
+    args = parse_args(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.device = local_rank if args.device is None else args.device
+    ref_db = DB_KEYS.get(args.mir_DB.lower()) or sys.exit("ERROR: Require valid database (-d miRBase or MirGeneDB)")
+    name = args.outDirName or ("miRge." + time.strftime('%Y-%m-%d_%H-%M-%S', time.localtime()))
+    workDir = Path(args.outDir or Path.cwd()) / name
+    workDir.mkdir(exist_ok=True, parents=True)
+    files = [f for f in args.samples.split(",") if f]
+    base_names = [Path(f).name.split(".")[0] for f in files]
+    if rank == 0:
+        with open(workDir / "run.log", "a+") as fh:
+            fh.write(" ".join(sys.argv) + "\n")
+    if not (Path(args.libraries_path) / args.organism_name / "index.Libs").exists():
+        sys.exit("\n ERROR: The path to miRge libraries is incorrect or does not exist!\n")
+
+    from .cascade import bwt_align
+    from .collapse import baking
+    from .countjoin import summarize, finish_tables
+    if world == 1:
+        df, src, trimmed, uniq = baking(args, files, base_names, str(workDir))
+        df = bwt_align(args, df, str(workDir), ref_db)
+        pdMapped, pdUnmapped = df[df.annotFlag.eq(1)], df[df.annotFlag.eq(0)]
+        summarize(args, str(workDir), ref_db, base_names, pdMapped, src, trimmed, uniq)
+        pdMapped.to_csv(workDir / "mapped.csv")
+        pdUnmapped.to_csv(workDir / "unmapped.csv")
+    else:
+        import torch.distributed as dist
+        from . import multigpu
+        from .cascade import get_cascade, EXACT_PASS, ISO_PASS
+        from .seqio import load_merges
+        dist.init_process_group("gloo")  # tables of a few kB: host-side gather, no device collective
+        casc = get_cascade(args, ref_db, args.device)
+
+        def process(i):
+            d, src, trimmed, uniq = baking(args, [files[i]], [base_names[i]], str(workDir), ctx=casc.ctx)
+            d = bwt_align(args, d, str(workDir), ref_db)
+            m = d[d.annotFlag.eq(1)]
+            m.to_csv(workDir / f"mapped.{base_names[i]}.csv")
+            d[d.annotFlag.eq(0)].to_csv(workDir / f"unmapped.{base_names[i]}.csv")
+            tabs = summarize(args, None, ref_db, [base_names[i]], m, src, trimmed, uniq)
+            return multigpu.SampleTables(i, base_names[i], src[base_names[i]], trimmed[base_names[i]],
+                                         uniq[base_names[i]], tabs["raw"][0][:, 0], tabs["raw"][1][:, 0],
+                                         tabs["raw"][2][:, 0])
+
+        tables = multigpu.run_sharded(len(files), rank, world, process, dist)
+        if rank == 0:
+            names, src, trimmed, uniq, cls, ex, iso = multigpu.merge_tables(tables)
+            finish_tables(cls, ex, iso, casc.libs["mirna"],
+                          load_merges(str(args.libraries_path), args.organism_name, ref_db), names, src, trimmed,
+                          uniq, float(args.crThreshold), bool(args.spikeIn), workDir=workDir)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not args.quiet:
+        print(f"\nThe analysis completed in {round(time.perf_counter() - globalstart, 4)} second(s)\n")
+
+
+if __name__ == "__main__":
+    main()

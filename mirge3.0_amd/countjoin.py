@@ -98,7 +98,7 @@ def finish_tables(class_sums: np.ndarray, exact: np.ndarray, iso: np.ndarray, mi
     summary = summary.reindex(columns=colRearrange)
     summary.index.name = "Sample name(s)"
     out = dict(counts=mirCounts_completeSet, rpm=mirRPM_completeSet, summary=summary,
-               class_sums={c: class_sums[p] for c, p in classes})
+               class_sums={c: class_sums[p] for c, p in classes}, raw=(class_sums, exact, iso))
     if workDir is not None:
         mirCounts_completeSet.to_csv(Path(workDir) / "miR.Counts.csv")
         mirRPM_completeSet.to_csv(Path(workDir) / "miR.RPM.csv")

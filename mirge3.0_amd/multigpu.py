@@ -1,0 +1,67 @@
+"""Sample sharding over the GPUs of one node.
+
+The reference processes samples one after the other in one process (``digest.py:133``) and only
+joins their columns at the end (``digest.py:243``; every later statistic is per sample column).  So
+the path shards by sample with **no exchange step**: one process per GPU, each rank runs
+collapse -> cascade -> count join on its own samples against its own copy of the libraries, and rank 0
+gathers the per-sample tables (a few kB each) to write the run's CSVs.  The gather is result
+collection on the host side (``torch.distributed.gather_object``), not a data-path collective.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+def assign_samples(n_samples: int, world: int) -> List[List[int]]:
+    """Round-robin: sample i goes to rank i % world (one sample per GPU when n_samples == world)."""
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in range(n_samples):
+        out[i % world].append(i)
+    return out
+
+
+@dataclass
+class SampleTables:
+    """What one sample contributes to the run's tables (all int64, S = 1 column)."""
+    index: int
+    name: str
+    total_input: int
+    trimmed_all: int
+    trimmed_unique: int
+    class_sums: np.ndarray  # [n_pass]
+    exact: np.ndarray       # [n_mirna]
+    iso: np.ndarray         # [n_mirna]
+
+
+def gather_tables(local: Sequence[SampleTables], rank: int, world: int, dist=None) -> Optional[List[SampleTables]]:
+    """All ranks' SampleTables on rank 0 (None elsewhere), ordered by sample index."""
+    if world == 1 or dist is None:
+        return sorted(local, key=lambda t: t.index)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(list(local), gathered, dst=0)
+    if rank != 0:
+        return None
+    flat = [t for part in gathered for t in part]
+    return sorted(flat, key=lambda t: t.index)
+
+
+def merge_tables(tables: Sequence[SampleTables]):
+    """Per-sample columns side by side: (base_names, counters, class_sums[P,S], exact[R,S], iso[R,S])."""
+    names = [t.name for t in tables]
+    cls = np.stack([t.class_sums for t in tables], axis=1).astype(np.int64)
+    ex = np.stack([t.exact for t in tables], axis=1).astype(np.int64)
+    iso = np.stack([t.iso for t in tables], axis=1).astype(np.int64)
+    src = {t.name: int(t.total_input) for t in tables}
+    trimmed = {t.name: int(t.trimmed_all) for t in tables}
+    uniq = {t.name: int(t.trimmed_unique) for t in tables}
+    return names, src, trimmed, uniq, cls, ex, iso
+
+
+def run_sharded(n_samples: int, rank: int, world: int, process: Callable[[int], SampleTables], dist=None):
+    """Run ``process(i)`` for this rank's samples and gather on rank 0."""
+    mine = assign_samples(n_samples, world)[rank]
+    local = [process(i) for i in mine]
+    return gather_tables(local, rank, world, dist)

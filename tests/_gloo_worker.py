@@ -1,0 +1,62 @@
+"""Worker of tests/test_multigpu_gloo.py: one rank of a world_size-2 gloo group.
+
+Each rank owns one sample of golden case 2.  The per-sample tables are computed from the
+reference's mapped.csv (numpy stands in for the kernels: the point of this test is the
+sharding / gather / merge logic of multigpu.py, which has no GPU in it), gathered on rank 0 and
+written with finish_tables; the parent compares the CSVs with the reference's."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import GoldenCase  # noqa: E402
+import mirge3_amd  # noqa: E402,F401
+from mirge3_amd import multigpu  # noqa: E402
+from mirge3_amd.countjoin import finish_tables  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    case = GoldenCase("case2_two_samples")
+    exp = case.expected_annotation()
+    mir = case.libs["mirna"]
+    lut = {}
+    for i, nm in enumerate(mir.names):
+        lut.setdefault(nm, i)
+
+    def process(i):
+        cls = np.zeros(case.n_pass, dtype=np.int64)
+        ex = np.zeros(len(mir), dtype=np.int64)
+        iso = np.zeros(len(mir), dtype=np.int64)
+        for s, row in zip(case.seqs, case.counts):
+            p, nm = exp[s]
+            c = int(row[i])
+            if p < 0 or c == 0:
+                continue
+            cls[p] += c
+            if p == 0:
+                ex[lut[nm]] += c
+            if p == 8:
+                iso[lut[nm]] += c
+        nme = case.samples[i]
+        return multigpu.SampleTables(i, nme, case.sample_read_counts[nme], case.trimmed[nme],
+                                     case.trimmed_unique[nme], cls, ex, iso)
+
+    assert multigpu.assign_samples(len(case.samples), world)[rank] == [rank]
+    tables = multigpu.run_sharded(len(case.samples), rank, world, process, dist)
+    if rank == 0:
+        names, src, trimmed, uniq, cls, ex, iso = multigpu.merge_tables(tables)
+        finish_tables(cls, ex, iso, mir, case.merges, names, src, trimmed, uniq, 0.1, False, workDir=out_dir)
+    else:
+        assert tables is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
