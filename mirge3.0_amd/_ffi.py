@@ -15,7 +15,8 @@ import numpy as np
 from .seqio import FlatSeqs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libmirge_native.so")
+# MIRGE_NATIVE_SO: A/B builds of the same library when tuning kernels (never a different backend)
+SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libmirge_native.so")
 
 EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",

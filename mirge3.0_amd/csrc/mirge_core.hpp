@@ -42,15 +42,24 @@ struct MirgePolicy {
 };
 
 struct MirgeKTable {
-    const uint32_t* bucket;  // 4^k + 1 entries
-    const uint32_t* pos;     // global positions, ascending inside a bucket
+    const uint32_t* bucket;  // 4^(k1+k2) + 1 entries
+    const uint32_t* pos;     // global positions of block A's first base, ascending inside a bucket
 };
+
+// A probe is one or two exact blocks of the read: block A = k1 bases at read offset a1, block B =
+// k2 bases at a1 + k1 + gap (k2 == 0: none).  Its table is addressed by the shape (k1, gap, k2).
+struct MirgeProbe {
+    int8_t a1, k1, gap, k2;
+};
+#define MIRGE_MAX_PROBES 9
+#define MIRGE_SHAPE_SLOTS (16 * 32 * 16)
+MIRGE_HD int mirge_shape_id(int k1, int gap, int k2) { return (k1 * 32 + gap) * 16 + k2; }
 
 struct MirgeLibView {
     const uint64_t* T;        // 2-bit text (+ >= 6 words of zero padding)
     const uint64_t* inv;      // invalid bitmap, 1 bit per base (+ padding of ones)
     const uint32_t* ref_start;  // n_refs + 1
-    const MirgeKTable* tables;  // [MIRGE_KMAX + 1], device memory
+    const MirgeKTable* tables;  // [MIRGE_SHAPE_SLOTS], indexed by mirge_shape_id, device memory
     uint64_t total;           // bases in T including separators
     uint32_t n_refs;
     int32_t kmax;             // largest k this library is probed with
@@ -187,27 +196,121 @@ MIRGE_HD bool mirge_window_invalid(const uint64_t* __restrict__ inv, uint64_t g,
     return false;
 }
 
-// Best alignment of an (already trimmed) read in one library through the k-mer tables.
-// Pigeonhole: the seed region (first min(seedlen,L) bases in -n mode, the whole read in -v
-// mode) is cut into mm+1 segments; an alignment within budget leaves one segment untouched,
-// so its first k bases are found by an exact table probe; every candidate window is then
-// verified in full.  best = (total mismatches << 32) | global position, minimised.
-// Returns false if a needed table is missing (k < 1).
+// ---- probe plan ---------------------------------------------------------------------------
+// Which exact probes guarantee that no alignment within the mismatch budget is missed.
+//   Plain pigeonhole: cut the seed region S (first min(seedlen,L) bases in -n mode, the whole
+//   read in -v mode) into mm+1 segments; one of them carries no mismatch.  With short reads the
+//   segments are short (a 16-nt read under -v 2 gives 4-mers) and a probe returns hundreds of
+//   windows.  Recursive pigeonhole: once segment i is mismatch-free, the other segments hold all
+//   <= mm mismatches, so cut THEM into mm+1 parts: one part is mismatch-free too.  Every
+//   (segment, part) pair is a probe of up to K exact bases in one or two blocks -- (mm+1)^2
+//   probes, each about 4^(part length) times more selective.  Used when a segment is shorter
+//   than K, the library's probe length.
+MIRGE_HD void mirge_two_blocks(int A0, int A1, int B0, int B1, int K, MirgeProbe& pr) {
+    int la = A1 - A0, lb = B1 - B0;
+    if (la <= 0 && lb <= 0) { pr.a1 = 0; pr.k1 = 0; pr.gap = 0; pr.k2 = 0; return; }
+    if (la <= 0) { A0 = B0; A1 = B1; la = lb; lb = 0; }
+    if (lb <= 0 || A1 == B0) {  // one contiguous run
+        const int len = lb > 0 ? (B1 - A0) : la;
+        pr.a1 = (int8_t)A0; pr.k1 = (int8_t)(len < K ? len : K); pr.gap = 0; pr.k2 = 0;
+        return;
+    }
+    // two runs: suffix of A + prefix of B, ka + kb = min(la + lb, K); the smaller run gets <= 4
+    // bases unless more are needed to reach K (keeps the number of distinct table shapes small)
+    const int tot = (la + lb) < K ? (la + lb) : K;
+    int ka, kb;
+    if (la <= lb) { ka = la < 4 ? la : 4; kb = lb < (tot - ka) ? lb : (tot - ka); ka = la < (tot - kb) ? la : (tot - kb); }
+    else { kb = lb < 4 ? lb : 4; ka = la < (tot - kb) ? la : (tot - kb); kb = lb < (tot - ka) ? lb : (tot - ka); }
+    pr.a1 = (int8_t)(A1 - ka); pr.k1 = (int8_t)ka; pr.gap = (int8_t)(B0 - A1); pr.k2 = (int8_t)kb;
+}
+
+// K is chosen so that 4^K is 4..16 x the library's positions; a plain segment of K-2 bases already
+// returns ~1 window per probe, and then (mm+1) lookups beat (mm+1)^2
+#define MIRGE_PLAIN_SLACK 2
+MIRGE_HD bool mirge_plan_is_plain(const MirgePolicy& p, int h, int K) {
+    return p.mm == 0 || p.mm > 2 || h >= K - MIRGE_PLAIN_SLACK || h < 1;
+}
+
+// number of probes for a read of (trimmed) length L in a library probed with up to K exact bases
+MIRGE_HD int mirge_probe_count(const MirgePolicy& p, int L, int K) {
+    const int S = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
+    const int nseg = p.mm + 1;
+    if (mirge_plan_is_plain(p, S / nseg, K)) return nseg < MIRGE_MAX_PROBES ? nseg : MIRGE_MAX_PROBES;
+    return nseg * nseg;
+}
+
+// probe number q (0 <= q < mirge_probe_count); written without arrays so that the kernels keep
+// everything in registers
+MIRGE_HD void mirge_probe_at(const MirgePolicy& p, int L, int K, int q, MirgeProbe& out) {
+    const int S = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
+    const int nseg = p.mm + 1;
+    const int h = S / nseg;
+    if (mirge_plan_is_plain(p, h, K)) {  // plain segments
+        out.a1 = (int8_t)(q * h); out.k1 = (int8_t)(h < K ? h : K); out.gap = 0; out.k2 = 0;
+        return;
+    }
+    if (p.mm == 1) {
+        const int h2a = (S - h) / 2, h2b = h / 2;
+        switch (q) {
+            case 0: mirge_two_blocks(0, h, h, h + h2a, K, out); break;  // mismatch in 2nd half of segment 1, or none
+            case 1: mirge_two_blocks(0, h, h + h2a, S, K, out); break;  // ... in the 1st half of segment 1
+            case 2: mirge_two_blocks(h2b, h, h, S, K, out); break;      // ... in the 1st half of segment 0
+            default: mirge_two_blocks(0, h2b, h, S, K, out); break;     // ... in the 2nd half of segment 0
+        }
+        return;
+    }
+    // mm == 2: segment i = q / 3 is mismatch-free, then third j = q % 3 of the other two segments
+    const int i = q / 3, j = q % 3;
+    if (i == 0) {  // rest = [h, S)
+        const int r = S - h, r1 = r / 3, r2 = r / 3;
+        const int t0 = j == 0 ? h : (j == 1 ? h + r1 : h + r1 + r2);
+        const int t1 = j == 0 ? h + r1 : (j == 1 ? h + r1 + r2 : S);
+        mirge_two_blocks(0, h, t0, t1, K, out);
+    } else if (i == 1) {  // rest = [0, 2h)
+        const int r = 2 * h, r1 = r / 3, r2 = r / 3;
+        const int t0 = j == 0 ? 0 : (j == 1 ? r1 : r1 + r2);
+        const int t1 = j == 0 ? r1 : (j == 1 ? r1 + r2 : 2 * h);
+        mirge_two_blocks(t0, t1, 2 * h, S, K, out);
+    } else {  // segment 1 = [h, 2h); rest = [0, h) then [2h, S); rest coordinate t -> t (t < h) or t + h
+        const int r = h + (S - 2 * h), r1 = r / 3, r2 = r / 3;
+        const int t0 = j == 0 ? 0 : (j == 1 ? r1 : r1 + r2);
+        const int t1 = j == 0 ? r1 : (j == 1 ? r1 + r2 : r);
+        if (t0 < h && t1 > h) mirge_two_blocks(t0, t1 + h, 0, 0, K, out);   // straddles segment 1: one run
+        else if (t1 <= h) mirge_two_blocks(t0, t1, h, 2 * h, K, out);       // left of segment 1
+        else mirge_two_blocks(h, 2 * h, t0 + h, t1 + h, K, out);            // right of segment 1
+    }
+}
+
+// key of a probe in the read, or false if an ambiguous call sits in a block (cannot be exact)
+template <int W>
+MIRGE_HD bool mirge_probe_key(const MirgeRead<W>& r, const MirgeProbe& pr, uint64_t& key) {
+    if (pr.k1 <= 0) return false;
+    if (mirge_extract<W>(r.nm, pr.a1, pr.k1)) return false;
+    key = mirge_extract<W>(r.w, pr.a1, pr.k1);
+    if (pr.k2 > 0) {
+        const int b = pr.a1 + pr.k1 + pr.gap;
+        if (mirge_extract<W>(r.nm, b, pr.k2)) return false;
+        key |= mirge_extract<W>(r.w, b, pr.k2) << (2 * pr.k1);
+    }
+    return true;
+}
+
+// Best alignment of an (already trimmed) read in one library through the probe tables: every
+// candidate window of every probe is verified in full.  best = (total mismatches << 32) | global
+// position, minimised.  Serial reference form (tests/hostsim); the kernels use align_hybrid.
 template <int W>
 MIRGE_HD bool mirge_align_indexed(const MirgeLibView& lib, const MirgePolicy& p,
                                   const MirgeRead<W>& r, uint64_t& best) {
     best = MIRGE_NO_HIT;
     const int L = r.len;
-    const int seed = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
-    const int nseg = p.mm + 1;
-    const int h = seed / nseg;
-    const int k = h < lib.kmax ? h : lib.kmax;
-    if (k < 1) return false;
-    const MirgeKTable tb = lib.tables[k];
-    for (int sg = 0; sg < nseg; sg++) {
-        const int a = sg * h;
-        if (mirge_extract<W>(r.nm, a, k)) continue;  // an N inside the probe: cannot be exact
-        const uint64_t key = mirge_extract<W>(r.w, a, k);
+    const int np = mirge_probe_count(p, L, lib.kmax);
+    for (int q = 0; q < np; q++) {
+        MirgeProbe pr;
+        mirge_probe_at(p, L, lib.kmax, q, pr);
+        uint64_t key;
+        if (!mirge_probe_key<W>(r, pr, key)) continue;
+        const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+        const int a = pr.a1;
         const uint32_t lo = tb.bucket[key], hi = tb.bucket[key + 1];
         for (uint32_t c = lo; c < hi; c++) {
             const uint32_t pz = tb.pos[c];
@@ -218,9 +321,6 @@ MIRGE_HD bool mirge_align_indexed(const MirgeLibView& lib, const MirgePolicy& p,
             if (mirge_window_invalid(lib.inv, g, L)) continue;
             const uint64_t cand = ((uint64_t)m << 32) | g;
             if (cand < best) best = cand;
-            // positions ascend inside a bucket and a 0-mismatch window is in segment 0's
-            // bucket, so the first one seen there is the global minimum
-            if (sg == 0 && m == 0) return true;
         }
     }
     return true;

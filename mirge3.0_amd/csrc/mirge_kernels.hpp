@@ -268,6 +268,12 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
 //   All 64 lanes of the wave must call this together (inactive lanes pass active = false).
 // ------------------------------------------------------------------------------------------
 #define MIRGE_LIGHT 4
+#define MIRGE_COOP_UNROLL 1
+
+// pointers that came out of memory or a v_readlane have lost their address space; these casts keep
+// the loads global_load_* (not flat_load_*, which also ties up lgkmcnt)
+typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
+typedef const __attribute__((address_space(1))) uint64_t* gptr_u64;
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
     uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src);
@@ -275,15 +281,73 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// the two text words under a window: issued for several candidates before any is consumed
+struct TextWin { uint64_t w[5]; };
+
 template <int W>
-__device__ __forceinline__ uint64_t eval_candidate(const MirgeLibView& lib, const MirgePolicy& pol,
-                                                   const MirgeRead<W>& r, uint32_t pz, int a) {
-    if (pz < (uint32_t)a) return MIRGE_NO_HIT;
-    const uint64_t g = (uint64_t)pz - (uint64_t)a;
-    const int m = mirge_window_mm<W>(lib.T, g, r, pol);
-    if (m < 0) return MIRGE_NO_HIT;
-    if (mirge_window_invalid(lib.inv, g, r.len)) return MIRGE_NO_HIT;
-    return ((uint64_t)m << 32) | g;
+__device__ __forceinline__ void load_window(gptr_u64 T, uint64_t g, int L, TextWin& tw) {
+    const uint64_t q = g >> 5;
+#pragma unroll
+    for (int i = 0; i <= W; i++) tw.w[i] = (i == 0 || 32 * (i - 1) < L) ? T[q + i] : 0ull;
+}
+
+// same arithmetic as mirge_window_mm, on words that are already in registers
+template <int W>
+__device__ __forceinline__ int window_mm_regs(const TextWin& tw, uint64_t g, const MirgeRead<W>& r,
+                                              const MirgePolicy& p) {
+    const int L = r.len;
+    const int s = (int)(g & 31) * 2;
+    int tot = 0, seedmm = 0;
+    const int seed = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        if (32 * i < L) {
+            const uint64_t t = s ? ((tw.w[i] >> s) | (tw.w[i + 1] << (64 - s))) : tw.w[i];
+            const uint64_t x = r.w[i] ^ t;
+            uint64_t m = (x | (x >> 1)) & 0x5555555555555555ull;
+            const int rem = L - 32 * i;
+            m &= mirge_lowmask2(rem > 32 ? 32 : rem);
+            m |= r.nm[i];
+            tot += mirge_popc(m);
+            const int srem = seed - 32 * i;
+            if (srem > 0) seedmm += mirge_popc(m & mirge_lowmask2(srem > 32 ? 32 : srem));
+        }
+    }
+    if (tot > p.maxtotal || seedmm > p.mm) return -1;
+    return tot;
+}
+
+// verify up to N candidate positions at once: all pos loads, then all text loads, then arithmetic
+template <int W, int N>
+__device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const MirgePolicy& pol,
+                                               const MirgeRead<W>& r, gptr_u32 pos, const uint32_t (&c)[N],
+                                               uint32_t hi, int a) {
+    uint32_t pz[N];
+    bool ok[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        ok[u] = c[u] < hi;
+        pz[u] = ok[u] ? pos[c[u]] : 0u;
+    }
+    TextWin tw[N];
+    uint64_t g[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        ok[u] = ok[u] && pz[u] >= (uint32_t)a;
+        g[u] = ok[u] ? (uint64_t)pz[u] - (uint64_t)a : 0ull;
+        load_window<W>((gptr_u64)lib.T, g[u], ok[u] ? r.len : 0, tw[u]);
+    }
+    uint64_t best = MIRGE_NO_HIT;
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        if (!ok[u]) continue;
+        const int m = window_mm_regs<W>(tw[u], g[u], r, pol);
+        if (m < 0) continue;
+        if (mirge_window_invalid(lib.inv, g[u], r.len)) continue;
+        const uint64_t cand = ((uint64_t)m << 32) | g[u];
+        if (cand < best) best = cand;
+    }
+    return best;
 }
 
 template <int W>
@@ -291,29 +355,34 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
                                              const MirgeRead<W>& r, bool active, uint64_t& best) {
     best = MIRGE_NO_HIT;
     const int lane = threadIdx.x & 63;
-    const int L = r.len;
-    const int seed = pol.mode == 0 ? (L < pol.seedlen ? L : pol.seedlen) : L;
-    const int nseg = pol.mm + 1;  // wave-uniform
-    const int h = seed / nseg;
-    const int k = h < lib.kmax ? h : lib.kmax;
-    if (k < 1) active = false;
-    MirgeKTable tb;
-    tb.bucket = nullptr; tb.pos = nullptr;
-    if (active) tb = lib.tables[k];
-    for (int sg = 0; sg < nseg; sg++) {
-        const int a = sg * h;
+    const int np = active ? mirge_probe_count(pol, r.len, lib.kmax) : 0;
+    // wave-uniform bound on the probe count: (mm+1) plain segments or (mm+1)^2 recursive probes
+    const int npmax = (pol.mm >= 1 && pol.mm <= 2) ? (pol.mm + 1) * (pol.mm + 1) : pol.mm + 1;
+#pragma unroll 1
+    for (int q = 0; q < npmax; q++) {
         uint32_t lo = 0, hi = 0;
-        if (active && !mirge_extract<W>(r.nm, a, k)) {  // an N inside the probe: cannot be exact
-            const uint64_t key = mirge_extract<W>(r.w, a, k);
-            lo = tb.bucket[key];
-            hi = tb.bucket[key + 1];
+        int a = 0;
+        gptr_u32 pos = nullptr;
+        if (active && q < np) {
+            MirgeProbe pr;
+            mirge_probe_at(pol, r.len, lib.kmax, q, pr);
+            uint64_t key;
+            if (mirge_probe_key<W>(r, pr, key)) {  // no ambiguous call inside the probe
+                const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+                gptr_u32 bucket = (gptr_u32)tb.bucket;
+                pos = (gptr_u32)tb.pos;
+                lo = bucket[key];
+                hi = bucket[key + 1];
+                a = pr.a1;
+            }
         }
         const bool heavy = (hi - lo) > MIRGE_LIGHT;
-        if (!heavy) {
-            for (uint32_t c = lo; c < hi; c++) {
-                const uint64_t cand = eval_candidate<W>(lib, pol, r, tb.pos[c], a);
-                if (cand < best) best = cand;
-            }
+        if (!heavy && hi > lo) {
+            uint32_t c[MIRGE_LIGHT];
+#pragma unroll
+            for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = lo + u;
+            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, r, pos, c, hi, a);
+            if (cand < best) best = cand;
         }
         unsigned long long hb = __ballot(heavy);
         while (hb) {
@@ -329,10 +398,13 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
             const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)lo, src);
             const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, src);
             const int ba = __builtin_amdgcn_readlane(a, src);
-            const uint32_t* bpos = (const uint32_t*)readlane_u64((uint64_t)tb.pos, src);
+            gptr_u32 bpos = (gptr_u32)readlane_u64((uint64_t)pos, src);
             uint64_t lbest = MIRGE_NO_HIT;
-            for (uint32_t c = blo + lane; c < bhi; c += 64) {
-                const uint64_t cand = eval_candidate<W>(lib, pol, rr, bpos[c], ba);
+            for (uint32_t c0 = blo + lane; c0 < bhi; c0 += 64 * MIRGE_COOP_UNROLL) {
+                uint32_t c[MIRGE_COOP_UNROLL];
+#pragma unroll
+                for (int u = 0; u < MIRGE_COOP_UNROLL; u++) c[u] = c0 + 64 * u;
+                const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, rr, bpos, c, bhi, ba);
                 if (cand < lbest) lbest = cand;
             }
             // almost every candidate fails verification: instead of a shuffle tree, visit the few
@@ -347,8 +419,8 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
             }
             if (lane == src && tbest < best) best = tbest;
         }
-        // a 0-mismatch window is in segment 0's bucket: nothing later can beat it
-        if (sg == 0 && (best >> 32) == 0) active = false;
+        // a 0-mismatch window is in probe 0's bucket and buckets ascend: nothing later can beat it
+        if (q == 0 && (best >> 32) == 0) active = false;
     }
 }
 
@@ -366,8 +438,11 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
 // ------------------------------------------------------------------------------------------
 // SLOT is the pass index and only names the symbol (k_pass<1,6> ...), so that rocprofv3's per-kernel
 // statistics separate the passes; the policy itself stays a run-time argument.
+#ifndef MIRGE_PASS_MIN_WAVES
+#define MIRGE_PASS_MIN_WAVES 1
+#endif
 template <int W, int SLOT>
-__global__ void __launch_bounds__(MIRGE_BLOCK)
+__global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES)
 k_pass(MirgeLibView lib, MirgePolicy pol, GroupView<W> g, const uint32_t* __restrict__ act_in,
        const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
        uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,

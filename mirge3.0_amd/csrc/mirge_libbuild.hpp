@@ -66,29 +66,40 @@ static inline int mirge_hostlib_build(MirgeHostLib& L, const char* seq, const in
     return 0;
 }
 
-// Every valid k-window, counting-sorted by its little-endian 2-bit value; positions ascend
-// inside a bucket (the early exit of mirge_align_indexed relies on that).
-static inline void mirge_hostlib_table(const MirgeHostLib& L, int k, std::vector<uint32_t>& bucket,
+// Every position whose whole span [p, p+k1+gap+k2) is valid, counting-sorted by the little-endian
+// 2-bit value of block A (k1 bases at p) | block B (k2 bases at p+k1+gap) << 2*k1; positions ascend
+// inside a bucket.  gap = k2 = 0 is the ordinary k1-mer table.
+static inline uint64_t mirge_text_kmer(const uint64_t* T, uint64_t g, int k) {
+    if (k <= 0) return 0;
+    const uint64_t q = g >> 5;
+    const int s = (int)(g & 31) * 2;
+    uint64_t lo = T[q] >> s;
+    if (s) lo |= T[q + 1] << (64 - s);
+    return lo & mirge_lowmask2(k);
+}
+
+static inline void mirge_hostlib_table(const MirgeHostLib& L, int k1, int gap, int k2, std::vector<uint32_t>& bucket,
                                        std::vector<uint32_t>& pos) {
-    const uint64_t nb = 1ull << (2 * k);
+    const uint64_t nb = 1ull << (2 * (k1 + k2));
+    const int span = k1 + (k2 > 0 ? gap + k2 : 0);
     bucket.assign(nb + 1, 0u);
     const uint64_t* T = L.T.data();
     const uint64_t* inv = L.inv.data();
-    const int sh = 2 * (k - 1);
     for (int phase = 0; phase < 2; phase++) {
         if (phase == 1) {
             uint32_t acc = 0;
             for (uint64_t b = 0; b <= nb; b++) { uint32_t c = bucket[b]; bucket[b] = acc; acc += c; }
             pos.assign(std::max<size_t>(acc, 1), 0u);
         }
-        uint64_t key = 0;
-        int run = 0;
+        int run = 0;  // valid bases ending at g
         for (uint64_t g = 0; g < L.total; g++) {
-            if ((inv[g >> 6] >> (g & 63)) & 1ull) { run = 0; key = 0; continue; }
-            key = (key >> 2) | (((T[g >> 5] >> (2 * (g & 31))) & 3ull) << sh);  // window [g-k+1, g]
-            if (++run >= k) {
+            if ((inv[g >> 6] >> (g & 63)) & 1ull) { run = 0; continue; }
+            if (++run >= span) {
+                const uint64_t p0 = g - (uint64_t)span + 1;
+                uint64_t key = mirge_text_kmer(T, p0, k1);
+                if (k2 > 0) key |= mirge_text_kmer(T, p0 + (uint64_t)(k1 + gap), k2) << (2 * k1);
                 if (phase == 0) bucket[key]++;
-                else pos[bucket[key]++] = (uint32_t)(g - (uint64_t)k + 1);
+                else pos[bucket[key]++] = (uint32_t)p0;
             }
         }
     }

@@ -251,9 +251,8 @@ struct mirge_lib {
     uint64_t* dT = nullptr;
     uint64_t* dinv = nullptr;
     uint32_t* dref_start = nullptr;
-    MirgeKTable* dtables = nullptr;
-    MirgeKTable htables[MIRGE_KMAX + 1];
-    size_t table_n[MIRGE_KMAX + 1];
+    MirgeKTable* dtables = nullptr;           // [MIRGE_SHAPE_SLOTS] on the device
+    std::vector<MirgeKTable> htables;          // host mirror (device pointers), by mirge_shape_id
     size_t device_bytes = 0;
     std::mutex mu;
     int64_t n_refs = 0;
@@ -277,17 +276,17 @@ extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* of
     if (rc) return fail(rc, "mirge_lib_create: " + err);
     L->n_refs = n_refs;
     L->kmax = L->h.kmax;
-    for (int i = 0; i <= MIRGE_KMAX; i++) { L->htables[i].bucket = nullptr; L->htables[i].pos = nullptr; L->table_n[i] = 0; }
+    L->htables.assign(MIRGE_SHAPE_SLOTS, MirgeKTable{nullptr, nullptr});
     const size_t nT = L->h.T.size() * 8, nI = L->h.inv.size() * 8, nR = ((size_t)n_refs + 1) * 4;
     HIPOK(hipMalloc((void**)&L->dT, nT));
     HIPOK(hipMalloc((void**)&L->dinv, nI));
     HIPOK(hipMalloc((void**)&L->dref_start, nR));
-    HIPOK(hipMalloc((void**)&L->dtables, sizeof(MirgeKTable) * (MIRGE_KMAX + 1)));
+    HIPOK(hipMalloc((void**)&L->dtables, sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS));
     HIPOK(hipMemcpy(L->dT, L->h.T.data(), nT, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(L->dinv, L->h.inv.data(), nI, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(L->dref_start, L->h.ref_start.data(), nR, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(L->dtables, L->htables, sizeof(MirgeKTable) * (MIRGE_KMAX + 1), hipMemcpyHostToDevice));
-    L->device_bytes = nT + nI + nR;
+    HIPOK(hipMemcpy(L->dtables, L->htables.data(), sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS, hipMemcpyHostToDevice));
+    L->device_bytes = nT + nI + nR + sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS;
     *out = L.release();
     return 0;
 }
@@ -297,32 +296,38 @@ extern "C" void mirge_lib_destroy(mirge_lib* L) {
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
     (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dtables);
-    for (int k = 0; k <= MIRGE_KMAX; k++) { (void)hipFree((void*)L->htables[k].bucket); (void)hipFree((void*)L->htables[k].pos); }
+    for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); }
     delete L;
 }
 extern "C" int64_t mirge_lib_n_refs(const mirge_lib* L) { return L ? L->n_refs : -1; }
 extern "C" int64_t mirge_lib_device_bytes(const mirge_lib* L) { return L ? (int64_t)L->device_bytes : -1; }
 
-extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {
-    if (!L) return fail(-1, "lib is NULL");
-    if (k < 1 || k > MIRGE_KMAX) return fail(-1, "k out of range");
+// build the table of one probe shape (k1 bases, gap, k2 bases) if it does not exist yet
+static int lib_prepare_shape(mirge_lib* L, int k1, int gap, int k2) {
+    if (k1 < 1 || k1 > MIRGE_KMAX || k2 < 0 || k1 + k2 > MIRGE_KMAX || gap < 0 || gap > 31 || (k2 == 0 && gap != 0))
+        return fail(-1, "probe shape out of range");
     std::lock_guard<std::mutex> lk(L->mu);
-    if (L->htables[k].bucket) return 0;
+    const int sid = mirge_shape_id(k1, gap, k2);
+    if (L->htables[sid].bucket) return 0;
     HIPOK(hipSetDevice(L->ctx->device));
     std::vector<uint32_t> bucket, pos;
-    mirge_hostlib_table(L->h, k, bucket, pos);
+    mirge_hostlib_table(L->h, k1, gap, k2, bucket, pos);
     uint32_t* dbucket = nullptr; uint32_t* dpos = nullptr;
     HIPOK(hipMalloc((void**)&dbucket, bucket.size() * 4));
     HIPOK(hipMalloc((void**)&dpos, pos.size() * 4));
     HIPOK(hipMemcpy(dbucket, bucket.data(), bucket.size() * 4, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(dpos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
-    L->htables[k].bucket = dbucket;
-    L->htables[k].pos = dpos;
-    L->table_n[k] = pos.size();
+    L->htables[sid].bucket = dbucket;
+    L->htables[sid].pos = dpos;
     L->device_bytes += bucket.size() * 4 + pos.size() * 4;
-    HIPOK(hipStreamSynchronize(L->ctx->stream));  // no kernel may be reading the table row being replaced
-    HIPOK(hipMemcpy(L->dtables, L->htables, sizeof(MirgeKTable) * (MIRGE_KMAX + 1), hipMemcpyHostToDevice));
+    HIPOK(hipStreamSynchronize(L->ctx->stream));  // no kernel may be reading the registry while it changes
+    HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));
     return 0;
+}
+
+extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {
+    if (!L) return fail(-1, "lib is NULL");
+    return lib_prepare_shape(L, k, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -649,8 +654,10 @@ extern "C" void mirge_result_destroy(mirge_result* r) {
     delete r;
 }
 
-// which table lengths can pass `p` ask for, given the read lengths present
-static void needed_k(const mirge_policy& p, const int32_t* hist, int kmax, bool need[MIRGE_KMAX + 1]) {
+// build every probe table pass `p` can ask for, given the read lengths present
+static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t* hist) {
+    MirgePolicy p;
+    std::memcpy(&p, &pol, sizeof(p));
     for (int L = 1; L <= MIRGE_MAX_READ_LEN; L++) {
         if (!hist[L]) continue;
         if (p.len_lt > 0 && !(L < p.len_lt)) continue;
@@ -658,14 +665,17 @@ static void needed_k(const mirge_policy& p, const int32_t* hist, int kmax, bool 
         int lo = L, hi = L;
         if (p.ttail) { lo = 1; hi = L - 3; }  // any head length once the T run is gone
         for (int l0 = lo; l0 <= hi; l0++) {
-            int l = l0 - p.trim5 - p.trim3;
+            const int l = l0 - p.trim5 - p.trim3;
             if (l < 1 || l <= p.mm) continue;
-            int seed = p.mode == 0 ? std::min(l, p.seedlen) : l;
-            int h = seed / (p.mm + 1);
-            int k = std::min(h, kmax);
-            if (k >= 1) need[k] = true;
+            const int np = mirge_probe_count(p, l, lib->kmax);
+            for (int q = 0; q < np; q++) {
+                MirgeProbe pr;
+                mirge_probe_at(p, l, lib->kmax, q, pr);
+                if (pr.k1 > 0) CHECK(lib_prepare_shape(lib, pr.k1, pr.gap, pr.k2));
+            }
         }
     }
+    return 0;
 }
 
 template <int W>
@@ -771,10 +781,7 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
         if (libs[p]->ctx->device != c->device) return fail(-1, "library lives on another device");
         if (pol[p].mm < 0 || pol[p].mm > 3 || pol[p].trim5 < 0 || pol[p].trim5 > 31 || pol[p].trim3 < 0)
             return fail(-1, "unsupported policy");
-        bool need[MIRGE_KMAX + 1] = {false};
-        needed_k(pol[p], hist, libs[p]->kmax, need);
-        for (int k = 1; k <= MIRGE_KMAX; k++)
-            if (need[k]) CHECK(mirge_lib_prepare(const_cast<mirge_lib*>(libs[p]), k));
+        CHECK(prepare_tables(const_cast<mirge_lib*>(libs[p]), pol[p], hist));
         rt.ref_start[p] = libs[p]->dref_start;
         rt.n_refs[p] = (uint32_t)libs[p]->n_refs;
     }

@@ -16,11 +16,14 @@
 
 struct SimLib {
     MirgeHostLib h;
-    std::vector<uint32_t> bucket[MIRGE_KMAX + 1], pos[MIRGE_KMAX + 1];
-    MirgeKTable tables[MIRGE_KMAX + 1];
+    std::vector<std::vector<uint32_t>> bucket, pos;
+    std::vector<MirgeKTable> tables;
+    SimLib() : bucket(MIRGE_SHAPE_SLOTS), pos(MIRGE_SHAPE_SLOTS), tables(MIRGE_SHAPE_SLOTS) {
+        for (auto& t : tables) { t.bucket = nullptr; t.pos = nullptr; }
+    }
     MirgeLibView view() {
         MirgeLibView v;
-        v.T = h.T.data(); v.inv = h.inv.data(); v.ref_start = h.ref_start.data(); v.tables = tables;
+        v.T = h.T.data(); v.inv = h.inv.data(); v.ref_start = h.ref_start.data(); v.tables = tables.data();
         v.total = h.total; v.n_refs = (uint32_t)h.n_refs; v.kmax = h.kmax;
         return v;
     }
@@ -47,14 +50,18 @@ static void sim_one(const char* s, int L, std::vector<SimLib>& libs, const std::
         MirgeRead<W> r;
         pack_read<W>(s, L, r);
         if (!mirge_effective_read<W>(r, pol[p])) continue;
-        // same table-on-demand rule as mirge_cascade_run
-        const int seed = pol[p].mode == 0 ? (r.len < pol[p].seedlen ? r.len : pol[p].seedlen) : r.len;
-        const int h = seed / (pol[p].mm + 1);
-        const int k = h < libs[p].h.kmax ? h : libs[p].h.kmax;
-        if (k >= 1 && !libs[p].tables[k].bucket) {
-            mirge_hostlib_table(libs[p].h, k, libs[p].bucket[k], libs[p].pos[k]);
-            libs[p].tables[k].bucket = libs[p].bucket[k].data();
-            libs[p].tables[k].pos = libs[p].pos[k].data();
+        // same table-on-demand rule as mirge_cascade_run: every shape the read's probe plan names
+        const int np = mirge_probe_count(pol[p], r.len, libs[p].h.kmax);
+        for (int q = 0; q < np; q++) {
+            MirgeProbe pr;
+            mirge_probe_at(pol[p], r.len, libs[p].h.kmax, q, pr);
+            if (pr.k1 <= 0) continue;
+            const int sid = mirge_shape_id(pr.k1, pr.gap, pr.k2);
+            if (!libs[p].tables[sid].bucket) {
+                mirge_hostlib_table(libs[p].h, pr.k1, pr.gap, pr.k2, libs[p].bucket[sid], libs[p].pos[sid]);
+                libs[p].tables[sid].bucket = libs[p].bucket[sid].data();
+                libs[p].tables[sid].pos = libs[p].pos[sid].data();
+            }
         }
         uint64_t best;
         MirgeLibView v = libs[p].view();
@@ -76,7 +83,6 @@ extern "C" int hostsim_cascade(const char* reads, const int64_t* roff, int64_t n
     std::vector<SimLib> libs((size_t)n_pass);
     std::vector<bool> present((size_t)n_pass, false);
     for (int p = 0; p < n_pass; p++) {
-        for (int k = 0; k <= MIRGE_KMAX; k++) { libs[p].tables[k].bucket = nullptr; libs[p].tables[k].pos = nullptr; }
         if (!lib_seq[p]) continue;
         std::string err;
         if (mirge_hostlib_build(libs[p].h, lib_seq[p], lib_off[p], lib_n[p], err)) return -1;
