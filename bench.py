@@ -31,8 +31,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (s
 # 8 B + 1 B length; an annotation is pass 1 B + position 4 B (+ mismatches 1 B, not counted).
 ALGO_BYTES = {
     "k_collapse_insert": 9 + 4,      # read in, slot id out, per raw read
-    "k_heads_blocksum": 4 + 4,       # slot id + first-index in, per raw read
-    "k_collapse_scatter": 4 + 4 + 13,  # slot id + first-index in; key+len+count out (upper bound: per raw read)
+    "k_collapse_insert_key": 9 + 4,  # same, 64-bit-key table (<=31 nt, no N, one sample)
+    "k_heads_blocksum": 4 + 4 + 1,   # slot id + first-index in, head flag out, per raw read
+    "k_collapse_scatter": 1 + 4 + 13,  # head flag + slot id in; key+len+count out (upper bound: per raw read)
     "k_pass": 4 + 9 + 5,             # active index + read in, annotation or survivor index out, per read handed to the pass
     "k_resolve": 5 + 8,              # pass+position in, ref+offset out
     "k_join": 5 + 4,                 # pass+ref + one count in (S = 1)
@@ -44,6 +45,7 @@ ALGO_BYTES = {
 def algo_bytes(name):
     """per-unit bytes of a profile record such as 'k_pass[6].w1' (w1/w2/w4 = 1/2/4-word reads)"""
     base, _, w = name.partition(".w")
+    w = w.rstrip("n")  # 'n' = the group of reads with an ambiguous base call
     extra = 8 * (int(w) - 1) if w.isdigit() and (base.startswith("k_pass") or base.startswith("k_collapse")) else 0
     return (ALGO_BYTES["k_pass"] if base.startswith("k_pass") else ALGO_BYTES.get(base, 0)) + extra
 

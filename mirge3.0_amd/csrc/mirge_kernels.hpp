@@ -186,20 +186,82 @@ __global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, ui
     }
 }
 
+// Fast form for the <=31-nt group without ambiguous calls and one sample (the bulk of any run): the
+// whole identity of a read -- its bits plus a length sentinel bit at 2*len -- fits one u64, so the
+// table holds the key itself: a duplicate is recognised from the slot (no representative read to
+// fetch), and key, first index and count share one 16-byte slot = one 64-byte sector per read
+// instead of six.  first is kept as ~j under atomicMax so that a zero-filled table is "empty".
+struct KeySlot {
+    unsigned long long key;  // 0 = empty
+    uint32_t first_inv;      // 0xFFFFFFFF - (smallest read index)
+    uint32_t cnt;
+};
+
+__global__ void k_collapse_insert_key(GroupView<1> g, KeySlot* __restrict__ slots, uint32_t* __restrict__ slot_of,
+                                      uint32_t mask) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g.n; j += gridDim.x * blockDim.x) {
+        const unsigned long long key = g.seq[j] | (1ull << (2 * g.len[j]));
+        uint32_t s = (uint32_t)(mirge_mix64(key) >> 20) & mask;
+        uint32_t seen_first = 0;
+        while (true) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&slots[s]);  // key, first_inv, cnt in one load
+            unsigned long long cur = ((unsigned long long)v.y << 32) | v.x;
+            seen_first = v.z;
+            if (cur == 0ull) { cur = atomicCAS(&slots[s].key, 0ull, key); seen_first = 0; }
+            if (cur == 0ull || cur == key) break;
+            s = (s + 1) & mask;
+        }
+        slot_of[j] = s;
+        // first_inv only grows, so a (possibly stale) plain read that is already >= ours proves the
+        // atomic would change nothing: most duplicates skip it (scattered atomics run at ~20 G/s
+        // chip-wide and are what bounds this kernel)
+        if (0xFFFFFFFFu - j > seen_first) atomicMax(&slots[s].first_inv, 0xFFFFFFFFu - j);
+        atomicAdd(&slots[s].cnt, 1u);
+    }
+}
+
+// heads: read j is the head of its group iff it is the group's smallest index.  `first` is addressed
+// as first[slot * stride] (inv: stored as 0xFFFFFFFF - index).  Writes flag[j] and per-block sums.
 #define MIRGE_SCAN_ITEMS 8  // per thread -> 2048 per block
-__global__ void k_heads_blocksum(const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ firstj,
-                                 uint32_t n, uint32_t* __restrict__ blocksum) {
+__global__ void k_heads_blocksum(const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ first,
+                                 uint32_t stride, uint32_t inv, uint32_t n, const uint8_t* __restrict__ len,
+                                 uint8_t* __restrict__ flag, uint32_t* __restrict__ blocksum,
+                                 uint32_t* __restrict__ hist) {
     __shared__ uint32_t lds4[4];
+    __shared__ uint32_t h[MIRGE_MAX_READ_LEN + 1];  // lengths of the heads = lengths of the unique reads
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) h[i] = 0;
+    __syncthreads();
     const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * MIRGE_SCAN_ITEMS) + threadIdx.x * MIRGE_SCAN_ITEMS;
     uint32_t c = 0;
+    uint8_t fl[MIRGE_SCAN_ITEMS];
 #pragma unroll
     for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
-        uint32_t j = b0 + i;
-        if (j < n) c += (firstj[slot_of[j]] == j);
+        const uint32_t j = b0 + i;
+        fl[i] = 0;
+        if (j < n) {
+            const uint32_t f = first[(size_t)slot_of[j] * stride];
+            fl[i] = (inv ? 0xFFFFFFFFu - f : f) == j;
+            if (fl[i]) {
+                c++;
+                const uint32_t L = len[j];
+                atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
+            }
+        }
+    }
+    if (b0 + MIRGE_SCAN_ITEMS <= n) {
+        uint64_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) packed |= (uint64_t)fl[i] << (8 * i);
+        *reinterpret_cast<uint64_t*>(flag + b0) = packed;
+    } else {
+#pragma unroll
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) if (b0 + i < n) flag[b0 + i] = fl[i];
     }
     uint32_t total;
-    block_excl_scan(c, total, lds4);
+    block_excl_scan(c, total, lds4);  // two barriers: the LDS histogram is complete after it
     if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
 // single block: exclusive scan of blocksum[0..nb) in place, total to *out_total
@@ -219,20 +281,23 @@ __global__ void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb, u
 
 template <int W>
 __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ slot_of,
-                                   const uint32_t* __restrict__ firstj, const uint32_t* __restrict__ cnt,
-                                   const uint32_t* __restrict__ blockoff, const uint32_t* __restrict__ n_uniq_ptr,
-                                   const uint32_t* __restrict__ orig, uint32_t base, int32_t S,
-                                   uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
-                                   uint64_t* __restrict__ unmask, uint32_t* __restrict__ ucnt,
-                                   uint32_t* __restrict__ ufirst) {
+                                   const uint8_t* __restrict__ flag, const uint32_t* __restrict__ cnt,
+                                   uint32_t cnt_stride, const uint32_t* __restrict__ blockoff,
+                                   const uint32_t* __restrict__ n_uniq_ptr, const uint32_t* __restrict__ orig,
+                                   uint32_t base, int32_t S, uint64_t* __restrict__ useq,
+                                   uint8_t* __restrict__ ulen, uint64_t* __restrict__ unmask,
+                                   uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst) {
     __shared__ uint32_t lds4[4];
     const uint32_t U = *n_uniq_ptr;
     const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * MIRGE_SCAN_ITEMS) + threadIdx.x * MIRGE_SCAN_ITEMS;
     uint32_t heads = 0, c = 0;
+    if (b0 + MIRGE_SCAN_ITEMS <= g.n) {
+        const uint64_t packed = *reinterpret_cast<const uint64_t*>(flag + b0);
 #pragma unroll
-    for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
-        uint32_t j = b0 + i;
-        if (j < g.n && firstj[slot_of[j]] == j) { heads |= 1u << i; c++; }
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) if ((packed >> (8 * i)) & 1ull) { heads |= 1u << i; c++; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) if (b0 + i < g.n && flag[b0 + i]) { heads |= 1u << i; c++; }
     }
     uint32_t total;
     uint32_t rank = blockoff[blockIdx.x] + block_excl_scan(c, total, lds4);
@@ -247,7 +312,7 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
                 if (unmask) unmask[(size_t)w * U + rank] = g.nmask ? g.nmask[(size_t)w * g.n + j] : 0ull;
             }
             ulen[rank] = g.len[j];
-            for (int32_t q = 0; q < S; q++) ucnt[(size_t)rank * S + q] = cnt[(size_t)s * S + q];
+            for (int32_t q = 0; q < S; q++) ucnt[(size_t)rank * S + q] = cnt[(size_t)s * cnt_stride + q];
             ufirst[rank] = orig ? orig[j] : base + j;
             rank++;
         }

@@ -55,11 +55,22 @@ struct PendingEvt {
     int rec;
     hipEvent_t a, b;
 };
+struct ProfUnits {  // "units" of a cascade pass = sum of the per-workgroup survivor counts of the stage before
+    int rec, stage;
+    uint32_t grid;
+    const uint32_t* host;  // pinned copy of seg_n[stage][grid]
+    double n_first;
+};
+#define MIRGE_PROF_PINNED_WORDS (1u << 18)
 
 struct mirge_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream: the small read groups (long reads, reads with N) run beside the big one.
+    // cur = the stream the launch helpers currently target.
+    hipStream_t aux = nullptr, cur = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_cu = 256;
     // pool
     std::multimap<size_t, void*> free_blocks;
@@ -74,6 +85,9 @@ struct mirge_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // pinned scratch for small D2H
     uint32_t* pinned = nullptr;
+    uint32_t* prof_pinned = nullptr;
+    size_t prof_used = 0;
+    std::vector<ProfUnits> prof_pending;
 
     int alloc(void** out, size_t bytes) {
         bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
@@ -102,6 +116,11 @@ struct mirge_ctx {
         if (it == sizes.end()) return;
         free_blocks.emplace(it->second, p);  // stream-ordered reuse: one stream per ctx
     }
+    // inside a fork/join region a buffer must not go back to the pool before the join: the other
+    // stream could be handed it while this stream's kernels still use it
+    std::vector<void*> deferred;
+    void defer(void* p) { if (p) deferred.push_back(p); }
+    void flush_deferred() { for (void* p : deferred) release(p); deferred.clear(); }
     int rec_index(const char* name) {
         auto it = rec_of.find(name);
         if (it != rec_of.end()) return it->second;
@@ -114,6 +133,13 @@ struct mirge_ctx {
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
     void drain() {  // resolve pending event pairs (caller has synchronised the stream)
+        for (auto& u : prof_pending) {
+            double units = u.n_first;
+            if (u.stage > 0) { units = 0; for (uint32_t b = 0; b < u.grid; b++) units += u.host[(size_t)u.grid * (u.stage - 1) + b]; }
+            recs[u.rec].units += units;
+        }
+        prof_pending.clear();
+        prof_used = 0;
         for (auto& p : pending) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) recs[p.rec].total_ms += ms;
@@ -136,14 +162,32 @@ struct LaunchScope {
         c->recs[rec].launches++;
         c->recs[rec].units += units;
         a = c->get_evt(); b = c->get_evt();
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, c->cur);
     }
     ~LaunchScope() {
         if (rec < 0) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, c->cur);
         c->pending.push_back(PendingEvt{rec, a, b});
     }
 };
+
+// fork: work queued on `aux` from now on starts after everything already queued on the main stream;
+// join: the main stream continues only after `aux` has drained.  Buffers handed back to the pool
+// between the two are reused only by work queued after the join, so stream-ordered reuse still holds.
+static int stream_fork(mirge_ctx* c) {
+    HIPOK(hipEventRecord(c->ev_fork, c->stream));
+    HIPOK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    return 0;
+}
+static int stream_join(mirge_ctx* c) {
+    c->cur = c->stream;
+    hipError_t e = hipEventRecord(c->ev_join, c->aux);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    c->flush_deferred();  // reused only by work queued on the main stream after the wait
+    if (e != hipSuccess) return fail(-2, std::string("stream join: ") + hipGetErrorString(e));
+    return 0;
+}
+static int largest_group(const struct mirge_reads* R);
 
 static inline int grid_for(const mirge_ctx* c, size_t n, int per_block = MIRGE_BLOCK) {
     size_t blocks = (n + per_block - 1) / per_block;
@@ -170,9 +214,14 @@ extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; }
     else { HIPOK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    c->cur = c->stream;
+    HIPOK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIPOK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPOK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPOK(hipEventCreate(&c->t0));
     HIPOK(hipEventCreate(&c->t1));
     HIPOK(hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault));
+    HIPOK(hipHostMalloc((void**)&c->prof_pinned, MIRGE_PROF_PINNED_WORDS * 4, hipHostMallocDefault));
     *out = c.release();
     return 0;
 }
@@ -187,6 +236,10 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->prof_pinned) (void)hipHostFree(c->prof_pinned);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -333,7 +386,12 @@ extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {
 // ------------------------------------------------------------------------------------------
 // reads
 // ------------------------------------------------------------------------------------------
-static const int kGroupW[3] = {1, 2, 4};
+// Six read groups: width class (<=31, <=64, <=128 nt) x (no ambiguous call | has an N).  Reads with
+// an N are rare (~0.1 %); keeping them apart lets the big groups run without an nmask array and lets
+// the <=31-nt group collapse on a 64-bit key (sequence bits + length sentinel).
+#define MIRGE_NGROUPS 6
+static const int kGroupW[MIRGE_NGROUPS] = {1, 2, 4, 1, 2, 4};
+static inline int width_class(int64_t L) { return L <= 31 ? 0 : (L <= 64 ? 1 : 2); }
 
 struct ReadGroup {
     int W = 1;
@@ -352,10 +410,16 @@ struct mirge_reads {
     int64_t n = 0;
     int64_t total_bases = 0;
     int32_t n_samples = 0;  // 0: no count matrix attached
-    ReadGroup g[3];
+    ReadGroup g[MIRGE_NGROUPS];
     int32_t len_hist[MIRGE_MAX_READ_LEN + 1];  // lengths present (host), for table preparation
     bool hist_valid = false;
 };
+
+static int largest_group(const mirge_reads* R) {
+    int best = 0;
+    for (int gi = 1; gi < MIRGE_NGROUPS; gi++) if (R->g[gi].n > R->g[best].n) best = gi;
+    return best;
+}
 
 template <int W>
 static GroupView<W> view_of(const ReadGroup& g) {
@@ -389,7 +453,9 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
     auto R = std::make_unique<mirge_reads>();
     R->ctx = c; R->n = n;
     std::memset(R->len_hist, 0, sizeof(R->len_hist));
-    std::vector<uint32_t> idx[3];
+    std::vector<uint32_t> idx[MIRGE_NGROUPS];
+    bool is_acgt[256] = {false};
+    for (const char* q = "ACGTUacgtu"; *q; q++) is_acgt[(unsigned char)*q] = true;
     for (int64_t i = 0; i < n; i++) {
         int64_t L = off[i + 1] - off[i];
         if (L < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
@@ -397,7 +463,9 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
             return fail(-6, "read " + std::to_string(i) + " is " + std::to_string(L) + " nt; the limit is " +
                             std::to_string(MIRGE_MAX_READ_LEN));
         R->len_hist[L]++;
-        idx[L <= 32 ? 0 : (L <= 64 ? 1 : 2)].push_back((uint32_t)i);
+        bool amb = false;
+        for (int64_t b = off[i]; b < off[i + 1]; b++) amb |= !is_acgt[(unsigned char)ascii[b]];
+        idx[width_class(L) + (amb ? 3 : 0)].push_back((uint32_t)i);
     }
     R->hist_valid = true;
     R->total_bases = n ? off[n] - off[0] : 0;
@@ -405,14 +473,14 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
     uint8_t* dascii = nullptr; int64_t* doff = nullptr; uint32_t* dflags = nullptr;
     CHECK(dalloc(c, &dascii, (size_t)std::max<int64_t>(nbytes, 1)));
     CHECK(dalloc(c, &doff, (size_t)n + 1));
-    CHECK(dalloc(c, &dflags, 8));
+    CHECK(dalloc(c, &dflags, 16));
     std::vector<int64_t> rel((size_t)n + 1);
     for (int64_t i = 0; i <= n; i++) rel[(size_t)i] = off[i] - off[0];
     if (nbytes) HIPOK(hipMemcpyAsync(dascii, ascii + off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipMemcpyAsync(doff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemsetAsync(dflags, 0, 32, c->stream));
-    uint32_t* didx[3] = {nullptr, nullptr, nullptr};
-    for (int gi = 0; gi < 3; gi++) {
+    HIPOK(hipMemsetAsync(dflags, 0, 64, c->stream));
+    uint32_t* didx[MIRGE_NGROUPS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         ReadGroup& g = R->g[gi];
         g.W = kGroupW[gi];
         g.n = (uint32_t)idx[gi].size();
@@ -423,14 +491,14 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
         CHECK(dalloc(c, &g.orig, (size_t)g.n));
         HIPOK(hipMemcpyAsync(g.orig, idx[gi].data(), (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream));
         didx[gi] = g.orig;
-        if (gi == 0) launch_pack<1>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
-        else if (gi == 1) launch_pack<2>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
+        if (kGroupW[gi] == 1) launch_pack<1>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
+        else if (kGroupW[gi] == 2) launch_pack<2>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
         else launch_pack<4>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
     }
-    HIPOK(hipMemcpyAsync(c->pinned, dflags, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(c->pinned, dflags, 64, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));  // idx/rel host vectors are read by the async copies
     c->release(dascii); c->release(doff); c->release(dflags);
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         if (c->pinned[2 * gi + 1]) {
             mirge_reads_destroy(R.release());
             return fail(-7, "a read contains a character other than A/C/G/T/U/N");
@@ -447,7 +515,7 @@ extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* asci
     const int64_t n = R->n;
     int32_t* dlen = nullptr;
     CHECK(dalloc(c, &dlen, (size_t)std::max<int64_t>(n, 1)));
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ReadGroup& g = R->g[gi];
         if (!g.n) continue;
         LaunchScope ls(c, "k_scatter_len", g.n);
@@ -464,12 +532,12 @@ extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* asci
     CHECK(dalloc(c, &doff, (size_t)n + 1));
     CHECK(dalloc(c, &dout, (size_t)std::max<int64_t>(total, 1)));
     HIPOK(hipMemcpyAsync(doff, off_out, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ReadGroup& g = R->g[gi];
         if (!g.n) continue;
         LaunchScope ls(c, "k_unpack", g.n);
-        if (gi == 0) hipLaunchKernelGGL(k_unpack<1>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(g), doff, g.base, g.orig, dout);
-        else if (gi == 1) hipLaunchKernelGGL(k_unpack<2>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<2>(g), doff, g.base, g.orig, dout);
+        if (kGroupW[gi] == 1) hipLaunchKernelGGL(k_unpack<1>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(g), doff, g.base, g.orig, dout);
+        else if (kGroupW[gi] == 2) hipLaunchKernelGGL(k_unpack<2>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<2>(g), doff, g.base, g.orig, dout);
         else hipLaunchKernelGGL(k_unpack<4>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<4>(g), doff, g.base, g.orig, dout);
     }
     if (total) HIPOK(hipMemcpyAsync(ascii_out, dout, (size_t)total, hipMemcpyDeviceToHost, c->stream));
@@ -483,7 +551,7 @@ extern "C" int mirge_reads_set_counts(mirge_ctx* c, mirge_reads* R, const uint32
     HIPOK(hipSetDevice(c->device));
     // counts are in handle order; each group wants its rows contiguous -> gather on the host
     // through the group's orig list (small: U x S)
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         ReadGroup& g = R->g[gi];
         if (!g.n) continue;
         std::vector<uint32_t> horig(g.n);
@@ -504,58 +572,96 @@ extern "C" int mirge_reads_set_counts(mirge_ctx* c, mirge_reads* R, const uint32
 // ------------------------------------------------------------------------------------------
 // collapse
 // ------------------------------------------------------------------------------------------
+// Collapse runs in two phases so that the whole call synchronises with the host ONCE: phase A
+// (insert, head flags + block sums, scan) for every read group, one copy of {U per group, length
+// histogram of the uniques} to the host, then phase B (output allocation sized by U, scatter).
+struct CollapseTmp {
+    uint32_t *rep = nullptr, *firstj = nullptr, *cnt = nullptr, *slot_of = nullptr, *blocksum = nullptr;
+    KeySlot* slots = nullptr;
+    uint8_t* flag = nullptr;
+    const uint32_t* cnt_base = nullptr;
+    uint32_t cnt_stride = 1, nb = 0;
+};
+// dmeta: [0..5] U of each group, [8 .. 8+128] length histogram
+#define MIRGE_META_HIST 8
+#define MIRGE_META_WORDS (MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1)
+
+static const char* group_tag(int gi) {
+    static const char* t[MIRGE_NGROUPS] = {".w1", ".w2", ".w4", ".w1n", ".w2n", ".w4n"};
+    return t[gi];
+}
+
 template <int W>
-static int collapse_group(mirge_ctx* c, const ReadGroup& in, ReadGroup& out, const int32_t* dsample, int32_t S,
-                          uint32_t out_base, uint32_t* dhist) {
-    out.W = W; out.n = 0; out.base = out_base;
+static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseTmp& t, const int32_t* dsample,
+                            int32_t S, uint32_t* dmeta) {
     if (!in.n) return 0;
+    // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
+    const bool key_path = (W == 1) && !in.nmask && S == 1;
     uint32_t tsize = 1024;
-    while (tsize < 2ull * in.n) tsize <<= 1;
-    uint32_t *rep = nullptr, *firstj = nullptr, *cnt = nullptr, *slot_of = nullptr, *blocksum = nullptr, *dU = nullptr;
-    CHECK(dalloc(c, &rep, tsize));
-    CHECK(dalloc(c, &firstj, tsize));
-    CHECK(dalloc(c, &cnt, (size_t)tsize * S));
-    CHECK(dalloc(c, &slot_of, in.n));
+    while (tsize < (key_path ? in.n + in.n / 2 : 2ull * in.n)) tsize <<= 1;
     const uint32_t per_block = MIRGE_BLOCK * MIRGE_SCAN_ITEMS;
-    const uint32_t nb = (in.n + per_block - 1) / per_block;
-    CHECK(dalloc(c, &blocksum, nb));
-    CHECK(dalloc(c, &dU, 4));
-    HIPOK(hipMemsetAsync(rep, 0xFF, (size_t)tsize * 4, c->stream));
-    HIPOK(hipMemsetAsync(firstj, 0xFF, (size_t)tsize * 4, c->stream));
-    HIPOK(hipMemsetAsync(cnt, 0, (size_t)tsize * S * 4, c->stream));
+    t.nb = (in.n + per_block - 1) / per_block;
+    CHECK(dalloc(c, &t.slot_of, in.n));
+    CHECK(dalloc(c, &t.flag, (size_t)t.nb * per_block));
+    CHECK(dalloc(c, &t.blocksum, t.nb));
     GroupView<W> v = view_of<W>(in);
-    {
-        LaunchScope ls(c, W == 1 ? "k_collapse_insert.w1" : (W == 2 ? "k_collapse_insert.w2" : "k_collapse_insert.w4"), in.n);
-        hipLaunchKernelGGL(k_collapse_insert<W>, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->stream,
-                           v, rep, firstj, cnt, slot_of, tsize - 1, dsample, in.orig, in.base, S);
+    char name[48];
+    const uint32_t* first_base;
+    uint32_t first_stride;
+    if (key_path) {
+        CHECK(dalloc(c, &t.slots, tsize));
+        HIPOK(hipMemsetAsync(t.slots, 0, (size_t)tsize * sizeof(KeySlot), c->cur));
+        LaunchScope ls(c, "k_collapse_insert_key.w1", in.n);
+        hipLaunchKernelGGL(k_collapse_insert_key, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->cur,
+                           view_of<1>(in), t.slots, t.slot_of, tsize - 1);
+        first_base = reinterpret_cast<const uint32_t*>(t.slots) + 2; first_stride = 4;
+        t.cnt_base = reinterpret_cast<const uint32_t*>(t.slots) + 3; t.cnt_stride = 4;
+    } else {
+        CHECK(dalloc(c, &t.rep, tsize));
+        CHECK(dalloc(c, &t.firstj, tsize));
+        CHECK(dalloc(c, &t.cnt, (size_t)tsize * S));
+        HIPOK(hipMemsetAsync(t.rep, 0xFF, (size_t)tsize * 4, c->cur));
+        HIPOK(hipMemsetAsync(t.firstj, 0xFF, (size_t)tsize * 4, c->cur));
+        HIPOK(hipMemsetAsync(t.cnt, 0, (size_t)tsize * S * 4, c->cur));
+        std::snprintf(name, sizeof(name), "k_collapse_insert%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        hipLaunchKernelGGL(k_collapse_insert<W>, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->cur,
+                           v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S);
+        first_base = t.firstj; first_stride = 1;
+        t.cnt_base = t.cnt; t.cnt_stride = (uint32_t)S;
     }
     {
-        LaunchScope ls(c, "k_heads_blocksum", in.n);
-        hipLaunchKernelGGL(k_heads_blocksum, dim3(nb), dim3(MIRGE_BLOCK), 0, c->stream, slot_of, firstj, in.n, blocksum);
+        std::snprintf(name, sizeof(name), "k_heads_blocksum%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        hipLaunchKernelGGL(k_heads_blocksum, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, t.slot_of, first_base, first_stride,
+                           key_path ? 1u : 0u, in.n, in.len, t.flag, t.blocksum, dmeta + MIRGE_META_HIST);
     }
     {
-        LaunchScope ls(c, "k_scan_blocksums", nb);
-        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->stream, blocksum, nb, dU);
+        LaunchScope ls(c, "k_scan_blocksums", t.nb);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.blocksum, t.nb, dmeta + gi);
     }
-    HIPOK(hipMemcpyAsync(c->pinned, dU, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));  // U sizes the output arrays
-    const uint32_t U = c->pinned[0];
-    out.n = U;
-    CHECK(dalloc(c, &out.seq, (size_t)W * U));
-    CHECK(dalloc(c, &out.len, (size_t)U));
-    if (in.nmask) CHECK(dalloc(c, &out.nmask, (size_t)W * U));
-    CHECK(dalloc(c, &out.counts, (size_t)U * S));
-    CHECK(dalloc(c, &out.first, (size_t)U));
-    {
-        LaunchScope ls(c, W == 1 ? "k_collapse_scatter.w1" : (W == 2 ? "k_collapse_scatter.w2" : "k_collapse_scatter.w4"), in.n);
-        hipLaunchKernelGGL(k_collapse_scatter<W>, dim3(nb), dim3(MIRGE_BLOCK), 0, c->stream, v, slot_of, firstj, cnt,
-                           blocksum, dU, in.orig, in.base, S, out.seq, out.len, out.nmask, out.counts, out.first);
+    return 0;
+}
+
+template <int W>
+static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, int32_t S,
+                            uint32_t U, uint32_t out_base, const uint32_t* dmeta) {
+    out.W = W; out.n = U; out.base = out_base;
+    if (in.n) {
+        CHECK(dalloc(c, &out.seq, (size_t)W * U));
+        CHECK(dalloc(c, &out.len, (size_t)U));
+        if (in.nmask) CHECK(dalloc(c, &out.nmask, (size_t)W * U));
+        CHECK(dalloc(c, &out.counts, (size_t)U * S));
+        CHECK(dalloc(c, &out.first, (size_t)U));
+        char name[48];
+        std::snprintf(name, sizeof(name), "k_collapse_scatter%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        hipLaunchKernelGGL(k_collapse_scatter<W>, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, view_of<W>(in), t.slot_of,
+                           t.flag, t.cnt_base, t.cnt_stride, t.blocksum, dmeta + gi, in.orig, in.base, S, out.seq,
+                           out.len, out.nmask, out.counts, out.first);
     }
-    if (U) {
-        LaunchScope ls(c, "k_len_hist", U);
-        hipLaunchKernelGGL(k_len_hist, dim3(grid_for(c, U)), dim3(MIRGE_BLOCK), 0, c->stream, out.len, U, dhist);
-    }
-    c->release(rep); c->release(firstj); c->release(cnt); c->release(slot_of); c->release(blocksum); c->release(dU);
+    c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
+    c->defer(t.flag); c->defer(t.blocksum);
     return 0;
 }
 
@@ -572,31 +678,46 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
     }
     auto R = std::make_unique<mirge_reads>();
     R->ctx = c; R->n_samples = S;
-    uint32_t base = 0;
+    uint32_t* dmeta = nullptr;
+    CHECK(dalloc(c, &dmeta, MIRGE_META_WORDS));
+    HIPOK(hipMemsetAsync(dmeta, 0, MIRGE_META_WORDS * 4, c->stream));
+    CollapseTmp tmp[MIRGE_NGROUPS];
     int rc = 0;
-    uint32_t* dhist = nullptr;
-    CHECK(dalloc(c, &dhist, MIRGE_MAX_READ_LEN + 1));
-    HIPOK(hipMemsetAsync(dhist, 0, (MIRGE_MAX_READ_LEN + 1) * 4, c->stream));
-    for (int gi = 0; gi < 3 && rc == 0; gi++) {
-        if (gi == 0) rc = collapse_group<1>(c, raw->g[gi], R->g[gi], dsample, S, base, dhist);
-        else if (gi == 1) rc = collapse_group<2>(c, raw->g[gi], R->g[gi], dsample, S, base, dhist);
-        else rc = collapse_group<4>(c, raw->g[gi], R->g[gi], dsample, S, base, dhist);
-        base += R->g[gi].n;
+    const int big = largest_group(raw);
+    CHECK(stream_fork(c));
+    for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+        c->cur = gi == big ? c->stream : c->aux;
+        if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta);
+        else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta);
+        else rc = collapse_phase_a<4>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta);
     }
-    if (rc == 0) {
-        hipError_t e = hipMemcpyAsync(c->pinned, dhist, (MIRGE_MAX_READ_LEN + 1) * 4, hipMemcpyDeviceToHost, c->stream);
+    { int jr = stream_join(c); if (rc == 0) rc = jr; }
+    if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
+        hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(-2, std::string("length histogram: ") + hipGetErrorString(e));
-        else {
-            R->total_bases = 0;
-            for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
-                R->len_hist[L] = (int32_t)c->pinned[L];
-                R->total_bases += (int64_t)L * c->pinned[L];
-            }
-            R->hist_valid = true;
-        }
+        if (e != hipSuccess) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
     }
-    c->release(dsample); c->release(dhist);
+    uint32_t base = 0;
+    if (rc == 0) {
+        uint32_t U[MIRGE_NGROUPS];
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) U[gi] = c->pinned[gi];
+        R->total_bases = 0;
+        for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
+            R->len_hist[L] = (int32_t)c->pinned[MIRGE_META_HIST + L];
+            R->total_bases += (int64_t)L * c->pinned[MIRGE_META_HIST + L];
+        }
+        R->hist_valid = true;
+        rc = stream_fork(c);
+        for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+            c->cur = gi == big ? c->stream : c->aux;
+            if (kGroupW[gi] == 1) rc = collapse_phase_b<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            else if (kGroupW[gi] == 2) rc = collapse_phase_b<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            else rc = collapse_phase_b<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            base += R->g[gi].n;
+        }
+        { int jr = stream_join(c); if (rc == 0) rc = jr; }
+    }
+    c->release(dsample); c->release(dmeta);
     if (rc) { mirge_reads_destroy(R.release()); return rc; }
     R->n = base;
     *uniq = R.release();
@@ -610,7 +731,7 @@ extern "C" int mirge_collapse_fetch(mirge_ctx* c, const mirge_reads* U, uint32_t
     HIPOK(hipSetDevice(c->device));
     const int32_t S = U->n_samples;
     std::vector<uint32_t> tmp;
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ReadGroup& g = U->g[gi];
         if (!g.n) continue;
         if (g.orig) return fail(-1, "mirge_collapse_fetch: handle is not a collapse result");
@@ -641,7 +762,7 @@ struct mirge_result {
     mirge_ctx* ctx = nullptr;
     int64_t n = 0;
     int32_t n_pass = 0;
-    ResGroup g[3];
+    ResGroup g[MIRGE_NGROUPS];
     const mirge_reads* reads = nullptr;  // borrowed: orig/base mapping (must outlive the fetch)
 };
 
@@ -680,7 +801,7 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
 
 template <int W>
 static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const mirge_lib* const* libs,
-                         const mirge_policy* pol, int32_t n_pass, const ResolveTable& rt) {
+                         const mirge_policy* pol, int32_t n_pass, const ResolveTable& rt, const char* gtag) {
     out.n = rg.n;
     if (!rg.n) return 0;
     const uint32_t n = rg.n;
@@ -697,8 +818,8 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     CHECK(dalloc(c, &actA, (size_t)grid * cap));
     CHECK(dalloc(c, &actB, (size_t)grid * cap));
     CHECK(dalloc(c, &seg_n, (size_t)grid * (MIRGE_MAX_PASSES + 1)));
-    HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->stream));
-    HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->stream));
+    HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->cur));
+    HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->cur));
     GroupView<W> v = view_of<W>(rg);
     const uint32_t* act_in = nullptr;
     uint32_t* act_out = actA;
@@ -710,13 +831,13 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         MirgePolicy mp;
         std::memcpy(&mp, &pol[p], sizeof(mp));
         {
-            std::snprintf(name, sizeof(name), "k_pass[%d].w%d", (int)p, W);
+            std::snprintf(name, sizeof(name), "k_pass[%d]%s", (int)p, gtag);
             LaunchScope ls(c, name, 0.0);
             if (ls.rec >= 0) stage_of_pass.emplace_back(ls.rec, stage);
             const uint32_t* sn_in = seg_n + (size_t)grid * (stage > 0 ? stage - 1 : 0);
             uint32_t* sn_out = seg_n + (size_t)grid * stage;
 #define MIRGE_LAUNCH_PASS(SLOT)                                                                                   \
-    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, libs[p]->view(), mp, v, act_in, \
+    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, libs[p]->view(), mp, v, act_in, \
                        sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm)
             switch (p) {
                 case 0: MIRGE_LAUNCH_PASS(0); break;
@@ -738,21 +859,21 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         stage++;
     }
     {
-        std::snprintf(name, sizeof(name), "k_resolve.w%d", W);
+        std::snprintf(name, sizeof(name), "k_resolve%s", gtag);
         LaunchScope ls(c, name, n);
-        hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, rt, out.pass, out.pos, n, out.ref, out.off);
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->cur, rt, out.pass, out.pos, n, out.ref, out.off);
     }
     if (c->profiling && stage > 0) {  // units of a pass = reads it was handed = survivors of the stage before
-        std::vector<uint32_t> h((size_t)grid * stage);
-        HIPOK(hipMemcpyAsync(h.data(), seg_n, h.size() * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(hipStreamSynchronize(c->stream));
-        for (auto& sp : stage_of_pass) {
-            double u = n;
-            if (sp.second > 0) { u = 0; for (uint32_t b = 0; b < grid; b++) u += h[(size_t)grid * (sp.second - 1) + b]; }
-            c->recs[sp.first].units += u;
+        // copied now (stream-ordered), summed after the one synchronisation at the end of the call
+        const size_t words = (size_t)grid * stage;
+        if (c->prof_used + words <= MIRGE_PROF_PINNED_WORDS) {
+            uint32_t* dst = c->prof_pinned + c->prof_used;
+            HIPOK(hipMemcpyAsync(dst, seg_n, words * 4, hipMemcpyDeviceToHost, c->cur));
+            for (auto& sp : stage_of_pass) c->prof_pending.push_back(ProfUnits{sp.first, sp.second, grid, dst, (double)n});
+            c->prof_used += words;
         }
     }
-    c->release(actA); c->release(actB); c->release(seg_n);
+    c->defer(actA); c->defer(actB); c->defer(seg_n);
     return 0;
 }
 
@@ -766,11 +887,11 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     if (R->hist_valid) std::memcpy(hist, R->len_hist, sizeof(hist));
     else {
         std::memset(hist, 0, sizeof(hist));
-        for (int gi = 0; gi < 3; gi++) {
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
             const ReadGroup& g = R->g[gi];
             if (!g.n) continue;
             // conservative: every length the width group can hold is assumed present
-            int lo = gi == 0 ? 1 : (gi == 1 ? 33 : 65), hi = gi == 0 ? 32 : (gi == 1 ? 64 : 128);
+            int lo = kGroupW[gi] == 1 ? 1 : (kGroupW[gi] == 2 ? 32 : 65), hi = kGroupW[gi] == 1 ? 31 : (kGroupW[gi] == 2 ? 64 : 128);
             for (int L = lo; L <= hi; L++) hist[L] = 1;
         }
     }
@@ -788,11 +909,15 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
     int rc = 0;
-    for (int gi = 0; gi < 3 && rc == 0; gi++) {
-        if (gi == 0) rc = cascade_group<1>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt);
-        else if (gi == 1) rc = cascade_group<2>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt);
-        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt);
+    const int big = largest_group(R);
+    CHECK(stream_fork(c));
+    for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+        c->cur = gi == big ? c->stream : c->aux;
+        if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
+        else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
+        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
     }
+    { int jr = stream_join(c); if (rc == 0) rc = jr; }
     if (rc) { mirge_result_destroy(res.release()); return rc; }
     *out = res.release();
     return 0;
@@ -803,7 +928,7 @@ static int fetch_field(mirge_ctx* c, const mirge_result* res, T* host_out, T* Re
     if (!host_out || !res->n) return 0;
     T* dfull = nullptr;
     CHECK(dalloc(c, &dfull, (size_t)res->n));
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
         const ReadGroup& rg = res->reads->g[gi];
         if (!g.n) continue;
@@ -841,7 +966,7 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     unsigned long long* d = nullptr;
     CHECK(dalloc(c, &d, n_cls + 2 * n_tab));
     HIPOK(hipMemsetAsync(d, 0, (n_cls + 2 * n_tab) * 8, c->stream));
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
         if (!g.n) continue;
         LaunchScope ls(c, "k_join", g.n);

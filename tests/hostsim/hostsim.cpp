@@ -98,3 +98,17 @@ extern "C" int hostsim_cascade(const char* reads, const int64_t* roff, int64_t n
     }
     return 0;
 }
+
+// probe plan of a read of (trimmed) length L: out[4*q + {0,1,2,3}] = a1, k1, gap, k2
+extern "C" int hostsim_probe_plan(int32_t mode, int32_t mm, int32_t seedlen, int32_t L, int32_t K, int8_t* out) {
+    MirgePolicy p;
+    std::memset(&p, 0, sizeof(p));
+    p.mode = mode; p.mm = mm; p.seedlen = seedlen; p.maxtotal = mode == 0 ? 2 : mm;
+    const int n = mirge_probe_count(p, L, K);
+    for (int q = 0; q < n; q++) {
+        MirgeProbe pr;
+        mirge_probe_at(p, L, K, q, pr);
+        out[4 * q] = pr.a1; out[4 * q + 1] = pr.k1; out[4 * q + 2] = pr.gap; out[4 * q + 3] = pr.k2;
+    }
+    return n;
+}

@@ -103,7 +103,7 @@ def test_cascade_vs_oracle_ci_scale(ctx, ci_libs, ci_cascade):
     extra = []  # W=2 / W=4 width groups incl. the 128-nt maximum
     for key in ("mrna", "ncrna_others", "rrna"):
         lib = ci_libs.libs[key]
-        for L in list(rng.integers(51, 129, size=80)) + [64, 65, 128]:
+        for L in list(rng.integers(51, 129, size=80)) + [31, 32, 33, 64, 65, 128]:
             s = lib.seqs.get(int(rng.integers(0, len(lib))))
             if len(s) <= L:
                 continue
