@@ -32,6 +32,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (s
 ALGO_BYTES = {
     "k_collapse_insert": 9 + 4,      # read in, slot id out, per raw read
     "k_collapse_insert_key": 9 + 4,  # same, 64-bit-key table (<=31 nt, no N, one sample)
+    "k_part_hist": 9, "k_part_scatter": 9 + 12, "k_part_dedup": 12 + 1 + 4, "k_flags_blocksum": 1,
+    "k_part_prefix": 8,
     "k_heads_blocksum": 4 + 4 + 1,   # slot id + first-index in, head flag out, per raw read
     "k_collapse_scatter": 1 + 4 + 13,  # head flag + slot id in; key+len+count out (upper bound: per raw read)
     "k_pass": 4 + 9 + 5,             # active index + read in, annotation or survivor index out, per read handed to the pass
@@ -144,7 +146,7 @@ def main():
     kd = kernels[dom]
     achieved = algo_bytes(dom) * kd["units_per_launch"] / (kd["avg_ms"] * 1e-3) / 1e9
     stage_ms = {
-        "collapse": sum(v["total_ms"] for k, v in kernels.items() if "collapse" in k or "heads" in k or "scan" in k or "hist" in k) / args.steps,
+        "collapse": sum(v["total_ms"] for k, v in kernels.items() if "collapse" in k or "heads" in k or "scan" in k or "hist" in k or "k_part" in k or "flags" in k) / args.steps,
         "cascade": sum(v["total_ms"] for k, v in kernels.items() if k.startswith("k_pass") or k.startswith("k_resolve")) / args.steps,
         "join": sum(v["total_ms"] for k, v in kernels.items() if k == "k_join") / args.steps,
     }

@@ -220,6 +220,135 @@ __global__ void k_collapse_insert_key(GroupView<1> g, KeySlot* __restrict__ slot
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Partitioned collapse for the key path (<=31 nt, no N, one sample).  Scattered device-scope atomics
+// run at ~20 G/s chip-wide, which is what bounds k_collapse_insert_key (2.4 atomics per read).  Here
+// equal keys are first brought together: reads are partitioned by the top bits of their hash into
+// buckets of ~1-2 k reads (histogram per workgroup -> column prefix -> scatter, no global atomics),
+// then ONE workgroup de-duplicates a bucket entirely in LDS (ds_cmpst / ds_min / ds_add) and writes
+// each read's head flag and, for heads, the group's count.
+//   k_part_hist   : hist[g][b]  = reads of workgroup g's chunk that fall into bucket b
+//   k_part_prefix : off[g][b]   = sum over g' < g of hist[g'][b];  total[b] = column sum
+//   (k_scan_blocksums over total[] -> bucket_start[])
+//   k_part_scatter: part[bucket_start[b] + off[g][b] + local cursor] = {key, j} (one 16-B record)
+//   k_part_dedup  : per bucket, LDS table (key -> min j, count) -> flag[j], headcnt[j]
+// ------------------------------------------------------------------------------------------
+#define MIRGE_PART_CAP 4096  // LDS table slots per bucket (16 B each = 64 KiB)
+
+__device__ __forceinline__ unsigned long long read_key64(const GroupView<1>& g, uint32_t j) {
+    return g.seq[j] | (1ull << (2 * g.len[j]));
+}
+
+__global__ void k_part_hist(GroupView<1> g, uint32_t chunk, uint32_t bshift, uint32_t B, uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_h[];
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lds_h[b] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, g.n);
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x)
+        atomicAdd(&lds_h[(uint32_t)(mirge_mix64(read_key64(g, j)) >> bshift)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[(size_t)blockIdx.x * B + b] = lds_h[b];
+}
+
+__global__ void k_part_prefix(const uint32_t* __restrict__ hist, uint32_t G, uint32_t B, uint32_t* __restrict__ off,
+                              uint32_t* __restrict__ total) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t run = 0;
+#pragma unroll 8
+    for (uint32_t gq = 0; gq < G; gq++) {
+        const uint32_t v = hist[(size_t)gq * B + b];
+        off[(size_t)gq * B + b] = run;
+        run += v;
+    }
+    total[b] = run;
+}
+
+__global__ void k_part_scatter(GroupView<1> g, uint32_t chunk, uint32_t bshift, uint32_t B,
+                               const uint32_t* __restrict__ off, const uint32_t* __restrict__ bucket_start,
+                               uint4* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_c[];
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lds_c[b] = bucket_start[b] + off[(size_t)blockIdx.x * B + b];
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, g.n);
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+        const unsigned long long key = read_key64(g, j);
+        const uint32_t p = atomicAdd(&lds_c[(uint32_t)(mirge_mix64(key) >> bshift)], 1u);
+        part[p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), j, 0u);  // one 16-B store per read
+    }
+}
+
+__global__ void __launch_bounds__(MIRGE_BLOCK)
+k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket_start, uint8_t* __restrict__ flag, uint32_t* __restrict__ headcnt,
+             uint32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
+    uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + MIRGE_PART_CAP);
+    uint32_t* lds_cnt = lds_min + MIRGE_PART_CAP;
+    uint32_t& n_distinct = lds_cnt[MIRGE_PART_CAP];  // all LDS in the one dynamic region (keeps it 16-B aligned)
+    for (uint32_t i = threadIdx.x; i < MIRGE_PART_CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
+    if (threadIdx.x == 0) n_distinct = 0;
+    __syncthreads();
+    const uint32_t lo = bucket_start[blockIdx.x], hi = bucket_start[blockIdx.x + 1];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint4 rec = part[i];
+        const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
+        const uint32_t j = rec.z;
+        uint32_t s = (uint32_t)(mirge_mix64(key) >> 7) & (MIRGE_PART_CAP - 1);
+        while (true) {
+            unsigned long long cur = lds_k[s];
+            if (cur == 0ull) {
+                cur = atomicCAS(&lds_k[s], 0ull, key);
+                if (cur == 0ull && atomicAdd(&n_distinct, 1u) >= MIRGE_PART_CAP - 64) atomicOr(overflow, 1u);
+            }
+            if (cur == 0ull || cur == key) break;
+            if (*(volatile uint32_t*)&n_distinct >= MIRGE_PART_CAP - 32) break;  // table full: flagged, results discarded
+            s = (s + 1) & (MIRGE_PART_CAP - 1);
+        }
+        atomicMin(&lds_min[s], j);
+        atomicAdd(&lds_cnt[s], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint4 rec = part[i];
+        const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
+        const uint32_t j = rec.z;
+        uint32_t s = (uint32_t)(mirge_mix64(key) >> 7) & (MIRGE_PART_CAP - 1);
+        uint32_t guard = 0;
+        while (lds_k[s] != key && guard++ < MIRGE_PART_CAP) s = (s + 1) & (MIRGE_PART_CAP - 1);
+        const bool head = lds_min[s] == j;
+        flag[j] = head ? 1 : 0;
+        if (head) headcnt[j] = lds_cnt[s];
+    }
+}
+
+// block sums of a ready flag array (+ length histogram of the heads)
+__global__ void k_flags_blocksum(const uint8_t* __restrict__ flag, const uint8_t* __restrict__ len, uint32_t n,
+                                 uint32_t* __restrict__ blocksum, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t h[MIRGE_MAX_READ_LEN + 1];
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * 8) + threadIdx.x * 8;
+    uint32_t c = 0;
+    uint64_t packed = 0;
+    if (b0 + 8 <= n) packed = *reinterpret_cast<const uint64_t*>(flag + b0);
+    else for (int i = 0; i < 8; i++) if (b0 + i < n) packed |= (uint64_t)(flag[b0 + i] & 1) << (8 * i);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t j = b0 + i;
+        if ((packed >> (8 * i)) & 1ull) {
+            c++;
+            const uint32_t L = len[j];
+            atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
+        }
+    }
+    uint32_t total;
+    block_excl_scan(c, total, lds4);
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
 // heads: read j is the head of its group iff it is the group's smallest index.  `first` is addressed
 // as first[slot * stride] (inv: stored as 0xFFFFFFFF - index).  Writes flag[j] and per-block sums.
 #define MIRGE_SCAN_ITEMS 8  // per thread -> 2048 per block
@@ -305,7 +434,7 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
     for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
         if (heads & (1u << i)) {
             const uint32_t j = b0 + i;
-            const uint32_t s = slot_of[j];
+            const uint32_t s = slot_of ? slot_of[j] : j;  // partitioned path: counts are stored per head read
 #pragma unroll
             for (int w = 0; w < W; w++) {
                 useq[(size_t)w * U + rank] = g.seq[(size_t)w * g.n + j];

@@ -86,6 +86,8 @@ struct mirge_ctx {
     // pinned scratch for small D2H
     uint32_t* pinned = nullptr;
     uint32_t* prof_pinned = nullptr;
+    unsigned long long* join_pinned = nullptr;
+    size_t join_pinned_bytes = 0;
     size_t prof_used = 0;
     std::vector<ProfUnits> prof_pending;
 
@@ -237,6 +239,7 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->prof_pinned) (void)hipHostFree(c->prof_pinned);
+    if (c->join_pinned) (void)hipHostFree(c->join_pinned);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -581,8 +584,13 @@ struct CollapseTmp {
     uint8_t* flag = nullptr;
     const uint32_t* cnt_base = nullptr;
     uint32_t cnt_stride = 1, nb = 0;
+    // partitioned key path
+    bool partitioned = false;
+    uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr, *headcnt = nullptr;
+    uint4* part = nullptr;
 };
-// dmeta: [0..5] U of each group, [8 .. 8+128] length histogram
+// dmeta: [0..5] U of each group, [6] partition overflow flag, [8 .. 8+128] length histogram
+#define MIRGE_META_OVERFLOW 6
 #define MIRGE_META_HIST 8
 #define MIRGE_META_WORDS (MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1)
 
@@ -593,7 +601,7 @@ static const char* group_tag(int gi) {
 
 template <int W>
 static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseTmp& t, const int32_t* dsample,
-                            int32_t S, uint32_t* dmeta) {
+                            int32_t S, uint32_t* dmeta, bool force_atomic) {
     if (!in.n) return 0;
     // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
     const bool key_path = (W == 1) && !in.nmask && S == 1;
@@ -608,6 +616,55 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseT
     char name[48];
     const uint32_t* first_base;
     uint32_t first_stride;
+    if (key_path && !force_atomic && in.n >= 65536) {
+        // partition by hash -> de-duplicate each bucket in LDS: no global atomics (see mirge_kernels.hpp)
+        t.partitioned = true;
+        uint32_t B = 64;
+        while (B < 8192 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket
+        int lg = 0; while ((1u << lg) < B) lg++;
+        const uint32_t bshift = 64 - lg;
+        const uint32_t G = std::min<uint32_t>(256, (in.n + 2047) / 2048);
+        uint32_t chunk = (in.n + G - 1) / G;
+        chunk = (chunk + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
+        CHECK(dalloc(c, &t.hist, (size_t)G * B));
+        CHECK(dalloc(c, &t.off, (size_t)G * B));
+        CHECK(dalloc(c, &t.btotal, (size_t)B + 1));
+        CHECK(dalloc(c, &t.part, (size_t)in.n));
+        CHECK(dalloc(c, &t.headcnt, (size_t)in.n));
+        GroupView<1> v1 = view_of<1>(in);
+        {
+            LaunchScope ls(c, "k_part_hist.w1", in.n);
+            hipLaunchKernelGGL(k_part_hist, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, v1, chunk, bshift, B, t.hist);
+        }
+        {
+            LaunchScope ls(c, "k_part_prefix.w1", (double)G * B);
+            hipLaunchKernelGGL(k_part_prefix, dim3((B + 63) / 64), dim3(64), 0, c->cur, t.hist, G, B, t.off, t.btotal);
+        }
+        {
+            LaunchScope ls(c, "k_scan_blocksums", B);
+            hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.btotal, B, t.btotal + B);
+        }
+        {
+            LaunchScope ls(c, "k_part_scatter.w1", in.n);
+            hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, v1, chunk, bshift, B, t.off, t.btotal, t.part);
+        }
+        {
+            LaunchScope ls(c, "k_part_dedup.w1", in.n);
+            hipLaunchKernelGGL(k_part_dedup, dim3(B), dim3(MIRGE_BLOCK), MIRGE_PART_CAP * 16 + 16, c->cur, t.part, t.btotal, t.flag, t.headcnt, dmeta + MIRGE_META_OVERFLOW);
+        }
+        {
+            LaunchScope ls(c, "k_flags_blocksum.w1", in.n);
+            hipLaunchKernelGGL(k_flags_blocksum, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, t.flag, in.len, in.n, t.blocksum,
+                               dmeta + MIRGE_META_HIST);
+        }
+        {
+            LaunchScope ls(c, "k_scan_blocksums", t.nb);
+            hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.blocksum, t.nb, dmeta + gi);
+        }
+        t.cnt_base = t.headcnt; t.cnt_stride = 1;
+        c->defer(t.slot_of); t.slot_of = nullptr;  // scatter indexes the counts by read
+        return 0;
+    }
     if (key_path) {
         CHECK(dalloc(c, &t.slots, tsize));
         HIPOK(hipMemsetAsync(t.slots, 0, (size_t)tsize * sizeof(KeySlot), c->cur));
@@ -660,9 +717,14 @@ static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
                            t.flag, t.cnt_base, t.cnt_stride, t.blocksum, dmeta + gi, in.orig, in.base, S, out.seq,
                            out.len, out.nmask, out.counts, out.first);
     }
+    return 0;  // the temporaries go back to the pool in mirge_collapse, after the join
+}
+
+static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
     c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
     c->defer(t.flag); c->defer(t.blocksum);
-    return 0;
+    c->defer(t.hist); c->defer(t.off); c->defer(t.btotal); c->defer(t.part); c->defer(t.headcnt);
+    t = CollapseTmp();
 }
 
 extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
@@ -680,22 +742,36 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
     R->ctx = c; R->n_samples = S;
     uint32_t* dmeta = nullptr;
     CHECK(dalloc(c, &dmeta, MIRGE_META_WORDS));
-    HIPOK(hipMemsetAsync(dmeta, 0, MIRGE_META_WORDS * 4, c->stream));
     CollapseTmp tmp[MIRGE_NGROUPS];
     int rc = 0;
     const int big = largest_group(raw);
-    CHECK(stream_fork(c));
-    for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
-        c->cur = gi == big ? c->stream : c->aux;
-        if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta);
-        else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta);
-        else rc = collapse_phase_a<4>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta);
-    }
-    { int jr = stream_join(c); if (rc == 0) rc = jr; }
-    if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
-        hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
+    // attempt 0 may use the partitioned LDS path; if one of its buckets overflows its LDS table
+    // (pathological hash skew) everything is redone with the global-atomic tables
+    for (int attempt = 0; attempt < 2 && rc == 0; attempt++) {
+        hipError_t e0 = hipMemsetAsync(dmeta, 0, MIRGE_META_WORDS * 4, c->stream);
+        if (e0 != hipSuccess) { rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e0)); break; }
+        rc = stream_fork(c);
+        for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
+            // small groups are queued first: their short kernels get onto the GPU before the big
+            // group's traffic saturates the memory system
+            const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;
+            c->cur = gi == big ? c->stream : c->aux;
+            if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
+            else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
+            else rc = collapse_phase_a<4>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
+        }
+        { int jr = stream_join(c); if (rc == 0) rc = jr; }
+        if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
+            hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
+        }
+        if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt == 0) {
+            for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
+            c->flush_deferred();
+            continue;
+        }
+        break;
     }
     uint32_t base = 0;
     if (rc == 0) {
@@ -717,6 +793,8 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
     }
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
+    c->flush_deferred();
     c->release(dsample); c->release(dmeta);
     if (rc) { mirge_reads_destroy(R.release()); return rc; }
     R->n = base;
@@ -911,7 +989,8 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     int rc = 0;
     const int big = largest_group(R);
     CHECK(stream_fork(c));
-    for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+    for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
+        const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;  // small groups first (see mirge_collapse)
         c->cur = gi == big ? c->stream : c->aux;
         if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
         else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
@@ -973,12 +1052,21 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
         hipLaunchKernelGGL(k_join, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, g.pass, g.ref,
                            U->g[gi].counts, g.n, S, P, exact_pass, iso_pass, d, d + n_cls, d + n_cls + n_tab);
     }
-    HIPOK(hipMemcpyAsync(class_sums, d, n_cls * 8, hipMemcpyDeviceToHost, c->stream));
-    if (n_mirna) {
-        HIPOK(hipMemcpyAsync(exact, d + n_cls, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(hipMemcpyAsync(iso, d + n_cls + n_tab, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
+    // one device-to-host copy through pinned memory for all three tables (they are contiguous)
+    const size_t words = n_cls + 2 * n_tab;
+    if (words * 8 > c->join_pinned_bytes) {
+        if (c->join_pinned) (void)hipHostFree(c->join_pinned);
+        c->join_pinned = nullptr; c->join_pinned_bytes = 0;
+        HIPOK(hipHostMalloc((void**)&c->join_pinned, words * 8 * 2, hipHostMallocDefault));
+        c->join_pinned_bytes = words * 8 * 2;
     }
+    HIPOK(hipMemcpyAsync(c->join_pinned, d, words * 8, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
+    std::memcpy(class_sums, c->join_pinned, n_cls * 8);
+    if (n_mirna) {
+        std::memcpy(exact, c->join_pinned + n_cls, (size_t)n_mirna * S * 8);
+        std::memcpy(iso, c->join_pinned + n_cls + n_tab, (size_t)n_mirna * S * 8);
+    }
     c->drain();
     c->release(d);
     return 0;
@@ -1012,12 +1100,21 @@ extern "C" int mirge_count_join_host(mirge_ctx* c, const int8_t* pass, const int
         hipLaunchKernelGGL(k_join, dim3(grid_for(c, (size_t)n)), dim3(MIRGE_BLOCK), 0, c->stream, dp, dr, dc, (uint32_t)n,
                            S, P, exact_pass, iso_pass, d, d + n_cls, d + n_cls + n_tab);
     }
-    HIPOK(hipMemcpyAsync(class_sums, d, n_cls * 8, hipMemcpyDeviceToHost, c->stream));
-    if (n_mirna) {
-        HIPOK(hipMemcpyAsync(exact, d + n_cls, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPOK(hipMemcpyAsync(iso, d + n_cls + n_tab, (size_t)n_mirna * S * 8, hipMemcpyDeviceToHost, c->stream));
+    // one device-to-host copy through pinned memory for all three tables (they are contiguous)
+    const size_t words = n_cls + 2 * n_tab;
+    if (words * 8 > c->join_pinned_bytes) {
+        if (c->join_pinned) (void)hipHostFree(c->join_pinned);
+        c->join_pinned = nullptr; c->join_pinned_bytes = 0;
+        HIPOK(hipHostMalloc((void**)&c->join_pinned, words * 8 * 2, hipHostMallocDefault));
+        c->join_pinned_bytes = words * 8 * 2;
     }
+    HIPOK(hipMemcpyAsync(c->join_pinned, d, words * 8, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
+    std::memcpy(class_sums, c->join_pinned, n_cls * 8);
+    if (n_mirna) {
+        std::memcpy(exact, c->join_pinned + n_cls, (size_t)n_mirna * S * 8);
+        std::memcpy(iso, c->join_pinned + n_cls + n_tab, (size_t)n_mirna * S * 8);
+    }
     c->drain();
     c->release(d); c->release(dp); c->release(dr); c->release(dc);
     return 0;
