@@ -752,8 +752,9 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
         if (e0 != hipSuccess) { rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e0)); break; }
         rc = stream_fork(c);
         for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
-            // small groups are queued first: their short kernels get onto the GPU before the big
-            // group's traffic saturates the memory system
+            // small groups are queued first (measured): their short kernels get onto the GPU before the
+            // big group's 2048-workgroup launches fill every CU; queued after it, each of their ~30
+            // small kernels waits for CUs to drain and the join at the end waits for them (5.3 vs 3.8 ms)
             const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;
             c->cur = gi == big ? c->stream : c->aux;
             if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
