@@ -52,6 +52,62 @@ def algo_bytes(name):
     return (ALGO_BYTES["k_pass"] if base.startswith("k_pass") else ALGO_BYTES.get(base, 0)) + extra
 
 
+def rocprof_symbol(rec_name):
+    """profile record 'k_pass[8].w1' -> rocprofv3 kernel name fragment 'k_pass<1, 8>'"""
+    base, _, w = rec_name.partition(".w")
+    w = w.rstrip("n") or "1"
+    if base.startswith("k_pass["):
+        return f"k_pass<{w}, {int(base[7:-1])}>"
+    if base in ("k_collapse_insert", "k_collapse_scatter"):
+        return f"{base}<{w}>"
+    return base + "("
+
+
+def pmc_traffic(args, rec_name):
+    """HBM bytes per launch of one kernel from the PMC counters, as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (no trace domains), kB units, and the gfx950
+    correction (FETCH_SIZE counts 128-B requests as 64 B -> x2).  Child processes; None on any failure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return None
+    # never nest: under a profiler its preloaded tool library would be inherited by the children
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
+    frag = rocprof_symbol(rec_name)
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mirge_pmc_", dir="/tmp")
+        # rocprofv3 is a python script: run it with this interpreter (no '#!/usr/bin/env' hop)
+        cmd = [sys.executable, rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--pmc", "0",
+               "--reads", str(args.reads), "--scale", args.scale, "--workload", args.workload]
+        try:
+            subprocess.run(cmd, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == ctr and frag in r["Kernel_Name"]:
+                            vals.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+            if not vals:
+                return None
+            gmax = max(g for g, _ in vals)  # the big read group's launches (the N / long-read groups share the symbol)
+            sel = [v for g, v in vals if g == gmax]
+            out[ctr] = sum(sel) / len(sel)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"fetch_kb_raw": out["FETCH_SIZE"], "write_kb": out["WRITE_SIZE"],
+            "bytes": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +118,8 @@ def main():
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--pmc", type=int, default=1,
+                    help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,6 +236,21 @@ def main():
         "setup_s": round(t_setup, 1),
     }
 
+    # ---------------- PCIe-inclusive rate (never `value`): host ASCII reads in, per-read annotation + counts out
+    if rank == 0:
+        t = time.perf_counter()
+        r_h = _ffi.DeviceReads.pack(ctx, reads)
+        u_h = r_h.collapse()
+        res_h = casc.run(u_h)
+        ann = res_h.fetch()
+        cnt_h, first_h = u_h.counts()
+        _ffi.count_join(ctx, u_h, res_h, EXACT_PASS, ISO_PASS if n_pass > ISO_PASS else -2, n_mirna)
+        dt = time.perf_counter() - t
+        out["host_buffer_path"] = {"M_reads_per_s": round(args.reads / dt / 1e6, 2), "ms": round(dt * 1e3, 2),
+                                   "note": "ASCII reads + offsets over PCIe, 2-bit pack on the GPU, annotation (10 B/unique) "
+                                           "and counts back to numpy; single pass, not part of `value`"}
+        res_h.close(); u_h.close(); r_h.close()
+
     # ---------------- CPU baseline (rank 0, N = 1): the oracle on a bounded sample, and parity on it
     if rank == 0 and n_gpus == 1 and args.cpu_baseline:
         import oracle
@@ -216,6 +289,17 @@ def main():
         out["parity_on_cpu_sample"] = bool(np.array_equal(cls_g[:, 0], cls_o)) and len(u_g) == len(u2)
         res.close(); u_g.close(); r2.close()
 
+    if rank == 0 and n_gpus == 1 and args.pmc:
+        t = pmc_traffic(args, dom)
+        if t is not None:
+            out["roofline"]["traffic"] = round(t["bytes"], 1)
+            out["roofline"]["traffic_detail"] = {
+                "unit": "bytes per launch", "FETCH_SIZE_kB_raw": round(t["fetch_kb_raw"], 1),
+                "WRITE_SIZE_kB": round(t["write_kb"], 1),
+                "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B; "
+                           "calibrated for wide streaming reads only, so an upper bound for this kernel's 16-B random reads)",
+                "algorithmic_bytes_per_launch": round(algo_bytes(dom) * kd["units_per_launch"], 1),
+            }
     if rank == 0:
         print(json.dumps(out))
     raw.close()
