@@ -127,10 +127,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # test hooks (tests/test_gpu_parity.py runs two ranks on the one GPU of the test box):
+    # MIRGE_BENCH_SHARE_GPU=1 puts every rank on device 0, MIRGE_BENCH_BACKEND=gloo keeps RCCL out of it
+    backend = os.environ.get("MIRGE_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("MIRGE_BENCH_SHARE_GPU") else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world if world > 1 else args.gpus
     if world == 1 and args.gpus > 1:
         print("bench.py: --gpus > 1 needs torch.distributed.run; running rank 0 only", file=sys.stderr)
@@ -148,7 +155,7 @@ def main():
     # ---------------- inputs (not timed): libraries indexed in HBM, reads packed in HBM
     t_setup = time.perf_counter()
     sl = synth.make_libraries(seed=20260101, scale=args.scale)
-    ctx = _ffi.Context(local_rank)
+    ctx = _ffi.Context(dev_index)
     n_pass = 1 if args.workload == "c2" else 9
     libs = {"mirna": sl.libs["mirna"]} if args.workload == "c2" else sl.libs
     casc = Cascade(ctx, libs, n_pass=n_pass)
@@ -188,7 +195,7 @@ def main():
     recs = ctx.profile_records()
     ctx.profile(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3

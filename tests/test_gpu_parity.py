@@ -252,3 +252,23 @@ def test_properties_at_scale(ctx):
     p0 = c2.annotate(sub)
     assert np.array_equal(p0[0] == 0, g[0] == 0) and np.array_equal(p0[1][p0[0] == 0], g[1][g[0] == 0])
     res.close(); uniq.close(); raw.close(); casc.close(); c2.close()
+
+
+def test_bench_two_ranks_share_the_gpu(tmp_path):
+    """The N > 1 code path of bench.py (rank-specific samples, barrier, max-over-ranks time, rank-0
+    JSON) with two ranks on the single GPU of the test box (gloo for the barrier; the driver's real
+    multi-GPU runs use RCCL, one GPU per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, MIRGE_BENCH_SHARE_GPU="1", MIRGE_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--reads", "300000", "--scale", "ci", "--cpu-baseline", "0", "--pmc", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
