@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--pmc", type=int, default=1,
                     help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()
@@ -182,9 +182,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):  # builds the k-mer tables on first use, warms the buffer pool
+    # warm-up: builds the probe tables on first use and warms the buffer pool; its last two steps run
+    # with every launch bracketed by HIP events -> the per-kernel table and the dominant kernel
+    n_prof = min(2, args.warmup) if args.warmup else 1
+    for _ in range(max(args.warmup - n_prof, 0)):
         step()
     ctx.profile(True)
+    ctx.profile_only("")
+    ctx.profile_reset()
+    for _ in range(n_prof):
+        step()
+    recs_all = ctx.profile_records()
+    table = {name: dict(launches=l, avg_ms=ms / l, total_ms=ms, units_per_launch=u / l) for name, l, ms, u in recs_all if l}
+    dom = max(table, key=lambda k: table[k]["total_ms"])
+    # timed region: only the dominant kernel stays bracketed (two events per launch; bracketing
+    # all ~90 launches of a step costs ~0.4 ms of a ~3 ms step)
+    ctx.profile_only(dom.split(".")[0] + "." if "." in dom else dom)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -194,6 +207,7 @@ def main():
     elapsed = time.perf_counter() - t0
     recs = ctx.profile_records()
     ctx.profile(False)
+    ctx.profile_only("")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -201,19 +215,18 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_gpus * args.reads / (elapsed / args.steps) / 1e6
 
-    # ---------------- per-kernel accounting (HIP events recorded on the ctx stream in the timed region)
-    kernels = {}
-    for name, launches, ms, units in recs:
-        if launches == 0:
-            continue
-        kernels[name] = dict(launches=launches, avg_ms=ms / launches, total_ms=ms, units_per_launch=units / launches)
-    dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
-    kd = kernels[dom]
+    # ---------------- per-kernel accounting
+    # `kernels` (all launches bracketed) comes from the profiled warm-up steps; the dominant kernel's
+    # roofline numbers come from the HIP events recorded inside the timed region
+    kernels = table
+    timed = {name: dict(launches=l, avg_ms=ms / l, total_ms=ms, units_per_launch=u / l) for name, l, ms, u in recs if l}
+    kd = timed.get(dom) or table[dom]
     achieved = algo_bytes(dom) * kd["units_per_launch"] / (kd["avg_ms"] * 1e-3) / 1e9
+    n_tab_steps = n_prof
     stage_ms = {
-        "collapse": sum(v["total_ms"] for k, v in kernels.items() if "collapse" in k or "heads" in k or "scan" in k or "hist" in k or "k_part" in k or "flags" in k) / args.steps,
-        "cascade": sum(v["total_ms"] for k, v in kernels.items() if k.startswith("k_pass") or k.startswith("k_resolve")) / args.steps,
-        "join": sum(v["total_ms"] for k, v in kernels.items() if k == "k_join") / args.steps,
+        "collapse": sum(v["total_ms"] for k, v in kernels.items() if "collapse" in k or "heads" in k or "scan" in k or "hist" in k or "k_part" in k or "flags" in k) / n_tab_steps,
+        "cascade": sum(v["total_ms"] for k, v in kernels.items() if k.startswith("k_pass") or k.startswith("k_resolve")) / n_tab_steps,
+        "join": sum(v["total_ms"] for k, v in kernels.items() if k == "k_join") / n_tab_steps,
     }
     U = state["U"]
     out = {
@@ -231,12 +244,15 @@ def main():
         },
         "collapsed_reads_per_s_M": round(n_gpus * U / (stage_ms["cascade"] * 1e-3) / 1e6, 3) if stage_ms["cascade"] else None,
         "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+        "stage_ms_note": "sums of per-kernel HIP-event times from the profiled warm-up steps; kernels of the small read "
+                         "groups overlap the big group's on a second stream, so the sums exceed ms_per_step",
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
             "algorithmic_bytes_per_unit": algo_bytes(dom), "units_per_launch": round(kd["units_per_launch"], 1),
             "avg_launch_ms": round(kd["avg_ms"], 5), "launches": kd["launches"],
-            "note": "latency-bound random-access integer kernel; HBM fraction reported as the brief requires",
+            "note": "latency / random-sector-bound integer kernel; HBM fraction reported as the brief requires; "
+                    "timed with HIP events on its launch stream inside the timed region",
         },
         "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5),
                         "units_per_launch": round(v["units_per_launch"], 1)} for k, v in sorted(kernels.items())},
@@ -266,6 +282,7 @@ def main():
         libs_o = [(sl.libs[PASSES[p][1]].seqs.data, sl.libs[PASSES[p][1]].seqs.offsets) for p in range(n_pass)]
 
         def cpu_run(m):
+            oracle.build_seconds(reset=True)
             t = time.perf_counter()
             sub_off = reads.offsets[: m + 1]
             sub_data = reads.data[: sub_off[-1]]
@@ -274,18 +291,16 @@ def main():
             u = FlatSeqs(sub_data, sub_off).take(first)
             ps, ref, off, mm = oracle.cascade(u.data, u.offsets, libs_o, n_pass=n_pass, indexed=True, threads=threads)
             cls = np.array([cnt[ps == p].sum() for p in range(n_pass)], dtype=np.int64)
-            return time.perf_counter() - t, cls, u
+            wall = time.perf_counter() - t
+            return wall, wall - oracle.build_seconds(), cls, u
 
-        m1 = max(1000, min(args.cpu_sample // 4, args.reads))
-        m2 = max(m1 + 1, min(args.cpu_sample, args.reads))
-        t1, _, _ = cpu_run(m1)
-        t2, cls_o, u2 = cpu_run(m2)
-        # marginal rate: the fixed cost (the oracle's k-mer tables, its "bowtie-build") cancels
-        rate = (m2 - m1) / max(t2 - t1, 1e-9) / 1e6
+        m2 = max(1000, min(args.cpu_sample, args.reads))
+        wall, work, cls_o, u2 = cpu_run(m2)
         out["cpu_baseline"] = {
-            "value": round(rate, 4), "unit": "M reads/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (C restatement, OpenMP) on the first {m1} and {m2} raw reads of the same sample; "
-                      f"marginal rate (t({m2})-t({m1})), index construction excluded; wall {t1:.1f}s + {t2:.1f}s",
+            "value": round(m2 / max(work, 1e-9) / 1e6, 4), "unit": "M reads/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (C restatement, OpenMP {threads} threads) on the first {m2} raw reads of the same sample: "
+                      f"collapse + 9-pass cascade + class sums, {work:.2f} s; its k-mer table construction "
+                      f"({wall - work:.2f} s, the oracle's 'bowtie-build') is excluded",
         }
         # live parity on the sample: per-class counts, GPU vs oracle
         sub = reads.take(np.arange(m2))

@@ -119,6 +119,8 @@ int mirge_count_join_host(mirge_ctx* ctx, const int8_t* pass, const int32_t* ref
 int mirge_ctx_timer_start(mirge_ctx* ctx);
 int mirge_ctx_timer_stop(mirge_ctx* ctx, double* ms_out);
 int mirge_ctx_profile_enable(mirge_ctx* ctx, int32_t on);
+/* record only launches whose name contains `substr` (NULL or "" = every launch) */
+int mirge_ctx_profile_only(mirge_ctx* ctx, const char* substr);
 int mirge_ctx_profile_reset(mirge_ctx* ctx);
 int32_t mirge_ctx_profile_count(mirge_ctx* ctx);
 int mirge_ctx_profile_get(mirge_ctx* ctx, int32_t i, char* name_out, int32_t name_cap,

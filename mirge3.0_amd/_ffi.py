@@ -25,7 +25,7 @@ EXPORTS = [
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
-    "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
+    "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
 
@@ -36,6 +36,7 @@ class MirgePolicy(C.Structure):
 
 
 _lib = None
+_live = []  # weak references to every wrapper, closed in dependency order at interpreter exit
 
 
 def load() -> C.CDLL:
@@ -55,6 +56,29 @@ def load() -> C.CDLL:
         getattr(lib, name).restype = None
     _lib = lib
     return lib
+
+
+def _track(obj):
+    import weakref
+    _live.append(weakref.ref(obj))
+
+
+def _shutdown():
+    """Close device handles before the interpreter and the HIP runtime tear down: result/read sets,
+    then libraries, then contexts (a handle freed after its context is gone would crash at exit)."""
+    objs = [r() for r in _live]
+    objs = [o for o in objs if o is not None]
+    for kind in (CascadeResult, DeviceReads, DeviceLibrary, Context):
+        for o in objs:
+            if isinstance(o, kind):
+                try:
+                    o.close()
+                except Exception:
+                    pass
+
+
+import atexit  # noqa: E402
+atexit.register(_shutdown)
 
 
 def _check(rc: int, what: str) -> None:
@@ -77,6 +101,7 @@ class Context:
         self._h = C.c_void_p()
         _check(lib.mirge_ctx_create(C.c_int(device), C.c_void_p(stream), C.byref(self._h)), "mirge_ctx_create")
         self.device = device
+        _track(self)
 
     def close(self):
         if self._h:
@@ -104,6 +129,10 @@ class Context:
     def profile(self, on: bool):
         _check(load().mirge_ctx_profile_enable(self._h, C.c_int32(1 if on else 0)), "profile_enable")
 
+    def profile_only(self, substr: str = ""):
+        """bracket only the launches whose name contains ``substr`` ('' = all)"""
+        _check(load().mirge_ctx_profile_only(self._h, substr.encode()), "profile_only")
+
     def profile_reset(self):
         _check(load().mirge_ctx_profile_reset(self._h), "profile_reset")
 
@@ -130,6 +159,7 @@ class DeviceLibrary:
         self._h = C.c_void_p()
         _check(load().mirge_lib_create(ctx._h, _p(data), _p(off), C.c_int64(len(seqs)), C.byref(self._h)),
                "mirge_lib_create")
+        _track(self)
 
     @property
     def n_refs(self) -> int:
@@ -160,6 +190,7 @@ class DeviceReads:
     def __init__(self, ctx: Context, handle: C.c_void_p):
         self.ctx = ctx
         self._h = handle
+        _track(self)
 
     @staticmethod
     def pack(ctx: Context, reads: FlatSeqs) -> "DeviceReads":
@@ -222,6 +253,7 @@ class CascadeResult:
 
     def __init__(self, ctx: Context, handle: C.c_void_p, reads: DeviceReads, n_pass: int):
         self.ctx, self._h, self.reads, self.n_pass = ctx, handle, reads, n_pass
+        _track(self)
 
     def fetch(self):
         """(pass int8, ref int32, off int32, mm int8) in the read set's order; -1 = unannotated."""

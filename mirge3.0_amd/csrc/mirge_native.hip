@@ -78,6 +78,7 @@ struct mirge_ctx {
     size_t pool_bytes = 0;
     // profiler
     bool profiling = false;
+    std::string prof_only;  // non-empty: only launches whose name contains it are bracketed
     std::vector<ProfRec> recs;
     std::unordered_map<std::string, int> rec_of;
     std::vector<PendingEvt> pending;
@@ -160,6 +161,7 @@ struct LaunchScope {
     mirge_ctx* c; int rec = -1; hipEvent_t a = nullptr, b = nullptr;
     LaunchScope(mirge_ctx* ctx, const char* name, double units) : c(ctx) {
         if (!c->profiling) return;
+        if (!c->prof_only.empty() && !std::strstr(name, c->prof_only.c_str())) return;
         rec = c->rec_index(name);
         c->recs[rec].launches++;
         c->recs[rec].units += units;
@@ -272,6 +274,11 @@ extern "C" int mirge_ctx_timer_stop(mirge_ctx* c, double* ms_out) {
 extern "C" int mirge_ctx_profile_enable(mirge_ctx* c, int32_t on) {
     if (!c) return fail(-1, "ctx is NULL");
     c->profiling = on != 0;
+    return 0;
+}
+extern "C" int mirge_ctx_profile_only(mirge_ctx* c, const char* substr) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->prof_only = substr ? substr : "";
     return 0;
 }
 extern "C" int mirge_ctx_profile_reset(mirge_ctx* c) {

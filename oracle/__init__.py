@@ -76,7 +76,13 @@ def _lib():
     so.oracle_cascade.restype = C.c_int
     so.oracle_collapse.restype = C.c_int64
     so.oracle_align_one.restype = C.c_int
+    so.oracle_build_seconds.restype = C.c_double
     return so
+
+
+def build_seconds(reset: bool = False) -> float:
+    """Seconds the C cascade spent constructing its k-mer tables since the last reset."""
+    return float(_lib().oracle_build_seconds(C.c_int(1 if reset else 0)))
 
 
 def _policy(d: dict) -> _Policy:
