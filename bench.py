@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--pmc", type=int, default=1,
                     help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()

@@ -113,7 +113,19 @@ def test_cascade_vs_oracle_ci_scale(ctx, ci_libs, ci_cascade):
                 q = int(rng.integers(0, len(x)))
                 x[q] = "ACGT"[("ACGT".index(x[q]) + 1) % 4] if x[q] in "ACGT" else "A"
             extra.append("".join(x))
-    allr = FlatSeqs.from_list(reads.to_list() + extra + ["T" * 16, "T" * 40, "A" * 16, "ACGTN" * 4])
+    short = []  # below the default --minimum-length: 1..15 nt, with and without a T tail
+    for key in ("mirna", "pre_trna", "mature_trna", "snorna", "mrna"):
+        lib = ci_libs.libs[key]
+        for L in range(1, 16):
+            for _ in range(6):
+                s = lib.seqs.get(int(rng.integers(0, len(lib))))
+                a = int(rng.integers(0, len(s) - L))
+                x = list(s[a:a + L])
+                if rng.random() < 0.4 and x[0] in "ACGT":
+                    q = int(rng.integers(0, L)); x[q] = "ACGT"[("ACGT".index(x[q]) + 1) % 4] if x[q] in "ACGT" else "A"
+                short += ["".join(x), "".join(x) + "T" * int(rng.integers(3, 7))]
+    short += ["A", "T", "TTT", "TTTT", "ATTT", "N", "NNNN", "ACGTTTT", "G" * 15, "AC" * 7]
+    allr = FlatSeqs.from_list(reads.to_list() + extra + short + ["T" * 16, "T" * 40, "A" * 16, "ACGTN" * 4])
     g = ci_cascade.annotate(allr)
     o = oracle.cascade(allr.data, allr.offsets, oracle_libs_from(ci_libs.libs), n_pass=9, indexed=True)
     _assert_same(o, g)

@@ -87,7 +87,22 @@ def test_hostsim_vs_oracle_ci_scale():
             for _ in range(int(rng.integers(0, 3))):
                 q = int(rng.integers(0, L)); x[q] = "ACGT"[("ACGT".index(x[q]) + 1) % 4] if x[q] in "ACGT" else "A"
             extra.append("".join(x))
-    allr = FlatSeqs.from_list(reads.to_list() + extra)
+    # very short reads (below the default --minimum-length): 1..15 nt substrings, some mutated,
+    # T-tailed heads of every length, poly-runs
+    short = []
+    for key in ("mirna", "pre_trna", "mature_trna", "snorna", "mrna"):
+        lib = sl.libs[key]
+        for L in range(1, 16):
+            for _ in range(6):
+                s = lib.seqs.get(int(rng.integers(0, len(lib))))
+                a = int(rng.integers(0, len(s) - L))
+                x = list(s[a:a + L])
+                if rng.random() < 0.4 and x[0] in "ACGT":
+                    q = int(rng.integers(0, L)); x[q] = "ACGT"[("ACGT".index(x[q]) + 1) % 4] if x[q] in "ACGT" else "A"
+                short.append("".join(x))
+                short.append("".join(x) + "T" * int(rng.integers(3, 7)))
+    short += ["A", "T", "TTT", "TTTT", "ATTT", "N", "NNNN", "ACGTTTT", "G" * 15, "AC" * 7]
+    allr = FlatSeqs.from_list(reads.to_list() + extra + short)
     o = oracle.cascade(allr.data, allr.offsets, oracle_libs_from(sl.libs), n_pass=9, indexed=True)
     h = hostsim_cascade(allr, sl.libs, 9)
     for a, b, nm in zip(o, h, ("pass", "ref", "off", "mm")):
@@ -127,3 +142,15 @@ def test_probe_plan_covers_every_mismatch_placement():
                     for bad in combos:
                         bs = set(bad)
                         assert any(not (c & bs) for c in probes), (mode, mm, K, L, bad)
+
+
+def test_core_arithmetic_is_asan_ubsan_clean(tmp_path):
+    """mirge_core.hpp / mirge_libbuild.hpp under AddressSanitizer + UBSan on the CPU build (the GPU
+    pool has no device sanitizer): random libraries with reference Ns, reads of 1..128 nt with Ns,
+    T tails and mismatches, all nine policies."""
+    exe = str(tmp_path / "sanitize")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17",
+                           "-Wno-unknown-pragmas", os.path.join(HERE, "hostsim", "sanitize_main.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rc=0" in r.stdout and "annotated=" in r.stdout
