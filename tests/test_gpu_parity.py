@@ -132,6 +132,43 @@ def test_cascade_vs_oracle_ci_scale(ctx, ci_libs, ci_cascade):
     assert (g[0] >= 0).mean() > 0.5
 
 
+def test_low_complexity_libraries(ctx):
+    """Repeats make probe buckets thousands of entries long (poly-A tails, dinucleotide repeats): this
+    is the wave-cooperative branch of align_hybrid, which random libraries hardly reach."""
+    rng = np.random.default_rng(9)
+    base = synth.make_libraries(seed=31, scale="tiny").libs
+    libs = dict(base)
+    for key, n in (("mrna", 60), ("ncrna_others", 40), ("snorna", 20), ("mirna", 0)):
+        lib = libs[key]
+        seqs = lib.seqs.to_list()
+        for i in range(n):
+            body = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(40, 200))))
+            kind = i % 4
+            rep = {0: "A" * int(rng.integers(30, 300)), 1: "CA" * int(rng.integers(20, 150)),
+                   2: "T" * int(rng.integers(30, 120)), 3: "GGC" * int(rng.integers(10, 60))}[kind]
+            seqs.append(body + rep + ("" if i % 2 else body[:20]))
+        from mirge3_amd.seqio import Library
+        libs[key] = Library(lib.names + [f"rep{key}{i}" for i in range(n)], FlatSeqs.from_list(seqs))
+    reads = []
+    for L in list(range(16, 51)) + [64, 100, 128]:
+        for unit in ("A", "CA", "T", "GGC", "AC"):
+            s = (unit * 200)[:L]
+            reads.append(s)
+            for _ in range(3):  # 1-2 substitutions
+                x = list(s)
+                for _ in range(int(rng.integers(1, 3))):
+                    q = int(rng.integers(0, L)); x[q] = "ACGT"[("ACGT".index(x[q]) + int(rng.integers(1, 4))) % 4]
+                reads.append("".join(x))
+    reads += synth.make_reads(synth.make_libraries(seed=31, scale="tiny"), 2000, seed=4).to_list()
+    fs = FlatSeqs.from_list(reads)
+    casc = Cascade(ctx, libs)
+    g = casc.annotate(fs)
+    o = oracle.cascade(fs.data, fs.offsets, oracle_libs_from(libs), n_pass=9, indexed=False)
+    _assert_same(o, g)
+    assert (g[0] >= 0).sum() > 300
+    casc.close()
+
+
 def test_cascade_vs_bruteforce_oracle(ctx, ci_libs, ci_cascade):
     reads = synth.make_reads(ci_libs, 3000, seed=17, n_frac=0.03)
     g = ci_cascade.annotate(reads)
