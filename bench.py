@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -156,8 +156,10 @@ def main():
     t_setup = time.perf_counter()
     sl = synth.make_libraries(seed=20260101, scale=args.scale)
     ctx = _ffi.Context(dev_index)
+    # c2: exact mature-miRNA pass only; c5: exact + <=2-mismatch isomiR passes against the miRNA library,
+    # then the per-position variant tally (configs[4]; BASELINE quotes it at --reads 50000000)
     n_pass = 1 if args.workload == "c2" else 9
-    libs = {"mirna": sl.libs["mirna"]} if args.workload == "c2" else sl.libs
+    libs = {"mirna": sl.libs["mirna"]} if args.workload in ("c2", "c5") else sl.libs
     casc = Cascade(ctx, libs, n_pass=n_pass)
     reads = synth.make_reads_chunked(sl, args.reads, seed=1000 + rank)  # one sample per rank
     raw = _ffi.DeviceReads.pack(ctx, reads)
@@ -170,6 +172,9 @@ def main():
         uniq = raw.collapse()
         res = casc.run(uniq)
         cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS if n_pass > ISO_PASS else -2, n_mirna)
+        if args.workload == "c5":
+            from mirge3_amd import a2i
+            state["tally"] = a2i.tally(casc, uniq, res)
         state["U"] = len(uniq)
         state["cls"] = cls
         res.close()
@@ -235,9 +240,10 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {
-            "workload": ("C3: 10M-read human-like sample, collapse -> full 9-pass cascade -> count join, 1 sample per GPU"
-                         if args.workload == "c3" else
-                         "C2: 10M-read human-like sample, collapse -> exact mature-miRNA pass only -> count join"),
+            "workload": {"c3": "C3: 10M-read human-like sample, collapse -> full 9-pass cascade -> count join, 1 sample per GPU",
+                         "c2": "C2: 10M-read human-like sample, collapse -> exact mature-miRNA pass only -> count join",
+                         "c5": "C5: collapse -> exact + <=2-mismatch isomiR passes vs the miRNA library -> count join -> "
+                               "per-position variant tally"}[args.workload],
             "raw_reads_per_gpu": args.reads, "unique_reads_per_gpu": U, "library_scale": args.scale,
             "library_bases": {k: v.total_len for k, v in libs.items()}, "passes": n_pass,
             "sharding": f"{n_gpus} sample(s), one per GPU, no collective",

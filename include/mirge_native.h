@@ -115,6 +115,15 @@ int mirge_count_join_host(mirge_ctx* ctx, const int8_t* pass, const int32_t* ref
                           int64_t n, int32_t n_samples, int32_t n_pass, int32_t exact_pass, int32_t iso_pass,
                           int64_t n_mirna, int64_t* class_sums, int64_t* exact, int64_t* iso);
 
+/* ---- per-position variant tally (BASELINE config 5): the counting core of
+ * A2IEditing / judgeAllign (mirge2_tRF_a2i.py:298-366) over the reads the cascade annotated to a
+ * miRNA in exact_pass / iso_pass (iso_trim5 = that pass's -5).  accepted/canonical[n_mirna * S],
+ * census[n_mirna * 32 * 16 * S] (position, canonical base * 4 + read base), A=0 C=1 G=2 T=3.    */
+#define MIRGE_TALLY_POSITIONS 32
+int mirge_variant_tally(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, const mirge_lib* mirna,
+                        int32_t exact_pass, int32_t iso_pass, int32_t iso_trim5, int64_t n_mirna,
+                        int64_t* accepted, int64_t* canonical, int64_t* census);
+
 /* ---- measurement (bench.py): HIP events on the ctx stream ---- */
 int mirge_ctx_timer_start(mirge_ctx* ctx);
 int mirge_ctx_timer_stop(mirge_ctx* ctx, double* ms_out);

@@ -24,7 +24,7 @@ EXPORTS = [
     "mirge_reads_pack", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_result_fetch", "mirge_result_destroy",
-    "mirge_count_join", "mirge_count_join_host", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
+    "mirge_count_join", "mirge_count_join_host", "mirge_variant_tally", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
@@ -314,3 +314,18 @@ def count_join_host(ctx: Context, ps: np.ndarray, ref: np.ndarray, counts: np.nd
                                         C.c_int32(n_pass), C.c_int32(exact_pass), C.c_int32(iso_pass),
                                         C.c_int64(n_mirna), _p(cls), _p(ex), _p(iso)), "mirge_count_join_host")
     return cls, ex[:n_mirna], iso[:n_mirna]
+
+
+TALLY_POSITIONS = 32
+
+
+def variant_tally(ctx: Context, uniq: DeviceReads, res: CascadeResult, mirna: DeviceLibrary, exact_pass: int,
+                  iso_pass: int, iso_trim5: int):
+    """-> (accepted [R, S], canonical [R, S], census [R, 32, 4, 4, S]) int64 (config 5 / row a16)."""
+    R, S = mirna.n_refs, uniq.n_samples
+    acc = np.zeros((max(R, 1), S), dtype=np.int64)
+    can = np.zeros((max(R, 1), S), dtype=np.int64)
+    cen = np.zeros((max(R, 1), TALLY_POSITIONS, 4, 4, S), dtype=np.int64)
+    _check(load().mirge_variant_tally(ctx._h, uniq._h, res._h, mirna._h, C.c_int32(exact_pass), C.c_int32(iso_pass),
+                                      C.c_int32(iso_trim5), C.c_int64(R), _p(acc), _p(can), _p(cen)), "mirge_variant_tally")
+    return acc[:R], can[:R], cen[:R]

@@ -1127,3 +1127,36 @@ extern "C" int mirge_count_join_host(mirge_ctx* c, const int8_t* pass, const int
     c->release(d); c->release(dp); c->release(dr); c->release(dc);
     return 0;
 }
+
+extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const mirge_lib* mirna,
+                                   int32_t exact_pass, int32_t iso_pass, int32_t iso_trim5, int64_t n_mirna,
+                                   int64_t* accepted, int64_t* canonical, int64_t* census) {
+    static_assert(MIRGE_TALLY_POSITIONS == MIRGE_TALLY_MAXPOS, "tally positions");
+    if (!c || !U || !res || !mirna || !accepted || !canonical || !census || n_mirna != mirna->n_refs)
+        return fail(-1, "mirge_variant_tally: bad argument");
+    if (U->n_samples < 1) return fail(-1, "read set has no count matrix");
+    if (res->n != U->n) return fail(-1, "result and read set differ in size");
+    HIPOK(hipSetDevice(c->device));
+    const int32_t S = U->n_samples;
+    const size_t n_rs = (size_t)std::max<int64_t>(n_mirna, 1) * S, n_cen = n_rs * MIRGE_TALLY_MAXPOS * 16;
+    unsigned long long* d = nullptr;
+    CHECK(dalloc(c, &d, 2 * n_rs + n_cen));
+    HIPOK(hipMemsetAsync(d, 0, (2 * n_rs + n_cen) * 8, c->stream));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        if (kGroupW[gi] != 1) continue;  // a read annotated to a miRNA is at most 3 nt longer than it
+        const ResGroup& g = res->g[gi];
+        if (!g.n) continue;
+        LaunchScope ls(c, "k_tally", g.n);
+        hipLaunchKernelGGL(k_tally, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(U->g[gi]), g.pass, g.ref,
+                           g.off, U->g[gi].counts, S, mirna->view(), exact_pass, iso_pass, iso_trim5, d, d + n_rs, d + 2 * n_rs);
+    }
+    std::vector<unsigned long long> h(2 * n_rs + n_cen);
+    HIPOK(hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->drain();
+    std::memcpy(accepted, h.data(), (size_t)n_mirna * S * 8);
+    std::memcpy(canonical, h.data() + n_rs, (size_t)n_mirna * S * 8);
+    std::memcpy(census, h.data() + 2 * n_rs, (size_t)n_mirna * S * MIRGE_TALLY_MAXPOS * 16 * 8);
+    c->release(d);
+    return 0;
+}

@@ -241,3 +241,55 @@ def join(pass_: np.ndarray, ref: np.ndarray, counts: np.ndarray, mirna_names: Li
     return dict(class_sums=class_sums, exact=exact, iso=iso, names=names_sorted, table=table, rpm=rpm,
                 report=report, counts_csv=table_csv(table, counts_int), rpm_csv=table_csv(rpm, [False] * S),
                 report_csv="\n".join(rep_lines) + "\n")
+
+
+# --------------------------------------------------------------------------------------
+# per-position variant tally (config 5 / row a16): judgeAllign + the counting loop of A2IEditing
+# (mirge/libs/mirge2_tRF_a2i.py:298-366) restated on strings, with the cascade's diagonal in place of
+# Bio.pairwise2's (parity unpinned: Biopython is absent, see mirge3.0_amd/a2i.py)
+# --------------------------------------------------------------------------------------
+def variant_tally(seqs: List[str], counts: np.ndarray, pass_: np.ndarray, ref: np.ndarray, off: np.ndarray,
+                  mirna_seqs: List[str], exact_pass: int = 0, iso_pass: int = 8, iso_trim5: int = 1, maxpos: int = 32):
+    S = counts.shape[1]
+    R = len(mirna_seqs)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    accepted = np.zeros((R, S), dtype=np.int64)
+    canonical = np.zeros((R, S), dtype=np.int64)
+    census = np.zeros((R, maxpos, 4, 4, S), dtype=np.int64)
+    for i, read in enumerate(seqs):
+        p = int(pass_[i])
+        if p != exact_pass and p != iso_pass:
+            continue
+        r = int(ref[i])
+        target = mirna_seqs[r]
+        d = int(off[i]) - (iso_trim5 if p == iso_pass else 0)
+        if d > 1:                                      # start_pos2 - start_pos1 > headShift  (:315)
+            continue
+        hd_t, hd_s = max(0, -d), max(0, d)
+        tgt = "-" * hd_t + target
+        sq = "-" * hd_s + read
+        A_len = max(len(tgt), len(sq))
+        tgt = tgt + "-" * (A_len - len(tgt))
+        sq = sq + "-" * (A_len - len(sq))
+        end_pos1 = A_len - hd_t - 1 - 3                 # :311
+        end_pos2 = hd_s + len(read) - 1                 # :313
+        mism = match = 0
+        for pos in range(hd_t, min(end_pos1, end_pos2) + 1):  # :318-324
+            if sq[pos] == "-":
+                continue
+            if tgt[pos] != sq[pos]:
+                mism += 1
+            else:
+                match += 1
+        match_limit = len(target) - 3 - 1 - (1 if d == 1 else 0)  # :309,325-328
+        if mism > 1 or match < match_limit:
+            continue
+        accepted[r] += counts[i]
+        if read in target and "N" not in read:          # :350
+            canonical[r] += counts[i]
+        for ri, b in enumerate(read):
+            q = d + ri
+            if q < 0 or q >= len(target) or q >= maxpos or b not in code:
+                continue
+            census[r, q, code[target[q]], code[b]] += counts[i]
+    return accepted, canonical, census
