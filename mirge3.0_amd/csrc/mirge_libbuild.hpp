@@ -10,6 +10,10 @@
 
 #include "mirge_core.hpp"
 
+#ifndef MIRGE_K_OVERSAMPLE
+#define MIRGE_K_OVERSAMPLE 4
+#endif
+
 struct MirgeHostLib {
     int64_t n_refs = 0;
     uint64_t total = 0;  // bases including one separator after every reference
@@ -59,9 +63,9 @@ static inline int mirge_hostlib_build(MirgeHostLib& L, const char* seq, const in
         g++;  // the separator stays invalid
     }
     L.ref_start[(size_t)n_refs] = (uint32_t)g;
-    // largest probe length: 4^k >= 4 x positions, clamped to [8, MIRGE_KMAX]
+    // largest probe length: 4^k >= MIRGE_K_OVERSAMPLE x positions, clamped to [8, MIRGE_KMAX]
     int k = 8;
-    while (k < MIRGE_KMAX && (1ull << (2 * k)) < 4ull * std::max<uint64_t>(L.valid_positions, 1)) k++;
+    while (k < MIRGE_KMAX && (1ull << (2 * k)) < (uint64_t)MIRGE_K_OVERSAMPLE * std::max<uint64_t>(L.valid_positions, 1)) k++;
     L.kmax = k;
     return 0;
 }

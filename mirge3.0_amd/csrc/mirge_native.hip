@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -466,16 +467,46 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
     std::vector<uint32_t> idx[MIRGE_NGROUPS];
     bool is_acgt[256] = {false};
     for (const char* q = "ACGTUacgtu"; *q; q++) is_acgt[(unsigned char)*q] = true;
-    for (int64_t i = 0; i < n; i++) {
-        int64_t L = off[i + 1] - off[i];
-        if (L < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
-        if (L > MIRGE_MAX_READ_LEN)
-            return fail(-6, "read " + std::to_string(i) + " is " + std::to_string(L) + " nt; the limit is " +
-                            std::to_string(MIRGE_MAX_READ_LEN));
-        R->len_hist[L]++;
-        bool amb = false;
-        for (int64_t b = off[i]; b < off[i + 1]; b++) amb |= !is_acgt[(unsigned char)ascii[b]];
-        idx[width_class(L) + (amb ? 3 : 0)].push_back((uint32_t)i);
+    {
+        // classify the reads (width class x has-an-ambiguous-call) on all host cores: this byte scan is the
+        // largest host cost of the PCIe-inclusive path
+        const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        const int T = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
+        std::vector<std::vector<uint32_t>> part((size_t)T * MIRGE_NGROUPS);
+        std::vector<std::vector<int32_t>> hist((size_t)T, std::vector<int32_t>(MIRGE_MAX_READ_LEN + 1, 0));
+        std::vector<int64_t> bad((size_t)T, -1), badlen((size_t)T, 0);
+        auto work = [&](int t) {
+            const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+            for (int64_t i = lo; i < hi; i++) {
+                const int64_t L = off[i + 1] - off[i];
+                if (L < 0 || L > MIRGE_MAX_READ_LEN) { if (bad[t] < 0) { bad[t] = i; badlen[t] = L; } continue; }
+                hist[t][L]++;
+                bool amb = false;
+                for (int64_t b = off[i]; b < off[i + 1]; b++) amb |= !is_acgt[(unsigned char)ascii[b]];
+                part[(size_t)t * MIRGE_NGROUPS + width_class(L) + (amb ? 3 : 0)].push_back((uint32_t)i);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; t++) {
+            if (bad[t] >= 0) {
+                if (badlen[t] < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
+                return fail(-6, "read " + std::to_string(bad[t]) + " is " + std::to_string(badlen[t]) + " nt; the limit is " +
+                                std::to_string(MIRGE_MAX_READ_LEN));
+            }
+            for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) R->len_hist[L] += hist[t][L];
+        }
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {  // thread ranges are consecutive: order is preserved
+            size_t tot = 0;
+            for (int t = 0; t < T; t++) tot += part[(size_t)t * MIRGE_NGROUPS + gi].size();
+            idx[gi].reserve(tot);
+            for (int t = 0; t < T; t++) {
+                auto& v = part[(size_t)t * MIRGE_NGROUPS + gi];
+                idx[gi].insert(idx[gi].end(), v.begin(), v.end());
+            }
+        }
     }
     R->hist_valid = true;
     R->total_bases = n ? off[n] - off[0] : 0;
