@@ -359,3 +359,47 @@ def test_variant_tally_vs_oracle(ctx):
     assert all(0.0 <= p <= 1.0 for r in rows for p in r["p_value"].values())
     assert a2i.mismatch_census(cen).shape == (12, 2)
     res.close(); uniq.close(); raw.close(); casc.close()
+
+
+def test_cli_end_to_end_single_process(tmp_path):
+    """`python -m mirge3_amd.cli` on FASTQ files expanded from golden case 2: the per-miRNA tables must be
+    the reference's byte for byte; the report differs only in 'Total Input Reads' (the golden counters
+    pretend 17 reads were lost to trimming)."""
+    import csv as _csv
+    import subprocess
+    import sys
+    case = GoldenCase("case2_two_samples")
+    files = []
+    for s, nm in enumerate(case.samples):
+        p = tmp_path / f"{nm}.fastq"
+        with open(p, "w") as fh:
+            k = 0
+            for seq, row in zip(case.seqs, case.counts):
+                for _ in range(int(row[s])):
+                    fh.write(f"@r{k}\n{seq}\n+\n{'I' * len(seq)}\n")
+                    k += 1
+            fh.write("@short\nACGTACGT\n+\nIIIIIIII\n")  # below --minimum-length: counted as input only
+        files.append(str(p))
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, "-c", "import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()" % root,
+           "-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", "out", "-q"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = tmp_path / "out"
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):
+        assert (out / f).read_text() == case.text(f), f
+    got = list(_csv.DictReader(open(out / "annotation.report.csv")))
+    exp = list(_csv.DictReader(open(os.path.join(case.dir, "annotation.report.csv"))))
+    for g_row, e_row in zip(got, exp):
+        for k in e_row:
+            if k == "Total Input Reads":
+                assert int(g_row[k]) == int(e_row["Trimmed Reads (all)"]) + 1
+            else:
+                assert g_row[k] == e_row[k], k
+    # mapped.csv: same rows as the reference's (the outer join sorts the sequences)
+    assert (out / "mapped.csv").read_text() == case.text("mapped.csv")
+    assert (out / "unmapped.csv").read_text() == case.text("unmapped.csv")
+    assert "Alignment completed" in (out / "run.log").read_text()
+    with pytest.raises(SystemExit):
+        from mirge3_amd.cli import parse_args
+        parse_args(["-s", "x.fastq", "-lib", "L", "-on", "human", "-gff"])
