@@ -57,7 +57,7 @@ def rocprof_symbol(rec_name):
     base, _, w = rec_name.partition(".w")
     w = w.rstrip("n") or "1"
     if base.startswith("k_pass["):
-        return f"k_pass<{w}, {int(base[7:-1])}>"
+        return f"k_pass<{w}, {int(base[7:-1].split('-')[0])}>"  # a merged run 'k_pass[4-6]' is launched as slot 4
     if base in ("k_collapse_insert", "k_collapse_scatter"):
         return f"{base}<{w}>"
     return base + "("

@@ -475,6 +475,21 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Consecutive passes with one and the same policy (snoRNA / rRNA / other ncRNA: all "-n 1") run as ONE
+// pass over the concatenation of their libraries.  The cascade's priority -- the first library with
+// ANY valid hit wins, whatever its mismatch count -- is kept by ranking candidates on
+// (library class, mismatches, position): class = which member's text the window lies in.
+struct MergeInfo {
+    uint32_t bound[4];  // global position where member c's text starts (bound[0] = 0)
+    int32_t n;          // members (1 = ordinary pass)
+};
+__device__ __forceinline__ uint64_t class_key(const MergeInfo& mi, uint64_t g) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++) c += (i < mi.n && g >= mi.bound[i]) ? 1u : 0u;
+    return c << 40;
+}
+
 // the two text words under a window: issued for several candidates before any is consumed
 struct TextWin { uint64_t w[5]; };
 
@@ -513,7 +528,7 @@ __device__ __forceinline__ int window_mm_regs(const TextWin& tw, uint64_t g, con
 
 // verify up to N candidate positions at once: all pos loads, then all text loads, then arithmetic
 template <int W, int N>
-__device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const MirgePolicy& pol,
+__device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
                                                const MirgeRead<W>& r, gptr_u32 pos, const uint32_t (&c)[N],
                                                uint32_t hi, int a) {
     uint32_t pz[N];
@@ -538,14 +553,14 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
         const int m = window_mm_regs<W>(tw[u], g[u], r, pol);
         if (m < 0) continue;
         if (mirge_window_invalid(lib.inv, g[u], r.len)) continue;
-        const uint64_t cand = ((uint64_t)m << 32) | g[u];
+        const uint64_t cand = class_key(mi, g[u]) | ((uint64_t)m << 32) | g[u];
         if (cand < best) best = cand;
     }
     return best;
 }
 
 template <int W>
-__device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol,
+__device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
                                              const MirgeRead<W>& r, bool active, uint64_t& best) {
     best = MIRGE_NO_HIT;
     const int lane = threadIdx.x & 63;
@@ -575,7 +590,7 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
             uint32_t c[MIRGE_LIGHT];
 #pragma unroll
             for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = lo + u;
-            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, r, pos, c, hi, a);
+            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a);
             if (cand < best) best = cand;
         }
         unsigned long long hb = __ballot(heavy);
@@ -598,7 +613,7 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
                 uint32_t c[MIRGE_COOP_UNROLL];
 #pragma unroll
                 for (int u = 0; u < MIRGE_COOP_UNROLL; u++) c[u] = c0 + 64 * u;
-                const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, rr, bpos, c, bhi, ba);
+                const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, mi, rr, bpos, c, bhi, ba);
                 if (cand < lbest) lbest = cand;
             }
             // almost every candidate fails verification: instead of a shuffle tree, visit the few
@@ -613,7 +628,8 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
             }
             if (lane == src && tbest < best) best = tbest;
         }
-        // a 0-mismatch window is in probe 0's bucket and buckets ascend: nothing later can beat it
+        // a 0-mismatch window (of the first member library) is in probe 0's bucket and buckets ascend:
+        // nothing later can beat it
         if (q == 0 && (best >> 32) == 0) active = false;
     }
 }
@@ -637,7 +653,7 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
 #endif
 template <int W, int SLOT>
 __global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES)
-k_pass(MirgeLibView lib, MirgePolicy pol, GroupView<W> g, const uint32_t* __restrict__ act_in,
+k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, GroupView<W> g, const uint32_t* __restrict__ act_in,
        const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
        uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
        int8_t* __restrict__ res_mm) {
@@ -670,11 +686,15 @@ k_pass(MirgeLibView lib, MirgePolicy pol, GroupView<W> g, const uint32_t* __rest
             r2.len = 0;
         }
         uint64_t best;
-        align_hybrid<W>(lib, pol, r2, elig, best);
+        align_hybrid<W>(lib, pol, mi, r2, elig, best);
         if (elig && best != MIRGE_NO_HIT) {
-            res_pass[idx] = (int8_t)pass_id;
-            res_pos[idx] = (uint32_t)best;
-            res_mm[idx] = (int8_t)(best >> 32);
+            const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
+            res_pass[idx] = (int8_t)(pass_id + cls);
+            uint32_t b0 = 0;
+#pragma unroll
+            for (int i = 1; i < 4; i++) if (i == cls) b0 = mi.bound[i];
+            res_pos[idx] = (uint32_t)best - b0;  // position in that member's own text
+            res_mm[idx] = (int8_t)((best >> 32) & 0xFF);
             survivor = false;
         }
         const unsigned long long bal = __ballot(survivor);

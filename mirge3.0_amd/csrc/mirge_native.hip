@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -120,6 +122,9 @@ struct mirge_ctx {
         if (it == sizes.end()) return;
         free_blocks.emplace(it->second, p);  // stream-ordered reuse: one stream per ctx
     }
+    // libraries merged for runs of passes that share one policy (see mirge_cascade_run)
+    struct Merged { std::vector<uint64_t> uids; struct mirge_lib* lib; };
+    std::vector<Merged> merged;
     // inside a fork/join region a buffer must not go back to the pool before the join: the other
     // stream could be handed it while this stream's kernels still use it
     std::vector<void*> deferred;
@@ -231,10 +236,13 @@ extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
     return 0;
 }
 
+extern "C" void mirge_lib_destroy(mirge_lib* L);
 extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (auto& m : c->merged) mirge_lib_destroy(m.lib);
+    c->merged.clear();
     c->drain();
     for (auto& kv : c->sizes) (void)hipFree(kv.first);
     for (auto e : c->evt_pool) (void)hipEventDestroy(e);
@@ -308,8 +316,11 @@ extern "C" int mirge_ctx_profile_get(mirge_ctx* c, int32_t i, char* name_out, in
 // ------------------------------------------------------------------------------------------
 // library: 2-bit text + invalid bitmap + per-k tables
 // ------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_lib_uid{1};
+
 struct mirge_lib {
     mirge_ctx* ctx = nullptr;
+    uint64_t uid = 0;  // never reused: identifies a member of a merged library after its pointer is gone
     MirgeHostLib h;  // host image (table construction)
     // device
     uint64_t* dT = nullptr;
@@ -335,6 +346,7 @@ extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* of
     HIPOK(hipSetDevice(c->device));
     auto L = std::make_unique<mirge_lib>();
     L->ctx = c;
+    L->uid = g_lib_uid.fetch_add(1);
     std::string err;
     int rc = mirge_hostlib_build(L->h, seq, off, n_refs, err);
     if (rc) return fail(rc, "mirge_lib_create: " + err);
@@ -892,6 +904,38 @@ extern "C" void mirge_result_destroy(mirge_result* r) {
     delete r;
 }
 
+// One library = the members' references in order (same bases, same separators), so that a position in
+// the merged text minus the member's start is the position in the member's own text.
+static int merged_library(mirge_ctx* c, const mirge_lib* const* members, int n, mirge_lib** out) {
+    std::vector<uint64_t> uids;
+    for (int i = 0; i < n; i++) uids.push_back(members[i]->uid);
+    for (auto& m : c->merged)
+        if (m.uids == uids) { *out = m.lib; return 0; }
+    std::string seq;
+    std::vector<int64_t> off{0};
+    for (int i = 0; i < n; i++) {
+        const MirgeHostLib& h = members[i]->h;
+        for (int64_t r = 0; r < h.n_refs; r++) {
+            for (uint64_t g = h.ref_start[(size_t)r]; g + 1 < h.ref_start[(size_t)r + 1]; g++) {
+                const bool bad = (h.inv[g >> 6] >> (g & 63)) & 1ull;
+                seq.push_back(bad ? 'N' : "ACGT"[(h.T[g >> 5] >> (2 * (g & 31))) & 3ull]);
+            }
+            off.push_back((int64_t)seq.size());
+        }
+    }
+    mirge_lib* L = nullptr;
+    CHECK(mirge_lib_create(c, seq.data(), off.data(), (int64_t)off.size() - 1, &L));
+    c->merged.push_back(mirge_ctx::Merged{uids, L});
+    *out = L;
+    return 0;
+}
+
+struct PassStep {
+    int32_t p0 = 0, np = 1;       // passes p0 .. p0+np-1 run as one launch
+    const mirge_lib* lib = nullptr;
+    MergeInfo mi;
+};
+
 // build every probe table pass `p` can ask for, given the read lengths present
 static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t* hist) {
     MirgePolicy p;
@@ -917,8 +961,8 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
 }
 
 template <int W>
-static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const mirge_lib* const* libs,
-                         const mirge_policy* pol, int32_t n_pass, const ResolveTable& rt, const char* gtag) {
+static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const std::vector<PassStep>& steps,
+                         const mirge_policy* pol, const ResolveTable& rt, const char* gtag) {
     out.n = rg.n;
     if (!rg.n) return 0;
     const uint32_t n = rg.n;
@@ -943,18 +987,19 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     int stage = 0;
     char name[32];
     std::vector<std::pair<int, int>> stage_of_pass;  // (profile record, stage) for unit accounting
-    for (int32_t p = 0; p < n_pass; p++) {
-        if (!libs[p]) continue;
+    for (const PassStep& st : steps) {
+        const int32_t p = st.p0;
         MirgePolicy mp;
         std::memcpy(&mp, &pol[p], sizeof(mp));
         {
-            std::snprintf(name, sizeof(name), "k_pass[%d]%s", (int)p, gtag);
+            if (st.np > 1) std::snprintf(name, sizeof(name), "k_pass[%d-%d]%s", (int)p, (int)(p + st.np - 1), gtag);
+            else std::snprintf(name, sizeof(name), "k_pass[%d]%s", (int)p, gtag);
             LaunchScope ls(c, name, 0.0);
             if (ls.rec >= 0) stage_of_pass.emplace_back(ls.rec, stage);
             const uint32_t* sn_in = seg_n + (size_t)grid * (stage > 0 ? stage - 1 : 0);
             uint32_t* sn_out = seg_n + (size_t)grid * stage;
-#define MIRGE_LAUNCH_PASS(SLOT)                                                                                   \
-    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, libs[p]->view(), mp, v, act_in, \
+#define MIRGE_LAUNCH_PASS(SLOT)                                                                                       \
+    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, st.lib->view(), mp, st.mi, v, act_in, \
                        sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm)
             switch (p) {
                 case 0: MIRGE_LAUNCH_PASS(0); break;
@@ -1014,14 +1059,46 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     }
     ResolveTable rt;
     for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.n_refs[p] = 0; }
+    std::vector<PassStep> steps;
     for (int32_t p = 0; p < n_pass; p++) {
         if (!libs[p]) continue;
         if (libs[p]->ctx->device != c->device) return fail(-1, "library lives on another device");
         if (pol[p].mm < 0 || pol[p].mm > 3 || pol[p].trim5 < 0 || pol[p].trim5 > 31 || pol[p].trim3 < 0)
             return fail(-1, "unsupported policy");
-        CHECK(prepare_tables(const_cast<mirge_lib*>(libs[p]), pol[p], hist));
         rt.ref_start[p] = libs[p]->dref_start;
         rt.n_refs[p] = (uint32_t)libs[p]->n_refs;
+    }
+    for (int32_t p = 0; p < n_pass;) {
+        if (!libs[p]) { p++; continue; }
+        // a run of consecutive passes with one and the same policy over distinct libraries becomes ONE
+        // launch over their concatenation (k_pass ranks candidates by member library first, so the
+        // cascade's "first library with a hit wins" is unchanged): human set -> passes 4,5,6
+        int np = 1;
+        uint64_t total = libs[p]->h.total;
+        static const bool merge_on = !(std::getenv("MIRGE_MERGE_PASSES") && std::getenv("MIRGE_MERGE_PASSES")[0] == '0');
+        while (merge_on && np < 4 && p + np < n_pass && libs[p + np] && std::memcmp(&pol[p + np], &pol[p], sizeof(mirge_policy)) == 0 &&
+               total + libs[p + np]->h.total < 0xFFFFFFF0ull) {
+            bool distinct = true;
+            for (int q = 0; q < np; q++) distinct &= libs[p + q] != libs[p + np];
+            if (!distinct) break;
+            total += libs[p + np]->h.total;
+            np++;
+        }
+        PassStep st;
+        st.p0 = p; st.np = np;
+        st.mi.n = np;
+        for (int i = 0; i < 4; i++) st.mi.bound[i] = 0;
+        if (np == 1) st.lib = libs[p];
+        else {
+            mirge_lib* m = nullptr;
+            CHECK(merged_library(c, libs + p, np, &m));
+            st.lib = m;
+            uint64_t b = 0;
+            for (int i = 0; i < np; i++) { st.mi.bound[i] = (uint32_t)b; b += libs[p + i]->h.total; }
+        }
+        CHECK(prepare_tables(const_cast<mirge_lib*>(st.lib), pol[p], hist));
+        steps.push_back(st);
+        p += np;
     }
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
@@ -1031,9 +1108,9 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
         const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;  // small groups first (see mirge_collapse)
         c->cur = gi == big ? c->stream : c->aux;
-        if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
-        else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
-        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], libs, pol, n_pass, rt, group_tag(gi));
+        if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+        else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
     }
     { int jr = stream_join(c); if (rc == 0) rc = jr; }
     if (rc) { mirge_result_destroy(res.release()); return rc; }
