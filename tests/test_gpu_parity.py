@@ -403,3 +403,26 @@ def test_cli_end_to_end_single_process(tmp_path):
     with pytest.raises(SystemExit):
         from mirge3_amd.cli import parse_args
         parse_args(["-s", "x.fastq", "-lib", "L", "-on", "human", "-gff"])
+
+
+def test_integration_md_stub_runs(tmp_path):
+    """The ctypes stub printed in INTEGRATION.md section 2 is executed as written (only the library path and the
+    `nine_libraries` input are supplied) on golden case 1 and must reproduce the reference's annotation."""
+    import re
+    import pandas as pd
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    stub = next(b for b in blocks if b.startswith("import ctypes as C, numpy as np"))
+    stub = stub.replace('C.CDLL("libmirge_native.so")', "C.CDLL(%r)" % _ffi.SO_PATH)
+    case = GoldenCase("case1_single")
+    from helpers import PASS_LIBKEY
+    nine = [(case.libs[PASS_LIBKEY[p]].names, case.libs[PASS_LIBKEY[p]].seqs.to_list()) for p in range(9)]
+    ns = {"nine_libraries": nine}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    df = pd.DataFrame(case.counts, columns=case.samples, index=pd.Index(case.seqs, name="Sequence"))
+    df = df.assign(**dict.fromkeys(PASS_COLS, ''))
+    df = df.assign(annotFlag=0).reindex(columns=['annotFlag'] + PASS_COLS + case.samples)
+    out = ns["bwtAlign"](None, df, str(tmp_path), DB)
+    out[out.annotFlag.eq(1)].to_csv(tmp_path / "mapped.csv")
+    assert (tmp_path / "mapped.csv").read_text() == case.text("mapped.csv")
