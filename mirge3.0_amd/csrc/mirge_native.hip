@@ -670,7 +670,17 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseT
         // partition by hash -> de-duplicate each bucket in LDS: no global atomics (see mirge_kernels.hpp)
         t.partitioned = true;
         uint32_t B = 64;
-        while (B < 8192 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket
+        while (B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
+        if (B * 4 > 48 * 1024) {  // histogram / cursor arrays beyond the default dynamic-LDS window
+            HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * 4)));
+            HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * 4)));
+        }
+        static bool dedup_attr = false;
+        if (!dedup_attr) {
+            HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      MIRGE_PART_CAP * 16 + 16));
+            dedup_attr = true;
+        }
         int lg = 0; while ((1u << lg) < B) lg++;
         const uint32_t bshift = 64 - lg;
         const uint32_t G = std::min<uint32_t>(256, (in.n + 2047) / 2048);
