@@ -111,8 +111,8 @@ def pmc_traffic(args, rec_name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])

@@ -44,6 +44,9 @@ struct MirgePolicy {
 struct MirgeKTable {
     const uint32_t* bucket;  // 4^(k1+k2) + 1 entries
     const uint32_t* pos;     // global positions of block A's first base, ascending inside a bucket
+    const uint32_t* bits;    // 1 bit per bucket (non-empty), or nullptr.  Present for tables of <= 4^10
+                             // buckets: the bitmap (<= 128 KiB) stays in L2 while the bucket array does
+                             // not, and most probes of an unannotatable read find an empty bucket
 };
 
 // A probe is one or two exact blocks of the read: block A = k1 bases at read offset a1, block B =
@@ -281,6 +284,25 @@ MIRGE_HD void mirge_probe_at(const MirgePolicy& p, int L, int K, int q, MirgePro
     }
 }
 
+// The plan depends only on (policy, K, trimmed length): the host tabulates it once per pass and the
+// kernels read probe q of length L with one 4-byte load instead of redoing the integer divisions.
+struct MirgePlanTable {
+    uint8_t np[MIRGE_MAX_READ_LEN + 1];
+    MirgeProbe pr[MIRGE_MAX_READ_LEN + 1][MIRGE_MAX_PROBES];
+};
+static inline void mirge_plan_table_fill(const MirgePolicy& p, int K, MirgePlanTable& t) {
+    for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
+        const bool ok = L >= 1 && L > p.mm;
+        const int n = ok ? mirge_probe_count(p, L, K) : 0;
+        t.np[L] = (uint8_t)n;
+        for (int q = 0; q < MIRGE_MAX_PROBES; q++) {
+            MirgeProbe pr; pr.a1 = 0; pr.k1 = 0; pr.gap = 0; pr.k2 = 0;
+            if (q < n) mirge_probe_at(p, L, K, q, pr);
+            t.pr[L][q] = pr;
+        }
+    }
+}
+
 // key of a probe in the read, or false if an ambiguous call sits in a block (cannot be exact)
 template <int W>
 MIRGE_HD bool mirge_probe_key(const MirgeRead<W>& r, const MirgeProbe& pr, uint64_t& key) {
@@ -311,6 +333,7 @@ MIRGE_HD bool mirge_align_indexed(const MirgeLibView& lib, const MirgePolicy& p,
         if (!mirge_probe_key<W>(r, pr, key)) continue;
         const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
         const int a = pr.a1;
+        if (tb.bits && !((tb.bits[key >> 5] >> (key & 31)) & 1u)) continue;
         const uint32_t lo = tb.bucket[key], hi = tb.bucket[key + 1];
         for (uint32_t c = lo; c < hi; c++) {
             const uint32_t pz = tb.pos[c];

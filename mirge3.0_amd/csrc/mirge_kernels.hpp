@@ -462,6 +462,9 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
 //   All 64 lanes of the wave must call this together (inactive lanes pass active = false).
 // ------------------------------------------------------------------------------------------
 #define MIRGE_LIGHT 4
+#ifndef MIRGE_LIGHT_MAX
+#define MIRGE_LIGHT_MAX 16
+#endif
 #define MIRGE_COOP_UNROLL 1
 
 // pointers that came out of memory or a v_readlane have lost their address space; these casts keep
@@ -561,10 +564,11 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
 
 template <int W>
 __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
-                                             const MirgeRead<W>& r, bool active, uint64_t& best) {
+                                             const MirgePlanTable* __restrict__ plan, const MirgeRead<W>& r,
+                                             bool active, uint64_t& best) {
     best = MIRGE_NO_HIT;
     const int lane = threadIdx.x & 63;
-    const int np = active ? mirge_probe_count(pol, r.len, lib.kmax) : 0;
+    const int np = active ? (int)plan->np[r.len] : 0;
     // wave-uniform bound on the probe count: (mm+1) plain segments or (mm+1)^2 recursive probes
     const int npmax = (pol.mm >= 1 && pol.mm <= 2) ? (pol.mm + 1) * (pol.mm + 1) : pol.mm + 1;
 #pragma unroll 1
@@ -573,25 +577,32 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
         int a = 0;
         gptr_u32 pos = nullptr;
         if (active && q < np) {
-            MirgeProbe pr;
-            mirge_probe_at(pol, r.len, lib.kmax, q, pr);
+            const MirgeProbe pr = plan->pr[r.len][q];  // tabulated mirge_probe_at(pol, len, K, q)
             uint64_t key;
             if (mirge_probe_key<W>(r, pr, key)) {  // no ambiguous call inside the probe
                 const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
-                gptr_u32 bucket = (gptr_u32)tb.bucket;
-                pos = (gptr_u32)tb.pos;
-                lo = bucket[key];
-                hi = bucket[key + 1];
-                a = pr.a1;
+                gptr_u32 bits = (gptr_u32)tb.bits;
+                if (!bits || ((bits[key >> 5] >> (key & 31)) & 1u)) {  // L2-resident "bucket is non-empty" bit
+                    gptr_u32 bucket = (gptr_u32)tb.bucket;
+                    pos = (gptr_u32)tb.pos;
+                    lo = bucket[key];
+                    hi = bucket[key + 1];
+                    a = pr.a1;
+                }
             }
         }
-        const bool heavy = (hi - lo) > MIRGE_LIGHT;
-        if (!heavy && hi > lo) {
-            uint32_t c[MIRGE_LIGHT];
+        // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
+        // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
+        // per list and many such lanes per probe the lane-serial batches are several times cheaper)
+        const bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
+        if (!heavy) {
+            for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
+                uint32_t c[MIRGE_LIGHT];
 #pragma unroll
-            for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = lo + u;
-            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a);
-            if (cand < best) best = cand;
+                for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
+                const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a);
+                if (cand < best) best = cand;
+            }
         }
         unsigned long long hb = __ballot(heavy);
         while (hb) {
@@ -653,7 +664,8 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
 #endif
 template <int W, int SLOT>
 __global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES)
-k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, GroupView<W> g, const uint32_t* __restrict__ act_in,
+k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __restrict__ plan, GroupView<W> g,
+       const uint32_t* __restrict__ act_in,
        const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
        uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
        int8_t* __restrict__ res_mm) {
@@ -686,7 +698,7 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, GroupView<W> g, const ui
             r2.len = 0;
         }
         uint64_t best;
-        align_hybrid<W>(lib, pol, mi, r2, elig, best);
+        align_hybrid<W>(lib, pol, mi, plan, r2, elig, best);
         if (elig && best != MIRGE_NO_HIT) {
             const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
             res_pass[idx] = (int8_t)(pass_id + cls);

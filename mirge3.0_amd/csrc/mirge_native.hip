@@ -92,6 +92,8 @@ struct mirge_ctx {
     uint32_t* prof_pinned = nullptr;
     unsigned long long* join_pinned = nullptr;
     size_t join_pinned_bytes = 0;
+    struct PlanEntry { uint64_t uid; MirgePolicy pol; MirgePlanTable* dplan; };
+    std::vector<PlanEntry> plans;
     size_t prof_used = 0;
     std::vector<ProfUnits> prof_pending;
 
@@ -251,6 +253,7 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->prof_pinned) (void)hipHostFree(c->prof_pinned);
     if (c->join_pinned) (void)hipHostFree(c->join_pinned);
+    for (auto& e : c->plans) (void)hipFree(e.dplan);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -352,7 +355,7 @@ extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* of
     if (rc) return fail(rc, "mirge_lib_create: " + err);
     L->n_refs = n_refs;
     L->kmax = L->h.kmax;
-    L->htables.assign(MIRGE_SHAPE_SLOTS, MirgeKTable{nullptr, nullptr});
+    L->htables.assign(MIRGE_SHAPE_SLOTS, MirgeKTable{nullptr, nullptr, nullptr});
     const size_t nT = L->h.T.size() * 8, nI = L->h.inv.size() * 8, nR = ((size_t)n_refs + 1) * 4;
     HIPOK(hipMalloc((void**)&L->dT, nT));
     HIPOK(hipMalloc((void**)&L->dinv, nI));
@@ -372,7 +375,7 @@ extern "C" void mirge_lib_destroy(mirge_lib* L) {
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
     (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dtables);
-    for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); }
+    for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); (void)hipFree((void*)t.bits); }
     delete L;
 }
 extern "C" int64_t mirge_lib_n_refs(const mirge_lib* L) { return L ? L->n_refs : -1; }
@@ -395,7 +398,18 @@ static int lib_prepare_shape(mirge_lib* L, int k1, int gap, int k2) {
     HIPOK(hipMemcpy(dpos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
     L->htables[sid].bucket = dbucket;
     L->htables[sid].pos = dpos;
+    L->htables[sid].bits = nullptr;
     L->device_bytes += bucket.size() * 4 + pos.size() * 4;
+    if (k1 + k2 <= 10) {  // non-empty-bucket bitmap, <= 128 KiB
+        const size_t nb = bucket.size() - 1;
+        std::vector<uint32_t> bits((nb + 31) / 32, 0u);
+        for (size_t b = 0; b < nb; b++) if (bucket[b + 1] > bucket[b]) bits[b >> 5] |= 1u << (b & 31);
+        uint32_t* dbits = nullptr;
+        HIPOK(hipMalloc((void**)&dbits, bits.size() * 4));
+        HIPOK(hipMemcpy(dbits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+        L->htables[sid].bits = dbits;
+        L->device_bytes += bits.size() * 4;
+    }
     HIPOK(hipStreamSynchronize(L->ctx->stream));  // no kernel may be reading the registry while it changes
     HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));
     return 0;
@@ -944,6 +958,7 @@ struct PassStep {
     int32_t p0 = 0, np = 1;       // passes p0 .. p0+np-1 run as one launch
     const mirge_lib* lib = nullptr;
     MergeInfo mi;
+    const MirgePlanTable* dplan = nullptr;  // device copy of the tabulated probe plan
 };
 
 // build every probe table pass `p` can ask for, given the read lengths present
@@ -1009,7 +1024,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
             const uint32_t* sn_in = seg_n + (size_t)grid * (stage > 0 ? stage - 1 : 0);
             uint32_t* sn_out = seg_n + (size_t)grid * stage;
 #define MIRGE_LAUNCH_PASS(SLOT)                                                                                       \
-    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, st.lib->view(), mp, st.mi, v, act_in, \
+    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, st.lib->view(), mp, st.mi, st.dplan, v, act_in, \
                        sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm)
             switch (p) {
                 case 0: MIRGE_LAUNCH_PASS(0); break;
@@ -1109,6 +1124,24 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
         CHECK(prepare_tables(const_cast<mirge_lib*>(st.lib), pol[p], hist));
         steps.push_back(st);
         p += np;
+    }
+    // tabulated probe plans: built and uploaded once per (library, policy), then reused by every call
+    for (auto& st : steps) {
+        MirgePolicy mp;
+        std::memcpy(&mp, &pol[st.p0], sizeof(mp));
+        const MirgePlanTable* dp = nullptr;
+        for (auto& e : c->plans)
+            if (e.uid == st.lib->uid && std::memcmp(&e.pol, &mp, sizeof(mp)) == 0) { dp = e.dplan; break; }
+        if (!dp) {
+            auto h = std::make_unique<MirgePlanTable>();
+            mirge_plan_table_fill(mp, st.lib->kmax, *h);
+            MirgePlanTable* d = nullptr;
+            HIPOK(hipMalloc((void**)&d, sizeof(MirgePlanTable)));
+            HIPOK(hipMemcpy(d, h.get(), sizeof(MirgePlanTable), hipMemcpyHostToDevice));
+            c->plans.push_back(mirge_ctx::PlanEntry{st.lib->uid, mp, d});
+            dp = d;
+        }
+        st.dplan = dp;
     }
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
