@@ -39,7 +39,6 @@ ALGO_BYTES = {
     "k_pass": 4 + 9 + 5,             # active index + read in, annotation or survivor index out, per read handed to the pass
     "k_resolve": 5 + 8,              # pass+position in, ref+offset out
     "k_join": 5 + 4,                 # pass+ref + one count in (S = 1)
-    "k_len_hist": 1,
     "k_scan_blocksums": 8,
 }
 

@@ -99,20 +99,6 @@ __global__ void k_scatter_len(const uint8_t* __restrict__ len, uint32_t n, uint3
         out[orig ? orig[j] : base + j] = len[j];
 }
 
-// histogram of read lengths (which k-mer tables will the cascade ask for)
-__global__ void k_len_hist(const uint8_t* __restrict__ len, uint32_t n, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[MIRGE_MAX_READ_LEN + 1];
-    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) h[i] = 0;
-    __syncthreads();
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        uint32_t L = len[j];
-        atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
-        if (h[i]) atomicAdd(&hist[i], h[i]);
-}
-
 // ------------------------------------------------------------------------------------------
 // block-wide exclusive scan of one value per thread (256 threads = 4 waves of 64)
 // ------------------------------------------------------------------------------------------
@@ -797,10 +783,6 @@ __global__ void k_scatter_out(const T* __restrict__ in, uint32_t n, uint32_t bas
         out[orig ? orig[j] : base + j] = in[j];
 }
 
-template <typename T>
-__global__ void k_fill(T* __restrict__ p, size_t n, T v) {
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) p[j] = v;
-}
 
 
 // ------------------------------------------------------------------------------------------
