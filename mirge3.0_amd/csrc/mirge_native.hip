@@ -684,7 +684,10 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseT
         // partition by hash -> de-duplicate each bucket in LDS: no global atomics (see mirge_kernels.hpp)
         t.partitioned = true;
         uint32_t B = 64;
-        while (B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
+        // test hook: MIRGE_TEST_SMALL_PART=1 keeps 64 buckets so that big inputs overflow the LDS tables and
+        // exercise the fallback to the global-atomic path (tests/test_gpu_parity.py)
+        static const bool small_part = std::getenv("MIRGE_TEST_SMALL_PART") != nullptr;
+        while (!small_part && B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
         if (B * 4 > 48 * 1024) {  // histogram / cursor arrays beyond the default dynamic-LDS window
             HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * 4)));
             HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * 4)));

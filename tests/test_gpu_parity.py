@@ -426,3 +426,38 @@ def test_integration_md_stub_runs(tmp_path):
     out = ns["bwtAlign"](None, df, str(tmp_path), DB)
     out[out.annotFlag.eq(1)].to_csv(tmp_path / "mapped.csv")
     assert (tmp_path / "mapped.csv").read_text() == case.text("mapped.csv")
+
+
+def test_collapse_partition_overflow_falls_back(tmp_path):
+    """A bucket holding more distinct reads than its LDS table raises the overflow flag and the call is redone
+    with the global-atomic tables: forced here with the MIRGE_TEST_SMALL_PART hook in a fresh process."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import mirge3_amd
+from mirge3_amd import _ffi
+from mirge3_amd.seqio import FlatSeqs
+rng = np.random.default_rng(5)
+n = 400000
+lens = rng.integers(16, 31, size=n)
+off = np.zeros(n + 1, np.int64); np.cumsum(lens, out=off[1:])
+data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(off[-1]))]
+reads = FlatSeqs(data, off)
+dup = reads.take(rng.integers(0, n, size=100000))
+allr = FlatSeqs(np.concatenate([reads.data, dup.data]), np.concatenate([reads.offsets, dup.offsets[1:] + reads.offsets[-1]]))
+ctx = _ffi.Context(0)
+raw = _ffi.DeviceReads.pack(ctx, allr)
+u = raw.collapse()
+cnt, first = u.counts()
+from collections import Counter
+exp = Counter(allr.to_list())
+got = dict(zip(u.unpack().to_list(), cnt[:, 0].tolist()))
+assert got == dict(exp), (len(got), len(exp))
+print("OK", len(got))
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MIRGE_TEST_SMALL_PART="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
