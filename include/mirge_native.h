@@ -82,8 +82,9 @@ int mirge_reads_unpack(mirge_ctx* ctx, const mirge_reads* reads, char* ascii_out
 
 /* ---- collapse: replaces the dict merge of digest.py:141-163 and the sample matrix of
  * digest.py:237-245.  sample_ids[n] (host, may be NULL when n_samples == 1) gives the sample
- * of every raw read.  The result holds the U distinct sequences (short reads first, each
- * width group in order of first appearance) and a U x n_samples count matrix.            */
+ * of every raw read.  The result holds the U distinct sequences (grouped by width class; their order
+ * inside a group is unspecified -- sort by first_index for the reference's dict order) and a
+ * U x n_samples count matrix.                                                              */
 int mirge_collapse(mirge_ctx* ctx, const mirge_reads* raw, const int32_t* sample_ids,
                    int32_t n_samples, mirge_reads** uniq, int64_t* n_uniq);
 /* counts_out[U * n_samples] (row-major), first_index_out[U] (index of the first raw read, may be NULL) */

@@ -211,13 +211,15 @@ __global__ void k_collapse_insert_key(GroupView<1> g, KeySlot* __restrict__ slot
 // run at ~20 G/s chip-wide, which is what bounds k_collapse_insert_key (2.4 atomics per read).  Here
 // equal keys are first brought together: reads are partitioned by the top bits of their hash into
 // buckets of ~1-2 k reads (histogram per workgroup -> column prefix -> scatter, no global atomics),
-// then ONE workgroup de-duplicates a bucket entirely in LDS (ds_cmpst / ds_min / ds_add) and writes
-// each read's head flag and, for heads, the group's count.
+// then ONE workgroup de-duplicates a bucket entirely in LDS (ds_cmpst / ds_min / ds_add) and emits the
+// bucket's distinct reads with their counts.
 //   k_part_hist   : hist[g][b]  = reads of workgroup g's chunk that fall into bucket b
 //   k_part_prefix : off[g][b]   = sum over g' < g of hist[g'][b];  total[b] = column sum
 //   (k_scan_blocksums over total[] -> bucket_start[])
 //   k_part_scatter: part[bucket_start[b] + off[g][b] + local cursor] = {key, j} (one 16-B record)
-//   k_part_dedup  : per bucket, LDS table (key -> min j, count) -> flag[j], headcnt[j]
+//   k_part_dedup  : per bucket, LDS table (key -> min j, count); the bucket's distinct reads are written
+//                   to the output at a range reserved with one global atomicAdd per workgroup (so the order
+//                   of the unique reads of this path is unspecified; first[] carries the first raw index)
 // ------------------------------------------------------------------------------------------
 #define MIRGE_PART_CAP 4096  // LDS table slots per bucket (16 B each = 64 KiB)
 
@@ -265,14 +267,17 @@ __global__ void k_part_scatter(GroupView<1> g, uint32_t chunk, uint32_t bshift, 
 }
 
 __global__ void __launch_bounds__(MIRGE_BLOCK)
-k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket_start, uint8_t* __restrict__ flag, uint32_t* __restrict__ headcnt,
-             uint32_t* __restrict__ overflow) {
+k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket_start,
+             const uint32_t* __restrict__ orig, uint32_t base, uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
+             uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst, uint32_t* __restrict__ cursor,
+             uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
     uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + MIRGE_PART_CAP);
     uint32_t* lds_cnt = lds_min + MIRGE_PART_CAP;
-    uint32_t& n_distinct = lds_cnt[MIRGE_PART_CAP];  // all LDS in the one dynamic region (keeps it 16-B aligned)
+    uint32_t* lds_x = lds_cnt + MIRGE_PART_CAP;  // [0] distinct keys, [1] output base, [2..5] scan scratch, [8..8+128] lengths
+    uint32_t& n_distinct = lds_x[0];
     for (uint32_t i = threadIdx.x; i < MIRGE_PART_CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
-    if (threadIdx.x == 0) n_distinct = 0;
+    for (uint32_t i = threadIdx.x; i < 8 + MIRGE_MAX_READ_LEN + 1; i += blockDim.x) lds_x[i] = 0;
     __syncthreads();
     const uint32_t lo = bucket_start[blockIdx.x], hi = bucket_start[blockIdx.x + 1];
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -294,45 +299,33 @@ k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket
         atomicAdd(&lds_cnt[s], 1u);
     }
     __syncthreads();
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint4 rec = part[i];
-        const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
-        const uint32_t j = rec.z;
-        uint32_t s = (uint32_t)(mirge_mix64(key) >> 7) & (MIRGE_PART_CAP - 1);
-        uint32_t guard = 0;
-        while (lds_k[s] != key && guard++ < MIRGE_PART_CAP) s = (s + 1) & (MIRGE_PART_CAP - 1);
-        const bool head = lds_min[s] == j;
-        flag[j] = head ? 1 : 0;
-        if (head) headcnt[j] = lds_cnt[s];
-    }
-}
-
-// block sums of a ready flag array (+ length histogram of the heads)
-__global__ void k_flags_blocksum(const uint8_t* __restrict__ flag, const uint8_t* __restrict__ len, uint32_t n,
-                                 uint32_t* __restrict__ blocksum, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t lds4[4];
-    __shared__ uint32_t h[MIRGE_MAX_READ_LEN + 1];
-    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) h[i] = 0;
-    __syncthreads();
-    const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * 8) + threadIdx.x * 8;
-    uint32_t c = 0;
-    uint64_t packed = 0;
-    if (b0 + 8 <= n) packed = *reinterpret_cast<const uint64_t*>(flag + b0);
-    else for (int i = 0; i < 8; i++) if (b0 + i < n) packed |= (uint64_t)(flag[b0 + i] & 1) << (8 * i);
+    // emit the bucket's distinct reads: one global cursor add per workgroup reserves their output range
+    constexpr int PER = MIRGE_PART_CAP / MIRGE_BLOCK;
+    const uint32_t s0 = threadIdx.x * PER;
+    uint32_t mine = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t j = b0 + i;
-        if ((packed >> (8 * i)) & 1ull) {
-            c++;
-            const uint32_t L = len[j];
-            atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
-        }
-    }
+    for (int i = 0; i < PER; i++) mine += lds_k[s0 + i] != 0ull;
     uint32_t total;
-    block_excl_scan(c, total, lds4);
-    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
-    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
-        if (h[i]) atomicAdd(&hist[i], h[i]);
+    uint32_t rank = block_excl_scan(mine, total, lds_x + 2);
+    if (threadIdx.x == 0) lds_x[1] = total ? atomicAdd(cursor, total) : 0u;
+    __syncthreads();
+    rank += lds_x[1];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const unsigned long long key = lds_k[s0 + i];
+        if (key == 0ull) continue;
+        const int L = (63 - __clzll((long long)key)) >> 1;  // the sentinel bit sits at 2*len
+        useq[rank] = key ^ (1ull << (2 * L));
+        ulen[rank] = (uint8_t)L;
+        ucnt[rank] = lds_cnt[s0 + i];
+        const uint32_t j = lds_min[s0 + i];
+        ufirst[rank] = orig ? orig[j] : base + j;
+        atomicAdd(&lds_x[8 + L], 1u);
+        rank++;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+        if (lds_x[8 + i]) atomicAdd(&hist[i], lds_x[8 + i]);
 }
 
 // heads: read j is the head of its group iff it is the group's smallest index.  `first` is addressed

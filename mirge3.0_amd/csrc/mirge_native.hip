@@ -650,7 +650,7 @@ struct CollapseTmp {
     uint32_t cnt_stride = 1, nb = 0;
     // partitioned key path
     bool partitioned = false;
-    uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr, *headcnt = nullptr;
+    uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr;
     uint4* part = nullptr;
 };
 // dmeta: [0..5] U of each group, [6] partition overflow flag, [8 .. 8+128] length histogram
@@ -664,8 +664,8 @@ static const char* group_tag(int gi) {
 }
 
 template <int W>
-static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseTmp& t, const int32_t* dsample,
-                            int32_t S, uint32_t* dmeta, bool force_atomic) {
+static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t,
+                            const int32_t* dsample, int32_t S, uint32_t* dmeta, bool force_atomic) {
     if (!in.n) return 0;
     // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
     const bool key_path = (W == 1) && !in.nmask && S == 1;
@@ -673,9 +673,6 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseT
     while (tsize < (key_path ? in.n + in.n / 2 : 2ull * in.n)) tsize <<= 1;
     const uint32_t per_block = MIRGE_BLOCK * MIRGE_SCAN_ITEMS;
     t.nb = (in.n + per_block - 1) / per_block;
-    CHECK(dalloc(c, &t.slot_of, in.n));
-    CHECK(dalloc(c, &t.flag, (size_t)t.nb * per_block));
-    CHECK(dalloc(c, &t.blocksum, t.nb));
     GroupView<W> v = view_of<W>(in);
     char name[48];
     const uint32_t* first_base;
@@ -695,7 +692,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseT
         static bool dedup_attr = false;
         if (!dedup_attr) {
             HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      MIRGE_PART_CAP * 16 + 16));
+                                      MIRGE_PART_CAP * 16 + 1024));
             dedup_attr = true;
         }
         int lg = 0; while ((1u << lg) < B) lg++;
@@ -707,7 +704,12 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseT
         CHECK(dalloc(c, &t.off, (size_t)G * B));
         CHECK(dalloc(c, &t.btotal, (size_t)B + 1));
         CHECK(dalloc(c, &t.part, (size_t)in.n));
-        CHECK(dalloc(c, &t.headcnt, (size_t)in.n));
+        // outputs at capacity n (U is not known yet): the bucket workgroups emit the unique reads themselves
+        out.W = 1;
+        CHECK(dalloc(c, &out.seq, (size_t)in.n));
+        CHECK(dalloc(c, &out.len, (size_t)in.n));
+        CHECK(dalloc(c, &out.counts, (size_t)in.n));
+        CHECK(dalloc(c, &out.first, (size_t)in.n));
         GroupView<1> v1 = view_of<1>(in);
         {
             LaunchScope ls(c, "k_part_hist.w1", in.n);
@@ -727,21 +729,15 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, CollapseT
         }
         {
             LaunchScope ls(c, "k_part_dedup.w1", in.n);
-            hipLaunchKernelGGL(k_part_dedup, dim3(B), dim3(MIRGE_BLOCK), MIRGE_PART_CAP * 16 + 16, c->cur, t.part, t.btotal, t.flag, t.headcnt, dmeta + MIRGE_META_OVERFLOW);
+            hipLaunchKernelGGL(k_part_dedup, dim3(B), dim3(MIRGE_BLOCK), MIRGE_PART_CAP * 16 + 1024, c->cur, t.part, t.btotal,
+                               in.orig, in.base, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
+                               dmeta + MIRGE_META_OVERFLOW);
         }
-        {
-            LaunchScope ls(c, "k_flags_blocksum.w1", in.n);
-            hipLaunchKernelGGL(k_flags_blocksum, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, t.flag, in.len, in.n, t.blocksum,
-                               dmeta + MIRGE_META_HIST);
-        }
-        {
-            LaunchScope ls(c, "k_scan_blocksums", t.nb);
-            hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.blocksum, t.nb, dmeta + gi);
-        }
-        t.cnt_base = t.headcnt; t.cnt_stride = 1;
-        c->defer(t.slot_of); t.slot_of = nullptr;  // scatter indexes the counts by read
         return 0;
     }
+    CHECK(dalloc(c, &t.slot_of, in.n));
+    CHECK(dalloc(c, &t.flag, (size_t)t.nb * per_block));
+    CHECK(dalloc(c, &t.blocksum, t.nb));
     if (key_path) {
         CHECK(dalloc(c, &t.slots, tsize));
         HIPOK(hipMemsetAsync(t.slots, 0, (size_t)tsize * sizeof(KeySlot), c->cur));
@@ -781,7 +777,7 @@ template <int W>
 static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, int32_t S,
                             uint32_t U, uint32_t out_base, const uint32_t* dmeta) {
     out.W = W; out.n = U; out.base = out_base;
-    if (in.n) {
+    if (in.n && !t.partitioned) {
         CHECK(dalloc(c, &out.seq, (size_t)W * U));
         CHECK(dalloc(c, &out.len, (size_t)U));
         if (in.nmask) CHECK(dalloc(c, &out.nmask, (size_t)W * U));
@@ -800,7 +796,7 @@ static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
 static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
     c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
     c->defer(t.flag); c->defer(t.blocksum);
-    c->defer(t.hist); c->defer(t.off); c->defer(t.btotal); c->defer(t.part); c->defer(t.headcnt);
+    c->defer(t.hist); c->defer(t.off); c->defer(t.btotal); c->defer(t.part);
     t = CollapseTmp();
 }
 
@@ -834,9 +830,9 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
             // small kernels waits for CUs to drain and the join at the end waits for them (5.3 vs 3.8 ms)
             const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;
             c->cur = gi == big ? c->stream : c->aux;
-            if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
-            else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
-            else rc = collapse_phase_a<4>(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
+            if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
+            else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
+            else rc = collapse_phase_a<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
@@ -845,7 +841,12 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
             if (e != hipSuccess) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
         }
         if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt == 0) {
-            for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
+            for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+                collapse_tmp_release(c, tmp[gi]);
+                ReadGroup& og = R->g[gi];  // outputs the partitioned attempt had allocated at capacity n
+                c->release(og.seq); c->release(og.len); c->release(og.counts); c->release(og.first);
+                og = ReadGroup();
+            }
             c->flush_deferred();
             continue;
         }
