@@ -23,6 +23,9 @@
 #include "mirge_kernels.hpp"
 #include "mirge_libbuild.hpp"
 
+#ifndef MIRGE_BITMAP_MAXK
+#define MIRGE_BITMAP_MAXK 10
+#endif
 static_assert(sizeof(mirge_policy) == sizeof(MirgePolicy), "policy layout");
 static_assert(MIRGE_MAX_PASSES == MIRGE_MAX_PASSES_K, "pass cap");
 
@@ -400,7 +403,7 @@ static int lib_prepare_shape(mirge_lib* L, int k1, int gap, int k2) {
     L->htables[sid].pos = dpos;
     L->htables[sid].bits = nullptr;
     L->device_bytes += bucket.size() * 4 + pos.size() * 4;
-    if (k1 + k2 <= 10) {  // non-empty-bucket bitmap, <= 128 KiB
+    if (k1 + k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
         const size_t nb = bucket.size() - 1;
         std::vector<uint32_t> bits((nb + 31) / 32, 0u);
         for (size_t b = 0; b < nb; b++) if (bucket[b + 1] > bucket[b]) bits[b >> 5] |= 1u << (b & 31);
