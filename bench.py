@@ -266,18 +266,21 @@ def main():
 
     # ---------------- PCIe-inclusive rate (never `value`): host ASCII reads in, per-read annotation + counts out
     if rank == 0:
-        t = time.perf_counter()
-        r_h = _ffi.DeviceReads.pack(ctx, reads)
-        u_h = r_h.collapse()
-        res_h = casc.run(u_h)
-        ann = res_h.fetch()
-        cnt_h, first_h = u_h.counts()
-        _ffi.count_join(ctx, u_h, res_h, EXACT_PASS, ISO_PASS if n_pass > ISO_PASS else -2, n_mirna)
-        dt = time.perf_counter() - t
-        out["host_buffer_path"] = {"M_reads_per_s": round(args.reads / dt / 1e6, 2), "ms": round(dt * 1e3, 2),
+        best_dt = None
+        for _ in range(3):  # best of three: the first pass also pays for new buffer-pool blocks
+            t = time.perf_counter()
+            r_h = _ffi.DeviceReads.pack(ctx, reads)
+            u_h = r_h.collapse()
+            res_h = casc.run(u_h)
+            ann = res_h.fetch()
+            cnt_h, first_h = u_h.counts()
+            _ffi.count_join(ctx, u_h, res_h, EXACT_PASS, ISO_PASS if n_pass > ISO_PASS else -2, n_mirna)
+            dt = time.perf_counter() - t
+            best_dt = dt if best_dt is None else min(best_dt, dt)
+            res_h.close(); u_h.close(); r_h.close()
+        out["host_buffer_path"] = {"M_reads_per_s": round(args.reads / best_dt / 1e6, 2), "ms": round(best_dt * 1e3, 2),
                                    "note": "ASCII reads + offsets over PCIe, 2-bit pack on the GPU, annotation (10 B/unique) "
-                                           "and counts back to numpy; single pass, not part of `value`"}
-        res_h.close(); u_h.close(); r_h.close()
+                                           "and counts back to numpy; best of 3 passes, not part of `value`"}
 
     # ---------------- CPU baseline (rank 0, N = 1): the oracle on a bounded sample, and parity on it
     if rank == 0 and n_gpus == 1 and args.cpu_baseline:
