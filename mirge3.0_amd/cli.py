@@ -57,7 +57,8 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    args.device = local_rank if args.device is None else args.device
+    # MIRGE_SHARE_GPU=1 (test hook): every rank uses device 0 of a single-GPU box
+    args.device = (0 if os.environ.get("MIRGE_SHARE_GPU") else local_rank) if args.device is None else args.device
     ref_db = DB_KEYS.get(args.mir_DB.lower()) or sys.exit("ERROR: Require valid database (-d miRBase or MirGeneDB)")
     name = args.outDirName or ("miRge." + time.strftime('%Y-%m-%d_%H-%M-%S', time.localtime()))
     workDir = Path(args.outDir or Path.cwd()) / name

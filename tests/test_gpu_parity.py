@@ -461,3 +461,39 @@ print("OK", len(got))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MIRGE_TEST_SMALL_PART="1"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_cli_two_ranks_one_sample_each(tmp_path):
+    """The sharded CLI (torch.distributed.run, one sample per rank, rank 0 gathers the per-sample tables over
+    gloo and writes the run's CSVs): two ranks on the single GPU of the test box, golden case 2."""
+    import subprocess
+    import sys
+    case = GoldenCase("case2_two_samples")
+    files = []
+    for s, nm in enumerate(case.samples):
+        p = tmp_path / f"{nm}.fastq"
+        with open(p, "w") as fh:
+            k = 0
+            for seq, row in zip(case.seqs, case.counts):
+                for _ in range(int(row[s])):
+                    fh.write(f"@r{k}\n{seq}\n+\n{'I' * len(seq)}\n")
+                    k += 1
+        files.append(str(p))
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    launcher = tmp_path / "run_cli.py"
+    launcher.write_text("import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()\n" % root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(launcher), "-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase",
+           "-o", str(tmp_path), "-dn", "out", "-q"]
+    r = subprocess.run(cmd, env=dict(os.environ, MIRGE_SHARE_GPU="1", OMP_NUM_THREADS="2"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = tmp_path / "out"
+    for f in ("miR.Counts.csv", "miR.RPM.csv"):
+        assert (out / f).read_text() == case.text(f), f
+    got = (out / "annotation.report.csv").read_text().splitlines()
+    exp = case.text("annotation.report.csv").splitlines()
+    assert got[0] == exp[0] and len(got) == len(exp)
+    for g_line, e_line in zip(got[1:], exp[1:]):
+        assert g_line.split(",")[2:] == e_line.split(",")[2:]  # all but sample name-adjacent 'Total Input Reads'
+    assert (out / "mapped.S1.csv").exists() and (out / "unmapped.S2.csv").exists()
