@@ -95,7 +95,8 @@ int mirge_reads_set_counts(mirge_ctx* ctx, mirge_reads* reads, const uint32_t* c
 
 /* ---- cascade: replaces bwtAlign + alignPlusParse (manifoldAlign.py:12-146): the n_pass
  * bowtie runs, their FASTA/SAM round trips and the DataFrame updates.  libs[p] == NULL skips
- * pass p.  Result per read: pass index (or MIRGE_NO_PASS), reference index in libs[pass],
+ * pass p.  Every pass sees the rows no earlier pass annotated (the reference tests annotFlag only from
+ * pass 2 on, :120,129, but its passes 0 and 1 are disjoint by length, :93,104, so this is the same).  Result per read: pass index (or MIRGE_NO_PASS), reference index in libs[pass],
  * 0-based offset in that reference, mismatches.                                            */
 int mirge_cascade_run(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib* const* libs,
                       const mirge_policy* policies, int32_t n_pass, mirge_result** out);

@@ -1,0 +1,100 @@
+"""Differential fuzzing on the GPU: random libraries (sizes chosen so that the probe length K and the
+plain / recursive plans vary), random reads (substrings with 0-3 substitutions, N calls, T tails, junk,
+1-128 nt) and RANDOM cascades (any -n / -v budget 0..3, -5/-3 trims, length filters, T-tail rule) through
+mirge_cascade_run, against the brute-force oracle given the same policies.  Bit-exact on every field."""
+import numpy as np
+import pytest
+
+import oracle
+import mirge3_amd  # noqa: F401
+from mirge3_amd import _ffi
+from mirge3_amd.seqio import FlatSeqs
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_seq(rng, L, pn=0.0):
+    s = rng.integers(0, 4, size=L)
+    out = np.frombuffer(b"ACGT", np.uint8)[s].copy()
+    if pn > 0:
+        out[rng.random(L) < pn] = ord("N")
+    return out.tobytes().decode()
+
+
+def _policy(rng):
+    mode = int(rng.integers(0, 2))
+    mm = int(rng.choice([0, 1, 1, 2, 2, 3]))
+    pol = dict(mode=mode, mm=mm, seedlen=int(rng.choice([28, 28, 20, 12])), maxtotal=(int(rng.integers(mm, 4)) if mode == 0 else mm))
+    if rng.random() < 0.3:
+        pol["trim5"] = int(rng.integers(0, 3)); pol["trim3"] = int(rng.integers(0, 3))
+    if rng.random() < 0.15:
+        pol["ttail"] = 1
+    if rng.random() < 0.15:
+        pol["len_lt"] = int(rng.integers(18, 40))
+    elif rng.random() < 0.15:
+        pol["len_gt"] = int(rng.integers(10, 30))
+    return pol
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_cascade_matches_bruteforce(seed):
+    rng = np.random.default_rng(1000 + seed)
+    ctx = _ffi.Context(0)
+    n_pass = int(rng.integers(2, 9))
+    libs, dev, pols = [], [], []
+    same_policy_run = rng.random() < 0.5  # consecutive identical policies -> merged launch
+    for p in range(n_pass):
+        nref = int(rng.choice([3, 20, 150, 1200]))
+        lo, hi = [(18, 25), (40, 120), (100, 600)][int(rng.integers(0, 3))]
+        seqs = [_rand_seq(rng, int(rng.integers(lo, hi + 1)), pn=0.003 if rng.random() < 0.3 else 0.0) for _ in range(nref)]
+        if rng.random() < 0.3:  # repeats: long buckets
+            seqs += [("A" * int(rng.integers(20, 200))) + _rand_seq(rng, 30), "CA" * int(rng.integers(15, 80))]
+        fs = FlatSeqs.from_list(seqs)
+        libs.append(fs)
+        dev.append(_ffi.DeviceLibrary(ctx, fs))
+        if p > 0 and same_policy_run and rng.random() < 0.6:
+            pols.append(dict(pols[-1]))
+        else:
+            pols.append(_policy(rng))
+    reads = []
+    for _ in range(3000):
+        lib = libs[int(rng.integers(0, n_pass))]
+        s = lib.get(int(rng.integers(0, len(lib))))
+        kind = rng.random()
+        L = int(rng.integers(1, 129)) if rng.random() < 0.1 else int(rng.integers(12, 45))
+        if kind < 0.75 and len(s) > 2:
+            L = min(L, len(s))
+            a = int(rng.integers(0, len(s) - L + 1))
+            x = list(s[a:a + L])
+            for _ in range(int(rng.choice([0, 0, 1, 1, 2, 3]))):
+                q = int(rng.integers(0, L)); x[q] = "ACGT"[int(rng.integers(0, 4))]
+            if rng.random() < 0.05:
+                x[int(rng.integers(0, L))] = "N"
+            r = "".join(x)
+            if rng.random() < 0.1:
+                r = (r + "T" * int(rng.integers(3, 8)))[:128]
+            if rng.random() < 0.1:
+                r = ("ACGT"[int(rng.integers(0, 4))] + r + _rand_seq(rng, 2))[:128]
+        else:
+            r = _rand_seq(rng, L, pn=0.02)
+        reads.append(r)
+    fs = FlatSeqs.from_list(reads)
+    policies = []
+    for pol in pols:
+        p = _ffi.MirgePolicy()
+        for k, v in pol.items():
+            setattr(p, k, v)
+        policies.append(p)
+    dr = _ffi.DeviceReads.pack(ctx, fs)
+    res = _ffi.cascade_run(ctx, dr, dev, policies)
+    g = res.fetch()
+    # oracle: passes >= 1 see only unannotated rows; pass 0 sees everything (nothing is annotated yet)
+    opol = [dict(pol, need_unannotated=1) for pol in pols]
+    o = oracle.cascade(fs.data, fs.offsets, [(l.data, l.offsets) for l in libs], n_pass=n_pass, indexed=False, policies=opol)
+    for a, b, nm in zip(o, g, ("pass", "ref", "off", "mm")):
+        bad = np.nonzero(a.astype(np.int64) != b.astype(np.int64))[0]
+        assert bad.size == 0, (seed, nm, pols, [(reads[int(i)], int(a[i]), int(b[i])) for i in bad[:3]])
+    res.close(); dr.close()
+    for d in dev:
+        d.close()
+    ctx.close()
