@@ -98,3 +98,35 @@ def test_random_cascade_matches_bruteforce(seed):
     for d in dev:
         d.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,n,S", [(1, 70000, 1), (2, 150000, 1), (3, 90000, 3), (4, 1000, 2), (5, 66000, 1)])
+def test_random_collapse_matches_counter(seed, n, S):
+    """Collapse on random inputs around the partition threshold (65536 reads), all three width classes, reads
+    with N, one or several samples: the (sequence -> per-sample count) map and first indices must equal Python's."""
+    from collections import Counter
+    rng = np.random.default_rng(50 + seed)
+    pool = []
+    for _ in range(max(n // 6, 10)):
+        L = int(rng.choice([16, 18, 20, 22, 22, 24, 27, 30, 31, 32, 33, 40, 64, 65, 100, 128]))
+        pool.append(_rand_seq(rng, L, pn=0.02 if rng.random() < 0.05 else 0.0))
+    w = 1.0 / np.arange(1, len(pool) + 1) ** 0.9
+    pick = rng.choice(len(pool), size=n, p=w / w.sum())
+    reads = [pool[i] for i in pick]
+    sid = rng.integers(0, S, size=n).astype(np.int32)
+    ctx = _ffi.Context(0)
+    raw = _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(reads))
+    uniq = raw.collapse(sid if S > 1 else None, S)
+    cnt, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    assert len(set(seqs)) == len(seqs)
+    exp = [Counter() for _ in range(S)]
+    first_exp = {}
+    for i, (r, s) in enumerate(zip(reads, sid if S > 1 else np.zeros(n, np.int32))):
+        exp[int(s)][r] += 1
+        first_exp.setdefault(r, i)
+    assert set(seqs) == set(first_exp)
+    for i, r in enumerate(seqs):
+        assert [int(x) for x in cnt[i]] == [exp[s].get(r, 0) for s in range(S)], r
+        assert int(first[i]) == first_exp[r], r
+    uniq.close(); raw.close(); ctx.close()
