@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (s
 ALGO_BYTES = {
     "k_collapse_insert": 9 + 4,      # read in, slot id out, per raw read
     "k_collapse_insert_key": 9 + 4,  # same, 64-bit-key table (<=31 nt, no N, one sample)
-    "k_part_hist": 9, "k_part_scatter": 9 + 12, "k_part_dedup": 12 + 17,  # 17 = key + len + count + first per unique (bound: per raw read)
+    "k_part_agg": 9 + 12, "k_part_scatter": 9 + 12, "k_part_dedup": 12 + 17,  # 17 = key + len + count + first per unique (bound: per raw read)
     "k_part_prefix": 8,
     "k_heads_blocksum": 4 + 4 + 1,   # slot id + first-index in, head flag out, per raw read
     "k_collapse_scatter": 1 + 4 + 13,  # head flag + slot id in; key+len+count out (upper bound: per raw read)
@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
+    ap.add_argument("--pool", type=int, default=0,
+                    help="draw the reads from this many templates with Zipf weights (SURVEY 8d 'realistic' U/N); 0 = independent draws")
     ap.add_argument("--pmc", type=int, default=1,
                     help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()
@@ -160,7 +162,10 @@ def main():
     n_pass = 1 if args.workload == "c2" else 9
     libs = {"mirna": sl.libs["mirna"]} if args.workload in ("c2", "c5") else sl.libs
     casc = Cascade(ctx, libs, n_pass=n_pass)
-    reads = synth.make_reads_chunked(sl, args.reads, seed=1000 + rank)  # one sample per rank
+    if args.pool:
+        reads = synth.make_reads(sl, args.reads, seed=1000 + rank, pool=args.pool)
+    else:
+        reads = synth.make_reads_chunked(sl, args.reads, seed=1000 + rank)  # one sample per rank
     raw = _ffi.DeviceReads.pack(ctx, reads)
     n_mirna = len(sl.libs["mirna"])
     t_setup = time.perf_counter() - t_setup
@@ -244,6 +249,7 @@ def main():
                          "c5": "C5: collapse -> exact + <=2-mismatch isomiR passes vs the miRNA library -> count join -> "
                                "per-position variant tally"}[args.workload],
             "raw_reads_per_gpu": args.reads, "unique_reads_per_gpu": U, "library_scale": args.scale,
+            "read_templates": args.pool or None,
             "library_bases": {k: v.total_len for k, v in libs.items()}, "passes": n_pass,
             "sharding": f"{n_gpus} sample(s), one per GPU, no collective",
         },

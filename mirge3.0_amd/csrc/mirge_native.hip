@@ -653,8 +653,8 @@ struct CollapseTmp {
     uint32_t cnt_stride = 1, nb = 0;
     // partitioned key path
     bool partitioned = false;
-    uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr;
-    uint4* part = nullptr;
+    uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr, *nrec = nullptr;
+    uint4 *part = nullptr, *recs = nullptr;
 };
 // dmeta: [0..5] U of each group, [6] partition overflow flag, [8 .. 8+128] length histogram
 #define MIRGE_META_OVERFLOW 6
@@ -688,10 +688,11 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         // exercise the fallback to the global-atomic path (tests/test_gpu_parity.py)
         static const bool small_part = std::getenv("MIRGE_TEST_SMALL_PART") != nullptr;
         while (!small_part && B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
-        if (B * 4 > 48 * 1024) {  // histogram / cursor arrays beyond the default dynamic-LDS window
-            HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * 4)));
+        const uint32_t CS = B > 16384 ? 1024 : 2048;  // chunk-level LDS cache slots (16 B each)
+        const int agg_lds = (int)(CS * 16 + (B + 1) * 4 + 64);
+        HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_agg), hipFuncAttributeMaxDynamicSharedMemorySize, agg_lds));
+        if (B * 4 > 48 * 1024)
             HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * 4)));
-        }
         static bool dedup_attr = false;
         if (!dedup_attr) {
             HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -707,6 +708,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         CHECK(dalloc(c, &t.off, (size_t)G * B));
         CHECK(dalloc(c, &t.btotal, (size_t)B + 1));
         CHECK(dalloc(c, &t.part, (size_t)in.n));
+        CHECK(dalloc(c, &t.recs, (size_t)G * chunk));
+        CHECK(dalloc(c, &t.nrec, (size_t)G));
         // outputs at capacity n (U is not known yet): the bucket workgroups emit the unique reads themselves
         out.W = 1;
         CHECK(dalloc(c, &out.seq, (size_t)in.n));
@@ -715,8 +718,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         CHECK(dalloc(c, &out.first, (size_t)in.n));
         GroupView<1> v1 = view_of<1>(in);
         {
-            LaunchScope ls(c, "k_part_hist.w1", in.n);
-            hipLaunchKernelGGL(k_part_hist, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, v1, chunk, bshift, B, t.hist);
+            LaunchScope ls(c, "k_part_agg.w1", in.n);
+            hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_BLOCK), agg_lds, c->cur, v1, chunk, bshift, B, CS, t.recs, t.nrec, t.hist);
         }
         {
             LaunchScope ls(c, "k_part_prefix.w1", (double)G * B);
@@ -728,7 +731,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         }
         {
             LaunchScope ls(c, "k_part_scatter.w1", in.n);
-            hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, v1, chunk, bshift, B, t.off, t.btotal, t.part);
+            hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, t.recs, t.nrec, chunk, bshift, B, t.off,
+                               t.btotal, t.part);
         }
         {
             LaunchScope ls(c, "k_part_dedup.w1", in.n);
@@ -758,7 +762,9 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         HIPOK(hipMemsetAsync(t.cnt, 0, (size_t)tsize * S * 4, c->cur));
         std::snprintf(name, sizeof(name), "k_collapse_insert%s", group_tag(gi));
         LaunchScope ls(c, name, in.n);
-        hipLaunchKernelGGL(k_collapse_insert<W>, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->cur,
+        // at most 2 workgroups per CU: each sees enough of the group for its LDS cell cache to merge hot reads
+        const int ins_grid = std::min(grid_for(c, in.n), c->n_cu * 2);
+        hipLaunchKernelGGL(k_collapse_insert<W>, dim3(ins_grid), dim3(MIRGE_BLOCK), 0, c->cur,
                            v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S);
         first_base = t.firstj; first_stride = 1;
         t.cnt_base = t.cnt; t.cnt_stride = (uint32_t)S;
@@ -799,7 +805,7 @@ static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
 static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
     c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
     c->defer(t.flag); c->defer(t.blocksum);
-    c->defer(t.hist); c->defer(t.off); c->defer(t.btotal); c->defer(t.part);
+    c->defer(t.hist); c->defer(t.off); c->defer(t.btotal); c->defer(t.part); c->defer(t.recs); c->defer(t.nrec);
     t = CollapseTmp();
 }
 
