@@ -497,3 +497,39 @@ def test_cli_two_ranks_one_sample_each(tmp_path):
     for g_line, e_line in zip(got[1:], exp[1:]):
         assert g_line.split(",")[2:] == e_line.split(",")[2:]  # all but sample name-adjacent 'Total Input Reads'
     assert (out / "mapped.S1.csv").exists() and (out / "unmapped.S2.csv").exists()
+
+
+def test_full_size_c3_properties(ctx):
+    """BASELINE configs[2] at its full size -- 10 M raw reads against the human-sized libraries (130 Mb mRNA,
+    11 Mb ncRNA): conservation, checksum of checksums, subset rules, order independence, and the oracle on
+    a random sample of the collapsed reads."""
+    sl = synth.make_libraries(seed=20260101, scale="full")
+    casc = Cascade(ctx, sl.libs)
+    reads = synth.make_reads_chunked(sl, 10_000_000, seed=1000)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq = raw.collapse()
+    counts, first = uniq.counts()
+    assert int(counts.sum()) == len(reads) and len(np.unique(first)) == len(uniq)
+    res = casc.run(uniq)
+    ps, ref, off, mm = res.fetch()
+    cls, ex, iso = _ffi.count_join(ctx, uniq, res, 0, 8, len(sl.libs["mirna"]))
+    c = counts[:, 0].astype(np.int64)
+    for p in range(9):
+        assert cls[p, 0] == c[ps == p].sum()
+    assert cls.sum() + c[ps < 0].sum() == len(reads)
+    assert ex.sum() == cls[0, 0] and iso.sum() == cls[8, 0]
+    useq = uniq.unpack()
+    lens = useq.lengths
+    assert (lens[ps == 0] < 26).all() and (lens[ps == 1] > 25).all()
+    assert (mm[ps >= 0] >= 0).all() and (mm[ps >= 0] <= 2).all() and (mm[ps == 0] == 0).all() and (mm[ps == 3] == 0).all()
+    rng = np.random.default_rng(2)
+    pick = rng.permutation(len(uniq))[:300000]
+    sub = useq.take(pick)
+    g = casc.annotate(sub)
+    for a, b in zip(g, (ps, ref, off, mm)):
+        assert np.array_equal(a, b[pick])
+    k = 40000
+    o = oracle.cascade(sub.data[: sub.offsets[k]], sub.offsets[: k + 1], oracle_libs_from(sl.libs), n_pass=9, indexed=True)
+    for a, b in zip(o, g):
+        assert np.array_equal(a.astype(np.int64), b[:k].astype(np.int64))
+    res.close(); uniq.close(); raw.close(); casc.close()
