@@ -38,6 +38,10 @@ def parse_args(argv=None):
     ap.add_argument("-m", "--minimum-length", dest="minimum_length", type=int, default=16)
     ap.add_argument("-spk", "--spikeIn", dest="spikeIn", action="store_true")
     ap.add_argument("-q", "--quiet", action="store_true")
+    ap.add_argument("-spl", "--save-pkl", dest="save_pkl", action="store_true",
+                    help="save collapsed.pkl / collapsed_accessories.pkl after collapsing (mirge/__main__.py:142-148)")
+    ap.add_argument("-rr", "--resume", action="store_true",
+                    help="-s names a directory holding those two files: skip the collapse (mirge/__main__.py:91-108)")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted, unused (GPU path)")
     ap.add_argument("--device", type=int, default=None)
     for flag in ("-a", "-g", "-umi", "-nmir", "-gff", "-bam", "-trf", "-ai", "-ie", "-mEC", "-dex"):
@@ -68,6 +72,8 @@ def main(argv=None):
     if rank == 0:
         with open(workDir / "run.log", "a+") as fh:
             fh.write(" ".join(sys.argv) + "\n")
+    if world > 1 and (args.resume or args.save_pkl):
+        sys.exit("-spl / -rr are single-process options")
     if not (Path(args.libraries_path) / args.organism_name / "index.Libs").exists():
         sys.exit("\n ERROR: The path to miRge libraries is incorrect or does not exist!\n")
 
@@ -75,7 +81,21 @@ def main(argv=None):
     from .collapse import baking
     from .countjoin import summarize, finish_tables
     if world == 1:
-        df, src, trimmed, uniq = baking(args, files, base_names, str(workDir))
+        import pickle
+        if args.resume:  # same two files, same order of their contents as the reference writes them
+            import pandas as pd
+            rootToPKL = Path(files[0]).absolute()
+            if not (rootToPKL / "collapsed.pkl").exists() or not (rootToPKL / "collapsed_accessories.pkl").exists():
+                sys.exit("\nERROR: The provided path doesn't contain pickle files with .pkl extensions!\n")
+            df = pd.read_pickle(rootToPKL / "collapsed.pkl")
+            with open(rootToPKL / "collapsed_accessories.pkl", "rb") as pklin:
+                src, trimmed, uniq, files, base_names = pickle.load(pklin)
+        else:
+            df, src, trimmed, uniq = baking(args, files, base_names, str(workDir))
+        if args.save_pkl and not args.resume:
+            df.to_pickle(workDir / "collapsed.pkl")
+            with open(workDir / "collapsed_accessories.pkl", "wb") as pklac:
+                pickle.dump([src, trimmed, uniq, files, base_names], pklac, protocol=pickle.HIGHEST_PROTOCOL)
         df = bwt_align(args, df, str(workDir), ref_db)
         pdMapped, pdUnmapped = df[df.annotFlag.eq(1)], df[df.annotFlag.eq(0)]
         summarize(args, str(workDir), ref_db, base_names, pdMapped, src, trimmed, uniq)

@@ -400,6 +400,16 @@ def test_cli_end_to_end_single_process(tmp_path):
     assert (out / "mapped.csv").read_text() == case.text("mapped.csv")
     assert (out / "unmapped.csv").read_text() == case.text("unmapped.csv")
     assert "Alignment completed" in (out / "run.log").read_text()
+    # save (-spl) and resume (-rr) through the reference's two pickle files (mirge/__main__.py:91-108,142-148)
+    r = subprocess.run(cmd[:-3] + ["-dn", "out_spl", "-q", "-spl"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    spl = tmp_path / "out_spl"
+    assert (spl / "collapsed.pkl").exists() and (spl / "collapsed_accessories.pkl").exists()
+    cmd_rr = cmd[:3] + ["-s", str(spl)] + cmd[5:-3] + ["-dn", "out_rr", "-q", "-rr"]
+    r = subprocess.run(cmd_rr, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for f in ("miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "annotation.report.csv"):
+        assert (tmp_path / "out_rr" / f).read_text() == (out / f).read_text(), f
     with pytest.raises(SystemExit):
         from mirge3_amd.cli import parse_args
         parse_args(["-s", "x.fastq", "-lib", "L", "-on", "human", "-gff"])
