@@ -384,43 +384,85 @@ extern "C" void mirge_lib_destroy(mirge_lib* L) {
 extern "C" int64_t mirge_lib_n_refs(const mirge_lib* L) { return L ? L->n_refs : -1; }
 extern "C" int64_t mirge_lib_device_bytes(const mirge_lib* L) { return L ? (int64_t)L->device_bytes : -1; }
 
-// build the table of one probe shape (k1 bases, gap, k2 bases) if it does not exist yet
-static int lib_prepare_shape(mirge_lib* L, int k1, int gap, int k2) {
-    if (k1 < 1 || k1 > MIRGE_KMAX || k2 < 0 || k1 + k2 > MIRGE_KMAX || gap < 0 || gap > 31 || (k2 == 0 && gap != 0))
-        return fail(-1, "probe shape out of range");
-    std::lock_guard<std::mutex> lk(L->mu);
-    const int sid = mirge_shape_id(k1, gap, k2);
-    if (L->htables[sid].bucket) return 0;
-    HIPOK(hipSetDevice(L->ctx->device));
-    std::vector<uint32_t> bucket, pos;
-    mirge_hostlib_table(L->h, k1, gap, k2, bucket, pos);
-    uint32_t* dbucket = nullptr; uint32_t* dpos = nullptr;
-    HIPOK(hipMalloc((void**)&dbucket, bucket.size() * 4));
-    HIPOK(hipMalloc((void**)&dpos, pos.size() * 4));
-    HIPOK(hipMemcpy(dbucket, bucket.data(), bucket.size() * 4, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(dpos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+// one probe shape (k1 bases, gap, k2 bases) and its host-built table
+struct ShapeJob {
+    int k1 = 0, gap = 0, k2 = 0;
+    std::vector<uint32_t> bucket, pos, bits;
+};
+
+static void shape_job_build(const mirge_lib* L, ShapeJob& j) {
+    mirge_hostlib_table(L->h, j.k1, j.gap, j.k2, j.bucket, j.pos);
+    if (j.k1 + j.k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
+        const size_t nb = j.bucket.size() - 1;
+        j.bits.assign((nb + 31) / 32, 0u);
+        for (size_t b = 0; b < nb; b++) if (j.bucket[b + 1] > j.bucket[b]) j.bits[b >> 5] |= 1u << (b & 31);
+    }
+}
+
+// upload one host-built table and publish it in the library's device registry
+static int lib_upload_shape(mirge_lib* L, const ShapeJob& j) {
+    const int sid = mirge_shape_id(j.k1, j.gap, j.k2);
+    uint32_t *dbucket = nullptr, *dpos = nullptr, *dbits = nullptr;
+    HIPOK(hipMalloc((void**)&dbucket, j.bucket.size() * 4));
+    HIPOK(hipMalloc((void**)&dpos, std::max<size_t>(j.pos.size(), 1) * 4));
+    HIPOK(hipMemcpy(dbucket, j.bucket.data(), j.bucket.size() * 4, hipMemcpyHostToDevice));
+    if (!j.pos.empty()) HIPOK(hipMemcpy(dpos, j.pos.data(), j.pos.size() * 4, hipMemcpyHostToDevice));
+    L->device_bytes += j.bucket.size() * 4 + j.pos.size() * 4;
+    if (!j.bits.empty()) {
+        HIPOK(hipMalloc((void**)&dbits, j.bits.size() * 4));
+        HIPOK(hipMemcpy(dbits, j.bits.data(), j.bits.size() * 4, hipMemcpyHostToDevice));
+        L->device_bytes += j.bits.size() * 4;
+    }
     L->htables[sid].bucket = dbucket;
     L->htables[sid].pos = dpos;
-    L->htables[sid].bits = nullptr;
-    L->device_bytes += bucket.size() * 4 + pos.size() * 4;
-    if (k1 + k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
-        const size_t nb = bucket.size() - 1;
-        std::vector<uint32_t> bits((nb + 31) / 32, 0u);
-        for (size_t b = 0; b < nb; b++) if (bucket[b + 1] > bucket[b]) bits[b >> 5] |= 1u << (b & 31);
-        uint32_t* dbits = nullptr;
-        HIPOK(hipMalloc((void**)&dbits, bits.size() * 4));
-        HIPOK(hipMemcpy(dbits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
-        L->htables[sid].bits = dbits;
-        L->device_bytes += bits.size() * 4;
-    }
+    L->htables[sid].bits = dbits;
     HIPOK(hipStreamSynchronize(L->ctx->stream));  // no kernel may be reading the registry while it changes
     HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));
     return 0;
 }
 
+// build the tables of the wanted probe shapes that do not exist yet: the host counting sorts run on up
+// to 8 threads (one table each), the uploads are serial
+static int lib_prepare_shapes(mirge_lib* L, const std::vector<ShapeJob>& wanted) {
+    std::lock_guard<std::mutex> lk(L->mu);
+    std::vector<ShapeJob> jobs;
+    for (const auto& w : wanted) {
+        if (w.k1 < 1 || w.k1 > MIRGE_KMAX || w.k2 < 0 || w.k1 + w.k2 > MIRGE_KMAX || w.gap < 0 || w.gap > 31 || (w.k2 == 0 && w.gap != 0))
+            return fail(-1, "probe shape out of range");
+        const int sid = mirge_shape_id(w.k1, w.gap, w.k2);
+        if (L->htables[sid].bucket) continue;
+        bool dup = false;
+        for (const auto& j : jobs) dup |= mirge_shape_id(j.k1, j.gap, j.k2) == sid;
+        if (dup) continue;
+        jobs.emplace_back();
+        jobs.back().k1 = w.k1; jobs.back().gap = w.gap; jobs.back().k2 = w.k2;
+    }
+    if (jobs.empty()) return 0;
+    HIPOK(hipSetDevice(L->ctx->device));
+    // a table of 4^14 buckets is 1 GiB of host memory before its positions: fewer of those at a time
+    size_t big = 0;
+    for (const auto& j : jobs) big = std::max(big, (size_t)1 << (2 * (j.k1 + j.k2)));
+    const size_t cap = big >= ((size_t)1 << 26) ? 4 : 8;
+    const size_t T = std::max<size_t>(1, std::min({cap, jobs.size(), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+    for (size_t base = 0; base < jobs.size(); base += T) {
+        const size_t end = std::min(jobs.size(), base + T);
+        std::vector<std::thread> th;
+        for (size_t i = base + 1; i < end; i++) th.emplace_back([L, &jobs, i] { shape_job_build(L, jobs[i]); });
+        shape_job_build(L, jobs[base]);
+        for (auto& t : th) t.join();
+        for (size_t i = base; i < end; i++) {
+            CHECK(lib_upload_shape(L, jobs[i]));
+            jobs[i] = ShapeJob();  // drop the host copy
+        }
+    }
+    return 0;
+}
+
 extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {
     if (!L) return fail(-1, "lib is NULL");
-    return lib_prepare_shape(L, k, 0, 0);
+    std::vector<ShapeJob> w(1);
+    w[0].k1 = k;
+    return lib_prepare_shapes(L, w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -978,6 +1020,8 @@ struct PassStep {
 static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t* hist) {
     MirgePolicy p;
     std::memcpy(&p, &pol, sizeof(p));
+    std::vector<ShapeJob> wanted;
+    std::vector<bool> seen(MIRGE_SHAPE_SLOTS, false);
     for (int L = 1; L <= MIRGE_MAX_READ_LEN; L++) {
         if (!hist[L]) continue;
         if (p.len_lt > 0 && !(L < p.len_lt)) continue;
@@ -991,11 +1035,16 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
             for (int q = 0; q < np; q++) {
                 MirgeProbe pr;
                 mirge_probe_at(p, l, lib->kmax, q, pr);
-                if (pr.k1 > 0) CHECK(lib_prepare_shape(lib, pr.k1, pr.gap, pr.k2));
+                if (pr.k1 <= 0) continue;
+                const int sid = mirge_shape_id(pr.k1, pr.gap, pr.k2);
+                if (seen[sid]) continue;
+                seen[sid] = true;
+                wanted.emplace_back();
+                wanted.back().k1 = pr.k1; wanted.back().gap = pr.gap; wanted.back().k2 = pr.k2;
             }
         }
     }
-    return 0;
+    return lib_prepare_shapes(lib, wanted);
 }
 
 template <int W>
