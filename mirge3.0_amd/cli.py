@@ -4,7 +4,7 @@
 
 Same flag names as the reference (``mirge/libs/parse.py``) for what is implemented; flags of
 subsystems that are out of scope (novel miRNA, GFF, BAM, tRF, A-to-I, DESeq2, miREC, adapter
-trimming) are rejected instead of being ignored.  Writes the reference's files: ``run.log``,
+trimming, -qumi) are rejected instead of being ignored.  Writes the reference's files: ``run.log``,
 ``mapped.csv``, ``unmapped.csv``, ``miR.Counts.csv``, ``miR.RPM.csv``, ``annotation.report.csv/html``.
 
 One process: all samples on one GPU, byte-compatible outputs.  Under ``torch.distributed.run`` with N
@@ -42,16 +42,24 @@ def parse_args(argv=None):
                     help="save collapsed.pkl / collapsed_accessories.pkl after collapsing (mirge/__main__.py:142-148)")
     ap.add_argument("-rr", "--resume", action="store_true",
                     help="-s names a directory holding those two files: skip the collapse (mirge/__main__.py:91-108)")
+    ap.add_argument("-umi", "--uniq-mol-ids", dest="uniq_mol_ids", default=None,
+                    help="f,b: drop f bases at the 5' end and b at the 3' end of every read before collapsing")
+    ap.add_argument("-udd", "--umiDedup", dest="umiDedup", action="store_true",
+                    help="with -umi: count distinct UMI-tagged reads per insert (writes <sample>_umiCounts.csv)")
+    ap.add_argument("-tcf", "--tcf-out", dest="tcf_out", action="store_true",
+                    help="write <sample>.trim.collapse.fa")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted, unused (GPU path)")
     ap.add_argument("--device", type=int, default=None)
-    for flag in ("-a", "-g", "-umi", "-nmir", "-gff", "-bam", "-trf", "-ai", "-ie", "-mEC", "-dex"):
+    for flag in ("-a", "-g", "-qumi", "-nmir", "-gff", "-bam", "-trf", "-ai", "-ie", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
     for k, v in vars(args).items():
         if k.startswith("oos_") and v is not None:
             ap.error(f"-{k[4:]} belongs to a miRge3.0 subsystem outside the MI355X hot path (DESIGN.md section 0)")
-    args.adapters = args.front = args.uniq_mol_ids = None
+    if args.umiDedup and not args.uniq_mol_ids:
+        ap.error("-udd requires -umi f,b")
+    args.adapters = args.front = args.qiagenumi = None
     return args
 
 

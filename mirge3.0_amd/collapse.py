@@ -10,6 +10,13 @@ U x S count matrix.
 Scope: reads are taken as already trimmed (adapter/quality trimming is
 cutadapt's, third-party and upstream of the path).  Asking for adapter trimming raises instead of
 silently skipping it.  Only the length filter of digest.py:348,368 (``--minimum-length``) applies.
+
+UMI handling (digest.py:164-205,305-315,358-365): ``-umi f,b`` slices f bases off
+the front and b off the back of every read before the collapse (counts add up); with ``-udd`` the
+full reads are collapsed first (on the GPU), ``<sample>_umiCounts.csv`` is written from that result,
+and the inserts of the DISTINCT tagged reads are collapsed again, so a count is a number of molecules.
+``-qumi`` needs the adapter match of cutadapt and is refused.  ``-tcf`` writes
+``<sample>.trim.collapse.fa`` (digest.py:219-229).
 """
 from __future__ import annotations
 
@@ -82,13 +89,29 @@ def collapse_samples(ctx: _ffi.Context, samples: Sequence[FlatSeqs]):
     return uniq
 
 
+def _collapse_one(ctx: _ffi.Context, reads: FlatSeqs):
+    """One sample alone -> (sequences, counts) in dict order (first appearance, digest.py:158-163)."""
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq = raw.collapse(None, 1)
+    raw.close()
+    counts, first = uniq.counts()
+    seqs = uniq.unpack()
+    uniq.close()
+    order = np.argsort(first, kind="stable")
+    return seqs.take(order), counts[order, 0].astype(np.int64)
+
+
 def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None):
     """Drop-in for ``baking`` (digest.py:105-302) on already-trimmed reads."""
     import pandas as pd
-    if getattr(args, "adapters", None) or getattr(args, "front", None) or getattr(args, "uniq_mol_ids", None):
+    if getattr(args, "adapters", None) or getattr(args, "front", None) or getattr(args, "qiagenumi", None):
         raise NotImplementedError(
-            "adapter / UMI trimming is outside the MI355X hot path (SURVEY.md 8f, N4): trim with cutadapt "
-            "first and pass the trimmed reads")
+            "adapter trimming (and -qumi, which reads the adapter match) is outside the MI355X hot path "
+            "(SURVEY.md 8f, N4): trim with cutadapt first and pass the trimmed reads")
+    umi = getattr(args, "uniq_mol_ids", None)
+    dedup = bool(getattr(args, "umiDedup", False))
+    if umi:
+        umi_f, umi_b = (int(x) for x in str(umi).split(","))
     begningTime = time.perf_counter()
     runlogFile = Path(workDir) / "run.log"
     outlog = open(str(runlogFile), "a+")
@@ -100,13 +123,32 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
         start = time.perf_counter()
         reads = read_fastq_sequences(str(FQfile))
         sampleReadCounts[name] = len(reads)
-        reads = filter_min_length(reads, min_len)
+        if not umi:
+            reads = filter_min_length(reads, min_len)
+        else:
+            pure, _ = reads.umi_split(umi_f, umi_b)
+            keep = np.flatnonzero(pure.lengths >= min_len)  # the worker's filter is on the insert (:360)
+            if not dedup:
+                reads = pure.take(keep)  # counts add up: slicing first == slicing the collapsed dict (:168-181)
+            else:
+                full, c = _collapse_one(ctx, reads.take(keep))
+                pure, tag = full.umi_split(umi_f, umi_b)
+                with open(Path(workDir) / (name + "_umiCounts.csv"), "a+") as iumiFile:  # (:183-197)
+                    iumiFile.write("UMISeq,transcriptSeq,UMICounts\n")
+                    iumiFile.write("".join(f"{t},{p},{n}\n" for t, p, n in zip(tag.to_list(), pure.to_list(), c.tolist())))
+                reads = pure  # one entry per distinct tagged read, in dict order
         trimmedReadCounts[name] = len(reads)
         samples.append(reads)
         finish2 = time.perf_counter()
         if not args.quiet:
             print(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)')
         outlog.write(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)\n')
+        if getattr(args, "tcf_out", False):  # (:219-229): by count, ties in dict order
+            tseqs, tc = _collapse_one(ctx, reads)
+            by = np.argsort(-tc, kind="stable")
+            tl = tseqs.to_list()
+            with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
+                fo.write("".join(f">seq{k + 1}_{int(tc[i])}\n{tl[i]}\n" for k, i in enumerate(by)))
     t0 = time.perf_counter()
     uniq = collapse_samples(ctx, samples)
     counts, first = uniq.counts()

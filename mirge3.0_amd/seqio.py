@@ -42,6 +42,33 @@ class FlatSeqs:
         data = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).copy()
         return FlatSeqs(data, offsets)
 
+    def _ranges(self, starts: np.ndarray, lens: np.ndarray) -> "FlatSeqs":
+        offsets = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        rows = np.repeat(np.arange(lens.shape[0], dtype=np.int64), lens)
+        within = np.arange(int(offsets[-1]), dtype=np.int64) - offsets[:-1][rows]
+        return FlatSeqs(self.data[starts[rows] + within], offsets)
+
+    def umi_split(self, front: int, back: int):
+        """``UMIParser`` of every sequence (digest.py:305-315) -> (inserts ``s[f:-b]``, tags ``s[:f]+s[-b:]``);
+        Python slice semantics, including ``s[-0:]`` = the whole sequence."""
+        f, b = int(front), int(back)
+        ln, o = self.lengths, self.offsets[:-1]
+        lo = np.minimum(f, ln)
+        hi = np.maximum(ln - b, 0) if b != 0 else ln
+        pure = self._ranges(o + lo, np.maximum(hi - lo, 0))
+        tail = np.minimum(b, ln) if b != 0 else ln
+        head, end = self._ranges(o, lo), self._ranges(o + ln - tail, tail)
+        tl = lo + tail
+        toff = np.zeros(ln.shape[0] + 1, dtype=np.int64)
+        np.cumsum(tl, out=toff[1:])
+        tdata = np.empty(int(toff[-1]), np.uint8)
+        rows = np.repeat(np.arange(ln.shape[0], dtype=np.int64), lo)
+        tdata[toff[:-1][rows] + (np.arange(head.data.shape[0]) - head.offsets[:-1][rows])] = head.data
+        rows = np.repeat(np.arange(ln.shape[0], dtype=np.int64), tail)
+        tdata[toff[:-1][rows] + lo[rows] + (np.arange(end.data.shape[0]) - end.offsets[:-1][rows])] = end.data
+        return pure, FlatSeqs(tdata, toff)
+
     def take(self, idx: np.ndarray) -> "FlatSeqs":
         idx = np.asarray(idx, dtype=np.int64)
         lens = self.lengths[idx]

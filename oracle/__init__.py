@@ -145,6 +145,31 @@ REPORT_CLASSES = [  # (report column, pass index)  summary.py:686-690,895-901
 ]
 
 
+def umi_parser(s: str, f: int, b: int):
+    """``UMIParser`` (digest.py:305-315): -> (insert, UMI bases).  ``s[-b:]`` with b == 0 is the whole
+    read, so the 'UMI' of a front-only layout is front + read -- kept, it is what the reference writes."""
+    center = s[f:-b] if int(b) != 0 else s[f:]
+    return center, s[:f] + s[-b:]
+
+
+def umi_collapse(raw: List[str], f: int, b: int, min_len: int, dedup: bool):
+    """Collapse with ``-umi f,b`` [``-udd``] (digest.py:358-365 worker filter, :158-163 merge, :164-205 UMI
+    stage) -> (ordered list of (insert, count), trimmed, rows of <sample>_umiCounts.csv or None)."""
+    complete = {}
+    for s in raw:
+        if len(umi_parser(s, f, b)[0]) >= min_len:
+            complete[s] = complete.get(s, 0) + 1
+    d, trimmed, rows = {}, 0, []
+    for s, c in complete.items():
+        pure, tag = umi_parser(s, f, b)
+        if len(pure) >= min_len:
+            if dedup:
+                rows.append(f"{tag},{pure},{c}\n")
+            d[pure] = d.get(pure, 0) + (1 if dedup else c)
+            trimmed += 1 if dedup else c
+    return list(d.items()), trimmed, (["UMISeq,transcriptSeq,UMICounts\n"] + rows if dedup else None)
+
+
 def _fmt_float(x: float) -> str:
     return repr(float(x))
 

@@ -205,7 +205,58 @@ def run_case(case, seed, n_raw, n_samples, spike_in):
     print(case, "rows", len(df), "mapped", len(pdMapped), "->", out_dir)
 
 
+def run_umi_case():
+    """UMI handling (digest.py:164-205,305-315,358-365): the reference's own ``UMIParser`` answers for
+    the slicing (incl. its ``s[-0:]`` behaviour); the dict loops around it are the 40 lines of
+    ``baking`` that cannot run without cutadapt/dnaio, replayed here with plain dicts."""
+    import json
+    from mirge.libs.digest import UMIParser  # the reference
+    out_dir = os.path.join(HERE, "umi")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    sl = synth.make_libraries(seed=21, scale="tiny")
+    rng = np.random.Generator(np.random.PCG64(77))
+    inserts = synth.make_reads(sl, 300, seed=5).to_list()
+    inserts = inserts + inserts[:40] * 3 + [inserts[7][:15], inserts[8][:16], "ACGTACGTACGTACGT"]
+    tags = ["".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=8)) for _ in range(12)]
+    raw = []
+    for ins in inserts:
+        for _ in range(int(rng.integers(1, 4))):
+            t = tags[int(rng.integers(0, len(tags)))]
+            raw.append(t[:4] + ins + t[4:])
+    raw += [raw[3]] * 5 + [raw[10]] * 2 + ["ACGT" * 5 + "N" + "ACGT" * 3]
+    order = rng.permutation(len(raw))
+    raw = [raw[i] for i in order]
+    with open(os.path.join(out_dir, "reads.txt"), "w") as fh:
+        fh.write("\n".join(raw) + "\n")
+    cases = []
+    for f, b in ((4, 4), (0, 4), (4, 0), (3, 30), (0, 0)):
+        min_len = 16
+        parser = [[s_, *UMIParser(s_, f, b)] for s_ in raw[:25] + ["ACGT", "", "ACGTACG"]]
+        completeDict = {}
+        for s_ in raw:  # cutadapt() worker, digest.py:358-365, + merge :158-163
+            if len(UMIParser(s_, f, b)[0]) >= min_len:
+                completeDict[s_] = completeDict.get(s_, 0) + 1
+        res = {}
+        for dedup in (False, True):  # digest.py:164-205
+            d, trimmed, lines = {}, 0, ["UMISeq,transcriptSeq,UMICounts\n"]
+            for s_, c in completeDict.items():
+                pureSeq, cutumiSeq = UMIParser(s_, f, b)
+                if len(pureSeq) >= min_len:
+                    if dedup:
+                        lines.append(str(cutumiSeq) + "," + str(pureSeq) + "," + str(c) + "\n")
+                    d[pureSeq] = d.get(pureSeq, 0) + (1 if dedup else c)
+                    trimmed += 1 if dedup else c
+            res["udd" if dedup else "umi"] = {"dict": list(d.items()), "trimmed": trimmed, "unique": len(d),
+                                              "umiCounts_csv": "".join(lines) if dedup else None}
+        cases.append({"front": f, "back": b, "min_len": min_len, "total_input": len(raw), "parser": parser, **res})
+    with open(os.path.join(out_dir, "umi_cases.json"), "w") as fh:
+        json.dump(cases, fh, indent=0)
+    print("umi", len(raw), "reads ->", out_dir)
+
+
 if __name__ == "__main__":
+    run_umi_case()
     run_case("case1_single", seed=11, n_raw=1200, n_samples=1, spike_in=False)
     run_case("case2_two_samples", seed=12, n_raw=900, n_samples=2, spike_in=False)
     run_case("case3_spikein", seed=13, n_raw=600, n_samples=2, spike_in=True)

@@ -96,6 +96,66 @@ def test_golden_dropin_signatures(name, tmp_path):
         assert (tmp_path / f).read_text() == case.text(f), f
 
 
+def test_bowtie_shim_process_boundary(tmp_path):
+    """mirge3.0_amd/shim/{bowtie,bowtie-inspect}: the reference's process boundary on the MI355X engine
+    (SURVEY.md 8b item 3).  The harness below replays what manifoldAlign.py:12-64,84-135 does around that
+    boundary -- argv strings verbatim, FASTA named by sequence, SAM consumed field 0 / field 2 -- and the
+    result must be the mapped.csv / unmapped.csv the reference itself wrote for the golden case."""
+    import re
+    import subprocess
+    import sys
+    import pandas as pd
+    case = GoldenCase("case3_spikein")
+    shim = os.path.join(os.path.dirname(os.path.abspath(mirge3_amd.__file__)), "shim")
+    v = subprocess.run([sys.executable, os.path.join(shim, "bowtie"), "--version"], capture_output=True, text=True, check=True)
+    assert v.stdout.split("\n")[0].split(" ")[2] in ["1.0.0", "1.2.1", "1.2.2", "1.2.3", "1.3.0", "1.3.1", "1.3.2"]
+    idxdir = os.path.join(case.libdir, ORG, "index.Libs")
+    n = subprocess.run([sys.executable, os.path.join(shim, "bowtie-inspect"), "-n", os.path.join(idxdir, f"{ORG}_mirna_{DB}")],
+                       capture_output=True, text=True, check=True)
+    assert n.stdout.strip().split("\n") == case.libs["mirna"].headers
+    fa = subprocess.run([sys.executable, os.path.join(shim, "bowtie-inspect"), os.path.join(idxdir, f"{ORG}_hairpin_{DB}")],
+                        capture_output=True, text=True, check=True).stdout.split("\n")
+    assert max(len(x) for x in fa) <= max(60, max(len(h) + 1 for h in case.libs["hairpin"].headers))
+    assert "".join(x for x in fa if not x.startswith(">")) == "".join(case.libs["hairpin"].seqs.to_list())
+
+    df = pd.DataFrame(case.counts, columns=case.samples, index=pd.Index(case.seqs, name="Sequence"))
+    df = df.assign(**dict.fromkeys(PASS_COLS, '')).assign(annotFlag=0).reindex(columns=['annotFlag'] + PASS_COLS + case.samples)
+    suffix = ['_mirna_' + DB, '_hairpin_' + DB, '_mature_trna', '_pre_trna', '_snorna', '_rrna', '_ncrna_others', '_mrna',
+              '_mirna_' + DB, '_spike-in']
+    fasta = tmp_path / "bwtInput.fasta"
+    for it in range(10):
+        if it == 0:
+            recs = [(q, q) for q in df.index if len(q) < 26]
+        elif it == 1:
+            recs = [(q, q) for q in df.index if len(q) > 25]
+        else:
+            un = list(df.index[df.annotFlag.eq(0)])
+            if it == 3:
+                recs = [(q, q[:re.search('T{3,}$', q).start()]) for q in un if re.search('T{3,}$', q)]
+            else:
+                recs = [(q, q) for q in un]
+        fasta.write_text("".join(f">{q}\n{x}\n" for q, x in recs))
+        cmd = os.path.join(shim, "bowtie") + " " + os.path.join(idxdir, ORG + suffix[it]) + PASSES[it][2] + "2 " + str(fasta)
+        run = subprocess.run(cmd, shell=True, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        body = [ln.split("\t") for ln in run.stdout.split("\n") if ln and not ln.startswith("@")]
+        assert [b[0] for b in body] == [q for q, _ in recs]  # one line per read, input order
+        for f in body:
+            assert len(f) >= 11
+            if f[2] != "*":
+                df.at[f[0], PASS_COLS[it]] = f[2]
+                df.at[f[0], 'annotFlag'] = 1
+                lib, r = case.lib_of_pass(it), case.lib_of_pass(it).names.index(f[2])
+                window = lib.seqs.get(r)[int(f[3]) - 1:int(f[3]) - 1 + len(f[9])]
+                nm = int([t for t in f[11:] if t.startswith("NM:i:")][0][5:])
+                assert len(window) == len(f[9]) and sum(a != b for a, b in zip(window, f[9])) == nm and f[5] == f"{len(f[9])}M"
+    df = df.fillna('')
+    mapped, unmapped = df[df.annotFlag.eq(1)], df[df.annotFlag.eq(0)]
+    mapped.to_csv(tmp_path / "mapped.csv")
+    unmapped.to_csv(tmp_path / "unmapped.csv")
+    assert (tmp_path / "mapped.csv").read_text() == case.text("mapped.csv")
+    assert (tmp_path / "unmapped.csv").read_text() == case.text("unmapped.csv")
+
+
 # ---------------------------------------------------------------- oracle on seeded inputs
 def test_cascade_vs_oracle_ci_scale(ctx, ci_libs, ci_cascade):
     reads = synth.make_reads(ci_libs, 60000, seed=5, n_frac=0.01)
@@ -260,6 +320,48 @@ def test_baking_dropin(ctx, ci_libs, tmp_path):
     with pytest.raises(NotImplementedError):
         baking(SimpleNamespace(quiet=True, minimum_length=16, adapters=["x"], front=None, uniq_mol_ids=None),
                files, names, str(tmp_path), ctx=ctx)
+
+
+def test_baking_umi_against_reference_vectors(ctx, tmp_path):
+    """-umi f,b [-udd] [-tcf] (digest.py:164-205,219-229,305-315): tests/golden/umi was written with the
+    reference's own UMIParser; two samples check the joined matrix against the oracle's restatement."""
+    import json
+    from helpers import GOLDEN
+    with open(os.path.join(GOLDEN, "umi", "umi_cases.json")) as fh:
+        cases = json.load(fh)
+    src_file = os.path.join(GOLDEN, "umi", "reads.txt")
+    raw = open(src_file).read().split("\n")[:-1]
+    for c in cases:
+        for key, dedup in (("umi", False), ("udd", True)):
+            wd = tmp_path / f"w{c['front']}_{c['back']}_{key}"
+            wd.mkdir()
+            args = SimpleNamespace(quiet=True, minimum_length=c["min_len"], adapters=None, front=None, tcf_out=True,
+                                   uniq_mol_ids=f"{c['front']},{c['back']}", umiDedup=dedup)
+            df, src, trimmed, uniq = baking(args, [src_file], ["reads"], str(wd), ctx=ctx)
+            exp = c[key]
+            assert [[q, n] for q, n in zip(df.index, df["reads"].tolist())] == exp["dict"]
+            assert src["reads"] == c["total_input"] and trimmed["reads"] == exp["trimmed"] and uniq["reads"] == exp["unique"]
+            if dedup:
+                assert open(wd / "reads_umiCounts.csv").read() == exp["umiCounts_csv"]
+            else:
+                assert not (wd / "reads_umiCounts.csv").exists()
+            d = dict(map(tuple, exp["dict"]))
+            tcf = "".join(f">seq{k + 1}_{d[q]}\n{q}\n" for k, q in enumerate(sorted(d, key=d.get, reverse=True)))
+            assert open(wd / "reads.trim.collapse.fa").read() == tcf
+    # two samples, -udd: the union is sorted (digest.py:243), counts are molecules per sample
+    half = tmp_path / "half.txt"
+    half.write_text("\n".join(raw[::2]) + "\n")
+    args = SimpleNamespace(quiet=True, minimum_length=16, adapters=None, front=None, uniq_mol_ids="4,4", umiDedup=True)
+    df, src, trimmed, uniq = baking(args, [src_file, str(half)], ["A", "B"], str(tmp_path), ctx=ctx)
+    da = dict(oracle.umi_collapse(raw, 4, 4, 16, True)[0])
+    db = dict(oracle.umi_collapse(raw[::2], 4, 4, 16, True)[0])
+    union = sorted(set(da) | set(db))
+    assert list(df.index) == union
+    assert df["A"].tolist() == [da.get(q, 0) for q in union] and df["B"].tolist() == [db.get(q, 0) for q in union]
+    assert uniq == {"A": len(da), "B": len(db)} and trimmed == {"A": sum(da.values()), "B": sum(db.values())}
+    with pytest.raises(NotImplementedError):
+        baking(SimpleNamespace(quiet=True, minimum_length=16, adapters=None, front=None, uniq_mol_ids="4,4",
+                               qiagenumi=True), [src_file], ["reads"], str(tmp_path), ctx=ctx)
 
 
 # ---------------------------------------------------------------- size-independent properties

@@ -117,3 +117,26 @@ def test_synthetic_generator_is_seeded():
     rb = synth.make_reads(b, 500, seed=4)
     assert np.array_equal(ra.data, rb.data) and np.array_equal(ra.offsets, rb.offsets)
     assert ra.lengths.min() >= 16 and len(set(ra.lengths.tolist())) > 3
+
+
+def test_cli_flags_in_and_out_of_scope():
+    """Flag names of mirge/libs/parse.py: hot-path flags parse, other subsystems' flags are refused."""
+    from mirge3_amd.cli import parse_args
+    base = ["-s", "a.fq", "-lib", "/x", "-on", "human"]
+    a = parse_args(base + ["-umi", "4,4", "-udd", "-tcf", "-spk", "-m", "18"])
+    assert a.uniq_mol_ids == "4,4" and a.umiDedup and a.tcf_out and a.spikeIn and a.minimum_length == 18
+    assert a.adapters is None and a.qiagenumi is None
+    for bad in (["-udd"], ["-qumi"], ["-a", "illumina"], ["-gff"], ["-bam"], ["-trf"], ["-ai"], ["-nmir"]):
+        with pytest.raises(SystemExit):
+            parse_args(base + bad)
+
+
+def test_umi_split_matches_python_slices():
+    """FlatSeqs.umi_split == UMIParser (digest.py:305-315) for ragged, short and empty sequences."""
+    rng = np.random.default_rng(3)
+    seqs = ["".join("ACGTN"[int(c)] for c in rng.integers(0, 5, size=int(n))) for n in rng.integers(0, 40, size=300)]
+    fs = FlatSeqs.from_list(seqs)
+    for f, b in ((4, 4), (0, 4), (4, 0), (3, 30), (0, 0), (50, 2), (2, 50)):
+        pure, tag = fs.umi_split(f, b)
+        exp = [oracle.umi_parser(s, f, b) for s in seqs]
+        assert pure.to_list() == [e[0] for e in exp] and tag.to_list() == [e[1] for e in exp]

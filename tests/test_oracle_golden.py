@@ -4,11 +4,13 @@ Pins: pass order, subset rules, T-tail strip, overwrite rule (manifoldAlign.py:1
 count join (summary.py) -- the reference's own code ran over the oracle's matcher to make these
 files.  Does not pin bowtie's predicate itself ("parity unpinned", see oracle/mirge_oracle.c).
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle
-from helpers import CASES, GoldenCase
+from helpers import CASES, GoldenCase, GOLDEN
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -50,3 +52,21 @@ def test_collapse_rule():
     assert inv.tolist() == [0, 1, 0, 2, 0, 1, 3]
     f0, c0, i0 = oracle.collapse(fs.data[:0], fs.offsets[:1])
     assert len(f0) == 0 and len(i0) == 0
+
+
+def test_umi_restatement_against_reference_vectors():
+    """tests/golden/umi: slicing by the reference's own UMIParser, dict stages replayed around it."""
+    import json
+    with open(os.path.join(GOLDEN, "umi", "umi_cases.json")) as fh:
+        cases = json.load(fh)
+    raw = open(os.path.join(GOLDEN, "umi", "reads.txt")).read().split("\n")[:-1]
+    assert len(cases) == 5
+    for c in cases:
+        f, b = c["front"], c["back"]
+        for s, pure, tag in c["parser"]:
+            assert oracle.umi_parser(s, f, b) == (pure, tag)
+        for key, dedup in (("umi", False), ("udd", True)):
+            d, trimmed, rows = oracle.umi_collapse(raw, f, b, c["min_len"], dedup)
+            assert [list(x) for x in d] == c[key]["dict"]
+            assert trimmed == c[key]["trimmed"] and len(d) == c[key]["unique"]
+            assert ("".join(rows) if rows else None) == c[key]["umiCounts_csv"]
