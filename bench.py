@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+RANDOM_SECTOR_PEAK_G = 55.0  # measured, tools/microbench_random.hip: L2-missing random loads, G/s
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 # Algorithmic bytes per unit (DESIGN.md "Kernels"): a packed short read is
@@ -336,6 +337,15 @@ def main():
                            "calibrated for wide streaming reads only, so an upper bound for this kernel's 16-B random reads)",
                 "algorithmic_bytes_per_launch": round(algo_bytes(dom) * kd["units_per_launch"], 1),
             }
+            # the resource this kernel actually consumes: L2-missing 64-B sectors of random table reads
+            sectors = t["fetch_kb_raw"] * 1024.0 / 64.0
+            rate = sectors / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+            out["roofline"]["random_sector"] = {
+                "sectors_per_launch": round(sectors, 1), "achieved": round(rate, 2), "peak": RANDOM_SECTOR_PEAK_G,
+                "unit": "G sectors/s", "frac": round(rate / RANDOM_SECTOR_PEAK_G, 4),
+                "note": "FETCH_SIZE raw (one 64-B request per random read) / launch time; peak = independent random "
+                        "4-B loads from a 0.25-16 GB table on this chip, tools/microbench_random.hip "
+                        "(profiles/r01_microbench_random.txt)"}
     if rank == 0:
         print(json.dumps(out))
     raw.close()

@@ -227,9 +227,12 @@ MIRGE_HD void mirge_two_blocks(int A0, int A1, int B0, int B1, int K, MirgeProbe
     pr.a1 = (int8_t)(A1 - ka); pr.k1 = (int8_t)ka; pr.gap = (int8_t)(B0 - A1); pr.k2 = (int8_t)kb;
 }
 
-// K is chosen so that 4^K is 4..16 x the library's positions; a plain segment of K-2 bases already
-// returns ~1 window per probe, and then (mm+1) lookups beat (mm+1)^2
-#define MIRGE_PLAIN_SLACK 2
+// K is chosen so that 4^K is 4..16 x the library's positions; a plain segment of K-1 bases returns
+// ~1 window per probe, and then (mm+1) lookups beat (mm+1)^2 (measured: slack 1 -3 % step time vs 2,
+// slack 3 +10 %; profiles/README.md)
+#ifndef MIRGE_PLAIN_SLACK
+#define MIRGE_PLAIN_SLACK 1
+#endif
 MIRGE_HD bool mirge_plan_is_plain(const MirgePolicy& p, int h, int K) {
     return p.mm == 0 || p.mm > 2 || h >= K - MIRGE_PLAIN_SLACK || h < 1;
 }
