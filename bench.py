@@ -38,6 +38,7 @@ ALGO_BYTES = {
     "k_heads_blocksum": 4 + 4 + 1,   # slot id + first-index in, head flag out, per raw read
     "k_collapse_scatter": 1 + 4 + 13,  # head flag + slot id in; key+len+count out (upper bound: per raw read)
     "k_pass": 4 + 9 + 5,             # active index + read in, annotation or survivor index out, per read handed to the pass
+    "k_cascade_fused": 9 + 6 + 8,   # small groups, whole cascade in one launch: read in; pass+position+mismatches, ref+offset out
     "k_resolve": 5 + 8,              # pass+position in, ref+offset out
     "k_join": 5 + 4,                 # pass+ref + one count in (S = 1)
     "k_scan_blocksums": 8,
@@ -48,7 +49,7 @@ def algo_bytes(name):
     """per-unit bytes of a profile record such as 'k_pass[6].w1' (w1/w2/w4 = 1/2/4-word reads)"""
     base, _, w = name.partition(".w")
     w = w.rstrip("n")  # 'n' = the group of reads with an ambiguous base call
-    extra = 8 * (int(w) - 1) if w.isdigit() and (base.startswith("k_pass") or base.startswith("k_collapse")) else 0
+    extra = 8 * (int(w) - 1) if w.isdigit() and (base.startswith("k_pass") or base.startswith("k_collapse") or base.startswith("k_cascade")) else 0
     return (ALGO_BYTES["k_pass"] if base.startswith("k_pass") else ALGO_BYTES.get(base, 0)) + extra
 
 
@@ -58,7 +59,7 @@ def rocprof_symbol(rec_name):
     w = w.rstrip("n") or "1"
     if base.startswith("k_pass["):
         return f"k_pass<{w}, {int(base[7:-1].split('-')[0])}>"  # a merged run 'k_pass[4-6]' is launched as slot 4
-    if base in ("k_collapse_insert", "k_collapse_scatter"):
+    if base in ("k_collapse_insert", "k_collapse_scatter", "k_cascade_fused"):
         return f"{base}<{w}>"
     return base + "("
 
@@ -235,7 +236,7 @@ def main():
     n_tab_steps = n_prof
     stage_ms = {
         "collapse": sum(v["total_ms"] for k, v in kernels.items() if "collapse" in k or "heads" in k or "scan" in k or "hist" in k or "k_part" in k or "flags" in k) / n_tab_steps,
-        "cascade": sum(v["total_ms"] for k, v in kernels.items() if k.startswith("k_pass") or k.startswith("k_resolve")) / n_tab_steps,
+        "cascade": sum(v["total_ms"] for k, v in kernels.items() if k.startswith(("k_pass", "k_resolve", "k_cascade"))) / n_tab_steps,
         "join": sum(v["total_ms"] for k, v in kernels.items() if k == "k_join") / n_tab_steps,
     }
     U = state["U"]

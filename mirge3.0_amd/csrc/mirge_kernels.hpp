@@ -807,28 +807,96 @@ struct ResolveTable {
     uint32_t n_refs[MIRGE_MAX_PASSES_K];
 };
 
+__device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint32_t g, int32_t& ref, int32_t& off) {
+    const uint32_t* rs = nullptr;
+    uint32_t nr = 0;
+#pragma unroll
+    for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
+        if (q == p) { rs = tb.ref_start[q]; nr = tb.n_refs[q]; }
+    uint32_t lo = 0, hi = nr;  // last t with rs[t] <= g
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (rs[mid] <= g) lo = mid; else hi = mid;
+    }
+    ref = (int32_t)lo;
+    off = (int32_t)(g - rs[lo]);
+}
+
 __global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, const uint32_t* __restrict__ res_pos,
                           uint32_t n, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int p = res_pass[i];
         int32_t ref = -1, off = -1;
-        if (p >= 0) {
-            const uint32_t g = res_pos[i];
-            const uint32_t* rs = nullptr;
-            uint32_t nr = 0;
-#pragma unroll
-            for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
-                if (q == p) { rs = tb.ref_start[q]; nr = tb.n_refs[q]; }
-            uint32_t lo = 0, hi = nr;  // last t with rs[t] <= g
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (rs[mid] <= g) lo = mid; else hi = mid;
-            }
-            ref = (int32_t)lo;
-            off = (int32_t)(g - rs[lo]);
-        }
+        if (p >= 0) resolve_one(tb, p, res_pos[i], ref, off);
         res_ref[i] = ref;
         res_off[i] = off;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cascade_fused: the whole cascade of a SMALL read group in one launch.  The groups beside the bulk
+// (reads with an N, 32-128 nt reads: a few hundred to a few 100 k reads) cost one launch per pass plus
+// memsets and a resolve each -- ~30 launches whose host-side enqueue time, not their GPU time, kept the
+// bulk group's first pass waiting (profiles/r01_timeline.txt).  Here a wave keeps its 64 reads through
+// every step; a read that is annotated simply stops being eligible (no compaction: the group is small).
+// Same device functions as k_pass, so the same answers.
+// ------------------------------------------------------------------------------------------
+struct FusedStep {
+    MirgeLibView lib;
+    MirgePolicy pol;
+    MergeInfo mi;
+    const MirgePlanTable* plan;
+    int32_t pass_id;
+};
+struct FusedSteps {
+    int32_t n;
+    FusedStep s[MIRGE_MAX_PASSES_K];
+};
+
+template <int W>
+__global__ void __launch_bounds__(MIRGE_BLOCK)
+k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView<W> g, int8_t* __restrict__ res_pass,
+                uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref,
+                int32_t* __restrict__ res_off) {
+    const uint32_t nrounds = (g.n + MIRGE_BLOCK - 1) / MIRGE_BLOCK;
+    const int nsteps = steps->n;
+    for (uint32_t round = blockIdx.x; round < nrounds; round += gridDim.x) {
+        const uint32_t idx = round * MIRGE_BLOCK + threadIdx.x;
+        const bool valid = idx < g.n;
+        MirgeRead<W> r0;
+        if (valid) load_read<W>(g, idx, r0);
+        else {
+#pragma unroll
+            for (int w = 0; w < W; w++) { r0.w[w] = 0; r0.nm[w] = 0; }
+            r0.len = 0;
+        }
+        bool open = valid;
+        int8_t o_pass = -1, o_mm = -1;
+        uint32_t o_pos = 0;
+        for (int si = 0; si < nsteps; si++) {
+            if (!__ballot(open)) break;  // wave-uniform
+            const FusedStep& st = steps->s[si];
+            MirgeRead<W> r2 = r0;
+            const bool elig = open && mirge_effective_read<W>(r2, st.pol);
+            uint64_t best;
+            align_hybrid<W>(st.lib, st.pol, st.mi, st.plan, r2, elig, best);
+            if (elig && best != MIRGE_NO_HIT) {
+                const int cls = (int)(best >> 40);
+                o_pass = (int8_t)(st.pass_id + cls);
+                uint32_t b0 = 0;
+#pragma unroll
+                for (int i = 1; i < 4; i++) if (i == cls) b0 = st.mi.bound[i];
+                o_pos = (uint32_t)best - b0;
+                o_mm = (int8_t)((best >> 32) & 0xFF);
+                open = false;
+            }
+        }
+        if (valid) {
+            int32_t ref = -1, off = -1;
+            if (o_pass >= 0) resolve_one(tb, o_pass, o_pos, ref, off);
+            res_pass[idx] = o_pass; res_pos[idx] = o_pos; res_mm[idx] = o_mm;
+            res_ref[idx] = ref; res_off[idx] = off;
+        }
     }
 }
 

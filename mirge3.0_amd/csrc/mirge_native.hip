@@ -97,6 +97,8 @@ struct mirge_ctx {
     size_t join_pinned_bytes = 0;
     struct PlanEntry { uint64_t uid; MirgePolicy pol; MirgePlanTable* dplan; };
     std::vector<PlanEntry> plans;
+    struct FusedEntry { std::unique_ptr<FusedSteps> host; FusedSteps* dev; };
+    std::vector<FusedEntry> fused;  // step lists of k_cascade_fused already on the device
     size_t prof_used = 0;
     std::vector<ProfUnits> prof_pending;
 
@@ -257,6 +259,7 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->prof_pinned) (void)hipHostFree(c->prof_pinned);
     if (c->join_pinned) (void)hipHostFree(c->join_pinned);
     for (auto& e : c->plans) (void)hipFree(e.dplan);
+    for (auto& e : c->fused) (void)hipFree(e.dev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -697,6 +700,7 @@ struct CollapseTmp {
     bool partitioned = false;
     uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr, *nrec = nullptr;
     uint4 *part = nullptr, *recs = nullptr;
+    uint32_t G = 0, chunk = 0, bshift = 0, B = 0;
 };
 // dmeta: [0..5] U of each group, [6] partition overflow flag, [8 .. 8+128] length histogram
 #define MIRGE_META_OVERFLOW 6
@@ -708,10 +712,37 @@ static const char* group_tag(int gi) {
     return t[gi];
 }
 
+// partitioned key path after k_part_agg: bucket offsets, scatter, per-bucket de-duplication
+static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, uint32_t* dmeta) {
+    const uint32_t G = t.G, B = t.B;
+    {
+        LaunchScope ls(c, "k_part_prefix.w1", (double)G * B);
+        hipLaunchKernelGGL(k_part_prefix, dim3((B + 63) / 64), dim3(64), 0, c->cur, t.hist, G, B, t.off, t.btotal);
+    }
+    {
+        LaunchScope ls(c, "k_scan_blocksums", B);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.btotal, B, t.btotal + B);
+    }
+    {
+        LaunchScope ls(c, "k_part_scatter.w1", in.n);
+        hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, t.recs, t.nrec, t.chunk, t.bshift, B, t.off,
+                           t.btotal, t.part);
+    }
+    {
+        LaunchScope ls(c, "k_part_dedup.w1", in.n);
+        hipLaunchKernelGGL(k_part_dedup, dim3(B), dim3(MIRGE_BLOCK), MIRGE_PART_CAP * 16 + 1024, c->cur, t.part, t.btotal,
+                           in.orig, in.base, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
+                           dmeta + MIRGE_META_OVERFLOW);
+    }
+    return 0;
+}
+
 template <int W>
 static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t,
-                            const int32_t* dsample, int32_t S, uint32_t* dmeta, bool force_atomic) {
+                            const int32_t* dsample, int32_t S, uint32_t* dmeta, bool force_atomic, int stage = 0) {
+    // stage 0 = everything; 1 = only the first kernel of the partitioned path; 2 = what stage 1 left
     if (!in.n) return 0;
+    if (stage == 2 && t.partitioned) return collapse_part_rest(c, gi, in, out, t, dmeta);
     // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
     const bool key_path = (W == 1) && !in.nmask && S == 1;
     uint32_t tsize = 1024;
@@ -763,27 +794,11 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
             LaunchScope ls(c, "k_part_agg.w1", in.n);
             hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_BLOCK), agg_lds, c->cur, v1, chunk, bshift, B, CS, t.recs, t.nrec, t.hist);
         }
-        {
-            LaunchScope ls(c, "k_part_prefix.w1", (double)G * B);
-            hipLaunchKernelGGL(k_part_prefix, dim3((B + 63) / 64), dim3(64), 0, c->cur, t.hist, G, B, t.off, t.btotal);
-        }
-        {
-            LaunchScope ls(c, "k_scan_blocksums", B);
-            hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.btotal, B, t.btotal + B);
-        }
-        {
-            LaunchScope ls(c, "k_part_scatter.w1", in.n);
-            hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, t.recs, t.nrec, chunk, bshift, B, t.off,
-                               t.btotal, t.part);
-        }
-        {
-            LaunchScope ls(c, "k_part_dedup.w1", in.n);
-            hipLaunchKernelGGL(k_part_dedup, dim3(B), dim3(MIRGE_BLOCK), MIRGE_PART_CAP * 16 + 1024, c->cur, t.part, t.btotal,
-                               in.orig, in.base, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
-                               dmeta + MIRGE_META_OVERFLOW);
-        }
-        return 0;
+        t.G = G; t.chunk = chunk; t.bshift = bshift; t.B = B;
+        if (stage == 1) return 0;
+        return collapse_part_rest(c, gi, in, out, t, dmeta);
     }
+    if (stage == 1) return 0;
     CHECK(dalloc(c, &t.slot_of, in.n));
     CHECK(dalloc(c, &t.flag, (size_t)t.nb * per_block));
     CHECK(dalloc(c, &t.blocksum, t.nb));
@@ -875,15 +890,19 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
         hipError_t e0 = hipMemsetAsync(dmeta, 0, MIRGE_META_WORDS * 4, c->stream);
         if (e0 != hipSuccess) { rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e0)); break; }
         rc = stream_fork(c);
-        for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
-            // small groups are queued first (measured): their short kernels get onto the GPU before the
-            // big group's 2048-workgroup launches fill every CU; queued after it, each of their ~30
-            // small kernels waits for CUs to drain and the join at the end waits for them (5.3 vs 3.8 ms)
-            const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;
+        // Order of enqueue (profiles/r01_timeline.txt): the bulk group's first kernel (k_part_agg: one workgroup
+        // per CU, ~0.2 ms) goes first, the small groups' ~15 short launches are enqueued while it runs and share
+        // the CUs with it, then the bulk group's wide kernels.  Small groups entirely first left the GPU idle for
+        // the ~0.2 ms their enqueue takes; entirely last, each of their kernels waits behind 2048-8192-workgroup
+        // launches for CUs to drain and the join at the end waits for them (5.3 vs 3.8 ms).
+        for (int k = -1; k <= MIRGE_NGROUPS && rc == 0; k++) {
+            const int gi = (k < 0 || k == MIRGE_NGROUPS) ? big : k;
+            if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
+            const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
             c->cur = gi == big ? c->stream : c->aux;
-            if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
-            else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
-            else rc = collapse_phase_a<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1);
+            if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
+            else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
+            else rc = collapse_phase_a<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
@@ -1126,6 +1145,27 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     return 0;
 }
 
+// a small group's whole cascade as one launch (k_cascade_fused)
+template <int W>
+static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const FusedSteps* dsteps,
+                               const ResolveTable& rt, const char* gtag) {
+    out.n = rg.n;
+    if (!rg.n) return 0;
+    const uint32_t n = rg.n;
+    CHECK(dalloc(c, &out.pass, n));
+    CHECK(dalloc(c, &out.pos, n));
+    CHECK(dalloc(c, &out.mm, n));
+    CHECK(dalloc(c, &out.ref, n));
+    CHECK(dalloc(c, &out.off, n));
+    char name[32];
+    std::snprintf(name, sizeof(name), "k_cascade_fused%s", gtag);
+    LaunchScope ls(c, name, n);
+    const uint32_t grid = std::min<uint32_t>((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (uint32_t)c->n_cu * 8);
+    hipLaunchKernelGGL(k_cascade_fused<W>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
+                       out.pos, out.mm, out.ref, out.off);
+    return 0;
+}
+
 extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
                                  const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
     if (!c || !R || !libs || !pol || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
@@ -1205,6 +1245,35 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
         }
         st.dplan = dp;
     }
+    // the step list of the fused small-group kernel lives in device memory; uploaded when it changes
+    auto fs = std::make_unique<FusedSteps>();
+    std::memset(fs.get(), 0, sizeof(FusedSteps));
+    fs->n = (int32_t)steps.size();
+    for (size_t i = 0; i < steps.size(); i++) {
+        FusedStep& f = fs->s[i];
+        f.lib = steps[i].lib->view();
+        std::memcpy(&f.pol, &pol[steps[i].p0], sizeof(MirgePolicy));
+        f.mi = steps[i].mi;
+        f.plan = steps[i].dplan;
+        f.pass_id = steps[i].p0;
+    }
+    const FusedSteps* dsteps = nullptr;
+    for (auto& e : c->fused)
+        if (std::memcmp(e.host.get(), fs.get(), sizeof(FusedSteps)) == 0) { dsteps = e.dev; break; }
+    if (!dsteps) {
+        if (c->fused.size() >= 64) {  // callers cycling through libraries: start over
+            HIPOK(hipDeviceSynchronize());
+            for (auto& e : c->fused) (void)hipFree(e.dev);
+            c->fused.clear();
+        }
+        FusedSteps* d = nullptr;
+        HIPOK(hipMalloc((void**)&d, sizeof(FusedSteps)));
+        HIPOK(hipMemcpy(d, fs.get(), sizeof(FusedSteps), hipMemcpyHostToDevice));
+        c->fused.push_back(mirge_ctx::FusedEntry{std::move(fs), d});
+        dsteps = d;
+    }
+    // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests)
+    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 20);
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
     int rc = 0;
@@ -1213,6 +1282,12 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
         const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;  // small groups first (see mirge_collapse)
         c->cur = gi == big ? c->stream : c->aux;
+        if (gi != big && R->g[gi].n <= fused_max) {
+            if (kGroupW[gi] == 1) rc = cascade_group_fused<1>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            else if (kGroupW[gi] == 2) rc = cascade_group_fused<2>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            else rc = cascade_group_fused<4>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            continue;
+        }
         if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
         else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
         else rc = cascade_group<4>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));

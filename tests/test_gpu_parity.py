@@ -575,6 +575,20 @@ print("OK", len(got))
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
+def test_staged_cascade_for_every_group():
+    """Small read groups normally take k_cascade_fused (one launch for the whole cascade); MIRGE_FUSED_MAX=0
+    sends every group through the staged per-pass kernels instead.  Both must agree with the oracle: the oracle
+    parity tests of this file and the cascade fuzz are re-run in a fresh process with the hook set."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k",
+                        "vs_oracle or vs_bruteforce or low_complexity or edge_cases or golden_cascade or random_cascade"],
+                       env=dict(os.environ, MIRGE_FUSED_MAX="0"), capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_cli_two_ranks_one_sample_each(tmp_path):
     """The sharded CLI (torch.distributed.run, one sample per rank, rank 0 gathers the per-sample tables over
     gloo and writes the run's CSVs): two ranks on the single GPU of the test box, golden case 2."""
