@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,6 +70,13 @@ struct ProfUnits {  // "units" of a cascade pass = sum of the per-workgroup surv
 };
 #define MIRGE_PROF_PINNED_WORDS (1u << 18)
 
+struct PassStep {
+    int32_t p0 = 0, np = 1;       // passes p0 .. p0+np-1 run as one launch
+    const mirge_lib* lib = nullptr;
+    MergeInfo mi;
+    const MirgePlanTable* dplan = nullptr;  // device copy of the tabulated probe plan
+};
+
 struct mirge_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -99,6 +107,10 @@ struct mirge_ctx {
     std::vector<PlanEntry> plans;
     struct FusedEntry { std::unique_ptr<FusedSteps> host; FusedSteps* dev; };
     std::vector<FusedEntry> fused;  // step lists of k_cascade_fused already on the device
+    std::string casc_key;           // configuration of the previous mirge_cascade_run ...
+    std::vector<PassStep> casc_steps;  // ... and what was prepared for it
+    ResolveTable casc_rt;
+    const FusedSteps* casc_dsteps = nullptr;
     size_t prof_used = 0;
     std::vector<ProfUnits> prof_pending;
 
@@ -763,14 +775,19 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         while (!small_part && B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
         const uint32_t CS = B > 16384 ? 1024 : 2048;  // chunk-level LDS cache slots (16 B each)
         const int agg_lds = (int)(CS * 16 + (B + 1) * 4 + 64);
-        HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_agg), hipFuncAttributeMaxDynamicSharedMemorySize, agg_lds));
-        if (B * 4 > 48 * 1024)
-            HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B * 4)));
-        static bool dedup_attr = false;
-        if (!dedup_attr) {
-            HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      MIRGE_PART_CAP * 16 + 1024));
-            dedup_attr = true;
+        // dynamic-LDS ceilings, raised once per process and device to the largest configuration (B = 32768)
+        static std::mutex attr_mu;
+        static std::vector<int> attr_done;
+        {
+            std::lock_guard<std::mutex> lk(attr_mu);
+            if (std::find(attr_done.begin(), attr_done.end(), c->device) == attr_done.end()) {
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          1024 * 16 + (32768 + 1) * 4 + 64));  // CS = 1024 at B = 32768; 2048 * 16 + 16385 * 4 + 64 is smaller
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          MIRGE_PART_CAP * 16 + 1024));
+                attr_done.push_back(c->device);
+            }
         }
         int lg = 0; while ((1u << lg) < B) lg++;
         const uint32_t bshift = 64 - lg;
@@ -1028,13 +1045,6 @@ static int merged_library(mirge_ctx* c, const mirge_lib* const* members, int n, 
     return 0;
 }
 
-struct PassStep {
-    int32_t p0 = 0, np = 1;       // passes p0 .. p0+np-1 run as one launch
-    const mirge_lib* lib = nullptr;
-    MergeInfo mi;
-    const MirgePlanTable* dplan = nullptr;  // device copy of the tabulated probe plan
-};
-
 // build every probe table pass `p` can ask for, given the read lengths present
 static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t* hist) {
     MirgePolicy p;
@@ -1166,27 +1176,12 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     return 0;
 }
 
-extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
-                                 const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
-    if (!c || !R || !libs || !pol || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
-        return fail(-1, "mirge_cascade_run: bad argument");
-    HIPOK(hipSetDevice(c->device));
-    // read lengths present (host histogram from pack; a collapse result asks the device once)
-    int32_t hist[MIRGE_MAX_READ_LEN + 1];
-    if (R->hist_valid) std::memcpy(hist, R->len_hist, sizeof(hist));
-    else {
-        std::memset(hist, 0, sizeof(hist));
-        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
-            const ReadGroup& g = R->g[gi];
-            if (!g.n) continue;
-            // conservative: every length the width group can hold is assumed present
-            int lo = kGroupW[gi] == 1 ? 1 : (kGroupW[gi] == 2 ? 32 : 65), hi = kGroupW[gi] == 1 ? 31 : (kGroupW[gi] == 2 ? 64 : 128);
-            for (int L = lo; L <= hi; L++) hist[L] = 1;
-        }
-    }
-    ResolveTable rt;
+// steps (merged runs, probe tables, plan tables), resolve table and the fused kernel's device step list for
+// one (libraries, policies, read-length set) configuration
+static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass,
+                           const int32_t* hist, std::vector<PassStep>& steps, ResolveTable& rt, const FusedSteps** dsteps_out) {
     for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.n_refs[p] = 0; }
-    std::vector<PassStep> steps;
+    steps.clear();
     for (int32_t p = 0; p < n_pass; p++) {
         if (!libs[p]) continue;
         if (libs[p]->ctx->device != c->device) return fail(-1, "library lives on another device");
@@ -1272,6 +1267,66 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
         c->fused.push_back(mirge_ctx::FusedEntry{std::move(fs), d});
         dsteps = d;
     }
+    *dsteps_out = dsteps;
+    return 0;
+}
+
+// MIRGE_HOST_TIMING=1: host microseconds spent in the stages of a call, to stderr (enqueue-bound phases)
+struct HostClock {
+    const char* what;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit HostClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {
+        static const bool e = std::getenv("MIRGE_HOST_TIMING") != nullptr;
+        on = e;
+    }
+    void lap(const char* stage) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[host] %s/%s %.1f us\n", what, stage, std::chrono::duration<double, std::micro>(t - t0).count());
+        t0 = t;
+    }
+};
+
+extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
+                                 const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
+    HostClock hc("cascade");
+    if (!c || !R || !libs || !pol || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
+        return fail(-1, "mirge_cascade_run: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    // read lengths present (host histogram from pack; a collapse result asks the device once)
+    int32_t hist[MIRGE_MAX_READ_LEN + 1];
+    if (R->hist_valid) std::memcpy(hist, R->len_hist, sizeof(hist));
+    else {
+        std::memset(hist, 0, sizeof(hist));
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+            const ReadGroup& g = R->g[gi];
+            if (!g.n) continue;
+            // conservative: every length the width group can hold is assumed present
+            int lo = kGroupW[gi] == 1 ? 1 : (kGroupW[gi] == 2 ? 32 : 65), hi = kGroupW[gi] == 1 ? 31 : (kGroupW[gi] == 2 ? 64 : 128);
+            for (int L = lo; L <= hi; L++) hist[L] = 1;
+        }
+    }
+    // Everything below up to the launches depends only on (libraries, policies, read lengths present): it is
+    // kept from the previous call and reused when those are unchanged (~45 us of host time per call otherwise,
+    // on the critical path between the collapse's synchronisation and the first pass)
+    std::string key;
+    key.append(reinterpret_cast<const char*>(&n_pass), sizeof(n_pass));
+    for (int32_t p = 0; p < n_pass; p++) {
+        const uint64_t uid = libs[p] ? libs[p]->uid : 0;
+        key.append(reinterpret_cast<const char*>(&uid), sizeof(uid));
+        key.append(reinterpret_cast<const char*>(&pol[p]), sizeof(mirge_policy));
+    }
+    for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) key.push_back(hist[L] ? 1 : 0);
+    if (c->casc_key != key) {
+        c->casc_key.clear();
+        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, c->casc_steps, c->casc_rt, &c->casc_dsteps));
+        c->casc_key = key;
+    }
+    const std::vector<PassStep>& steps = c->casc_steps;
+    const ResolveTable& rt = c->casc_rt;
+    const FusedSteps* dsteps = c->casc_dsteps;
+    hc.lap("plans+fused");
     // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests)
     static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 20);
     auto res = std::make_unique<mirge_result>();
@@ -1279,8 +1334,14 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     int rc = 0;
     const int big = largest_group(R);
     CHECK(stream_fork(c));
+    // enqueue order: the small groups first (one fused launch each, or the staged launches if a group is too
+    // large for that), the bulk group last: measured, its 2048-workgroup launches otherwise hold every CU and the
+    // small kernels squeeze in between them, stretching single passes of the bulk group by 30 %
+    int order[MIRGE_NGROUPS], no = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) if (gi != big) order[no++] = gi;
+    order[no++] = big;
     for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
-        const int gi = k < MIRGE_NGROUPS - 1 ? (k < big ? k : k + 1) : big;  // small groups first (see mirge_collapse)
+        const int gi = order[k];
         c->cur = gi == big ? c->stream : c->aux;
         if (gi != big && R->g[gi].n <= fused_max) {
             if (kGroupW[gi] == 1) rc = cascade_group_fused<1>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
@@ -1292,7 +1353,9 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
         else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
         else rc = cascade_group<4>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
     }
+    hc.lap("enqueue");
     { int jr = stream_join(c); if (rc == 0) rc = jr; }
+    hc.lap("join");
     if (rc) { mirge_result_destroy(res.release()); return rc; }
     *out = res.release();
     return 0;
