@@ -541,7 +541,9 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
 //   their minimum goes to the owner.
 //   All 64 lanes of the wave must call this together (inactive lanes pass active = false).
 // ------------------------------------------------------------------------------------------
+#ifndef MIRGE_LIGHT
 #define MIRGE_LIGHT 4
+#endif
 #ifndef MIRGE_LIGHT_MAX
 #define MIRGE_LIGHT_MAX 16
 #endif

@@ -1090,8 +1090,10 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     // every workgroup keeps its own survivor segment through all passes: no global cursor.  All workgroups
     // must be resident at once: a grid of 8 per CU ran the workgroups that did not fit as a second round on an
     // almost empty machine (average occupancy 47 %, SQ_WAVE_CYCLES; -20 % kernel time with the right grid).
-    // Measured optimum for k_pass<1,*> (69 VGPRs) is 6 per CU, one less than hipOccupancyMaxActiveBlocksPer-
-    // Multiprocessor reports: registers are counted here in blocks of 16.  MIRGE_WG_PER_CU overrides (sweeps).
+    // Measured on MI355X (tools/occ_sweep.sh, profiles/README.md): kernel time falls up to 6 workgroups per CU
+    // and jumps back by 30 % at 7 and beyond -- for the 69-VGPR build and for 57/63-VGPR builds alike, so the
+    // cliff is not the register file although hipOccupancyMaxActiveBlocksPerMultiprocessor reports 7.  The grid
+    // is therefore min(occupancy query, register bound, 6) per CU.  MIRGE_WG_PER_CU overrides (sweeps).
     static int wg_per_cu[5] = {0, 0, 0, 0, 0};
     if (!wg_per_cu[W]) {
         int nb = 0;
@@ -1099,7 +1101,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         HIPOK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_pass<W, 15>), MIRGE_BLOCK, 0));
         HIPOK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_pass<W, 15>)));
         const int by_regs = 512 / std::max(16, (fa.numRegs + 15) / 16 * 16);  // waves per SIMD = 4-wave workgroups per CU
-        wg_per_cu[W] = std::max(1, std::min({nb, by_regs, 8}));
+        wg_per_cu[W] = std::max(1, std::min({nb, by_regs, 6}));
         if (std::getenv("MIRGE_WG_PER_CU")) wg_per_cu[W] = std::max(1, std::atoi(std::getenv("MIRGE_WG_PER_CU")));
         if (std::getenv("MIRGE_HOST_TIMING"))
             std::fprintf(stderr, "[host] k_pass<%d>: %d VGPRs, occupancy query %d -> %d workgroups per CU\n", W, fa.numRegs, nb, wg_per_cu[W]);
