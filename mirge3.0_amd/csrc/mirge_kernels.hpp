@@ -103,6 +103,7 @@ __global__ void k_scatter_len(const uint8_t* __restrict__ len, uint32_t n, uint3
 // ------------------------------------------------------------------------------------------
 // block-wide exclusive scan of one value per thread (256 threads = 4 waves of 64)
 // ------------------------------------------------------------------------------------------
+template <int NW = MIRGE_BLOCK / 64>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* lds4) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t inc = v;
@@ -115,7 +116,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
     __syncthreads();
     uint32_t woff = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < MIRGE_BLOCK / 64; i++) {
+    for (int i = 0; i < NW; i++) {
         uint32_t s = lds4[i];
         if (i < wv) woff += s;
         tot += s;
@@ -256,7 +257,7 @@ __global__ void k_collapse_insert_key(GroupView<1> g, KeySlot* __restrict__ slot
 //                   to the output at a range reserved with one global atomicAdd per workgroup (so the order
 //                   of the unique reads of this path is unspecified; first[] carries the first raw index)
 // ------------------------------------------------------------------------------------------
-#define MIRGE_PART_CAP 4096  // LDS table slots per bucket (16 B each = 64 KiB)
+#define MIRGE_PART_CAP 4096  // largest LDS table per bucket (16 B per slot = 64 KiB)
 
 __device__ __forceinline__ unsigned long long read_key64(const GroupView<1>& g, uint32_t j) {
     return g.seq[j] | (1ull << (2 * g.len[j]));
@@ -269,9 +270,14 @@ __device__ __forceinline__ unsigned long long read_key64(const GroupView<1>& g, 
 // 2.8 ms on unskewed reads).  With it a key contributes at most one record per workgroup.  The cache is
 // best effort: a read that finds no slot within 4 probes is emitted as a record of count 1.
 // Output: recs[blockIdx * chunk ...] (compacted, nrec[blockIdx] of them) and hist[blockIdx][bucket].
-__global__ void __launch_bounds__(MIRGE_BLOCK)
-k_part_agg(GroupView<1> g, uint32_t chunk, uint32_t bshift, uint32_t B, uint32_t CS, uint4* __restrict__ recs,
-           uint32_t* __restrict__ nrec, uint32_t* __restrict__ hist) {
+// One workgroup per CU (the LDS cache + histogram take most of a CU's LDS), so the workgroup itself must bring
+// the waves that hide its load and LDS latencies: 1024 threads = 16 waves per CU (256 threads: 0.26 ms, 2x slower)
+#ifndef MIRGE_PART_THREADS
+#define MIRGE_PART_THREADS 1024
+#endif
+__global__ void __launch_bounds__(MIRGE_PART_THREADS)
+k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uint32_t chunk, uint32_t bshift, uint32_t B,
+           uint32_t CS, uint4* __restrict__ recs, uint32_t* __restrict__ nrec, uint32_t* __restrict__ hist) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_a[];  // [CS] keys | [CS] minj | [CS] cnt | [B] hist | cursor
     uint32_t* c_min = reinterpret_cast<uint32_t*>(lds_a + CS);
     uint32_t* c_cnt = c_min + CS;
@@ -288,8 +294,11 @@ k_part_agg(GroupView<1> g, uint32_t chunk, uint32_t bshift, uint32_t B, uint32_t
         bool direct = false;
         unsigned long long key = 0ull;
         uint64_t h = 0;
+        uint32_t jr = 0;  // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
+                          // instead of gathered per unique read at the end)
         if (j < hi) {
             key = read_key64(g, j);
+            jr = orig ? orig[j] : base + j;
             h = mirge_mix64(key);
             uint32_t s = (uint32_t)(h >> 9) & (CS - 1);
             direct = true;
@@ -297,7 +306,7 @@ k_part_agg(GroupView<1> g, uint32_t chunk, uint32_t bshift, uint32_t B, uint32_t
                 unsigned long long cur = lds_a[s];
                 if (cur == 0ull) cur = atomicCAS(&lds_a[s], 0ull, key);
                 if (cur == 0ull || cur == key) {
-                    atomicMin(&c_min[s], j);
+                    atomicMin(&c_min[s], jr);
                     atomicAdd(&c_cnt[s], 1u);
                     direct = false;
                     break;
@@ -311,7 +320,7 @@ k_part_agg(GroupView<1> g, uint32_t chunk, uint32_t bshift, uint32_t B, uint32_t
             if (lane == 0) wb = atomicAdd(&cursor, (uint32_t)__popcll(bal));
             wb = __shfl(wb, 0, 64);
             if (direct) {
-                out[wb + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), j, 1u);
+                out[wb + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), jr, 1u);
                 atomicAdd(&lds_h[(uint32_t)(h >> bshift)], 1u);
             }
         }
@@ -351,7 +360,8 @@ __global__ void k_part_prefix(const uint32_t* __restrict__ hist, uint32_t G, uin
     total[b] = run;
 }
 
-__global__ void k_part_scatter(const uint4* __restrict__ recs, const uint32_t* __restrict__ nrec, uint32_t chunk,
+__global__ void __launch_bounds__(MIRGE_PART_THREADS)
+k_part_scatter(const uint4* __restrict__ recs, const uint32_t* __restrict__ nrec, uint32_t chunk,
                                uint32_t bshift, uint32_t B, const uint32_t* __restrict__ off,
                                const uint32_t* __restrict__ bucket_start, uint4* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_c[];
@@ -367,47 +377,51 @@ __global__ void k_part_scatter(const uint4* __restrict__ recs, const uint32_t* _
     }
 }
 
-__global__ void __launch_bounds__(MIRGE_BLOCK)
+// CAP = LDS table slots (16 B each): 2048 when the buckets hold <= 1024 records (4 workgroups per CU), else 4096
+// The table takes 32-64 KiB of LDS, so only 2-4 workgroups fit a CU: 1024-thread workgroups bring the waves.
+#define MIRGE_DEDUP_THREADS 1024
+template <int CAP>
+__global__ void __launch_bounds__(MIRGE_DEDUP_THREADS)
 k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket_start,
-             const uint32_t* __restrict__ orig, uint32_t base, uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
+             uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
              uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst, uint32_t* __restrict__ cursor,
              uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
-    uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + MIRGE_PART_CAP);
-    uint32_t* lds_cnt = lds_min + MIRGE_PART_CAP;
-    uint32_t* lds_x = lds_cnt + MIRGE_PART_CAP;  // [0] distinct keys, [1] output base, [2..5] scan scratch, [8..8+128] lengths
+    uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + CAP);
+    uint32_t* lds_cnt = lds_min + CAP;
+    uint32_t* lds_x = lds_cnt + CAP;  // [0] distinct keys, [1] output base, [2..17] scan scratch, [32..32+128] lengths
     uint32_t& n_distinct = lds_x[0];
-    for (uint32_t i = threadIdx.x; i < MIRGE_PART_CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
-    for (uint32_t i = threadIdx.x; i < 8 + MIRGE_MAX_READ_LEN + 1; i += blockDim.x) lds_x[i] = 0;
+    for (uint32_t i = threadIdx.x; i < CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < 32 + MIRGE_MAX_READ_LEN + 1; i += blockDim.x) lds_x[i] = 0;
     __syncthreads();
     const uint32_t lo = bucket_start[blockIdx.x], hi = bucket_start[blockIdx.x + 1];
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint4 rec = part[i];
         const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
         const uint32_t j = rec.z;
-        uint32_t s = (uint32_t)(mirge_mix64(key) >> 7) & (MIRGE_PART_CAP - 1);
+        uint32_t s = (uint32_t)(mirge_mix64(key) >> 7) & (CAP - 1);
         while (true) {
             unsigned long long cur = lds_k[s];
             if (cur == 0ull) {
                 cur = atomicCAS(&lds_k[s], 0ull, key);
-                if (cur == 0ull && atomicAdd(&n_distinct, 1u) >= MIRGE_PART_CAP - 64) atomicOr(overflow, 1u);
+                if (cur == 0ull && atomicAdd(&n_distinct, 1u) >= CAP - 64) atomicOr(overflow, 1u);
             }
             if (cur == 0ull || cur == key) break;
-            if (*(volatile uint32_t*)&n_distinct >= MIRGE_PART_CAP - 32) break;  // table full: flagged, results discarded
-            s = (s + 1) & (MIRGE_PART_CAP - 1);
+            if (*(volatile uint32_t*)&n_distinct >= CAP - 32) break;  // table full: flagged, results discarded
+            s = (s + 1) & (CAP - 1);
         }
         atomicMin(&lds_min[s], j);
         atomicAdd(&lds_cnt[s], rec.w);  // a record stands for rec.w identical reads of one workgroup's chunk
     }
     __syncthreads();
     // emit the bucket's distinct reads: one global cursor add per workgroup reserves their output range
-    constexpr int PER = MIRGE_PART_CAP / MIRGE_BLOCK;
+    constexpr int PER = CAP / MIRGE_DEDUP_THREADS;
     const uint32_t s0 = threadIdx.x * PER;
     uint32_t mine = 0;
 #pragma unroll
     for (int i = 0; i < PER; i++) mine += lds_k[s0 + i] != 0ull;
     uint32_t total;
-    uint32_t rank = block_excl_scan(mine, total, lds_x + 2);
+    uint32_t rank = block_excl_scan<MIRGE_DEDUP_THREADS / 64>(mine, total, lds_x + 2);
     if (threadIdx.x == 0) lds_x[1] = total ? atomicAdd(cursor, total) : 0u;
     __syncthreads();
     rank += lds_x[1];
@@ -419,14 +433,13 @@ k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket
         useq[rank] = key ^ (1ull << (2 * L));
         ulen[rank] = (uint8_t)L;
         ucnt[rank] = lds_cnt[s0 + i];
-        const uint32_t j = lds_min[s0 + i];
-        ufirst[rank] = orig ? orig[j] : base + j;
-        atomicAdd(&lds_x[8 + L], 1u);
+        ufirst[rank] = lds_min[s0 + i];
+        atomicAdd(&lds_x[32 + L], 1u);
         rank++;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
-        if (lds_x[8 + i]) atomicAdd(&hist[i], lds_x[8 + i]);
+        if (lds_x[32 + i]) atomicAdd(&hist[i], lds_x[32 + i]);
 }
 
 // heads: read j is the head of its group iff it is the group's smallest index.  `first` is addressed

@@ -220,7 +220,8 @@ static int largest_group(const struct mirge_reads* R);
 
 static inline int grid_for(const mirge_ctx* c, size_t n, int per_block = MIRGE_BLOCK) {
     size_t blocks = (n + per_block - 1) / per_block;
-    size_t cap = (size_t)c->n_cu * 8;
+    static const size_t per_cu = std::getenv("MIRGE_GRID_PER_CU") ? (size_t)std::atoi(std::getenv("MIRGE_GRID_PER_CU")) : 8;
+    size_t cap = (size_t)c->n_cu * per_cu;
     return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
 
@@ -712,7 +713,7 @@ struct CollapseTmp {
     bool partitioned = false;
     uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr, *nrec = nullptr;
     uint4 *part = nullptr, *recs = nullptr;
-    uint32_t G = 0, chunk = 0, bshift = 0, B = 0;
+    uint32_t G = 0, chunk = 0, bshift = 0, B = 0, cap = MIRGE_PART_CAP;
 };
 // dmeta: [0..5] U of each group, [6] partition overflow flag, [8 .. 8+128] length histogram
 #define MIRGE_META_OVERFLOW 6
@@ -737,14 +738,18 @@ static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGro
     }
     {
         LaunchScope ls(c, "k_part_scatter.w1", in.n);
-        hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_BLOCK), B * 4, c->cur, t.recs, t.nrec, t.chunk, t.bshift, B, t.off,
+        hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_PART_THREADS), B * 4, c->cur, t.recs, t.nrec, t.chunk, t.bshift, B, t.off,
                            t.btotal, t.part);
     }
     {
         LaunchScope ls(c, "k_part_dedup.w1", in.n);
-        hipLaunchKernelGGL(k_part_dedup, dim3(B), dim3(MIRGE_BLOCK), MIRGE_PART_CAP * 16 + 1024, c->cur, t.part, t.btotal,
-                           in.orig, in.base, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
-                           dmeta + MIRGE_META_OVERFLOW);
+        if (t.cap == 2048)
+            hipLaunchKernelGGL(k_part_dedup<2048>, dim3(B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 1024, c->cur, t.part, t.btotal,
+                               out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST, dmeta + MIRGE_META_OVERFLOW);
+        else
+            hipLaunchKernelGGL(k_part_dedup<MIRGE_PART_CAP>, dim3(B), dim3(MIRGE_DEDUP_THREADS), MIRGE_PART_CAP * 16 + 1024, c->cur, t.part,
+                               t.btotal, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
+                               dmeta + MIRGE_META_OVERFLOW);
     }
     return 0;
 }
@@ -773,6 +778,9 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         // exercise the fallback to the global-atomic path (tests/test_gpu_parity.py)
         static const bool small_part = std::getenv("MIRGE_TEST_SMALL_PART") != nullptr;
         while (!small_part && B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
+        // buckets of <= 1024 records get a 2048-slot LDS table in k_part_dedup (4 workgroups per CU instead of 2).
+        // Forcing that by doubling B was measured slower overall: k_part_agg/k_part_scatter pay for the larger B
+        t.cap = (!small_part && (uint64_t)B * 1024 >= in.n) ? 2048u : (uint32_t)MIRGE_PART_CAP;
         const uint32_t CS = B > 16384 ? 1024 : 2048;  // chunk-level LDS cache slots (16 B each)
         const int agg_lds = (int)(CS * 16 + (B + 1) * 4 + 64);
         // dynamic-LDS ceilings, raised once per process and device to the largest configuration (B = 32768)
@@ -784,8 +792,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           1024 * 16 + (32768 + 1) * 4 + 64));  // CS = 1024 at B = 32768; 2048 * 16 + 16385 * 4 + 64 is smaller
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
-                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          MIRGE_PART_CAP * 16 + 1024));
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup<MIRGE_PART_CAP>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, MIRGE_PART_CAP * 16 + 1024));
                 attr_done.push_back(c->device);
             }
         }
@@ -809,7 +817,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         GroupView<1> v1 = view_of<1>(in);
         {
             LaunchScope ls(c, "k_part_agg.w1", in.n);
-            hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_BLOCK), agg_lds, c->cur, v1, chunk, bshift, B, CS, t.recs, t.nrec, t.hist);
+            hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_PART_THREADS), agg_lds, c->cur, v1, in.orig, in.base, chunk, bshift, B, CS, t.recs, t.nrec, t.hist);
         }
         t.G = G; t.chunk = chunk; t.bshift = bshift; t.B = B;
         if (stage == 1) return 0;
