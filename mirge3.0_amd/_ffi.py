@@ -7,6 +7,7 @@ MI355X is visible, the first call raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -59,8 +60,9 @@ def load() -> C.CDLL:
 
 
 def _track(obj):
-    import weakref
     _live.append(weakref.ref(obj))
+    if len(_live) > 4096:  # long-running callers create two handles per sample: drop the dead references
+        _live[:] = [r for r in _live if r() is not None]
 
 
 def _shutdown():
@@ -278,14 +280,21 @@ class CascadeResult:
             pass
 
 
-def cascade_run(ctx: Context, reads: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],
-                policies: Sequence[MirgePolicy]) -> CascadeResult:
+def cascade_args(libs: Sequence[Optional[DeviceLibrary]], policies: Sequence[MirgePolicy]):
+    """The two C arrays ``mirge_cascade_run`` takes, built once by callers that run many read sets through one
+    library set (this sits on the host's critical path between the collapse's sync and the first pass)."""
     n_pass = len(policies)
     arr = (C.c_void_p * n_pass)(*[(lb._h if lb is not None else C.c_void_p(0)) for lb in libs])
     pol = (MirgePolicy * n_pass)(*policies)
+    return arr, pol, C.c_int32(n_pass)
+
+
+def cascade_run(ctx: Context, reads: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],
+                policies: Sequence[MirgePolicy], prepared=None) -> CascadeResult:
+    arr, pol, n_pass = prepared if prepared is not None else cascade_args(libs, policies)
     h = C.c_void_p()
-    _check(load().mirge_cascade_run(ctx._h, reads._h, arr, pol, C.c_int32(n_pass), C.byref(h)), "mirge_cascade_run")
-    return CascadeResult(ctx, h, reads, n_pass)
+    _check(load().mirge_cascade_run(ctx._h, reads._h, arr, pol, n_pass, C.byref(h)), "mirge_cascade_run")
+    return CascadeResult(ctx, h, reads, n_pass.value)
 
 
 def count_join(ctx: Context, uniq: DeviceReads, res: CascadeResult, exact_pass: int, iso_pass: int,

@@ -74,12 +74,13 @@ class Cascade:
                 self._dev[key] = _ffi.DeviceLibrary(ctx, libs[key].seqs)
             self.dev_libs.append(self._dev[key])
         self.policies = policies(self.n_pass)
+        self._prepared = _ffi.cascade_args(self.dev_libs, self.policies)
 
     def lib_of_pass(self, p: int) -> Library:
         return self.libs[PASSES[p][1]]
 
     def run(self, reads: _ffi.DeviceReads) -> _ffi.CascadeResult:
-        return _ffi.cascade_run(self.ctx, reads, self.dev_libs, self.policies)
+        return _ffi.cascade_run(self.ctx, reads, self.dev_libs, self.policies, self._prepared)
 
     def annotate(self, seqs: FlatSeqs):
         """Convenience: host sequences in, (pass, ref, off, mm) numpy arrays out."""

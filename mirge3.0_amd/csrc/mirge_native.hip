@@ -225,6 +225,27 @@ static inline int grid_for(const mirge_ctx* c, size_t n, int per_block = MIRGE_B
     return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
 
+// MIRGE_HOST_TIMING=1: host microseconds spent in the stages of a call, to stderr (enqueue-bound phases)
+static std::chrono::steady_clock::time_point g_last_exit = std::chrono::steady_clock::now();
+struct HostClock {
+    const char* what;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit HostClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {
+        static const bool e = std::getenv("MIRGE_HOST_TIMING") != nullptr;
+        on = e;
+        if (on) std::fprintf(stderr, "[host] %s entered %.1f us after the previous call returned\n", what,
+                             std::chrono::duration<double, std::micro>(t0 - g_last_exit).count());
+    }
+    ~HostClock() { if (on) g_last_exit = std::chrono::steady_clock::now(); }
+    void lap(const char* stage) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[host] %s/%s %.1f us\n", what, stage, std::chrono::duration<double, std::micro>(t - t0).count());
+        t0 = t;
+    }
+};
+
 extern "C" int mirge_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -893,6 +914,7 @@ static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
 
 extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
                               mirge_reads** uniq, int64_t* n_uniq) {
+    HostClock hc("collapse");
     if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids)) return fail(-1, "mirge_collapse: bad argument");
     HIPOK(hipSetDevice(c->device));
     int32_t* dsample = nullptr;
@@ -930,6 +952,7 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
             else rc = collapse_phase_a<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
+        hc.lap("enqueue A");
         if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
             hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -947,6 +970,7 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
         }
         break;
     }
+    hc.lap("sync");
     uint32_t base = 0;
     if (rc == 0) {
         uint32_t U[MIRGE_NGROUPS];
@@ -974,6 +998,7 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
     R->n = base;
     *uniq = R.release();
     if (n_uniq) *n_uniq = base;
+    hc.lap("phase B + release");
     return 0;
 }
 
@@ -1296,23 +1321,6 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
     *dsteps_out = dsteps;
     return 0;
 }
-
-// MIRGE_HOST_TIMING=1: host microseconds spent in the stages of a call, to stderr (enqueue-bound phases)
-struct HostClock {
-    const char* what;
-    std::chrono::steady_clock::time_point t0;
-    bool on;
-    explicit HostClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {
-        static const bool e = std::getenv("MIRGE_HOST_TIMING") != nullptr;
-        on = e;
-    }
-    void lap(const char* stage) {
-        if (!on) return;
-        const auto t = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[host] %s/%s %.1f us\n", what, stage, std::chrono::duration<double, std::micro>(t - t0).count());
-        t0 = t;
-    }
-};
 
 extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
                                  const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
