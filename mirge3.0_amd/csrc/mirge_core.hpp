@@ -227,32 +227,46 @@ MIRGE_HD void mirge_two_blocks(int A0, int A1, int B0, int B1, int K, MirgeProbe
     pr.a1 = (int8_t)(A1 - ka); pr.k1 = (int8_t)ka; pr.gap = (int8_t)(B0 - A1); pr.k2 = (int8_t)kb;
 }
 
-// K is chosen so that 4^K is 4..16 x the library's positions; a plain segment of K-1 bases returns
-// ~1 window per probe, and then (mm+1) lookups beat (mm+1)^2 (measured: slack 1 -3 % step time vs 2,
-// slack 3 +10 %; profiles/README.md)
-#ifndef MIRGE_PLAIN_SLACK
-#define MIRGE_PLAIN_SLACK 1
+// Three families of probe plans, all pigeonhole arguments over the seed region S:
+//   plain    (mm+1 probes): mm+1 segments, one of them is mismatch-free.
+//   recursive ((mm+1)^2): segment i is mismatch-free AND one of the mm+1 parts of the rest is (above).
+//   subset   (C(mm+2, 2) = 3 or 6): cut S into mm+2 blocks; at most mm of them carry a mismatch, so some PAIR of
+//            blocks is mismatch-free -- every pair is one two-block probe of 2S/(mm+2) exact bases (up to K).
+// Fewer probes = fewer dependent table lookups (each an L2-missing sector in the big libraries); longer keys =
+// fewer candidate windows to verify.  Which family is cheapest depends on S, K and the library's size, so the
+// choice is made per (policy, read length, library) with an expected-cost model in units of random 64-B
+// sectors: a probe costs 1 (bucket bounds) + P(bucket not empty) (position list) + MIRGE_VERIFY_SECTORS per
+// expected window (text + invalid bitmap; less when the text is L2-resident).  tests/test_hostsim.py proves
+// coverage for every family.  Measured: -7 % on the merged -n 1 pass, -5 % on the isomiR pass vs plain/recursive only.
+#define MIRGE_SCHEME_PLAIN 0
+#define MIRGE_SCHEME_RECURSIVE 1
+#define MIRGE_SCHEME_SUBSET 2
+#ifndef MIRGE_VERIFY_SECTORS
+#define MIRGE_VERIFY_SECTORS 2.2      // text + invalid bitmap of a window in a library larger than L2
+#define MIRGE_VERIFY_SECTORS_L2 0.7   // ... of a library whose text stays in L2 (< 4 M bases): a lookup costs latency, a window little
 #endif
-MIRGE_HD bool mirge_plan_is_plain(const MirgePolicy& p, int h, int K) {
-    return p.mm == 0 || p.mm > 2 || h >= K - MIRGE_PLAIN_SLACK || h < 1;
-}
 
-// number of probes for a read of (trimmed) length L in a library probed with up to K exact bases
-MIRGE_HD int mirge_probe_count(const MirgePolicy& p, int L, int K) {
-    const int S = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
+MIRGE_HD int mirge_scheme_count(const MirgePolicy& p, int scheme) {
     const int nseg = p.mm + 1;
-    if (mirge_plan_is_plain(p, S / nseg, K)) return nseg < MIRGE_MAX_PROBES ? nseg : MIRGE_MAX_PROBES;
-    return nseg * nseg;
+    if (scheme == MIRGE_SCHEME_RECURSIVE) return nseg * nseg;
+    if (scheme == MIRGE_SCHEME_SUBSET) return (p.mm + 2) * (p.mm + 1) / 2;
+    return nseg < MIRGE_MAX_PROBES ? nseg : MIRGE_MAX_PROBES;
 }
 
-// probe number q (0 <= q < mirge_probe_count); written without arrays so that the kernels keep
-// everything in registers
-MIRGE_HD void mirge_probe_at(const MirgePolicy& p, int L, int K, int q, MirgeProbe& out) {
-    const int S = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
+// probe number q of one family; written without arrays so that callers keep everything in registers
+MIRGE_HD void mirge_scheme_probe(const MirgePolicy& p, int S, int K, int scheme, int q, MirgeProbe& out) {
     const int nseg = p.mm + 1;
     const int h = S / nseg;
-    if (mirge_plan_is_plain(p, h, K)) {  // plain segments
+    if (scheme == MIRGE_SCHEME_PLAIN) {
         out.a1 = (int8_t)(q * h); out.k1 = (int8_t)(h < K ? h : K); out.gap = 0; out.k2 = 0;
+        return;
+    }
+    if (scheme == MIRGE_SCHEME_SUBSET) {
+        const int B = p.mm + 2;
+        int i = 0, j = 1, t = q;  // q-th pair (i < j) in lexicographic order
+        while (t >= B - 1 - i) { t -= B - 1 - i; i++; }
+        j = i + 1 + t;
+        mirge_two_blocks(S * i / B, S * (i + 1) / B, S * j / B, S * (j + 1) / B, K, out);
         return;
     }
     if (p.mm == 1) {
@@ -287,20 +301,66 @@ MIRGE_HD void mirge_probe_at(const MirgePolicy& p, int L, int K, int q, MirgePro
     }
 }
 
+// expected cost of one family, in random sectors (see above); npos = bases of the library's text
+MIRGE_HD double mirge_scheme_cost(const MirgePolicy& p, int S, int K, int scheme, uint64_t npos) {
+    double cost = 0.0;
+    const int n = mirge_scheme_count(p, scheme);
+    for (int q = 0; q < n; q++) {
+        MirgeProbe pr;
+        mirge_scheme_probe(p, S, K, scheme, q, pr);
+        const int k = pr.k1 + pr.k2;
+        if (k <= 0) return 1e30;  // a degenerate probe (empty block) filters nothing: family unusable here
+        double lam = (double)npos;
+        for (int t = 0; t < k; t++) lam *= 0.25;
+        // 1 - exp(-lam) without libm: lam / (1 + lam) is within 20 % of it and monotone, enough to rank plans
+        cost += 1.0 + lam / (1.0 + lam) + (npos > (1ull << 22) ? MIRGE_VERIFY_SECTORS : MIRGE_VERIFY_SECTORS_L2) * lam;
+    }
+    return cost;
+}
+
+// family used for a read whose seed region is S bases, in a library of npos bases probed with up to K exact bases
+MIRGE_HD int mirge_plan_scheme(const MirgePolicy& p, int S, int K, uint64_t npos) {
+    if (p.mm == 0 || p.mm > 2 || S / (p.mm + 1) < 1) return MIRGE_SCHEME_PLAIN;
+    int best = MIRGE_SCHEME_PLAIN;
+    double bc = mirge_scheme_cost(p, S, K, MIRGE_SCHEME_PLAIN, npos);
+    if (S >= 2 * (p.mm + 1)) {  // every part of the recursive cut holds at least one base
+        const double c = mirge_scheme_cost(p, S, K, MIRGE_SCHEME_RECURSIVE, npos);
+        if (c < bc) { bc = c; best = MIRGE_SCHEME_RECURSIVE; }
+    }
+    if (S >= p.mm + 2) {
+        const double c = mirge_scheme_cost(p, S, K, MIRGE_SCHEME_SUBSET, npos);
+        if (c < bc) { bc = c; best = MIRGE_SCHEME_SUBSET; }
+    }
+    return best;
+}
+
+MIRGE_HD int mirge_seed_region(const MirgePolicy& p, int L) { return p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L; }
+
+// number of probes for a read of (trimmed) length L; scheme < 0 = chosen by cost
+MIRGE_HD int mirge_probe_count(const MirgePolicy& p, int L, int K, uint64_t npos, int scheme = -1) {
+    const int S = mirge_seed_region(p, L);
+    return mirge_scheme_count(p, scheme >= 0 ? scheme : mirge_plan_scheme(p, S, K, npos));
+}
+
+MIRGE_HD void mirge_probe_at(const MirgePolicy& p, int L, int K, uint64_t npos, int q, MirgeProbe& out, int scheme = -1) {
+    const int S = mirge_seed_region(p, L);
+    mirge_scheme_probe(p, S, K, scheme >= 0 ? scheme : mirge_plan_scheme(p, S, K, npos), q, out);
+}
+
 // The plan depends only on (policy, K, trimmed length): the host tabulates it once per pass and the
 // kernels read probe q of length L with one 4-byte load instead of redoing the integer divisions.
 struct MirgePlanTable {
     uint8_t np[MIRGE_MAX_READ_LEN + 1];
     MirgeProbe pr[MIRGE_MAX_READ_LEN + 1][MIRGE_MAX_PROBES];
 };
-static inline void mirge_plan_table_fill(const MirgePolicy& p, int K, MirgePlanTable& t) {
+static inline void mirge_plan_table_fill(const MirgePolicy& p, int K, uint64_t npos, MirgePlanTable& t) {
     for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
         const bool ok = L >= 1 && L > p.mm;
-        const int n = ok ? mirge_probe_count(p, L, K) : 0;
+        const int n = ok ? mirge_probe_count(p, L, K, npos) : 0;
         t.np[L] = (uint8_t)n;
         for (int q = 0; q < MIRGE_MAX_PROBES; q++) {
             MirgeProbe pr; pr.a1 = 0; pr.k1 = 0; pr.gap = 0; pr.k2 = 0;
-            if (q < n) mirge_probe_at(p, L, K, q, pr);
+            if (q < n) mirge_probe_at(p, L, K, npos, q, pr);
             t.pr[L][q] = pr;
         }
     }
@@ -328,10 +388,10 @@ MIRGE_HD bool mirge_align_indexed(const MirgeLibView& lib, const MirgePolicy& p,
                                   const MirgeRead<W>& r, uint64_t& best) {
     best = MIRGE_NO_HIT;
     const int L = r.len;
-    const int np = mirge_probe_count(p, L, lib.kmax);
+    const int np = mirge_probe_count(p, L, lib.kmax, lib.total);
     for (int q = 0; q < np; q++) {
         MirgeProbe pr;
-        mirge_probe_at(p, L, lib.kmax, q, pr);
+        mirge_probe_at(p, L, lib.kmax, lib.total, q, pr);
         uint64_t key;
         if (!mirge_probe_key<W>(r, pr, key)) continue;
         const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];

@@ -1093,10 +1093,10 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
         for (int l0 = lo; l0 <= hi; l0++) {
             const int l = l0 - p.trim5 - p.trim3;
             if (l < 1 || l <= p.mm) continue;
-            const int np = mirge_probe_count(p, l, lib->kmax);
+            const int np = mirge_probe_count(p, l, lib->kmax, lib->h.total);
             for (int q = 0; q < np; q++) {
                 MirgeProbe pr;
-                mirge_probe_at(p, l, lib->kmax, q, pr);
+                mirge_probe_at(p, l, lib->kmax, lib->h.total, q, pr);
                 if (pr.k1 <= 0) continue;
                 const int sid = mirge_shape_id(pr.k1, pr.gap, pr.k2);
                 if (seen[sid]) continue;
@@ -1282,7 +1282,7 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
             if (e.uid == st.lib->uid && std::memcmp(&e.pol, &mp, sizeof(mp)) == 0) { dp = e.dplan; break; }
         if (!dp) {
             auto h = std::make_unique<MirgePlanTable>();
-            mirge_plan_table_fill(mp, st.lib->kmax, *h);
+            mirge_plan_table_fill(mp, st.lib->kmax, st.lib->h.total, *h);
             MirgePlanTable* d = nullptr;
             HIPOK(hipMalloc((void**)&d, sizeof(MirgePlanTable)));
             HIPOK(hipMemcpy(d, h.get(), sizeof(MirgePlanTable), hipMemcpyHostToDevice));

@@ -51,10 +51,10 @@ static void sim_one(const char* s, int L, std::vector<SimLib>& libs, const std::
         pack_read<W>(s, L, r);
         if (!mirge_effective_read<W>(r, pol[p])) continue;
         // same table-on-demand rule as mirge_cascade_run: every shape the read's probe plan names
-        const int np = mirge_probe_count(pol[p], r.len, libs[p].h.kmax);
+        const int np = mirge_probe_count(pol[p], r.len, libs[p].h.kmax, libs[p].h.total);
         for (int q = 0; q < np; q++) {
             MirgeProbe pr;
-            mirge_probe_at(pol[p], r.len, libs[p].h.kmax, q, pr);
+            mirge_probe_at(pol[p], r.len, libs[p].h.kmax, libs[p].h.total, q, pr);
             if (pr.k1 <= 0) continue;
             const int sid = mirge_shape_id(pr.k1, pr.gap, pr.k2);
             if (!libs[p].tables[sid].bucket) {
@@ -107,15 +107,24 @@ extern "C" int hostsim_cascade(const char* reads, const int64_t* roff, int64_t n
 }
 
 // probe plan of a read of (trimmed) length L: out[4*q + {0,1,2,3}] = a1, k1, gap, k2
-extern "C" int hostsim_probe_plan(int32_t mode, int32_t mm, int32_t seedlen, int32_t L, int32_t K, int8_t* out) {
+// scheme: -1 = the family the cost model picks for a library of npos bases, else MIRGE_SCHEME_*
+extern "C" int hostsim_probe_plan(int32_t mode, int32_t mm, int32_t seedlen, int32_t L, int32_t K, int64_t npos,
+                                  int32_t scheme, int8_t* out) {
     MirgePolicy p;
     std::memset(&p, 0, sizeof(p));
     p.mode = mode; p.mm = mm; p.seedlen = seedlen; p.maxtotal = mode == 0 ? 2 : mm;
-    const int n = mirge_probe_count(p, L, K);
+    const int n = mirge_probe_count(p, L, K, (uint64_t)npos, scheme);
     for (int q = 0; q < n; q++) {
         MirgeProbe pr;
-        mirge_probe_at(p, L, K, q, pr);
+        mirge_probe_at(p, L, K, (uint64_t)npos, q, pr, scheme);
         out[4 * q] = pr.a1; out[4 * q + 1] = pr.k1; out[4 * q + 2] = pr.gap; out[4 * q + 3] = pr.k2;
     }
     return n;
+}
+
+extern "C" int hostsim_plan_scheme(int32_t mode, int32_t mm, int32_t seedlen, int32_t L, int32_t K, int64_t npos) {
+    MirgePolicy p;
+    std::memset(&p, 0, sizeof(p));
+    p.mode = mode; p.mm = mm; p.seedlen = seedlen; p.maxtotal = mode == 0 ? 2 : mm;
+    return mirge_plan_scheme(p, mirge_seed_region(p, L), K, (uint64_t)npos);
 }

@@ -112,36 +112,53 @@ def test_hostsim_vs_oracle_ci_scale():
 
 
 def test_probe_plan_covers_every_mismatch_placement():
-    """Exhaustive proof of the filter: for every seed length, probe length K and every placement of
-    <= mm mismatches inside the seed, some probe's exact blocks avoid all of them (so the true
-    window is among its candidates), blocks stay inside the seed, and shapes fit the registry."""
+    """Exhaustive proof of the filter: for every probe family (plain / recursive / pair-of-blocks), every seed
+    length, probe length K and every placement of <= mm mismatches inside the seed, some probe's exact blocks
+    avoid all of them (so the true window is among its candidates), blocks stay inside the seed, and shapes fit
+    the registry.  Also for the family the cost model picks at several library sizes."""
     import itertools
     so = _sim()
     out = (C.c_int8 * 36)()
+    picked = set()
     for mode, mm in ((0, 0), (0, 1), (1, 1), (1, 2), (1, 3), (0, 2)):
         for K in range(8, 15):
             for L in range(mm + 1, 50):
-                n = so.hostsim_probe_plan(mode, mm, 28, L, K, out)
                 S = min(L, 28) if mode == 0 else L
-                probes = []
-                assert 1 <= n <= 9
-                for q in range(n):
-                    a1, k1, gap, k2 = out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]
-                    if k1 <= 0:
+                plans = [(-1, npos) for npos in (2000, 60000, 11_000_000, 140_000_000)]
+                plans.append((0, 1))
+                if mm in (1, 2) and S >= 2 * (mm + 1):
+                    plans.append((1, 1))
+                if mm in (1, 2) and S >= mm + 2:
+                    plans.append((2, 1))
+                seen = set()
+                for scheme, npos in plans:
+                    n = so.hostsim_probe_plan(mode, mm, 28, L, K, C.c_int64(npos), scheme, out)
+                    if scheme < 0:
+                        picked.add(so.hostsim_plan_scheme(mode, mm, 28, L, K, C.c_int64(npos)))
+                    sig = bytes(out[:4 * n])
+                    if sig in seen:
                         continue
-                    cover = set(range(a1, a1 + k1)) | set(range(a1 + k1 + gap, a1 + k1 + gap + k2))
-                    assert min(cover) >= 0 and max(cover) < S, (mode, mm, K, L, q)
-                    assert k1 + k2 <= K and 0 <= gap < 32 and (k2 > 0 or gap == 0)
-                    probes.append(cover)
-                budget = mm  # mismatches allowed inside the seed region
-                for r in range(budget + 1):
-                    if S > 34 and r == 2:
-                        combos = itertools.islice(itertools.combinations(range(S), r), 0, None, 7)
-                    else:
-                        combos = itertools.combinations(range(S), r)
-                    for bad in combos:
-                        bs = set(bad)
-                        assert any(not (c & bs) for c in probes), (mode, mm, K, L, bad)
+                    seen.add(sig)
+                    probes = []
+                    assert 1 <= n <= 9
+                    for q in range(n):
+                        a1, k1, gap, k2 = out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]
+                        if k1 <= 0:
+                            continue
+                        cover = set(range(a1, a1 + k1)) | set(range(a1 + k1 + gap, a1 + k1 + gap + k2))
+                        assert min(cover) >= 0 and max(cover) < S, (mode, mm, K, L, scheme, q)
+                        assert k1 + k2 <= K and 0 <= gap < 32 and (k2 > 0 or gap == 0)
+                        probes.append(cover)
+                    budget = mm  # mismatches allowed inside the seed region
+                    for r in range(budget + 1):
+                        if S > 34 and r == 2:
+                            combos = itertools.islice(itertools.combinations(range(S), r), 0, None, 7)
+                        else:
+                            combos = itertools.combinations(range(S), r)
+                        for bad in combos:
+                            bs = set(bad)
+                            assert any(not (c & bs) for c in probes), (mode, mm, K, L, scheme, bad)
+    assert picked == {0, 1, 2}  # the cost model uses every family somewhere
 
 
 def test_core_arithmetic_is_asan_ubsan_clean(tmp_path):
