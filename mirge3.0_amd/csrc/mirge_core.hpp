@@ -22,7 +22,11 @@
 #define MIRGE_HD inline
 #endif
 
-#define MIRGE_KMAX 14          // largest direct-addressed k (4^14+1 u32 = 1 GiB)
+#define MIRGE_KMAX 14          // largest direct-addressed k (4^14+1 u32 = 1 GiB) of multi-probe plans
+#define MIRGE_KMAX0 15         // ... of the single exact probe of an mm = 0 policy (one 4 GiB table per library)
+#ifndef MIRGE_K_OVERSAMPLE
+#define MIRGE_K_OVERSAMPLE 4   // 4^K >= this x the library's positions
+#endif
 #define MIRGE_MAX_READ_LEN 128
 #define MIRGE_NO_HIT 0xFFFFFFFFFFFFFFFFull
 
@@ -336,14 +340,24 @@ MIRGE_HD int mirge_plan_scheme(const MirgePolicy& p, int S, int K, uint64_t npos
 
 MIRGE_HD int mirge_seed_region(const MirgePolicy& p, int L) { return p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L; }
 
+// An exact-seed policy (mm = 0) asks ONE table per library, so it can afford the next k when the library has
+// outgrown K = 14 (human mRNA: 130 M positions in 268 M buckets, 39 % of the lookups go on to a position list
+// and a window; at k = 15 11 % do: -45 % sectors in the mRNA pass for 4 GiB of HBM)
+MIRGE_HD int mirge_policy_k(const MirgePolicy& p, int K, uint64_t npos) {
+    if (p.mm == 0 && K == MIRGE_KMAX && (1ull << (2 * MIRGE_KMAX)) < (uint64_t)MIRGE_K_OVERSAMPLE * npos) return MIRGE_KMAX0;
+    return K;
+}
+
 // number of probes for a read of (trimmed) length L; scheme < 0 = chosen by cost
 MIRGE_HD int mirge_probe_count(const MirgePolicy& p, int L, int K, uint64_t npos, int scheme = -1) {
     const int S = mirge_seed_region(p, L);
+    K = mirge_policy_k(p, K, npos);
     return mirge_scheme_count(p, scheme >= 0 ? scheme : mirge_plan_scheme(p, S, K, npos));
 }
 
 MIRGE_HD void mirge_probe_at(const MirgePolicy& p, int L, int K, uint64_t npos, int q, MirgeProbe& out, int scheme = -1) {
     const int S = mirge_seed_region(p, L);
+    K = mirge_policy_k(p, K, npos);
     mirge_scheme_probe(p, S, K, scheme >= 0 ? scheme : mirge_plan_scheme(p, S, K, npos), q, out);
 }
 

@@ -10,9 +10,6 @@
 
 #include "mirge_core.hpp"
 
-#ifndef MIRGE_K_OVERSAMPLE
-#define MIRGE_K_OVERSAMPLE 4
-#endif
 
 struct MirgeHostLib {
     int64_t n_refs = 0;

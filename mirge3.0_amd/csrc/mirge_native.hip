@@ -5,6 +5,7 @@
 // sequences for pack / collapse / cascade / count join.  Kernels: mirge_kernels.hpp.
 // There is no CPU implementation of any of the compute in this file or anywhere in the product.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -421,76 +422,59 @@ extern "C" void mirge_lib_destroy(mirge_lib* L) {
 extern "C" int64_t mirge_lib_n_refs(const mirge_lib* L) { return L ? L->n_refs : -1; }
 extern "C" int64_t mirge_lib_device_bytes(const mirge_lib* L) { return L ? (int64_t)L->device_bytes : -1; }
 
-// one probe shape (k1 bases, gap, k2 bases) and its host-built table
+// one probe shape (k1 bases, gap, k2 bases)
 struct ShapeJob {
     int k1 = 0, gap = 0, k2 = 0;
-    std::vector<uint32_t> bucket, pos, bits;
 };
 
-static void shape_job_build(const mirge_lib* L, ShapeJob& j) {
-    mirge_hostlib_table(L->h, j.k1, j.gap, j.k2, j.bucket, j.pos);
-    if (j.k1 + j.k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
-        const size_t nb = j.bucket.size() - 1;
-        j.bits.assign((nb + 31) / 32, 0u);
-        for (size_t b = 0; b < nb; b++) if (j.bucket[b + 1] > j.bucket[b]) j.bits[b >> 5] |= 1u << (b & 31);
-    }
-}
-
-// upload one host-built table and publish it in the library's device registry
-static int lib_upload_shape(mirge_lib* L, const ShapeJob& j) {
+// build one table on the device (k_table_pass: count, scan, fill) and publish it in the library's registry
+static int lib_build_shape(mirge_lib* L, const ShapeJob& j) {
+    mirge_ctx* c = L->ctx;
     const int sid = mirge_shape_id(j.k1, j.gap, j.k2);
-    uint32_t *dbucket = nullptr, *dpos = nullptr, *dbits = nullptr;
-    HIPOK(hipMalloc((void**)&dbucket, j.bucket.size() * 4));
-    HIPOK(hipMalloc((void**)&dpos, std::max<size_t>(j.pos.size(), 1) * 4));
-    HIPOK(hipMemcpy(dbucket, j.bucket.data(), j.bucket.size() * 4, hipMemcpyHostToDevice));
-    if (!j.pos.empty()) HIPOK(hipMemcpy(dpos, j.pos.data(), j.pos.size() * 4, hipMemcpyHostToDevice));
-    L->device_bytes += j.bucket.size() * 4 + j.pos.size() * 4;
-    if (!j.bits.empty()) {
-        HIPOK(hipMalloc((void**)&dbits, j.bits.size() * 4));
-        HIPOK(hipMemcpy(dbits, j.bits.data(), j.bits.size() * 4, hipMemcpyHostToDevice));
-        L->device_bytes += j.bits.size() * 4;
+    const uint64_t nb = 1ull << (2 * (j.k1 + j.k2));
+    uint32_t *A = nullptr, *dpos = nullptr, *dbits = nullptr;
+    HIPOK(hipMalloc((void**)&A, (nb + 2) * 4));
+    HIPOK(hipMemsetAsync(A, 0, (nb + 2) * 4, c->stream));
+    const int grid = c->n_cu * 8;
+    hipLaunchKernelGGL(k_table_pass<false>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1, j.gap,
+                       j.k2, A, (uint32_t*)nullptr);
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIPOK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream));
+    HIPOK(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    HIPOK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream));
+    uint32_t npos = 0;
+    HIPOK(hipMemcpyAsync(&npos, A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+    HIPOK(hipMalloc((void**)&dpos, std::max<size_t>(npos, 1) * 4));
+    hipLaunchKernelGGL(k_table_pass<true>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1, j.gap,
+                       j.k2, A, dpos);
+    L->device_bytes += (nb + 2) * 4 + (size_t)npos * 4;
+    if (j.k1 + j.k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
+        const size_t words = (size_t)((nb + 31) / 32);
+        HIPOK(hipMalloc((void**)&dbits, words * 4));
+        hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, words)), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, dbits);
+        L->device_bytes += words * 4;
     }
-    L->htables[sid].bucket = dbucket;
+    L->htables[sid].bucket = A;
     L->htables[sid].pos = dpos;
     L->htables[sid].bits = dbits;
-    HIPOK(hipStreamSynchronize(L->ctx->stream));  // no kernel may be reading the registry while it changes
+    HIPOK(hipStreamSynchronize(c->stream));  // table complete; no kernel may be reading the registry while it changes
     HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));
     return 0;
 }
 
-// build the tables of the wanted probe shapes that do not exist yet: the host counting sorts run on up
-// to 8 threads (one table each), the uploads are serial
+// build the tables of the wanted probe shapes that do not exist yet
 static int lib_prepare_shapes(mirge_lib* L, const std::vector<ShapeJob>& wanted) {
     std::lock_guard<std::mutex> lk(L->mu);
-    std::vector<ShapeJob> jobs;
+    bool first = true;
     for (const auto& w : wanted) {
-        if (w.k1 < 1 || w.k1 > MIRGE_KMAX || w.k2 < 0 || w.k1 + w.k2 > MIRGE_KMAX || w.gap < 0 || w.gap > 31 || (w.k2 == 0 && w.gap != 0))
+        if (w.k1 < 1 || w.k2 < 0 || w.k1 + w.k2 > (w.k2 == 0 ? MIRGE_KMAX0 : MIRGE_KMAX) || w.gap < 0 || w.gap > 31 || (w.k2 == 0 && w.gap != 0))
             return fail(-1, "probe shape out of range");
-        const int sid = mirge_shape_id(w.k1, w.gap, w.k2);
-        if (L->htables[sid].bucket) continue;
-        bool dup = false;
-        for (const auto& j : jobs) dup |= mirge_shape_id(j.k1, j.gap, j.k2) == sid;
-        if (dup) continue;
-        jobs.emplace_back();
-        jobs.back().k1 = w.k1; jobs.back().gap = w.gap; jobs.back().k2 = w.k2;
-    }
-    if (jobs.empty()) return 0;
-    HIPOK(hipSetDevice(L->ctx->device));
-    // a table of 4^14 buckets is 1 GiB of host memory before its positions: fewer of those at a time
-    size_t big = 0;
-    for (const auto& j : jobs) big = std::max(big, (size_t)1 << (2 * (j.k1 + j.k2)));
-    const size_t cap = big >= ((size_t)1 << 26) ? 4 : 8;
-    const size_t T = std::max<size_t>(1, std::min({cap, jobs.size(), (size_t)std::max(1u, std::thread::hardware_concurrency())}));
-    for (size_t base = 0; base < jobs.size(); base += T) {
-        const size_t end = std::min(jobs.size(), base + T);
-        std::vector<std::thread> th;
-        for (size_t i = base + 1; i < end; i++) th.emplace_back([L, &jobs, i] { shape_job_build(L, jobs[i]); });
-        shape_job_build(L, jobs[base]);
-        for (auto& t : th) t.join();
-        for (size_t i = base; i < end; i++) {
-            CHECK(lib_upload_shape(L, jobs[i]));
-            jobs[i] = ShapeJob();  // drop the host copy
-        }
+        if (L->htables[mirge_shape_id(w.k1, w.gap, w.k2)].bucket) continue;
+        if (first) { HIPOK(hipSetDevice(L->ctx->device)); first = false; }
+        CHECK(lib_build_shape(L, w));
     }
     return 0;
 }

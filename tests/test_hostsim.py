@@ -147,7 +147,8 @@ def test_probe_plan_covers_every_mismatch_placement():
                             continue
                         cover = set(range(a1, a1 + k1)) | set(range(a1 + k1 + gap, a1 + k1 + gap + k2))
                         assert min(cover) >= 0 and max(cover) < S, (mode, mm, K, L, scheme, q)
-                        assert k1 + k2 <= K and 0 <= gap < 32 and (k2 > 0 or gap == 0)
+                        # an mm = 0 policy may take k = 15 in a library that has outgrown K = 14 (one plain table)
+                        assert k1 + k2 <= (15 if (mm == 0 and K == 14 and k2 == 0) else K) and 0 <= gap < 32 and (k2 > 0 or gap == 0)
                         probes.append(cover)
                     budget = mm  # mismatches allowed inside the seed region
                     for r in range(budget + 1):
