@@ -433,34 +433,44 @@ static int lib_build_shape(mirge_lib* L, const ShapeJob& j) {
     const int sid = mirge_shape_id(j.k1, j.gap, j.k2);
     const uint64_t nb = 1ull << (2 * (j.k1 + j.k2));
     uint32_t *A = nullptr, *dpos = nullptr, *dbits = nullptr;
-    HIPOK(hipMalloc((void**)&A, (nb + 2) * 4));
-    HIPOK(hipMemsetAsync(A, 0, (nb + 2) * 4, c->stream));
-    const int grid = c->n_cu * 8;
-    hipLaunchKernelGGL(k_table_pass<false>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1, j.gap,
-                       j.k2, A, (uint32_t*)nullptr);
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
-    HIPOK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream));
-    HIPOK(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
-    HIPOK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream));
     uint32_t npos = 0;
-    HIPOK(hipMemcpyAsync(&npos, A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
-    (void)hipFree(tmp);
-    HIPOK(hipMalloc((void**)&dpos, std::max<size_t>(npos, 1) * 4));
-    hipLaunchKernelGGL(k_table_pass<true>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1, j.gap,
-                       j.k2, A, dpos);
-    L->device_bytes += (nb + 2) * 4 + (size_t)npos * 4;
-    if (j.k1 + j.k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
-        const size_t words = (size_t)((nb + 31) / 32);
-        HIPOK(hipMalloc((void**)&dbits, words * 4));
-        hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, words)), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, dbits);
-        L->device_bytes += words * 4;
+    const int grid = c->n_cu * 8;
+    hipError_t e = hipMalloc((void**)&A, (nb + 2) * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(A, 0, (nb + 2) * 4, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_table_pass<false>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1,
+                           j.gap, j.k2, A, (uint32_t*)nullptr);
+        e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream);  // size query
     }
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&npos, A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&dpos, std::max<size_t>(npos, 1) * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_table_pass<true>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1,
+                           j.gap, j.k2, A, dpos);
+        if (j.k1 + j.k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
+            const size_t words = (size_t)((nb + 31) / 32);
+            e = hipMalloc((void**)&dbits, words * 4);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, words)), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, dbits);
+        }
+    }
+    // table complete; no kernel may be reading the registry while it changes
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        (void)hipFree(A); (void)hipFree(dpos); (void)hipFree(dbits);
+        return fail(-2, std::string("probe table construction: ") + hipGetErrorString(e));
+    }
+    L->device_bytes += (nb + 2) * 4 + (size_t)npos * 4 + (dbits ? (size_t)((nb + 31) / 32) * 4 : 0);
     L->htables[sid].bucket = A;
     L->htables[sid].pos = dpos;
     L->htables[sid].bits = dbits;
-    HIPOK(hipStreamSynchronize(c->stream));  // table complete; no kernel may be reading the registry while it changes
     HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));
     return 0;
 }
