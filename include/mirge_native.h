@@ -73,6 +73,12 @@ int mirge_lib_prepare(mirge_lib* lib, int32_t k);
 /* ---- reads: replaces writing bwtInput.fasta (manifoldAlign.py:92-95) / dnaio parsing ---- */
 int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, int64_t n,
                      mirge_reads** out);
+/* The same from the FILE's text, parsed on the device: replaces dnaio's record parsing and the length filter of the
+ * per-chunk worker (digest.py:320-375, --minimum-length :348,368).  format: 1 FASTQ (4-line records), 2 FASTA (one
+ * sequence line per record), 3 one sequence per line, 0 = by the first byte.  *n_records = records seen before the
+ * filter (`count`, digest.py:326).  Reads come out in file order. */
+int mirge_reads_parse(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                      mirge_reads** out, int64_t* n_records);
 void mirge_reads_destroy(mirge_reads* reads);
 int64_t mirge_reads_count(const mirge_reads* reads);
 int64_t mirge_reads_total_bases(const mirge_reads* reads);

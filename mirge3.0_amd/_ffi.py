@@ -22,7 +22,7 @@ SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libm
 EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
-    "mirge_reads_pack", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
+    "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_variant_tally", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
@@ -202,6 +202,18 @@ class DeviceReads:
         _check(load().mirge_reads_pack(ctx._h, _p(data), _p(off), C.c_int64(len(reads)), C.byref(h)),
                "mirge_reads_pack")
         return DeviceReads(ctx, h)
+
+    @staticmethod
+    def parse(ctx: Context, text, fmt: int = 0, min_len: int = 0):
+        """FASTQ / single-line FASTA / one-sequence-per-line TEXT (bytes or a uint8 array) -> (DeviceReads of the
+        records with len >= min_len, number of records seen).  Parsed on the GPU: no per-read host work."""
+        buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else \
+            np.ascontiguousarray(text, dtype=np.uint8)
+        h = C.c_void_p()
+        nrec = C.c_int64()
+        _check(load().mirge_reads_parse(ctx._h, _p(buf) if buf.size else C.c_void_p(0), C.c_int64(buf.size), C.c_int32(fmt),
+                                        C.c_int32(min_len), C.byref(h), C.byref(nrec)), "mirge_reads_parse")
+        return DeviceReads(ctx, h), int(nrec.value)
 
     def __len__(self) -> int:
         return load().mirge_reads_count(self._h)

@@ -62,6 +62,13 @@ def read_fastq_sequences(path: str) -> FlatSeqs:
     return FlatSeqs(buf[s[rows] + within], offsets)
 
 
+def read_text(path: str) -> bytes:
+    """The file's bytes (gunzipped if .gz) for the device-side parser (``mirge_reads_parse``)."""
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "rb") as fh:
+        return fh.read()
+
+
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:
     keep = np.flatnonzero(reads.lengths >= int(min_len))
     if keep.shape[0] == len(reads):
@@ -119,8 +126,30 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
     min_len = int(getattr(args, "minimum_length", 16))
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     samples: List[FlatSeqs] = []
+    # One sample, no UMI: the file's text goes to the GPU as it is (records found, filtered by length, packed and
+    # collapsed there: digest.py:320-375 + :141-163 without a per-read host step).  Several samples or UMIs: the
+    # sequences are cut out on the host and all samples are collapsed together with a sample id.
+    device_parse = len(inFileArray) == 1 and not umi
+    uniq = None
     for FQfile, name in zip(inFileArray, inFileBaseArray):
         start = time.perf_counter()
+        if device_parse:
+            raw, n_rec = _ffi.DeviceReads.parse(ctx, read_text(str(FQfile)), 0, min_len)
+            sampleReadCounts[name] = n_rec
+            trimmedReadCounts[name] = len(raw)
+            uniq = raw.collapse()
+            raw.close()
+            finish2 = time.perf_counter()
+            if not args.quiet:
+                print(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)')
+            outlog.write(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)\n')
+            if getattr(args, "tcf_out", False):
+                tc, tfirst = uniq.counts()
+                tl = uniq.unpack().to_list()
+                by = sorted(range(len(tl)), key=lambda i: (-int(tc[i, 0]), int(tfirst[i])))  # by count, ties in dict order
+                with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
+                    fo.write("".join(f">seq{k + 1}_{int(tc[i, 0])}\n{tl[i]}\n" for k, i in enumerate(by)))
+            continue
         reads = read_fastq_sequences(str(FQfile))
         sampleReadCounts[name] = len(reads)
         if not umi:
@@ -150,7 +179,8 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
             with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
                 fo.write("".join(f">seq{k + 1}_{int(tc[i])}\n{tl[i]}\n" for k, i in enumerate(by)))
     t0 = time.perf_counter()
-    uniq = collapse_samples(ctx, samples)
+    if uniq is None:
+        uniq = collapse_samples(ctx, samples)
     counts, first = uniq.counts()
     seqs = uniq.unpack().to_list()
     uniq.close()

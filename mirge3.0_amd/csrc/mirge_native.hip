@@ -552,11 +552,11 @@ extern "C" int64_t mirge_reads_total_bases(const mirge_reads* r) { return r ? r-
 extern "C" int32_t mirge_reads_n_samples(const mirge_reads* r) { return r ? r->n_samples : -1; }
 
 template <int W>
-static void launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* doff, const uint32_t* didx,
+static void launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstart, const int64_t* dend, const uint32_t* didx,
                         ReadGroup& g, uint32_t* dflags) {
     LaunchScope ls(c, "k_pack", g.n);
     hipLaunchKernelGGL(k_pack<W>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
-                       dascii, doff, didx, g.n, g.seq, g.len, g.nmask, dflags);
+                       dascii, dstart, dend, didx, g.n, g.seq, g.len, g.nmask, dflags);
 }
 
 extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads** out) {
@@ -634,9 +634,9 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
         CHECK(dalloc(c, &g.orig, (size_t)g.n));
         HIPOK(hipMemcpyAsync(g.orig, idx[gi].data(), (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream));
         didx[gi] = g.orig;
-        if (kGroupW[gi] == 1) launch_pack<1>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
-        else if (kGroupW[gi] == 2) launch_pack<2>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
-        else launch_pack<4>(c, dascii, doff, didx[gi], g, dflags + 2 * gi);
+        if (kGroupW[gi] == 1) launch_pack<1>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
+        else if (kGroupW[gi] == 2) launch_pack<2>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
+        else launch_pack<4>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
     }
     HIPOK(hipMemcpyAsync(c->pinned, dflags, 64, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));  // idx/rel host vectors are read by the async copies
@@ -651,6 +651,135 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
     *out = R.release();
     return 0;
 }
+
+// Sequence text -> packed reads, parsed on the device (k_nl_count / k_nl_mark / k_seq_class / k_seq_place, then
+// k_pack straight from the text).  format: 1 = FASTQ (4-line records), 2 = FASTA (one sequence line per record),
+// 3 = one sequence per line, 0 = by the first byte ('@', '>', else 3).  Reads shorter than min_len are dropped
+// (digest.py:348,368); *n_records = records seen before the filter (digest.py:326 `count`).
+extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                                 mirge_reads** out, int64_t* n_records) {
+    if (!c || !out || nbytes < 0 || (nbytes > 0 && !text) || format < 0 || format > 3)
+        return fail(-1, "mirge_reads_parse: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    if (format == 0) format = nbytes == 0 ? 3 : (text[0] == '@' ? 1 : (text[0] == '>' ? 2 : 3));
+    const int period = format == 1 ? 4 : (format == 2 ? 2 : 1), sphase = format == 3 ? 0 : 1;
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = 0;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    R->hist_valid = true;
+    R->total_bases = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
+    if (n_records) *n_records = 0;
+    if (nbytes == 0) { *out = R.release(); return 0; }
+    // the text, with a final newline if the file has none
+    const bool add_nl = text[nbytes - 1] != '\n';
+    const uint64_t n = (uint64_t)nbytes + (add_nl ? 1 : 0);
+    const uint32_t ntile = (uint32_t)((n + MIRGE_PARSE_TILE - 1) / MIRGE_PARSE_TILE);
+    uint8_t* dtext = nullptr;
+    uint32_t *tile_cnt = nullptr, *tile_off = nullptr;
+    CHECK(dalloc(c, &dtext, (size_t)n + 16));
+    CHECK(dalloc(c, &tile_cnt, (size_t)ntile + 1));
+    CHECK(dalloc(c, &tile_off, (size_t)ntile + 1));
+    HIPOK(hipMemcpyAsync(dtext, text, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    if (add_nl) HIPOK(hipMemsetAsync(dtext + nbytes, '\n', 1, c->stream));
+    HIPOK(hipMemsetAsync(tile_cnt + ntile, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_nl_count, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_cnt);
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIPOK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, tile_cnt, tile_off, (int)(ntile + 1), c->stream));
+    size_t tmp_cap = std::max<size_t>(tmp_bytes, 1 << 16);
+    CHECK(dalloc(c, (uint8_t**)&tmp, tmp_cap));
+    HIPOK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, tile_cnt, tile_off, (int)(ntile + 1), c->stream));
+    uint32_t n_lines = 0;
+    HIPOK(hipMemcpyAsync(&n_lines, tile_off + ntile, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    // sequence lines: li in [0, n_lines) with li % period == sphase
+    const uint64_t n_seq64 = n_lines > (uint32_t)sphase ? ((uint64_t)n_lines - sphase + period - 1) / period : 0;
+    int rc = n_seq64 >= 0xFFFFFFF0ull ? fail(-5, "more than 2^32 reads in one set is not supported") : 0;
+    const uint32_t n_seq = rc ? 0u : (uint32_t)n_seq64;
+    if (n_records) *n_records = n_seq;
+    int64_t *dstart = nullptr, *dend = nullptr;
+    uint8_t* dcls = nullptr;
+    uint32_t *blk = nullptr, *blk_off = nullptr, *keep = nullptr, *keep_off = nullptr, *dmeta = nullptr, *src_all = nullptr,
+             *orig_all = nullptr;
+    const uint32_t nblk = std::max<uint32_t>(1, (n_seq + MIRGE_BLOCK - 1) / MIRGE_BLOCK);
+    const size_t meta_words = 8 + MIRGE_MAX_READ_LEN + 1;  // [0..2] flags, [8..] length histogram
+    do {
+        if (!n_seq) break;
+        if ((rc = dalloc(c, &dstart, (size_t)n_seq))) break;
+        if ((rc = dalloc(c, &dend, (size_t)n_seq))) break;
+        if ((rc = dalloc(c, &dcls, (size_t)n_seq))) break;
+        if ((rc = dalloc(c, &blk, (size_t)6 * nblk + 1))) break;
+        if ((rc = dalloc(c, &blk_off, (size_t)6 * nblk + 1))) break;
+        if ((rc = dalloc(c, &keep, (size_t)nblk + 1))) break;
+        if ((rc = dalloc(c, &keep_off, (size_t)nblk + 1))) break;
+        if ((rc = dalloc(c, &dmeta, meta_words))) break;
+        hipError_t e = hipMemsetAsync(dmeta, 0, meta_words * 4, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(blk + (size_t)6 * nblk, 0, 4, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(keep + nblk, 0, 4, c->stream);
+        if (e != hipSuccess) { rc = fail(-2, hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL(k_nl_mark, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_off, period, sphase, dstart, dend,
+                           (uint64_t)n_seq);
+        hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dtext, dstart, dend, n_seq, min_len, dcls, blk,
+                           keep, nblk, dmeta + 8, dmeta);
+        size_t need = 0;
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, blk, blk_off, (int)(6 * nblk + 1), c->stream);
+        if (e == hipSuccess && need > tmp_cap) { c->release(tmp); tmp = nullptr; tmp_cap = need; if ((rc = dalloc(c, (uint8_t**)&tmp, tmp_cap))) break; }
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need, blk, blk_off, (int)(6 * nblk + 1), c->stream);
+        size_t need2 = tmp_cap;
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need2, keep, keep_off, (int)(nblk + 1), c->stream);
+        // group bounds = blk_off at the first block of every class, and the total
+        uint32_t bounds[7];
+        for (int q = 0; q < 6 && e == hipSuccess; q++)
+            e = hipMemcpyAsync(&bounds[q], blk_off + (size_t)q * nblk, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&bounds[6], blk_off + (size_t)6 * nblk, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->pinned, dmeta, meta_words * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_reads_parse: ") + hipGetErrorString(e)); break; }
+        if (c->pinned[1]) { rc = fail(-6, "a read is " + std::to_string(c->pinned[2]) + " nt; the limit is " + std::to_string(MIRGE_MAX_READ_LEN)); break; }
+        if (c->pinned[0]) { rc = fail(-7, "a read contains a character other than A/C/G/T/U/N"); break; }
+        const uint32_t kept = bounds[6];
+        R->n = kept;
+        for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
+            R->len_hist[L] = (int32_t)c->pinned[8 + L];
+            R->total_bases += (int64_t)L * c->pinned[8 + L];
+        }
+        if (!kept) break;
+        if ((rc = dalloc(c, &src_all, (size_t)kept))) break;
+        if ((rc = dalloc(c, &orig_all, (size_t)kept))) break;
+        hipLaunchKernelGGL(k_seq_place, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dcls, n_seq, blk_off, keep_off, nblk, src_all,
+                           orig_all);
+        uint32_t* dflags = dmeta;  // reused: k_pack's per-group (saw N, bad byte) pairs
+        e = hipMemsetAsync(dflags, 0, 64, c->stream);
+        for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0 && e == hipSuccess; gi++) {
+            ReadGroup& g = R->g[gi];
+            g.n = bounds[gi + 1] - bounds[gi];
+            if (!g.n) continue;
+            if ((rc = dalloc(c, &g.seq, (size_t)g.W * g.n))) break;
+            if ((rc = dalloc(c, &g.nmask, (size_t)g.W * g.n))) break;
+            if ((rc = dalloc(c, &g.len, (size_t)g.n))) break;
+            if ((rc = dalloc(c, &g.orig, (size_t)g.n))) break;
+            e = hipMemcpyAsync(g.orig, orig_all + bounds[gi], (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream);
+            const uint32_t* src = src_all + bounds[gi];
+            if (kGroupW[gi] == 1) launch_pack<1>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
+            else if (kGroupW[gi] == 2) launch_pack<2>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
+            else launch_pack<4>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
+        }
+        if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (rc == 0 && e != hipSuccess) rc = fail(-2, std::string("mirge_reads_parse: ") + hipGetErrorString(e));
+        if (rc == 0)
+            for (int gi = 0; gi < 3; gi++)  // the groups without an ambiguous call carry no mask
+                if (R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(dtext); c->release(tile_cnt); c->release(tile_off); c->release(tmp); c->release(dstart); c->release(dend);
+    c->release(dcls); c->release(blk); c->release(blk_off); c->release(keep); c->release(keep_off); c->release(dmeta);
+    c->release(src_all); c->release(orig_all);
+    if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    *out = R.release();
+    return 0;
+}
+
 
 extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* ascii_out, int64_t* off_out) {
     if (!c || !R || !off_out || (R->total_bases > 0 && !ascii_out)) return fail(-1, "mirge_reads_unpack: bad argument");

@@ -322,6 +322,53 @@ def test_baking_dropin(ctx, ci_libs, tmp_path):
                files, names, str(tmp_path), ctx=ctx)
 
 
+def test_device_text_parser_equals_host_parser(ctx, ci_libs, tmp_path):
+    """mirge_reads_parse (records found, length filter, grouping and 2-bit packing on the GPU) against the host
+    parser + mirge_reads_pack on the same text: FASTQ with CRLF and no final newline, single-line FASTA, one
+    sequence per line, reads with N, reads of 32-128 nt, records shorter than --minimum-length, empty input."""
+    from mirge3_amd.collapse import read_fastq_sequences, filter_min_length
+    rng = np.random.default_rng(8)
+    reads = synth.make_reads(ci_libs, 30000, seed=77, n_frac=0.02).to_list()
+    longs = ["".join("ACGT"[c] for c in rng.integers(0, 4, size=int(L))) for L in list(rng.integers(32, 129, size=400)) + [31, 32, 64, 65, 128]]
+    shorts = ["ACGT", "ACGTACGTACGTACG", "", "A"]
+    seqs = reads + longs + shorts + [longs[3][:40] + "N" + longs[3][41:90], "acgtacgtacgtacgtnnu"]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    texts = {
+        "fastq": "".join(f"@r{i} x\n{q}\n+\n{'I' * len(q)}\n" for i, q in enumerate(seqs)),
+        "fastq_crlf_noeol": "".join(f"@r{i}\r\n{q}\r\n+\r\n{'I' * len(q)}\r\n" for i, q in enumerate(seqs))[:-2],
+        "fasta": "".join(f">r{i}\n{q}\n" for i, q in enumerate(seqs)),
+        "lines": "\n".join(q for q in seqs if q) + "\n",
+    }
+    for name, text in texts.items():
+        path = tmp_path / (name + ".txt")
+        path.write_text(text, newline="")
+        host = read_fastq_sequences(str(path))
+        for min_len in (0, 16):
+            exp = filter_min_length(host, min_len)
+            dr, n_rec = _ffi.DeviceReads.parse(ctx, path.read_bytes(), 0, min_len)
+            assert n_rec == len(host), (name, n_rec, len(host))
+            assert len(dr) == len(exp), (name, min_len)
+            assert dr.unpack().to_list() == [q.upper().replace("U", "T") for q in exp.to_list()], (name, min_len)
+            hp = _ffi.DeviceReads.pack(ctx, exp)
+            u1, u2 = dr.collapse(), hp.collapse()
+            c1, f1 = u1.counts(); c2, f2 = u2.counts()
+            o1, o2 = np.argsort(f1, kind="stable"), np.argsort(f2, kind="stable")
+            assert np.array_equal(f1[o1], f2[o2]) and np.array_equal(c1[o1], c2[o2])
+            s1, s2 = u1.unpack().to_list(), u2.unpack().to_list()
+            assert [s1[i] for i in o1] == [s2[i] for i in o2]
+            for h in (u1, u2, dr, hp):
+                h.close()
+    dr, n_rec = _ffi.DeviceReads.parse(ctx, b"", 0, 16)
+    assert len(dr) == 0 and n_rec == 0
+    dr, n_rec = _ffi.DeviceReads.parse(ctx, b"@r\nACGT\n+\nIIII\n", 0, 16)
+    assert len(dr) == 0 and n_rec == 1 and len(dr.collapse()) == 0
+    with pytest.raises(RuntimeError, match="limit is 128"):
+        _ffi.DeviceReads.parse(ctx, ("A" * 129 + "\n").encode(), 3, 0)
+    with pytest.raises(RuntimeError, match="other than"):
+        _ffi.DeviceReads.parse(ctx, b"ACGTACGTACGTACGTXACGT\n", 3, 0)
+
+
 def test_baking_umi_against_reference_vectors(ctx, tmp_path):
     """-umi f,b [-udd] [-tcf] (digest.py:164-205,219-229,305-315): tests/golden/umi was written with the
     reference's own UMIParser; two samples check the joined matrix against the oracle's restatement."""
