@@ -79,6 +79,9 @@ int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, 
  * filter (`count`, digest.py:326).  Reads come out in file order. */
 int mirge_reads_parse(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                       mirge_reads** out, int64_t* n_records);
+/* Several raw read sets as one, in the order given (the samples of a run, one file each, before the joint collapse
+ * that replaces the per-file dicts and their outer join, digest.py:133-163,243).  The parts stay valid. */
+int mirge_reads_concat(mirge_ctx* ctx, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out);
 void mirge_reads_destroy(mirge_reads* reads);
 int64_t mirge_reads_count(const mirge_reads* reads);
 int64_t mirge_reads_total_bases(const mirge_reads* reads);

@@ -22,7 +22,7 @@ SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libm
 EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
-    "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
+    "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_variant_tally", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
@@ -214,6 +214,14 @@ class DeviceReads:
         _check(load().mirge_reads_parse(ctx._h, _p(buf) if buf.size else C.c_void_p(0), C.c_int64(buf.size), C.c_int32(fmt),
                                         C.c_int32(min_len), C.byref(h), C.byref(nrec)), "mirge_reads_parse")
         return DeviceReads(ctx, h), int(nrec.value)
+
+    @staticmethod
+    def concat(ctx: Context, parts: Sequence["DeviceReads"]) -> "DeviceReads":
+        """Raw read sets appended in the order given (one per sample, before the joint collapse)."""
+        arr = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        h = C.c_void_p()
+        _check(load().mirge_reads_concat(ctx._h, arr, C.c_int32(len(parts)), C.byref(h)), "mirge_reads_concat")
+        return DeviceReads(ctx, h)
 
     def __len__(self) -> int:
         return load().mirge_reads_count(self._h)

@@ -126,26 +126,29 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
     min_len = int(getattr(args, "minimum_length", 16))
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     samples: List[FlatSeqs] = []
-    # One sample, no UMI: the file's text goes to the GPU as it is (records found, filtered by length, packed and
-    # collapsed there: digest.py:320-375 + :141-163 without a per-read host step).  Several samples or UMIs: the
-    # sequences are cut out on the host and all samples are collapsed together with a sample id.
-    device_parse = len(inFileArray) == 1 and not umi
+    # No UMI: every file's text goes to the GPU as it is (records found, filtered by length and packed there:
+    # digest.py:320-375 without a per-read host step); the samples' read sets are appended on the device and
+    # collapsed together with a sample id (digest.py:141-163 + the outer join :243).  With UMIs the sequences are
+    # cut out and sliced on the host first.
+    device_parse = not umi
     uniq = None
+    parsed: List[_ffi.DeviceReads] = []
     for FQfile, name in zip(inFileArray, inFileBaseArray):
         start = time.perf_counter()
         if device_parse:
             raw, n_rec = _ffi.DeviceReads.parse(ctx, read_text(str(FQfile)), 0, min_len)
             sampleReadCounts[name] = n_rec
             trimmedReadCounts[name] = len(raw)
-            uniq = raw.collapse()
-            raw.close()
+            parsed.append(raw)
             finish2 = time.perf_counter()
             if not args.quiet:
                 print(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)')
             outlog.write(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)\n')
             if getattr(args, "tcf_out", False):
-                tc, tfirst = uniq.counts()
-                tl = uniq.unpack().to_list()
+                u1 = raw.collapse()
+                tc, tfirst = u1.counts()
+                tl = u1.unpack().to_list()
+                u1.close()
                 by = sorted(range(len(tl)), key=lambda i: (-int(tc[i, 0]), int(tfirst[i])))  # by count, ties in dict order
                 with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
                     fo.write("".join(f">seq{k + 1}_{int(tc[i, 0])}\n{tl[i]}\n" for k, i in enumerate(by)))
@@ -179,7 +182,17 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
             with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
                 fo.write("".join(f">seq{k + 1}_{int(tc[i])}\n{tl[i]}\n" for k, i in enumerate(by)))
     t0 = time.perf_counter()
-    if uniq is None:
+    if device_parse:
+        if len(parsed) == 1:
+            uniq = parsed[0].collapse()
+        else:
+            allr = _ffi.DeviceReads.concat(ctx, parsed)
+            sid = np.repeat(np.arange(len(parsed), dtype=np.int32), [len(p) for p in parsed])
+            uniq = allr.collapse(sid, len(parsed))
+            allr.close()
+        for p in parsed:
+            p.close()
+    else:
         uniq = collapse_samples(ctx, samples)
     counts, first = uniq.counts()
     seqs = uniq.unpack().to_list()

@@ -77,6 +77,13 @@ __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restr
     }
 }
 
+// dst[i] = (src ? src[i] : src_base + i) + add : handle-order indices of a read set appended to another
+__global__ void k_index_shift(const uint32_t* __restrict__ src, uint32_t src_base, uint32_t n, uint32_t add,
+                              uint32_t* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = (src ? src[i] : src_base + i) + add;
+}
+
 template <int W>
 __global__ void k_unpack(GroupView<W> g, const int64_t* __restrict__ out_off, uint32_t base,
                          const uint32_t* __restrict__ orig, uint8_t* __restrict__ ascii_out) {

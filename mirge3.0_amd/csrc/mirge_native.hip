@@ -547,6 +547,69 @@ extern "C" void mirge_reads_destroy(mirge_reads* r) {
     }
     delete r;
 }
+// Several raw read sets (the samples of a run, each parsed from its own file) as one, in the order given: read j of
+// part p gets handle index (reads of the parts before p) + j.  No count matrices; the parts stay valid.
+extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out) {
+    if (!c || !parts || n_parts < 1 || !out) return fail(-1, "mirge_reads_concat: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    int64_t total = 0;
+    for (int p = 0; p < n_parts; p++) {
+        if (!parts[p] || parts[p]->ctx != c) return fail(-1, "mirge_reads_concat: foreign or NULL read set");
+        if (parts[p]->n_samples) return fail(-1, "mirge_reads_concat: collapsed read sets cannot be appended");
+        total += parts[p]->n;
+    }
+    if (total >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = total; R->hist_valid = true;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    for (int p = 0; p < n_parts; p++) {
+        R->total_bases += parts[p]->total_bases;
+        R->hist_valid = R->hist_valid && parts[p]->hist_valid;
+        for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) R->len_hist[L] += parts[p]->len_hist[L];
+    }
+    int rc = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+        ReadGroup& g = R->g[gi];
+        g.W = kGroupW[gi];
+        uint64_t n = 0;
+        bool mask = false;
+        for (int p = 0; p < n_parts; p++) { n += parts[p]->g[gi].n; mask = mask || parts[p]->g[gi].nmask; }
+        g.n = (uint32_t)n;
+        if (!g.n) continue;
+        if ((rc = dalloc(c, &g.seq, (size_t)g.W * g.n))) break;
+        if ((rc = dalloc(c, &g.len, (size_t)g.n))) break;
+        if ((rc = dalloc(c, &g.orig, (size_t)g.n))) break;
+        if (mask && (rc = dalloc(c, &g.nmask, (size_t)g.W * g.n))) break;
+        uint32_t at = 0, before = 0;
+        hipError_t e = hipSuccess;
+        for (int p = 0; p < n_parts && e == hipSuccess; p++) {
+            const ReadGroup& q = parts[p]->g[gi];
+            if (q.n) {
+                for (int w = 0; w < g.W && e == hipSuccess; w++) {  // word-major arrays: one copy per word plane
+                    e = hipMemcpyAsync(g.seq + (size_t)w * g.n + at, q.seq + (size_t)w * q.n, (size_t)q.n * 8, hipMemcpyDeviceToDevice, c->stream);
+                    if (e == hipSuccess && g.nmask) {
+                        if (q.nmask) e = hipMemcpyAsync(g.nmask + (size_t)w * g.n + at, q.nmask + (size_t)w * q.n, (size_t)q.n * 8, hipMemcpyDeviceToDevice, c->stream);
+                        else e = hipMemsetAsync(g.nmask + (size_t)w * g.n + at, 0, (size_t)q.n * 8, c->stream);
+                    }
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(g.len + at, q.len, (size_t)q.n, hipMemcpyDeviceToDevice, c->stream);
+                hipLaunchKernelGGL(k_index_shift, dim3(grid_for(c, q.n)), dim3(MIRGE_BLOCK), 0, c->stream, (const uint32_t*)q.orig, q.base,
+                                   q.n, before, g.orig + at);
+                at += q.n;
+            }
+            before += (uint32_t)parts[p]->n;
+        }
+        if (e != hipSuccess) rc = fail(-2, std::string("mirge_reads_concat: ") + hipGetErrorString(e));
+    }
+    if (rc == 0) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(-2, std::string("mirge_reads_concat: ") + hipGetErrorString(e));
+    }
+    if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    *out = R.release();
+    return 0;
+}
+
 extern "C" int64_t mirge_reads_count(const mirge_reads* r) { return r ? r->n : -1; }
 extern "C" int64_t mirge_reads_total_bases(const mirge_reads* r) { return r ? r->total_bases : -1; }
 extern "C" int32_t mirge_reads_n_samples(const mirge_reads* r) { return r ? r->n_samples : -1; }

@@ -359,6 +359,18 @@ def test_device_text_parser_equals_host_parser(ctx, ci_libs, tmp_path):
             assert [s1[i] for i in o1] == [s2[i] for i in o2]
             for h in (u1, u2, dr, hp):
                 h.close()
+    # mirge_reads_concat: the samples of a run appended on the device, handle order = part order
+    a, _ = _ffi.DeviceReads.parse(ctx, texts["fastq"].encode(), 0, 16)
+    b, _ = _ffi.DeviceReads.parse(ctx, texts["fasta"].encode()[:20000] + b"\n", 0, 0)
+    e, _ = _ffi.DeviceReads.parse(ctx, b"", 0, 0)
+    ab = _ffi.DeviceReads.concat(ctx, [a, e, b, a])
+    assert ab.unpack().to_list() == a.unpack().to_list() + b.unpack().to_list() + a.unpack().to_list()
+    sid = np.repeat(np.arange(4, dtype=np.int32), [len(a), 0, len(b), len(a)])
+    u = ab.collapse(sid, 4)
+    cnt, _ = u.counts()
+    assert cnt[:, 0].sum() == len(a) and cnt[:, 1].sum() == 0 and cnt[:, 2].sum() == len(b) and np.array_equal(cnt[:, 0], cnt[:, 3])
+    for h in (u, ab, a, b, e):
+        h.close()
     dr, n_rec = _ffi.DeviceReads.parse(ctx, b"", 0, 16)
     assert len(dr) == 0 and n_rec == 0
     dr, n_rec = _ffi.DeviceReads.parse(ctx, b"@r\nACGT\n+\nIIII\n", 0, 16)
