@@ -1,0 +1,375 @@
+// kernels_cascade.hpp -- part of mirge_kernels.hpp: alignment (probe, verify), k_pass, k_cascade_fused, k_resolve.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// align_hybrid: the device form of mirge_align_indexed (same probes, same verification, same
+// minimum) with the candidate lists balanced over the wave.
+//   A probe's bucket holds from 0 to thousands of candidate windows (a 16-nt read under -v 2 is
+//   probed with 4-mers: ~220 candidates per probe in a 57 kb library, while a 28-nt read sees ~1).
+//   Lane-serial evaluation makes the whole wave wait for its unluckiest lane and walks each list
+//   as a chain of dependent loads.  Here a lane verifies only short lists (<= MIRGE_LIGHT) itself;
+//   longer lists are taken one at a time by the whole wave: the owner's read is broadcast with
+//   v_readlane, the 64 lanes stride through the bucket (coalesced pos[] loads, 64 windows
+//   verified per step); the few lanes that found a valid window are read back with v_readlane and
+//   their minimum goes to the owner.
+//   All 64 lanes of the wave must call this together (inactive lanes pass active = false).
+// ------------------------------------------------------------------------------------------
+#ifndef MIRGE_LIGHT
+#define MIRGE_LIGHT 4
+#endif
+#ifndef MIRGE_LIGHT_MAX
+#define MIRGE_LIGHT_MAX 16
+#endif
+#define MIRGE_COOP_UNROLL 1
+
+// pointers that came out of memory or a v_readlane have lost their address space; these casts keep
+// the loads global_load_* (not flat_load_*, which also ties up lgkmcnt)
+typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
+typedef const __attribute__((address_space(1))) uint64_t* gptr_u64;
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Consecutive passes with one and the same policy (snoRNA / rRNA / other ncRNA: all "-n 1") run as ONE
+// pass over the concatenation of their libraries.  The cascade's priority -- the first library with
+// ANY valid hit wins, whatever its mismatch count -- is kept by ranking candidates on
+// (library class, mismatches, position): class = which member's text the window lies in.
+struct MergeInfo {
+    uint32_t bound[4];  // global position where member c's text starts (bound[0] = 0)
+    int32_t n;          // members (1 = ordinary pass)
+};
+__device__ __forceinline__ uint64_t class_key(const MergeInfo& mi, uint64_t g) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++) c += (i < mi.n && g >= mi.bound[i]) ? 1u : 0u;
+    return c << 40;
+}
+
+// the two text words under a window: issued for several candidates before any is consumed
+struct TextWin { uint64_t w[5]; };
+
+template <int W>
+__device__ __forceinline__ void load_window(gptr_u64 T, uint64_t g, int L, TextWin& tw) {
+    const uint64_t q = g >> 5;
+#pragma unroll
+    for (int i = 0; i <= W; i++) tw.w[i] = (i == 0 || 32 * (i - 1) < L) ? T[q + i] : 0ull;
+}
+
+// same arithmetic as mirge_window_mm, on words that are already in registers
+template <int W>
+__device__ __forceinline__ int window_mm_regs(const TextWin& tw, uint64_t g, const MirgeRead<W>& r,
+                                              const MirgePolicy& p) {
+    const int L = r.len;
+    const int s = (int)(g & 31) * 2;
+    int tot = 0, seedmm = 0;
+    const int seed = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        if (32 * i < L) {
+            const uint64_t t = s ? ((tw.w[i] >> s) | (tw.w[i + 1] << (64 - s))) : tw.w[i];
+            const uint64_t x = r.w[i] ^ t;
+            uint64_t m = (x | (x >> 1)) & 0x5555555555555555ull;
+            const int rem = L - 32 * i;
+            m &= mirge_lowmask2(rem > 32 ? 32 : rem);
+            m |= r.nm[i];
+            tot += mirge_popc(m);
+            const int srem = seed - 32 * i;
+            if (srem > 0) seedmm += mirge_popc(m & mirge_lowmask2(srem > 32 ? 32 : srem));
+        }
+    }
+    if (tot > p.maxtotal || seedmm > p.mm) return -1;
+    return tot;
+}
+
+// verify up to N candidate positions at once: all pos loads, then all text loads, then arithmetic
+template <int W, int N>
+__device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
+                                               const MirgeRead<W>& r, gptr_u32 pos, const uint32_t (&c)[N],
+                                               uint32_t hi, int a) {
+    uint32_t pz[N];
+    bool ok[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        ok[u] = c[u] < hi;
+        pz[u] = ok[u] ? pos[c[u]] : 0u;
+    }
+    TextWin tw[N];
+    uint64_t g[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        ok[u] = ok[u] && pz[u] >= (uint32_t)a;
+        g[u] = ok[u] ? (uint64_t)pz[u] - (uint64_t)a : 0ull;
+        load_window<W>((gptr_u64)lib.T, g[u], ok[u] ? r.len : 0, tw[u]);
+    }
+    uint64_t best = MIRGE_NO_HIT;
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        if (!ok[u]) continue;
+        const int m = window_mm_regs<W>(tw[u], g[u], r, pol);
+        if (m < 0) continue;
+        if (mirge_window_invalid(lib.inv, g[u], r.len)) continue;
+        const uint64_t cand = class_key(mi, g[u]) | ((uint64_t)m << 32) | g[u];
+        if (cand < best) best = cand;
+    }
+    return best;
+}
+
+template <int W>
+__device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
+                                             const MirgePlanTable* __restrict__ plan, const MirgeRead<W>& r,
+                                             bool active, uint64_t& best) {
+    best = MIRGE_NO_HIT;
+    const int lane = threadIdx.x & 63;
+    const int np = active ? (int)plan->np[r.len] : 0;
+    // wave-uniform bound on the probe count: (mm+1) plain segments or (mm+1)^2 recursive probes
+    const int npmax = (pol.mm >= 1 && pol.mm <= 2) ? (pol.mm + 1) * (pol.mm + 1) : pol.mm + 1;
+#pragma unroll 1
+    for (int q = 0; q < npmax; q++) {
+        uint32_t lo = 0, hi = 0;
+        int a = 0;
+        gptr_u32 pos = nullptr;
+        if (active && q < np) {
+            const MirgeProbe pr = plan->pr[r.len][q];  // tabulated mirge_probe_at(pol, len, K, q)
+            uint64_t key;
+            if (mirge_probe_key<W>(r, pr, key)) {  // no ambiguous call inside the probe
+                const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+                gptr_u32 bits = (gptr_u32)tb.bits;
+                if (!bits || ((bits[key >> 5] >> (key & 31)) & 1u)) {  // L2-resident "bucket is non-empty" bit
+                    gptr_u32 bucket = (gptr_u32)tb.bucket;
+                    pos = (gptr_u32)tb.pos;
+                    lo = bucket[key];
+                    hi = bucket[key + 1];
+                    a = pr.a1;
+                }
+            }
+        }
+        // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
+        // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
+        // per list and many such lanes per probe the lane-serial batches are several times cheaper)
+        const bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
+        if (!heavy) {
+            for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
+                uint32_t c[MIRGE_LIGHT];
+#pragma unroll
+                for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
+                const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a);
+                if (cand < best) best = cand;
+            }
+        }
+        unsigned long long hb = __ballot(heavy);
+        while (hb) {
+            const int src = __ffsll(hb) - 1;
+            hb &= hb - 1;
+            MirgeRead<W> rr;
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                rr.w[w] = readlane_u64(r.w[w], src);
+                rr.nm[w] = readlane_u64(r.nm[w], src);
+            }
+            rr.len = __builtin_amdgcn_readlane(r.len, src);
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)lo, src);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, src);
+            const int ba = __builtin_amdgcn_readlane(a, src);
+            gptr_u32 bpos = (gptr_u32)readlane_u64((uint64_t)pos, src);
+            uint64_t lbest = MIRGE_NO_HIT;
+            for (uint32_t c0 = blo + lane; c0 < bhi; c0 += 64 * MIRGE_COOP_UNROLL) {
+                uint32_t c[MIRGE_COOP_UNROLL];
+#pragma unroll
+                for (int u = 0; u < MIRGE_COOP_UNROLL; u++) c[u] = c0 + 64 * u;
+                const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, mi, rr, bpos, c, bhi, ba);
+                if (cand < lbest) lbest = cand;
+            }
+            // almost every candidate fails verification: instead of a shuffle tree, visit the few
+            // lanes that hold a hit (v_readlane -> scalar min)
+            unsigned long long hits = __ballot(lbest != MIRGE_NO_HIT);
+            uint64_t tbest = MIRGE_NO_HIT;
+            while (hits) {
+                const int hl = __ffsll(hits) - 1;
+                hits &= hits - 1;
+                const uint64_t v = readlane_u64(lbest, hl);
+                if (v < tbest) tbest = v;
+            }
+            if (lane == src && tbest < best) best = tbest;
+        }
+        // a 0-mismatch window (of the first member library) is in probe 0's bucket and buckets ascend:
+        // nothing later can beat it
+        if (q == 0 && (best >> 32) == 0) active = false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pass: one cascade pass over the still-unannotated reads of one width group.
+//   Every workgroup owns a fixed segment of `cap` slots.  First pass (act_in == nullptr):
+//   workgroup b takes the contiguous reads [b*cap, (b+1)*cap).  Later passes: workgroup b takes
+//   the seg_n_in[b] survivors its own previous pass left in act_in[b*cap ...].
+//   A hit writes (pass, global position, mismatches) at the read's slot; every other read (not
+//   selected by the pass's subset rule, skipped by bowtie, or unaligned) is appended to the
+//   workgroup's segment of act_out, so the next pass sees exactly the rows with annotFlag == 0
+//   (manifoldAlign.py:120,129).  The append needs no global atomic: one LDS counter per
+//   workgroup, one ds_add per wave (ballot + prefix popcount).  A single global cursor was
+//   measured at ~0.35 ms per pass for 2 M reads (33 k same-address returning atomics).
+// ------------------------------------------------------------------------------------------
+// SLOT is the pass index and only names the symbol (k_pass<1,6> ...), so that rocprofv3's per-kernel
+// statistics separate the passes; the policy itself stays a run-time argument.
+#ifndef MIRGE_PASS_MIN_WAVES
+#define MIRGE_PASS_MIN_WAVES 1
+#endif
+template <int W, int SLOT>
+__global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES)
+k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __restrict__ plan, GroupView<W> g,
+       const uint32_t* __restrict__ act_in,
+       const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
+       uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
+       int8_t* __restrict__ res_mm) {
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const size_t seg = (size_t)blockIdx.x * cap;
+    uint32_t n_in;
+    if (act_in) n_in = seg_n_in[blockIdx.x];
+    else n_in = seg < g.n ? (uint32_t)((g.n - seg) < cap ? (g.n - seg) : cap) : 0u;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = 0; base < n_in; base += MIRGE_BLOCK) {
+        const uint32_t t = base + threadIdx.x;
+        const bool valid = t < n_in;
+        bool survivor = false;
+        uint32_t idx = 0;
+        if (valid) {
+            idx = act_in ? act_in[seg + t] : (uint32_t)seg + t;
+            survivor = true;
+        }
+        // the wave aligns its 64 reads together (align_hybrid balances the candidate lists)
+        MirgeRead<W> r2;
+        bool elig = false;
+        if (valid) {
+            load_read<W>(g, idx, r2);
+            elig = mirge_effective_read<W>(r2, pol);
+        } else {
+#pragma unroll
+            for (int w = 0; w < W; w++) { r2.w[w] = 0; r2.nm[w] = 0; }
+            r2.len = 0;
+        }
+        uint64_t best;
+        align_hybrid<W>(lib, pol, mi, plan, r2, elig, best);
+        if (elig && best != MIRGE_NO_HIT) {
+            const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
+            res_pass[idx] = (int8_t)(pass_id + cls);
+            uint32_t b0 = 0;
+#pragma unroll
+            for (int i = 1; i < 4; i++) if (i == cls) b0 = mi.bound[i];
+            res_pos[idx] = (uint32_t)best - b0;  // position in that member's own text
+            res_mm[idx] = (int8_t)((best >> 32) & 0xFF);
+            survivor = false;
+        }
+        const unsigned long long bal = __ballot(survivor);
+        if (bal) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(bal));
+            wbase = __shfl(wbase, 0, 64);
+            if (survivor) act_out[seg + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) seg_n_out[blockIdx.x] = s_count;
+}
+
+// global position -> (reference index, offset) by binary search in ref_start of the pass's library
+struct ResolveTable {
+    const uint32_t* ref_start[MIRGE_MAX_PASSES_K];
+    uint32_t n_refs[MIRGE_MAX_PASSES_K];
+};
+
+__device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint32_t g, int32_t& ref, int32_t& off) {
+    const uint32_t* rs = nullptr;
+    uint32_t nr = 0;
+#pragma unroll
+    for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
+        if (q == p) { rs = tb.ref_start[q]; nr = tb.n_refs[q]; }
+    uint32_t lo = 0, hi = nr;  // last t with rs[t] <= g
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (rs[mid] <= g) lo = mid; else hi = mid;
+    }
+    ref = (int32_t)lo;
+    off = (int32_t)(g - rs[lo]);
+}
+
+__global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, const uint32_t* __restrict__ res_pos,
+                          uint32_t n, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int p = res_pass[i];
+        int32_t ref = -1, off = -1;
+        if (p >= 0) resolve_one(tb, p, res_pos[i], ref, off);
+        res_ref[i] = ref;
+        res_off[i] = off;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cascade_fused: the whole cascade of a SMALL read group in one launch.  The groups beside the bulk
+// (reads with an N, 32-128 nt reads: a few hundred to a few 100 k reads) cost one launch per pass plus
+// memsets and a resolve each -- ~30 launches whose host-side enqueue time, not their GPU time, kept the
+// bulk group's first pass waiting (profiles/r01_timeline.txt).  Here a wave keeps its 64 reads through
+// every step; a read that is annotated simply stops being eligible (no compaction: the group is small).
+// Same device functions as k_pass, so the same answers.
+// ------------------------------------------------------------------------------------------
+struct FusedStep {
+    MirgeLibView lib;
+    MirgePolicy pol;
+    MergeInfo mi;
+    const MirgePlanTable* plan;
+    int32_t pass_id;
+};
+struct FusedSteps {
+    int32_t n;
+    FusedStep s[MIRGE_MAX_PASSES_K];
+};
+
+template <int W>
+__global__ void __launch_bounds__(MIRGE_BLOCK)
+k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView<W> g, int8_t* __restrict__ res_pass,
+                uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref,
+                int32_t* __restrict__ res_off) {
+    const uint32_t nrounds = (g.n + MIRGE_BLOCK - 1) / MIRGE_BLOCK;
+    const int nsteps = steps->n;
+    for (uint32_t round = blockIdx.x; round < nrounds; round += gridDim.x) {
+        const uint32_t idx = round * MIRGE_BLOCK + threadIdx.x;
+        const bool valid = idx < g.n;
+        MirgeRead<W> r0;
+        if (valid) load_read<W>(g, idx, r0);
+        else {
+#pragma unroll
+            for (int w = 0; w < W; w++) { r0.w[w] = 0; r0.nm[w] = 0; }
+            r0.len = 0;
+        }
+        bool open = valid;
+        int8_t o_pass = -1, o_mm = -1;
+        uint32_t o_pos = 0;
+        for (int si = 0; si < nsteps; si++) {
+            if (!__ballot(open)) break;  // wave-uniform
+            const FusedStep& st = steps->s[si];
+            MirgeRead<W> r2 = r0;
+            const bool elig = open && mirge_effective_read<W>(r2, st.pol);
+            uint64_t best;
+            align_hybrid<W>(st.lib, st.pol, st.mi, st.plan, r2, elig, best);
+            if (elig && best != MIRGE_NO_HIT) {
+                const int cls = (int)(best >> 40);
+                o_pass = (int8_t)(st.pass_id + cls);
+                uint32_t b0 = 0;
+#pragma unroll
+                for (int i = 1; i < 4; i++) if (i == cls) b0 = st.mi.bound[i];
+                o_pos = (uint32_t)best - b0;
+                o_mm = (int8_t)((best >> 32) & 0xFF);
+                open = false;
+            }
+        }
+        if (valid) {
+            int32_t ref = -1, off = -1;
+            if (o_pass >= 0) resolve_one(tb, o_pass, o_pos, ref, off);
+            res_pass[idx] = o_pass; res_pos[idx] = o_pos; res_mm[idx] = o_mm;
+            res_ref[idx] = ref; res_off[idx] = off;
+        }
+    }
+}

@@ -1,0 +1,416 @@
+// kernels_collapse.hpp -- part of mirge_kernels.hpp: collapse kernels (general hash path, partitioned key path, heads / scan / scatter).
+#pragma once
+// ------------------------------------------------------------------------------------------
+// collapse (digest.py:141-163): open-addressing hash table of representative read indices.
+//   insert : slot claimed by atomicCAS on rep[]; a later equal read finds the slot by comparing
+//            its words with the representative's (the raw arrays are read-only during the kernel)
+//            and adds 1 to cnt[slot][sample]; firstj[slot] = min index (first appearance).
+//   heads  : read j is the head of its group iff firstj[slot_of[j]] == j; block sums of heads.
+//   scatter: exclusive scan of heads = rank in order of first appearance; heads copy their read
+//            and their slot's count row to the output.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ bool same_read(const GroupView<W>& g, uint32_t a, const MirgeRead<W>& r) {
+    if (g.len[a] != (uint8_t)r.len) return false;
+    bool eq = true;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        eq &= g.seq[(size_t)w * g.n + a] == r.w[w];
+        if (g.nmask) eq &= g.nmask[(size_t)w * g.n + a] == r.nm[w];
+    }
+    return eq;
+}
+
+template <int W>
+__global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, uint32_t* __restrict__ firstj,
+                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of,
+                                  uint32_t mask, const int32_t* __restrict__ sample_ids,
+                                  const uint32_t* __restrict__ orig, uint32_t base, int32_t S) {
+    __shared__ unsigned long long c_key[MIRGE_CELL_CACHE];
+    __shared__ uint32_t c_min[MIRGE_CELL_CACHE];
+    __shared__ uint32_t c_cnt[MIRGE_CELL_CACHE];
+    for (uint32_t i = threadIdx.x; i < MIRGE_CELL_CACHE; i += blockDim.x) { c_key[i] = 0ull; c_min[i] = 0xFFFFFFFFu; c_cnt[i] = 0; }
+    __syncthreads();
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g.n; j += gridDim.x * blockDim.x) {
+        MirgeRead<W> r;
+        load_read<W>(g, j, r);
+        uint64_t h = mirge_mix64(r.w[0] ^ ((uint64_t)r.len << 56));
+#pragma unroll
+        for (int w = 1; w < W; w++) h = mirge_mix64(h ^ r.w[w]);
+#pragma unroll
+        for (int w = 0; w < W; w++) h ^= mirge_mix64(r.nm[w] + 0x9e3779b97f4a7c15ull * (w + 1));
+        uint32_t s = (uint32_t)(h >> 20) & mask;
+        while (true) {
+            uint32_t cur = rep[s];
+            if (cur == MIRGE_EMPTY) cur = atomicCAS(&rep[s], MIRGE_EMPTY, j);
+            if (cur == MIRGE_EMPTY || cur == j || same_read<W>(g, cur, r)) break;
+            s = (s + 1) & mask;
+        }
+        slot_of[j] = s;
+        const int32_t sid = sample_ids ? sample_ids[orig ? orig[j] : base + j] : 0;
+        // The slot now identifies the read's sequence.  Its (min index, count) update goes through a
+        // workgroup cache in LDS keyed by the cell (slot, sample): a hot sequence -- adapter dimers
+        // are millions of identical long reads -- then costs this workgroup one pair of global
+        // atomics instead of one pair per copy (same-address device atomics run at ~90 per us).
+        const unsigned long long cell = (unsigned long long)s * (unsigned)S + (unsigned)sid + 1ull;  // 0 = empty
+        uint32_t cs = (uint32_t)(mirge_mix64(cell) >> 11) & (MIRGE_CELL_CACHE - 1);
+        bool cached = false;
+        for (int t = 0; t < 4; t++) {
+            unsigned long long cur = c_key[cs];
+            if (cur == 0ull) cur = atomicCAS(&c_key[cs], 0ull, cell);
+            if (cur == 0ull || cur == cell) {
+                atomicMin(&c_min[cs], j);
+                atomicAdd(&c_cnt[cs], 1u);
+                cached = true;
+                break;
+            }
+            cs = (cs + 1) & (MIRGE_CELL_CACHE - 1);
+        }
+        if (!cached) {
+            atomicMin(&firstj[s], j);
+            atomicAdd(&cnt[(size_t)s * S + sid], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < MIRGE_CELL_CACHE; i += blockDim.x) {
+        const unsigned long long cell = c_key[i];
+        if (cell == 0ull) continue;
+        const unsigned long long lin = cell - 1ull;
+        atomicMin(&firstj[lin / (unsigned)S], c_min[i]);
+        atomicAdd(&cnt[lin], c_cnt[i]);
+    }
+}
+
+// Fast form for the <=31-nt group without ambiguous calls and one sample (the bulk of any run): the
+// whole identity of a read -- its bits plus a length sentinel bit at 2*len -- fits one u64, so the
+// table holds the key itself: a duplicate is recognised from the slot (no representative read to
+// fetch), and key, first index and count share one 16-byte slot = one 64-byte sector per read
+// instead of six.  first is kept as ~j under atomicMax so that a zero-filled table is "empty".
+struct KeySlot {
+    unsigned long long key;  // 0 = empty
+    uint32_t first_inv;      // 0xFFFFFFFF - (smallest read index)
+    uint32_t cnt;
+};
+
+__global__ void k_collapse_insert_key(GroupView<1> g, KeySlot* __restrict__ slots, uint32_t* __restrict__ slot_of,
+                                      uint32_t mask) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g.n; j += gridDim.x * blockDim.x) {
+        const unsigned long long key = g.seq[j] | (1ull << (2 * g.len[j]));
+        uint32_t s = (uint32_t)(mirge_mix64(key) >> 20) & mask;
+        uint32_t seen_first = 0;
+        while (true) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&slots[s]);  // key, first_inv, cnt in one load
+            unsigned long long cur = ((unsigned long long)v.y << 32) | v.x;
+            seen_first = v.z;
+            if (cur == 0ull) { cur = atomicCAS(&slots[s].key, 0ull, key); seen_first = 0; }
+            if (cur == 0ull || cur == key) break;
+            s = (s + 1) & mask;
+        }
+        slot_of[j] = s;
+        // first_inv only grows, so a (possibly stale) plain read that is already >= ours proves the
+        // atomic would change nothing: most duplicates skip it (scattered atomics run at ~20 G/s
+        // chip-wide and are what bounds this kernel)
+        if (0xFFFFFFFFu - j > seen_first) atomicMax(&slots[s].first_inv, 0xFFFFFFFFu - j);
+        atomicAdd(&slots[s].cnt, 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Partitioned collapse for the key path (<=31 nt, no N, one sample).  Scattered device-scope atomics
+// run at ~20 G/s chip-wide, which is what bounds k_collapse_insert_key (2.4 atomics per read).  Here
+// equal keys are first brought together: reads are partitioned by the top bits of their hash into
+// buckets of ~1-2 k reads (histogram per workgroup -> column prefix -> scatter, no global atomics),
+// then ONE workgroup de-duplicates a bucket entirely in LDS (ds_cmpst / ds_min / ds_add) and emits the
+// bucket's distinct reads with their counts.
+//   k_part_agg    : per workgroup chunk: LDS cache merges equal reads -> records {key, min j, count};
+//                   hist[g][b] = records of chunk g that fall into bucket b
+//   k_part_prefix : off[g][b]   = sum over g' < g of hist[g'][b];  total[b] = column sum
+//   (k_scan_blocksums over total[] -> bucket_start[])
+//   k_part_scatter: part[bucket_start[b] + off[g][b] + local cursor] = record (16 B)
+//   k_part_dedup  : per bucket, LDS table (key -> min j, count); the bucket's distinct reads are written
+//                   to the output at a range reserved with one global atomicAdd per workgroup (so the order
+//                   of the unique reads of this path is unspecified; first[] carries the first raw index)
+// ------------------------------------------------------------------------------------------
+#define MIRGE_PART_CAP 4096  // largest LDS table per bucket (16 B per slot = 64 KiB)
+
+__device__ __forceinline__ unsigned long long read_key64(const GroupView<1>& g, uint32_t j) {
+    return g.seq[j] | (1ull << (2 * g.len[j]));
+}
+
+// k_part_agg: a workgroup walks its chunk of reads through a small LDS cache (key -> min index,
+// count) before anything is partitioned.  Real small-RNA samples are extremely skewed (one miRNA can be
+// a third of all reads): without this the hot key's bucket holds millions of records for ONE workgroup
+// and every LDS atomic on it is a 64-way conflict (measured on a Zipf sample: 10.9 ms per step against
+// 2.8 ms on unskewed reads).  With it a key contributes at most one record per workgroup.  The cache is
+// best effort: a read that finds no slot within 4 probes is emitted as a record of count 1.
+// Output: recs[blockIdx * chunk ...] (compacted, nrec[blockIdx] of them) and hist[blockIdx][bucket].
+// One workgroup per CU (the LDS cache + histogram take most of a CU's LDS), so the workgroup itself must bring
+// the waves that hide its load and LDS latencies: 1024 threads = 16 waves per CU (256 threads: 0.26 ms, 2x slower)
+#ifndef MIRGE_PART_THREADS
+#define MIRGE_PART_THREADS 1024
+#endif
+__global__ void __launch_bounds__(MIRGE_PART_THREADS)
+k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uint32_t chunk, uint32_t bshift, uint32_t B,
+           uint32_t CS, uint4* __restrict__ recs, uint32_t* __restrict__ nrec, uint32_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_a[];  // [CS] keys | [CS] minj | [CS] cnt | [B] hist | cursor
+    uint32_t* c_min = reinterpret_cast<uint32_t*>(lds_a + CS);
+    uint32_t* c_cnt = c_min + CS;
+    uint32_t* lds_h = c_cnt + CS;
+    uint32_t& cursor = lds_h[B];
+    for (uint32_t i = threadIdx.x; i < CS; i += blockDim.x) { lds_a[i] = 0ull; c_min[i] = 0xFFFFFFFFu; c_cnt[i] = 0; }
+    for (uint32_t b = threadIdx.x; b <= B; b += blockDim.x) lds_h[b] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, g.n);
+    uint4* out = recs + (size_t)blockIdx.x * chunk;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t j0 = lo; j0 < hi; j0 += blockDim.x) {
+        const uint32_t j = j0 + threadIdx.x;
+        bool direct = false;
+        unsigned long long key = 0ull;
+        uint64_t h = 0;
+        uint32_t jr = 0;  // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
+                          // instead of gathered per unique read at the end)
+        if (j < hi) {
+            key = read_key64(g, j);
+            jr = orig ? orig[j] : base + j;
+            h = mirge_mix64(key);
+            uint32_t s = (uint32_t)(h >> 9) & (CS - 1);
+            direct = true;
+            for (int t = 0; t < 4; t++) {
+                unsigned long long cur = lds_a[s];
+                if (cur == 0ull) cur = atomicCAS(&lds_a[s], 0ull, key);
+                if (cur == 0ull || cur == key) {
+                    atomicMin(&c_min[s], jr);
+                    atomicAdd(&c_cnt[s], 1u);
+                    direct = false;
+                    break;
+                }
+                s = (s + 1) & (CS - 1);
+            }
+        }
+        const unsigned long long bal = __ballot(direct);  // cache full around this key: emit the read itself
+        if (bal) {
+            uint32_t wb = 0;
+            if (lane == 0) wb = atomicAdd(&cursor, (uint32_t)__popcll(bal));
+            wb = __shfl(wb, 0, 64);
+            if (direct) {
+                out[wb + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), jr, 1u);
+                atomicAdd(&lds_h[(uint32_t)(h >> bshift)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < CS; i0 += blockDim.x) {  // flush the cache
+        const uint32_t i = i0 + threadIdx.x;
+        const unsigned long long key = i < CS ? lds_a[i] : 0ull;
+        const bool has = key != 0ull;
+        const unsigned long long bal = __ballot(has);
+        if (bal) {
+            uint32_t wb = 0;
+            if (lane == 0) wb = atomicAdd(&cursor, (uint32_t)__popcll(bal));
+            wb = __shfl(wb, 0, 64);
+            if (has) {
+                out[wb + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), c_min[i], c_cnt[i]);
+                atomicAdd(&lds_h[(uint32_t)(mirge_mix64(key) >> bshift)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[(size_t)blockIdx.x * B + b] = lds_h[b];
+    if (threadIdx.x == 0) nrec[blockIdx.x] = cursor;
+}
+
+__global__ void k_part_prefix(const uint32_t* __restrict__ hist, uint32_t G, uint32_t B, uint32_t* __restrict__ off,
+                              uint32_t* __restrict__ total) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t run = 0;
+#pragma unroll 8
+    for (uint32_t gq = 0; gq < G; gq++) {
+        const uint32_t v = hist[(size_t)gq * B + b];
+        off[(size_t)gq * B + b] = run;
+        run += v;
+    }
+    total[b] = run;
+}
+
+__global__ void __launch_bounds__(MIRGE_PART_THREADS)
+k_part_scatter(const uint4* __restrict__ recs, const uint32_t* __restrict__ nrec, uint32_t chunk,
+                               uint32_t bshift, uint32_t B, const uint32_t* __restrict__ off,
+                               const uint32_t* __restrict__ bucket_start, uint4* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_c[];
+    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lds_c[b] = bucket_start[b] + off[(size_t)blockIdx.x * B + b];
+    __syncthreads();
+    const uint4* in = recs + (size_t)blockIdx.x * chunk;
+    const uint32_t n = nrec[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint4 rec = in[i];
+        const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
+        const uint32_t p = atomicAdd(&lds_c[(uint32_t)(mirge_mix64(key) >> bshift)], 1u);
+        part[p] = rec;  // {key, min index, count}: one 16-B store per record
+    }
+}
+
+// CAP = LDS table slots (16 B each): 2048 when the buckets hold <= 1024 records (4 workgroups per CU), else 4096
+// The table takes 32-64 KiB of LDS, so only 2-4 workgroups fit a CU: 1024-thread workgroups bring the waves.
+#define MIRGE_DEDUP_THREADS 1024
+template <int CAP>
+__global__ void __launch_bounds__(MIRGE_DEDUP_THREADS)
+k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket_start,
+             uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
+             uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst, uint32_t* __restrict__ cursor,
+             uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
+    uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + CAP);
+    uint32_t* lds_cnt = lds_min + CAP;
+    uint32_t* lds_x = lds_cnt + CAP;  // [0] distinct keys, [1] output base, [2..17] scan scratch, [32..32+128] lengths
+    uint32_t& n_distinct = lds_x[0];
+    for (uint32_t i = threadIdx.x; i < CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < 32 + MIRGE_MAX_READ_LEN + 1; i += blockDim.x) lds_x[i] = 0;
+    __syncthreads();
+    const uint32_t lo = bucket_start[blockIdx.x], hi = bucket_start[blockIdx.x + 1];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint4 rec = part[i];
+        const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
+        const uint32_t j = rec.z;
+        uint32_t s = (uint32_t)(mirge_mix64(key) >> 7) & (CAP - 1);
+        while (true) {
+            unsigned long long cur = lds_k[s];
+            if (cur == 0ull) {
+                cur = atomicCAS(&lds_k[s], 0ull, key);
+                if (cur == 0ull && atomicAdd(&n_distinct, 1u) >= CAP - 64) atomicOr(overflow, 1u);
+            }
+            if (cur == 0ull || cur == key) break;
+            if (*(volatile uint32_t*)&n_distinct >= CAP - 32) break;  // table full: flagged, results discarded
+            s = (s + 1) & (CAP - 1);
+        }
+        atomicMin(&lds_min[s], j);
+        atomicAdd(&lds_cnt[s], rec.w);  // a record stands for rec.w identical reads of one workgroup's chunk
+    }
+    __syncthreads();
+    // emit the bucket's distinct reads: one global cursor add per workgroup reserves their output range
+    constexpr int PER = CAP / MIRGE_DEDUP_THREADS;
+    const uint32_t s0 = threadIdx.x * PER;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) mine += lds_k[s0 + i] != 0ull;
+    uint32_t total;
+    uint32_t rank = block_excl_scan<MIRGE_DEDUP_THREADS / 64>(mine, total, lds_x + 2);
+    if (threadIdx.x == 0) lds_x[1] = total ? atomicAdd(cursor, total) : 0u;
+    __syncthreads();
+    rank += lds_x[1];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const unsigned long long key = lds_k[s0 + i];
+        if (key == 0ull) continue;
+        const int L = (63 - __clzll((long long)key)) >> 1;  // the sentinel bit sits at 2*len
+        useq[rank] = key ^ (1ull << (2 * L));
+        ulen[rank] = (uint8_t)L;
+        ucnt[rank] = lds_cnt[s0 + i];
+        ufirst[rank] = lds_min[s0 + i];
+        atomicAdd(&lds_x[32 + L], 1u);
+        rank++;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+        if (lds_x[32 + i]) atomicAdd(&hist[i], lds_x[32 + i]);
+}
+
+// heads: read j is the head of its group iff it is the group's smallest index.  `first` is addressed
+// as first[slot * stride] (inv: stored as 0xFFFFFFFF - index).  Writes flag[j] and per-block sums.
+#define MIRGE_SCAN_ITEMS 8  // per thread -> 2048 per block
+__global__ void k_heads_blocksum(const uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ first,
+                                 uint32_t stride, uint32_t inv, uint32_t n, const uint8_t* __restrict__ len,
+                                 uint8_t* __restrict__ flag, uint32_t* __restrict__ blocksum,
+                                 uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t h[MIRGE_MAX_READ_LEN + 1];  // lengths of the heads = lengths of the unique reads
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * MIRGE_SCAN_ITEMS) + threadIdx.x * MIRGE_SCAN_ITEMS;
+    uint32_t c = 0;
+    uint8_t fl[MIRGE_SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
+        const uint32_t j = b0 + i;
+        fl[i] = 0;
+        if (j < n) {
+            const uint32_t f = first[(size_t)slot_of[j] * stride];
+            fl[i] = (inv ? 0xFFFFFFFFu - f : f) == j;
+            if (fl[i]) {
+                c++;
+                const uint32_t L = len[j];
+                atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
+            }
+        }
+    }
+    if (b0 + MIRGE_SCAN_ITEMS <= n) {
+        uint64_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) packed |= (uint64_t)fl[i] << (8 * i);
+        *reinterpret_cast<uint64_t*>(flag + b0) = packed;
+    } else {
+#pragma unroll
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) if (b0 + i < n) flag[b0 + i] = fl[i];
+    }
+    uint32_t total;
+    block_excl_scan(c, total, lds4);  // two barriers: the LDS histogram is complete after it
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// single block: exclusive scan of blocksum[0..nb) in place, total to *out_total
+__global__ void k_scan_blocksums(uint32_t* __restrict__ blocksum, uint32_t nb, uint32_t* __restrict__ out_total) {
+    __shared__ uint32_t lds4[4];
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < nb; b += MIRGE_BLOCK) {
+        uint32_t i = b + threadIdx.x;
+        uint32_t v = i < nb ? blocksum[i] : 0u;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(v, total, lds4);
+        if (i < nb) blocksum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *out_total = carry;
+}
+
+template <int W>
+__global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ slot_of,
+                                   const uint8_t* __restrict__ flag, const uint32_t* __restrict__ cnt,
+                                   uint32_t cnt_stride, const uint32_t* __restrict__ blockoff,
+                                   const uint32_t* __restrict__ n_uniq_ptr, const uint32_t* __restrict__ orig,
+                                   uint32_t base, int32_t S, uint64_t* __restrict__ useq,
+                                   uint8_t* __restrict__ ulen, uint64_t* __restrict__ unmask,
+                                   uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst) {
+    __shared__ uint32_t lds4[4];
+    const uint32_t U = *n_uniq_ptr;
+    const uint32_t b0 = blockIdx.x * (MIRGE_BLOCK * MIRGE_SCAN_ITEMS) + threadIdx.x * MIRGE_SCAN_ITEMS;
+    uint32_t heads = 0, c = 0;
+    if (b0 + MIRGE_SCAN_ITEMS <= g.n) {
+        const uint64_t packed = *reinterpret_cast<const uint64_t*>(flag + b0);
+#pragma unroll
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) if ((packed >> (8 * i)) & 1ull) { heads |= 1u << i; c++; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) if (b0 + i < g.n && flag[b0 + i]) { heads |= 1u << i; c++; }
+    }
+    uint32_t total;
+    uint32_t rank = blockoff[blockIdx.x] + block_excl_scan(c, total, lds4);
+#pragma unroll
+    for (int i = 0; i < MIRGE_SCAN_ITEMS; i++) {
+        if (heads & (1u << i)) {
+            const uint32_t j = b0 + i;
+            const uint32_t s = slot_of ? slot_of[j] : j;  // partitioned path: counts are stored per head read
+#pragma unroll
+            for (int w = 0; w < W; w++) {
+                useq[(size_t)w * U + rank] = g.seq[(size_t)w * g.n + j];
+                if (unmask) unmask[(size_t)w * U + rank] = g.nmask ? g.nmask[(size_t)w * g.n + j] : 0ull;
+            }
+            ulen[rank] = g.len[j];
+            for (int32_t q = 0; q < S; q++) ucnt[(size_t)rank * S + q] = cnt[(size_t)s * cnt_stride + q];
+            ufirst[rank] = orig ? orig[j] : base + j;
+            rank++;
+        }
+    }
+}

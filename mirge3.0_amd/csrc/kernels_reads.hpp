@@ -1,0 +1,260 @@
+// kernels_reads.hpp -- part of mirge_kernels.hpp: pack / unpack, probe-table construction, block scan, text parsing.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// k_pack: ASCII -> 2-bit.  One thread per read; the read's bytes are contiguous in `ascii`.
+// flags[0] |= 1 if any N was seen, flags[1] |= 1 if a byte outside ACGTN (any case) was seen.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ starts, const int64_t* __restrict__ ends,
+                       const uint32_t* __restrict__ idx, uint32_t n, uint64_t* __restrict__ seq,
+                       uint8_t* __restrict__ len, uint64_t* __restrict__ nmask,
+                       uint32_t* __restrict__ flags) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint32_t src = idx[j];
+        const int64_t b = starts[src];
+        const int L = (int)(ends[src] - b);  // contiguous reads: ends = starts + 1
+        uint64_t w[W], nm[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) { w[i] = 0; nm[i] = 0; }
+        uint32_t sawN = 0, bad = 0;
+        for (int p = 0; p < L; p++) {
+            uint8_t c = ascii[b + p] & 0xDF;  // upper-case
+            uint64_t code = 0, isn = 0;
+            switch (c) {
+                case 'A': code = 0; break;
+                case 'C': code = 1; break;
+                case 'G': code = 2; break;
+                case 'T': code = 3; break;
+                case 'U': code = 3; break;
+                case 'N': isn = 1; break;
+                default: isn = 1; bad = 1; break;
+            }
+            sawN |= (uint32_t)isn;
+#pragma unroll
+            for (int i = 0; i < W; i++)
+                if ((p >> 5) == i) { w[i] |= code << (2 * (p & 31)); nm[i] |= isn << (2 * (p & 31)); }
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            seq[(size_t)i * n + j] = w[i];
+            nmask[(size_t)i * n + j] = nm[i];
+        }
+        len[j] = (uint8_t)L;
+        if (sawN) atomicOr(&flags[0], 1u);
+        if (bad) atomicOr(&flags[1], 1u);
+    }
+}
+
+// dst[i] = (src ? src[i] : src_base + i) + add : handle-order indices of a read set appended to another
+__global__ void k_index_shift(const uint32_t* __restrict__ src, uint32_t src_base, uint32_t n, uint32_t add,
+                              uint32_t* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        dst[i] = (src ? src[i] : src_base + i) + add;
+}
+
+template <int W>
+__global__ void k_unpack(GroupView<W> g, const int64_t* __restrict__ out_off, uint32_t base,
+                         const uint32_t* __restrict__ orig, uint8_t* __restrict__ ascii_out) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g.n; j += gridDim.x * blockDim.x) {
+        MirgeRead<W> r;
+        load_read<W>(g, j, r);
+        const uint32_t dst = orig ? orig[j] : base + j;
+        uint8_t* o = ascii_out + out_off[dst];
+        for (int p = 0; p < r.len; p++) {
+            uint32_t code = (uint32_t)((r.w[p >> 5] >> (2 * (p & 31))) & 3ull);
+            uint32_t isn = (uint32_t)((r.nm[p >> 5] >> (2 * (p & 31))) & 1ull);
+            o[p] = isn ? 'N' : "ACGT"[code];
+        }
+    }
+}
+
+// lengths scattered to handle order (for unpack offsets / histograms)
+__global__ void k_scatter_len(const uint8_t* __restrict__ len, uint32_t n, uint32_t base,
+                              const uint32_t* __restrict__ orig, int32_t* __restrict__ out) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        out[orig ? orig[j] : base + j] = len[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// Probe tables are built where they live.  For shape (k1, gap, k2): every position p whose span
+// [p, p+k1+gap+k2) holds no invalid base, keyed by block A | block B << 2*k1 (mirge_hostlib_table is the host
+// twin, tests/hostsim).  Counting sort with the count array shifted by two: count into A[key+2], inclusive
+// scan, then slot = atomicAdd(&A[key+1], 1) leaves A[0..nb] = the CSR bucket bounds.  Positions inside a bucket
+// come out in arbitrary order; every consumer takes a minimum over the whole bucket.
+// Human mRNA, k = 15 (130 M positions, 2^30 buckets): ~30 ms on the GPU against ~6 s on the host.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t text_kmer_dev(const uint64_t* __restrict__ T, uint64_t g, int k) {
+    const uint64_t q = g >> 5;
+    const int s = (int)(g & 31) * 2;
+    uint64_t lo = T[q] >> s;
+    if (s) lo |= T[q + 1] << (64 - s);
+    return lo & mirge_lowmask2(k);
+}
+
+template <bool FILL>
+__global__ void k_table_pass(const uint64_t* __restrict__ T, const uint64_t* __restrict__ inv, uint64_t total, int k1, int gap,
+                             int k2, uint32_t* __restrict__ A, uint32_t* __restrict__ pos) {
+    const int span = k1 + (k2 > 0 ? gap + k2 : 0);
+    if (total < (uint64_t)span) return;
+    const uint64_t n = total - (uint64_t)span + 1;
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
+        if (mirge_window_invalid(inv, p, span)) continue;
+        uint64_t key = text_kmer_dev(T, p, k1);
+        if (k2 > 0) key |= text_kmer_dev(T, p + (uint64_t)(k1 + gap), k2) << (2 * k1);
+        if (FILL) pos[atomicAdd(&A[key + 1], 1u)] = (uint32_t)p;
+        else atomicAdd(&A[key + 2], 1u);
+    }
+}
+
+__global__ void k_table_bits(const uint32_t* __restrict__ bucket, uint64_t nb, uint32_t* __restrict__ bits) {
+    const uint64_t nw = (nb + 31) / 32;
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < nw; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t m = 0;
+        for (int b = 0; b < 32; b++) {
+            const uint64_t k = w * 32 + b;
+            if (k < nb && bucket[k + 1] > bucket[k]) m |= 1u << b;
+        }
+        bits[w] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves of 64)
+// ------------------------------------------------------------------------------------------
+template <int NW = MIRGE_BLOCK / 64>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total, uint32_t* lds4) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) lds4[wv] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        uint32_t s = lds4[i];
+        if (i < wv) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Sequence text parsed on the device (digest.py:320-375 reads FASTQ records with dnaio on the host): the file's
+// bytes go to HBM as they are.  Line li is ended by newline number li; the sequence lines are those with
+// li % period == sphase (FASTQ 4/1, single-line FASTA 2/1, one sequence per line 1/0).
+//   k_nl_count  : newlines per 4 KiB tile                       (then an exclusive scan over the tiles)
+//   k_nl_mark   : start[] / end[] of every sequence line
+//   k_seq_class : per record: strip '\r', length filter (--minimum-length), width class x has-an-N, byte check;
+//                 per-block class counts                          (then scans -> stable positions per group)
+//   k_seq_place : record -> slot of its group's index list, in input order; kept rank = index among kept reads
+// The groups are then packed by k_pack straight from the text.
+// ------------------------------------------------------------------------------------------
+#define MIRGE_PARSE_TILE (MIRGE_BLOCK * 16)
+#define MIRGE_CLS_DROP 6  // shorter than --minimum-length (or longer than the engine's limit: flagged)
+
+__device__ __forceinline__ uint32_t tile_newlines(const uint8_t* __restrict__ text, uint64_t n, uint64_t b0, uint32_t& mask) {
+    mask = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) if (b0 + i < n && text[b0 + i] == 10) mask |= 1u << i;
+    return (uint32_t)__popc(mask);
+}
+
+__global__ void k_nl_count(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ tile_cnt) {
+    __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
+    uint32_t mask;
+    const uint32_t c = tile_newlines(text, n, (uint64_t)blockIdx.x * MIRGE_PARSE_TILE + threadIdx.x * 16ull, mask);
+    uint32_t total;
+    (void)block_excl_scan(c, total, lds4);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+__global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_off, int period,
+                          int sphase, int64_t* __restrict__ start, int64_t* __restrict__ end, uint64_t n_seq) {
+    __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * MIRGE_PARSE_TILE + threadIdx.x * 16ull;
+    uint32_t mask;
+    const uint32_t c = tile_newlines(text, n, b0, mask);
+    uint32_t total;
+    uint64_t li = (uint64_t)tile_off[blockIdx.x] + block_excl_scan(c, total, lds4);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sphase == 0 && n_seq) start[0] = 0;
+    while (mask) {
+        const int i = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const uint64_t pos = b0 + i;
+        if ((int)(li % (uint64_t)period) == sphase && li / period < n_seq) end[li / period] = (int64_t)pos;
+        if ((int)((li + 1) % (uint64_t)period) == sphase && (li + 1) / period < n_seq) start[(li + 1) / period] = (int64_t)pos + 1;
+        li++;
+    }
+}
+
+// flags: [0] reads with N seen per group ... kept by k_pack; here [0] = byte outside ACGTUN seen, [1] = reads longer
+// than the limit, [2] = longest such read
+__global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __restrict__ start, int64_t* __restrict__ end,
+                            uint32_t n_seq, int32_t min_len, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cls,
+                            uint32_t* __restrict__ blk_keep, uint32_t nblk, uint32_t* __restrict__ hist, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_cnt[8];
+    __shared__ uint32_t s_hist[MIRGE_MAX_READ_LEN + 1];
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 7;  // no record
+    if (r < n_seq) {
+        const int64_t b = start[r];
+        int64_t e = end[r];
+        if (e > b && text[e - 1] == 13) { e--; end[r] = e; }
+        const int64_t L = e - b;
+        if (L > MIRGE_MAX_READ_LEN) {
+            atomicOr(&flags[1], 1u);
+            atomicMax(&flags[2], (uint32_t)(L > 0xFFFFFFF ? 0xFFFFFFF : L));
+            c = MIRGE_CLS_DROP;
+        } else if (L < (int64_t)min_len) {
+            c = MIRGE_CLS_DROP;
+        } else {
+            uint32_t amb = 0, bad = 0;
+            for (int p = 0; p < (int)L; p++) {
+                const uint8_t ch = text[b + p] & 0xDF;
+                const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'U';
+                amb |= !acgt;
+                bad |= !acgt && ch != 'N';
+            }
+            if (bad) atomicOr(&flags[0], 1u);
+            c = (L <= 31 ? 0 : (L <= 64 ? 1 : 2)) + (amb ? 3 : 0);
+            atomicAdd(&s_hist[L], 1u);
+        }
+        cls[r] = (uint8_t)c;
+    }
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        const unsigned long long bal = __ballot(c == q);
+        if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&s_cnt[q], (uint32_t)__popcll(bal));
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) blk_cls[(size_t)threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x == 6) blk_keep[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] + s_cnt[4] + s_cnt[5];
+    for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
+__global__ void k_seq_place(const uint8_t* __restrict__ cls, uint32_t n_seq, const uint32_t* __restrict__ cls_off,
+                            const uint32_t* __restrict__ keep_off, uint32_t nblk, uint32_t* __restrict__ src_all,
+                            uint32_t* __restrict__ orig_all) {
+    __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = r < n_seq ? (int)cls[r] : 7;
+    uint32_t total;
+    const uint32_t kr = keep_off[blockIdx.x] + block_excl_scan(c < MIRGE_CLS_DROP ? 1u : 0u, total, lds4);
+    uint32_t slot = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const uint32_t rk = block_excl_scan(c == q ? 1u : 0u, total, lds4);
+        if (c == q) slot = cls_off[(size_t)q * nblk + blockIdx.x] + rk;
+    }
+    if (c < MIRGE_CLS_DROP) { src_all[slot] = r; orig_all[slot] = kr; }
+}

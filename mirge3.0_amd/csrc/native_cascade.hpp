@@ -1,0 +1,401 @@
+// native_cascade.hpp -- part of mirge_native.hip (one translation unit): cascade: merged steps, plan tables, staged and fused launches.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// cascade
+// ------------------------------------------------------------------------------------------
+struct ResGroup {
+    uint32_t n = 0;
+    int8_t* pass = nullptr;
+    uint32_t* pos = nullptr;
+    int8_t* mm = nullptr;
+    int32_t* ref = nullptr;
+    int32_t* off = nullptr;
+};
+struct mirge_result {
+    mirge_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int32_t n_pass = 0;
+    ResGroup g[MIRGE_NGROUPS];
+    const mirge_reads* reads = nullptr;  // borrowed: orig/base mapping (must outlive the fetch)
+};
+
+extern "C" void mirge_result_destroy(mirge_result* r) {
+    if (!r) return;
+    for (auto& g : r->g) {
+        r->ctx->release(g.pass); r->ctx->release(g.pos); r->ctx->release(g.mm);
+        r->ctx->release(g.ref); r->ctx->release(g.off);
+    }
+    delete r;
+}
+
+// One library = the members' references in order (same bases, same separators), so that a position in
+// the merged text minus the member's start is the position in the member's own text.
+static int merged_library(mirge_ctx* c, const mirge_lib* const* members, int n, mirge_lib** out) {
+    std::vector<uint64_t> uids;
+    for (int i = 0; i < n; i++) uids.push_back(members[i]->uid);
+    for (auto& m : c->merged)
+        if (m.uids == uids) { *out = m.lib; return 0; }
+    std::string seq;
+    std::vector<int64_t> off{0};
+    for (int i = 0; i < n; i++) {
+        const MirgeHostLib& h = members[i]->h;
+        for (int64_t r = 0; r < h.n_refs; r++) {
+            for (uint64_t g = h.ref_start[(size_t)r]; g + 1 < h.ref_start[(size_t)r + 1]; g++) {
+                const bool bad = (h.inv[g >> 6] >> (g & 63)) & 1ull;
+                seq.push_back(bad ? 'N' : "ACGT"[(h.T[g >> 5] >> (2 * (g & 31))) & 3ull]);
+            }
+            off.push_back((int64_t)seq.size());
+        }
+    }
+    mirge_lib* L = nullptr;
+    CHECK(mirge_lib_create(c, seq.data(), off.data(), (int64_t)off.size() - 1, &L));
+    c->merged.push_back(mirge_ctx::Merged{uids, L});
+    *out = L;
+    return 0;
+}
+
+// build every probe table pass `p` can ask for, given the read lengths present
+static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t* hist) {
+    MirgePolicy p;
+    std::memcpy(&p, &pol, sizeof(p));
+    std::vector<ShapeJob> wanted;
+    std::vector<bool> seen(MIRGE_SHAPE_SLOTS, false);
+    for (int L = 1; L <= MIRGE_MAX_READ_LEN; L++) {
+        if (!hist[L]) continue;
+        if (p.len_lt > 0 && !(L < p.len_lt)) continue;
+        if (p.len_gt > 0 && !(L > p.len_gt)) continue;
+        int lo = L, hi = L;
+        if (p.ttail) { lo = 1; hi = L - 3; }  // any head length once the T run is gone
+        for (int l0 = lo; l0 <= hi; l0++) {
+            const int l = l0 - p.trim5 - p.trim3;
+            if (l < 1 || l <= p.mm) continue;
+            const int np = mirge_probe_count(p, l, lib->kmax, lib->h.total);
+            for (int q = 0; q < np; q++) {
+                MirgeProbe pr;
+                mirge_probe_at(p, l, lib->kmax, lib->h.total, q, pr);
+                if (pr.k1 <= 0) continue;
+                const int sid = mirge_shape_id(pr.k1, pr.gap, pr.k2);
+                if (seen[sid]) continue;
+                seen[sid] = true;
+                wanted.emplace_back();
+                wanted.back().k1 = pr.k1; wanted.back().gap = pr.gap; wanted.back().k2 = pr.k2;
+            }
+        }
+    }
+    return lib_prepare_shapes(lib, wanted);
+}
+
+template <int W>
+static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const std::vector<PassStep>& steps,
+                         const mirge_policy* pol, const ResolveTable& rt, const char* gtag) {
+    out.n = rg.n;
+    if (!rg.n) return 0;
+    const uint32_t n = rg.n;
+    CHECK(dalloc(c, &out.pass, n));
+    CHECK(dalloc(c, &out.pos, n));
+    CHECK(dalloc(c, &out.mm, n));
+    CHECK(dalloc(c, &out.ref, n));
+    CHECK(dalloc(c, &out.off, n));
+    // every workgroup keeps its own survivor segment through all passes: no global cursor.  All workgroups
+    // must be resident at once: a grid of 8 per CU ran the workgroups that did not fit as a second round on an
+    // almost empty machine (average occupancy 47 %, SQ_WAVE_CYCLES; -20 % kernel time with the right grid).
+    // Measured on MI355X (tools/occ_sweep.sh, profiles/README.md): kernel time falls up to 6 workgroups per CU
+    // and jumps back by 30 % at 7 and beyond -- for the 69-VGPR build and for 57/63-VGPR builds alike, so the
+    // cliff is not the register file although hipOccupancyMaxActiveBlocksPerMultiprocessor reports 7.  The grid
+    // is therefore min(occupancy query, register bound, 6) per CU.  MIRGE_WG_PER_CU overrides (sweeps).
+    static int wg_per_cu[5] = {0, 0, 0, 0, 0};
+    if (!wg_per_cu[W]) {
+        int nb = 0;
+        hipFuncAttributes fa;
+        HIPOK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_pass<W, 15>), MIRGE_BLOCK, 0));
+        HIPOK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_pass<W, 15>)));
+        const int by_regs = 512 / std::max(16, (fa.numRegs + 15) / 16 * 16);  // waves per SIMD = 4-wave workgroups per CU
+        wg_per_cu[W] = std::max(1, std::min({nb, by_regs, 6}));
+        if (std::getenv("MIRGE_WG_PER_CU")) wg_per_cu[W] = std::max(1, std::atoi(std::getenv("MIRGE_WG_PER_CU")));
+        if (std::getenv("MIRGE_HOST_TIMING"))
+            std::fprintf(stderr, "[host] k_pass<%d>: %d VGPRs, occupancy query %d -> %d workgroups per CU\n", W, fa.numRegs, nb, wg_per_cu[W]);
+    }
+    const uint32_t grid = (uint32_t)std::min<size_t>((size_t)grid_for(c, n), (size_t)c->n_cu * wg_per_cu[W]);
+    uint32_t cap = (n + grid - 1) / grid;
+    cap = (cap + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
+    uint32_t *actA = nullptr, *actB = nullptr, *seg_n = nullptr;
+    CHECK(dalloc(c, &actA, (size_t)grid * cap));
+    CHECK(dalloc(c, &actB, (size_t)grid * cap));
+    CHECK(dalloc(c, &seg_n, (size_t)grid * (MIRGE_MAX_PASSES + 1)));
+    HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->cur));
+    HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->cur));
+    GroupView<W> v = view_of<W>(rg);
+    const uint32_t* act_in = nullptr;
+    uint32_t* act_out = actA;
+    int stage = 0;
+    char name[32];
+    std::vector<std::pair<int, int>> stage_of_pass;  // (profile record, stage) for unit accounting
+    for (const PassStep& st : steps) {
+        const int32_t p = st.p0;
+        MirgePolicy mp;
+        std::memcpy(&mp, &pol[p], sizeof(mp));
+        {
+            if (st.np > 1) std::snprintf(name, sizeof(name), "k_pass[%d-%d]%s", (int)p, (int)(p + st.np - 1), gtag);
+            else std::snprintf(name, sizeof(name), "k_pass[%d]%s", (int)p, gtag);
+            LaunchScope ls(c, name, 0.0);
+            if (ls.rec >= 0) stage_of_pass.emplace_back(ls.rec, stage);
+            const uint32_t* sn_in = seg_n + (size_t)grid * (stage > 0 ? stage - 1 : 0);
+            uint32_t* sn_out = seg_n + (size_t)grid * stage;
+#define MIRGE_LAUNCH_PASS(SLOT)                                                                                       \
+    hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, st.lib->view(), mp, st.mi, st.dplan, v, act_in, \
+                       sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm)
+            switch (p) {
+                case 0: MIRGE_LAUNCH_PASS(0); break;
+                case 1: MIRGE_LAUNCH_PASS(1); break;
+                case 2: MIRGE_LAUNCH_PASS(2); break;
+                case 3: MIRGE_LAUNCH_PASS(3); break;
+                case 4: MIRGE_LAUNCH_PASS(4); break;
+                case 5: MIRGE_LAUNCH_PASS(5); break;
+                case 6: MIRGE_LAUNCH_PASS(6); break;
+                case 7: MIRGE_LAUNCH_PASS(7); break;
+                case 8: MIRGE_LAUNCH_PASS(8); break;
+                case 9: MIRGE_LAUNCH_PASS(9); break;
+                default: MIRGE_LAUNCH_PASS(15); break;
+            }
+#undef MIRGE_LAUNCH_PASS
+        }
+        act_in = act_out;
+        act_out = (act_out == actA) ? actB : actA;
+        stage++;
+    }
+    {
+        std::snprintf(name, sizeof(name), "k_resolve%s", gtag);
+        LaunchScope ls(c, name, n);
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->cur, rt, out.pass, out.pos, n, out.ref, out.off);
+    }
+    if (c->profiling && stage > 0) {  // units of a pass = reads it was handed = survivors of the stage before
+        // copied now (stream-ordered), summed after the one synchronisation at the end of the call
+        const size_t words = (size_t)grid * stage;
+        if (c->prof_used + words <= MIRGE_PROF_PINNED_WORDS) {
+            uint32_t* dst = c->prof_pinned + c->prof_used;
+            HIPOK(hipMemcpyAsync(dst, seg_n, words * 4, hipMemcpyDeviceToHost, c->cur));
+            for (auto& sp : stage_of_pass) c->prof_pending.push_back(ProfUnits{sp.first, sp.second, grid, dst, (double)n});
+            c->prof_used += words;
+        }
+    }
+    c->defer(actA); c->defer(actB); c->defer(seg_n);
+    return 0;
+}
+
+// a small group's whole cascade as one launch (k_cascade_fused)
+template <int W>
+static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const FusedSteps* dsteps,
+                               const ResolveTable& rt, const char* gtag) {
+    out.n = rg.n;
+    if (!rg.n) return 0;
+    const uint32_t n = rg.n;
+    CHECK(dalloc(c, &out.pass, n));
+    CHECK(dalloc(c, &out.pos, n));
+    CHECK(dalloc(c, &out.mm, n));
+    CHECK(dalloc(c, &out.ref, n));
+    CHECK(dalloc(c, &out.off, n));
+    char name[32];
+    std::snprintf(name, sizeof(name), "k_cascade_fused%s", gtag);
+    LaunchScope ls(c, name, n);
+    const uint32_t grid = std::min<uint32_t>((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (uint32_t)c->n_cu * 8);
+    hipLaunchKernelGGL(k_cascade_fused<W>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
+                       out.pos, out.mm, out.ref, out.off);
+    return 0;
+}
+
+// steps (merged runs, probe tables, plan tables), resolve table and the fused kernel's device step list for
+// one (libraries, policies, read-length set) configuration
+static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass,
+                           const int32_t* hist, std::vector<PassStep>& steps, ResolveTable& rt, const FusedSteps** dsteps_out) {
+    for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.n_refs[p] = 0; }
+    steps.clear();
+    for (int32_t p = 0; p < n_pass; p++) {
+        if (!libs[p]) continue;
+        if (libs[p]->ctx->device != c->device) return fail(-1, "library lives on another device");
+        if (pol[p].mm < 0 || pol[p].mm > 3 || pol[p].trim5 < 0 || pol[p].trim5 > 31 || pol[p].trim3 < 0)
+            return fail(-1, "unsupported policy");
+        rt.ref_start[p] = libs[p]->dref_start;
+        rt.n_refs[p] = (uint32_t)libs[p]->n_refs;
+    }
+    for (int32_t p = 0; p < n_pass;) {
+        if (!libs[p]) { p++; continue; }
+        // a run of consecutive passes with one and the same policy over distinct libraries becomes ONE
+        // launch over their concatenation (k_pass ranks candidates by member library first, so the
+        // cascade's "first library with a hit wins" is unchanged): human set -> passes 4,5,6
+        int np = 1;
+        uint64_t total = libs[p]->h.total;
+        static const bool merge_on = !(std::getenv("MIRGE_MERGE_PASSES") && std::getenv("MIRGE_MERGE_PASSES")[0] == '0');
+        while (merge_on && np < 4 && p + np < n_pass && libs[p + np] && std::memcmp(&pol[p + np], &pol[p], sizeof(mirge_policy)) == 0 &&
+               total + libs[p + np]->h.total < 0xFFFFFFF0ull) {
+            bool distinct = true;
+            for (int q = 0; q < np; q++) distinct &= libs[p + q] != libs[p + np];
+            if (!distinct) break;
+            total += libs[p + np]->h.total;
+            np++;
+        }
+        PassStep st;
+        st.p0 = p; st.np = np;
+        st.mi.n = np;
+        for (int i = 0; i < 4; i++) st.mi.bound[i] = 0;
+        if (np == 1) st.lib = libs[p];
+        else {
+            mirge_lib* m = nullptr;
+            CHECK(merged_library(c, libs + p, np, &m));
+            st.lib = m;
+            uint64_t b = 0;
+            for (int i = 0; i < np; i++) { st.mi.bound[i] = (uint32_t)b; b += libs[p + i]->h.total; }
+        }
+        CHECK(prepare_tables(const_cast<mirge_lib*>(st.lib), pol[p], hist));
+        steps.push_back(st);
+        p += np;
+    }
+    // tabulated probe plans: built and uploaded once per (library, policy), then reused by every call
+    for (auto& st : steps) {
+        MirgePolicy mp;
+        std::memcpy(&mp, &pol[st.p0], sizeof(mp));
+        const MirgePlanTable* dp = nullptr;
+        for (auto& e : c->plans)
+            if (e.uid == st.lib->uid && std::memcmp(&e.pol, &mp, sizeof(mp)) == 0) { dp = e.dplan; break; }
+        if (!dp) {
+            auto h = std::make_unique<MirgePlanTable>();
+            mirge_plan_table_fill(mp, st.lib->kmax, st.lib->h.total, *h);
+            MirgePlanTable* d = nullptr;
+            HIPOK(hipMalloc((void**)&d, sizeof(MirgePlanTable)));
+            HIPOK(hipMemcpy(d, h.get(), sizeof(MirgePlanTable), hipMemcpyHostToDevice));
+            c->plans.push_back(mirge_ctx::PlanEntry{st.lib->uid, mp, d});
+            dp = d;
+        }
+        st.dplan = dp;
+    }
+    // the step list of the fused small-group kernel lives in device memory; uploaded when it changes
+    auto fs = std::make_unique<FusedSteps>();
+    std::memset(fs.get(), 0, sizeof(FusedSteps));
+    fs->n = (int32_t)steps.size();
+    for (size_t i = 0; i < steps.size(); i++) {
+        FusedStep& f = fs->s[i];
+        f.lib = steps[i].lib->view();
+        std::memcpy(&f.pol, &pol[steps[i].p0], sizeof(MirgePolicy));
+        f.mi = steps[i].mi;
+        f.plan = steps[i].dplan;
+        f.pass_id = steps[i].p0;
+    }
+    const FusedSteps* dsteps = nullptr;
+    for (auto& e : c->fused)
+        if (std::memcmp(e.host.get(), fs.get(), sizeof(FusedSteps)) == 0) { dsteps = e.dev; break; }
+    if (!dsteps) {
+        if (c->fused.size() >= 64) {  // callers cycling through libraries: start over
+            HIPOK(hipDeviceSynchronize());
+            for (auto& e : c->fused) (void)hipFree(e.dev);
+            c->fused.clear();
+        }
+        FusedSteps* d = nullptr;
+        HIPOK(hipMalloc((void**)&d, sizeof(FusedSteps)));
+        HIPOK(hipMemcpy(d, fs.get(), sizeof(FusedSteps), hipMemcpyHostToDevice));
+        c->fused.push_back(mirge_ctx::FusedEntry{std::move(fs), d});
+        dsteps = d;
+    }
+    *dsteps_out = dsteps;
+    return 0;
+}
+
+extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
+                                 const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
+    HostClock hc("cascade");
+    if (!c || !R || !libs || !pol || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
+        return fail(-1, "mirge_cascade_run: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    // read lengths present (host histogram from pack; a collapse result asks the device once)
+    int32_t hist[MIRGE_MAX_READ_LEN + 1];
+    if (R->hist_valid) std::memcpy(hist, R->len_hist, sizeof(hist));
+    else {
+        std::memset(hist, 0, sizeof(hist));
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+            const ReadGroup& g = R->g[gi];
+            if (!g.n) continue;
+            // conservative: every length the width group can hold is assumed present
+            int lo = kGroupW[gi] == 1 ? 1 : (kGroupW[gi] == 2 ? 32 : 65), hi = kGroupW[gi] == 1 ? 31 : (kGroupW[gi] == 2 ? 64 : 128);
+            for (int L = lo; L <= hi; L++) hist[L] = 1;
+        }
+    }
+    // Everything below up to the launches depends only on (libraries, policies, read lengths present): it is
+    // kept from the previous call and reused when those are unchanged (~45 us of host time per call otherwise,
+    // on the critical path between the collapse's synchronisation and the first pass)
+    std::string key;
+    key.append(reinterpret_cast<const char*>(&n_pass), sizeof(n_pass));
+    for (int32_t p = 0; p < n_pass; p++) {
+        const uint64_t uid = libs[p] ? libs[p]->uid : 0;
+        key.append(reinterpret_cast<const char*>(&uid), sizeof(uid));
+        key.append(reinterpret_cast<const char*>(&pol[p]), sizeof(mirge_policy));
+    }
+    for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) key.push_back(hist[L] ? 1 : 0);
+    if (c->casc_key != key) {
+        c->casc_key.clear();
+        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, c->casc_steps, c->casc_rt, &c->casc_dsteps));
+        c->casc_key = key;
+    }
+    const std::vector<PassStep>& steps = c->casc_steps;
+    const ResolveTable& rt = c->casc_rt;
+    const FusedSteps* dsteps = c->casc_dsteps;
+    hc.lap("plans+fused");
+    // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests)
+    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 20);
+    auto res = std::make_unique<mirge_result>();
+    res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
+    int rc = 0;
+    const int big = largest_group(R);
+    CHECK(stream_fork(c));
+    // enqueue order: the small groups first (one fused launch each, or the staged launches if a group is too
+    // large for that), the bulk group last: measured, its 2048-workgroup launches otherwise hold every CU and the
+    // small kernels squeeze in between them, stretching single passes of the bulk group by 30 %
+    int order[MIRGE_NGROUPS], no = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) if (gi != big) order[no++] = gi;
+    order[no++] = big;
+    for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
+        const int gi = order[k];
+        c->cur = gi == big ? c->stream : c->aux;
+        if (gi != big && R->g[gi].n <= fused_max) {
+            if (kGroupW[gi] == 1) rc = cascade_group_fused<1>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            else if (kGroupW[gi] == 2) rc = cascade_group_fused<2>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            else rc = cascade_group_fused<4>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            continue;
+        }
+        if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+        else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+    }
+    hc.lap("enqueue");
+    { int jr = stream_join(c); if (rc == 0) rc = jr; }
+    hc.lap("join");
+    if (rc) { mirge_result_destroy(res.release()); return rc; }
+    *out = res.release();
+    return 0;
+}
+
+template <typename T>
+static int fetch_field(mirge_ctx* c, const mirge_result* res, T* host_out, T* ResGroup::*field) {
+    if (!host_out || !res->n) return 0;
+    T* dfull = nullptr;
+    CHECK(dalloc(c, &dfull, (size_t)res->n));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ResGroup& g = res->g[gi];
+        const ReadGroup& rg = res->reads->g[gi];
+        if (!g.n) continue;
+        hipLaunchKernelGGL(k_scatter_out<T>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                           (const T*)(g.*field), g.n, rg.base, (const uint32_t*)rg.orig, dfull);
+    }
+    HIPOK(hipMemcpyAsync(host_out, dfull, (size_t)res->n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->release(dfull);
+    return 0;
+}
+
+extern "C" int mirge_result_fetch(mirge_ctx* c, const mirge_result* res, int8_t* pass_out, int32_t* ref_out,
+                                  int32_t* off_out, int8_t* mm_out) {
+    if (!c || !res) return fail(-1, "mirge_result_fetch: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    CHECK(fetch_field<int8_t>(c, res, pass_out, &ResGroup::pass));
+    CHECK(fetch_field<int32_t>(c, res, ref_out, &ResGroup::ref));
+    CHECK(fetch_field<int32_t>(c, res, off_out, &ResGroup::off));
+    CHECK(fetch_field<int8_t>(c, res, mm_out, &ResGroup::mm));
+    return 0;
+}

@@ -1,0 +1,307 @@
+// native_collapse.hpp -- part of mirge_native.hip (one translation unit): collapse: partitioned key path, general path, one host synchronisation.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// collapse
+// ------------------------------------------------------------------------------------------
+// Collapse runs in two phases so that the whole call synchronises with the host ONCE: phase A
+// (insert, head flags + block sums, scan) for every read group, one copy of {U per group, length
+// histogram of the uniques} to the host, then phase B (output allocation sized by U, scatter).
+struct CollapseTmp {
+    uint32_t *rep = nullptr, *firstj = nullptr, *cnt = nullptr, *slot_of = nullptr, *blocksum = nullptr;
+    KeySlot* slots = nullptr;
+    uint8_t* flag = nullptr;
+    const uint32_t* cnt_base = nullptr;
+    uint32_t cnt_stride = 1, nb = 0;
+    // partitioned key path
+    bool partitioned = false;
+    uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr, *nrec = nullptr;
+    uint4 *part = nullptr, *recs = nullptr;
+    uint32_t G = 0, chunk = 0, bshift = 0, B = 0, cap = MIRGE_PART_CAP;
+};
+// dmeta: [0..5] U of each group, [6] partition overflow flag, [8 .. 8+128] length histogram
+#define MIRGE_META_OVERFLOW 6
+#define MIRGE_META_HIST 8
+#define MIRGE_META_WORDS (MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1)
+
+static const char* group_tag(int gi) {
+    static const char* t[MIRGE_NGROUPS] = {".w1", ".w2", ".w4", ".w1n", ".w2n", ".w4n"};
+    return t[gi];
+}
+
+// partitioned key path after k_part_agg: bucket offsets, scatter, per-bucket de-duplication
+static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, uint32_t* dmeta) {
+    const uint32_t G = t.G, B = t.B;
+    {
+        LaunchScope ls(c, "k_part_prefix.w1", (double)G * B);
+        hipLaunchKernelGGL(k_part_prefix, dim3((B + 63) / 64), dim3(64), 0, c->cur, t.hist, G, B, t.off, t.btotal);
+    }
+    {
+        LaunchScope ls(c, "k_scan_blocksums", B);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.btotal, B, t.btotal + B);
+    }
+    {
+        LaunchScope ls(c, "k_part_scatter.w1", in.n);
+        hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_PART_THREADS), B * 4, c->cur, t.recs, t.nrec, t.chunk, t.bshift, B, t.off,
+                           t.btotal, t.part);
+    }
+    {
+        LaunchScope ls(c, "k_part_dedup.w1", in.n);
+        if (t.cap == 2048)
+            hipLaunchKernelGGL(k_part_dedup<2048>, dim3(B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 1024, c->cur, t.part, t.btotal,
+                               out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST, dmeta + MIRGE_META_OVERFLOW);
+        else
+            hipLaunchKernelGGL(k_part_dedup<MIRGE_PART_CAP>, dim3(B), dim3(MIRGE_DEDUP_THREADS), MIRGE_PART_CAP * 16 + 1024, c->cur, t.part,
+                               t.btotal, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
+                               dmeta + MIRGE_META_OVERFLOW);
+    }
+    return 0;
+}
+
+template <int W>
+static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t,
+                            const int32_t* dsample, int32_t S, uint32_t* dmeta, bool force_atomic, int stage = 0) {
+    // stage 0 = everything; 1 = only the first kernel of the partitioned path; 2 = what stage 1 left
+    if (!in.n) return 0;
+    if (stage == 2 && t.partitioned) return collapse_part_rest(c, gi, in, out, t, dmeta);
+    // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
+    const bool key_path = (W == 1) && !in.nmask && S == 1;
+    uint32_t tsize = 1024;
+    while (tsize < (key_path ? in.n + in.n / 2 : 2ull * in.n)) tsize <<= 1;
+    const uint32_t per_block = MIRGE_BLOCK * MIRGE_SCAN_ITEMS;
+    t.nb = (in.n + per_block - 1) / per_block;
+    GroupView<W> v = view_of<W>(in);
+    char name[48];
+    const uint32_t* first_base;
+    uint32_t first_stride;
+    if (key_path && !force_atomic && in.n >= 65536) {
+        // partition by hash -> de-duplicate each bucket in LDS: no global atomics (see mirge_kernels.hpp)
+        t.partitioned = true;
+        uint32_t B = 64;
+        // test hook: MIRGE_TEST_SMALL_PART=1 keeps 64 buckets so that big inputs overflow the LDS tables and
+        // exercise the fallback to the global-atomic path (tests/test_gpu_parity.py)
+        static const bool small_part = std::getenv("MIRGE_TEST_SMALL_PART") != nullptr;
+        while (!small_part && B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
+        // buckets of <= 1024 records get a 2048-slot LDS table in k_part_dedup (4 workgroups per CU instead of 2).
+        // Forcing that by doubling B was measured slower overall: k_part_agg/k_part_scatter pay for the larger B
+        t.cap = (!small_part && (uint64_t)B * 1024 >= in.n) ? 2048u : (uint32_t)MIRGE_PART_CAP;
+        const uint32_t CS = B > 16384 ? 1024 : 2048;  // chunk-level LDS cache slots (16 B each)
+        const int agg_lds = (int)(CS * 16 + (B + 1) * 4 + 64);
+        // dynamic-LDS ceilings, raised once per process and device to the largest configuration (B = 32768)
+        static std::mutex attr_mu;
+        static std::vector<int> attr_done;
+        {
+            std::lock_guard<std::mutex> lk(attr_mu);
+            if (std::find(attr_done.begin(), attr_done.end(), c->device) == attr_done.end()) {
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          1024 * 16 + (32768 + 1) * 4 + 64));  // CS = 1024 at B = 32768; 2048 * 16 + 16385 * 4 + 64 is smaller
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup<MIRGE_PART_CAP>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, MIRGE_PART_CAP * 16 + 1024));
+                attr_done.push_back(c->device);
+            }
+        }
+        int lg = 0; while ((1u << lg) < B) lg++;
+        const uint32_t bshift = 64 - lg;
+        const uint32_t G = std::min<uint32_t>(256, (in.n + 2047) / 2048);
+        uint32_t chunk = (in.n + G - 1) / G;
+        chunk = (chunk + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
+        CHECK(dalloc(c, &t.hist, (size_t)G * B));
+        CHECK(dalloc(c, &t.off, (size_t)G * B));
+        CHECK(dalloc(c, &t.btotal, (size_t)B + 1));
+        CHECK(dalloc(c, &t.part, (size_t)in.n));
+        CHECK(dalloc(c, &t.recs, (size_t)G * chunk));
+        CHECK(dalloc(c, &t.nrec, (size_t)G));
+        // outputs at capacity n (U is not known yet): the bucket workgroups emit the unique reads themselves
+        out.W = 1;
+        CHECK(dalloc(c, &out.seq, (size_t)in.n));
+        CHECK(dalloc(c, &out.len, (size_t)in.n));
+        CHECK(dalloc(c, &out.counts, (size_t)in.n));
+        CHECK(dalloc(c, &out.first, (size_t)in.n));
+        GroupView<1> v1 = view_of<1>(in);
+        {
+            LaunchScope ls(c, "k_part_agg.w1", in.n);
+            hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_PART_THREADS), agg_lds, c->cur, v1, in.orig, in.base, chunk, bshift, B, CS, t.recs, t.nrec, t.hist);
+        }
+        t.G = G; t.chunk = chunk; t.bshift = bshift; t.B = B;
+        if (stage == 1) return 0;
+        return collapse_part_rest(c, gi, in, out, t, dmeta);
+    }
+    if (stage == 1) return 0;
+    CHECK(dalloc(c, &t.slot_of, in.n));
+    CHECK(dalloc(c, &t.flag, (size_t)t.nb * per_block));
+    CHECK(dalloc(c, &t.blocksum, t.nb));
+    if (key_path) {
+        CHECK(dalloc(c, &t.slots, tsize));
+        HIPOK(hipMemsetAsync(t.slots, 0, (size_t)tsize * sizeof(KeySlot), c->cur));
+        LaunchScope ls(c, "k_collapse_insert_key.w1", in.n);
+        hipLaunchKernelGGL(k_collapse_insert_key, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->cur,
+                           view_of<1>(in), t.slots, t.slot_of, tsize - 1);
+        first_base = reinterpret_cast<const uint32_t*>(t.slots) + 2; first_stride = 4;
+        t.cnt_base = reinterpret_cast<const uint32_t*>(t.slots) + 3; t.cnt_stride = 4;
+    } else {
+        CHECK(dalloc(c, &t.rep, tsize));
+        CHECK(dalloc(c, &t.firstj, tsize));
+        CHECK(dalloc(c, &t.cnt, (size_t)tsize * S));
+        HIPOK(hipMemsetAsync(t.rep, 0xFF, (size_t)tsize * 4, c->cur));
+        HIPOK(hipMemsetAsync(t.firstj, 0xFF, (size_t)tsize * 4, c->cur));
+        HIPOK(hipMemsetAsync(t.cnt, 0, (size_t)tsize * S * 4, c->cur));
+        std::snprintf(name, sizeof(name), "k_collapse_insert%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        // at most 2 workgroups per CU: each sees enough of the group for its LDS cell cache to merge hot reads
+        const int ins_grid = std::min(grid_for(c, in.n), c->n_cu * 2);
+        hipLaunchKernelGGL(k_collapse_insert<W>, dim3(ins_grid), dim3(MIRGE_BLOCK), 0, c->cur,
+                           v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S);
+        first_base = t.firstj; first_stride = 1;
+        t.cnt_base = t.cnt; t.cnt_stride = (uint32_t)S;
+    }
+    {
+        std::snprintf(name, sizeof(name), "k_heads_blocksum%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        hipLaunchKernelGGL(k_heads_blocksum, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, t.slot_of, first_base, first_stride,
+                           key_path ? 1u : 0u, in.n, in.len, t.flag, t.blocksum, dmeta + MIRGE_META_HIST);
+    }
+    {
+        LaunchScope ls(c, "k_scan_blocksums", t.nb);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.blocksum, t.nb, dmeta + gi);
+    }
+    return 0;
+}
+
+template <int W>
+static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, int32_t S,
+                            uint32_t U, uint32_t out_base, const uint32_t* dmeta) {
+    out.W = W; out.n = U; out.base = out_base;
+    if (in.n && !t.partitioned) {
+        CHECK(dalloc(c, &out.seq, (size_t)W * U));
+        CHECK(dalloc(c, &out.len, (size_t)U));
+        if (in.nmask) CHECK(dalloc(c, &out.nmask, (size_t)W * U));
+        CHECK(dalloc(c, &out.counts, (size_t)U * S));
+        CHECK(dalloc(c, &out.first, (size_t)U));
+        char name[48];
+        std::snprintf(name, sizeof(name), "k_collapse_scatter%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        hipLaunchKernelGGL(k_collapse_scatter<W>, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, view_of<W>(in), t.slot_of,
+                           t.flag, t.cnt_base, t.cnt_stride, t.blocksum, dmeta + gi, in.orig, in.base, S, out.seq,
+                           out.len, out.nmask, out.counts, out.first);
+    }
+    return 0;  // the temporaries go back to the pool in mirge_collapse, after the join
+}
+
+static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
+    c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
+    c->defer(t.flag); c->defer(t.blocksum);
+    c->defer(t.hist); c->defer(t.off); c->defer(t.btotal); c->defer(t.part); c->defer(t.recs); c->defer(t.nrec);
+    t = CollapseTmp();
+}
+
+extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
+                              mirge_reads** uniq, int64_t* n_uniq) {
+    HostClock hc("collapse");
+    if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids)) return fail(-1, "mirge_collapse: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    int32_t* dsample = nullptr;
+    if (sample_ids && raw->n) {
+        for (int64_t i = 0; i < raw->n; i++)
+            if (sample_ids[i] < 0 || sample_ids[i] >= S) return fail(-1, "sample id out of range");
+        CHECK(dalloc(c, &dsample, (size_t)raw->n));
+        HIPOK(hipMemcpyAsync(dsample, sample_ids, (size_t)raw->n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n_samples = S;
+    uint32_t* dmeta = nullptr;
+    CHECK(dalloc(c, &dmeta, MIRGE_META_WORDS));
+    CollapseTmp tmp[MIRGE_NGROUPS];
+    int rc = 0;
+    const int big = largest_group(raw);
+    // attempt 0 may use the partitioned LDS path; if one of its buckets overflows its LDS table
+    // (pathological hash skew) everything is redone with the global-atomic tables
+    for (int attempt = 0; attempt < 2 && rc == 0; attempt++) {
+        hipError_t e0 = hipMemsetAsync(dmeta, 0, MIRGE_META_WORDS * 4, c->stream);
+        if (e0 != hipSuccess) { rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e0)); break; }
+        rc = stream_fork(c);
+        // Order of enqueue (profiles/r01_timeline.txt): the bulk group's first kernel (k_part_agg: one workgroup
+        // per CU, ~0.2 ms) goes first, the small groups' ~15 short launches are enqueued while it runs and share
+        // the CUs with it, then the bulk group's wide kernels.  Small groups entirely first left the GPU idle for
+        // the ~0.2 ms their enqueue takes; entirely last, each of their kernels waits behind 2048-8192-workgroup
+        // launches for CUs to drain and the join at the end waits for them (5.3 vs 3.8 ms).
+        for (int k = -1; k <= MIRGE_NGROUPS && rc == 0; k++) {
+            const int gi = (k < 0 || k == MIRGE_NGROUPS) ? big : k;
+            if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
+            const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
+            c->cur = gi == big ? c->stream : c->aux;
+            if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
+            else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
+            else rc = collapse_phase_a<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
+        }
+        { int jr = stream_join(c); if (rc == 0) rc = jr; }
+        hc.lap("enqueue A");
+        if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
+            hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
+        }
+        if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt == 0) {
+            for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+                collapse_tmp_release(c, tmp[gi]);
+                ReadGroup& og = R->g[gi];  // outputs the partitioned attempt had allocated at capacity n
+                c->release(og.seq); c->release(og.len); c->release(og.counts); c->release(og.first);
+                og = ReadGroup();
+            }
+            c->flush_deferred();
+            continue;
+        }
+        break;
+    }
+    hc.lap("sync");
+    uint32_t base = 0;
+    if (rc == 0) {
+        uint32_t U[MIRGE_NGROUPS];
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) U[gi] = c->pinned[gi];
+        R->total_bases = 0;
+        for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
+            R->len_hist[L] = (int32_t)c->pinned[MIRGE_META_HIST + L];
+            R->total_bases += (int64_t)L * c->pinned[MIRGE_META_HIST + L];
+        }
+        R->hist_valid = true;
+        rc = stream_fork(c);
+        for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+            c->cur = gi == big ? c->stream : c->aux;
+            if (kGroupW[gi] == 1) rc = collapse_phase_b<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            else if (kGroupW[gi] == 2) rc = collapse_phase_b<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            else rc = collapse_phase_b<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            base += R->g[gi].n;
+        }
+        { int jr = stream_join(c); if (rc == 0) rc = jr; }
+    }
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
+    c->flush_deferred();
+    c->release(dsample); c->release(dmeta);
+    if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    R->n = base;
+    *uniq = R.release();
+    if (n_uniq) *n_uniq = base;
+    hc.lap("phase B + release");
+    return 0;
+}
+
+extern "C" int mirge_collapse_fetch(mirge_ctx* c, const mirge_reads* U, uint32_t* counts_out, int64_t* first_out) {
+    if (!c || !U || !counts_out) return fail(-1, "mirge_collapse_fetch: bad argument");
+    if (U->n_samples < 1) return fail(-1, "read set has no count matrix");
+    HIPOK(hipSetDevice(c->device));
+    const int32_t S = U->n_samples;
+    std::vector<uint32_t> tmp;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = U->g[gi];
+        if (!g.n) continue;
+        if (g.orig) return fail(-1, "mirge_collapse_fetch: handle is not a collapse result");
+        HIPOK(hipMemcpyAsync(counts_out + (size_t)g.base * S, g.counts, (size_t)g.n * S * 4, hipMemcpyDeviceToHost, c->stream));
+        if (first_out && g.first) {
+            tmp.resize(g.n);
+            HIPOK(hipMemcpyAsync(tmp.data(), g.first, (size_t)g.n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPOK(hipStreamSynchronize(c->stream));
+            for (uint32_t j = 0; j < g.n; j++) first_out[g.base + j] = tmp[j];
+        }
+    }
+    HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}

@@ -1,0 +1,327 @@
+// native_ctx.hpp -- part of mirge_native.hip (one translation unit): errors, device context: streams, stream-ordered buffer pool, profiler, host timing hook.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPOK(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+#define CHECK(expr)            \
+    do {                       \
+        int _c = (expr);       \
+        if (_c != 0) return _c; \
+    } while (0)
+
+extern "C" const char* mirge_last_error(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------
+// context: device, stream, pooled device memory, profiler
+// ------------------------------------------------------------------------------------------
+struct ProfRec {
+    std::string name;
+    int64_t launches = 0;
+    double total_ms = 0.0;
+    double units = 0.0;
+};
+struct PendingEvt {
+    int rec;
+    hipEvent_t a, b;
+};
+struct ProfUnits {  // "units" of a cascade pass = sum of the per-workgroup survivor counts of the stage before
+    int rec, stage;
+    uint32_t grid;
+    const uint32_t* host;  // pinned copy of seg_n[stage][grid]
+    double n_first;
+};
+#define MIRGE_PROF_PINNED_WORDS (1u << 18)
+
+struct PassStep {
+    int32_t p0 = 0, np = 1;       // passes p0 .. p0+np-1 run as one launch
+    const mirge_lib* lib = nullptr;
+    MergeInfo mi;
+    const MirgePlanTable* dplan = nullptr;  // device copy of the tabulated probe plan
+};
+
+struct mirge_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // second stream: the small read groups (long reads, reads with N) run beside the big one.
+    // cur = the stream the launch helpers currently target.
+    hipStream_t aux = nullptr, cur = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int n_cu = 256;
+    // pool
+    std::multimap<size_t, void*> free_blocks;
+    std::unordered_map<void*, size_t> sizes;
+    size_t pool_bytes = 0;
+    // profiler
+    bool profiling = false;
+    std::string prof_only;  // non-empty: only launches whose name contains it are bracketed
+    std::vector<ProfRec> recs;
+    std::unordered_map<std::string, int> rec_of;
+    std::vector<PendingEvt> pending;
+    std::vector<hipEvent_t> evt_pool;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // pinned scratch for small D2H
+    uint32_t* pinned = nullptr;
+    uint32_t* prof_pinned = nullptr;
+    unsigned long long* join_pinned = nullptr;
+    size_t join_pinned_bytes = 0;
+    struct PlanEntry { uint64_t uid; MirgePolicy pol; MirgePlanTable* dplan; };
+    std::vector<PlanEntry> plans;
+    struct FusedEntry { std::unique_ptr<FusedSteps> host; FusedSteps* dev; };
+    std::vector<FusedEntry> fused;  // step lists of k_cascade_fused already on the device
+    std::string casc_key;           // configuration of the previous mirge_cascade_run ...
+    std::vector<PassStep> casc_steps;  // ... and what was prepared for it
+    ResolveTable casc_rt;
+    const FusedSteps* casc_dsteps = nullptr;
+    size_t prof_used = 0;
+    std::vector<ProfUnits> prof_pending;
+
+    int alloc(void** out, size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~size_t(255);
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes * 2 + (1u << 20)) {
+            *out = it->second;
+            free_blocks.erase(it);
+            return 0;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
+            for (auto& kv : free_blocks) { (void)hipFree(kv.second); pool_bytes -= kv.first; sizes.erase(kv.second); }
+            free_blocks.clear();
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return fail(-3, "hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e));
+        }
+        sizes[p] = bytes;
+        pool_bytes += bytes;
+        *out = p;
+        return 0;
+    }
+    void release(void* p) {
+        if (!p) return;
+        auto it = sizes.find(p);
+        if (it == sizes.end()) return;
+        free_blocks.emplace(it->second, p);  // stream-ordered reuse: one stream per ctx
+    }
+    // libraries merged for runs of passes that share one policy (see mirge_cascade_run)
+    struct Merged { std::vector<uint64_t> uids; struct mirge_lib* lib; };
+    std::vector<Merged> merged;
+    // inside a fork/join region a buffer must not go back to the pool before the join: the other
+    // stream could be handed it while this stream's kernels still use it
+    std::vector<void*> deferred;
+    void defer(void* p) { if (p) deferred.push_back(p); }
+    void flush_deferred() { for (void* p : deferred) release(p); deferred.clear(); }
+    int rec_index(const char* name) {
+        auto it = rec_of.find(name);
+        if (it != rec_of.end()) return it->second;
+        recs.push_back(ProfRec{name});
+        rec_of[name] = (int)recs.size() - 1;
+        return (int)recs.size() - 1;
+    }
+    hipEvent_t get_evt() {
+        if (!evt_pool.empty()) { hipEvent_t e = evt_pool.back(); evt_pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    void drain() {  // resolve pending event pairs (caller has synchronised the stream)
+        for (auto& u : prof_pending) {
+            double units = u.n_first;
+            if (u.stage > 0) { units = 0; for (uint32_t b = 0; b < u.grid; b++) units += u.host[(size_t)u.grid * (u.stage - 1) + b]; }
+            recs[u.rec].units += units;
+        }
+        prof_pending.clear();
+        prof_used = 0;
+        for (auto& p : pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) recs[p.rec].total_ms += ms;
+            evt_pool.push_back(p.a);
+            evt_pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+
+template <typename T>
+static int dalloc(mirge_ctx* c, T** out, size_t count) { return c->alloc((void**)out, count * sizeof(T)); }
+
+// launch bracket: HIP events on the ctx stream around each kernel when profiling is on
+struct LaunchScope {
+    mirge_ctx* c; int rec = -1; hipEvent_t a = nullptr, b = nullptr;
+    LaunchScope(mirge_ctx* ctx, const char* name, double units) : c(ctx) {
+        if (!c->profiling) return;
+        if (!c->prof_only.empty() && !std::strstr(name, c->prof_only.c_str())) return;
+        rec = c->rec_index(name);
+        c->recs[rec].launches++;
+        c->recs[rec].units += units;
+        a = c->get_evt(); b = c->get_evt();
+        (void)hipEventRecord(a, c->cur);
+    }
+    ~LaunchScope() {
+        if (rec < 0) return;
+        (void)hipEventRecord(b, c->cur);
+        c->pending.push_back(PendingEvt{rec, a, b});
+    }
+};
+
+// fork: work queued on `aux` from now on starts after everything already queued on the main stream;
+// join: the main stream continues only after `aux` has drained.  Buffers handed back to the pool
+// between the two are reused only by work queued after the join, so stream-ordered reuse still holds.
+static int stream_fork(mirge_ctx* c) {
+    HIPOK(hipEventRecord(c->ev_fork, c->stream));
+    HIPOK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    return 0;
+}
+static int stream_join(mirge_ctx* c) {
+    c->cur = c->stream;
+    hipError_t e = hipEventRecord(c->ev_join, c->aux);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    c->flush_deferred();  // reused only by work queued on the main stream after the wait
+    if (e != hipSuccess) return fail(-2, std::string("stream join: ") + hipGetErrorString(e));
+    return 0;
+}
+static int largest_group(const struct mirge_reads* R);
+
+static inline int grid_for(const mirge_ctx* c, size_t n, int per_block = MIRGE_BLOCK) {
+    size_t blocks = (n + per_block - 1) / per_block;
+    static const size_t per_cu = std::getenv("MIRGE_GRID_PER_CU") ? (size_t)std::atoi(std::getenv("MIRGE_GRID_PER_CU")) : 8;
+    size_t cap = (size_t)c->n_cu * per_cu;
+    return (int)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+// MIRGE_HOST_TIMING=1: host microseconds spent in the stages of a call, to stderr (enqueue-bound phases)
+static std::chrono::steady_clock::time_point g_last_exit = std::chrono::steady_clock::now();
+struct HostClock {
+    const char* what;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit HostClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {
+        static const bool e = std::getenv("MIRGE_HOST_TIMING") != nullptr;
+        on = e;
+        if (on) std::fprintf(stderr, "[host] %s entered %.1f us after the previous call returned\n", what,
+                             std::chrono::duration<double, std::micro>(t0 - g_last_exit).count());
+    }
+    ~HostClock() { if (on) g_last_exit = std::chrono::steady_clock::now(); }
+    void lap(const char* stage) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[host] %s/%s %.1f us\n", what, stage, std::chrono::duration<double, std::micro>(t - t0).count());
+        t0 = t;
+    }
+};
+
+extern "C" int mirge_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
+    if (!out) return fail(-1, "mirge_ctx_create: out is NULL");
+    int n = mirge_device_count();
+    if (n <= 0) return fail(-4, "no HIP device visible: the hot path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(-1, "device index out of range");
+    HIPOK(hipSetDevice(device));
+    auto c = std::make_unique<mirge_ctx>();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPOK(hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; }
+    else { HIPOK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    c->cur = c->stream;
+    HIPOK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIPOK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPOK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPOK(hipEventCreate(&c->t0));
+    HIPOK(hipEventCreate(&c->t1));
+    HIPOK(hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault));
+    HIPOK(hipHostMalloc((void**)&c->prof_pinned, MIRGE_PROF_PINNED_WORDS * 4, hipHostMallocDefault));
+    *out = c.release();
+    return 0;
+}
+
+extern "C" void mirge_lib_destroy(mirge_lib* L);
+extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& m : c->merged) mirge_lib_destroy(m.lib);
+    c->merged.clear();
+    c->drain();
+    for (auto& kv : c->sizes) (void)hipFree(kv.first);
+    for (auto e : c->evt_pool) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->prof_pinned) (void)hipHostFree(c->prof_pinned);
+    if (c->join_pinned) (void)hipHostFree(c->join_pinned);
+    for (auto& e : c->plans) (void)hipFree(e.dplan);
+    for (auto& e : c->fused) (void)hipFree(e.dev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mirge_ctx_sync(mirge_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->drain();
+    return 0;
+}
+
+extern "C" int mirge_ctx_timer_start(mirge_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    HIPOK(hipEventRecord(c->t0, c->stream));
+    return 0;
+}
+extern "C" int mirge_ctx_timer_stop(mirge_ctx* c, double* ms_out) {
+    if (!c || !ms_out) return fail(-1, "NULL argument");
+    HIPOK(hipEventRecord(c->t1, c->stream));
+    HIPOK(hipEventSynchronize(c->t1));
+    float ms = 0.f;
+    HIPOK(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *ms_out = ms;
+    return 0;
+}
+extern "C" int mirge_ctx_profile_enable(mirge_ctx* c, int32_t on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->profiling = on != 0;
+    return 0;
+}
+extern "C" int mirge_ctx_profile_only(mirge_ctx* c, const char* substr) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->prof_only = substr ? substr : "";
+    return 0;
+}
+extern "C" int mirge_ctx_profile_reset(mirge_ctx* c) {
+    if (!c) return fail(-1, "ctx is NULL");
+    CHECK(mirge_ctx_sync(c));
+    c->recs.clear();
+    c->rec_of.clear();
+    return 0;
+}
+extern "C" int32_t mirge_ctx_profile_count(mirge_ctx* c) {
+    if (!c) return 0;
+    if (mirge_ctx_sync(c) != 0) return 0;
+    return (int32_t)c->recs.size();
+}
+extern "C" int mirge_ctx_profile_get(mirge_ctx* c, int32_t i, char* name_out, int32_t name_cap,
+                                     int64_t* launches, double* total_ms, double* units) {
+    if (!c || i < 0 || i >= (int32_t)c->recs.size()) return fail(-1, "profile index out of range");
+    const ProfRec& r = c->recs[i];
+    if (name_out && name_cap > 0) { std::snprintf(name_out, (size_t)name_cap, "%s", r.name.c_str()); }
+    if (launches) *launches = r.launches;
+    if (total_ms) *total_ms = r.total_ms;
+    if (units) *units = r.units;
+    return 0;
+}

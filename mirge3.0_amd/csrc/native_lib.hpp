@@ -1,0 +1,140 @@
+// native_lib.hpp -- part of mirge_native.hip (one translation unit): libraries: 2-bit text + invalid bitmap on the device, probe tables built on the device.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// library: 2-bit text + invalid bitmap + per-k tables
+// ------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_lib_uid{1};
+
+struct mirge_lib {
+    mirge_ctx* ctx = nullptr;
+    uint64_t uid = 0;  // never reused: identifies a member of a merged library after its pointer is gone
+    MirgeHostLib h;  // host image (table construction)
+    // device
+    uint64_t* dT = nullptr;
+    uint64_t* dinv = nullptr;
+    uint32_t* dref_start = nullptr;
+    MirgeKTable* dtables = nullptr;           // [MIRGE_SHAPE_SLOTS] on the device
+    std::vector<MirgeKTable> htables;          // host mirror (device pointers), by mirge_shape_id
+    size_t device_bytes = 0;
+    std::mutex mu;
+    int64_t n_refs = 0;
+    int kmax = 8;
+
+    MirgeLibView view() const {
+        MirgeLibView v;
+        v.T = dT; v.inv = dinv; v.ref_start = dref_start; v.tables = dtables;
+        v.total = h.total; v.n_refs = (uint32_t)n_refs; v.kmax = kmax;
+        return v;
+    }
+};
+
+extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* off, int64_t n_refs, mirge_lib** out) {
+    if (!c || !out || (!seq && n_refs > 0) || !off || n_refs < 0) return fail(-1, "mirge_lib_create: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    auto L = std::make_unique<mirge_lib>();
+    L->ctx = c;
+    L->uid = g_lib_uid.fetch_add(1);
+    std::string err;
+    int rc = mirge_hostlib_build(L->h, seq, off, n_refs, err);
+    if (rc) return fail(rc, "mirge_lib_create: " + err);
+    L->n_refs = n_refs;
+    L->kmax = L->h.kmax;
+    L->htables.assign(MIRGE_SHAPE_SLOTS, MirgeKTable{nullptr, nullptr, nullptr});
+    const size_t nT = L->h.T.size() * 8, nI = L->h.inv.size() * 8, nR = ((size_t)n_refs + 1) * 4;
+    HIPOK(hipMalloc((void**)&L->dT, nT));
+    HIPOK(hipMalloc((void**)&L->dinv, nI));
+    HIPOK(hipMalloc((void**)&L->dref_start, nR));
+    HIPOK(hipMalloc((void**)&L->dtables, sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS));
+    HIPOK(hipMemcpy(L->dT, L->h.T.data(), nT, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(L->dinv, L->h.inv.data(), nI, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(L->dref_start, L->h.ref_start.data(), nR, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(L->dtables, L->htables.data(), sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS, hipMemcpyHostToDevice));
+    L->device_bytes = nT + nI + nR + sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS;
+    *out = L.release();
+    return 0;
+}
+
+extern "C" void mirge_lib_destroy(mirge_lib* L) {
+    if (!L) return;
+    (void)hipSetDevice(L->ctx->device);
+    (void)hipStreamSynchronize(L->ctx->stream);
+    (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dtables);
+    for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); (void)hipFree((void*)t.bits); }
+    delete L;
+}
+extern "C" int64_t mirge_lib_n_refs(const mirge_lib* L) { return L ? L->n_refs : -1; }
+extern "C" int64_t mirge_lib_device_bytes(const mirge_lib* L) { return L ? (int64_t)L->device_bytes : -1; }
+
+// one probe shape (k1 bases, gap, k2 bases)
+struct ShapeJob {
+    int k1 = 0, gap = 0, k2 = 0;
+};
+
+// build one table on the device (k_table_pass: count, scan, fill) and publish it in the library's registry
+static int lib_build_shape(mirge_lib* L, const ShapeJob& j) {
+    mirge_ctx* c = L->ctx;
+    const int sid = mirge_shape_id(j.k1, j.gap, j.k2);
+    const uint64_t nb = 1ull << (2 * (j.k1 + j.k2));
+    uint32_t *A = nullptr, *dpos = nullptr, *dbits = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    uint32_t npos = 0;
+    const int grid = c->n_cu * 8;
+    hipError_t e = hipMalloc((void**)&A, (nb + 2) * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(A, 0, (nb + 2) * 4, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_table_pass<false>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1,
+                           j.gap, j.k2, A, (uint32_t*)nullptr);
+        e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream);  // size query
+    }
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
+    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&npos, A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&dpos, std::max<size_t>(npos, 1) * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_table_pass<true>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1,
+                           j.gap, j.k2, A, dpos);
+        if (j.k1 + j.k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
+            const size_t words = (size_t)((nb + 31) / 32);
+            e = hipMalloc((void**)&dbits, words * 4);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, words)), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, dbits);
+        }
+    }
+    // table complete; no kernel may be reading the registry while it changes
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(tmp);
+    if (e != hipSuccess) {
+        (void)hipFree(A); (void)hipFree(dpos); (void)hipFree(dbits);
+        return fail(-2, std::string("probe table construction: ") + hipGetErrorString(e));
+    }
+    L->device_bytes += (nb + 2) * 4 + (size_t)npos * 4 + (dbits ? (size_t)((nb + 31) / 32) * 4 : 0);
+    L->htables[sid].bucket = A;
+    L->htables[sid].pos = dpos;
+    L->htables[sid].bits = dbits;
+    HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// build the tables of the wanted probe shapes that do not exist yet
+static int lib_prepare_shapes(mirge_lib* L, const std::vector<ShapeJob>& wanted) {
+    std::lock_guard<std::mutex> lk(L->mu);
+    bool first = true;
+    for (const auto& w : wanted) {
+        if (w.k1 < 1 || w.k2 < 0 || w.k1 + w.k2 > (w.k2 == 0 ? MIRGE_KMAX0 : MIRGE_KMAX) || w.gap < 0 || w.gap > 31 || (w.k2 == 0 && w.gap != 0))
+            return fail(-1, "probe shape out of range");
+        if (L->htables[mirge_shape_id(w.k1, w.gap, w.k2)].bucket) continue;
+        if (first) { HIPOK(hipSetDevice(L->ctx->device)); first = false; }
+        CHECK(lib_build_shape(L, w));
+    }
+    return 0;
+}
+
+extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {
+    if (!L) return fail(-1, "lib is NULL");
+    std::vector<ShapeJob> w(1);
+    w[0].k1 = k;
+    return lib_prepare_shapes(L, w);
+}

@@ -1,0 +1,409 @@
+// native_reads.hpp -- part of mirge_native.hip (one translation unit): read sets: pack, parse (FASTQ/FASTA text on the device), concat, unpack.
+#pragma once
+// ------------------------------------------------------------------------------------------
+// reads
+// ------------------------------------------------------------------------------------------
+// Six read groups: width class (<=31, <=64, <=128 nt) x (no ambiguous call | has an N).  Reads with
+// an N are rare (~0.1 %); keeping them apart lets the big groups run without an nmask array and lets
+// the <=31-nt group collapse on a 64-bit key (sequence bits + length sentinel).
+#define MIRGE_NGROUPS 6
+static const int kGroupW[MIRGE_NGROUPS] = {1, 2, 4, 1, 2, 4};
+static inline int width_class(int64_t L) { return L <= 31 ? 0 : (L <= 64 ? 1 : 2); }
+
+struct ReadGroup {
+    int W = 1;
+    uint32_t n = 0;
+    uint64_t* seq = nullptr;
+    uint8_t* len = nullptr;
+    uint64_t* nmask = nullptr;
+    uint32_t* orig = nullptr;    // handle-order index of each read (nullptr: base + j)
+    uint32_t base = 0;
+    uint32_t* counts = nullptr;  // [n][S]
+    uint32_t* first = nullptr;   // [n] raw index of first appearance (collapse output)
+};
+
+struct mirge_reads {
+    mirge_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int64_t total_bases = 0;
+    int32_t n_samples = 0;  // 0: no count matrix attached
+    ReadGroup g[MIRGE_NGROUPS];
+    int32_t len_hist[MIRGE_MAX_READ_LEN + 1];  // lengths present (host), for table preparation
+    bool hist_valid = false;
+};
+
+static int largest_group(const mirge_reads* R) {
+    int best = 0;
+    for (int gi = 1; gi < MIRGE_NGROUPS; gi++) if (R->g[gi].n > R->g[best].n) best = gi;
+    return best;
+}
+
+template <int W>
+static GroupView<W> view_of(const ReadGroup& g) {
+    GroupView<W> v; v.seq = g.seq; v.len = g.len; v.nmask = g.nmask; v.n = g.n; return v;
+}
+
+extern "C" void mirge_reads_destroy(mirge_reads* r) {
+    if (!r) return;
+    for (auto& g : r->g) {
+        r->ctx->release(g.seq); r->ctx->release(g.len); r->ctx->release(g.nmask);
+        r->ctx->release(g.orig); r->ctx->release(g.counts); r->ctx->release(g.first);
+    }
+    delete r;
+}
+// Several raw read sets (the samples of a run, each parsed from its own file) as one, in the order given: read j of
+// part p gets handle index (reads of the parts before p) + j.  No count matrices; the parts stay valid.
+extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out) {
+    if (!c || !parts || n_parts < 1 || !out) return fail(-1, "mirge_reads_concat: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    int64_t total = 0;
+    for (int p = 0; p < n_parts; p++) {
+        if (!parts[p] || parts[p]->ctx != c) return fail(-1, "mirge_reads_concat: foreign or NULL read set");
+        if (parts[p]->n_samples) return fail(-1, "mirge_reads_concat: collapsed read sets cannot be appended");
+        total += parts[p]->n;
+    }
+    if (total >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = total; R->hist_valid = true;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    for (int p = 0; p < n_parts; p++) {
+        R->total_bases += parts[p]->total_bases;
+        R->hist_valid = R->hist_valid && parts[p]->hist_valid;
+        for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) R->len_hist[L] += parts[p]->len_hist[L];
+    }
+    int rc = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+        ReadGroup& g = R->g[gi];
+        g.W = kGroupW[gi];
+        uint64_t n = 0;
+        bool mask = false;
+        for (int p = 0; p < n_parts; p++) { n += parts[p]->g[gi].n; mask = mask || parts[p]->g[gi].nmask; }
+        g.n = (uint32_t)n;
+        if (!g.n) continue;
+        if ((rc = dalloc(c, &g.seq, (size_t)g.W * g.n))) break;
+        if ((rc = dalloc(c, &g.len, (size_t)g.n))) break;
+        if ((rc = dalloc(c, &g.orig, (size_t)g.n))) break;
+        if (mask && (rc = dalloc(c, &g.nmask, (size_t)g.W * g.n))) break;
+        uint32_t at = 0, before = 0;
+        hipError_t e = hipSuccess;
+        for (int p = 0; p < n_parts && e == hipSuccess; p++) {
+            const ReadGroup& q = parts[p]->g[gi];
+            if (q.n) {
+                for (int w = 0; w < g.W && e == hipSuccess; w++) {  // word-major arrays: one copy per word plane
+                    e = hipMemcpyAsync(g.seq + (size_t)w * g.n + at, q.seq + (size_t)w * q.n, (size_t)q.n * 8, hipMemcpyDeviceToDevice, c->stream);
+                    if (e == hipSuccess && g.nmask) {
+                        if (q.nmask) e = hipMemcpyAsync(g.nmask + (size_t)w * g.n + at, q.nmask + (size_t)w * q.n, (size_t)q.n * 8, hipMemcpyDeviceToDevice, c->stream);
+                        else e = hipMemsetAsync(g.nmask + (size_t)w * g.n + at, 0, (size_t)q.n * 8, c->stream);
+                    }
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(g.len + at, q.len, (size_t)q.n, hipMemcpyDeviceToDevice, c->stream);
+                hipLaunchKernelGGL(k_index_shift, dim3(grid_for(c, q.n)), dim3(MIRGE_BLOCK), 0, c->stream, (const uint32_t*)q.orig, q.base,
+                                   q.n, before, g.orig + at);
+                at += q.n;
+            }
+            before += (uint32_t)parts[p]->n;
+        }
+        if (e != hipSuccess) rc = fail(-2, std::string("mirge_reads_concat: ") + hipGetErrorString(e));
+    }
+    if (rc == 0) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(-2, std::string("mirge_reads_concat: ") + hipGetErrorString(e));
+    }
+    if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    *out = R.release();
+    return 0;
+}
+
+extern "C" int64_t mirge_reads_count(const mirge_reads* r) { return r ? r->n : -1; }
+extern "C" int64_t mirge_reads_total_bases(const mirge_reads* r) { return r ? r->total_bases : -1; }
+extern "C" int32_t mirge_reads_n_samples(const mirge_reads* r) { return r ? r->n_samples : -1; }
+
+template <int W>
+static void launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstart, const int64_t* dend, const uint32_t* didx,
+                        ReadGroup& g, uint32_t* dflags) {
+    LaunchScope ls(c, "k_pack", g.n);
+    hipLaunchKernelGGL(k_pack<W>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                       dascii, dstart, dend, didx, g.n, g.seq, g.len, g.nmask, dflags);
+}
+
+extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads** out) {
+    if (!c || !out || !off || n < 0 || (n > 0 && !ascii)) return fail(-1, "mirge_reads_pack: bad argument");
+    if (n >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
+    HIPOK(hipSetDevice(c->device));
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = n;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    std::vector<uint32_t> idx[MIRGE_NGROUPS];
+    bool is_acgt[256] = {false};
+    for (const char* q = "ACGTUacgtu"; *q; q++) is_acgt[(unsigned char)*q] = true;
+    {
+        // classify the reads (width class x has-an-ambiguous-call) on all host cores: this byte scan is the
+        // largest host cost of the PCIe-inclusive path
+        const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        const int T = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
+        std::vector<std::vector<uint32_t>> part((size_t)T * MIRGE_NGROUPS);
+        std::vector<std::vector<int32_t>> hist((size_t)T, std::vector<int32_t>(MIRGE_MAX_READ_LEN + 1, 0));
+        std::vector<int64_t> bad((size_t)T, -1), badlen((size_t)T, 0);
+        auto work = [&](int t) {
+            const int64_t lo = n * t / T, hi = n * (t + 1) / T;
+            for (int64_t i = lo; i < hi; i++) {
+                const int64_t L = off[i + 1] - off[i];
+                if (L < 0 || L > MIRGE_MAX_READ_LEN) { if (bad[t] < 0) { bad[t] = i; badlen[t] = L; } continue; }
+                hist[t][L]++;
+                bool amb = false;
+                for (int64_t b = off[i]; b < off[i + 1]; b++) amb |= !is_acgt[(unsigned char)ascii[b]];
+                part[(size_t)t * MIRGE_NGROUPS + width_class(L) + (amb ? 3 : 0)].push_back((uint32_t)i);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; t++) {
+            if (bad[t] >= 0) {
+                if (badlen[t] < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
+                return fail(-6, "read " + std::to_string(bad[t]) + " is " + std::to_string(badlen[t]) + " nt; the limit is " +
+                                std::to_string(MIRGE_MAX_READ_LEN));
+            }
+            for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) R->len_hist[L] += hist[t][L];
+        }
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {  // thread ranges are consecutive: order is preserved
+            size_t tot = 0;
+            for (int t = 0; t < T; t++) tot += part[(size_t)t * MIRGE_NGROUPS + gi].size();
+            idx[gi].reserve(tot);
+            for (int t = 0; t < T; t++) {
+                auto& v = part[(size_t)t * MIRGE_NGROUPS + gi];
+                idx[gi].insert(idx[gi].end(), v.begin(), v.end());
+            }
+        }
+    }
+    R->hist_valid = true;
+    R->total_bases = n ? off[n] - off[0] : 0;
+    const int64_t nbytes = R->total_bases;
+    uint8_t* dascii = nullptr; int64_t* doff = nullptr; uint32_t* dflags = nullptr;
+    CHECK(dalloc(c, &dascii, (size_t)std::max<int64_t>(nbytes, 1)));
+    CHECK(dalloc(c, &doff, (size_t)n + 1));
+    CHECK(dalloc(c, &dflags, 16));
+    std::vector<int64_t> rel((size_t)n + 1);
+    for (int64_t i = 0; i <= n; i++) rel[(size_t)i] = off[i] - off[0];
+    if (nbytes) HIPOK(hipMemcpyAsync(dascii, ascii + off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(doff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemsetAsync(dflags, 0, 64, c->stream));
+    uint32_t* didx[MIRGE_NGROUPS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        ReadGroup& g = R->g[gi];
+        g.W = kGroupW[gi];
+        g.n = (uint32_t)idx[gi].size();
+        if (!g.n) continue;
+        CHECK(dalloc(c, &g.seq, (size_t)g.W * g.n));
+        CHECK(dalloc(c, &g.nmask, (size_t)g.W * g.n));
+        CHECK(dalloc(c, &g.len, (size_t)g.n));
+        CHECK(dalloc(c, &g.orig, (size_t)g.n));
+        HIPOK(hipMemcpyAsync(g.orig, idx[gi].data(), (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream));
+        didx[gi] = g.orig;
+        if (kGroupW[gi] == 1) launch_pack<1>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
+        else if (kGroupW[gi] == 2) launch_pack<2>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
+        else launch_pack<4>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
+    }
+    HIPOK(hipMemcpyAsync(c->pinned, dflags, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));  // idx/rel host vectors are read by the async copies
+    c->release(dascii); c->release(doff); c->release(dflags);
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        if (c->pinned[2 * gi + 1]) {
+            mirge_reads_destroy(R.release());
+            return fail(-7, "a read contains a character other than A/C/G/T/U/N");
+        }
+        if (!c->pinned[2 * gi] && R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
+    }
+    *out = R.release();
+    return 0;
+}
+
+// Sequence text -> packed reads, parsed on the device (k_nl_count / k_nl_mark / k_seq_class / k_seq_place, then
+// k_pack straight from the text).  format: 1 = FASTQ (4-line records), 2 = FASTA (one sequence line per record),
+// 3 = one sequence per line, 0 = by the first byte ('@', '>', else 3).  Reads shorter than min_len are dropped
+// (digest.py:348,368); *n_records = records seen before the filter (digest.py:326 `count`).
+extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                                 mirge_reads** out, int64_t* n_records) {
+    if (!c || !out || nbytes < 0 || (nbytes > 0 && !text) || format < 0 || format > 3)
+        return fail(-1, "mirge_reads_parse: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    if (format == 0) format = nbytes == 0 ? 3 : (text[0] == '@' ? 1 : (text[0] == '>' ? 2 : 3));
+    const int period = format == 1 ? 4 : (format == 2 ? 2 : 1), sphase = format == 3 ? 0 : 1;
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = 0;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    R->hist_valid = true;
+    R->total_bases = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
+    if (n_records) *n_records = 0;
+    if (nbytes == 0) { *out = R.release(); return 0; }
+    // the text, with a final newline if the file has none
+    const bool add_nl = text[nbytes - 1] != '\n';
+    const uint64_t n = (uint64_t)nbytes + (add_nl ? 1 : 0);
+    const uint32_t ntile = (uint32_t)((n + MIRGE_PARSE_TILE - 1) / MIRGE_PARSE_TILE);
+    uint8_t* dtext = nullptr;
+    uint32_t *tile_cnt = nullptr, *tile_off = nullptr;
+    CHECK(dalloc(c, &dtext, (size_t)n + 16));
+    CHECK(dalloc(c, &tile_cnt, (size_t)ntile + 1));
+    CHECK(dalloc(c, &tile_off, (size_t)ntile + 1));
+    HIPOK(hipMemcpyAsync(dtext, text, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    if (add_nl) HIPOK(hipMemsetAsync(dtext + nbytes, '\n', 1, c->stream));
+    HIPOK(hipMemsetAsync(tile_cnt + ntile, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_nl_count, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_cnt);
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIPOK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, tile_cnt, tile_off, (int)(ntile + 1), c->stream));
+    size_t tmp_cap = std::max<size_t>(tmp_bytes, 1 << 16);
+    CHECK(dalloc(c, (uint8_t**)&tmp, tmp_cap));
+    HIPOK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, tile_cnt, tile_off, (int)(ntile + 1), c->stream));
+    uint32_t n_lines = 0;
+    HIPOK(hipMemcpyAsync(&n_lines, tile_off + ntile, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    // sequence lines: li in [0, n_lines) with li % period == sphase
+    const uint64_t n_seq64 = n_lines > (uint32_t)sphase ? ((uint64_t)n_lines - sphase + period - 1) / period : 0;
+    int rc = n_seq64 >= 0xFFFFFFF0ull ? fail(-5, "more than 2^32 reads in one set is not supported") : 0;
+    const uint32_t n_seq = rc ? 0u : (uint32_t)n_seq64;
+    if (n_records) *n_records = n_seq;
+    int64_t *dstart = nullptr, *dend = nullptr;
+    uint8_t* dcls = nullptr;
+    uint32_t *blk = nullptr, *blk_off = nullptr, *keep = nullptr, *keep_off = nullptr, *dmeta = nullptr, *src_all = nullptr,
+             *orig_all = nullptr;
+    const uint32_t nblk = std::max<uint32_t>(1, (n_seq + MIRGE_BLOCK - 1) / MIRGE_BLOCK);
+    const size_t meta_words = 8 + MIRGE_MAX_READ_LEN + 1;  // [0..2] flags, [8..] length histogram
+    do {
+        if (!n_seq) break;
+        if ((rc = dalloc(c, &dstart, (size_t)n_seq))) break;
+        if ((rc = dalloc(c, &dend, (size_t)n_seq))) break;
+        if ((rc = dalloc(c, &dcls, (size_t)n_seq))) break;
+        if ((rc = dalloc(c, &blk, (size_t)6 * nblk + 1))) break;
+        if ((rc = dalloc(c, &blk_off, (size_t)6 * nblk + 1))) break;
+        if ((rc = dalloc(c, &keep, (size_t)nblk + 1))) break;
+        if ((rc = dalloc(c, &keep_off, (size_t)nblk + 1))) break;
+        if ((rc = dalloc(c, &dmeta, meta_words))) break;
+        hipError_t e = hipMemsetAsync(dmeta, 0, meta_words * 4, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(blk + (size_t)6 * nblk, 0, 4, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(keep + nblk, 0, 4, c->stream);
+        if (e != hipSuccess) { rc = fail(-2, hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL(k_nl_mark, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_off, period, sphase, dstart, dend,
+                           (uint64_t)n_seq);
+        hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dtext, dstart, dend, n_seq, min_len, dcls, blk,
+                           keep, nblk, dmeta + 8, dmeta);
+        size_t need = 0;
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, blk, blk_off, (int)(6 * nblk + 1), c->stream);
+        if (e == hipSuccess && need > tmp_cap) { c->release(tmp); tmp = nullptr; tmp_cap = need; if ((rc = dalloc(c, (uint8_t**)&tmp, tmp_cap))) break; }
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need, blk, blk_off, (int)(6 * nblk + 1), c->stream);
+        size_t need2 = tmp_cap;
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need2, keep, keep_off, (int)(nblk + 1), c->stream);
+        // group bounds = blk_off at the first block of every class, and the total
+        uint32_t bounds[7];
+        for (int q = 0; q < 6 && e == hipSuccess; q++)
+            e = hipMemcpyAsync(&bounds[q], blk_off + (size_t)q * nblk, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&bounds[6], blk_off + (size_t)6 * nblk, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->pinned, dmeta, meta_words * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_reads_parse: ") + hipGetErrorString(e)); break; }
+        if (c->pinned[1]) { rc = fail(-6, "a read is " + std::to_string(c->pinned[2]) + " nt; the limit is " + std::to_string(MIRGE_MAX_READ_LEN)); break; }
+        if (c->pinned[0]) { rc = fail(-7, "a read contains a character other than A/C/G/T/U/N"); break; }
+        const uint32_t kept = bounds[6];
+        R->n = kept;
+        for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
+            R->len_hist[L] = (int32_t)c->pinned[8 + L];
+            R->total_bases += (int64_t)L * c->pinned[8 + L];
+        }
+        if (!kept) break;
+        if ((rc = dalloc(c, &src_all, (size_t)kept))) break;
+        if ((rc = dalloc(c, &orig_all, (size_t)kept))) break;
+        hipLaunchKernelGGL(k_seq_place, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dcls, n_seq, blk_off, keep_off, nblk, src_all,
+                           orig_all);
+        uint32_t* dflags = dmeta;  // reused: k_pack's per-group (saw N, bad byte) pairs
+        e = hipMemsetAsync(dflags, 0, 64, c->stream);
+        for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0 && e == hipSuccess; gi++) {
+            ReadGroup& g = R->g[gi];
+            g.n = bounds[gi + 1] - bounds[gi];
+            if (!g.n) continue;
+            if ((rc = dalloc(c, &g.seq, (size_t)g.W * g.n))) break;
+            if ((rc = dalloc(c, &g.nmask, (size_t)g.W * g.n))) break;
+            if ((rc = dalloc(c, &g.len, (size_t)g.n))) break;
+            if ((rc = dalloc(c, &g.orig, (size_t)g.n))) break;
+            e = hipMemcpyAsync(g.orig, orig_all + bounds[gi], (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream);
+            const uint32_t* src = src_all + bounds[gi];
+            if (kGroupW[gi] == 1) launch_pack<1>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
+            else if (kGroupW[gi] == 2) launch_pack<2>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
+            else launch_pack<4>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
+        }
+        if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (rc == 0 && e != hipSuccess) rc = fail(-2, std::string("mirge_reads_parse: ") + hipGetErrorString(e));
+        if (rc == 0)
+            for (int gi = 0; gi < 3; gi++)  // the groups without an ambiguous call carry no mask
+                if (R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(dtext); c->release(tile_cnt); c->release(tile_off); c->release(tmp); c->release(dstart); c->release(dend);
+    c->release(dcls); c->release(blk); c->release(blk_off); c->release(keep); c->release(keep_off); c->release(dmeta);
+    c->release(src_all); c->release(orig_all);
+    if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    *out = R.release();
+    return 0;
+}
+
+
+extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* ascii_out, int64_t* off_out) {
+    if (!c || !R || !off_out || (R->total_bases > 0 && !ascii_out)) return fail(-1, "mirge_reads_unpack: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    const int64_t n = R->n;
+    int32_t* dlen = nullptr;
+    CHECK(dalloc(c, &dlen, (size_t)std::max<int64_t>(n, 1)));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = R->g[gi];
+        if (!g.n) continue;
+        LaunchScope ls(c, "k_scatter_len", g.n);
+        hipLaunchKernelGGL(k_scatter_len, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                           g.len, g.n, g.base, g.orig, dlen);
+    }
+    std::vector<int32_t> hlen((size_t)std::max<int64_t>(n, 1));
+    if (n) HIPOK(hipMemcpyAsync(hlen.data(), dlen, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    off_out[0] = 0;
+    for (int64_t i = 0; i < n; i++) off_out[i + 1] = off_out[i] + hlen[(size_t)i];
+    const int64_t total = off_out[n];
+    int64_t* doff = nullptr; uint8_t* dout = nullptr;
+    CHECK(dalloc(c, &doff, (size_t)n + 1));
+    CHECK(dalloc(c, &dout, (size_t)std::max<int64_t>(total, 1)));
+    HIPOK(hipMemcpyAsync(doff, off_out, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = R->g[gi];
+        if (!g.n) continue;
+        LaunchScope ls(c, "k_unpack", g.n);
+        if (kGroupW[gi] == 1) hipLaunchKernelGGL(k_unpack<1>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(g), doff, g.base, g.orig, dout);
+        else if (kGroupW[gi] == 2) hipLaunchKernelGGL(k_unpack<2>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<2>(g), doff, g.base, g.orig, dout);
+        else hipLaunchKernelGGL(k_unpack<4>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<4>(g), doff, g.base, g.orig, dout);
+    }
+    if (total) HIPOK(hipMemcpyAsync(ascii_out, dout, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    c->release(dlen); c->release(doff); c->release(dout);
+    return 0;
+}
+
+extern "C" int mirge_reads_set_counts(mirge_ctx* c, mirge_reads* R, const uint32_t* counts, int32_t S) {
+    if (!c || !R || !counts || S < 1) return fail(-1, "mirge_reads_set_counts: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    // counts are in handle order; each group wants its rows contiguous -> gather on the host
+    // through the group's orig list (small: U x S)
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        ReadGroup& g = R->g[gi];
+        if (!g.n) continue;
+        std::vector<uint32_t> horig(g.n);
+        if (g.orig) { HIPOK(hipMemcpyAsync(horig.data(), g.orig, (size_t)g.n * 4, hipMemcpyDeviceToHost, c->stream)); HIPOK(hipStreamSynchronize(c->stream)); }
+        else for (uint32_t j = 0; j < g.n; j++) horig[j] = g.base + j;
+        std::vector<uint32_t> rows((size_t)g.n * S);
+        for (uint32_t j = 0; j < g.n; j++)
+            std::memcpy(&rows[(size_t)j * S], &counts[(size_t)horig[j] * S], (size_t)S * 4);
+        c->release(g.counts); g.counts = nullptr;
+        CHECK(dalloc(c, &g.counts, (size_t)g.n * S));
+        HIPOK(hipMemcpyAsync(g.counts, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+    }
+    R->n_samples = S;
+    return 0;
+}
