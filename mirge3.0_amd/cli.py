@@ -5,7 +5,8 @@
 Same flag names as the reference (``mirge/libs/parse.py``) for what is implemented; flags of
 subsystems that are out of scope (novel miRNA, GFF, BAM, tRF, A-to-I, DESeq2, miREC, adapter
 trimming, -qumi) are rejected instead of being ignored.  Writes the reference's files: ``run.log``,
-``mapped.csv``, ``unmapped.csv``, ``miR.Counts.csv``, ``miR.RPM.csv``, ``annotation.report.csv/html``.
+``mapped.csv``, ``unmapped.csv``, ``miR.Counts.csv``, ``miR.RPM.csv``, ``annotation.report.csv/html``
+(+ ``isomirs.csv`` / ``isomirs.samples.csv`` with ``-ie``).
 
 One process: all samples on one GPU, byte-compatible outputs.  Under ``torch.distributed.run`` with N
 ranks: samples are sharded one per GPU (multigpu.py), rank 0 writes the three tables; the per-read
@@ -48,9 +49,11 @@ def parse_args(argv=None):
                     help="with -umi: count distinct UMI-tagged reads per insert (writes <sample>_umiCounts.csv)")
     ap.add_argument("-tcf", "--tcf-out", dest="tcf_out", action="store_true",
                     help="write <sample>.trim.collapse.fa")
+    ap.add_argument("-ie", "--isoform-entropy", dest="isoform_entropy", action="store_true",
+                    help="write isomirs.csv and isomirs.samples.csv (isomiR RPMs and entropies)")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted, unused (GPU path)")
     ap.add_argument("--device", type=int, default=None)
-    for flag in ("-a", "-g", "-qumi", "-nmir", "-gff", "-bam", "-trf", "-ai", "-ie", "-mEC", "-dex"):
+    for flag in ("-a", "-g", "-qumi", "-nmir", "-gff", "-bam", "-trf", "-ai", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
     args = ap.parse_args(argv)

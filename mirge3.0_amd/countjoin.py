@@ -98,7 +98,8 @@ def finish_tables(class_sums: np.ndarray, exact: np.ndarray, iso: np.ndarray, mi
     summary = summary.reindex(columns=colRearrange)
     summary.index.name = "Sample name(s)"
     out = dict(counts=mirCounts_completeSet, rpm=mirRPM_completeSet, summary=summary,
-               class_sums={c: class_sums[p] for c, p in classes}, raw=(class_sums, exact, iso))
+               class_sums={c: class_sums[p] for c, p in classes}, raw=(class_sums, exact, iso),
+               filtered=Filtered_miRNA_Reads)
     if workDir is not None:
         mirCounts_completeSet.to_csv(Path(workDir) / "miR.Counts.csv")
         mirRPM_completeSet.to_csv(Path(workDir) / "miR.RPM.csv")
@@ -108,6 +109,83 @@ def finish_tables(class_sums: np.ndarray, exact: np.ndarray, iso: np.ndarray, mi
         with open(Path(workDir) / "annotation.report.html", 'w') as f:
             f.write(html.to_html(index=False))
     return out
+
+
+def _calc_entropy(values) -> float:
+    """``calcEntropy`` (summary.py:906-913): Shannon entropy in bits over the entries greater than ONE."""
+    import math
+    total = sum(values)
+    e = 0
+    for v in values:
+        if v > 1:
+            f = float(v) / total
+            e = e + -1 * f * math.log(f, 2)
+    return e
+
+
+def isomir_entropy_tables(pdMapped, base_names, Filtered_miRNA_Reads, workDir):
+    """``-ie`` (``create_ie``, summary.py:915-1021): ``isomirs.csv`` (one line per isomiR sequence: RPM per sample and
+    its across-sample entropy, tab separated under a comma separated header, as the reference writes it) and
+    ``isomirs.samples.csv`` (per miRNA and sample: entropy of isomiRs + canonical, canonical share, canonical RPM,
+    top isomiR RPM).  Input: the mapped rows with their 'exact miRNA' / 'isomiR miRNA' names and sample counts."""
+    import math
+    base_names = list(base_names)
+    seqs = [str(x) for x in pdMapped.index]
+    cnt = pdMapped[base_names].to_numpy(dtype=np.int64).tolist()
+    exact = pdMapped['exact miRNA'].tolist()
+    iso = pdMapped['isomiR miRNA'].tolist()
+    freq_list = []
+    for fname in base_names:
+        try:
+            freq_list.append(1000000 / Filtered_miRNA_Reads[fname])
+        except ZeroDivisionError:
+            freq_list.append(0)
+    maxEntropy = math.log(len(base_names), 2)
+
+    def strip_snp(name):
+        return name.split('.')[0] if ".SNP" in name else name
+
+    miR_can: Dict[str, list] = {}
+    for i, nm in enumerate(exact):
+        if nm:
+            miR_can.setdefault(strip_snp(nm), []).append(cnt[i])
+    for k, v in miR_can.items():
+        miR_can[k] = [sum(col) for col in zip(*v)]
+    lines1 = ['miRNA,sequence' + ''.join(',' + b for b in base_names) + ',Entropy\n']
+    miR_iso: Dict[str, list] = {}
+    for i, nm in enumerate(iso):
+        if not nm:
+            continue
+        vals = cnt[i]
+        entropy = "NA" if maxEntropy == 0 else str(_calc_entropy(vals) / maxEntropy)
+        rpm = "\t".join(str(v * freq_list[k]) for k, v in enumerate(vals))
+        name = strip_snp(nm)
+        miR_iso.setdefault(name, []).append(vals)
+        lines1.append(name + "\t" + seqs[i] + "\t" + rpm + "\t" + entropy + "\n")
+    hdr2 = 'miRNA'
+    for b in base_names:
+        hdr2 += ',' + b + ' isomir+miRNA Entropy' + ',' + b + ' Canonical Sequence' + ',' + b + ' Canonical RPM' + ',' + b + ' Top Isomir RPM'
+    lines2 = [hdr2 + '\n']
+    for name, rows in miR_iso.items():
+        out = [name]
+        for k, col in enumerate(zip(*rows)):
+            vals = list(col)
+            top = max(vals) * freq_list[k]
+            iso_sum = sum(vals) * freq_list[k]
+            if name in miR_can:
+                can_rpm = miR_can[name][k] * freq_list[k]
+                e = _calc_entropy(vals + [miR_can[name][k]])
+                out.append(str(e / (math.log(len(vals), 2))) if len(vals) > 1 else 'NA')
+                combined = can_rpm + iso_sum
+                out.append(str(100.0 * can_rpm / combined) if combined > 0 else 'NA')
+                out.append(str(can_rpm))
+                out.append(str(top))
+        if len(out) > 1:
+            lines2.append(','.join(out) + '\n')
+    with open(Path(workDir) / "isomirs.csv", 'w') as fh:
+        fh.write("".join(lines1))
+    with open(Path(workDir) / "isomirs.samples.csv", 'w') as fh:
+        fh.write("".join(lines2))
 
 
 def summarize_device(ctx: _ffi.Context, uniq: _ffi.DeviceReads, res: _ffi.CascadeResult, mirna: Library,
@@ -150,6 +228,9 @@ def summarize(args, workDir, ref_db, base_names, pdMapped, sampleReadCounts, tri
     mirna = casc.libs["mirna"]
     cls, ex, iso = _ffi.count_join_host(ctx, ps, ref, counts.astype(np.uint32), casc.n_pass, EXACT_PASS, ISO_PASS,
                                         len(mirna))
-    return finish_tables(cls, ex, iso, mirna, load_merges(str(args.libraries_path), args.organism_name, ref_db),
-                         list(base_names), sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique,
-                         float(args.crThreshold), bool(args.spikeIn), workDir)
+    out = finish_tables(cls, ex, iso, mirna, load_merges(str(args.libraries_path), args.organism_name, ref_db),
+                        list(base_names), sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique,
+                        float(args.crThreshold), bool(args.spikeIn), workDir)
+    if getattr(args, "isoform_entropy", False) and workDir is not None:  # -ie
+        isomir_entropy_tables(pdMapped, base_names, out["filtered"], workDir)
+    return out

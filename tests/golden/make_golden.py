@@ -185,7 +185,7 @@ def run_case(case, seed, n_raw, n_samples, spike_in):
     args = SimpleNamespace(threads=2, bowtie_path=os.path.join(HERE, "fake_bowtie"), bowtieVersion="True",
                            quiet=True, bam_out=False, tRNA_frag=False, spikeIn=bool(spike_in),
                            organism_name=ORG, libraries_path=libdir, crThreshold="0.1", gff_out=False,
-                           isoform_entropy=False, AtoI=False)
+                           isoform_entropy=True, AtoI=False)  # -ie: isomirs.csv, isomirs.samples.csv (summary.py:906-1032)
     # inputs
     df[base_names].to_csv(os.path.join(out_dir, "collapsed_input.csv"))
     with open(os.path.join(out_dir, "counters.csv"), "w") as fh:
@@ -199,7 +199,8 @@ def run_case(case, seed, n_raw, n_samples, spike_in):
     summarize(args, work, DB, base_names, pdMapped, src, trimmed, uniq)
     pdMapped.to_csv(os.path.join(work, "mapped.csv"))
     pdUnmapped.to_csv(os.path.join(work, "unmapped.csv"))
-    for f in ("mapped.csv", "unmapped.csv", "annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+    for f in ("mapped.csv", "unmapped.csv", "annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv",
+              "isomirs.samples.csv"):
         shutil.copy(os.path.join(work, f), os.path.join(out_dir, f))
     shutil.rmtree(tmp)
     print(case, "rows", len(df), "mapped", len(pdMapped), "->", out_dir)

@@ -80,7 +80,7 @@ def test_golden_dropin_signatures(name, tmp_path):
     case = GoldenCase(name)
     args = SimpleNamespace(threads=1, bowtie_path=None, bowtieVersion="True", quiet=True, bam_out=False,
                            tRNA_frag=False, spikeIn=case.spike, organism_name=ORG, libraries_path=case.libdir,
-                           crThreshold="0.1", gff_out=False, isoform_entropy=False, AtoI=False)
+                           crThreshold="0.1", gff_out=False, isoform_entropy=True, AtoI=False)
     df = pd.DataFrame(case.counts, columns=case.samples, index=pd.Index(case.seqs, name="Sequence"))
     df = df.assign(**dict.fromkeys(PASS_COLS, ''))
     df = df.assign(annotFlag=0).reindex(columns=['annotFlag'] + PASS_COLS + case.samples)
@@ -92,7 +92,7 @@ def test_golden_dropin_signatures(name, tmp_path):
     assert (tmp_path / "unmapped.csv").read_text() == case.text("unmapped.csv")
     summarize(args, str(tmp_path), DB, case.samples, mapped, case.sample_read_counts, case.trimmed,
               case.trimmed_unique)
-    for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+    for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv", "isomirs.samples.csv"):
         assert (tmp_path / f).read_text() == case.text(f), f
 
 

@@ -123,10 +123,10 @@ def test_cli_flags_in_and_out_of_scope():
     """Flag names of mirge/libs/parse.py: hot-path flags parse, other subsystems' flags are refused."""
     from mirge3_amd.cli import parse_args
     base = ["-s", "a.fq", "-lib", "/x", "-on", "human"]
-    a = parse_args(base + ["-umi", "4,4", "-udd", "-tcf", "-spk", "-m", "18"])
-    assert a.uniq_mol_ids == "4,4" and a.umiDedup and a.tcf_out and a.spikeIn and a.minimum_length == 18
+    a = parse_args(base + ["-umi", "4,4", "-udd", "-tcf", "-spk", "-m", "18", "-ie"])
+    assert a.uniq_mol_ids == "4,4" and a.umiDedup and a.tcf_out and a.spikeIn and a.minimum_length == 18 and a.isoform_entropy
     assert a.adapters is None and a.qiagenumi is None
-    for bad in (["-udd"], ["-qumi"], ["-a", "illumina"], ["-gff"], ["-bam"], ["-trf"], ["-ai"], ["-nmir"]):
+    for bad in (["-udd"], ["-qumi"], ["-a", "illumina"], ["-gff"], ["-bam"], ["-trf"], ["-ai"], ["-nmir"], ["-mEC"]):
         with pytest.raises(SystemExit):
             parse_args(base + bad)
 
@@ -140,3 +140,18 @@ def test_umi_split_matches_python_slices():
         pure, tag = fs.umi_split(f, b)
         exp = [oracle.umi_parser(s, f, b) for s in seqs]
         assert pure.to_list() == [e[0] for e in exp] and tag.to_list() == [e[1] for e in exp]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_isomir_entropy_tables_equal_the_reference(name, tmp_path):
+    """-ie: isomirs.csv / isomirs.samples.csv from the reference's own mapped.csv must come out byte-identical to
+    what the reference's create_ie wrote (summary.py:915-1021; tests/golden made with isoform_entropy=True)."""
+    import pandas as pd
+    from mirge3_amd.countjoin import isomir_entropy_tables
+    case = GoldenCase(name)
+    mapped = pd.read_csv(os.path.join(case.dir, "mapped.csv"), index_col=0, keep_default_na=False)
+    counts = pd.read_csv(os.path.join(case.dir, "miR.Counts.csv"), index_col=0)
+    filtered = counts[case.samples].sum(axis=0).to_dict()  # Filtered miRNA Reads (summary.py:766)
+    isomir_entropy_tables(mapped, case.samples, filtered, tmp_path)
+    for f in ("isomirs.csv", "isomirs.samples.csv"):
+        assert (tmp_path / f).read_text() == case.text(f), f
