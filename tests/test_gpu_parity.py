@@ -484,6 +484,32 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
 
 
+def test_bench_single_gpu_line(tmp_path):
+    """bench.py at N = 1 on a small configuration: the ONE JSON line with the contract's fields, the oracle-checked
+    sample, the roofline object of the dominant kernel and the two host-inclusive paths."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--reads", "400000", "--scale", "ci",
+           "--pmc", "0"]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="8"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["vs_baseline"] is None and d["dtype"] == "u64"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-5
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert d["parity_on_cpu_sample"] is True and d["fastq_text_path"]["same_counts_as_step"] is True
+
+
 def test_variant_tally_vs_oracle(ctx):
     """Config-5 primitive: accepted / canonical / per-position base-change census of the miRNA reads,
     GPU (mirge_variant_tally) vs the string restatement of judgeAllign + A2IEditing's counting loop."""
