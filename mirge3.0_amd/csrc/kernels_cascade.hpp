@@ -216,8 +216,13 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
 #ifndef MIRGE_PASS_MIN_WAVES
 #define MIRGE_PASS_MIN_WAVES 1
 #endif
+#ifdef MIRGE_PASS_SGPRS
+#define MIRGE_PASS_ATTR __attribute__((amdgpu_num_sgpr(MIRGE_PASS_SGPRS)))
+#else
+#define MIRGE_PASS_ATTR
+#endif
 template <int W, int SLOT>
-__global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES)
+__global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES) MIRGE_PASS_ATTR
 k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __restrict__ plan, GroupView<W> g,
        const uint32_t* __restrict__ act_in,
        const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,

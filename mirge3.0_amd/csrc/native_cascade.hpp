@@ -100,9 +100,13 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     // must be resident at once: a grid of 8 per CU ran the workgroups that did not fit as a second round on an
     // almost empty machine (average occupancy 47 %, SQ_WAVE_CYCLES; -20 % kernel time with the right grid).
     // Measured on MI355X (tools/occ_sweep.sh, profiles/README.md): kernel time falls up to 6 workgroups per CU
-    // and jumps back by 30 % at 7 and beyond -- for the 69-VGPR build and for 57/63-VGPR builds alike, so the
-    // cliff is not the register file although hipOccupancyMaxActiveBlocksPerMultiprocessor reports 7.  The grid
-    // is therefore min(occupancy query, register bound, 6) per CU.  MIRGE_WG_PER_CU overrides (sweeps).
+    // and jumps back by 30 % at 7 and beyond -- for the 69-VGPR build and for 57/63-VGPR builds alike, although
+    // hipOccupancyMaxActiveBlocksPerMultiprocessor reports 7.  The limiter is the scalar register file: k_pass
+    // holds its library view / policy / pointers in ~104 SGPRs (+ VCC etc.), 6 such waves fit a SIMD; builds
+    // capped with amdgpu_num_sgpr(96) / (80) move the cliff to 8 / 9 workgroups, but the extra waves buy
+    // nothing here (the heavy passes are sector-bound) and the SGPR spills cost a little.  The runtime reports
+    // VGPRs only, hence the explicit 6: grid = min(occupancy query, register bound, 6) per CU.
+    // MIRGE_WG_PER_CU overrides (sweeps).
     static int wg_per_cu[5] = {0, 0, 0, 0, 0};
     if (!wg_per_cu[W]) {
         int nb = 0;
