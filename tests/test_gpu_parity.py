@@ -156,6 +156,22 @@ def test_bowtie_shim_process_boundary(tmp_path):
     assert (tmp_path / "unmapped.csv").read_text() == case.text("unmapped.csv")
 
 
+def test_bowtie_crosscheck_harness(tmp_path):
+    """tools/bowtie_crosscheck.py pins the predicate against a real bowtie wherever one is installed.  None is here:
+    the harness itself (argv strings, FASTA naming, SAM parsing, per-pass comparison) is exercised against the shim,
+    and against a real bowtie when MIRGE_BOWTIE_DIR (or PATH) has one."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    shim = os.path.join(os.path.dirname(os.path.abspath(mirge3_amd.__file__)), "shim")
+    real = os.environ.get("MIRGE_BOWTIE_DIR") or (os.path.dirname(shutil.which("bowtie-build")) if shutil.which("bowtie-build") else None)
+    for d in [shim] + ([real] if real else []):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "bowtie_crosscheck.py"), "--bowtie-dir", d, "--synthetic", "4000"],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "membership identical in every pass" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------- oracle on seeded inputs
 def test_cascade_vs_oracle_ci_scale(ctx, ci_libs, ci_cascade):
     reads = synth.make_reads(ci_libs, 60000, seed=5, n_frac=0.01)
