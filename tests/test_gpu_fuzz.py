@@ -36,7 +36,12 @@ def _policy(rng):
     return pol
 
 
-@pytest.mark.parametrize("seed", range(16))
+# MIRGE_FUZZ_SEEDS=N widens the sweep for a one-off soak (default 16 cascades)
+import os  # noqa: E402
+N_FUZZ = int(os.environ.get("MIRGE_FUZZ_SEEDS", "16"))
+
+
+@pytest.mark.parametrize("seed", range(N_FUZZ))
 def test_random_cascade_matches_bruteforce(seed):
     rng = np.random.default_rng(1000 + seed)
     ctx = _ffi.Context(0)
