@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])
+    ap.add_argument("--two-calls", type=int, default=0, help="1: mirge_collapse then mirge_cascade_run instead of the one-call path")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     ap.add_argument("--pool", type=int, default=0,
@@ -175,8 +176,11 @@ def main():
     state = {}
 
     def step():
-        uniq = raw.collapse()
-        res = casc.run(uniq)
+        if args.two_calls:
+            uniq = raw.collapse()
+            res = casc.run(uniq)
+        else:
+            uniq, res = casc.collapse_and_run(raw)  # one sample: mirge_collapse_cascade
         cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS if n_pass > ISO_PASS else -2, n_mirna)
         if args.workload == "c5":
             from mirge3_amd import a2i

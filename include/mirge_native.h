@@ -109,6 +109,13 @@ int mirge_reads_set_counts(mirge_ctx* ctx, mirge_reads* reads, const uint32_t* c
  * 0-based offset in that reference, mismatches.                                            */
 int mirge_cascade_run(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib* const* libs,
                       const mirge_policy* policies, int32_t n_pass, mirge_result** out);
+/* mirge_collapse followed by mirge_cascade_run for ONE sample, as one call: the bulk read group's passes are queued on
+ * the GPU behind the collapse kernels before the host has read the unique counts back (the kernels take the count
+ * from device memory), so the GPU does not idle across the collapse's host synchronisation.  Same results; falls
+ * back to the two calls when the bulk group is not on the partitioned key path.  Replaces the baking -> bwtAlign
+ * hand-over of mirge/__main__.py:140-157 for a single sample. */
+int mirge_collapse_cascade(mirge_ctx* ctx, const mirge_reads* raw, const mirge_lib* const* libs, const mirge_policy* policies,
+                           int32_t n_pass, mirge_reads** uniq, int64_t* n_uniq, mirge_result** out);
 int mirge_result_fetch(mirge_ctx* ctx, const mirge_result* res, int8_t* pass_out, int32_t* ref_out,
                        int32_t* off_out, int8_t* mm_out);
 void mirge_result_destroy(mirge_result* res);

@@ -24,7 +24,7 @@ EXPORTS = [
     "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
-    "mirge_reads_set_counts", "mirge_cascade_run", "mirge_result_fetch", "mirge_result_destroy",
+    "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_variant_tally", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
@@ -315,6 +315,18 @@ def cascade_run(ctx: Context, reads: DeviceReads, libs: Sequence[Optional[Device
     h = C.c_void_p()
     _check(load().mirge_cascade_run(ctx._h, reads._h, arr, pol, n_pass, C.byref(h)), "mirge_cascade_run")
     return CascadeResult(ctx, h, reads, n_pass.value)
+
+
+def collapse_cascade(ctx: Context, raw: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],
+                     policies: Sequence[MirgePolicy], prepared=None) -> Tuple[DeviceReads, CascadeResult]:
+    """One sample: collapse + cascade in one call (``mirge_collapse_cascade``) -> (unique reads, annotation)."""
+    arr, pol, n_pass = prepared if prepared is not None else cascade_args(libs, policies)
+    hu, hr = C.c_void_p(), C.c_void_p()
+    nu = C.c_int64()
+    _check(load().mirge_collapse_cascade(ctx._h, raw._h, arr, pol, n_pass, C.byref(hu), C.byref(nu), C.byref(hr)),
+           "mirge_collapse_cascade")
+    uniq = DeviceReads(ctx, hu)
+    return uniq, CascadeResult(ctx, hr, uniq, n_pass.value)
 
 
 def count_join(ctx: Context, uniq: DeviceReads, res: CascadeResult, exact_pass: int, iso_pass: int,

@@ -82,6 +82,11 @@ class Cascade:
     def run(self, reads: _ffi.DeviceReads) -> _ffi.CascadeResult:
         return _ffi.cascade_run(self.ctx, reads, self.dev_libs, self.policies, self._prepared)
 
+    def collapse_and_run(self, raw: _ffi.DeviceReads):
+        """One sample's raw reads -> (unique reads, annotation): collapse and cascade as one call, the bulk group's
+        passes queued behind the collapse kernels without waiting for the host (``mirge_collapse_cascade``)."""
+        return _ffi.collapse_cascade(self.ctx, raw, self.dev_libs, self.policies, self._prepared)
+
     def annotate(self, seqs: FlatSeqs):
         """Convenience: host sequences in, (pass, ref, off, mm) numpy arrays out."""
         dr = _ffi.DeviceReads.pack(self.ctx, seqs)

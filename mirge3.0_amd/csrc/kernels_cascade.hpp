@@ -227,14 +227,24 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
        const uint32_t* __restrict__ act_in,
        const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
        uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
-       int8_t* __restrict__ res_mm) {
+       int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t s_count;
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
-    const size_t seg = (size_t)blockIdx.x * cap;
+    const size_t seg = (size_t)blockIdx.x * cap;  // the workgroup's slice of the survivor arrays
+    // n_dev: the read count is still on the device (a cascade enqueued behind the collapse that produces it, before
+    // the host has read U back): the first pass cuts the U reads into gridDim.x segments itself; `cap`, sized from
+    // the raw read count, only spaces the survivor slices
+    size_t seg_r = seg;
     uint32_t n_in;
     if (act_in) n_in = seg_n_in[blockIdx.x];
-    else n_in = seg < g.n ? (uint32_t)((g.n - seg) < cap ? (g.n - seg) : cap) : 0u;
+    else {
+        const uint32_t ntot = n_dev ? *n_dev : g.n;
+        uint32_t cap_r = cap;
+        if (n_dev) cap_r = ((ntot + gridDim.x - 1) / gridDim.x + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
+        seg_r = (size_t)blockIdx.x * cap_r;
+        n_in = seg_r < ntot ? (uint32_t)((ntot - seg_r) < cap_r ? (ntot - seg_r) : cap_r) : 0u;
+    }
     const int lane = threadIdx.x & 63;
     for (uint32_t base = 0; base < n_in; base += MIRGE_BLOCK) {
         const uint32_t t = base + threadIdx.x;
@@ -242,7 +252,7 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
         bool survivor = false;
         uint32_t idx = 0;
         if (valid) {
-            idx = act_in ? act_in[seg + t] : (uint32_t)seg + t;
+            idx = act_in ? act_in[seg + t] : (uint32_t)seg_r + t;
             survivor = true;
         }
         // the wave aligns its 64 reads together (align_hybrid balances the candidate lists)
@@ -302,7 +312,9 @@ __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint3
 }
 
 __global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, const uint32_t* __restrict__ res_pos,
-                          uint32_t n, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off) {
+                          uint32_t n, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off,
+                          const uint32_t* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int p = res_pass[i];
         int32_t ref = -1, off = -1;

@@ -17,6 +17,7 @@ struct mirge_result {
     int32_t n_pass = 0;
     ResGroup g[MIRGE_NGROUPS];
     const mirge_reads* reads = nullptr;  // borrowed: orig/base mapping (must outlive the fetch)
+    uint32_t* dmeta = nullptr;           // mirge_collapse_cascade: the device-side read counts its kernels read
 };
 
 extern "C" void mirge_result_destroy(mirge_result* r) {
@@ -25,6 +26,7 @@ extern "C" void mirge_result_destroy(mirge_result* r) {
         r->ctx->release(g.pass); r->ctx->release(g.pos); r->ctx->release(g.mm);
         r->ctx->release(g.ref); r->ctx->release(g.off);
     }
+    r->ctx->release(r->dmeta);
     delete r;
 }
 
@@ -87,10 +89,13 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
 
 template <int W>
 static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const std::vector<PassStep>& steps,
-                         const mirge_policy* pol, const ResolveTable& rt, const char* gtag) {
-    out.n = rg.n;
-    if (!rg.n) return 0;
-    const uint32_t n = rg.n;
+                         const mirge_policy* pol, const ResolveTable& rt, const char* gtag,
+                         const uint32_t* n_dev = nullptr, uint32_t n_cap = 0) {
+    // n_dev != nullptr: the group's read count is not on the host yet (see k_pass); everything is sized for
+    // n_cap >= the count, the caller fills out.n in later
+    out.n = n_dev ? 0 : rg.n;
+    if (!n_dev && !rg.n) return 0;
+    const uint32_t n = n_dev ? n_cap : rg.n;
     CHECK(dalloc(c, &out.pass, n));
     CHECK(dalloc(c, &out.pos, n));
     CHECK(dalloc(c, &out.mm, n));
@@ -129,6 +134,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->cur));
     HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->cur));
     GroupView<W> v = view_of<W>(rg);
+    if (n_dev) v.n = n;  // only a stride for W > 1; the deferred-count path is the one-word bulk group
     const uint32_t* act_in = nullptr;
     uint32_t* act_out = actA;
     int stage = 0;
@@ -147,7 +153,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
             uint32_t* sn_out = seg_n + (size_t)grid * stage;
 #define MIRGE_LAUNCH_PASS(SLOT)                                                                                       \
     hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, st.lib->view(), mp, st.mi, st.dplan, v, act_in, \
-                       sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm)
+                       sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm, n_dev)
             switch (p) {
                 case 0: MIRGE_LAUNCH_PASS(0); break;
                 case 1: MIRGE_LAUNCH_PASS(1); break;
@@ -170,7 +176,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     {
         std::snprintf(name, sizeof(name), "k_resolve%s", gtag);
         LaunchScope ls(c, name, n);
-        hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->cur, rt, out.pass, out.pos, n, out.ref, out.off);
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->cur, rt, out.pass, out.pos, n, out.ref, out.off, n_dev);
     }
     if (c->profiling && stage > 0) {  // units of a pass = reads it was handed = survivors of the stage before
         // copied now (stream-ordered), summed after the one synchronisation at the end of the call
@@ -302,6 +308,61 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
     return 0;
 }
 
+// (libraries, policies, read lengths present) -> c->casc_steps / casc_rt / casc_dsteps, kept between calls
+static int cascade_config(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass, const int32_t* hist) {
+    // Everything up to the launches depends only on (libraries, policies, read lengths present): it is
+    // kept from the previous call and reused when those are unchanged (~45 us of host time per call otherwise,
+    // on the critical path between the collapse's synchronisation and the first pass)
+    std::string key;
+    key.append(reinterpret_cast<const char*>(&n_pass), sizeof(n_pass));
+    for (int32_t p = 0; p < n_pass; p++) {
+        const uint64_t uid = libs[p] ? libs[p]->uid : 0;
+        key.append(reinterpret_cast<const char*>(&uid), sizeof(uid));
+        key.append(reinterpret_cast<const char*>(&pol[p]), sizeof(mirge_policy));
+    }
+    for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) key.push_back(hist[L] ? 1 : 0);
+    if (c->casc_key != key) {
+        c->casc_key.clear();
+        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, c->casc_steps, c->casc_rt, &c->casc_dsteps));
+        c->casc_key = key;
+    }
+    return 0;
+}
+
+// launches of every group but `skip` (already queued by the caller; -1 = none): small groups first, the bulk last
+static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_result* res, const mirge_policy* pol, int skip) {
+    const std::vector<PassStep>& steps = c->casc_steps;
+    const ResolveTable& rt = c->casc_rt;
+    const FusedSteps* dsteps = c->casc_dsteps;
+    // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests)
+    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 20);
+    int rc = 0;
+    const int big = largest_group(R);
+    CHECK(stream_fork(c));
+    // enqueue order: the small groups first (one fused launch each, or the staged launches if a group is too
+    // large for that), the bulk group last: measured, its 2048-workgroup launches otherwise hold every CU and the
+    // small kernels squeeze in between them, stretching single passes of the bulk group by 30 %
+    int order[MIRGE_NGROUPS], no = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) if (gi != big) order[no++] = gi;
+    order[no++] = big;
+    for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
+        const int gi = order[k];
+        if (gi == skip) continue;
+        c->cur = gi == big ? c->stream : c->aux;
+        if (gi != big && R->g[gi].n <= fused_max) {
+            if (kGroupW[gi] == 1) rc = cascade_group_fused<1>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            else if (kGroupW[gi] == 2) rc = cascade_group_fused<2>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            else rc = cascade_group_fused<4>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            continue;
+        }
+        if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+        else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+    }
+    { int jr = stream_join(c); if (rc == 0) rc = jr; }
+    return rc;
+}
+
 extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
                                  const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
     HostClock hc("cascade");
@@ -321,56 +382,82 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
             for (int L = lo; L <= hi; L++) hist[L] = 1;
         }
     }
-    // Everything below up to the launches depends only on (libraries, policies, read lengths present): it is
-    // kept from the previous call and reused when those are unchanged (~45 us of host time per call otherwise,
-    // on the critical path between the collapse's synchronisation and the first pass)
-    std::string key;
-    key.append(reinterpret_cast<const char*>(&n_pass), sizeof(n_pass));
-    for (int32_t p = 0; p < n_pass; p++) {
-        const uint64_t uid = libs[p] ? libs[p]->uid : 0;
-        key.append(reinterpret_cast<const char*>(&uid), sizeof(uid));
-        key.append(reinterpret_cast<const char*>(&pol[p]), sizeof(mirge_policy));
-    }
-    for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) key.push_back(hist[L] ? 1 : 0);
-    if (c->casc_key != key) {
-        c->casc_key.clear();
-        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, c->casc_steps, c->casc_rt, &c->casc_dsteps));
-        c->casc_key = key;
-    }
-    const std::vector<PassStep>& steps = c->casc_steps;
-    const ResolveTable& rt = c->casc_rt;
-    const FusedSteps* dsteps = c->casc_dsteps;
+    CHECK(cascade_config(c, libs, pol, n_pass, hist));
     hc.lap("plans+fused");
-    // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests)
-    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 20);
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
-    int rc = 0;
-    const int big = largest_group(R);
-    CHECK(stream_fork(c));
-    // enqueue order: the small groups first (one fused launch each, or the staged launches if a group is too
-    // large for that), the bulk group last: measured, its 2048-workgroup launches otherwise hold every CU and the
-    // small kernels squeeze in between them, stretching single passes of the bulk group by 30 %
-    int order[MIRGE_NGROUPS], no = 0;
-    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) if (gi != big) order[no++] = gi;
-    order[no++] = big;
-    for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
-        const int gi = order[k];
-        c->cur = gi == big ? c->stream : c->aux;
-        if (gi != big && R->g[gi].n <= fused_max) {
-            if (kGroupW[gi] == 1) rc = cascade_group_fused<1>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
-            else if (kGroupW[gi] == 2) rc = cascade_group_fused<2>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
-            else rc = cascade_group_fused<4>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
-            continue;
-        }
-        if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
-        else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
-        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
-    }
-    hc.lap("enqueue");
-    { int jr = stream_join(c); if (rc == 0) rc = jr; }
-    hc.lap("join");
+    const int rc = cascade_launch_groups(c, R, res.get(), pol, -1);
+    hc.lap("enqueue+join");
     if (rc) { mirge_result_destroy(res.release()); return rc; }
+    *out = res.release();
+    return 0;
+}
+
+// Collapse and cascade of one sample as ONE call: the bulk read group's passes are queued on the GPU right behind
+// the collapse kernels, BEFORE the host has read the unique counts back (the kernels take the count from device
+// memory: k_pass / k_resolve `n_dev`), so the GPU does not idle while the host wakes up, finishes the small groups'
+// collapse and enqueues the cascade (~0.1 ms of a 2 ms step).  Same results as mirge_collapse followed by
+// mirge_cascade_run, which is also what runs when the bulk group is not on the partitioned key path or its
+// partition overflowed (MIRGE_NO_PRESYNC=1 forces that, for A/B).
+extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, const mirge_lib* const* libs, const mirge_policy* pol,
+                                      int32_t n_pass, mirge_reads** uniq, int64_t* n_uniq, mirge_result** out) {
+    if (!c || !raw || !libs || !pol || !uniq || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
+        return fail(-1, "mirge_collapse_cascade: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    static const bool presync_off = std::getenv("MIRGE_NO_PRESYNC") != nullptr;
+    mirge_reads* U = nullptr;
+    if (presync_off || !raw->hist_valid || raw->n == 0) {
+        CHECK(mirge_collapse(c, raw, nullptr, 1, &U, n_uniq));
+        const int rc = mirge_cascade_run(c, U, libs, pol, n_pass, out);
+        if (rc) { mirge_reads_destroy(U); return rc; }
+        *uniq = U;
+        return 0;
+    }
+    // the unique reads have the raw reads' lengths: the cascade can be configured before they exist
+    CHECK(cascade_config(c, libs, pol, n_pass, raw->len_hist));
+    auto res = std::make_unique<mirge_result>();
+    res->ctx = c; res->n_pass = n_pass;
+    const size_t prof_mark = c->prof_pending.size();
+    int hooked_group = -1;
+    CollapseHook hook;
+    hook.pre_sync = [&](mirge_reads* partial, const CollapseTmp*, uint32_t* dmeta, int big) -> int {
+        ReadGroup rg = partial->g[big];  // the unique reads' arrays, allocated for the raw count
+        rg.n = raw->g[big].n;
+        c->cur = c->stream;
+        const int rc = cascade_group<1>(c, rg, res->g[big], c->casc_steps, pol, c->casc_rt, group_tag(big), dmeta + big, raw->g[big].n);
+        if (rc == 0) { hooked_group = big; c->overlap_mode = true; }
+        return rc;
+    };
+    hook.discard = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->aux);
+        c->overlap_mode = false;
+        if (hooked_group >= 0) {
+            ResGroup& g = res->g[hooked_group];
+            c->release(g.pass); c->release(g.pos); c->release(g.mm); c->release(g.ref); c->release(g.off);
+            g = ResGroup();
+        }
+        hooked_group = -1;
+        c->prof_pending.resize(std::min(c->prof_pending.size(), prof_mark));
+        c->flush_deferred();
+    };
+    int rc = collapse_impl(c, raw, nullptr, 1, &U, n_uniq, &hook);
+    if (rc) { c->overlap_mode = false; mirge_result_destroy(res.release()); return rc; }
+    if (!hook.ran) {  // general path or overflow: the ordinary sequence
+        res.reset();
+        rc = mirge_cascade_run(c, U, libs, pol, n_pass, out);
+        if (rc) { mirge_reads_destroy(U); return rc; }
+        *uniq = U;
+        return 0;
+    }
+    res->n = U->n; res->reads = U; res->dmeta = hook.dmeta;
+    res->g[hooked_group].n = U->g[hooked_group].n;
+    for (size_t i = prof_mark; i < c->prof_pending.size(); i++) c->prof_pending[i].n_first = (double)U->g[hooked_group].n;
+    rc = cascade_launch_groups(c, U, res.get(), pol, hooked_group);  // small groups; ends with the join
+    c->overlap_mode = false;
+    c->flush_deferred();
+    if (rc) { (void)hipStreamSynchronize(c->stream); mirge_result_destroy(res.release()); mirge_reads_destroy(U); return rc; }
+    *uniq = U;
     *out = res.release();
     return 0;
 }

@@ -194,8 +194,26 @@ static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
     t = CollapseTmp();
 }
 
+// Work a caller wants on the GPU BEHIND the collapse kernels but before the host has read the unique counts back
+// (mirge_collapse_cascade: the bulk group's cascade).  pre_sync runs after the count read-back has been enqueued;
+// discard must undo it when the partitioned attempt overflowed and everything is redone.
+struct CollapseHook {
+    std::function<int(mirge_reads* partial, const CollapseTmp* tmp, uint32_t* dmeta, int big)> pre_sync;
+    std::function<void()> discard;
+    bool ran = false;         // pre_sync was called and its work stands
+    uint32_t* dmeta = nullptr;  // handed over: the hook's kernels read the counts from it
+};
+
+static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S, mirge_reads** uniq,
+                         int64_t* n_uniq, CollapseHook* hook);
+
 extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
                               mirge_reads** uniq, int64_t* n_uniq) {
+    return collapse_impl(c, raw, sample_ids, S, uniq, n_uniq, nullptr);
+}
+
+static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S, mirge_reads** uniq,
+                         int64_t* n_uniq, CollapseHook* hook) {
     HostClock hc("collapse");
     if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids)) return fail(-1, "mirge_collapse: bad argument");
     HIPOK(hipSetDevice(c->device));
@@ -235,11 +253,19 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         hc.lap("enqueue A");
+        bool hooked = false;
         if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
             hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
+            if (e == hipSuccess) e = hipEventRecord(c->ev_meta, c->stream);
+            if (e == hipSuccess && hook && attempt == 0 && tmp[big].partitioned) {
+                rc = hook->pre_sync(R.get(), tmp, dmeta, big);
+                hooked = rc == 0;
+            }
+            if (e == hipSuccess) e = hipEventSynchronize(c->ev_meta);  // the counts, not whatever was queued behind them
+            if (e != hipSuccess && rc == 0) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
         }
+        if (hooked && (rc != 0 || c->pinned[MIRGE_META_OVERFLOW])) { hook->discard(); hooked = false; }
+        if (hook) hook->ran = hooked;
         if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt == 0) {
             for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
                 collapse_tmp_release(c, tmp[gi]);
@@ -275,7 +301,10 @@ extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_
     }
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
     c->flush_deferred();
-    c->release(dsample); c->release(dmeta);
+    c->release(dsample);
+    if (rc && hook && hook->ran) { hook->discard(); hook->ran = false; }
+    if (hook && hook->ran) hook->dmeta = dmeta;  // still read by the work queued in pre_sync
+    else c->release(dmeta);
     if (rc) { mirge_reads_destroy(R.release()); return rc; }
     R->n = base;
     *uniq = R.release();

@@ -54,7 +54,12 @@ struct mirge_ctx {
     // second stream: the small read groups (long reads, reads with N) run beside the big one.
     // cur = the stream the launch helpers currently target.
     hipStream_t aux = nullptr, cur = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_meta = nullptr;
+    // mirge_collapse_cascade: the bulk group's cascade is already queued on the main stream while the small groups'
+    // collapse tail and cascades are still being enqueued on the second one.  They do not depend on it: no fork
+    // wait (it would serialise them behind ~1.3 ms of kernels), and no pool block goes back into circulation
+    // before the final join (a block still in use on one stream could be handed to the other).
+    bool overlap_mode = false;
     int n_cu = 256;
     // pool
     std::multimap<size_t, void*> free_blocks;
@@ -118,7 +123,8 @@ struct mirge_ctx {
     // stream could be handed it while this stream's kernels still use it
     std::vector<void*> deferred;
     void defer(void* p) { if (p) deferred.push_back(p); }
-    void flush_deferred() { for (void* p : deferred) release(p); deferred.clear(); }
+    // (a no-op while overlap_mode holds every block back, see below)
+    void flush_deferred() { if (overlap_mode) return; for (void* p : deferred) release(p); deferred.clear(); }
     int rec_index(const char* name) {
         auto it = rec_of.find(name);
         if (it != rec_of.end()) return it->second;
@@ -174,6 +180,7 @@ struct LaunchScope {
 // join: the main stream continues only after `aux` has drained.  Buffers handed back to the pool
 // between the two are reused only by work queued after the join, so stream-ordered reuse still holds.
 static int stream_fork(mirge_ctx* c) {
+    if (c->overlap_mode) return 0;
     HIPOK(hipEventRecord(c->ev_fork, c->stream));
     HIPOK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
     return 0;
@@ -239,6 +246,7 @@ extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
     HIPOK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIPOK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPOK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIPOK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
     HIPOK(hipEventCreate(&c->t0));
     HIPOK(hipEventCreate(&c->t1));
     HIPOK(hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault));
@@ -266,6 +274,7 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     for (auto& e : c->fused) (void)hipFree(e.dev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -690,6 +690,63 @@ def test_staged_cascade_for_every_group():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_collapse_cascade_one_call_equals_two_calls(ctx):
+    """mirge_collapse_cascade (the bulk group's passes queued behind the collapse kernels, read count taken from
+    device memory) against mirge_collapse + mirge_cascade_run on the same reads: same unique reads, counts, first
+    indices and per-read annotation.  Sizes on both sides of the partitioned-path threshold, and the overflow
+    fallback (MIRGE_TEST_SMALL_PART) in a fresh process."""
+    import subprocess
+    import sys
+    sl = synth.make_libraries(seed=20260101, scale="small")
+    casc = Cascade(ctx, sl.libs)
+
+    def canon(uniq, res):
+        cnt, first = uniq.counts()
+        order = np.argsort(first, kind="stable")
+        seqs = uniq.unpack().to_list()
+        ann = res.fetch()
+        return [seqs[i] for i in order], cnt[order], first[order], [a[order] for a in ann]
+
+    for n, seed in ((30000, 3), (400000, 4), (1500000, 5)):
+        reads = synth.make_reads_chunked(sl, n, seed=seed) if n > 100000 else synth.make_reads(sl, n, seed=seed, n_frac=0.01)
+        raw = _ffi.DeviceReads.pack(ctx, reads)
+        u1 = raw.collapse(); r1 = casc.run(u1)
+        u2, r2 = casc.collapse_and_run(raw)
+        a, b = canon(u1, r1), canon(u2, r2)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
+        c1 = _ffi.count_join(ctx, u1, r1, 0, 8, len(sl.libs["mirna"]))
+        c2 = _ffi.count_join(ctx, u2, r2, 0, 8, len(sl.libs["mirna"]))
+        assert all(np.array_equal(x, y) for x, y in zip(c1, c2))
+        for h in (r1, r2, u1, u2, raw):
+            h.close()
+    casc.close()
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import mirge3_amd
+from mirge3_amd import _ffi, synth
+from mirge3_amd.cascade import Cascade
+sl = synth.make_libraries(seed=5, scale="ci")
+ctx = _ffi.Context(0)
+casc = Cascade(ctx, sl.libs)
+reads = synth.make_reads_chunked(sl, 600000, seed=2)
+raw = _ffi.DeviceReads.pack(ctx, reads)
+u1 = raw.collapse(); r1 = casc.run(u1)
+u2, r2 = casc.collapse_and_run(raw)   # 64 buckets: the partition overflows, the queued cascade is discarded
+def canon(u, r):
+    cnt, first = u.counts(); o = np.argsort(first, kind="stable"); s = u.unpack().to_list()
+    return [s[i] for i in o], cnt[o], [a[o] for a in r.fetch()]
+a, b = canon(u1, r1), canon(u2, r2)
+assert a[0] == b[0] and np.array_equal(a[1], b[1]) and all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+print("OK", len(a[0]))
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MIRGE_TEST_SMALL_PART="1"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 def test_cli_two_ranks_one_sample_each(tmp_path):
     """The sharded CLI (torch.distributed.run, one sample per rank, rank 0 gathers the per-sample tables over
     gloo and writes the run's CSVs): two ranks on the single GPU of the test box, golden case 2."""
