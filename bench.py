@@ -278,7 +278,7 @@ def main():
 
     # ---------------- the same from the FILE's text (never `value`): FASTQ bytes in host memory -> records parsed,
     # filtered, packed on the GPU -> collapse -> cascade -> count tables on the host
-    if rank == 0 and n_gpus == 1:
+    if rank == 0 and n_gpus == 1 and len(reads) <= 20_000_000:  # the text is built with numpy: ~0.5 KB of host memory per read
         L = reads.lengths
         rec = 2 * L + 6  # "@\n" seq "\n+\n" qual "\n"
         roff = np.zeros(len(reads) + 1, dtype=np.int64)
