@@ -135,3 +135,47 @@ def test_random_collapse_matches_counter(seed, n, S):
         assert [int(x) for x in cnt[i]] == [exp[s].get(r, 0) for s in range(S)], r
         assert int(first[i]) == first_exp[r], r
     uniq.close(); raw.close(); ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(max(6, N_FUZZ // 4)))
+def test_random_text_parses_like_the_host_parser(seed, tmp_path):
+    """mirge_reads_parse on random FASTQ / FASTA / line files (random lengths 0-128, N calls, lower case, CRLF or LF,
+    with or without a final newline, tiles of the newline scan cut at every offset) against the host parser."""
+    from mirge3_amd.collapse import read_fastq_sequences, filter_min_length
+    rng = np.random.default_rng(500 + seed)
+    ctx = _ffi.Context(0)
+    n = int(rng.choice([1, 7, 300, 5000, 40000]))
+    fmt = int(rng.integers(1, 4))
+    eol = "\r\n" if rng.random() < 0.3 else "\n"
+    seqs = []
+    for _ in range(n):
+        L = int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 64, 65, 128])) if rng.random() < 0.2 else int(rng.integers(14, 60))
+        s = _rand_seq(rng, L, pn=0.02 if rng.random() < 0.1 else 0.0)
+        if rng.random() < 0.05:
+            s = s.lower()
+        seqs.append(s)
+    if fmt == 3:
+        seqs = [s for s in seqs if s] or ["ACGTACGTACGTACGTAC"]
+    pad = "x" * int(rng.integers(0, 40))  # shifts every record against the 4 KiB scan tiles
+    if fmt == 1:
+        text = "".join(f"@r{i} {pad}{eol}{s}{eol}+{eol}{'I' * len(s)}{eol}" for i, s in enumerate(seqs))
+    elif fmt == 2:
+        text = "".join(f">r{i} {pad}{eol}{s}{eol}" for i, s in enumerate(seqs))
+    else:
+        text = eol.join(seqs) + eol
+    if rng.random() < 0.5:
+        text = text[:-len(eol)]
+    path = tmp_path / "t.txt"
+    path.write_text(text, newline="")
+    host = read_fastq_sequences(str(path))
+    min_len = int(rng.choice([0, 16, 18]))
+    exp = filter_min_length(host, min_len)
+    dr, n_rec = _ffi.DeviceReads.parse(ctx, path.read_bytes(), fmt, min_len)
+    assert n_rec == len(host) and len(dr) == len(exp)
+    assert dr.unpack().to_list() == [q.upper() for q in exp.to_list()]
+    u = dr.collapse()
+    cnt, first = u.counts()
+    from collections import Counter
+    want = Counter(q.upper() for q in exp.to_list())
+    assert dict(zip(u.unpack().to_list(), cnt[:, 0].tolist())) == dict(want)
+    u.close(); dr.close(); ctx.close()
