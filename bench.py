@@ -109,6 +109,92 @@ def pmc_traffic(args, rec_name):
             "bytes": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0}
 
 
+def reference_bowtie_dir():
+    """directory of a real bowtie 1.x (bowtie + bowtie-build), or None"""
+    import shutil
+    d = os.environ.get("MIRGE_BOWTIE_DIR")
+    if d and os.path.exists(os.path.join(d, "bowtie-build")):
+        return d
+    b = shutil.which("bowtie-build")
+    if b and shutil.which("bowtie") and os.path.dirname(os.path.realpath(b)) != os.path.join(ROOT, "mirge3.0_amd", "shim"):
+        return os.path.dirname(b)
+    return None
+
+
+def reference_bowtie_baseline(bowtie_dir, sl, libs, reads, n_pass, ctx, casc, args):
+    """`cpu_baseline.kind = "reference"`: the reference's own ten bowtie runs (manifoldAlign.py:85,92-135) on the
+    collapsed reads of a bounded sample, all host cores, index construction (bowtie-build) not timed; then the
+    per-pass membership of bowtie vs the GPU engine on the same reads (tools/bowtie_crosscheck.py's comparison)."""
+    import re
+    import subprocess
+    import tempfile
+    from collections import Counter
+    from mirge3_amd import _ffi
+    from mirge3_amd.cascade import PASSES
+    from mirge3_amd.seqio import FlatSeqs, index_basename, write_fasta
+    cores = os.cpu_count() or 1
+    tmp = tempfile.mkdtemp(prefix="mirge_refbowtie_", dir="/tmp")
+    idx = {}
+    for key, lib in libs.items():
+        base = os.path.join(tmp, index_basename("bench", key, "miRBase"))
+        write_fasta(base + ".fa", lib)
+        subprocess.run([os.path.join(bowtie_dir, "bowtie-build"), "-q", "--threads", str(cores), base + ".fa", base],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        idx[key] = base
+    m = min(len(reads), max(1000, min(args.cpu_sample, 2_000_000)))
+    cnt = Counter(reads.take(np.arange(m)).to_list())
+    seqs = list(cnt)
+    ver = subprocess.run([os.path.join(bowtie_dir, "bowtie"), "--version"], capture_output=True, text=True).stdout.split("\n")[0]
+    fasta = os.path.join(tmp, "bwtInput.fasta")
+    annotated, per_pass, t_total, differ = {}, [], 0.0, 0
+    for it in range(n_pass):
+        col, key, argstr, _ = PASSES[it]
+        if key not in libs:
+            continue
+        if it == 0:
+            recs = [(q, q) for q in seqs if len(q) < 26]
+        elif it == 1:
+            recs = [(q, q) for q in seqs if len(q) > 25]
+        else:
+            un = [q for q in seqs if q not in annotated]
+            recs = [(q, q[:re.search('T{3,}$', q).start()]) for q in un if re.search('T{3,}$', q)] if it == 3 else [(q, q) for q in un]
+        with open(fasta, "w") as fh:
+            fh.write("".join(f">{q}\n{x}\n" for q, x in recs))
+        t = time.perf_counter()
+        o = subprocess.run(os.path.join(bowtie_dir, "bowtie") + " " + idx[key] + argstr + str(cores) + " " + fasta, shell=True,
+                           check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
+        dt = time.perf_counter() - t
+        t_total += dt
+        hit = {}
+        for ln in o.split("\n"):
+            if ln and not ln.startswith("@"):
+                f = ln.split("\t")
+                if f[2] != "*":
+                    hit[f[0]] = f[2]
+        got = set()
+        if recs:
+            dr = _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list([q for q, _ in recs]))
+            res = _ffi.cascade_run(ctx, dr, [casc.dev_libs[it]], [casc.policies[it]])
+            ps = res.fetch()[0]
+            got = {q for (q, _), p in zip(recs, ps) if p == 0}
+            res.close(); dr.close()
+        differ += len(set(hit) ^ got)
+        per_pass.append({"pass": it, "reads": len(recs), "bowtie_aligned": len(hit), "gpu_aligned": len(got),
+                         "membership_differs": len(set(hit) ^ got), "s": round(dt, 3)})
+        for q in hit:
+            annotated[q] = it
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": round(m / max(t_total, 1e-9) / 1e6, 4), "unit": "M reads/s", "cores": cores, "kind": "reference",
+            "sample": f"{ver}: the reference's bowtie argument strings verbatim, --threads {cores}, on the {len(seqs)} collapsed reads "
+                      f"of the first {m} raw reads of the same sample; {t_total:.2f} s of bowtie (bowtie-build and the Python "
+                      f"around it not timed)",
+            "per_pass": per_pass,
+            "parity": ("alignment predicate PINNED on this box: per-pass aligned/unaligned membership of bowtie vs the GPU engine "
+                       f"differs for {differ} reads" if differ else
+                       "alignment predicate PINNED on this box: per-pass membership identical to " + ver)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,8 +415,19 @@ def main():
                                    "note": "ASCII reads + offsets over PCIe, 2-bit pack on the GPU, annotation (10 B/unique) "
                                            "and counts back to numpy; best of 3 passes, not part of `value`"}
 
-    # ---------------- CPU baseline (rank 0, N = 1): the oracle on a bounded sample, and parity on it
-    if rank == 0 and n_gpus == 1 and args.cpu_baseline:
+    # ---------------- CPU baseline (rank 0, N = 1): the reference path (bowtie 1.x, the ten argument strings of
+    # manifoldAlign.py:85 verbatim) when the box has one, else the oracle; on a bounded sample, and parity on it
+    out["parity"] = ("GPU path == in-repo oracle (restated bowtie-1 manual semantics) and == the files the reference's own "
+                     "bwtAlign/summarize wrote around that oracle; the bowtie predicate itself is UNPINNED (no bowtie 1.x "
+                     "in the image or on the pool): 'bit-exact vs ref' in `metric` is BASELINE.json's wording, not a claim")
+    bowtie_dir = reference_bowtie_dir()
+    if rank == 0 and n_gpus == 1 and args.cpu_baseline and bowtie_dir:
+        try:
+            out["cpu_baseline"] = reference_bowtie_baseline(bowtie_dir, sl, libs, reads, n_pass, ctx, casc, args)
+            out["parity"] = out["cpu_baseline"].pop("parity")
+        except Exception as e:  # a broken bowtie install must not take the bench line down
+            out["cpu_baseline_reference_error"] = repr(e)[:300]
+    if rank == 0 and n_gpus == 1 and args.cpu_baseline and "cpu_baseline" not in out:
         import oracle
         cores = os.cpu_count() or 1
         threads = min(cores, 64)

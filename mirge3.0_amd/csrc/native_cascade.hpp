@@ -17,6 +17,7 @@ struct mirge_result {
     int32_t n_pass = 0;
     ResGroup g[MIRGE_NGROUPS];
     const mirge_reads* reads = nullptr;  // borrowed: orig/base mapping (must outlive the fetch)
+    uint32_t n_refs[MIRGE_MAX_PASSES] = {0};  // references of each pass's library (bounds of res.ref; checked by the join)
     uint32_t* dmeta = nullptr;           // mirge_collapse_cascade: the device-side read counts its kernels read
 };
 
@@ -386,6 +387,7 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     hc.lap("plans+fused");
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
+    for (int32_t p = 0; p < n_pass; p++) res->n_refs[p] = libs[p] ? (uint32_t)libs[p]->n_refs : 0u;
     const int rc = cascade_launch_groups(c, R, res.get(), pol, -1);
     hc.lap("enqueue+join");
     if (rc) { mirge_result_destroy(res.release()); return rc; }
@@ -417,6 +419,7 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
     CHECK(cascade_config(c, libs, pol, n_pass, raw->len_hist));
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n_pass = n_pass;
+    for (int32_t p = 0; p < n_pass; p++) res->n_refs[p] = libs[p] ? (uint32_t)libs[p]->n_refs : 0u;
     const size_t prof_mark = c->prof_pending.size();
     int hooked_group = -1;
     CollapseHook hook;

@@ -65,8 +65,13 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
     if (stage == 2 && t.partitioned) return collapse_part_rest(c, gi, in, out, t, dmeta);
     // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
     const bool key_path = (W == 1) && !in.nmask && S == 1;
-    uint32_t tsize = 1024;
-    while (tsize < (key_path ? in.n + in.n / 2 : 2ull * in.n)) tsize <<= 1;
+    // slots of the open-addressing table: next power of two above 1.5 n (key path) / 2 n, computed in 64 bits --
+    // a read set near the 2^32 limit of mirge_reads_pack would wrap a 32-bit size to 0 and never terminate
+    const uint64_t need = key_path ? (uint64_t)in.n + in.n / 2 : 2ull * in.n;
+    uint64_t tsize64 = 1024;
+    while (tsize64 < need) tsize64 <<= 1;
+    if (tsize64 > (1ull << 31)) return fail(-5, "collapse: a read group of " + std::to_string(in.n) + " reads needs a hash table beyond 2^31 slots");
+    const uint32_t tsize = (uint32_t)tsize64;
     const uint32_t per_block = MIRGE_BLOCK * MIRGE_SCAN_ITEMS;
     t.nb = (in.n + per_block - 1) / per_block;
     GroupView<W> v = view_of<W>(in);

@@ -8,6 +8,12 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     if (!c || !U || !res || !class_sums || !exact || !iso || n_mirna < 0) return fail(-1, "mirge_count_join: bad argument");
     if (U->n_samples < 1) return fail(-1, "read set has no count matrix (collapse it or mirge_reads_set_counts)");
     if (res->n != U->n) return fail(-1, "result and read set differ in size");
+    // k_join adds into exact[ref] / iso[ref] with ref taken from the cascade: the tables must cover the libraries
+    // those two passes ran against (a pass index outside the cascade simply selects nothing)
+    for (int32_t p : {exact_pass, iso_pass})
+        if (p >= 0 && p < res->n_pass && (int64_t)res->n_refs[p] > n_mirna)
+            return fail(-1, "mirge_count_join: n_mirna (" + std::to_string(n_mirna) + ") is smaller than the " +
+                                std::to_string(res->n_refs[p]) + " references of pass " + std::to_string(p));
     HIPOK(hipSetDevice(c->device));
     const int32_t S = U->n_samples, P = res->n_pass;
     const size_t n_cls = (size_t)P * S, n_tab = (size_t)std::max<int64_t>(n_mirna, 1) * S;

@@ -151,22 +151,27 @@ def index_basename(organism: str, key: str, ref_db: str) -> str:
 
 def load_library_dir(libraries_path: str, organism: str, ref_db: str,
                      with_spike: bool = False) -> Dict[str, Library]:
-    """Load ``<lib>/<org>/index.Libs/<org>_<key>[_<db>].fa``.
-
-    The reference keeps only bowtie ``.ebwt`` indexes there; this build reads the FASTA the
-    index was made from, stored next to it under the same base name (hard
-    part 2: the ``.ebwt`` reader is a 'next' row).
-    """
+    """Load the libraries of ``<lib>/<org>/index.Libs/``: the bowtie-1 indexes a miRge3.0 library directory ships
+    (``<org>_<key>[_<db>].{1,3,4}.ebwt``, read by ``ebwt.read_ebwt`` -- names from the tail of ``.1.ebwt``, sequences
+    from ``.3.ebwt`` / ``.4.ebwt``), or ``<org>_<key>[_<db>].fa`` where a FASTA sits under the index's base name (it
+    wins when both exist: it is what the index was built from and loads without decoding)."""
     base = os.path.join(libraries_path, organism, "index.Libs")
     out: Dict[str, Library] = {}
     for key in LIB_KEYS:
         if key == "spike-in" and not with_spike:
             continue
-        p = os.path.join(base, index_basename(organism, key, ref_db) + ".fa")
-        if not os.path.exists(p):
-            raise FileNotFoundError(f"library FASTA missing: {p}")
-        out[key] = read_fasta(p)
+        out[key] = load_index(os.path.join(base, index_basename(organism, key, ref_db)))
     return out
+
+
+def load_index(base: str) -> Library:
+    """One library by its index base name: ``<base>.fa`` or ``<base>.{1,3,4}.ebwt[l]``."""
+    if os.path.exists(base + ".fa"):
+        return read_fasta(base + ".fa")
+    from . import ebwt
+    if ebwt.has_index(base):
+        return ebwt.read_ebwt(base)
+    raise FileNotFoundError(f"library missing: neither {base}.fa nor {base}.1.ebwt exists")
 
 
 def load_merges(libraries_path: str, organism: str, ref_db: str) -> List[List[str]]:

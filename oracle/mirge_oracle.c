@@ -120,7 +120,7 @@ static int align_brute(const char *r, int l, const oracle_lib *lib, const oracle
 }
 
 /* ---- indexed: pigeonhole seeds over a direct-addressed k-mer table (for sizes where brute
- * force does not finish); validated against align_brute by tests/test_oracle.py ---- */
+ * force does not finish); validated against align_brute by tests/test_host_logic.py::test_oracle_bruteforce_vs_indexed_ci_scale ---- */
 #define OR_KMAX 12
 typedef struct {
     int k;

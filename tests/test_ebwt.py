@@ -1,0 +1,104 @@
+"""bowtie-1 index reader (mirge3_amd/ebwt.py) against the matching minimal writer
+(tests/ebwt_writer.py).  No index written by a real bowtie-build is available offline: the row stays "unverified
+against a real index" (DESIGN.md)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import mirge3_amd  # noqa: F401
+from mirge3_amd import ebwt, synth
+from mirge3_amd.seqio import load_index, load_library_dir, read_fasta
+from ebwt_writer import fasta_dir_to_ebwt, write_ebwt
+from helpers import CASES, GoldenCase, ORG, DB
+
+
+def _rand_seq(rng, n, p_n=0.0):
+    s = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=n))
+    if p_n:
+        s = "".join("N" if rng.random() < p_n else c for c in s)
+    return s
+
+
+@pytest.mark.parametrize("large,big_endian", [(False, False), (True, False), (False, True)])
+def test_round_trip_with_ambiguous_stretches(tmp_path, large, big_endian):
+    rng = np.random.default_rng(3)
+    seqs = [_rand_seq(rng, 23), "NNNN" + _rand_seq(rng, 40) + "NN" + _rand_seq(rng, 7) + "NNN", _rand_seq(rng, 1),
+            "N" * 9 + _rand_seq(rng, 5), _rand_seq(rng, 300, 0.05), _rand_seq(rng, 64), "ACGT" * 8 + "N", "N" + "ACGT" * 8]
+    headers = [f"ref{i} chr{i} segs:1-{len(s)} note with spaces" if i % 2 else f"hsa-miR-{i}-5p" for i, s in enumerate(seqs)]
+    base = str(tmp_path / "idx")
+    meta = write_ebwt(base, headers, seqs, large=large, big_endian=big_endian)
+    lib = ebwt.read_ebwt(base)
+    assert lib.headers == headers
+    assert lib.names == [h.split()[0] for h in headers]
+    assert lib.seqs.to_list() == seqs
+    h = ebwt.read_header(base)
+    assert h["nPat"] == len(seqs) and h["off_size"] == (8 if large else 4) and h["endian"] == (">" if big_endian else "<")
+    # the tail scan finds the names where bowtie's own layout arithmetic puts them
+    assert ebwt.names_offset(h, meta["n_frag"]) == meta["names_offset"]
+    _, per = ebwt.read_sequences(base)
+    assert sum(per) == meta["n_records"] and per[1] == 3
+
+
+def test_names_from_an_unknown_layout(tmp_path):
+    """if the name block is not where the header arithmetic puts it (extra bytes in front), the last nPat lines of
+    the file are taken and the binary bytes in front of the first name are dropped"""
+    base = str(tmp_path / "idx")
+    write_ebwt(base, ["a", "b b", "c"], ["ACGT", "GGGG", "TTTTT"], ftab_chars=1)
+    raw = open(base + ".1.ebwt", "rb").read()
+    at = raw.rindex(b"a\nb b\nc\n")
+    open(base + ".1.ebwt", "wb").write(raw[:at] + bytes([0, 7, 10, 0, 255, 1]) + raw[at:])
+    assert ebwt.read_names(base) == ["a", "b b", "c"]
+
+
+def test_refuses_index_without_reference_files(tmp_path):
+    base = str(tmp_path / "idx")
+    write_ebwt(base, ["a"], ["ACGT"])
+    os.remove(base + ".4.ebwt")
+    with pytest.raises(FileNotFoundError, match="noref"):
+        ebwt.read_ebwt(base)
+    with pytest.raises(FileNotFoundError):
+        load_index(str(tmp_path / "nothing"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_library_directories_as_ebwt_only(name, tmp_path):
+    """every golden library directory, converted to what a miRge3.0 library ships (indexes only), loads to the same
+    names, headers and sequences -- and the bowtie-inspect shim prints what the reference reads from it
+    (summary.py:776-788: `-n`; :812-826: `-a 20000 -e`)"""
+    case = GoldenCase(name)
+    dst = tmp_path / "Libs"
+    shutil.copytree(os.path.join(case.dir, "libs"), dst)
+    idx = dst / ORG / "index.Libs"
+    want = {f[:-3]: read_fasta(str(idx / f)) for f in os.listdir(idx) if f.endswith(".fa")}
+    fasta_dir_to_ebwt(str(idx))
+    assert not [f for f in os.listdir(idx) if f.endswith(".fa")]
+    for b, lib in want.items():
+        got = load_index(str(idx / b))
+        assert got.names == lib.names and got.headers == lib.headers and got.seqs.to_list() == lib.seqs.to_list()
+    libs = load_library_dir(str(dst), ORG, DB, with_spike=case.spike)
+    assert set(libs) >= {"mirna", "hairpin", "mrna"}
+    shim = os.path.join(os.path.dirname(os.path.abspath(mirge3_amd.__file__)), "shim", "bowtie-inspect")
+    b = str(idx / f"{ORG}_mirna_{DB}")
+    out = subprocess.run([sys.executable, shim, "-n", b], capture_output=True, text=True, check=True).stdout
+    assert out.splitlines() == want[f"{ORG}_mirna_{DB}"].headers
+    hb = str(idx / f"{ORG}_hairpin_{DB}")
+    out = subprocess.run([sys.executable, shim, "-a", "20000", "-e", hb], capture_output=True, text=True, check=True).stdout
+    hp = want[f"{ORG}_hairpin_{DB}"]
+    assert out == "".join(f">{h}\n{s}\n" for h, s in zip(hp.headers, hp.seqs.to_list()))
+
+
+def test_human_sized_mrna_decodes_quickly(tmp_path):
+    import time
+    sl = synth.make_libraries(seed=3, scale="small")
+    lib = sl.libs["mrna"]
+    base = str(tmp_path / "mrna")
+    write_ebwt(base, lib.headers, lib.seqs.to_list())
+    t = time.perf_counter()
+    got = ebwt.read_ebwt(base)
+    dt = time.perf_counter() - t
+    assert np.array_equal(got.seqs.data, lib.seqs.data) and np.array_equal(got.seqs.offsets, lib.seqs.offsets)
+    assert dt < 5.0, dt
