@@ -133,6 +133,18 @@ int mirge_count_join_host(mirge_ctx* ctx, const int8_t* pass, const int32_t* ref
                           int64_t n, int32_t n_samples, int32_t n_pass, int32_t exact_pass, int32_t iso_pass,
                           int64_t n_mirna, int64_t* class_sums, int64_t* exact, int64_t* iso);
 
+/* ---- the per-read tables: replaces pdMapped.to_csv / pdUnmapped.to_csv (mirge/__main__.py:164-173) and the U-row
+ * DataFrame of Python strings they print.  Host arrays in (what mirge_reads_unpack / mirge_result_fetch /
+ * mirge_collapse_fetch returned), the reference's bytes out, formatted on the host's cores.  rows[k] = read printed in
+ * row k; a read with pass >= 0 goes to mapped_path, the others to unmapped_path (either may be NULL).  Columns:
+ * Sequence, annotFlag, n_name_cols name columns (pass p writes its reference name into column col_of_pass[p]),
+ * S counts.  name_data[p] / name_off[p] / name_n[p]: the reference names of pass p's library.  No GPU involved. */
+int mirge_annotation_csv(const char* mapped_path, const char* unmapped_path, const char* header,
+                         const char* seq_ascii, const int64_t* seq_off, const int8_t* pass, const int32_t* ref,
+                         const uint32_t* counts, int32_t n_samples, const int64_t* rows, int64_t n_rows,
+                         int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                         const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n);
+
 /* ---- per-position variant tally (BASELINE config 5): the counting core of
  * A2IEditing / judgeAllign (mirge2_tRF_a2i.py:298-366) over the reads the cascade annotated to a
  * miRNA in exact_pass / iso_pass (iso_trim5 = that pass's -5).  accepted/canonical[n_mirna * S],

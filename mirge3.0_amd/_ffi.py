@@ -25,7 +25,7 @@ EXPORTS = [
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
-    "mirge_count_join", "mirge_count_join_host", "mirge_variant_tally", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
+    "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_variant_tally", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
@@ -370,3 +370,34 @@ def variant_tally(ctx: Context, uniq: DeviceReads, res: CascadeResult, mirna: De
     _check(load().mirge_variant_tally(ctx._h, uniq._h, res._h, mirna._h, C.c_int32(exact_pass), C.c_int32(iso_pass),
                                       C.c_int32(iso_trim5), C.c_int64(R), _p(acc), _p(can), _p(cen)), "mirge_variant_tally")
     return acc[:R], can[:R], cen[:R]
+
+
+def annotation_csv(mapped_path, unmapped_path, header: str, seqs: FlatSeqs, ps: np.ndarray, ref: np.ndarray,
+                   counts: np.ndarray, rows: np.ndarray, col_of_pass: Sequence[int], n_name_cols: int,
+                   names_by_pass: Sequence[Optional[FlatSeqs]]):
+    """``mapped.csv`` / ``unmapped.csv`` (mirge/__main__.py:164-173) from flat arrays; ``names_by_pass[p]`` = the
+    reference names of pass p's library as a FlatSeqs (None: the pass has none)."""
+    n_pass = len(col_of_pass)
+    data = np.ascontiguousarray(seqs.data, dtype=np.uint8)
+    off = np.ascontiguousarray(seqs.offsets, dtype=np.int64)
+    ps = np.ascontiguousarray(ps, dtype=np.int8)
+    ref = np.ascontiguousarray(ref, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(ps.shape[0], -1)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    col = (C.c_int32 * n_pass)(*[int(x) for x in col_of_pass])
+    keep = []
+    nd, no, nn = (C.c_void_p * n_pass)(), (C.c_void_p * n_pass)(), (C.c_int64 * n_pass)()
+    for p in range(n_pass):
+        fs = names_by_pass[p]
+        if fs is None:
+            nd[p], no[p], nn[p] = None, None, 0
+            continue
+        d = np.ascontiguousarray(fs.data, dtype=np.uint8)
+        o = np.ascontiguousarray(fs.offsets, dtype=np.int64)
+        keep += [d, o]
+        nd[p], no[p], nn[p] = d.ctypes.data if d.size else None, o.ctypes.data, len(fs)
+    enc = lambda x: None if x is None else str(x).encode()
+    _check(load().mirge_annotation_csv(enc(mapped_path), enc(unmapped_path), header.encode(), _p(data) if data.size else C.c_void_p(0),
+                                       _p(off), _p(ps), _p(ref), _p(counts), C.c_int32(counts.shape[1]), _p(rows),
+                                       C.c_int64(rows.shape[0]), C.c_int32(n_pass), col, C.c_int32(n_name_cols), nd, no, nn),
+           "mirge_annotation_csv")

@@ -88,6 +88,7 @@ def main(argv=None):
     if not (Path(args.libraries_path) / args.organism_name / "index.Libs").exists():
         sys.exit("\n ERROR: The path to miRge libraries is incorrect or does not exist!\n")
 
+    from . import fastpath
     from .cascade import bwt_align
     from .collapse import baking
     from .countjoin import summarize, finish_tables
@@ -101,6 +102,13 @@ def main(argv=None):
             df = pd.read_pickle(rootToPKL / "collapsed.pkl")
             with open(rootToPKL / "collapsed_accessories.pkl", "rb") as pklin:
                 src, trimmed, uniq, files, base_names = pickle.load(pklin)
+        elif fastpath.eligible(args):
+            # everything between the files' text and the count tables stays on the GPU (fastpath.py); the three
+            # reference-signature functions below remain the drop-ins for the reference's own call sites
+            fastpath.run(args, files, base_names, workDir, ref_db)
+            if rank == 0 and not args.quiet:
+                print(f"\nThe analysis completed in {round(time.perf_counter() - globalstart, 4)} second(s)\n")
+            return
         else:
             df, src, trimmed, uniq = baking(args, files, base_names, str(workDir))
         if args.save_pkl and not args.resume:

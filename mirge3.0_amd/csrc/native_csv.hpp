@@ -1,0 +1,96 @@
+// native_csv.hpp -- part of mirge_native.hip (one translation unit): the per-read tables mapped.csv / unmapped.csv
+// written from flat arrays on the host's cores.  Replaces the two DataFrame.to_csv calls of mirge/__main__.py:164-173
+// (row a15): the reference builds a U-row pandas frame of Python strings to print it; here the rows are formatted
+// straight from what the device returned (sequence bytes, pass, reference index, count matrix), same bytes out.
+#pragma once
+
+namespace {
+struct CsvNames {  // reference names of one pass: one ASCII blob + offsets (n + 1); data == nullptr: pass has no library
+    const char* data = nullptr;
+    const int64_t* off = nullptr;
+    int64_t n = 0;
+};
+
+// pandas.to_csv quoting (csv.QUOTE_MINIMAL): quote a field that holds the delimiter, a quote or a line break
+inline void csv_field(std::string& out, const char* s, size_t len) {
+    bool q = false;
+    for (size_t i = 0; i < len; i++) q |= s[i] == ',' || s[i] == '"' || s[i] == '\n' || s[i] == '\r';
+    if (!q) { out.append(s, len); return; }
+    out.push_back('"');
+    for (size_t i = 0; i < len; i++) { if (s[i] == '"') out.push_back('"'); out.push_back(s[i]); }
+    out.push_back('"');
+}
+inline void csv_uint(std::string& out, uint64_t v) {
+    char buf[24];
+    int k = 24;
+    do { buf[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+    out.append(buf + k, (size_t)(24 - k));
+}
+}  // namespace
+
+// rows[k] (k < n_rows) = index of the read printed in row k (the caller's row order: first appearance for one sample,
+// sorted sequences for several).  A read goes to `mapped_path` when pass[i] >= 0, else to `unmapped_path` (either may
+// be NULL).  Columns: Sequence, annotFlag, one name column per pass column (col_of_pass[p] = which column pass p
+// writes, -1 = none; n_name_cols columns in all), then the S counts.  `header` is the first line, written as given.
+extern "C" int mirge_annotation_csv(const char* mapped_path, const char* unmapped_path, const char* header,
+                                    const char* seq_ascii, const int64_t* seq_off, const int8_t* pass, const int32_t* ref,
+                                    const uint32_t* counts, int32_t S, const int64_t* rows, int64_t n_rows,
+                                    int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                    const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n) {
+    if (!header || !seq_off || !pass || !ref || !counts || !rows || S < 1 || n_rows < 0 || n_pass < 1 || n_pass > MIRGE_MAX_PASSES ||
+        !col_of_pass || n_name_cols < 0 || !name_data || !name_off || !name_n || (n_rows > 0 && !seq_ascii))
+        return fail(-1, "mirge_annotation_csv: bad argument");
+    CsvNames nm[MIRGE_MAX_PASSES];
+    for (int p = 0; p < n_pass; p++) {
+        nm[p].data = name_data[p]; nm[p].off = name_off[p]; nm[p].n = name_n[p];
+        if (col_of_pass[p] >= n_name_cols) return fail(-1, "mirge_annotation_csv: column index out of range");
+    }
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int T = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n_rows / 16384));
+    std::vector<std::string> bufm((size_t)T), bufu((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    auto work = [&](int t) {
+        const int64_t lo = n_rows * t / T, hi = n_rows * (t + 1) / T;
+        std::string &M = bufm[(size_t)t], &U = bufu[(size_t)t];
+        M.reserve((size_t)(hi - lo) * 48);
+        for (int64_t k = lo; k < hi; k++) {
+            const int64_t i = rows[k];
+            const int p = pass[i];
+            if (p >= n_pass) { bad[(size_t)t] = 1; continue; }
+            std::string& out = p >= 0 ? M : U;
+            if ((p >= 0 ? mapped_path : unmapped_path) == nullptr) continue;
+            csv_field(out, seq_ascii + seq_off[i], (size_t)(seq_off[i + 1] - seq_off[i]));
+            out.append(p >= 0 ? ",1" : ",0");
+            const int col = p >= 0 ? col_of_pass[p] : -1;
+            for (int cidx = 0; cidx < n_name_cols; cidx++) {
+                out.push_back(',');
+                if (cidx == col) {
+                    const int32_t r = ref[i];
+                    if (!nm[p].data || r < 0 || r >= nm[p].n) { bad[(size_t)t] = 1; continue; }
+                    csv_field(out, nm[p].data + nm[p].off[r], (size_t)(nm[p].off[r + 1] - nm[p].off[r]));
+                }
+            }
+            for (int s = 0; s < S; s++) { out.push_back(','); csv_uint(out, counts[(size_t)i * S + s]); }
+            out.push_back('\n');
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < T; t++) if (bad[(size_t)t]) return fail(-1, "mirge_annotation_csv: pass or reference index out of range");
+    for (int which = 0; which < 2; which++) {
+        const char* path = which == 0 ? mapped_path : unmapped_path;
+        if (!path) continue;
+        FILE* f = std::fopen(path, "wb");
+        if (!f) return fail(-8, std::string("cannot write ") + path);
+        bool ok = std::fputs(header, f) >= 0;
+        for (int t = 0; t < T && ok; t++) {
+            const std::string& b = which == 0 ? bufm[(size_t)t] : bufu[(size_t)t];
+            ok = b.empty() || std::fwrite(b.data(), 1, b.size(), f) == b.size();
+        }
+        ok = (std::fclose(f) == 0) && ok;
+        if (!ok) return fail(-8, std::string("write error on ") + path);
+    }
+    return 0;
+}

@@ -1,0 +1,146 @@
+"""The single-process CLI run without a per-read Python object anywhere.
+
+``cli.main`` used to chain the three reference-signature functions (``baking`` -> ``bwt_align`` -> ``summarize``): a
+4 M-row DataFrame of Python strings was built, turned back into packed reads for the cascade, and its name columns
+were looked up again for the join.  Those functions stay what they are -- drop-ins for the reference's call sites
+(``mirge/__main__.py:140,157,166``) -- but the CLI itself now keeps everything between the FASTQ text and the count
+tables on the GPU:
+
+    file text --mirge_reads_parse--> raw reads --mirge_collapse_cascade / mirge_collapse + mirge_cascade_run-->
+    unique reads + annotation --mirge_count_join--> per-class / per-miRNA tables --finish_tables--> the three CSVs
+    unique reads + annotation + counts --one fetch each--> mirge_annotation_csv --> mapped.csv / unmapped.csv
+
+Same files, same bytes (tests/test_gpu_parity.py replays the golden cases through it).
+"""
+from __future__ import annotations
+
+import time
+from pathlib import Path
+from typing import Dict, List
+
+import numpy as np
+
+from . import PASS_COLUMNS, _ffi
+from .cascade import PASSES, get_cascade
+from .collapse import read_text
+from .countjoin import summarize_device
+from .seqio import FlatSeqs, load_merges
+
+
+def eligible(args) -> bool:
+    """flags the device-resident run covers; the others take the DataFrame route (they need the frame itself)"""
+    return not (getattr(args, "uniq_mol_ids", None) or getattr(args, "tcf_out", False) or getattr(args, "save_pkl", False)
+                or getattr(args, "resume", False))
+
+
+def row_order(seqs: FlatSeqs, first: np.ndarray, n_samples: int) -> np.ndarray:
+    """Row order of the reference's DataFrame: dict insertion order = first appearance for one sample
+    (digest.py:158-163), the sorted union of the sequences for several (pandas ``join(how='outer')``, digest.py:243)."""
+    if n_samples == 1:
+        # `first` holds distinct raw-read indices: ranking them is one scatter and one compress, not a sort
+        if len(first) == 0:
+            return np.zeros(0, dtype=np.int64)
+        slot = np.full(int(first.max()) + 1, -1, dtype=np.int64)
+        slot[first] = np.arange(len(first), dtype=np.int64)
+        return slot[slot >= 0]
+    ln = seqs.lengths
+    width = int(ln.max()) if len(seqs) else 1
+    mat = np.zeros((len(seqs), width), dtype=np.uint8)  # NUL-padded: a prefix sorts before its extensions, as str does
+    rows = np.repeat(np.arange(len(seqs), dtype=np.int64), ln)
+    mat[rows, np.arange(int(seqs.offsets[-1]), dtype=np.int64) - seqs.offsets[:-1][rows]] = seqs.data
+    return np.argsort(mat.view(f"S{width}").reshape(-1), kind="stable")
+
+
+def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, timings: Dict[str, float] = None):
+    """FASTQ files -> every output file of the hot path.  Returns the dict of ``finish_tables``."""
+    t0 = time.perf_counter()
+    tm = timings if timings is not None else {}
+    workDir = Path(workDir)
+    outlog = open(workDir / "run.log", "a+")
+
+    def say(msg):
+        if not args.quiet:
+            print(msg)
+        outlog.write(msg + "\n")
+
+    casc = get_cascade(args, ref_db, getattr(args, "device", 0))
+    ctx = casc.ctx
+    tm["libraries_s"] = time.perf_counter() - t0
+    min_len = int(getattr(args, "minimum_length", 16))
+    sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
+    parsed = []
+    t_read = t_parse = 0.0
+    for f, name in zip(files, base_names):
+        t = time.perf_counter()
+        text = read_text(str(f))
+        t_read += time.perf_counter() - t
+        t1 = time.perf_counter()
+        raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 0, min_len)
+        del text
+        t_parse += time.perf_counter() - t1
+        sampleReadCounts[name], trimmedReadCounts[name] = n_rec, len(raw)
+        parsed.append(raw)
+        say(f'Cutadapt finished for file {name} in {round(time.perf_counter() - t, 4)} second(s)')
+    tm["read_files_s"], tm["parse_s"] = t_read, t_parse
+    t = time.perf_counter()
+    say("Alignment in progress ...")
+    S = len(parsed)
+    if S == 1:
+        uniq, res = casc.collapse_and_run(parsed[0])
+    else:
+        allr = _ffi.DeviceReads.concat(ctx, parsed)
+        sid = np.repeat(np.arange(S, dtype=np.int32), [len(p) for p in parsed])
+        uniq = allr.collapse(sid, S)
+        allr.close()
+        res = casc.run(uniq)
+    for p in parsed:
+        p.close()
+    counts, first = uniq.counts()
+    for s, name in enumerate(base_names):
+        trimmedReadCountsUnique[name] = int(np.count_nonzero(counts[:, s]))
+    tm["collapse_cascade_s"] = time.perf_counter() - t
+    say(f'Alignment completed in {round(time.perf_counter() - t, 4)} second(s)\n')
+    t = time.perf_counter()
+    out = summarize_device(ctx, uniq, res, casc.libs["mirna"], load_merges(str(args.libraries_path), args.organism_name, ref_db),
+                           list(base_names), sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique,
+                           float(args.crThreshold), bool(args.spikeIn), workDir)
+    tm["join_tables_s"] = time.perf_counter() - t
+    # ---- the per-read tables (mirge/__main__.py:164-173)
+    t = time.perf_counter()
+    seqs = uniq.unpack()
+    ps, ref, off, mm = res.fetch()
+    tm["fetch_reads_annotation_s"] = time.perf_counter() - t
+    order = row_order(seqs, first, S)
+    tm["row_order_s"] = time.perf_counter() - t - tm["fetch_reads_annotation_s"]
+    n_cols = 10 if args.spikeIn else 9  # bwtAlign drops the 'spike-in' column when -spk is off (manifoldAlign.py:137-138)
+    cols = PASS_COLUMNS[:n_cols]
+    header = ",".join(["Sequence", "annotFlag"] + cols + list(base_names)) + "\n"
+    names_by_pass = []
+    for p in range(casc.n_pass):
+        key = PASSES[p][1]
+        names_by_pass.append(FlatSeqs.from_list(casc.libs[key].names) if key in casc.libs else None)
+    _ffi.annotation_csv(workDir / "mapped.csv", workDir / "unmapped.csv", header, seqs, ps, ref, counts, order,
+                        list(range(casc.n_pass)), n_cols, names_by_pass)
+    tm["per_read_csv_s"] = time.perf_counter() - t
+    if getattr(args, "isoform_entropy", False):  # -ie reads the miRNA rows of the mapped frame: build just those
+        from .countjoin import isomir_entropy_tables
+        isomir_entropy_tables(mirna_frame(seqs, ps, ref, counts, order, casc, base_names), base_names, out["filtered"], workDir)
+    out["device"] = dict(ctx=ctx, casc=casc, uniq=uniq, res=res, seqs=seqs, ann=(ps, ref, off, mm), counts=counts, order=order)
+    tm["total_s"] = time.perf_counter() - t0
+    outlog.close()
+    return out
+
+
+def mirna_frame(seqs: FlatSeqs, ps, ref, counts, order, casc, base_names):
+    """the rows of the mapped frame that carry an 'exact miRNA' or 'isomiR miRNA' name, in frame order, as the small
+    DataFrame the host-side miRNA reports (-ie, -gff, -ai) iterate over"""
+    import pandas as pd
+    from .cascade import EXACT_PASS, ISO_PASS
+    sel = order[(ps[order] == EXACT_PASS) | (ps[order] == ISO_PASS)]
+    names = np.asarray(casc.libs["mirna"].names, dtype=object)
+    sub = seqs.take(sel)
+    df = pd.DataFrame(counts[sel].astype(np.int64), columns=list(base_names), index=pd.Index(sub.to_list(), name="Sequence"))
+    nm = names[ref[sel]] if sel.size else np.zeros(0, dtype=object)
+    df.insert(0, "isomiR miRNA", np.where(ps[sel] == ISO_PASS, nm, ""))
+    df.insert(0, "exact miRNA", np.where(ps[sel] == EXACT_PASS, nm, ""))
+    return df
