@@ -316,7 +316,7 @@ def main():
         cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS if n_pass > ISO_PASS else -2, n_mirna)
         if args.workload == "c5":
             from mirge3_amd import a2i
-            state["tally"] = a2i.tally(casc, uniq, res)
+            state["tally"] = a2i.tally(casc, uniq, res)["count_true"]
         state["U"] = len(uniq)
         state["cls"] = cls
         res.close()

@@ -145,14 +145,22 @@ int mirge_annotation_csv(const char* mapped_path, const char* unmapped_path, con
                          int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
                          const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n);
 
-/* ---- per-position variant tally (BASELINE config 5): the counting core of
- * A2IEditing / judgeAllign (mirge2_tRF_a2i.py:298-366) over the reads the cascade annotated to a
- * miRNA in exact_pass / iso_pass (iso_trim5 = that pass's -5).  accepted/canonical[n_mirna * S],
- * census[n_mirna * 32 * 16 * S] (position, canonical base * 4 + read base), A=0 C=1 G=2 T=3.    */
+/* ---- per-position variant tally / A-to-I counting core (BASELINE config 5): replaces
+ * align2TargetSeq / judgeAllign / A2IEditing / mismatchCountAnalysis (mirge2_tRF_a2i.py:246-518) and the membership
+ * rules of a2i_editing (:988-1016) for the reads the cascade annotated to a miRNA in exact_pass / iso_pass.
+ *   fam_of_ref[n_mirna]   family (merged miRNA name) of every reference of the miRNA library, -1 = none
+ *   target_ascii/off      canonical sequence of each family (<org>_mirna_SNP_pseudo_<db>.fa), <= 32 nt
+ *   retained[n reads]     the genome filter's answer per read in handle order (:1085-1096), NULL = every read
+ *   freq[S]               1e6 / Filtered miRNA Reads per sample (an isomiR read is a member iff count*freq >= 1 somewhere)
+ * out: fam_tables[5][n_fam][S] = n_seqs, seq_true, count_true, canon, kept_exact;
+ *      census[n_fam][32][16][3][S] (position, target base * 4 + read base, variant raw / accepted / accepted+retained),
+ *      read base != target base and position < len - 5 only;  A=0 C=1 G=2 T=3;
+ *      diag_out/state_out[n reads] (may be NULL): diagonal of the alignment; 1 accepted, 0 rejected, -1 not a member. */
 #define MIRGE_TALLY_POSITIONS 32
-int mirge_variant_tally(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, const mirge_lib* mirna,
-                        int32_t exact_pass, int32_t iso_pass, int32_t iso_trim5, int64_t n_mirna,
-                        int64_t* accepted, int64_t* canonical, int64_t* census);
+int mirge_variant_tally(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, int32_t exact_pass,
+                        int32_t iso_pass, const int32_t* fam_of_ref, int64_t n_mirna, const char* target_ascii,
+                        const int64_t* target_off, int64_t n_fam, const uint8_t* retained, const double* freq,
+                        int64_t* fam_tables, int64_t* census, int8_t* diag_out, int8_t* state_out);
 
 /* ---- measurement (bench.py): HIP events on the ctx stream ---- */
 int mirge_ctx_timer_start(mirge_ctx* ctx);

@@ -360,16 +360,34 @@ def count_join_host(ctx: Context, ps: np.ndarray, ref: np.ndarray, counts: np.nd
 TALLY_POSITIONS = 32
 
 
-def variant_tally(ctx: Context, uniq: DeviceReads, res: CascadeResult, mirna: DeviceLibrary, exact_pass: int,
-                  iso_pass: int, iso_trim5: int):
-    """-> (accepted [R, S], canonical [R, S], census [R, 32, 4, 4, S]) int64 (config 5 / row a16)."""
-    R, S = mirna.n_refs, uniq.n_samples
-    acc = np.zeros((max(R, 1), S), dtype=np.int64)
-    can = np.zeros((max(R, 1), S), dtype=np.int64)
-    cen = np.zeros((max(R, 1), TALLY_POSITIONS, 4, 4, S), dtype=np.int64)
-    _check(load().mirge_variant_tally(ctx._h, uniq._h, res._h, mirna._h, C.c_int32(exact_pass), C.c_int32(iso_pass),
-                                      C.c_int32(iso_trim5), C.c_int64(R), _p(acc), _p(can), _p(cen)), "mirge_variant_tally")
-    return acc[:R], can[:R], cen[:R]
+def variant_tally(ctx: Context, uniq: DeviceReads, res: CascadeResult, exact_pass: int, iso_pass: int,
+                  fam_of_ref: np.ndarray, targets: FlatSeqs, retained: Optional[np.ndarray], freq: np.ndarray,
+                  per_read: bool = True):
+    """``mirge_variant_tally`` (config 5 / rows a16, N1) -> dict: n_seqs, seq_true, count_true, canon, kept_exact
+    [n_fam, S]; census [n_fam, 32, 4, 4, 3, S]; diag, state [n reads] (handle order) when ``per_read``."""
+    n_fam, S, n = len(targets), uniq.n_samples, len(uniq)
+    fam_of_ref = np.ascontiguousarray(fam_of_ref, dtype=np.int32)
+    tdata = np.ascontiguousarray(targets.data, dtype=np.uint8)
+    toff = np.ascontiguousarray(targets.offsets, dtype=np.int64)
+    freq = np.ascontiguousarray(freq, dtype=np.float64)
+    assert freq.shape[0] == S
+    ret = None if retained is None else np.ascontiguousarray(retained, dtype=np.uint8)
+    assert ret is None or ret.shape[0] == n
+    tabs = np.zeros((5, max(n_fam, 1), S), dtype=np.int64)
+    cen = np.zeros((max(n_fam, 1), TALLY_POSITIONS, 4, 4, 3, S), dtype=np.int64)
+    diag = np.zeros(max(n, 1), dtype=np.int8) if per_read else None
+    state = np.zeros(max(n, 1), dtype=np.int8) if per_read else None
+    if n_fam == 0:
+        tabs = np.zeros((5, 0, S), dtype=np.int64)
+    _check(load().mirge_variant_tally(ctx._h, uniq._h, res._h, C.c_int32(exact_pass), C.c_int32(iso_pass), _p(fam_of_ref),
+                                      C.c_int64(fam_of_ref.shape[0]), _p(tdata) if tdata.size else C.c_void_p(0), _p(toff),
+                                      C.c_int64(n_fam), _p(ret), _p(freq), _p(tabs) if n_fam else _p(np.zeros(1, np.int64)),
+                                      _p(cen), _p(diag), _p(state)), "mirge_variant_tally")
+    out = dict(zip(("n_seqs", "seq_true", "count_true", "canon", "kept_exact"), tabs[:, :n_fam]))
+    out["census"] = cen[:n_fam]
+    if per_read:
+        out["diag"], out["state"] = diag[:n], state[:n]
+    return out
 
 
 def annotation_csv(mapped_path, unmapped_path, header: str, seqs: FlatSeqs, ps: np.ndarray, ref: np.ndarray,

@@ -51,9 +51,18 @@ def parse_args(argv=None):
                     help="write <sample>.trim.collapse.fa")
     ap.add_argument("-ie", "--isoform-entropy", dest="isoform_entropy", action="store_true",
                     help="write isomirs.csv and isomirs.samples.csv (isomiR RPMs and entropies)")
-    ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted, unused (GPU path)")
+    ap.add_argument("-ai", "--AtoI", dest="AtoI", action="store_true",
+                    help="A-to-I editing report (a2IEditing.report.csv, .newform.csv, .detail.txt); the genome filter runs "
+                         "`bowtie` against <org>_genome as the reference does (-pbwt / PATH), or reads --genome-retained")
+    ap.add_argument("-pbwt", "--bowtie-path", dest="bowtie_path", default=None,
+                    help="directory of the bowtie binary used by -ai for the two whole-genome runs")
+    ap.add_argument("--genome-retained", dest="genome_retained", default=None,
+                    help="-ai without bowtie: file of the miRNA reads with a unique best genome alignment (one per line)")
+    ap.add_argument("--genome-aligned", dest="genome_aligned", default=None,
+                    help="-ai without bowtie: file of the edited canonical sequences that align to the genome")
+    ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted; only -ai's bowtie runs use it")
     ap.add_argument("--device", type=int, default=None)
-    for flag in ("-a", "-g", "-qumi", "-nmir", "-gff", "-bam", "-trf", "-ai", "-mEC", "-dex"):
+    for flag in ("-a", "-g", "-qumi", "-nmir", "-gff", "-bam", "-trf", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -62,6 +71,9 @@ def parse_args(argv=None):
             ap.error(f"-{k[4:]} belongs to a miRge3.0 subsystem outside the MI355X hot path (DESIGN.md section 0)")
     if args.umiDedup and not args.uniq_mol_ids:
         ap.error("-udd requires -umi f,b")
+    args.bowtieVersion, args.phred64 = "True", False
+    if args.AtoI and (args.uniq_mol_ids or args.tcf_out or args.save_pkl or args.resume):
+        ap.error("-ai runs on the device-resident route: not together with -umi / -tcf / -spl / -rr")
     args.adapters = args.front = args.qiagenumi = None
     return args
 

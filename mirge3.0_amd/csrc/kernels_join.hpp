@@ -48,73 +48,108 @@ __global__ void k_scatter_out(const T* __restrict__ in, uint32_t n, uint32_t bas
 
 
 // ------------------------------------------------------------------------------------------
-// k_tally (BASELINE config 5): per-position base-change tally of the reads
-// annotated to a miRNA (exact pass or isomiR pass) against that miRNA's canonical sequence -- the
-// arithmetic of A2IEditing / judgeAllign (mirge/libs/mirge2_tRF_a2i.py:298-366) on the cascade's
-// ungapped alignment instead of Bio.pairwise2's.
-//   d = offset of read base 0 relative to canonical base 0 (negative: the read starts before it).
-//   judgeAllign (:298-332), literally: reject if d > 1; walk the aligned columns from the canonical's
-//   first base to min(end_pos1, end_pos2) (end_pos1 = aligned length - head dashes of the target - 1 - 3,
-//   end_pos2 = last read base), count matches and mismatches (a column past the canonical's end is a
-//   mismatch, a column before the read's first base is skipped); accept iff mismatches <= 1 and
-//   matches >= Lc - 4 (- 1 more if d == 1).
-//   Accepted reads add their counts to accepted[ref][s], to canonical[ref][s] when the read is an
-//   exact substring of the canonical (:350-351), and to census[ref][q][canon base*4 + read base][s]
-//   for every canonical position q they cover (A->G at q < Lc-5 is the A-to-I count, :358-366).
+// k_tally (BASELINE config 5): the arithmetic of align2TargetSeq / judgeAllign /
+// A2IEditing / mismatchCountAnalysis (mirge/libs/mirge2_tRF_a2i.py:246-518) for every read the cascade annotated to
+// a miRNA, against the canonical sequence of that miRNA's FAMILY (the merged name's entry of
+// <org>_mirna_SNP_pseudo_<db>.fa, :1037-1044 -- not necessarily the reference the read aligned to).
+//   member of its family's list: an exact-miRNA read, or an isomiR read with count * freq[s] >= 1 in some sample
+//     (freq[s] = 1e6 / Filtered miRNA Reads, :988-1016);
+//   alignment: pairwise2.align.localms(target, read, 2, -1, -20, -20) (:254) = the best-scoring ungapped diagonal
+//     (a gap costs 20, more than any annotated read can win back); ties: the alignment that ends first in the
+//     target, then first in the read;  d = position of read base 0 relative to target base 0;
+//   judgeAllign (:298-332), literally: reject if d > 1; walk the columns from the target's first base to
+//     min(end_pos1, end_pos2) (end_pos1 = aligned length - head dashes of the target - 1 - 3, end_pos2 = last read
+//     base), count matches and mismatches (a column past the target's end is a mismatch, a column before the read's
+//     first base is skipped); accept iff mismatches <= 1 and matches >= Lt - 4 (- 1 more if d == 1);
+//   per (family, sample) with count > 0: n_seqs (list length, :1133-1137), and over accepted AND retained reads
+//     (retained = the genome filter's answer, :1085-1096): seq_true, count_true, canon (the read is a substring of the
+//     target, :350), kept_exact (kept reads that are exact-miRNA rows: checkSeqList, :964-976);
+//   census[family][q][target base * 4 + read base][variant][s] for q < Lt - 5 and read base != target base:
+//     variant 0 = every member (raw), 1 = accepted, 2 = accepted and retained (mismatchCountAnalysis, :440-517;
+//     A -> G of variant 2 is A2IEditing's position count, :358-366).
 // ------------------------------------------------------------------------------------------
 #define MIRGE_TALLY_MAXPOS 32
-__global__ void k_tally(GroupView<1> g, const int8_t* __restrict__ res_pass, const int32_t* __restrict__ res_ref,
-                        const int32_t* __restrict__ res_off, const uint32_t* __restrict__ counts, int32_t S,
-                        MirgeLibView lib, int32_t exact_pass, int32_t iso_pass, int32_t iso_trim5,
-                        unsigned long long* __restrict__ accepted, unsigned long long* __restrict__ canonical,
-                        unsigned long long* __restrict__ census) {
+struct TallyOut {
+    unsigned long long *n_seqs, *seq_true, *count_true, *canon, *kept_exact, *census;
+    int8_t *diag, *state;  // per read, handle order: diagonal; 1 accepted / 0 rejected / -1 not a member
+};
+
+__global__ void k_tally(GroupView<1> g, uint32_t base, const uint32_t* __restrict__ orig, const int8_t* __restrict__ res_pass,
+                        const int32_t* __restrict__ res_ref, const uint32_t* __restrict__ counts, int32_t S,
+                        int32_t exact_pass, int32_t iso_pass, const int32_t* __restrict__ fam_of_ref,
+                        const uint64_t* __restrict__ tgt_bits, const uint8_t* __restrict__ tgt_len,
+                        const uint8_t* __restrict__ retained, const double* __restrict__ freq, TallyOut o) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
         const int p = res_pass[i];
-        if (p != exact_pass && p != iso_pass) continue;
-        const int32_t r = res_ref[i];
-        const int d = res_off[i] - (p == iso_pass ? iso_trim5 : 0);
-        const uint32_t rs = lib.ref_start[r];
-        const int Lc = (int)(lib.ref_start[r + 1] - rs) - 1;  // minus the separator
-        const int Lr = g.len[i];
+        const uint32_t h = orig ? orig[i] : base + i;
+        if (p != exact_pass && p != iso_pass) { o.diag[h] = 0; o.state[h] = -1; continue; }
+        const int32_t f = fam_of_ref[res_ref[i]];
+        bool member = f >= 0 && p == exact_pass;
+        if (f >= 0 && p == iso_pass)
+            for (int32_t s = 0; s < S; s++) member |= (double)counts[(size_t)i * S + s] * freq[s] >= 1.0;
+        if (!member) { o.diag[h] = 0; o.state[h] = -1; continue; }
+        const uint64_t tw = tgt_bits[f];
+        const int Lt = tgt_len[f], Lr = g.len[i];
         const uint64_t rw = g.seq[i];
         const uint64_t rn = g.nmask ? g.nmask[i] : 0ull;
-        if (d > 1) continue;
-        const int hd_t = d < 0 ? -d : 0, hd_s = d > 0 ? d : 0;
-        const int A = max(hd_t + Lc, hd_s + Lr);
-        const int end1 = A - hd_t - 1 - 3, end2 = hd_s + Lr - 1;
-        const int last = min(end1, end2);
-        int mism = 0, match = 0;
-        for (int pos = hd_t; pos <= last; pos++) {
-            const int ri = pos - hd_s, q = pos - hd_t;
-            if (ri < 0) continue;
-            bool eq = false;
-            if (q < Lc && !((rn >> (2 * ri)) & 1ull)) {
-                const uint64_t gq = (uint64_t)rs + (uint64_t)q;
-                eq = ((lib.T[gq >> 5] >> (2 * (gq & 31))) & 3ull) == ((rw >> (2 * ri)) & 3ull);
+        // ---- best ungapped local alignment: Kadane along every diagonal, +2 / -1
+        int best = 0, best_i = 0, best_j = 0, d = 0;
+        for (int dd = -(Lr - 1); dd < Lt; dd++) {
+            int run = 0;
+            const int i0 = dd > 0 ? dd : 0, i1 = min(Lt, dd + Lr);
+            for (int ti = i0; ti < i1; ti++) {
+                const int rj = ti - dd;
+                const bool eq = !((rn >> (2 * rj)) & 1ull) && (((tw >> (2 * ti)) & 3ull) == ((rw >> (2 * rj)) & 3ull));
+                run = max(0, run + (eq ? 2 : -1));
+                if (run > best || (run == best && run > 0 && (ti < best_i || (ti == best_i && rj < best_j)))) {
+                    best = run; best_i = ti; best_j = rj; d = dd;
+                }
             }
-            if (eq) match++; else mism++;
         }
-        const int match_limit = Lc - 3 - 1 - (d == 1 ? 1 : 0);
-        if (mism > 1 || match < match_limit) continue;
-        // exact substring of the canonical?
-        bool sub = d >= 0 && d + Lr <= Lc && rn == 0ull;
-        for (int ri = 0; sub && ri < Lr; ri++) {
-            const uint64_t gq = (uint64_t)rs + (uint64_t)(d + ri);
-            sub = ((lib.T[gq >> 5] >> (2 * (gq & 31))) & 3ull) == ((rw >> (2 * ri)) & 3ull);
+        // ---- judgeAllign
+        bool state = d <= 1;
+        if (state) {
+            const int hd_t = d < 0 ? -d : 0, hd_s = d > 0 ? d : 0;
+            const int A = max(hd_t + Lt, hd_s + Lr);
+            const int last = min(A - hd_t - 1 - 3, hd_s + Lr - 1);
+            int mism = 0, match = 0;
+            for (int pos = hd_t; pos <= last; pos++) {
+                const int rj = pos - hd_s, q = pos - hd_t;
+                if (rj < 0) continue;
+                const bool eq = q < Lt && !((rn >> (2 * rj)) & 1ull) && (((tw >> (2 * q)) & 3ull) == ((rw >> (2 * rj)) & 3ull));
+                if (eq) match++; else mism++;
+            }
+            state = !(mism > 1 || match < Lt - 3 - 1 - (d == 1 ? 1 : 0));
+        }
+        o.diag[h] = (int8_t)d;
+        o.state[h] = state ? 1 : 0;
+        const bool keep = state && (!retained || retained[h]);
+        // the read is a substring of the target (`seqList[j] in targetSeq`, :350): any offset, no N
+        bool sub = false;
+        if (keep && rn == 0ull && Lr <= Lt) {
+            const uint64_t m = mirge_lowmask2(Lr);
+            for (int a = 0; a + Lr <= Lt && !sub; a++) sub = ((tw >> (2 * a)) & m) == rw;
         }
         for (int32_t s = 0; s < S; s++) {
             const unsigned long long c = counts[(size_t)i * S + s];
             if (!c) continue;
-            atomicAdd(&accepted[(size_t)r * S + s], c);
-            if (sub) atomicAdd(&canonical[(size_t)r * S + s], c);
-            for (int ri = max(0, -d); ri < Lr; ri++) {
-                const int q = d + ri;
-                if (q >= Lc || q >= MIRGE_TALLY_MAXPOS) break;
-                if ((rn >> (2 * ri)) & 1ull) continue;  // an N call is no base change
-                const uint64_t gq = (uint64_t)rs + (uint64_t)q;
-                const int cb = (int)((lib.T[gq >> 5] >> (2 * (gq & 31))) & 3ull);
-                const int rb = (int)((rw >> (2 * ri)) & 3ull);
-                atomicAdd(&census[(((size_t)r * MIRGE_TALLY_MAXPOS + q) * 16 + cb * 4 + rb) * S + s], c);
+            const size_t fs = (size_t)f * S + s;
+            atomicAdd(&o.n_seqs[fs], 1ull);
+            if (keep) {
+                atomicAdd(&o.seq_true[fs], 1ull);
+                atomicAdd(&o.count_true[fs], c);
+                if (sub) atomicAdd(&o.canon[fs], c);
+                if (p == exact_pass) atomicAdd(&o.kept_exact[fs], 1ull);
+            }
+            for (int q = max(0, d); q < Lt - 5 && q - d < Lr; q++) {
+                const int rj = q - d;
+                if ((rn >> (2 * rj)) & 1ull) continue;  // an N call is none of the twelve base changes
+                const int cb = (int)((tw >> (2 * q)) & 3ull), rb = (int)((rw >> (2 * rj)) & 3ull);
+                if (cb == rb) continue;
+                unsigned long long* cell = &o.census[((((size_t)f * MIRGE_TALLY_MAXPOS + q) * 16 + cb * 4 + rb) * 3) * S + s];
+                atomicAdd(cell, c);
+                if (state) atomicAdd(cell + S, c);
+                if (keep) atomicAdd(cell + 2 * S, c);
             }
         }
     }

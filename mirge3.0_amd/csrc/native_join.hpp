@@ -95,35 +95,84 @@ extern "C" int mirge_count_join_host(mirge_ctx* c, const int8_t* pass, const int
     return 0;
 }
 
-extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const mirge_lib* mirna,
-                                   int32_t exact_pass, int32_t iso_pass, int32_t iso_trim5, int64_t n_mirna,
-                                   int64_t* accepted, int64_t* canonical, int64_t* census) {
+// per-position variant tally / A-to-I counting core: see k_tally.  Everything per (family, sample) comes back in
+// ONE block: [n_seqs | seq_true | count_true | canon | kept_exact] (n_fam * S each) then census
+// [n_fam][32][16][3][S]; diag / state per read in handle order.
+extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, int32_t exact_pass,
+                                   int32_t iso_pass, const int32_t* fam_of_ref, int64_t n_mirna, const char* target_ascii,
+                                   const int64_t* target_off, int64_t n_fam, const uint8_t* retained, const double* freq,
+                                   int64_t* fam_tables, int64_t* census, int8_t* diag_out, int8_t* state_out) {
     static_assert(MIRGE_TALLY_POSITIONS == MIRGE_TALLY_MAXPOS, "tally positions");
-    if (!c || !U || !res || !mirna || !accepted || !canonical || !census || n_mirna != mirna->n_refs)
+    if (!c || !U || !res || !fam_of_ref || n_mirna < 0 || n_fam < 0 || !target_off || (n_fam > 0 && !target_ascii) || !freq ||
+        !fam_tables || !census)
         return fail(-1, "mirge_variant_tally: bad argument");
     if (U->n_samples < 1) return fail(-1, "read set has no count matrix");
     if (res->n != U->n) return fail(-1, "result and read set differ in size");
+    for (int32_t p : {exact_pass, iso_pass})
+        if (p >= 0 && p < res->n_pass && (int64_t)res->n_refs[p] > n_mirna)
+            return fail(-1, "mirge_variant_tally: fam_of_ref is shorter than the miRNA library of pass " + std::to_string(p));
     HIPOK(hipSetDevice(c->device));
     const int32_t S = U->n_samples;
-    const size_t n_rs = (size_t)std::max<int64_t>(n_mirna, 1) * S, n_cen = n_rs * MIRGE_TALLY_MAXPOS * 16;
+    // family targets, 2-bit packed on the host (a few thousand sequences of <= 32 nt)
+    std::vector<uint64_t> tb((size_t)std::max<int64_t>(n_fam, 1), 0ull);
+    std::vector<uint8_t> tl((size_t)std::max<int64_t>(n_fam, 1), 0);
+    for (int64_t f = 0; f < n_fam; f++) {
+        const int64_t L = target_off[f + 1] - target_off[f];
+        if (L < 0 || L > MIRGE_TALLY_MAXPOS) return fail(-6, "family " + std::to_string(f) + ": canonical sequence of " + std::to_string(L) + " nt; the limit is 32");
+        for (int64_t k = 0; k < L; k++) {
+            const int code = mirge_base_code(target_ascii[target_off[f] + k]);
+            if (code < 0) return fail(-7, "family " + std::to_string(f) + ": canonical sequence holds a character other than A/C/G/T/U");
+            tb[(size_t)f] |= (uint64_t)code << (2 * k);
+        }
+        tl[(size_t)f] = (uint8_t)L;
+    }
+    for (int64_t r = 0; r < n_mirna; r++)
+        if (fam_of_ref[r] >= n_fam) return fail(-1, "fam_of_ref holds a family index out of range");
+    const size_t n_fs = (size_t)std::max<int64_t>(n_fam, 1) * S, n_cen = n_fs * MIRGE_TALLY_MAXPOS * 16 * 3;
+    const size_t n_words = 5 * n_fs + n_cen;
     unsigned long long* d = nullptr;
-    CHECK(dalloc(c, &d, 2 * n_rs + n_cen));
-    HIPOK(hipMemsetAsync(d, 0, (2 * n_rs + n_cen) * 8, c->stream));
+    uint64_t* dtb = nullptr; uint8_t* dtl = nullptr; int32_t* dfam = nullptr; uint8_t* dret = nullptr; double* dfreq = nullptr;
+    int8_t *ddiag = nullptr, *dstate = nullptr;
+    const size_t n = (size_t)std::max<int64_t>(U->n, 1);
+    CHECK(dalloc(c, &d, n_words));
+    CHECK(dalloc(c, &dtb, tb.size()));
+    CHECK(dalloc(c, &dtl, tl.size()));
+    CHECK(dalloc(c, &dfam, (size_t)std::max<int64_t>(n_mirna, 1)));
+    CHECK(dalloc(c, &dfreq, (size_t)S));
+    CHECK(dalloc(c, &ddiag, n));
+    CHECK(dalloc(c, &dstate, n));
+    if (retained) CHECK(dalloc(c, &dret, n));
+    HIPOK(hipMemsetAsync(d, 0, n_words * 8, c->stream));
+    HIPOK(hipMemcpyAsync(dtb, tb.data(), tb.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(dtl, tl.data(), tl.size(), hipMemcpyHostToDevice, c->stream));
+    if (n_mirna) HIPOK(hipMemcpyAsync(dfam, fam_of_ref, (size_t)n_mirna * 4, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(dfreq, freq, (size_t)S * 8, hipMemcpyHostToDevice, c->stream));
+    if (retained && U->n) HIPOK(hipMemcpyAsync(dret, retained, (size_t)U->n, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemsetAsync(dstate, 0xFF, n, c->stream));  // reads of the wide groups are never members
+    HIPOK(hipMemsetAsync(ddiag, 0, n, c->stream));
+    TallyOut o;
+    o.n_seqs = d; o.seq_true = d + n_fs; o.count_true = d + 2 * n_fs; o.canon = d + 3 * n_fs; o.kept_exact = d + 4 * n_fs;
+    o.census = d + 5 * n_fs; o.diag = ddiag; o.state = dstate;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
-        if (kGroupW[gi] != 1) continue;  // a read annotated to a miRNA is at most 3 nt longer than it
+        if (kGroupW[gi] != 1) continue;  // a read annotated to a miRNA is at most 3 nt longer than it: the <= 31-nt groups
         const ResGroup& g = res->g[gi];
+        const ReadGroup& rg = U->g[gi];
         if (!g.n) continue;
         LaunchScope ls(c, "k_tally", g.n);
-        hipLaunchKernelGGL(k_tally, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(U->g[gi]), g.pass, g.ref,
-                           g.off, U->g[gi].counts, S, mirna->view(), exact_pass, iso_pass, iso_trim5, d, d + n_rs, d + 2 * n_rs);
+        hipLaunchKernelGGL(k_tally, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(rg), rg.base,
+                           (const uint32_t*)rg.orig, g.pass, g.ref, rg.counts, S, exact_pass, iso_pass, dfam, dtb, dtl,
+                           (const uint8_t*)dret, dfreq, o);
     }
-    std::vector<unsigned long long> h(2 * n_rs + n_cen);
-    HIPOK(hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> h(n_words);
+    HIPOK(hipMemcpyAsync(h.data(), d, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+    if (diag_out && U->n) HIPOK(hipMemcpyAsync(diag_out, ddiag, (size_t)U->n, hipMemcpyDeviceToHost, c->stream));
+    if (state_out && U->n) HIPOK(hipMemcpyAsync(state_out, dstate, (size_t)U->n, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
     c->drain();
-    std::memcpy(accepted, h.data(), (size_t)n_mirna * S * 8);
-    std::memcpy(canonical, h.data() + n_rs, (size_t)n_mirna * S * 8);
-    std::memcpy(census, h.data() + 2 * n_rs, (size_t)n_mirna * S * MIRGE_TALLY_MAXPOS * 16 * 8);
-    c->release(d);
+    for (int t = 0; t < 5; t++)  // the device block is sized for max(n_fam, 1)
+        std::memcpy(fam_tables + (size_t)t * n_fam * S, h.data() + (size_t)t * n_fs, (size_t)n_fam * S * 8);
+    std::memcpy(census, h.data() + 5 * n_fs, (size_t)n_fam * S * MIRGE_TALLY_MAXPOS * 16 * 3 * 8);
+    c->release(d); c->release(dtb); c->release(dtl); c->release(dfam); c->release(dret); c->release(dfreq);
+    c->release(ddiag); c->release(dstate);
     return 0;
 }

@@ -101,7 +101,8 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     tm["collapse_cascade_s"] = time.perf_counter() - t
     say(f'Alignment completed in {round(time.perf_counter() - t, 4)} second(s)\n')
     t = time.perf_counter()
-    out = summarize_device(ctx, uniq, res, casc.libs["mirna"], load_merges(str(args.libraries_path), args.organism_name, ref_db),
+    merges = load_merges(str(args.libraries_path), args.organism_name, ref_db)
+    out = summarize_device(ctx, uniq, res, casc.libs["mirna"], merges,
                            list(base_names), sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique,
                            float(args.crThreshold), bool(args.spikeIn), workDir)
     tm["join_tables_s"] = time.perf_counter() - t
@@ -122,6 +123,15 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     _ffi.annotation_csv(workDir / "mapped.csv", workDir / "unmapped.csv", header, seqs, ps, ref, counts, order,
                         list(range(casc.n_pass)), n_cols, names_by_pass)
     tm["per_read_csv_s"] = time.perf_counter() - t
+    if getattr(args, "AtoI", False):  # -ai (summary.py:1034-1057)
+        from .a2i import ListedGenome, a2i_report
+        t = time.perf_counter()
+        genome = getattr(args, "genome_predicate", None)
+        if genome is None and getattr(args, "genome_retained", None):
+            genome = ListedGenome.from_files(args.genome_retained, getattr(args, "genome_aligned", None))
+        out["a2i"] = a2i_report(args, workDir, ref_db, base_names, casc, uniq, res, seqs, ps, ref, counts, order, out, merges,
+                                genome=genome)
+        tm["a2i_report_s"] = time.perf_counter() - t
     if getattr(args, "isoform_entropy", False):  # -ie reads the miRNA rows of the mapped frame: build just those
         from .countjoin import isomir_entropy_tables
         isomir_entropy_tables(mirna_frame(seqs, ps, ref, counts, order, casc, base_names), base_names, out["filtered"], workDir)

@@ -269,52 +269,168 @@ def join(pass_: np.ndarray, ref: np.ndarray, counts: np.ndarray, mirna_names: Li
 
 
 # --------------------------------------------------------------------------------------
-# per-position variant tally (config 5 / row a16): judgeAllign + the counting loop of A2IEditing
-# (mirge/libs/mirge2_tRF_a2i.py:298-366) restated on strings, with the cascade's diagonal in place of
-# Bio.pairwise2's (parity unpinned: Biopython is absent, see mirge3.0_amd/a2i.py)
+# A-to-I editing (row a16 / N1), restated on strings from mirge/libs/mirge2_tRF_a2i.py:230-518.  PINNED against
+# the reference's own align2TargetSeq / judgeAllign / A2IEditing / mismatchCountAnalysis through
+# tests/golden/case4_gff_a2i/a2i_direct.json (made by tests/golden/make_golden.py with a Bio.pairwise2 stand-in:
+# Biopython is absent, so the ALIGNER is restated from its documented behaviour -- best local alignment, +2 / -1,
+# a gap costs 20 per character so it never pays for reads the cascade annotated; ties between diagonals are not
+# pinned and the fixtures hold none).
 # --------------------------------------------------------------------------------------
-def variant_tally(seqs: List[str], counts: np.ndarray, pass_: np.ndarray, ref: np.ndarray, off: np.ndarray,
-                  mirna_seqs: List[str], exact_pass: int = 0, iso_pass: int = 8, iso_trim5: int = 1, maxpos: int = 32):
+def local_diagonal(target: str, read: str):
+    """Best ungapped local alignment of ``read`` on ``target`` (pairwise2.align.localms(target, read, 2, -1, -20, -20)
+    for every pair whose optimum has no gap, mirge2_tRF_a2i.py:254): -> (d, score) with d = position of read base 0
+    relative to target base 0.  Ties: the alignment that ENDS first in the target, then first in the read."""
+    best = (0, None, None)  # (score, end_i, end_j)
+    best_d = None
+    lt, lr = len(target), len(read)
+    for d in range(-(lr - 1), lt):
+        run = 0
+        i0 = max(d, 0)
+        for i in range(i0, min(lt, d + lr)):
+            j = i - d
+            run = max(0, run + (2 if target[i] == read[j] else -1))
+            if run > 0:
+                key = (run, -(i + 1), -(j + 1))
+                if best[1] is None or key > (best[0], -best[1], -best[2]):
+                    best, best_d = (run, i + 1, j + 1), d
+    return best_d, best[0]
+
+
+def padded_pair(target: str, read: str, d: int):
+    """the two strings as pairwise2 returns them for diagonal d: full sequences, '-' padded to one length"""
+    hd_t, hd_s = max(0, -d), max(0, d)
+    a, b = "-" * hd_t + target, "-" * hd_s + read
+    n = max(len(a), len(b))
+    return a + "-" * (n - len(a)), b + "-" * (n - len(b))
+
+
+def judge_align(tgt: str, sq: str) -> bool:
+    """judgeAllign (mirge2_tRF_a2i.py:298-332) on the padded pair"""
+    def dashes(s):
+        h = len(s) - len(s.lstrip("-"))
+        t = len(s) - len(s.rstrip("-"))
+        return h, t
+    hd_t, td_t = dashes(tgt)
+    hd_s, td_s = dashes(sq)
+    len1 = len(tgt) - hd_t - td_t
+    match_limit = len1 - 3 - 1
+    end_pos1 = len(tgt) - hd_t - 1 - 3
+    end_pos2 = len(sq) - td_s - 1
+    if hd_s - hd_t > 1:
+        return False
+    mism = match = 0
+    for pos in range(hd_t, min(end_pos1, end_pos2) + 1):
+        if sq[pos] == "-":
+            continue
+        if tgt[pos] != sq[pos]:
+            mism += 1
+        else:
+            match += 1
+    if hd_s - hd_t == 1:
+        match_limit -= 1
+    return not (mism > 1 or match < match_limit)
+
+
+BASE_PAIRS = [('A', 'G'), ('A', 'C'), ('A', 'T'), ('T', 'G'), ('T', 'A'), ('T', 'C'), ('C', 'G'), ('C', 'A'), ('C', 'T'),
+              ('G', 'A'), ('G', 'C'), ('G', 'T')]  # the order of mismatchCountAnalysis (:440)
+
+
+def a2i_group(target: str, reads: List[str], counts: List[int], retained, start_base="A", end_base="G"):
+    """A2IEditing (mirge2_tRF_a2i.py:335-419) for one miRNA and one sample -> dict with the reference's return values
+    (positions in order of first appearance) plus the per-read diagonal / state and the aligned block of the detail
+    file; mismatchCountAnalysis (:424-518) -> ``census`` [12][3] (raw, state-true, state-true & retained)."""
+    from scipy import stats
+    ds = [local_diagonal(target, r)[0] for r in reads]
+    states = [judge_align(*padded_pair(target, r, d)) for r, d in zip(reads, ds)]
+    H = max([0] + [-d for d in ds])                       # head dashes of the target in the joint frame
+    T = max([0] + [d + len(r) - len(target) for r, d in zip(reads, ds)])
+    width = H + len(target) + T
+    frame = ["-" * H + target + "-" * T] + ["-" * (H + d) + r + "-" * (width - H - d - len(r)) for r, d in zip(reads, ds)]
+    lt = len(target)
+    positions, pcount, kept = [], {}, []
+    count_true = seq_true = canon = 0
+    for j, r in enumerate(reads):
+        if states[j] and r in retained:
+            if r in target:
+                canon += counts[j]
+            kept.append(frame[j + 1])
+            seq_true += 1
+            count_true += counts[j]
+            for q in range(0, lt - 5):
+                if target[q] == start_base and frame[j + 1][H + q] == end_base:
+                    if q + 1 not in pcount:
+                        positions.append(q + 1)
+                        pcount[q + 1] = 0
+                    pcount[q + 1] += counts[j]
+    ratio = {p: (pcount[p] / count_true if count_true else 0) for p in positions}
+    pval = {p: (float(stats.binom.cdf(count_true - pcount[p], count_true, 1 - 0.001)) if count_true - pcount[p] >= 0 else 1.0)
+            for p in positions}
+    census = []
+    for a, b in BASE_PAIRS:
+        tot = [0, 0, 0]
+        for j, r in enumerate(reads):
+            for q in range(0, lt - 5):
+                if target[q] == a and frame[j + 1][H + q] == b:
+                    tot[0] += counts[j]
+                    if states[j]:
+                        tot[1] += counts[j]
+                        if r in retained:
+                            tot[2] += counts[j]
+        census.append(tot)
+    return dict(diagonals=ds, states=states, frame=frame, kept=kept, positions=positions, count=pcount, ratio=ratio,
+                pvalue=pval, countSumTrue=count_true, seqCountTrue=seq_true, canonicalSeqCount=canon, census=census)
+
+
+def variant_tally(seqs: List[str], counts: np.ndarray, pass_: np.ndarray, ref: np.ndarray, fam_of_ref: np.ndarray,
+                  targets: List[str], retained=None, freq=None, exact_pass: int = 0, iso_pass: int = 8, maxpos: int = 32):
+    """What ``mirge_variant_tally`` returns, from the string restatements above: membership (:988-1016), alignment,
+    judgeAllign, and the per-(family, sample) counts / per-position base-change census in three variants."""
     S = counts.shape[1]
-    R = len(mirna_seqs)
+    F = len(targets)
     code = {"A": 0, "C": 1, "G": 2, "T": 3}
-    accepted = np.zeros((R, S), dtype=np.int64)
-    canonical = np.zeros((R, S), dtype=np.int64)
-    census = np.zeros((R, maxpos, 4, 4, S), dtype=np.int64)
+    out = {k: np.zeros((F, S), dtype=np.int64) for k in ("n_seqs", "seq_true", "count_true", "canon", "kept_exact")}
+    census = np.zeros((F, maxpos, 4, 4, 3, S), dtype=np.int64)
+    diag = np.zeros(len(seqs), dtype=np.int8)
+    state = np.full(len(seqs), -1, dtype=np.int8)
     for i, read in enumerate(seqs):
         p = int(pass_[i])
         if p != exact_pass and p != iso_pass:
             continue
-        r = int(ref[i])
-        target = mirna_seqs[r]
-        d = int(off[i]) - (iso_trim5 if p == iso_pass else 0)
-        if d > 1:                                      # start_pos2 - start_pos1 > headShift  (:315)
+        f = int(fam_of_ref[int(ref[i])])
+        if f < 0:
             continue
-        hd_t, hd_s = max(0, -d), max(0, d)
-        tgt = "-" * hd_t + target
-        sq = "-" * hd_s + read
-        A_len = max(len(tgt), len(sq))
-        tgt = tgt + "-" * (A_len - len(tgt))
-        sq = sq + "-" * (A_len - len(sq))
-        end_pos1 = A_len - hd_t - 1 - 3                 # :311
-        end_pos2 = hd_s + len(read) - 1                 # :313
-        mism = match = 0
-        for pos in range(hd_t, min(end_pos1, end_pos2) + 1):  # :318-324
-            if sq[pos] == "-":
-                continue
-            if tgt[pos] != sq[pos]:
-                mism += 1
-            else:
-                match += 1
-        match_limit = len(target) - 3 - 1 - (1 if d == 1 else 0)  # :309,325-328
-        if mism > 1 or match < match_limit:
+        if p == iso_pass and freq is not None and not any(float(counts[i, s]) * float(freq[s]) >= 1 for s in range(S)):
             continue
-        accepted[r] += counts[i]
-        if read in target and "N" not in read:          # :350
-            canonical[r] += counts[i]
-        for ri, b in enumerate(read):
-            q = d + ri
-            if q < 0 or q >= len(target) or q >= maxpos or b not in code:
+        target = targets[f]
+        d, _ = local_diagonal(target, read)
+        if d is None:
+            d = 0
+        st = judge_align(*padded_pair(target, read, d))
+        diag[i], state[i] = d, 1 if st else 0
+        keep = st and (retained is None or bool(retained[i]))
+        for s in range(S):
+            c = int(counts[i, s])
+            if not c:
                 continue
-            census[r, q, code[target[q]], code[b]] += counts[i]
-    return accepted, canonical, census
+            out["n_seqs"][f, s] += 1
+            if keep:
+                out["seq_true"][f, s] += 1
+                out["count_true"][f, s] += c
+                if read in target:
+                    out["canon"][f, s] += c
+                if p == exact_pass:
+                    out["kept_exact"][f, s] += 1
+            for q in range(max(0, d), len(target) - 5):
+                rj = q - d
+                if rj >= len(read):
+                    break
+                b = read[rj]
+                if b not in code or b == target[q]:
+                    continue
+                census[f, q, code[target[q]], code[b], 0, s] += c
+                if st:
+                    census[f, q, code[target[q]], code[b], 1, s] += c
+                if keep:
+                    census[f, q, code[target[q]], code[b], 2, s] += c
+    out["census"], out["diag"], out["state"] = census, diag, state
+    return out

@@ -542,14 +542,16 @@ def test_bench_single_gpu_line(tmp_path):
 
 
 def test_variant_tally_vs_oracle(ctx):
-    """Config-5 primitive: accepted / canonical / per-position base-change census of the miRNA reads,
-    GPU (mirge_variant_tally) vs the string restatement of judgeAllign + A2IEditing's counting loop."""
+    """Config-5 primitive (mirge_variant_tally / k_tally): membership, alignment to the family's canonical sequence,
+    judgeAllign and the per-(family, sample) counts + per-position census in three variants, GPU vs the string
+    restatement the reference's own functions pinned (tests/test_a2i_gff_oracle.py) -- with merged families whose
+    canonical sequence is not the read's own reference, a retained mask and an RPM gate that cuts."""
     from mirge3_amd import a2i
     sl = synth.make_libraries(seed=52, scale="ci")
     rng = np.random.default_rng(6)
     mir = sl.libs["mirna"].seqs.to_list()
     hp = sl.libs["hairpin"].seqs.to_list()
-    reads = synth.make_reads(sl, 40000, seed=3, mix=dict(exact=0.4, isomir=0.5, random=0.1)).to_list()
+    reads = synth.make_reads(sl, 12000, seed=3, mix=dict(exact=0.4, isomir=0.5, random=0.1)).to_list()
     for i in range(0, len(mir), 3):                       # planted A->G edits and end variants
         s = mir[i]
         for q, b in enumerate(s[:-5]):
@@ -565,17 +567,27 @@ def test_variant_tally_vs_oracle(ctx):
     raw = _ffi.DeviceReads.pack(ctx, fs)
     uniq = raw.collapse(sid, 2)
     res = casc.run(uniq)
-    acc, can, cen = a2i.tally(casc, uniq, res)
     ps, ref, off, mm = res.fetch()
     counts, _ = uniq.counts()
     useq = uniq.unpack().to_list()
-    o_acc, o_can, o_cen = oracle.variant_tally(useq, counts.astype(np.int64), ps, ref, off, mir)
-    assert np.array_equal(acc, o_acc) and np.array_equal(can, o_can) and np.array_equal(cen, o_cen)
-    assert acc.sum() > 10000 and cen[:, :, 0, 2, :].sum() > 100
-    rows = a2i.a_to_i_table(acc, cen, sl.libs["mirna"].names, sl.libs["mirna"].seqs.lengths, ["S1", "S2"])
-    assert rows and all(0 < r["position"] <= 25 for r in rows)
-    assert all(0.0 <= p <= 1.0 for r in rows for p in r["p_value"].values())
-    assert a2i.mismatch_census(cen).shape == (12, 2)
+    fam_names, fam_of_ref = a2i.families(sl.libs["mirna"].names, sl.merges)
+    first_member = {}
+    for r, f in enumerate(fam_of_ref):
+        first_member.setdefault(int(f), r)
+    targets = [mir[first_member[f]] for f in range(len(fam_names))]
+    retained = (rng.random(len(useq)) < 0.8).astype(np.uint8)
+    freq = np.array([0.4, 1e300])  # sample 1: an isomiR read needs 3 copies; sample 2: every read is a member
+    g = a2i.tally(casc, uniq, res, fam_of_ref, FlatSeqs.from_list(targets), retained, freq, per_read=True)
+    o = oracle.variant_tally(useq, counts.astype(np.int64), ps, ref, fam_of_ref, targets, retained, freq)
+    for k in ("diag", "state", "n_seqs", "seq_true", "count_true", "canon", "kept_exact", "census"):
+        assert np.array_equal(g[k], o[k]), k
+    assert g["count_true"].sum() > 5000 and g["census"][:, :, 0, 2, 2, :].sum() > 50 and (g["state"] == 0).sum() > 20
+    assert (g["state"] == -1).sum() > (ps < 0).sum()  # the gate dropped isomiR reads
+    # the defaults (bench.py's config 5): every miRNA its own family, every read retained and a member
+    g2 = a2i.tally(casc, uniq, res, per_read=True)
+    o2 = oracle.variant_tally(useq, counts.astype(np.int64), ps, ref, np.arange(len(mir)), mir)
+    for k in ("diag", "state", "count_true", "canon", "census"):
+        assert np.array_equal(g2[k], o2[k]), k
     res.close(); uniq.close(); raw.close(); casc.close()
 
 
@@ -950,11 +962,12 @@ def test_full_size_c5_properties(ctx):
     c = counts[:, 0].astype(np.int64)
     assert cls[0, 0] == c[ps == 0].sum() and cls[8, 0] == c[ps == 8].sum() and cls.sum() + c[ps < 0].sum() == n
     assert np.array_equal(iso[:, 0], np.bincount(ref[ps == 8], weights=c[ps == 8], minlength=n_mirna).astype(np.int64))
-    acc, can, cen = a2i.tally(casc, uniq, res)
-    assert (acc[:, 0] <= ex[:, 0] + iso[:, 0]).all() and (can <= acc).all() and acc.sum() > n // 4
-    # an accepted read adds its count once per aligned position inside the miRNA: position sums never exceed accepted
-    per_pos = cen.sum(axis=(2, 3))[:, :, 0]
-    assert (per_pos <= acc[:, :1]).all() and per_pos[:, 2:12].max() > 0
+    t = a2i.tally(casc, uniq, res)
+    assert (t["count_true"][:, 0] <= ex[:, 0] + iso[:, 0]).all() and (t["canon"] <= t["count_true"]).all()
+    assert t["count_true"].sum() > n // 4 and (t["seq_true"] <= t["n_seqs"]).all()
+    cen = t["census"]
+    assert (cen[..., 2, :] <= cen[..., 1, :]).all() and (cen[..., 1, :] <= cen[..., 0, :]).all()
+    assert cen[:, :, 0, 2, 2, 0].sum() > 0 and cen[:, 27:].sum() == 0
     useq = uniq.unpack()
     pick = np.random.default_rng(5).permutation(len(uniq))[:40000]
     sub = useq.take(pick)
@@ -966,12 +979,72 @@ def test_full_size_c5_properties(ctx):
     r_s = _ffi.DeviceReads.pack(ctx, sub)
     r_s.set_counts(counts[pick])
     res_s = casc.run(r_s)
-    t_g = a2i.tally(casc, r_s, res_s)
+    t_g = a2i.tally(casc, r_s, res_s, per_read=True)
     a_s = res_s.fetch()
     for x, y in zip(a_s, (ps, ref, off, mm)):
         assert np.array_equal(x, y[pick])
-    t_o = oracle.variant_tally(sub.to_list(), counts[pick].astype(np.int64), a_s[0], a_s[1], a_s[2],
-                               sl.libs["mirna"].seqs.to_list())
-    for x, y in zip(t_g, t_o):
-        assert np.array_equal(x, y)
+    mir = sl.libs["mirna"].seqs.to_list()
+    t_o = oracle.variant_tally(sub.to_list(), counts[pick].astype(np.int64), a_s[0], a_s[1], np.arange(len(mir)), mir)
+    for k in ("diag", "state", "n_seqs", "seq_true", "count_true", "canon", "kept_exact", "census"):
+        assert np.array_equal(t_g[k], t_o[k]), k
     res_s.close(); r_s.close(); res.close(); uniq.close(); raw.close(); casc.close()
+
+
+# ---------------------------------------------------------------- -ai / -gff against the reference's own files (case4)
+def _case4_run(tmp_path, **flags):
+    """golden case 4 expanded to FASTQ files and pushed through the CLI's device-resident route"""
+    from mirge3_amd import fastpath
+    case = GoldenCase("case4_gff_a2i")
+    files = []
+    for s, nm in enumerate(case.samples):
+        p = tmp_path / f"{nm}.fastq"
+        with open(p, "w") as fh:
+            for seq, row in zip(case.seqs, case.counts):
+                if row[s]:
+                    fh.write(f"@r\n{seq}\n+\n{'I' * len(seq)}\n" * int(row[s]))
+        files.append(str(p))
+    work = tmp_path / "out"
+    work.mkdir()
+    args = SimpleNamespace(libraries_path=case.libdir, organism_name=ORG, spikeIn=False, quiet=True, minimum_length=16,
+                           crThreshold="0.1", device=0, isoform_entropy=False, threads=1, bowtieVersion="True", phred64=False,
+                           bowtie_path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fake_bowtie"), **flags)
+    out = fastpath.run(args, files, case.samples, str(work), "miRBase")
+    return case, work, out
+
+
+def test_a2i_report_equals_the_reference_files(tmp_path):
+    """-ai: a2IEditing.report.csv, a2IEditing.report.newform.csv and a2IEditing.detail.txt byte for byte what the
+    reference's a2i_editing wrote for the same reads (the two genome runs answered by the same bowtie stand-in), and
+    the kernel's per-(miRNA, sample) counts against the oracle's string restatement."""
+    case, work, out = _case4_run(tmp_path, AtoI=True)
+    for f in ("miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "a2IEditing.report.csv",
+              "a2IEditing.report.newform.csv", "a2IEditing.detail.txt"):
+        assert (work / f).read_text() == case.text(f), f
+    a = out["a2i"]
+    with open(os.path.join(case.dir, "genome_retained.txt")) as fh:
+        golden_ret = {ln.strip() for ln in fh if ln.strip() and not ln.startswith("#")}
+    d = out["device"]
+    seqs = d["seqs"].to_list()
+    assert {s for s, r in zip(seqs, a["retained"]) if r} <= golden_ret
+    # every gated (family, sample): counts, census and per-read states vs the restated reference functions
+    t, fam = a["tally"], a["families"]
+    from mirge3_amd.a2i import families, read_pseudo_fasta, BASE_PAIRS, CODE
+    _, fam_of_ref = families(case.libs["mirna"].names, case.merges)
+    pseudo = read_pseudo_fasta(os.path.join(case.libdir, ORG, "fasta.Libs", f"{ORG}_mirna_SNP_pseudo_miRBase.fa"))
+    ps, ref = d["ann"][0], d["ann"][1]
+    checked = 0
+    for f, s in zip(*np.nonzero(a["gate"])):
+        rows = [i for i in d["order"] if ps[i] in (0, 8) and fam_of_ref[ref[i]] == f and t["state"][i] >= 0 and d["counts"][i, s] > 0]
+        rows.sort(key=lambda i: ps[i] != 0)  # exact rows first, frame order inside
+        reads = [seqs[i] for i in rows]
+        cnts = [int(d["counts"][i, s]) for i in rows]
+        o = oracle.a2i_group(pseudo[fam[f]], reads, cnts, {seqs[i] for i in rows if a["retained"][i]})
+        assert o["diagonals"] == [int(t["diag"][i]) for i in rows] and o["states"] == [bool(t["state"][i]) for i in rows]
+        assert (o["countSumTrue"], o["seqCountTrue"], o["canonicalSeqCount"]) == (t["count_true"][f, s], t["seq_true"][f, s], t["canon"][f, s])
+        assert len(rows) == t["n_seqs"][f, s]
+        for k, (x, y) in enumerate(BASE_PAIRS):
+            assert o["census"][k] == t["census"][f, :, CODE[x], CODE[y], :, s].sum(axis=0).tolist()
+        for q, c in o["count"].items():
+            assert t["census"][f, q - 1, 0, 2, 2, s] == c
+        checked += 1
+    assert checked >= 20

@@ -126,7 +126,9 @@ def test_cli_flags_in_and_out_of_scope():
     a = parse_args(base + ["-umi", "4,4", "-udd", "-tcf", "-spk", "-m", "18", "-ie"])
     assert a.uniq_mol_ids == "4,4" and a.umiDedup and a.tcf_out and a.spikeIn and a.minimum_length == 18 and a.isoform_entropy
     assert a.adapters is None and a.qiagenumi is None
-    for bad in (["-udd"], ["-qumi"], ["-a", "illumina"], ["-gff"], ["-bam"], ["-trf"], ["-ai"], ["-nmir"], ["-mEC"]):
+    b = parse_args(base + ["-ai", "-pbwt", "/opt/bowtie", "--genome-retained", "r.txt"])
+    assert b.AtoI and b.bowtie_path == "/opt/bowtie" and b.genome_retained == "r.txt"
+    for bad in (["-udd"], ["-qumi"], ["-a", "illumina"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"]):
         with pytest.raises(SystemExit):
             parse_args(base + bad)
 
