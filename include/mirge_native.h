@@ -162,6 +162,25 @@ int mirge_variant_tally(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_res
                         const int64_t* target_off, int64_t n_fam, const uint8_t* retained, const double* freq,
                         int64_t* fam_tables, int64_t* census, int8_t* diag_out, int8_t* state_out);
 
+/* ---- isomiR typing for the miRTop GFF3: replaces the per-read difflib.Differ diff and list
+ * rewriting of create_gff (mirge/libs/summary.py:204-470) with one kernel.  For every read the cascade annotated in
+ * exact_pass / iso_pass: the canonical sequence of its miRNA name (master_of_ref -> master tables), the precursor and
+ * the canonical's position in it (what summary.py:147-186 looks up), and from those the record the reference prints:
+ * type, precursor coordinates, Variant string, Cigar string.  slot_of_read[read] = row of records_out (-1: skip);
+ * a record is MIRGE_ISO_RECORD_BYTES: int32 start, int32 end, uint8 kind (0 none, 1 ref_miRNA, 2 isomiR), uint8 pad,
+ * uint16 variant length, uint16 cigar length, char text[320] (variant then cigar).                                 */
+#define MIRGE_ISO_RECORD_BYTES 336
+int mirge_isomir_type(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, int32_t exact_pass, int32_t iso_pass,
+                      const int32_t* master_of_ref, int64_t n_mirna, const char* master_ascii, const int32_t* master_off,
+                      const int32_t* pre_of_master, const int32_t* start0, int64_t n_master, const char* pre_ascii,
+                      const int32_t* pre_off, int64_t n_pre, const int32_t* slot_of_read, int64_t n_rows, void* records_out);
+/* the GFF3 file from those records (summary.py:60-64 header, :204 / :465 lines; UID = miRgeEssential.UID), formatted on
+ * the host's cores; rows with kind 0 print nothing.  read_ascii/read_off, counts[n_rows * S] are per ROW. */
+int mirge_gff_write(const char* path, const char* head, const char* source, const void* records, int64_t n_rows,
+                    const char* read_ascii, const int64_t* read_off, const uint32_t* counts, int32_t n_samples,
+                    const int32_t* name_of_row, const char* name_data, const int64_t* name_off, int64_t n_names,
+                    const int32_t* parent_of_row, const char* parent_data, const int64_t* parent_off, int64_t n_parents);
+
 /* ---- measurement (bench.py): HIP events on the ctx stream ---- */
 int mirge_ctx_timer_start(mirge_ctx* ctx);
 int mirge_ctx_timer_stop(mirge_ctx* ctx, double* ms_out);

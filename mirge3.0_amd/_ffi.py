@@ -25,7 +25,7 @@ EXPORTS = [
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
-    "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_variant_tally", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
+    "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 

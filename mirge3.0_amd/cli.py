@@ -51,6 +51,8 @@ def parse_args(argv=None):
                     help="write <sample>.trim.collapse.fa")
     ap.add_argument("-ie", "--isoform-entropy", dest="isoform_entropy", action="store_true",
                     help="write isomirs.csv and isomirs.samples.csv (isomiR RPMs and entropies)")
+    ap.add_argument("-gff", "--gff-out", dest="gff_out", action="store_true",
+                    help="write sample_miRge3.gff (miRTop GFF3 of the miRNA reads, isomiR variant types from the GPU)")
     ap.add_argument("-ai", "--AtoI", dest="AtoI", action="store_true",
                     help="A-to-I editing report (a2IEditing.report.csv, .newform.csv, .detail.txt); the genome filter runs "
                          "`bowtie` against <org>_genome as the reference does (-pbwt / PATH), or reads --genome-retained")
@@ -62,7 +64,7 @@ def parse_args(argv=None):
                     help="-ai without bowtie: file of the edited canonical sequences that align to the genome")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted; only -ai's bowtie runs use it")
     ap.add_argument("--device", type=int, default=None)
-    for flag in ("-a", "-g", "-qumi", "-nmir", "-gff", "-bam", "-trf", "-mEC", "-dex"):
+    for flag in ("-a", "-g", "-qumi", "-nmir", "-bam", "-trf", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -72,8 +74,8 @@ def parse_args(argv=None):
     if args.umiDedup and not args.uniq_mol_ids:
         ap.error("-udd requires -umi f,b")
     args.bowtieVersion, args.phred64 = "True", False
-    if args.AtoI and (args.uniq_mol_ids or args.tcf_out or args.save_pkl or args.resume):
-        ap.error("-ai runs on the device-resident route: not together with -umi / -tcf / -spl / -rr")
+    if (args.AtoI or args.gff_out) and (args.uniq_mol_ids or args.tcf_out or args.save_pkl or args.resume):
+        ap.error("-ai / -gff run on the device-resident route: not together with -umi / -tcf / -spl / -rr")
     args.adapters = args.front = args.qiagenumi = None
     return args
 

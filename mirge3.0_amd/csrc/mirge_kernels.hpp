@@ -36,3 +36,4 @@ __device__ __forceinline__ void load_read(const GroupView<W>& g, uint32_t i, Mir
 #include "kernels_collapse.hpp"
 #include "kernels_cascade.hpp"
 #include "kernels_join.hpp"
+#include "kernels_iso.hpp"

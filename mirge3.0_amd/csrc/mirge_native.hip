@@ -39,3 +39,4 @@ static_assert(MIRGE_MAX_PASSES == MIRGE_MAX_PASSES_K, "pass cap");
 #include "native_cascade.hpp"
 #include "native_join.hpp"
 #include "native_csv.hpp"
+#include "native_iso.hpp"

@@ -123,6 +123,11 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     _ffi.annotation_csv(workDir / "mapped.csv", workDir / "unmapped.csv", header, seqs, ps, ref, counts, order,
                         list(range(casc.n_pass)), n_cols, names_by_pass)
     tm["per_read_csv_s"] = time.perf_counter() - t
+    if getattr(args, "gff_out", False):  # -gff (summary.py:800-837)
+        from .gff import write_gff
+        t = time.perf_counter()
+        out["gff"] = write_gff(args, workDir, ref_db, base_names, casc, uniq, res, seqs, ps, ref, counts, order)
+        tm["gff_s"] = time.perf_counter() - t
     if getattr(args, "AtoI", False):  # -ai (summary.py:1034-1057)
         from .a2i import ListedGenome, a2i_report
         t = time.perf_counter()

@@ -434,3 +434,157 @@ def variant_tally(seqs: List[str], counts: np.ndarray, pass_: np.ndarray, ref: n
                     census[f, q, code[target[q]], code[b], 2, s] += c
     out["census"], out["diag"], out["state"] = census, diag, state
     return out
+
+
+# --------------------------------------------------------------------------------------
+# isomiR typing for the miRTop GFF3 (row N2), restated from create_gff (mirge/libs/summary.py:48-606).  The reference
+# diffs the canonical sequence against the read with difflib.Differ -- stdlib, so the oracle calls it too -- and then
+# rewrites the two aligned lists in place; those rewrites are restated here on explicit index loops that follow
+# Python's list-iterator semantics (an element deleted during iteration shifts the rest under the cursor).
+# PINNED against the file the reference's create_gff wrote (tests/golden/case4_gff_a2i/sample_miRge3.gff).
+# --------------------------------------------------------------------------------------
+def _aligned_lists(master: str, read: str):
+    from difflib import Differ
+    result = list(Differ().compare(master, read))
+    m = list(master)
+    k = 0
+    while k < len(m):  # summary.py:229-233: a '-' goes into the canonical list wherever the diff inserts a base
+        if result[k].startswith("+"):
+            m.insert(k, "-")
+        k += 1
+    sub = ["_" if r.startswith("-") else r.replace(" ", "") for r in result]
+    m += ["-"] * (len(sub) - len(m))
+    return m, sub
+
+
+def _merge_replacements(m: list, sub: list):
+    """the two in-place passes of summary.py:249-289 (a deletion next to an insertion is one substitution)"""
+    y = 0
+    while y < len(m):  # forward: '_' just before a '-'
+        try:
+            if y > 0 and m[y] == "-" and sub[y - 1] == "_":
+                if y - 2 > 0 and sub[y - 2] == "_" and m[y + 1] == "-":
+                    del m[y:y + 2]
+                    del sub[y - 2:y]
+                else:
+                    m.pop(y)
+                    sub.pop(y - 1)
+        except IndexError:
+            pass
+        y += 1
+    y = 0
+    while y < len(m):  # reverse: '_' just after a '-'
+        try:
+            if y > 0 and m[y] == "-" and sub[y + 1] == "_":
+                if y + 2 <= len(sub) and sub[y + 2] == "_" and m[y + 1] == "-":
+                    del m[y:y + 2]
+                    del sub[y:y + 2]
+                else:
+                    m.pop(y)
+                    sub.pop(y + 1)
+        except IndexError:
+            pass
+        y += 1
+
+
+SNV_CLASSES = ["iso_snv_central_offset", "iso_snv_seed", "iso_snv_central", "iso_snv_central_supp", "iso_snv"]
+
+
+def gff_record(master: str, read: str, precursor: str):
+    """-> (type, start, end, variant, cigar) of one read against its miRNA (summary.py:170-470)"""
+    if precursor != "":
+        start = precursor.find(master) + 1
+    else:
+        start = 1
+    end = start + len(master) - 1
+    if read == master:
+        return "ref_miRNA", start, end, "NA", str(len(read)) + "M"
+    m, sub = _aligned_lists(master, read)
+    _merge_replacements(m, sub)
+    add, dele, subst = {}, {}, {}
+    for k, v in enumerate(m):
+        if v == "-":
+            add[k] = sub[k]
+        elif sub[k] == "_":
+            dele[k] = v
+        elif v != sub[k]:
+            subst[k] = sub[k]
+    a5 = d5 = a3 = d3 = ""
+    for k in range(len(m)):
+        if k in add:
+            a5 += add[k]
+        elif k in dele:
+            d5 += dele[k]
+        else:
+            break
+    for k in range(len(m), -1, -1):
+        if k - 1 in add:
+            a3 += add[k - 1]
+        elif k - 1 in dele:
+            d3 += dele[k - 1]
+        else:
+            break
+    variant = ""
+    if a5:
+        s5 = a5.replace("+", "")
+        ctx = list(precursor[start - len(s5) - 1:start - 1])
+        try:
+            t = sum(1 for k, c in enumerate(s5) if c == ctx[k])
+            nt = len(s5) - t
+            if t:
+                variant += "iso_5p:+" + str(t) + ","
+            if nt:
+                variant += "iso_add5p:+" + str(nt) + ","
+        except IndexError:
+            variant += "iso_5p:-" + str(len(s5)) + ","
+        start -= len(s5)
+    if d5:
+        variant += "iso_5p:+" + str(len(d5)) + ","
+        start += len(d5)
+    if a3:
+        s3 = a3[::-1].replace("+", "")
+        ctx = list(precursor[end:end + len(s3)])
+        try:
+            t = sum(1 for k, c in enumerate(s3) if c == ctx[k])
+            nt = len(s3) - t
+            if t:
+                variant += "iso_3p:+" + str(t) + ","
+            if nt:
+                variant += "iso_add3p:+" + str(nt) + ","
+        except IndexError:
+            variant += "iso_3p:+" + str(len(s3)) + ","
+        end += len(s3)
+    if d3:
+        variant += "iso_3p:-" + str(len(d3)) + ","
+        end -= len(d3)
+    seen = []
+    for k in subst:
+        cls = SNV_CLASSES[0] if k == 7 else SNV_CLASSES[1] if 1 <= k <= 6 else SNV_CLASSES[2] if 8 <= k <= 12 else \
+            SNV_CLASSES[3] if 13 <= k <= 17 else SNV_CLASSES[4]
+        if cls not in seen:
+            seen.append(cls)
+    variant += "".join(c + "," for c in seen)
+    if variant.endswith(","):
+        variant = variant[:-1]
+    # CIGAR (summary.py:427-463): M for a column the two lists agree on, for an insertion and for a deletion; the
+    # canonical base for a substitution; run-length encoded, a run of one printed without its count
+    case = ""
+    for k, v in enumerate(m):
+        case += "M" if (v == sub[k] or v == "-" or sub[k] == "_") else v
+    case = case.replace("+", "")
+    cigar, run = "", 0
+    last = ""
+    for k, ch in enumerate(case):
+        if k != 0:
+            if ch == case[k - 1]:
+                run += 1
+            else:
+                cigar += (str(run) if run != 1 else "") + case[k - 1]
+                run = 1
+        else:
+            run += 1
+        last = ch
+    cigar += (str(run) if run != 1 else "") + last
+    if not any(c in case for c in "ATGC"):
+        cigar = str(len(read)) + "M"
+    return "isomiR", start, end, variant or "iso_snv", cigar

@@ -128,3 +128,19 @@ extern "C" int hostsim_plan_scheme(int32_t mode, int32_t mm, int32_t seedlen, in
     p.mode = mode; p.mm = mm; p.seedlen = seedlen; p.maxtotal = mode == 0 ? 2 : mm;
     return mirge_plan_scheme(p, mirge_seed_region(p, L), K, (uint64_t)npos);
 }
+
+// ---- isomiR typing (mirge_isotype.hpp, what k_isotype runs per read) on the CPU, one pair per call
+#include "../../mirge3.0_amd/csrc/mirge_isotype.hpp"
+extern "C" int hostsim_isotype(const char* a, int32_t la, const char* b, int32_t lb, const char* pre, int32_t lpre, int32_t start0,
+                               int32_t* kind, int32_t* start, int32_t* end, char* variant, char* cigar) {
+    if (la > MIRGE_ISO_MAXA || lb > MIRGE_ISO_MAXB) return -1;
+    MirgeIsoRec r;
+    r.kind = 0; r.vlen = r.clen = 0; r.start = r.end = 0;
+    mirge_isotype(a, la, b, lb, pre, lpre, start0, r);
+    *kind = r.kind; *start = r.start; *end = r.end;
+    for (int k = 0; k < r.vlen; k++) variant[k] = r.text[k];
+    variant[r.vlen] = 0;
+    for (int k = 0; k < r.clen; k++) cigar[k] = r.text[r.vlen + k];
+    cigar[r.clen] = 0;
+    return 0;
+}

@@ -1048,3 +1048,13 @@ def test_a2i_report_equals_the_reference_files(tmp_path):
             assert t["census"][f, q - 1, 0, 2, 2, s] == c
         checked += 1
     assert checked >= 20
+
+
+def test_gff_equals_the_reference_file(tmp_path):
+    """-gff: sample_miRge3.gff byte for byte what the reference's create_gff wrote for the same reads (727 typed
+    lines: every variant class, templated and non-templated additions, the three worked examples of
+    summary.py:249-283, reads with N, names without annotation)."""
+    case, work, out = _case4_run(tmp_path, gff_out=True)
+    assert (work / "sample_miRge3.gff").read_text() == case.text("sample_miRge3.gff")
+    recs = out["gff"]["records"]
+    assert (recs["kind"] == 2).sum() > 600 and (recs["kind"] == 1).sum() > 40 and (recs["kind"] == 0).sum() > 0

@@ -22,7 +22,7 @@ SO = os.path.join(HERE, "hostsim", "_build", "libhostsim.so")
 
 
 def _sim():
-    deps = [SRC] + [os.path.join(HERE, "..", "mirge3.0_amd", "csrc", f) for f in ("mirge_core.hpp", "mirge_libbuild.hpp")]
+    deps = [SRC] + [os.path.join(HERE, "..", "mirge3.0_amd", "csrc", f) for f in ("mirge_core.hpp", "mirge_libbuild.hpp", "mirge_isotype.hpp")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(SO), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", SO, SRC])
@@ -172,3 +172,69 @@ def test_core_arithmetic_is_asan_ubsan_clean(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "rc=0" in r.stdout and "annotated=" in r.stdout
+
+
+def hostsim_isotype(master: str, read: str, precursor: str):
+    so = _sim()
+    kind, start, end = C.c_int32(), C.c_int32(), C.c_int32()
+    var, cig = C.create_string_buffer(400), C.create_string_buffer(400)
+    start0 = (precursor.find(master) + 1) if precursor != "" else 1
+    rc = so.hostsim_isotype(master.encode(), len(master), read.encode(), len(read), precursor.encode(), len(precursor), start0,
+                            C.byref(kind), C.byref(start), C.byref(end), var, cig)
+    assert rc == 0
+    return ({0: "none", 1: "ref_miRNA", 2: "isomiR"}[kind.value], start.value, end.value, var.value.decode(), cig.value.decode())
+
+
+def test_isotype_core_equals_the_oracle_on_the_reference_lines():
+    """every line of the GFF the reference wrote (golden case 4), through the header k_isotype is compiled from"""
+    from test_a2i_gff_oracle import _case4_gff_tables
+    case, mat, pre, pre_of = _case4_gff_tables()
+    n = 0
+    for ln in open(os.path.join(case.dir, "sample_miRge3.gff")):
+        if ln.startswith("#"):
+            continue
+        f = ln.rstrip("\n").split("\t")
+        attrs = dict(x.split("=", 1) for x in f[8].split("; "))
+        got = hostsim_isotype(mat[f[0]], attrs["Read"], pre[pre_of[f[0]]])
+        assert got == (f[2], int(f[3]), int(f[4]), attrs["Variant"], attrs["Cigar"]), (f[0], mat[f[0]], attrs["Read"])
+        n += 1
+    assert n > 700
+
+
+def test_isotype_core_equals_the_oracle_on_random_pairs():
+    """mutated, shifted, extended and unrelated reads against random canonicals inside random precursors (canonical
+    at the very start / end of the precursor, absent from it, empty precursor): the difflib restatement and the two
+    list-rewriting passes are compared on every field"""
+    rng = np.random.default_rng(11)
+    n = 0
+    shapes = set()
+    for it in range(6000):
+        la = int(rng.integers(16, 27))
+        master = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=la))
+        if it % 9 == 0:
+            master = master[:6] + master[5] * 4 + master[10:]  # homopolymer runs: ambiguous diffs
+        mode = it % 7
+        lead = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(0, 12) if mode != 1 else 0)))
+        trail = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(0, 12) if mode != 2 else 0)))
+        precursor = "" if mode == 3 else (lead + trail if mode == 4 else lead + master + trail)
+        d5, d3 = int(rng.integers(-3, 4)), int(rng.integers(-4, 5))
+        body = master[max(d5, 0):la + min(d3, 0)]
+        src = lead + master + trail
+        o = len(lead)
+        five = src[max(o + min(d5, 0), 0):o] if rng.random() < 0.6 else "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=max(-d5, 0)))
+        three = src[o + la:o + la + max(d3, 0)] if rng.random() < 0.6 else "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=max(d3, 0)))
+        read = list(five + body + three)
+        for _ in range(int(rng.choice([0, 0, 1, 1, 2, 3]))):
+            if read:
+                read[int(rng.integers(0, len(read)))] = "ACGTN"[int(rng.integers(0, 5))]
+        if it % 50 == 0:
+            read = list("".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(14, 31)))))
+        read = "".join(read)
+        if len(read) < 10:
+            continue
+        want = oracle.gff_record(master, read, precursor)
+        got = hostsim_isotype(master, read, precursor)
+        assert got == want, (master, read, precursor, got, want)
+        shapes.add(want[3].split(":")[0].split(",")[0])
+        n += 1
+    assert n > 5000 and len(shapes) >= 8
