@@ -63,10 +63,36 @@ def read_fastq_sequences(path: str) -> FlatSeqs:
 
 
 def read_text(path: str) -> bytes:
-    """The file's bytes (gunzipped if .gz) for the device-side parser (``mirge_reads_parse``)."""
+    """The file's bytes (gunzipped if .gz) for the device-side parser (``mirge_reads_parse``).  A FASTA whose sequences
+    are wrapped over several lines (dnaio reads those) is unwrapped here: the device parser finds records by line
+    number and refuses anything else."""
     opener = gzip.open if str(path).endswith(".gz") else open
     with opener(path, "rb") as fh:
-        return fh.read()
+        data = fh.read()
+    if data[:1] == b">":
+        data = unwrap_fasta(data)
+    return data
+
+
+def unwrap_fasta(data: bytes) -> bytes:
+    """FASTA text -> one sequence line per record.  A newline stays when it ends a header line or when the next line
+    is a header (or the text ends); every other newline (and '\\r') sits inside a sequence and is dropped."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    nl = np.flatnonzero(buf == 10)
+    if nl.size == 0:
+        return data
+    line_start = np.concatenate(([0], nl[:-1] + 1))
+    is_header = buf[np.minimum(line_start, buf.size - 1)] == ord(">")
+    nxt = nl + 1
+    next_is_header = (nxt >= buf.size) | (buf[np.minimum(nxt, buf.size - 1)] == ord(">"))
+    drop_nl = nl[~(is_header | next_is_header)]
+    if drop_nl.size == 0:
+        return data
+    keep = np.ones(buf.size, dtype=bool)
+    keep[drop_nl] = False
+    cr = drop_nl[(drop_nl > 0)] - 1
+    keep[cr[buf[cr] == 13]] = False
+    return buf[keep].tobytes()
 
 
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:

@@ -48,10 +48,11 @@ __device__ __forceinline__ uint64_t class_key(const MergeInfo& mi, uint64_t g) {
 }
 
 // the two text words under a window: issued for several candidates before any is consumed
-struct TextWin { uint64_t w[5]; };
+template <int W>
+struct TextWin { uint64_t w[W + 1]; };
 
 template <int W>
-__device__ __forceinline__ void load_window(gptr_u64 T, uint64_t g, int L, TextWin& tw) {
+__device__ __forceinline__ void load_window(gptr_u64 T, uint64_t g, int L, TextWin<W>& tw) {
     const uint64_t q = g >> 5;
 #pragma unroll
     for (int i = 0; i <= W; i++) tw.w[i] = (i == 0 || 32 * (i - 1) < L) ? T[q + i] : 0ull;
@@ -59,7 +60,7 @@ __device__ __forceinline__ void load_window(gptr_u64 T, uint64_t g, int L, TextW
 
 // same arithmetic as mirge_window_mm, on words that are already in registers
 template <int W>
-__device__ __forceinline__ int window_mm_regs(const TextWin& tw, uint64_t g, const MirgeRead<W>& r,
+__device__ __forceinline__ int window_mm_regs(const TextWin<W>& tw, uint64_t g, const MirgeRead<W>& r,
                                               const MirgePolicy& p) {
     const int L = r.len;
     const int s = (int)(g & 31) * 2;
@@ -95,7 +96,7 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
         ok[u] = c[u] < hi;
         pz[u] = ok[u] ? pos[c[u]] : 0u;
     }
-    TextWin tw[N];
+    TextWin<W> tw[N];
     uint64_t g[N];
 #pragma unroll
     for (int u = 0; u < N; u++) {

@@ -263,10 +263,10 @@ k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
     uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + CAP);
     uint32_t* lds_cnt = lds_min + CAP;
-    uint32_t* lds_x = lds_cnt + CAP;  // [0] distinct keys, [1] output base, [2..17] scan scratch, [32..32+128] lengths
+    uint32_t* lds_x = lds_cnt + CAP;  // [0] distinct keys, [1] output base, [2..17] scan scratch, [32..63] lengths (<= 31 nt)
     uint32_t& n_distinct = lds_x[0];
     for (uint32_t i = threadIdx.x; i < CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
-    for (uint32_t i = threadIdx.x; i < 32 + MIRGE_MAX_READ_LEN + 1; i += blockDim.x) lds_x[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 32 + 32; i += blockDim.x) lds_x[i] = 0;  // key-path reads are <= 31 nt
     __syncthreads();
     const uint32_t lo = bucket_start[blockIdx.x], hi = bucket_start[blockIdx.x + 1];
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -312,7 +312,7 @@ k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket
         rank++;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < 32; i += blockDim.x)
         if (lds_x[32 + i]) atomicAdd(&hist[i], lds_x[32 + i]);
 }
 

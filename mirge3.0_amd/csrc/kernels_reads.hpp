@@ -156,7 +156,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 // The groups are then packed by k_pack straight from the text.
 // ------------------------------------------------------------------------------------------
 #define MIRGE_PARSE_TILE (MIRGE_BLOCK * 16)
-#define MIRGE_CLS_DROP 6  // shorter than --minimum-length (or longer than the engine's limit: flagged)
+#define MIRGE_NCLS 8      // width class (<= 31, 64, 128, 255 nt) x (no ambiguous call | has one)
+#define MIRGE_CLS_DROP 8  // shorter than --minimum-length (or longer than the engine's limit: flagged)
 
 __device__ __forceinline__ uint32_t tile_newlines(const uint8_t* __restrict__ text, uint64_t n, uint64_t b0, uint32_t& mask) {
     mask = 0;
@@ -174,8 +175,12 @@ __global__ void k_nl_count(const uint8_t* __restrict__ text, uint64_t n, uint32_
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
 }
 
+// fmt 1 (FASTQ): a record's first line starts with '@', its third with '+'; fmt 2 (FASTA): with '>' -- anything else
+// (a truncated record, a blank line, a wrapped FASTA sequence) sets flags[3]: a parser that finds records by line
+// number alone would otherwise return shifted garbage for the rest of the file
 __global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_off, int period,
-                          int sphase, int64_t* __restrict__ start, int64_t* __restrict__ end, uint64_t n_seq) {
+                          int sphase, int64_t* __restrict__ start, int64_t* __restrict__ end, uint64_t n_seq, int fmt,
+                          uint32_t* __restrict__ flags) {
     __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * MIRGE_PARSE_TILE + threadIdx.x * 16ull;
     uint32_t mask;
@@ -183,10 +188,16 @@ __global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const ui
     uint32_t total;
     uint64_t li = (uint64_t)tile_off[blockIdx.x] + block_excl_scan(c, total, lds4);
     if (blockIdx.x == 0 && threadIdx.x == 0 && sphase == 0 && n_seq) start[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n && ((fmt == 1 && text[0] != '@') || (fmt == 2 && text[0] != '>'))) atomicOr(&flags[3], 1u);
     while (mask) {
         const int i = __ffs(mask) - 1;
         mask &= mask - 1;
         const uint64_t pos = b0 + i;
+        if (pos + 1 < n && fmt != 3) {
+            const int ph = (int)((li + 1) % (uint64_t)period);
+            const uint8_t nx = text[pos + 1];
+            if ((ph == 0 && nx != (fmt == 1 ? '@' : '>')) || (fmt == 1 && ph == 2 && nx != '+')) atomicOr(&flags[3], 1u);
+        }
         if ((int)(li % (uint64_t)period) == sphase && li / period < n_seq) end[li / period] = (int64_t)pos;
         if ((int)((li + 1) % (uint64_t)period) == sphase && (li + 1) / period < n_seq) start[(li + 1) / period] = (int64_t)pos + 1;
         li++;
@@ -198,13 +209,13 @@ __global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const ui
 __global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __restrict__ start, int64_t* __restrict__ end,
                             uint32_t n_seq, int32_t min_len, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cls,
                             uint32_t* __restrict__ blk_keep, uint32_t nblk, uint32_t* __restrict__ hist, uint32_t* __restrict__ flags) {
-    __shared__ uint32_t s_cnt[8];
+    __shared__ uint32_t s_cnt[MIRGE_NCLS + 2];
     __shared__ uint32_t s_hist[MIRGE_MAX_READ_LEN + 1];
-    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < MIRGE_NCLS + 2) s_cnt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    int c = 7;  // no record
+    int c = MIRGE_NCLS + 1;  // no record
     if (r < n_seq) {
         const int64_t b = start[r];
         int64_t e = end[r];
@@ -225,19 +236,23 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __r
                 bad |= !acgt && ch != 'N';
             }
             if (bad) atomicOr(&flags[0], 1u);
-            c = (L <= 31 ? 0 : (L <= 64 ? 1 : 2)) + (amb ? 3 : 0);
+            c = (L <= 31 ? 0 : (L <= 64 ? 1 : (L <= 128 ? 2 : 3))) + (amb ? MIRGE_NCLS / 2 : 0);
             atomicAdd(&s_hist[L], 1u);
         }
         cls[r] = (uint8_t)c;
     }
 #pragma unroll
-    for (int q = 0; q < 7; q++) {
+    for (int q = 0; q <= MIRGE_NCLS; q++) {
         const unsigned long long bal = __ballot(c == q);
         if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&s_cnt[q], (uint32_t)__popcll(bal));
     }
     __syncthreads();
-    if (threadIdx.x < 6) blk_cls[(size_t)threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
-    if (threadIdx.x == 6) blk_keep[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] + s_cnt[4] + s_cnt[5];
+    if (threadIdx.x < MIRGE_NCLS) blk_cls[(size_t)threadIdx.x * nblk + blockIdx.x] = s_cnt[threadIdx.x];
+    if (threadIdx.x == MIRGE_NCLS) {
+        uint32_t kept = 0;
+        for (int q = 0; q < MIRGE_NCLS; q++) kept += s_cnt[q];
+        blk_keep[blockIdx.x] = kept;
+    }
     for (int i = threadIdx.x; i <= MIRGE_MAX_READ_LEN; i += blockDim.x)
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
 }
@@ -247,12 +262,12 @@ __global__ void k_seq_place(const uint8_t* __restrict__ cls, uint32_t n_seq, con
                             uint32_t* __restrict__ orig_all) {
     __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = r < n_seq ? (int)cls[r] : 7;
+    const int c = r < n_seq ? (int)cls[r] : MIRGE_NCLS + 1;
     uint32_t total;
     const uint32_t kr = keep_off[blockIdx.x] + block_excl_scan(c < MIRGE_CLS_DROP ? 1u : 0u, total, lds4);
     uint32_t slot = 0;
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
+    for (int q = 0; q < MIRGE_NCLS; q++) {
         const uint32_t rk = block_excl_scan(c == q ? 1u : 0u, total, lds4);
         if (c == q) slot = cls_off[(size_t)q * nblk + blockIdx.x] + rk;
     }

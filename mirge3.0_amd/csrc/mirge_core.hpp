@@ -5,7 +5,7 @@
 // Layout (DESIGN.md "Data layout in HBM"):
 //   * a base is 2 bits, A=0 C=1 G=2 T=3; base j of a sequence sits at bits [2j, 2j+1] of
 //     word j/32 (little-endian inside a u64), so "the first k bases" is a low-bit mask;
-//   * reads live in width groups W in {1,2,4} words (<=32, <=64, <=128 nt), structure of
+//   * reads live in width groups W in {1,2,4,8} words (<=31, <=64, <=128, <=255 nt), structure of
 //     arrays, word-major: seq[w*n + i]; len[i] (u8); nmask[w*n + i] (bit 2j set = base j is
 //     an ambiguous call, its 2-bit code is 0) or nullptr when the group has no N;
 //   * a library is ONE concatenated 2-bit string T with one separator base after every
@@ -27,7 +27,7 @@
 #ifndef MIRGE_K_OVERSAMPLE
 #define MIRGE_K_OVERSAMPLE 4   // 4^K >= this x the library's positions
 #endif
-#define MIRGE_MAX_READ_LEN 128
+#define MIRGE_MAX_READ_LEN 255   // four width classes of 1 / 2 / 4 / 8 words; the length is stored in a byte
 #define MIRGE_NO_HIT 0xFFFFFFFFFFFFFFFFull
 
 // Cascade policy of one pass: the restated bowtie-1 argument string
@@ -56,7 +56,8 @@ struct MirgeKTable {
 // A probe is one or two exact blocks of the read: block A = k1 bases at read offset a1, block B =
 // k2 bases at a1 + k1 + gap (k2 == 0: none).  Its table is addressed by the shape (k1, gap, k2).
 struct MirgeProbe {
-    int8_t a1, k1, gap, k2;
+    uint8_t a1;  // up to MIRGE_MAX_READ_LEN - 1
+    int8_t k1, gap, k2;
 };
 #define MIRGE_MAX_PROBES 9
 #define MIRGE_SHAPE_SLOTS (16 * 32 * 16)
@@ -219,7 +220,7 @@ MIRGE_HD void mirge_two_blocks(int A0, int A1, int B0, int B1, int K, MirgeProbe
     if (la <= 0) { A0 = B0; A1 = B1; la = lb; lb = 0; }
     if (lb <= 0 || A1 == B0) {  // one contiguous run
         const int len = lb > 0 ? (B1 - A0) : la;
-        pr.a1 = (int8_t)A0; pr.k1 = (int8_t)(len < K ? len : K); pr.gap = 0; pr.k2 = 0;
+        pr.a1 = (uint8_t)A0; pr.k1 = (int8_t)(len < K ? len : K); pr.gap = 0; pr.k2 = 0;
         return;
     }
     // two runs: suffix of A + prefix of B, ka + kb = min(la + lb, K); the smaller run gets <= 4
@@ -228,7 +229,7 @@ MIRGE_HD void mirge_two_blocks(int A0, int A1, int B0, int B1, int K, MirgeProbe
     int ka, kb;
     if (la <= lb) { ka = la < 4 ? la : 4; kb = lb < (tot - ka) ? lb : (tot - ka); ka = la < (tot - kb) ? la : (tot - kb); }
     else { kb = lb < 4 ? lb : 4; ka = la < (tot - kb) ? la : (tot - kb); kb = lb < (tot - ka) ? lb : (tot - ka); }
-    pr.a1 = (int8_t)(A1 - ka); pr.k1 = (int8_t)ka; pr.gap = (int8_t)(B0 - A1); pr.k2 = (int8_t)kb;
+    pr.a1 = (uint8_t)(A1 - ka); pr.k1 = (int8_t)ka; pr.gap = (int8_t)(B0 - A1); pr.k2 = (int8_t)kb;
 }
 
 // Three families of probe plans, all pigeonhole arguments over the seed region S:
@@ -262,7 +263,7 @@ MIRGE_HD void mirge_scheme_probe(const MirgePolicy& p, int S, int K, int scheme,
     const int nseg = p.mm + 1;
     const int h = S / nseg;
     if (scheme == MIRGE_SCHEME_PLAIN) {
-        out.a1 = (int8_t)(q * h); out.k1 = (int8_t)(h < K ? h : K); out.gap = 0; out.k2 = 0;
+        out.a1 = (uint8_t)(q * h); out.k1 = (int8_t)(h < K ? h : K); out.gap = 0; out.k2 = 0;
         return;
     }
     if (scheme == MIRGE_SCHEME_SUBSET) {

@@ -113,7 +113,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     // nothing here (the heavy passes are sector-bound) and the SGPR spills cost a little.  The runtime reports
     // VGPRs only, hence the explicit 6: grid = min(occupancy query, register bound, 6) per CU.
     // MIRGE_WG_PER_CU overrides (sweeps).
-    static int wg_per_cu[5] = {0, 0, 0, 0, 0};
+    static int wg_per_cu[9] = {0};
     if (!wg_per_cu[W]) {
         int nb = 0;
         hipFuncAttributes fa;
@@ -351,14 +351,10 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
         if (gi == skip) continue;
         c->cur = gi == big ? c->stream : c->aux;
         if (gi != big && R->g[gi].n <= fused_max) {
-            if (kGroupW[gi] == 1) rc = cascade_group_fused<1>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
-            else if (kGroupW[gi] == 2) rc = cascade_group_fused<2>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
-            else rc = cascade_group_fused<4>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            MIRGE_BY_WIDTH(gi, rc, cascade_group_fused<W>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi)));
             continue;
         }
-        if (kGroupW[gi] == 1) rc = cascade_group<1>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
-        else if (kGroupW[gi] == 2) rc = cascade_group<2>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
-        else rc = cascade_group<4>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi));
+        MIRGE_BY_WIDTH(gi, rc, cascade_group<W>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi)));
     }
     { int jr = stream_join(c); if (rc == 0) rc = jr; }
     return rc;
@@ -379,7 +375,8 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
             const ReadGroup& g = R->g[gi];
             if (!g.n) continue;
             // conservative: every length the width group can hold is assumed present
-            int lo = kGroupW[gi] == 1 ? 1 : (kGroupW[gi] == 2 ? 32 : 65), hi = kGroupW[gi] == 1 ? 31 : (kGroupW[gi] == 2 ? 64 : 128);
+            const int w = kGroupW[gi];
+            int lo = w == 1 ? 1 : (w == 2 ? 32 : (w == 4 ? 65 : 129)), hi = w == 1 ? 31 : (w == 2 ? 64 : (w == 4 ? 128 : MIRGE_MAX_READ_LEN));
             for (int L = lo; L <= hi; L++) hist[L] = 1;
         }
     }

@@ -18,13 +18,13 @@ struct CollapseTmp {
     uint4 *part = nullptr, *recs = nullptr;
     uint32_t G = 0, chunk = 0, bshift = 0, B = 0, cap = MIRGE_PART_CAP;
 };
-// dmeta: [0..5] U of each group, [6] partition overflow flag, [8 .. 8+128] length histogram
-#define MIRGE_META_OVERFLOW 6
-#define MIRGE_META_HIST 8
+// dmeta: [0..7] U of each group, [8] partition overflow flag, [16 .. 16+255] length histogram
+#define MIRGE_META_OVERFLOW 8
+#define MIRGE_META_HIST 16
 #define MIRGE_META_WORDS (MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1)
 
 static const char* group_tag(int gi) {
-    static const char* t[MIRGE_NGROUPS] = {".w1", ".w2", ".w4", ".w1n", ".w2n", ".w4n"};
+    static const char* t[MIRGE_NGROUPS] = {".w1", ".w2", ".w4", ".w8", ".w1n", ".w2n", ".w4n", ".w8n"};
     return t[gi];
 }
 
@@ -252,9 +252,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
             const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
             c->cur = gi == big ? c->stream : c->aux;
-            if (kGroupW[gi] == 1) rc = collapse_phase_a<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
-            else if (kGroupW[gi] == 2) rc = collapse_phase_a<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
-            else rc = collapse_phase_a<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage);
+            MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage));
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         hc.lap("enqueue A");
@@ -297,9 +295,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         rc = stream_fork(c);
         for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
             c->cur = gi == big ? c->stream : c->aux;
-            if (kGroupW[gi] == 1) rc = collapse_phase_b<1>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
-            else if (kGroupW[gi] == 2) rc = collapse_phase_b<2>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
-            else rc = collapse_phase_b<4>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta));
             base += R->g[gi].n;
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }

@@ -3,12 +3,24 @@
 // ------------------------------------------------------------------------------------------
 // reads
 // ------------------------------------------------------------------------------------------
-// Six read groups: width class (<=31, <=64, <=128 nt) x (no ambiguous call | has an N).  Reads with
+// Eight read groups: width class (<=31, <=64, <=128, <=255 nt) x (no ambiguous call | has an N).  Reads with
 // an N are rare (~0.1 %); keeping them apart lets the big groups run without an nmask array and lets
 // the <=31-nt group collapse on a 64-bit key (sequence bits + length sentinel).
-#define MIRGE_NGROUPS 6
-static const int kGroupW[MIRGE_NGROUPS] = {1, 2, 4, 1, 2, 4};
-static inline int width_class(int64_t L) { return L <= 31 ? 0 : (L <= 64 ? 1 : 2); }
+#define MIRGE_NGROUPS 8
+#define MIRGE_NWIDTHS (MIRGE_NGROUPS / 2)
+static_assert(MIRGE_NGROUPS == MIRGE_NCLS, "read groups = classes of k_seq_class");
+static const int kGroupW[MIRGE_NGROUPS] = {1, 2, 4, 8, 1, 2, 4, 8};
+static inline int width_class(int64_t L) { return L <= 31 ? 0 : (L <= 64 ? 1 : (L <= 128 ? 2 : 3)); }
+// run `call` with W = the width of read group gi
+#define MIRGE_BY_WIDTH(gi, rc, call)                         \
+    do {                                                     \
+        switch (kGroupW[gi]) {                               \
+            case 1: { constexpr int W = 1; rc = call; } break; \
+            case 2: { constexpr int W = 2; rc = call; } break; \
+            case 4: { constexpr int W = 4; rc = call; } break; \
+            default: { constexpr int W = 8; rc = call; } break; \
+        }                                                    \
+    } while (0)
 
 struct ReadGroup {
     int W = 1;
@@ -119,11 +131,12 @@ extern "C" int64_t mirge_reads_total_bases(const mirge_reads* r) { return r ? r-
 extern "C" int32_t mirge_reads_n_samples(const mirge_reads* r) { return r ? r->n_samples : -1; }
 
 template <int W>
-static void launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstart, const int64_t* dend, const uint32_t* didx,
+static int launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstart, const int64_t* dend, const uint32_t* didx,
                         ReadGroup& g, uint32_t* dflags) {
     LaunchScope ls(c, "k_pack", g.n);
     hipLaunchKernelGGL(k_pack<W>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
                        dascii, dstart, dend, didx, g.n, g.seq, g.len, g.nmask, dflags);
+    return 0;
 }
 
 extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads** out) {
@@ -152,7 +165,7 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
                 hist[t][L]++;
                 bool amb = false;
                 for (int64_t b = off[i]; b < off[i + 1]; b++) amb |= !is_acgt[(unsigned char)ascii[b]];
-                part[(size_t)t * MIRGE_NGROUPS + width_class(L) + (amb ? 3 : 0)].push_back((uint32_t)i);
+                part[(size_t)t * MIRGE_NGROUPS + width_class(L) + (amb ? MIRGE_NWIDTHS : 0)].push_back((uint32_t)i);
             }
         };
         std::vector<std::thread> th;
@@ -189,7 +202,7 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
     if (nbytes) HIPOK(hipMemcpyAsync(dascii, ascii + off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipMemcpyAsync(doff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipMemsetAsync(dflags, 0, 64, c->stream));
-    uint32_t* didx[MIRGE_NGROUPS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t* didx[MIRGE_NGROUPS] = {nullptr};
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         ReadGroup& g = R->g[gi];
         g.W = kGroupW[gi];
@@ -201,9 +214,9 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
         CHECK(dalloc(c, &g.orig, (size_t)g.n));
         HIPOK(hipMemcpyAsync(g.orig, idx[gi].data(), (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream));
         didx[gi] = g.orig;
-        if (kGroupW[gi] == 1) launch_pack<1>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
-        else if (kGroupW[gi] == 2) launch_pack<2>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
-        else launch_pack<4>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
+        int prc = 0;
+        MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi));
+        (void)prc;
     }
     HIPOK(hipMemcpyAsync(c->pinned, dflags, 64, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));  // idx/rel host vectors are read by the async copies
@@ -237,10 +250,14 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
     R->total_bases = 0;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
     if (n_records) *n_records = 0;
+    // blank lines at the end of the file are not records (dnaio stops at them too)
+    while (nbytes > 0 && (text[nbytes - 1] == '\n' || text[nbytes - 1] == '\r' || text[nbytes - 1] == ' ' || text[nbytes - 1] == '\t')) nbytes--;
     if (nbytes == 0) { *out = R.release(); return 0; }
-    // the text, with a final newline if the file has none
-    const bool add_nl = text[nbytes - 1] != '\n';
+    // the text, with a final newline
+    const bool add_nl = true;
     const uint64_t n = (uint64_t)nbytes + (add_nl ? 1 : 0);
+    // lines are counted in 32 bits: below 8 GiB a text would need lines of less than two bytes to wrap the counter
+    if (n >= (1ull << 33)) return fail(-5, "mirge_reads_parse: a text of 8 GiB or more must be passed in parts (mirge_reads_concat)");
     const uint32_t ntile = (uint32_t)((n + MIRGE_PARSE_TILE - 1) / MIRGE_PARSE_TILE);
     uint8_t* dtext = nullptr;
     uint32_t *tile_cnt = nullptr, *tile_off = nullptr;
@@ -260,6 +277,11 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
     uint32_t n_lines = 0;
     HIPOK(hipMemcpyAsync(&n_lines, tile_off + ntile, 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
+    if (n_lines % (uint32_t)period != 0) {
+        c->release(dtext); c->release(tile_cnt); c->release(tile_off); c->release(tmp);
+        return fail(-9, "mirge_reads_parse: " + std::to_string(n_lines) + " lines is not a whole number of " + std::to_string(period) +
+                            "-line records (truncated file, blank line, or a FASTA with wrapped sequences)");
+    }
     // sequence lines: li in [0, n_lines) with li % period == sphase
     const uint64_t n_seq64 = n_lines > (uint32_t)sphase ? ((uint64_t)n_lines - sphase + period - 1) / period : 0;
     int rc = n_seq64 >= 0xFFFFFFF0ull ? fail(-5, "more than 2^32 reads in one set is not supported") : 0;
@@ -276,36 +298,38 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
         if ((rc = dalloc(c, &dstart, (size_t)n_seq))) break;
         if ((rc = dalloc(c, &dend, (size_t)n_seq))) break;
         if ((rc = dalloc(c, &dcls, (size_t)n_seq))) break;
-        if ((rc = dalloc(c, &blk, (size_t)6 * nblk + 1))) break;
-        if ((rc = dalloc(c, &blk_off, (size_t)6 * nblk + 1))) break;
+        if ((rc = dalloc(c, &blk, (size_t)MIRGE_NGROUPS * nblk + 1))) break;
+        if ((rc = dalloc(c, &blk_off, (size_t)MIRGE_NGROUPS * nblk + 1))) break;
         if ((rc = dalloc(c, &keep, (size_t)nblk + 1))) break;
         if ((rc = dalloc(c, &keep_off, (size_t)nblk + 1))) break;
         if ((rc = dalloc(c, &dmeta, meta_words))) break;
         hipError_t e = hipMemsetAsync(dmeta, 0, meta_words * 4, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(blk + (size_t)6 * nblk, 0, 4, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(blk + (size_t)MIRGE_NGROUPS * nblk, 0, 4, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(keep + nblk, 0, 4, c->stream);
         if (e != hipSuccess) { rc = fail(-2, hipGetErrorString(e)); break; }
         hipLaunchKernelGGL(k_nl_mark, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_off, period, sphase, dstart, dend,
-                           (uint64_t)n_seq);
+                           (uint64_t)n_seq, (int)format, dmeta);
         hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dtext, dstart, dend, n_seq, min_len, dcls, blk,
                            keep, nblk, dmeta + 8, dmeta);
         size_t need = 0;
-        e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, blk, blk_off, (int)(6 * nblk + 1), c->stream);
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, blk, blk_off, (int)(MIRGE_NGROUPS * nblk + 1), c->stream);
         if (e == hipSuccess && need > tmp_cap) { c->release(tmp); tmp = nullptr; tmp_cap = need; if ((rc = dalloc(c, (uint8_t**)&tmp, tmp_cap))) break; }
-        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need, blk, blk_off, (int)(6 * nblk + 1), c->stream);
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need, blk, blk_off, (int)(MIRGE_NGROUPS * nblk + 1), c->stream);
         size_t need2 = tmp_cap;
         if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need2, keep, keep_off, (int)(nblk + 1), c->stream);
         // group bounds = blk_off at the first block of every class, and the total
-        uint32_t bounds[7];
-        for (int q = 0; q < 6 && e == hipSuccess; q++)
+        uint32_t bounds[MIRGE_NGROUPS + 1];
+        for (int q = 0; q < MIRGE_NGROUPS && e == hipSuccess; q++)
             e = hipMemcpyAsync(&bounds[q], blk_off + (size_t)q * nblk, 4, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&bounds[6], blk_off + (size_t)6 * nblk, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&bounds[MIRGE_NGROUPS], blk_off + (size_t)MIRGE_NGROUPS * nblk, 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->pinned, dmeta, meta_words * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(-2, std::string("mirge_reads_parse: ") + hipGetErrorString(e)); break; }
+        if (c->pinned[3]) { rc = fail(-9, std::string("mirge_reads_parse: a record does not start with '") + (format == 1 ? "@' / its third line with '+'" : ">'") +
+                                            " (truncated file, blank line, or a FASTA with wrapped sequences)"); break; }
         if (c->pinned[1]) { rc = fail(-6, "a read is " + std::to_string(c->pinned[2]) + " nt; the limit is " + std::to_string(MIRGE_MAX_READ_LEN)); break; }
         if (c->pinned[0]) { rc = fail(-7, "a read contains a character other than A/C/G/T/U/N"); break; }
-        const uint32_t kept = bounds[6];
+        const uint32_t kept = bounds[MIRGE_NGROUPS];
         R->n = kept;
         for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
             R->len_hist[L] = (int32_t)c->pinned[8 + L];
@@ -328,14 +352,14 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
             if ((rc = dalloc(c, &g.orig, (size_t)g.n))) break;
             e = hipMemcpyAsync(g.orig, orig_all + bounds[gi], (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream);
             const uint32_t* src = src_all + bounds[gi];
-            if (kGroupW[gi] == 1) launch_pack<1>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
-            else if (kGroupW[gi] == 2) launch_pack<2>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
-            else launch_pack<4>(c, dtext, dstart, dend, src, g, dflags + 2 * gi);
+            int prc = 0;
+            MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, dtext, dstart, dend, src, g, dflags + 2 * gi));
+            (void)prc;
         }
         if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (rc == 0 && e != hipSuccess) rc = fail(-2, std::string("mirge_reads_parse: ") + hipGetErrorString(e));
         if (rc == 0)
-            for (int gi = 0; gi < 3; gi++)  // the groups without an ambiguous call carry no mask
+            for (int gi = 0; gi < MIRGE_NWIDTHS; gi++)  // the groups without an ambiguous call carry no mask
                 if (R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
     } while (0);
     (void)hipStreamSynchronize(c->stream);
@@ -347,6 +371,12 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
     return 0;
 }
 
+
+template <int W>
+static int launch_unpack(mirge_ctx* c, const ReadGroup& g, const int64_t* doff, uint8_t* dout) {
+    hipLaunchKernelGGL(k_unpack<W>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<W>(g), doff, g.base, g.orig, dout);
+    return 0;
+}
 
 extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* ascii_out, int64_t* off_out) {
     if (!c || !R || !off_out || (R->total_bases > 0 && !ascii_out)) return fail(-1, "mirge_reads_unpack: bad argument");
@@ -375,9 +405,9 @@ extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* asci
         const ReadGroup& g = R->g[gi];
         if (!g.n) continue;
         LaunchScope ls(c, "k_unpack", g.n);
-        if (kGroupW[gi] == 1) hipLaunchKernelGGL(k_unpack<1>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(g), doff, g.base, g.orig, dout);
-        else if (kGroupW[gi] == 2) hipLaunchKernelGGL(k_unpack<2>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<2>(g), doff, g.base, g.orig, dout);
-        else hipLaunchKernelGGL(k_unpack<4>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<4>(g), doff, g.base, g.orig, dout);
+        int urc = 0;
+        MIRGE_BY_WIDTH(gi, urc, launch_unpack<W>(c, g, doff, dout));
+        (void)urc;
     }
     if (total) HIPOK(hipMemcpyAsync(ascii_out, dout, (size_t)total, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));

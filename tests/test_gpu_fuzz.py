@@ -1,6 +1,6 @@
 """Differential fuzzing on the GPU: random libraries (sizes chosen so that the probe length K and the
 plain / recursive plans vary), random reads (substrings with 0-3 substitutions, N calls, T tails, junk,
-1-128 nt) and RANDOM cascades (any -n / -v budget 0..3, -5/-3 trims, length filters, T-tail rule) through
+1-255 nt) and RANDOM cascades (any -n / -v budget 0..3, -5/-3 trims, length filters, T-tail rule) through
 mirge_cascade_run, against the brute-force oracle given the same policies.  Bit-exact on every field."""
 import numpy as np
 import pytest
@@ -50,7 +50,7 @@ def test_random_cascade_matches_bruteforce(seed):
     same_policy_run = rng.random() < 0.5  # consecutive identical policies -> merged launch
     for p in range(n_pass):
         nref = int(rng.choice([3, 20, 150, 1200]))
-        lo, hi = [(18, 25), (40, 120), (100, 600)][int(rng.integers(0, 3))]
+        lo, hi = [(18, 25), (40, 120), (100, 600), (250, 900)][int(rng.integers(0, 4))]
         seqs = [_rand_seq(rng, int(rng.integers(lo, hi + 1)), pn=0.003 if rng.random() < 0.3 else 0.0) for _ in range(nref)]
         if rng.random() < 0.3:  # repeats: long buckets
             seqs += [("A" * int(rng.integers(20, 200))) + _rand_seq(rng, 30), "CA" * int(rng.integers(15, 80))]
@@ -66,7 +66,7 @@ def test_random_cascade_matches_bruteforce(seed):
         lib = libs[int(rng.integers(0, n_pass))]
         s = lib.get(int(rng.integers(0, len(lib))))
         kind = rng.random()
-        L = int(rng.integers(1, 129)) if rng.random() < 0.1 else int(rng.integers(12, 45))
+        L = int(rng.integers(1, 256)) if rng.random() < 0.1 else int(rng.integers(12, 45))
         if kind < 0.75 and len(s) > 2:
             L = min(L, len(s))
             a = int(rng.integers(0, len(s) - L + 1))
@@ -77,9 +77,9 @@ def test_random_cascade_matches_bruteforce(seed):
                 x[int(rng.integers(0, L))] = "N"
             r = "".join(x)
             if rng.random() < 0.1:
-                r = (r + "T" * int(rng.integers(3, 8)))[:128]
+                r = (r + "T" * int(rng.integers(3, 8)))[:255]
             if rng.random() < 0.1:
-                r = ("ACGT"[int(rng.integers(0, 4))] + r + _rand_seq(rng, 2))[:128]
+                r = ("ACGT"[int(rng.integers(0, 4))] + r + _rand_seq(rng, 2))[:255]
         else:
             r = _rand_seq(rng, L, pn=0.02)
         reads.append(r)
@@ -107,13 +107,13 @@ def test_random_cascade_matches_bruteforce(seed):
 
 @pytest.mark.parametrize("seed,n,S", [(1, 70000, 1), (2, 150000, 1), (3, 90000, 3), (4, 1000, 2), (5, 66000, 1)])
 def test_random_collapse_matches_counter(seed, n, S):
-    """Collapse on random inputs around the partition threshold (65536 reads), all three width classes, reads
+    """Collapse on random inputs around the partition threshold (65536 reads), all four width classes, reads
     with N, one or several samples: the (sequence -> per-sample count) map and first indices must equal Python's."""
     from collections import Counter
     rng = np.random.default_rng(50 + seed)
     pool = []
     for _ in range(max(n // 6, 10)):
-        L = int(rng.choice([16, 18, 20, 22, 22, 24, 27, 30, 31, 32, 33, 40, 64, 65, 100, 128]))
+        L = int(rng.choice([16, 18, 20, 22, 22, 24, 27, 30, 31, 32, 33, 40, 64, 65, 100, 128, 129, 150, 200, 255]))
         pool.append(_rand_seq(rng, L, pn=0.02 if rng.random() < 0.05 else 0.0))
     w = 1.0 / np.arange(1, len(pool) + 1) ** 0.9
     pick = rng.choice(len(pool), size=n, p=w / w.sum())

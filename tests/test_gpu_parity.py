@@ -314,8 +314,31 @@ def test_edge_cases(ctx, ci_libs, ci_cascade):
     o = oracle.cascade(rnd.data, rnd.offsets, oracle_libs_from(ci_libs.libs), n_pass=9)
     assert np.array_equal(ps.astype(np.int32), o[0])
     # loud failures
-    with pytest.raises(RuntimeError, match="limit is 128"):
-        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["A" * 129]))
+    with pytest.raises(RuntimeError, match="limit is 255"):
+        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["A" * 256]))
+    with pytest.raises(RuntimeError, match="limit is 255"):
+        _ffi.DeviceReads.parse(ctx, b"@r\n" + b"A" * 300 + b"\n+\n" + b"I" * 300 + b"\n", 1, 16)
+    # untrimmed Illumina lengths (150 nt) go through: the fourth width class
+    long_ref = ci_libs.libs["mrna"].seqs.get(5)
+    lr = [long_ref[40:190], long_ref[100:355], long_ref[7:136]]
+    g = ci_cascade.annotate(FlatSeqs.from_list(lr))
+    o = oracle.cascade(FlatSeqs.from_list(lr).data, FlatSeqs.from_list(lr).offsets, oracle_libs_from(ci_libs.libs), n_pass=9)
+    assert all(np.array_equal(x.astype(np.int64), y.astype(np.int64)) for x, y in zip(g, o)) and (g[0] == 7).all()
+    # malformed texts are refused, not shifted: a truncated FASTQ record, a blank line inside, a wrapped FASTA
+    for bad in (b"@r1\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\n@r2\nACGT\n", b"@r1\nACGTACGTACGTACGTAC\n\n+\nIIIIIIIIIIIIIIIIII\n",
+                b"@r1\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\nr2\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\n",
+                b">a\nACGTACGTACGT\nACGTACGT\n>b\nACGTACGTACGTACGTAC\n"):
+        with pytest.raises(RuntimeError, match="record"):
+            _ffi.DeviceReads.parse(ctx, bad, 0, 16)
+    # blank lines at the end of the file are not records
+    r_ok, n_rec = _ffi.DeviceReads.parse(ctx, b"@r1\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\n\n\r\n", 0, 16)
+    assert n_rec == 1 and len(r_ok) == 1
+    r_ok.close()
+    # a wrapped FASTA through the host-side unwrap
+    from mirge3_amd.collapse import unwrap_fasta
+    r_ok, n_rec = _ffi.DeviceReads.parse(ctx, unwrap_fasta(b">a\nACGTACGTACGT\nACGTACGT\n>b x\nACGTACGTACGTACGTAC\r\nGG\r\n"), 0, 16)
+    assert n_rec == 2 and r_ok.unpack().to_list() == ["ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGG"]
+    r_ok.close()
     with pytest.raises(RuntimeError, match="character other than"):
         _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGTRYACGTACGTACGT"]))
     # lower-case and U are accepted as their upper-case / T
@@ -406,8 +429,8 @@ def test_device_text_parser_equals_host_parser(ctx, ci_libs, tmp_path):
     assert len(dr) == 0 and n_rec == 0
     dr, n_rec = _ffi.DeviceReads.parse(ctx, b"@r\nACGT\n+\nIIII\n", 0, 16)
     assert len(dr) == 0 and n_rec == 1 and len(dr.collapse()) == 0
-    with pytest.raises(RuntimeError, match="limit is 128"):
-        _ffi.DeviceReads.parse(ctx, ("A" * 129 + "\n").encode(), 3, 0)
+    with pytest.raises(RuntimeError, match="limit is 255"):
+        _ffi.DeviceReads.parse(ctx, ("A" * 256 + "\n").encode(), 3, 0)
     with pytest.raises(RuntimeError, match="other than"):
         _ffi.DeviceReads.parse(ctx, b"ACGTACGTACGTACGTXACGT\n", 3, 0)
 
