@@ -20,6 +20,9 @@
 #define MIRGE_LIGHT_MAX 16
 #endif
 #define MIRGE_COOP_UNROLL 1
+#ifndef MIRGE_LDS_PLAN
+#define MIRGE_LDS_PLAN 1
+#endif
 
 // pointers that came out of memory or a v_readlane have lost their address space; these casts keep
 // the loads global_load_* (not flat_load_*, which also ties up lgkmcnt)
@@ -85,6 +88,7 @@ __device__ __forceinline__ int window_mm_regs(const TextWin<W>& tw, uint64_t g, 
 }
 
 // verify up to N candidate positions at once: all pos loads, then all text loads, then arithmetic
+// (pos == nullptr: the bucket held one window and c[0] IS its position)
 template <int W, int N>
 __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
                                                const MirgeRead<W>& r, gptr_u32 pos, const uint32_t (&c)[N],
@@ -94,7 +98,7 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
 #pragma unroll
     for (int u = 0; u < N; u++) {
         ok[u] = c[u] < hi;
-        pz[u] = ok[u] ? pos[c[u]] : 0u;
+        pz[u] = ok[u] ? (pos ? pos[c[u]] : c[u]) : 0u;
     }
     TextWin<W> tw[N];
     uint64_t g[N];
@@ -117,13 +121,109 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
     return best;
 }
 
+// Where a lane finds probe q of a read of length L and the table it addresses.  The plan and the table registry
+// live in global memory; every lane of a wave asks for a different (L, q) entry, so each probe used to cost three
+// uncoalesced lookups (plan entry, 24-byte table descriptor) before the first useful one -- about half of all the
+// lane-level cache lookups of the passes over the small libraries, which is what bounds them (per-CU L1 tag rate, not
+// latency and not VALU: profiles/README.md round 2).  For the one-word read group (trimmed length <= 31) a workgroup
+// therefore copies the (L, q) -> {probe, table} map into LDS once (8 KiB) and the lanes read it from there.
+struct LdsPlan {
+    MirgeKTable tb[32][MIRGE_MAX_PROBES];
+    MirgeProbe pr[32][MIRGE_MAX_PROBES];
+    uint8_t np[32];
+};
+template <bool LDS>
+struct PlanSrc {
+    const MirgePlanTable* g;
+    const LdsPlan* l;
+};
+
+__device__ __forceinline__ void lds_plan_fill(LdsPlan& s, const MirgeLibView& lib, const MirgePlanTable* __restrict__ plan) {
+    for (int idx = threadIdx.x; idx < 32 * MIRGE_MAX_PROBES; idx += blockDim.x) {
+        const int L = idx / MIRGE_MAX_PROBES, q = idx % MIRGE_MAX_PROBES;
+        const MirgeProbe pr = plan->pr[L][q];
+        MirgeKTable tb;
+        tb.bucket = nullptr; tb.pos = nullptr; tb.bits = nullptr;
+        if (q < (int)plan->np[L] && pr.k1 > 0) tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+        s.pr[L][q] = pr;
+        s.tb[L][q] = tb;
+    }
+    for (int L = threadIdx.x; L < 32; L += blockDim.x) s.np[L] = plan->np[L];
+}
+
+// probe q of this lane's read: key and table; false = no such probe / an ambiguous call inside it
+template <int W, bool LDS>
+__device__ __forceinline__ bool probe_setup(const MirgeLibView& lib, const PlanSrc<LDS>& ps, const MirgeRead<W>& r,
+                                            int q, int np, bool active, MirgeProbe& pr, MirgeKTable& tb, uint64_t& key) {
+    if (!(active && q < np)) return false;
+    if (LDS) pr = ps.l->pr[r.len][q];
+    else pr = ps.g->pr[r.len][q];  // tabulated mirge_probe_at(pol, len, K, q)
+    if (!mirge_probe_key<W>(r, pr, key)) return false;
+    if (LDS) tb = ps.l->tb[r.len][q];
+    else tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+    return true;
+}
+
+// the candidate list [lo, hi) of one probe, verified: short lists by their own lane, long ones by the whole wave
 template <int W>
-__device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
-                                             const MirgePlanTable* __restrict__ plan, const MirgeRead<W>& r,
-                                             bool active, uint64_t& best) {
-    best = MIRGE_NO_HIT;
+__device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const MirgeRead<W>& r,
+                                             gptr_u32 pos, uint32_t lo, uint32_t hi, int a, uint64_t& best) {
     const int lane = threadIdx.x & 63;
-    const int np = active ? (int)plan->np[r.len] : 0;
+    // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
+    // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
+    // per list and many such lanes per probe the lane-serial batches are several times cheaper)
+    const bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
+    if (!heavy) {
+        for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
+            uint32_t c[MIRGE_LIGHT];
+#pragma unroll
+            for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
+            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a);
+            if (cand < best) best = cand;
+        }
+    }
+    unsigned long long hb = __ballot(heavy);
+    while (hb) {
+        const int src = __ffsll(hb) - 1;
+        hb &= hb - 1;
+        MirgeRead<W> rr;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            rr.w[w] = readlane_u64(r.w[w], src);
+            rr.nm[w] = readlane_u64(r.nm[w], src);
+        }
+        rr.len = __builtin_amdgcn_readlane(r.len, src);
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)lo, src);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, src);
+        const int ba = __builtin_amdgcn_readlane(a, src);
+        gptr_u32 bpos = (gptr_u32)readlane_u64((uint64_t)pos, src);
+        uint64_t lbest = MIRGE_NO_HIT;
+        for (uint32_t c0 = blo + lane; c0 < bhi; c0 += 64 * MIRGE_COOP_UNROLL) {
+            uint32_t c[MIRGE_COOP_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MIRGE_COOP_UNROLL; u++) c[u] = c0 + 64 * u;
+            const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, mi, rr, bpos, c, bhi, ba);
+            if (cand < lbest) lbest = cand;
+        }
+        // almost every candidate fails verification: instead of a shuffle tree, visit the few
+        // lanes that hold a hit (v_readlane -> scalar min)
+        unsigned long long hits = __ballot(lbest != MIRGE_NO_HIT);
+        uint64_t tbest = MIRGE_NO_HIT;
+        while (hits) {
+            const int hl = __ffsll(hits) - 1;
+            hits &= hits - 1;
+            const uint64_t v = readlane_u64(lbest, hl);
+            if (v < tbest) tbest = v;
+        }
+        if (lane == src && tbest < best) best = tbest;
+    }
+}
+
+template <int W, bool LDS>
+__device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
+                                             const PlanSrc<LDS>& ps, const MirgeRead<W>& r, bool active, uint64_t& best) {
+    best = MIRGE_NO_HIT;
+    const int np = active ? (int)(LDS ? ps.l->np[r.len] : ps.g->np[r.len]) : 0;
     // wave-uniform bound on the probe count: (mm+1) plain segments or (mm+1)^2 recursive probes
     const int npmax = (pol.mm >= 1 && pol.mm <= 2) ? (pol.mm + 1) * (pol.mm + 1) : pol.mm + 1;
 #pragma unroll 1
@@ -131,69 +231,26 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
         uint32_t lo = 0, hi = 0;
         int a = 0;
         gptr_u32 pos = nullptr;
-        if (active && q < np) {
-            const MirgeProbe pr = plan->pr[r.len][q];  // tabulated mirge_probe_at(pol, len, K, q)
-            uint64_t key;
-            if (mirge_probe_key<W>(r, pr, key)) {  // no ambiguous call inside the probe
-                const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
-                gptr_u32 bits = (gptr_u32)tb.bits;
-                if (!bits || ((bits[key >> 5] >> (key & 31)) & 1u)) {  // L2-resident "bucket is non-empty" bit
-                    gptr_u32 bucket = (gptr_u32)tb.bucket;
-                    pos = (gptr_u32)tb.pos;
-                    lo = bucket[key];
-                    hi = bucket[key + 1];
-                    a = pr.a1;
-                }
+        MirgeProbe pr;
+        MirgeKTable tb;
+        uint64_t key;
+        if (probe_setup<W, LDS>(lib, ps, r, q, np, active, pr, tb, key)) {  // no ambiguous call inside the probe
+            gptr_u32 bits = (gptr_u32)tb.bits;
+            if (!bits) {  // large table: one self-contained entry, a single window inline
+                const uint64_t e = ((gptr_u64)tb.bucket)[key];
+                const uint32_t cnt = (uint32_t)(e >> 32);
+                lo = (uint32_t)e;
+                hi = lo + cnt;
+                pos = cnt == 1 ? nullptr : (gptr_u32)tb.pos;  // one window: `lo` is its position
+            } else if ((bits[key >> 5] >> (key & 31)) & 1u) {  // small table: L2-resident "bucket is non-empty" bit, then CSR bounds
+                gptr_u32 bucket = (gptr_u32)tb.bucket;
+                pos = (gptr_u32)tb.pos;
+                lo = bucket[key];
+                hi = bucket[key + 1];
             }
+            a = pr.a1;
         }
-        // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
-        // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
-        // per list and many such lanes per probe the lane-serial batches are several times cheaper)
-        const bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
-        if (!heavy) {
-            for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
-                uint32_t c[MIRGE_LIGHT];
-#pragma unroll
-                for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
-                const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a);
-                if (cand < best) best = cand;
-            }
-        }
-        unsigned long long hb = __ballot(heavy);
-        while (hb) {
-            const int src = __ffsll(hb) - 1;
-            hb &= hb - 1;
-            MirgeRead<W> rr;
-#pragma unroll
-            for (int w = 0; w < W; w++) {
-                rr.w[w] = readlane_u64(r.w[w], src);
-                rr.nm[w] = readlane_u64(r.nm[w], src);
-            }
-            rr.len = __builtin_amdgcn_readlane(r.len, src);
-            const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)lo, src);
-            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)hi, src);
-            const int ba = __builtin_amdgcn_readlane(a, src);
-            gptr_u32 bpos = (gptr_u32)readlane_u64((uint64_t)pos, src);
-            uint64_t lbest = MIRGE_NO_HIT;
-            for (uint32_t c0 = blo + lane; c0 < bhi; c0 += 64 * MIRGE_COOP_UNROLL) {
-                uint32_t c[MIRGE_COOP_UNROLL];
-#pragma unroll
-                for (int u = 0; u < MIRGE_COOP_UNROLL; u++) c[u] = c0 + 64 * u;
-                const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, mi, rr, bpos, c, bhi, ba);
-                if (cand < lbest) lbest = cand;
-            }
-            // almost every candidate fails verification: instead of a shuffle tree, visit the few
-            // lanes that hold a hit (v_readlane -> scalar min)
-            unsigned long long hits = __ballot(lbest != MIRGE_NO_HIT);
-            uint64_t tbest = MIRGE_NO_HIT;
-            while (hits) {
-                const int hl = __ffsll(hits) - 1;
-                hits &= hits - 1;
-                const uint64_t v = readlane_u64(lbest, hl);
-                if (v < tbest) tbest = v;
-            }
-            if (lane == src && tbest < best) best = tbest;
-        }
+        verify_lists<W>(lib, pol, mi, r, pos, lo, hi, a, best);
         // a 0-mismatch window (of the first member library) is in probe 0's bucket and buckets ascend:
         // nothing later can beat it
         if (q == 0 && (best >> 32) == 0) active = false;
@@ -230,8 +287,14 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
        uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
        int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t s_count;
+    constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
+    __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? sizeof(LdsPlan) : 16];
+    LdsPlan* s_plan = reinterpret_cast<LdsPlan*>(s_plan_raw);
     if (threadIdx.x == 0) s_count = 0;
+    if (LDSP) lds_plan_fill(*s_plan, lib, plan);
     __syncthreads();
+    PlanSrc<LDSP> psrc;
+    psrc.g = plan; psrc.l = LDSP ? s_plan : nullptr;
     const size_t seg = (size_t)blockIdx.x * cap;  // the workgroup's slice of the survivor arrays
     // n_dev: the read count is still on the device (a cascade enqueued behind the collapse that produces it, before
     // the host has read U back): the first pass cuts the U reads into gridDim.x segments itself; `cap`, sized from
@@ -268,7 +331,7 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
             r2.len = 0;
         }
         uint64_t best;
-        align_hybrid<W>(lib, pol, mi, plan, r2, elig, best);
+        align_hybrid<W, LDSP>(lib, pol, mi, psrc, r2, elig, best);
         if (elig && best != MIRGE_NO_HIT) {
             const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
             res_pass[idx] = (int8_t)(pass_id + cls);
@@ -371,7 +434,9 @@ k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
             MirgeRead<W> r2 = r0;
             const bool elig = open && mirge_effective_read<W>(r2, st.pol);
             uint64_t best;
-            align_hybrid<W>(st.lib, st.pol, st.mi, st.plan, r2, elig, best);
+            PlanSrc<false> psrc;
+            psrc.g = st.plan; psrc.l = nullptr;
+            align_hybrid<W, false>(st.lib, st.pol, st.mi, psrc, r2, elig, best);
             if (elig && best != MIRGE_NO_HIT) {
                 const int cls = (int)(best >> 40);
                 o_pass = (int8_t)(st.pass_id + cls);

@@ -106,6 +106,15 @@ __global__ void k_table_pass(const uint64_t* __restrict__ T, const uint64_t* __r
     }
 }
 
+// CSR bounds + position list -> self-contained entries (MirgeKTable): {count, the position itself | list start}
+__global__ void k_table_entries(const uint32_t* __restrict__ bucket, const uint32_t* __restrict__ pos, uint64_t nb,
+                                uint64_t* __restrict__ entry) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < nb; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t lo = bucket[k], cnt = bucket[k + 1] - lo;
+        entry[k] = MIRGE_ENTRY(cnt, cnt == 1 ? pos[lo] : lo);
+    }
+}
+
 __global__ void k_table_bits(const uint32_t* __restrict__ bucket, uint64_t nb, uint32_t* __restrict__ bits) {
     const uint64_t nw = (nb + 31) / 32;
     for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < nw; w += (uint64_t)gridDim.x * blockDim.x) {

@@ -10,7 +10,7 @@
 //     an ambiguous call, its 2-bit code is 0) or nullptr when the group has no N;
 //   * a library is ONE concatenated 2-bit string T with one separator base after every
 //     reference, an "invalid" bitmap inv (1 bit per base: separator, reference N, padding)
-//     and per-k direct-addressed k-mer tables (bucket[4^k+1], pos[]) over the valid k-windows.
+//     and per-k direct-addressed k-mer tables (bucket[4^k] entries {count, position | start}, pos[]) over the valid k-windows.
 //     A hit is reported as its global position in T; lowest position == lowest reference
 //     index, then leftmost offset, which is the documented tie-break.
 #pragma once
@@ -45,9 +45,18 @@ struct MirgePolicy {
     int32_t reserved;
 };
 
+// Two bucket formats, by table size:
+//   * tables of <= 4^MIRGE_BITMAP_MAXK buckets (bits != nullptr) keep CSR bounds, uint32 bucket[4^k + 1]: the bitmap
+//     answers "empty?" from L2 and only the ~20 % non-empty probes read the two bounds; 4 bytes per bucket keep the
+//     tables of the small libraries L2-resident (8-byte entries measured 2-5 % slower on those passes);
+//   * larger tables (bits == nullptr) hold ONE self-contained 8-byte entry per bucket: count in the high word; in the
+//     low word the position itself when the bucket holds a single window (most non-empty buckets do: 4^K >= 4 x
+//     positions), else where its list starts in pos[].  One L2-missing sector answers "empty?", and a singleton goes
+//     straight to the text: no second bound, no position list (-11 % on the merged snoRNA/rRNA/ncRNA pass).
+#define MIRGE_ENTRY(count, low) (((uint64_t)(count) << 32) | (uint64_t)(uint32_t)(low))
 struct MirgeKTable {
-    const uint32_t* bucket;  // 4^(k1+k2) + 1 entries
-    const uint32_t* pos;     // global positions of block A's first base, ascending inside a bucket
+    const void* bucket;      // bits ? uint32 CSR bounds [4^(k1+k2) + 1] : uint64 entries [4^(k1+k2)] {count, position | start}
+    const uint32_t* pos;     // global positions of block A's first base (entries: of the buckets with several windows)
     const uint32_t* bits;    // 1 bit per bucket (non-empty), or nullptr.  Present for tables of <= 4^10
                              // buckets: the bitmap (<= 128 KiB) stays in L2 while the bucket array does
                              // not, and most probes of an unannotatable read find an empty bucket
@@ -412,9 +421,17 @@ MIRGE_HD bool mirge_align_indexed(const MirgeLibView& lib, const MirgePolicy& p,
         const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
         const int a = pr.a1;
         if (tb.bits && !((tb.bits[key >> 5] >> (key & 31)) & 1u)) continue;
-        const uint32_t lo = tb.bucket[key], hi = tb.bucket[key + 1];
-        for (uint32_t c = lo; c < hi; c++) {
-            const uint32_t pz = tb.pos[c];
+        uint32_t cnt, lo;
+        bool inl = false;
+        if (tb.bits) {
+            const uint32_t* b = static_cast<const uint32_t*>(tb.bucket);
+            lo = b[key]; cnt = b[key + 1] - lo;
+        } else {
+            const uint64_t e = static_cast<const uint64_t*>(tb.bucket)[key];
+            cnt = (uint32_t)(e >> 32); lo = (uint32_t)e; inl = cnt == 1;
+        }
+        for (uint32_t c = 0; c < cnt; c++) {
+            const uint32_t pz = inl ? lo : tb.pos[lo + c];
             if (pz < (uint32_t)a) continue;
             const uint64_t g = (uint64_t)pz - (uint64_t)a;
             const int m = mirge_window_mm<W>(lib.T, g, r, p);

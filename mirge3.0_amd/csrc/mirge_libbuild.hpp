@@ -80,7 +80,7 @@ static inline uint64_t mirge_text_kmer(const uint64_t* T, uint64_t g, int k) {
 }
 
 static inline void mirge_hostlib_table(const MirgeHostLib& L, int k1, int gap, int k2, std::vector<uint32_t>& bucket,
-                                       std::vector<uint32_t>& pos) {
+                                       std::vector<uint64_t>& entry, std::vector<uint32_t>& pos) {
     const uint64_t nb = 1ull << (2 * (k1 + k2));
     const int span = k1 + (k2 > 0 ? gap + k2 : 0);
     bucket.assign(nb + 1, 0u);
@@ -106,4 +106,9 @@ static inline void mirge_hostlib_table(const MirgeHostLib& L, int k1, int gap, i
     }
     for (uint64_t b = nb; b > 0; b--) bucket[b] = bucket[b - 1];
     bucket[0] = 0;
+    entry.assign(nb, 0ull);
+    for (uint64_t b = 0; b < nb; b++) {
+        const uint32_t cnt = bucket[b + 1] - bucket[b];
+        entry[b] = MIRGE_ENTRY(cnt, cnt == 1 ? pos[bucket[b]] : bucket[b]);
+    }
 }

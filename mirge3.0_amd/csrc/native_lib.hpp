@@ -76,6 +76,7 @@ static int lib_build_shape(mirge_lib* L, const ShapeJob& j) {
     const int sid = mirge_shape_id(j.k1, j.gap, j.k2);
     const uint64_t nb = 1ull << (2 * (j.k1 + j.k2));
     uint32_t *A = nullptr, *dpos = nullptr, *dbits = nullptr;
+    uint64_t* dentry = nullptr;
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
     uint32_t npos = 0;
@@ -102,16 +103,22 @@ static int lib_build_shape(mirge_lib* L, const ShapeJob& j) {
                 hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, words)), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, dbits);
         }
     }
+    if (e == hipSuccess && !dbits) {  // a table too large for a bitmap: self-contained entries (MirgeKTable)
+        e = hipMalloc((void**)&dentry, nb * 8);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(k_table_entries, dim3(grid_for(c, nb)), dim3(MIRGE_BLOCK), 0, c->stream, A, dpos, nb, dentry);
+    }
     // table complete; no kernel may be reading the registry while it changes
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
     (void)hipFree(tmp);
     if (e != hipSuccess) {
-        (void)hipFree(A); (void)hipFree(dpos); (void)hipFree(dbits);
+        (void)hipFree(A); (void)hipFree(dpos); (void)hipFree(dbits); (void)hipFree(dentry);
         return fail(-2, std::string("probe table construction: ") + hipGetErrorString(e));
     }
-    L->device_bytes += (nb + 2) * 4 + (size_t)npos * 4 + (dbits ? (size_t)((nb + 31) / 32) * 4 : 0);
-    L->htables[sid].bucket = A;
+    if (dentry) { (void)hipFree(A); A = nullptr; }  // the CSR bounds were only the way to the entries
+    L->device_bytes += (dentry ? nb * 8 : (nb + 2) * 4) + (size_t)npos * 4 + (dbits ? (size_t)((nb + 31) / 32) * 4 : 0);
+    L->htables[sid].bucket = dentry ? (const void*)dentry : (const void*)A;
     L->htables[sid].pos = dpos;
     L->htables[sid].bits = dbits;
     HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));

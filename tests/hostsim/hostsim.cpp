@@ -16,9 +16,10 @@
 
 struct SimLib {
     MirgeHostLib h;
+    std::vector<std::vector<uint64_t>> entry;
     std::vector<std::vector<uint32_t>> bucket, pos, bits;
     std::vector<MirgeKTable> tables;
-    SimLib() : bucket(MIRGE_SHAPE_SLOTS), pos(MIRGE_SHAPE_SLOTS), bits(MIRGE_SHAPE_SLOTS), tables(MIRGE_SHAPE_SLOTS) {
+    SimLib() : entry(MIRGE_SHAPE_SLOTS), bucket(MIRGE_SHAPE_SLOTS), pos(MIRGE_SHAPE_SLOTS), bits(MIRGE_SHAPE_SLOTS), tables(MIRGE_SHAPE_SLOTS) {
         for (auto& t : tables) { t.bucket = nullptr; t.pos = nullptr; t.bits = nullptr; }
     }
     MirgeLibView view() {
@@ -58,8 +59,8 @@ static void sim_one(const char* s, int L, std::vector<SimLib>& libs, const std::
             if (pr.k1 <= 0) continue;
             const int sid = mirge_shape_id(pr.k1, pr.gap, pr.k2);
             if (!libs[p].tables[sid].bucket) {
-                mirge_hostlib_table(libs[p].h, pr.k1, pr.gap, pr.k2, libs[p].bucket[sid], libs[p].pos[sid]);
-                libs[p].tables[sid].bucket = libs[p].bucket[sid].data();
+                mirge_hostlib_table(libs[p].h, pr.k1, pr.gap, pr.k2, libs[p].bucket[sid], libs[p].entry[sid], libs[p].pos[sid]);
+                libs[p].tables[sid].bucket = libs[p].entry[sid].data();  // replaced by the CSR bounds below for a bitmap table
                 libs[p].tables[sid].pos = libs[p].pos[sid].data();
                 if (pr.k1 + pr.k2 <= 10) {  // same non-empty-bucket bitmap as mirge_native.hip builds
                     const auto& bk = libs[p].bucket[sid];
@@ -67,6 +68,7 @@ static void sim_one(const char* s, int L, std::vector<SimLib>& libs, const std::
                     bt.assign((bk.size() - 1 + 31) / 32, 0u);
                     for (size_t b = 0; b + 1 < bk.size(); b++) if (bk[b + 1] > bk[b]) bt[b >> 5] |= 1u << (b & 31);
                     libs[p].tables[sid].bits = bt.data();
+                    libs[p].tables[sid].bucket = bk.data();
                 }
             }
         }
