@@ -79,6 +79,28 @@ int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, 
  * filter (`count`, digest.py:326).  Reads come out in file order. */
 int mirge_reads_parse(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                       mirge_reads** out, int64_t* n_records);
+/* The same with the read modifiers the reference runs through cutadapt before it counts a read (digest.py:59-101; SURVEY.md
+ * 8f row N4), applied on the device between record finding and the length filter: NextSeq quality trimming, quality
+ * trimming, 3' adapter removal, N trimming, unconditional cuts -- in that order, each present when its field says so.
+ * count_per_modifier = 1 reproduces the reference's worker at HEAD, which tests the length and counts the read after
+ * EVERY modifier (digest.py:354-373); 0 counts the fully trimmed read once.  *n_records stays the number of records of
+ * the text.  trim == NULL: mirge_reads_parse.  Restated from cutadapt's published algorithms: parity unpinned. */
+typedef struct mirge_trim {
+    int32_t nextseq_cutoff;   /* --nextseq-trim, -1 = off                                   */
+    int32_t quality_front;    /* -q 5'CUTOFF (0 when only one value is given)                */
+    int32_t quality_back;     /* -q 3'CUTOFF (the reference's default: 10), -1 = off         */
+    int32_t phred_base;       /* 33 (or 64)                                                  */
+    const char* adapter;      /* -a: 3' adapter, A/C/G/T/N, or NULL                          */
+    int32_t adapter_len;
+    int32_t min_overlap;      /* --overlap (3)                                               */
+    double error_rate;        /* --error-rate (0.12), of the aligned adapter length          */
+    int32_t trim_n;           /* --trim-n                                                    */
+    int32_t n_cut;            /* -u, up to two values: > 0 from the 5' end, < 0 from the 3'  */
+    int32_t cut[2];
+    int32_t count_per_modifier;
+} mirge_trim;
+int mirge_reads_parse_trim(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                           const mirge_trim* trim, mirge_reads** out, int64_t* n_records);
 /* Several raw read sets as one, in the order given (the samples of a run, one file each, before the joint collapse
  * that replaces the per-file dicts and their outer join, digest.py:133-163,243).  The parts stay valid. */
 int mirge_reads_concat(mirge_ctx* ctx, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out);

@@ -22,7 +22,7 @@ SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libm
 EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
-    "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
+    "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
@@ -34,6 +34,30 @@ class MirgePolicy(C.Structure):
     """``mirge_policy`` of include/mirge_native.h."""
     _fields_ = [(n, C.c_int32) for n in (
         "mode", "mm", "seedlen", "maxtotal", "trim5", "trim3", "ttail", "len_lt", "len_gt", "reserved")]
+
+
+class MirgeTrim(C.Structure):
+    """``mirge_trim`` of include/mirge_native.h: the cutadapt modifier chain of digest.py:59-101."""
+    _fields_ = [("nextseq_cutoff", C.c_int32), ("quality_front", C.c_int32), ("quality_back", C.c_int32),
+                ("phred_base", C.c_int32), ("adapter", C.c_char_p), ("adapter_len", C.c_int32), ("min_overlap", C.c_int32),
+                ("error_rate", C.c_double), ("trim_n", C.c_int32), ("n_cut", C.c_int32), ("cut", C.c_int32 * 2),
+                ("count_per_modifier", C.c_int32)]
+
+    @staticmethod
+    def make(adapter: Optional[str] = None, quality_back: int = -1, quality_front: int = 0, nextseq: int = -1,
+             phred_base: int = 33, min_overlap: int = 3, error_rate: float = 0.12, trim_n: bool = False,
+             cut: Sequence[int] = (), count_per_modifier: bool = True) -> "MirgeTrim":
+        t = MirgeTrim()
+        t.nextseq_cutoff, t.quality_front, t.quality_back, t.phred_base = nextseq, quality_front, quality_back, phred_base
+        a = adapter.encode() if adapter else None
+        t.adapter, t.adapter_len = a, (len(a) if a else 0)
+        t.min_overlap, t.error_rate, t.trim_n = min_overlap, error_rate, 1 if trim_n else 0
+        cut = [int(x) for x in cut]
+        t.n_cut = len(cut)
+        for k, v in enumerate(cut[:2]):
+            t.cut[k] = v
+        t.count_per_modifier = 1 if count_per_modifier else 0
+        return t
 
 
 _lib = None
@@ -204,15 +228,17 @@ class DeviceReads:
         return DeviceReads(ctx, h)
 
     @staticmethod
-    def parse(ctx: Context, text, fmt: int = 0, min_len: int = 0):
+    def parse(ctx: Context, text, fmt: int = 0, min_len: int = 0, trim: Optional["MirgeTrim"] = None):
         """FASTQ / single-line FASTA / one-sequence-per-line TEXT (bytes or a uint8 array) -> (DeviceReads of the
-        records with len >= min_len, number of records seen).  Parsed on the GPU: no per-read host work."""
+        records with len >= min_len, number of records seen).  Parsed -- and, with ``trim``, trimmed (quality, 3'
+        adapter, N ends, cuts: ``mirge_reads_parse_trim``) -- on the GPU: no per-read host work."""
         buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else \
             np.ascontiguousarray(text, dtype=np.uint8)
         h = C.c_void_p()
         nrec = C.c_int64()
-        _check(load().mirge_reads_parse(ctx._h, _p(buf) if buf.size else C.c_void_p(0), C.c_int64(buf.size), C.c_int32(fmt),
-                                        C.c_int32(min_len), C.byref(h), C.byref(nrec)), "mirge_reads_parse")
+        _check(load().mirge_reads_parse_trim(ctx._h, _p(buf) if buf.size else C.c_void_p(0), C.c_int64(buf.size), C.c_int32(fmt),
+                                             C.c_int32(min_len), C.byref(trim) if trim is not None else C.c_void_p(0),
+                                             C.byref(h), C.byref(nrec)), "mirge_reads_parse")
         return DeviceReads(ctx, h), int(nrec.value)
 
     @staticmethod

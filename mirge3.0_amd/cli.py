@@ -38,7 +38,7 @@ def parse_args(argv=None):
     ap.add_argument("-cr", "--crThreshold", dest="crThreshold", default="0.1")
     ap.add_argument("-m", "--minimum-length", dest="minimum_length", type=int, default=16)
     ap.add_argument("-spk", "--spikeIn", dest="spikeIn", action="store_true")
-    ap.add_argument("-q", "--quiet", action="store_true")
+    ap.add_argument("-shh", "--quiet", action="store_true")
     ap.add_argument("-spl", "--save-pkl", dest="save_pkl", action="store_true",
                     help="save collapsed.pkl / collapsed_accessories.pkl after collapsing (mirge/__main__.py:142-148)")
     ap.add_argument("-rr", "--resume", action="store_true",
@@ -51,6 +51,18 @@ def parse_args(argv=None):
                     help="write <sample>.trim.collapse.fa")
     ap.add_argument("-ie", "--isoform-entropy", dest="isoform_entropy", action="store_true",
                     help="write isomirs.csv and isomirs.samples.csv (isomiR RPMs and entropies)")
+    ap.add_argument("-a", "--adapter", dest="adapters", action="append", default=None,
+                    help="3' adapter removed from every read (cutadapt's regular 3' adapter; 'illumina' = TGGAATTCTCGGGTGCCAAGGAACTCCAG)")
+    ap.add_argument("-q", "--quality-cutoff", dest="quality_cutoff", default="10", help="[5'CUTOFF,]3'CUTOFF (default 10, as the reference)")
+    ap.add_argument("-nxt", "--nextseq-trim", dest="nextseq_trim", type=int, default=None)
+    ap.add_argument("-NX", "--trim-n", dest="trim_n", action="store_true")
+    ap.add_argument("-u", "--cut", dest="cut", action="append", type=int, default=[])
+    ap.add_argument("--overlap", type=int, default=3)
+    ap.add_argument("--error-rate", dest="error_rate", type=float, default=0.12)
+    ap.add_argument("-phr", "--phred64", dest="phred64", type=int, default=33)
+    ap.add_argument("--trim-count", dest="trim_count", choices=["per-modifier", "once"], default="per-modifier",
+                    help="per-modifier: a read is counted after every modifier of the chain, as the reference's worker does "
+                         "(digest.py:354-373); once: only the fully trimmed read")
     ap.add_argument("-gff", "--gff-out", dest="gff_out", action="store_true",
                     help="write sample_miRge3.gff (miRTop GFF3 of the miRNA reads, isomiR variant types from the GPU)")
     ap.add_argument("-ai", "--AtoI", dest="AtoI", action="store_true",
@@ -64,7 +76,7 @@ def parse_args(argv=None):
                     help="-ai without bowtie: file of the edited canonical sequences that align to the genome")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted; only -ai's bowtie runs use it")
     ap.add_argument("--device", type=int, default=None)
-    for flag in ("-a", "-g", "-qumi", "-nmir", "-bam", "-trf", "-mEC", "-dex"):
+    for flag in ("-g", "-qumi", "-nmir", "-bam", "-trf", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -73,10 +85,10 @@ def parse_args(argv=None):
             ap.error(f"-{k[4:]} belongs to a miRge3.0 subsystem outside the MI355X hot path (DESIGN.md section 0)")
     if args.umiDedup and not args.uniq_mol_ids:
         ap.error("-udd requires -umi f,b")
-    args.bowtieVersion, args.phred64 = "True", False
+    args.bowtieVersion = "True"
     if (args.AtoI or args.gff_out) and (args.uniq_mol_ids or args.tcf_out or args.save_pkl or args.resume):
         ap.error("-ai / -gff run on the device-resident route: not together with -umi / -tcf / -spl / -rr")
-    args.adapters = args.front = args.qiagenumi = None
+    args.front = args.qiagenumi = None
     return args
 
 

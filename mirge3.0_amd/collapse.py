@@ -95,6 +95,48 @@ def unwrap_fasta(data: bytes) -> bytes:
     return buf[keep].tobytes()
 
 
+ILLUMINA_3P = 'TGGAATTCTCGGGTGCCAAGGAACTCCAG'  # what `-a illumina` stands for (mirge/__main__.py:65-83)
+
+
+def trim_from_args(args):
+    """The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) as the options of ``mirge_reads_parse_trim``:
+    ``-q`` (default "10": quality trimming is ALWAYS in the reference's chain), ``-a`` (one 3' adapter; 'illumina' =
+    the TruSeq small-RNA adapter), ``-nxt``, ``-NX``, ``-u``, ``--overlap``, ``--error-rate``, ``-phr``.  5' adapters
+    (``-g``), several adapters, ``-n > 1`` and ``--action`` other than trim are refused."""
+    if getattr(args, "front", None):
+        raise NotImplementedError("5' adapters (-g) are not part of the MI355X path: only one 3' adapter (-a)")
+    adapters = getattr(args, "adapters", None) or []
+    if isinstance(adapters, str):
+        adapters = [("back", adapters)]
+    adapters = [(a if isinstance(a, (tuple, list)) else ("back", a)) for a in adapters]
+    if len(adapters) > 1 or any(kind != "back" for kind, _ in adapters):
+        raise NotImplementedError("one 3' adapter (-a) is supported; several adapters / 5' adapters are not")
+    adapter = adapters[0][1] if adapters else None
+    if adapter == "illumina":
+        adapter = ILLUMINA_3P
+    q = getattr(args, "quality_cutoff", "10")
+    qf, qb = 0, -1
+    if q is not None:
+        vals = [int(v) for v in str(q).split(",")]
+        if len(vals) == 1:
+            qf, qb = 0, vals[0]
+        elif len(vals) == 2:
+            qf, qb = vals
+        else:
+            raise SystemExit("Expected one value or two values separated by comma for the quality cutoff")
+    cut = [int(c) for c in (getattr(args, "cut", None) or [])]
+    if len(cut) > 2:
+        raise SystemExit("You cannot remove bases from more than two ends.")
+    if len(cut) == 2 and cut[0] * cut[1] > 0:
+        raise SystemExit("You cannot remove bases from the same end twice.")
+    nxt = getattr(args, "nextseq_trim", None)
+    base = 64 if int(getattr(args, "phred64", 33) or 33) == 64 else 33
+    return _ffi.MirgeTrim.make(adapter=adapter, quality_back=qb, quality_front=qf, nextseq=-1 if nxt is None else int(nxt),
+                               phred_base=base, min_overlap=int(getattr(args, "overlap", 3)),
+                               error_rate=float(getattr(args, "error_rate", 0.12)), trim_n=bool(getattr(args, "trim_n", False)),
+                               cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once")
+
+
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:
     keep = np.flatnonzero(reads.lengths >= int(min_len))
     if keep.shape[0] == len(reads):
@@ -137,11 +179,12 @@ def _collapse_one(ctx: _ffi.Context, reads: FlatSeqs):
 def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None):
     """Drop-in for ``baking`` (digest.py:105-302) on already-trimmed reads."""
     import pandas as pd
-    if getattr(args, "adapters", None) or getattr(args, "front", None) or getattr(args, "qiagenumi", None):
-        raise NotImplementedError(
-            "adapter trimming (and -qumi, which reads the adapter match) is outside the MI355X hot path "
-            "(SURVEY.md 8f, N4): trim with cutadapt first and pass the trimmed reads")
+    if getattr(args, "qiagenumi", None):
+        raise NotImplementedError("-qumi reads cutadapt's adapter match object and is not part of the MI355X path")
+    trim = trim_from_args(args)
     umi = getattr(args, "uniq_mol_ids", None)
+    if umi and (trim.adapter_len or trim.trim_n or trim.n_cut or trim.nextseq_cutoff >= 0):
+        raise NotImplementedError("-umi together with adapter / N / unconditional trimming is not supported: trim first")
     dedup = bool(getattr(args, "umiDedup", False))
     if umi:
         umi_f, umi_b = (int(x) for x in str(umi).split(","))
@@ -162,7 +205,7 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
     for FQfile, name in zip(inFileArray, inFileBaseArray):
         start = time.perf_counter()
         if device_parse:
-            raw, n_rec = _ffi.DeviceReads.parse(ctx, read_text(str(FQfile)), 0, min_len)
+            raw, n_rec = _ffi.DeviceReads.parse(ctx, read_text(str(FQfile)), 0, min_len, trim)
             sampleReadCounts[name] = n_rec
             trimmedReadCounts[name] = len(raw)
             parsed.append(raw)

@@ -189,7 +189,7 @@ __global__ void k_nl_count(const uint8_t* __restrict__ text, uint64_t n, uint32_
 // number alone would otherwise return shifted garbage for the rest of the file
 __global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_off, int period,
                           int sphase, int64_t* __restrict__ start, int64_t* __restrict__ end, uint64_t n_seq, int fmt,
-                          uint32_t* __restrict__ flags) {
+                          uint32_t* __restrict__ flags, int64_t* __restrict__ qstart) {
     __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * MIRGE_PARSE_TILE + threadIdx.x * 16ull;
     uint32_t mask;
@@ -209,6 +209,7 @@ __global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const ui
         }
         if ((int)(li % (uint64_t)period) == sphase && li / period < n_seq) end[li / period] = (int64_t)pos;
         if ((int)((li + 1) % (uint64_t)period) == sphase && (li + 1) / period < n_seq) start[(li + 1) / period] = (int64_t)pos + 1;
+        if (qstart && fmt == 1 && (li + 1) % 4 == 3 && (li + 1) / 4 < n_seq) qstart[(li + 1) / 4] = (int64_t)pos + 1;  // quality line (k_trim)
         li++;
     }
 }

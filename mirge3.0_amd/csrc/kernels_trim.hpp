@@ -1,0 +1,141 @@
+// kernels_trim.hpp -- part of mirge_kernels.hpp: k_trim, the read modifiers the reference runs through cutadapt before
+// it counts a read (mirge/libs/digest.py:59-101,320-375), on the text in HBM between k_nl_mark and
+// k_seq_class: a record's [start, end) is narrowed, nothing is copied.
+//   modifiers, in the reference's order: NextSeq quality trimming, quality trimming (-q, default 10 at the 3' end),
+//   3' adapter removal (-a; error rate 0.12 of the aligned adapter length, minimum overlap 3, indels allowed), N
+//   trimming at both ends, unconditional cuts (-u).
+//   The reference's worker tests the length and counts the read INSIDE its loop over the modifiers (digest.py:354-373):
+//   a read is counted once after EVERY modifier.  stages_out = number of modifiers reproduces that (virtual record
+//   r * stages_out + s = read r after modifier s); stages_out = 1 keeps only the fully trimmed read.
+// Restated from cutadapt's published algorithms (qualtrim.pyx, _align.pyx Aligner.locate, modifiers.py): parity
+// unpinned -- cutadapt is third-party and absent here.
+#pragma once
+
+#define MIRGE_TRIM_MAX_ADAPTER 64
+#define MIRGE_TRIM_MAX_MODS 8
+struct TrimOpts {
+    int32_t nextseq;        // cutoff, -1 = off
+    int32_t q_front, q_back;  // q_back -1 = off
+    int32_t base;           // 33 / 64
+    int32_t alen;           // 3' adapter length, 0 = none
+    int32_t min_overlap;
+    double rate;            // maximum error rate
+    int32_t trim_n;
+    int32_t n_cut, cut[2];
+    int32_t n_mods;         // modifiers in the chain (after dropping the quality ones for a text without qualities)
+    int32_t stages_out;     // n_mods (count after every modifier) or 1
+    uint8_t adapter[MIRGE_TRIM_MAX_ADAPTER];
+    uint8_t wild[MIRGE_TRIM_MAX_ADAPTER];  // adapter position is N: matches any base, not counted in the error-rate length
+};
+
+// Aligner.locate for a regular 3' adapter on read[0, n): returns the read position where the adapter starts, or n
+__device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_t* __restrict__ read, int n) {
+    const int m = o.alen;
+    uint16_t cost[MIRGE_TRIM_MAX_ADAPTER + 1];
+    uint8_t mat[MIRGE_TRIM_MAX_ADAPTER + 1], org[MIRGE_TRIM_MAX_ADAPTER + 1], nw[MIRGE_TRIM_MAX_ADAPTER + 1];
+    nw[0] = 0;
+    for (int i = 0; i <= m; i++) { cost[i] = (uint16_t)i; mat[i] = 0; org[i] = 0; if (i) nw[i] = (uint8_t)(nw[i - 1] + o.wild[i - 1]); }
+    int b_mat = -1, b_cost = 0, b_org = 0;
+    bool found = false, exact = false;
+    for (int j = 1; j <= n && !exact; j++) {
+        const uint8_t ch = read[j - 1] & 0xDF;
+        uint16_t d_cost = cost[0];
+        uint8_t d_mat = mat[0], d_org = org[0];
+        cost[0] = 0; mat[0] = 0; org[0] = (uint8_t)j;
+        for (int i = 1; i <= m; i++) {
+            const uint16_t l_cost = cost[i];  // previous column, same row ("deletion")
+            const uint8_t l_mat = mat[i], l_org = org[i];
+            uint16_t c; uint8_t mm, og;
+            if (o.wild[i - 1] || o.adapter[i - 1] == ch) { c = d_cost; mm = (uint8_t)(d_mat + 1); og = d_org; }
+            else {
+                const uint16_t cd = (uint16_t)(d_cost + 1), cdel = (uint16_t)(l_cost + 1), cins = (uint16_t)(cost[i - 1] + 1);
+                if (cd <= cdel && cd <= cins) { c = cd; mm = d_mat; og = d_org; }
+                else if (cins <= cdel) { c = cins; mm = mat[i - 1]; og = org[i - 1]; }
+                else { c = cdel; mm = l_mat; og = l_org; }
+            }
+            d_cost = l_cost; d_mat = l_mat; d_org = l_org;
+            cost[i] = c; mat[i] = mm; org[i] = og;
+        }
+        const int eff = m - nw[m];
+        if (m >= o.min_overlap && (double)cost[m] <= (double)eff * o.rate &&
+            (!found || (int)mat[m] > b_mat || ((int)mat[m] == b_mat && (int)cost[m] < b_cost))) {
+            found = true; b_mat = mat[m]; b_cost = cost[m]; b_org = org[m];
+            exact = b_cost == 0 && b_mat == m;
+        }
+    }
+    if (!exact) {  // the adapter may run off the read's end: every prefix of it, in the last column
+        for (int i = 0; i <= m; i++) {
+            const int eff = i - nw[i];
+            if (i >= o.min_overlap && (double)cost[i] <= (double)eff * o.rate &&
+                (!found || (int)mat[i] > b_mat || ((int)mat[i] == b_mat && (int)cost[i] < b_cost))) {
+                found = true; b_mat = mat[i]; b_cost = cost[i]; b_org = org[i];
+            }
+        }
+    }
+    return found ? b_org : n;
+}
+
+// lstart/lend: the sequence line of every record (after '\r' stripping here); qstart: its quality line (FASTQ) or null.
+// vstart/vend[r * stages_out + s]: the read after modifier s (stages_out == n_mods) or after the last one.
+__global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, const int64_t* __restrict__ lend,
+                       const int64_t* __restrict__ qstart, uint32_t n_seq, TrimOpts o, int64_t* __restrict__ vstart,
+                       int64_t* __restrict__ vend) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_seq; r += gridDim.x * blockDim.x) {
+        int64_t b = lstart[r], e = lend[r];
+        if (e > b && text[e - 1] == 13) e--;
+        const uint8_t* q = qstart ? text + qstart[r] : nullptr;  // quality of base k of the LINE: q[k]
+        int a0 = 0, a1 = (int)((e - b) > 0x7FFF ? 0x7FFF : (e - b));  // current read = line[a0, a1)
+        const uint8_t* s = text + b;
+        int stage = 0;
+        auto emit = [&]() {
+            if (o.stages_out > 1) { vstart[(size_t)r * o.stages_out + stage] = b + a0; vend[(size_t)r * o.stages_out + stage] = b + a1; }
+            stage++;
+        };
+        if (o.nextseq >= 0 && q) {
+            int sum = 0, mx = 0, stop = a1;
+            for (int i = a1 - 1; i >= a0; i--) {
+                int qq = (int)q[i] - o.base;
+                if ((s[i] & 0xDF) == 'G') qq = o.nextseq - 1;
+                sum += o.nextseq - qq;
+                if (sum < 0) break;
+                if (sum > mx) { mx = sum; stop = i; }
+            }
+            a1 = stop;
+            emit();
+        }
+        if (o.q_back >= 0 && q) {
+            int sum = 0, mx = 0, st = a0;
+            for (int i = a0; i < a1; i++) {
+                sum += o.q_front - ((int)q[i] - o.base);
+                if (sum < 0) break;
+                if (sum > mx) { mx = sum; st = i + 1; }
+            }
+            int stop = a1;
+            sum = 0; mx = 0;
+            for (int i = a1 - 1; i >= a0; i--) {
+                sum += o.q_back - ((int)q[i] - o.base);
+                if (sum < 0) break;
+                if (sum > mx) { mx = sum; stop = i; }
+            }
+            if (st >= stop) { st = a0; stop = a0; }  // (0, 0) of the current read: nothing left
+            a0 = st; a1 = stop;
+            emit();
+        }
+        if (o.alen > 0) {
+            a1 = a0 + adapter_cut_point(o, s + a0, a1 - a0);
+            emit();
+        }
+        if (o.trim_n) {
+            while (a0 < a1 && (s[a0] & 0xDF) == 'N') a0++;
+            while (a1 > a0 && (s[a1 - 1] & 0xDF) == 'N') a1--;
+            emit();
+        }
+        for (int k = 0; k < o.n_cut; k++) {
+            const int cval = o.cut[k];
+            if (cval > 0) a0 = min(a0 + cval, a1);
+            else if (cval < 0) a1 = max(a1 + cval, a0);
+            if (cval != 0) emit();
+        }
+        if (o.stages_out <= 1) { vstart[r] = b + a0; vend[r] = b + a1; }
+    }
+}

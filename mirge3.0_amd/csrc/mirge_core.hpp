@@ -112,7 +112,7 @@ MIRGE_HD uint64_t mirge_extract(const uint64_t* w, int a, int k) {
 
 // drop `n5` bases at the 5' end (n5 < 32) and keep `newlen` bases
 template <int W>
-MIRGE_HD void mirge_trim(MirgeRead<W>& r, int n5, int newlen) {
+MIRGE_HD void mirge_trim_read(MirgeRead<W>& r, int n5, int newlen) {
     if (n5 > 0) {
         int s = 2 * n5;
 #pragma unroll
@@ -161,7 +161,7 @@ MIRGE_HD bool mirge_effective_read(MirgeRead<W>& r, const MirgePolicy& p) {
     }
     l -= p.trim5 + p.trim3;
     if (l < 1 || l <= p.mm) return false;
-    if (l != L || p.trim5) mirge_trim<W>(r, p.trim5, l);
+    if (l != L || p.trim5) mirge_trim_read<W>(r, p.trim5, l);
     return true;
 }
 

@@ -33,6 +33,7 @@ __device__ __forceinline__ void load_read(const GroupView<W>& g, uint32_t i, Mir
 }
 
 #include "kernels_reads.hpp"
+#include "kernels_trim.hpp"
 #include "kernels_collapse.hpp"
 #include "kernels_cascade.hpp"
 #include "kernels_join.hpp"

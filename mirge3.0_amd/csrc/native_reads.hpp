@@ -236,12 +236,50 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
 // k_pack straight from the text).  format: 1 = FASTQ (4-line records), 2 = FASTA (one sequence line per record),
 // 3 = one sequence per line, 0 = by the first byte ('@', '>', else 3).  Reads shorter than min_len are dropped
 // (digest.py:348,368); *n_records = records seen before the filter (digest.py:326 `count`).
+// mirge_trim (C ABI) -> the kernel's options; the two quality modifiers exist only where the text has qualities
+static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
+    std::memset(&o, 0, sizeof(o));
+    o.nextseq = t->nextseq_cutoff; o.q_front = t->quality_front; o.q_back = t->quality_back; o.base = t->phred_base ? t->phred_base : 33;
+    o.min_overlap = t->min_overlap; o.rate = t->error_rate; o.trim_n = t->trim_n ? 1 : 0;
+    if (format != 1) { o.nextseq = -1; o.q_back = -1; }
+    if (t->adapter_len < 0 || t->adapter_len > MIRGE_TRIM_MAX_ADAPTER || (t->adapter_len > 0 && !t->adapter))
+        return fail(-1, "mirge_reads_parse_trim: the 3' adapter must be 1-" + std::to_string(MIRGE_TRIM_MAX_ADAPTER) + " nt");
+    o.alen = t->adapter_len;
+    for (int i = 0; i < o.alen; i++) {
+        const char ch = (char)(t->adapter[i] & 0xDF);
+        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N')
+            return fail(-1, "mirge_reads_parse_trim: adapter characters other than A/C/G/T/N are not supported");
+        o.adapter[i] = (uint8_t)ch; o.wild[i] = ch == 'N';
+    }
+    if (o.alen && (!(o.rate >= 0.0) || o.rate > 1.0 || o.min_overlap < 1)) return fail(-1, "mirge_reads_parse_trim: error rate / overlap out of range");
+    if (t->n_cut < 0 || t->n_cut > 2) return fail(-1, "mirge_reads_parse_trim: at most two unconditional cuts");
+    o.n_cut = t->n_cut; o.cut[0] = t->cut[0]; o.cut[1] = t->cut[1];
+    o.n_mods = (o.nextseq >= 0) + (o.q_back >= 0) + (o.alen > 0) + o.trim_n;
+    for (int k = 0; k < o.n_cut; k++) o.n_mods += o.cut[k] != 0;
+    o.stages_out = (t->count_per_modifier && o.n_mods > 1) ? o.n_mods : 1;
+    if (o.n_mods > MIRGE_TRIM_MAX_MODS) return fail(-1, "mirge_reads_parse_trim: too many modifiers");
+    return 0;
+}
+
+extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                                      const mirge_trim* trim, mirge_reads** out, int64_t* n_records);
 extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                                  mirge_reads** out, int64_t* n_records) {
+    return mirge_reads_parse_trim(c, text, nbytes, format, min_len, nullptr, out, n_records);
+}
+
+extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                                      const mirge_trim* trim, mirge_reads** out, int64_t* n_records) {
     if (!c || !out || nbytes < 0 || (nbytes > 0 && !text) || format < 0 || format > 3)
         return fail(-1, "mirge_reads_parse: bad argument");
     HIPOK(hipSetDevice(c->device));
     if (format == 0) format = nbytes == 0 ? 3 : (text[0] == '@' ? 1 : (text[0] == '>' ? 2 : 3));
+    TrimOpts topt;
+    bool trimming = false;
+    if (trim) {
+        CHECK(trim_options(trim, format, topt));
+        trimming = topt.n_mods > 0;
+    }
     const int period = format == 1 ? 4 : (format == 2 ? 2 : 1), sphase = format == 3 ? 0 : 1;
     auto R = std::make_unique<mirge_reads>();
     R->ctx = c; R->n = 0;
@@ -285,9 +323,13 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
     // sequence lines: li in [0, n_lines) with li % period == sphase
     const uint64_t n_seq64 = n_lines > (uint32_t)sphase ? ((uint64_t)n_lines - sphase + period - 1) / period : 0;
     int rc = n_seq64 >= 0xFFFFFFF0ull ? fail(-5, "more than 2^32 reads in one set is not supported") : 0;
-    const uint32_t n_seq = rc ? 0u : (uint32_t)n_seq64;
-    if (n_records) *n_records = n_seq;
-    int64_t *dstart = nullptr, *dend = nullptr;
+    const uint32_t n_raw = rc ? 0u : (uint32_t)n_seq64;  // records of the text
+    if (n_records) *n_records = n_raw;
+    // with trimming a record becomes `stages_out` virtual records (the read after every modifier, or after the last)
+    const uint64_t n_virt64 = (uint64_t)n_raw * (trimming ? (uint64_t)topt.stages_out : 1ull);
+    if (rc == 0 && n_virt64 >= 0xFFFFFFF0ull) rc = fail(-5, "more than 2^32 reads in one set is not supported");
+    const uint32_t n_seq = rc ? 0u : (uint32_t)n_virt64;
+    int64_t *dstart = nullptr, *dend = nullptr, *lstart = nullptr, *lend = nullptr, *qstart = nullptr;
     uint8_t* dcls = nullptr;
     uint32_t *blk = nullptr, *blk_off = nullptr, *keep = nullptr, *keep_off = nullptr, *dmeta = nullptr, *src_all = nullptr,
              *orig_all = nullptr;
@@ -307,8 +349,17 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
         if (e == hipSuccess) e = hipMemsetAsync(blk + (size_t)MIRGE_NGROUPS * nblk, 0, 4, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(keep + nblk, 0, 4, c->stream);
         if (e != hipSuccess) { rc = fail(-2, hipGetErrorString(e)); break; }
-        hipLaunchKernelGGL(k_nl_mark, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_off, period, sphase, dstart, dend,
-                           (uint64_t)n_seq, (int)format, dmeta);
+        if (trimming) {
+            if ((rc = dalloc(c, &lstart, (size_t)n_raw))) break;
+            if ((rc = dalloc(c, &lend, (size_t)n_raw))) break;
+            if (format == 1 && (rc = dalloc(c, &qstart, (size_t)n_raw))) break;
+        }
+        hipLaunchKernelGGL(k_nl_mark, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_off, period, sphase,
+                           trimming ? lstart : dstart, trimming ? lend : dend, (uint64_t)n_raw, (int)format, dmeta, qstart);
+        if (trimming) {
+            LaunchScope ls(c, "k_trim", n_raw);
+            hipLaunchKernelGGL(k_trim, dim3(grid_for(c, n_raw, 64)), dim3(64), 0, c->stream, dtext, lstart, lend, qstart, n_raw, topt, dstart, dend);
+        }
         hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dtext, dstart, dend, n_seq, min_len, dcls, blk,
                            keep, nblk, dmeta + 8, dmeta);
         size_t need = 0;
@@ -365,7 +416,7 @@ extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes,
     (void)hipStreamSynchronize(c->stream);
     c->release(dtext); c->release(tile_cnt); c->release(tile_off); c->release(tmp); c->release(dstart); c->release(dend);
     c->release(dcls); c->release(blk); c->release(blk_off); c->release(keep); c->release(keep_off); c->release(dmeta);
-    c->release(src_all); c->release(orig_all);
+    c->release(src_all); c->release(orig_all); c->release(lstart); c->release(lend); c->release(qstart);
     if (rc) { mirge_reads_destroy(R.release()); return rc; }
     *out = R.release();
     return 0;

@@ -22,7 +22,7 @@ import numpy as np
 
 from . import PASS_COLUMNS, _ffi
 from .cascade import PASSES, get_cascade
-from .collapse import read_text
+from .collapse import read_text, trim_from_args
 from .countjoin import summarize_device
 from .seqio import FlatSeqs, load_merges
 
@@ -67,6 +67,7 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     ctx = casc.ctx
     tm["libraries_s"] = time.perf_counter() - t0
     min_len = int(getattr(args, "minimum_length", 16))
+    trim = trim_from_args(args)
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     parsed = []
     t_read = t_parse = 0.0
@@ -75,7 +76,7 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         text = read_text(str(f))
         t_read += time.perf_counter() - t
         t1 = time.perf_counter()
-        raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 0, min_len)
+        raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 0, min_len, trim)
         del text
         t_parse += time.perf_counter() - t1
         sampleReadCounts[name], trimmedReadCounts[name] = n_rec, len(raw)

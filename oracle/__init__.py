@@ -588,3 +588,145 @@ def gff_record(master: str, read: str, precursor: str):
     if not any(c in case for c in "ATGC"):
         cigar = str(len(read)) + "M"
     return "isomiR", start, end, variant or "iso_snv", cigar
+
+
+# --------------------------------------------------------------------------------------
+# read trimming (row N4): the modifier chain the reference builds from cutadapt (mirge/libs/digest.py:59-101) and the
+# way its worker counts reads (:320-375).  PARITY UNPINNED: cutadapt is third-party and absent here, and the reference
+# holds no vectors for it -- these functions restate cutadapt 2.x-4.x's published algorithms (qualtrim.pyx:
+# quality_trim_index / nextseq_trim_index; _align.pyx: Aligner.locate for a 3' adapter; modifiers.py) from its
+# documentation and sources as remembered; full-matrix Python, the checker of k_trim.
+# --------------------------------------------------------------------------------------
+def quality_trim_index(qual: str, cutoff_front: int, cutoff_back: int, base: int = 33):
+    s = mx = start = 0
+    for i in range(len(qual)):
+        s += cutoff_front - (ord(qual[i]) - base)
+        if s < 0:
+            break
+        if s > mx:
+            mx, start = s, i + 1
+    stop, s, mx = len(qual), 0, 0
+    for i in reversed(range(len(qual))):
+        s += cutoff_back - (ord(qual[i]) - base)
+        if s < 0:
+            break
+        if s > mx:
+            mx, stop = s, i
+    if start >= stop:
+        start, stop = 0, 0
+    return start, stop
+
+
+def nextseq_trim_index(seq: str, qual: str, cutoff: int, base: int = 33):
+    s = mx = 0
+    stop = len(qual)
+    for i in reversed(range(len(qual))):
+        q = ord(qual[i]) - base
+        if seq[i] == "G":
+            q = cutoff - 1
+        s += cutoff - q
+        if s < 0:
+            break
+        if s > mx:
+            mx, stop = s, i
+    return stop
+
+
+def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3):
+    """Aligner.locate for a regular 3' adapter (the alignment may start anywhere in the read, stop anywhere in it, and
+    stop inside the adapter when it runs off the read's end): unit costs, indels allowed; of the alignments with
+    cost <= aligned adapter length * max_error_rate and at least min_overlap adapter bases, the one with the most
+    matches, then the lowest cost, first found (full-adapter matches in order of their end in the read, then the
+    partial ones at the read's end by growing adapter prefix).  An 'N' in the adapter matches any base and does not
+    count towards the length the error rate applies to.  -> (astart, astop, rstart, rstop, matches, errors) or None."""
+    m, n = len(adapter), len(read)
+    wild = [c == "N" for c in adapter]
+    nwild = [0] * (m + 1)
+    for i in range(m):
+        nwild[i + 1] = nwild[i] + (1 if wild[i] else 0)
+    prev = [(i, 0, 0) for i in range(m + 1)]  # (cost, matches, origin)
+    best = None
+
+    def consider(entry, i, j):
+        nonlocal best
+        cost, matches, origin = entry
+        length = i
+        eff = length - nwild[i]
+        if length >= min_overlap and cost <= eff * max_error_rate and \
+                (best is None or matches > best[4] or (matches == best[4] and cost < best[5])):
+            best = (0, i, origin, j, matches, cost)
+
+    done = False
+    for j in range(1, n + 1):
+        cur = [(0, 0, j)] + [None] * m
+        for i in range(1, m + 1):
+            d, up, left = prev[i - 1], cur[i - 1], prev[i]
+            if wild[i - 1] or adapter[i - 1] == read[j - 1]:
+                cur[i] = (d[0], d[1] + 1, d[2])
+            else:
+                cd, cdel, cins = d[0] + 1, left[0] + 1, up[0] + 1
+                if cd <= cdel and cd <= cins:
+                    cur[i] = (cd, d[1], d[2])
+                elif cins <= cdel:
+                    cur[i] = (cins, up[1], up[2])
+                else:
+                    cur[i] = (cdel, left[1], left[2])
+        prev = cur
+        consider(cur[m], m, j)
+        if best is not None and best[5] == 0 and best[4] == m and best[1] == m:
+            done = True
+            break
+    if not done:
+        for i in range(0, m + 1):
+            consider(prev[i], i, n)
+    return best
+
+
+def trim_stages(seq: str, qual, opts: dict):
+    """The read after each modifier of the chain (digest.py:59-101 builds it in this order): NextSeq quality trimming,
+    quality trimming, 3' adapter removal, N trimming at both ends, unconditional cuts."""
+    out = []
+    if opts.get("nextseq") is not None and qual is not None:
+        stop = nextseq_trim_index(seq, qual, opts["nextseq"], opts.get("base", 33))
+        seq, qual = seq[:stop], qual[:stop]
+        out.append(seq)
+    if opts.get("q_back") is not None and qual is not None:
+        a, b = quality_trim_index(qual, opts.get("q_front", 0), opts["q_back"], opts.get("base", 33))
+        seq, qual = seq[a:b], qual[a:b]
+        out.append(seq)
+    if opts.get("adapter"):
+        hit = adapter_locate_back(opts["adapter"], seq, opts.get("error_rate", 0.12), opts.get("overlap", 3))
+        if hit is not None:
+            seq = seq[:hit[2]]
+            qual = qual[:hit[2]] if qual is not None else None
+        out.append(seq)
+    if opts.get("trim_n"):
+        a = 0
+        while a < len(seq) and seq[a] in "Nn":
+            a += 1
+        b = len(seq)
+        while b > a and seq[b - 1] in "Nn":
+            b -= 1
+        seq = seq[a:b]
+        out.append(seq)
+    for c in opts.get("cut", []):
+        if c > 0:
+            seq = seq[c:]
+        elif c < 0:
+            seq = seq[:c]
+        if c != 0:
+            out.append(seq)
+    return out
+
+
+def trimmed_counts(records, opts: dict, min_len: int = 16, per_modifier: bool = True):
+    """The per-file dictionary the reference's worker builds (digest.py:320-375): at HEAD the length test and the count
+    sit INSIDE the loop over the modifiers, so a read is counted once after every modifier (``per_modifier``); counted
+    once, after the last one, is what the loop evidently meant.  -> dict in insertion order."""
+    d = {}
+    for seq, qual in records:
+        stages = trim_stages(seq, qual, opts)
+        for s in (stages if per_modifier else stages[-1:]):
+            if len(s) >= min_len:
+                d[s] = d.get(s, 0) + 1
+    return d

@@ -125,10 +125,19 @@ def test_cli_flags_in_and_out_of_scope():
     base = ["-s", "a.fq", "-lib", "/x", "-on", "human"]
     a = parse_args(base + ["-umi", "4,4", "-udd", "-tcf", "-spk", "-m", "18", "-ie"])
     assert a.uniq_mol_ids == "4,4" and a.umiDedup and a.tcf_out and a.spikeIn and a.minimum_length == 18 and a.isoform_entropy
-    assert a.adapters is None and a.qiagenumi is None
+    assert a.adapters is None and a.qiagenumi is None and a.quality_cutoff == "10"
     b = parse_args(base + ["-ai", "-pbwt", "/opt/bowtie", "--genome-retained", "r.txt"])
     assert b.AtoI and b.bowtie_path == "/opt/bowtie" and b.genome_retained == "r.txt"
-    for bad in (["-udd"], ["-qumi"], ["-a", "illumina"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"]):
+    t = parse_args(base + ["-a", "illumina", "-q", "5,20", "-NX", "-u", "2", "-u", "-1", "--trim-count", "once"])
+    from mirge3_amd.collapse import trim_from_args, ILLUMINA_3P
+    tr = trim_from_args(t)
+    assert tr.adapter == ILLUMINA_3P.encode() and (tr.quality_front, tr.quality_back) == (5, 20) and tr.trim_n == 1
+    assert tr.n_cut == 2 and list(tr.cut) == [2, -1] and tr.count_per_modifier == 0 and tr.error_rate == 0.12 and tr.min_overlap == 3
+    d = trim_from_args(parse_args(base))  # the reference's chain always holds the quality trimmer (-q default "10")
+    assert d.adapter_len == 0 and d.quality_back == 10 and d.count_per_modifier == 1
+    with pytest.raises(NotImplementedError):
+        trim_from_args(parse_args(base + ["-a", "AAAA", "-a", "CCCC"]))
+    for bad in (["-udd"], ["-qumi"], ["-g", "ACGT"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"]):
         with pytest.raises(SystemExit):
             parse_args(base + bad)
 

@@ -17,7 +17,7 @@ fq = os.path.join(tmp, "S1.fastq")
 with open(fq, "w") as fh:
     fh.write("".join(f"@r\n{r}\n+\n{'I'*len(r)}\n" for r in reads))
 print("fastq MB", os.path.getsize(fq) / 1e6, flush=True)
-argv = ["-s", fq, "-lib", os.path.join(tmp, "Libs"), "-on", "human", "-db", "miRBase", "-o", tmp, "-dn", "out", "-q"]
+argv = ["-s", fq, "-lib", os.path.join(tmp, "Libs"), "-on", "human", "-db", "miRBase", "-o", tmp, "-dn", "out", "-shh"]
 t = time.time()
 pr = cProfile.Profile(); pr.enable()
 cli.main(argv)
