@@ -28,49 +28,57 @@ struct TrimOpts {
     uint8_t wild[MIRGE_TRIM_MAX_ADAPTER];  // adapter position is N: matches any base, not counted in the error-rate length
 };
 
-// Aligner.locate for a regular 3' adapter on read[0, n): returns the read position where the adapter starts, or n
+// Aligner.locate for a regular 3' adapter on read[0, n): returns the read position where the adapter starts, or n.
+// One DP column lives in registers: entry = cost << 16 | matches << 8 | origin, MAXM + 1 of them, the row loop fully
+// unrolled (MAXM = 32 covers the adapters in use -- TruSeq small RNA is 29 nt; 64 is the general form).
+template <int MAXM>
 __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_t* __restrict__ read, int n) {
     const int m = o.alen;
-    uint16_t cost[MIRGE_TRIM_MAX_ADAPTER + 1];
-    uint8_t mat[MIRGE_TRIM_MAX_ADAPTER + 1], org[MIRGE_TRIM_MAX_ADAPTER + 1], nw[MIRGE_TRIM_MAX_ADAPTER + 1];
+    uint32_t e[MAXM + 1];
+    uint8_t nw[MAXM + 1];
     nw[0] = 0;
-    for (int i = 0; i <= m; i++) { cost[i] = (uint16_t)i; mat[i] = 0; org[i] = 0; if (i) nw[i] = (uint8_t)(nw[i - 1] + o.wild[i - 1]); }
+#pragma unroll
+    for (int i = 0; i <= MAXM; i++) {
+        e[i] = (uint32_t)i << 16;
+        if (i) nw[i] = (uint8_t)(nw[i - 1] + (i <= m ? o.wild[i - 1] : 0));
+    }
     int b_mat = -1, b_cost = 0, b_org = 0;
     bool found = false, exact = false;
+    auto consider = [&](uint32_t ent, int i) {
+        const int cost = (int)(ent >> 16), mat = (int)((ent >> 8) & 0xFF);
+        if (i >= o.min_overlap && (double)cost <= (double)(i - nw[i]) * o.rate &&
+            (!found || mat > b_mat || (mat == b_mat && cost < b_cost))) {
+            found = true; b_mat = mat; b_cost = cost; b_org = (int)(ent & 0xFF);
+        }
+    };
     for (int j = 1; j <= n && !exact; j++) {
         const uint8_t ch = read[j - 1] & 0xDF;
-        uint16_t d_cost = cost[0];
-        uint8_t d_mat = mat[0], d_org = org[0];
-        cost[0] = 0; mat[0] = 0; org[0] = (uint8_t)j;
-        for (int i = 1; i <= m; i++) {
-            const uint16_t l_cost = cost[i];  // previous column, same row ("deletion")
-            const uint8_t l_mat = mat[i], l_org = org[i];
-            uint16_t c; uint8_t mm, og;
-            if (o.wild[i - 1] || o.adapter[i - 1] == ch) { c = d_cost; mm = (uint8_t)(d_mat + 1); og = d_org; }
-            else {
-                const uint16_t cd = (uint16_t)(d_cost + 1), cdel = (uint16_t)(l_cost + 1), cins = (uint16_t)(cost[i - 1] + 1);
-                if (cd <= cdel && cd <= cins) { c = cd; mm = d_mat; og = d_org; }
-                else if (cins <= cdel) { c = cins; mm = mat[i - 1]; og = org[i - 1]; }
-                else { c = cdel; mm = l_mat; og = l_org; }
+        uint32_t diag = e[0];
+        e[0] = (uint32_t)j;  // cost 0, matches 0, origin j
+        uint32_t last = e[0];
+#pragma unroll
+        for (int i = 1; i <= MAXM; i++) {
+            if (i <= m) {
+                const uint32_t left = e[i];  // previous column, same row
+                uint32_t v;
+                if (o.wild[i - 1] || o.adapter[i - 1] == ch) v = diag + 0x100u;  // a match: cost and origin of the diagonal
+                else {
+                    const uint32_t cd = diag >> 16, cdel = left >> 16, cins = e[i - 1] >> 16;
+                    const uint32_t src = (cd <= cdel && cd <= cins) ? diag : (cins <= cdel ? e[i - 1] : left);
+                    v = src + 0x10000u;
+                }
+                diag = left;
+                e[i] = v;
+                if (i == m) last = v;
             }
-            d_cost = l_cost; d_mat = l_mat; d_org = l_org;
-            cost[i] = c; mat[i] = mm; org[i] = og;
         }
-        const int eff = m - nw[m];
-        if (m >= o.min_overlap && (double)cost[m] <= (double)eff * o.rate &&
-            (!found || (int)mat[m] > b_mat || ((int)mat[m] == b_mat && (int)cost[m] < b_cost))) {
-            found = true; b_mat = mat[m]; b_cost = cost[m]; b_org = org[m];
-            exact = b_cost == 0 && b_mat == m;
-        }
+        consider(last, m);
+        exact = found && b_cost == 0 && b_mat == m;
     }
     if (!exact) {  // the adapter may run off the read's end: every prefix of it, in the last column
-        for (int i = 0; i <= m; i++) {
-            const int eff = i - nw[i];
-            if (i >= o.min_overlap && (double)cost[i] <= (double)eff * o.rate &&
-                (!found || (int)mat[i] > b_mat || ((int)mat[i] == b_mat && (int)cost[i] < b_cost))) {
-                found = true; b_mat = mat[i]; b_cost = cost[i]; b_org = org[i];
-            }
-        }
+#pragma unroll
+        for (int i = 0; i <= MAXM; i++)
+            if (i <= m) consider(e[i], i);
     }
     return found ? b_org : n;
 }
@@ -122,7 +130,7 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
             emit();
         }
         if (o.alen > 0) {
-            a1 = a0 + adapter_cut_point(o, s + a0, a1 - a0);
+            a1 = a0 + (o.alen <= 32 ? adapter_cut_point<32>(o, s + a0, a1 - a0) : adapter_cut_point<MIRGE_TRIM_MAX_ADAPTER>(o, s + a0, a1 - a0));
             emit();
         }
         if (o.trim_n) {

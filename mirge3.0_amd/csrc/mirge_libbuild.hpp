@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mirge_core.hpp"
@@ -46,20 +47,49 @@ static inline int mirge_hostlib_build(MirgeHostLib& L, const char* seq, const in
     L.inv.assign((size_t)((total + 63) / 64) + 4, ~0ull);
     L.ref_start.resize((size_t)n_refs + 1);
     uint64_t g = 0;
-    L.valid_positions = 0;
     for (int64_t t = 0; t < n_refs; t++) {
         L.ref_start[(size_t)t] = (uint32_t)g;
-        for (int64_t i = off[t]; i < off[t + 1]; i++, g++) {
-            int code = mirge_base_code(seq[i]);
-            if (code >= 0) {
-                L.T[g >> 5] |= (uint64_t)code << (2 * (g & 31));
-                L.inv[g >> 6] &= ~(1ull << (g & 63));
-                L.valid_positions++;
-            }
-        }
-        g++;  // the separator stays invalid
+        g += (uint64_t)(off[t + 1] - off[t]) + 1;  // the separator after every reference stays invalid
     }
     L.ref_start[(size_t)n_refs] = (uint32_t)g;
+    // 2-bit packing on all host cores: every thread owns a range of global positions that starts and ends on a
+    // multiple of 64 bases, so no word of T (32 bases) or inv (64 bases) is shared.  (The human-sized set used to
+    // take 4.8 s of one core per process; this is what a one-sample CLI run waits for before its first kernel.)
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int NT = (int)std::min<uint64_t>(hw, std::max<uint64_t>(1, total >> 20));
+    std::vector<uint64_t> valid((size_t)NT, 0);
+    auto work = [&](int w) {
+        const uint64_t lo = (total * (uint64_t)w / NT) & ~63ull, hi = w + 1 == NT ? total : ((total * (uint64_t)(w + 1) / NT) & ~63ull);
+        if (lo >= hi) return;
+        // first reference that reaches into [lo, hi)
+        int64_t t = (int64_t)(std::upper_bound(L.ref_start.begin(), L.ref_start.begin() + n_refs, (uint32_t)lo) - L.ref_start.begin()) - 1;
+        if (t < 0) t = 0;
+        uint64_t nv = 0;
+        for (; t < n_refs && (uint64_t)L.ref_start[(size_t)t] < hi; t++) {
+            const uint64_t rs = L.ref_start[(size_t)t];
+            const int64_t len = off[t + 1] - off[t];
+            const int64_t i0 = rs < lo ? (int64_t)(lo - rs) : 0;
+            const int64_t i1 = rs + (uint64_t)len > hi ? (int64_t)(hi - rs) : len;
+            for (int64_t i = i0; i < i1; i++) {
+                const int code = mirge_base_code(seq[off[t] + i]);
+                if (code >= 0) {
+                    const uint64_t gp = rs + (uint64_t)i;
+                    L.T[gp >> 5] |= (uint64_t)code << (2 * (gp & 31));
+                    L.inv[gp >> 6] &= ~(1ull << (gp & 63));
+                    nv++;
+                }
+            }
+        }
+        valid[(size_t)w] = nv;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int w = 1; w < NT; w++) th.emplace_back(work, w);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    L.valid_positions = 0;
+    for (uint64_t v : valid) L.valid_positions += v;
     // largest probe length: 4^k >= MIRGE_K_OVERSAMPLE x positions, clamped to [8, MIRGE_KMAX]
     int k = 8;
     while (k < MIRGE_KMAX && (1ull << (2 * k)) < (uint64_t)MIRGE_K_OVERSAMPLE * std::max<uint64_t>(L.valid_positions, 1)) k++;

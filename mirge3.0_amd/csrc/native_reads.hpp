@@ -358,7 +358,7 @@ extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nb
                            trimming ? lstart : dstart, trimming ? lend : dend, (uint64_t)n_raw, (int)format, dmeta, qstart);
         if (trimming) {
             LaunchScope ls(c, "k_trim", n_raw);
-            hipLaunchKernelGGL(k_trim, dim3(grid_for(c, n_raw, 64)), dim3(64), 0, c->stream, dtext, lstart, lend, qstart, n_raw, topt, dstart, dend);
+            hipLaunchKernelGGL(k_trim, dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, topt, dstart, dend);
         }
         hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dtext, dstart, dend, n_seq, min_len, dcls, blk,
                            keep, nblk, dmeta + 8, dmeta);

@@ -25,7 +25,7 @@ def _sim():
     deps = [SRC] + [os.path.join(HERE, "..", "mirge3.0_amd", "csrc", f) for f in ("mirge_core.hpp", "mirge_libbuild.hpp", "mirge_isotype.hpp")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(SO), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", SO, SRC])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-pthread", "-o", SO, SRC])
     return C.CDLL(SO)
 
 
