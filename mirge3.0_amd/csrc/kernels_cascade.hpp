@@ -341,6 +341,9 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
             res_pos[idx] = (uint32_t)best - b0;  // position in that member's own text
             res_mm[idx] = (int8_t)((best >> 32) & 0xFF);
             survivor = false;
+        } else if (valid && !act_in) {  // the first pass sees every read of the group: it also writes "unannotated"
+            res_pass[idx] = -1;         // (two memsets per group and the queue gaps around them, before)
+            res_mm[idx] = -1;
         }
         const unsigned long long bal = __ballot(survivor);
         if (bal) {

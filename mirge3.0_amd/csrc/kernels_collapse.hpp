@@ -115,6 +115,15 @@ __global__ void k_collapse_insert_key(GroupView<1> g, KeySlot* __restrict__ slot
     }
 }
 
+// rep[] / firstj[] = 0xFFFFFFFF, cnt[] = 0 in ONE launch (three hipMemsetAsync = six fill kernels per small group before)
+__global__ void k_collapse_init(uint32_t* __restrict__ rep, uint32_t* __restrict__ firstj, uint32_t* __restrict__ cnt,
+                                uint32_t tsize, uint32_t ncnt) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncnt; i += gridDim.x * blockDim.x) {
+        if (i < tsize) { rep[i] = MIRGE_EMPTY; firstj[i] = MIRGE_EMPTY; }
+        cnt[i] = 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Partitioned collapse for the key path (<=31 nt, no N, one sample).  Scattered device-scope atomics
 // run at ~20 G/s chip-wide, which is what bounds k_collapse_insert_key (2.4 atomics per read).  Here

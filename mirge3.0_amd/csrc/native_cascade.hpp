@@ -132,8 +132,10 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     CHECK(dalloc(c, &actA, (size_t)grid * cap));
     CHECK(dalloc(c, &actB, (size_t)grid * cap));
     CHECK(dalloc(c, &seg_n, (size_t)grid * (MIRGE_MAX_PASSES + 1)));
-    HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->cur));
-    HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->cur));
+    if (steps.empty()) {  // no pass runs: nothing will write the "unannotated" marks
+        HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->cur));
+        HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->cur));
+    }
     GroupView<W> v = view_of<W>(rg);
     if (n_dev) v.n = n;  // only a stride for W > 1; the deferred-count path is the one-word bulk group
     const uint32_t* act_in = nullptr;

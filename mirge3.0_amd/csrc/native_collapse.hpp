@@ -28,9 +28,13 @@ static const char* group_tag(int gi) {
     return t[gi];
 }
 
-// partitioned key path after k_part_agg: bucket offsets, scatter, per-bucket de-duplication
-static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, uint32_t* dmeta) {
+// partitioned key path after k_part_agg.  `part` 1: bucket offsets + scatter (k_part_scatter is one workgroup per CU
+// like k_part_agg: the small groups' kernels, enqueued while these run, find room beside them); 2: the per-bucket
+// de-duplication (8192 workgroups: takes the machine); 0: both.  The main queue used to idle ~0.1 ms between
+// k_part_agg and k_part_prefix while the host enqueued the small groups' launches (profiles/r02_timeline.txt).
+static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, uint32_t* dmeta, int part = 0) {
     const uint32_t G = t.G, B = t.B;
+    if (part != 2) {
     {
         LaunchScope ls(c, "k_part_prefix.w1", (double)G * B);
         hipLaunchKernelGGL(k_part_prefix, dim3((B + 63) / 64), dim3(64), 0, c->cur, t.hist, G, B, t.off, t.btotal);
@@ -44,7 +48,8 @@ static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGro
         hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_PART_THREADS), B * 4, c->cur, t.recs, t.nrec, t.chunk, t.bshift, B, t.off,
                            t.btotal, t.part);
     }
-    {
+    }
+    if (part != 1) {
         LaunchScope ls(c, "k_part_dedup.w1", in.n);
         if (t.cap == 2048)
             hipLaunchKernelGGL(k_part_dedup<2048>, dim3(B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 1024, c->cur, t.part, t.btotal,
@@ -62,7 +67,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
                             const int32_t* dsample, int32_t S, uint32_t* dmeta, bool force_atomic, int stage = 0) {
     // stage 0 = everything; 1 = only the first kernel of the partitioned path; 2 = what stage 1 left
     if (!in.n) return 0;
-    if (stage == 2 && t.partitioned) return collapse_part_rest(c, gi, in, out, t, dmeta);
+    if (stage == 2 && t.partitioned) return collapse_part_rest(c, gi, in, out, t, dmeta, 2);
     // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
     const bool key_path = (W == 1) && !in.nmask && S == 1;
     // slots of the open-addressing table: next power of two above 1.5 n (key path) / 2 n, computed in 64 bits --
@@ -128,7 +133,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
             hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_PART_THREADS), agg_lds, c->cur, v1, in.orig, in.base, chunk, bshift, B, CS, t.recs, t.nrec, t.hist);
         }
         t.G = G; t.chunk = chunk; t.bshift = bshift; t.B = B;
-        if (stage == 1) return 0;
+        if (stage == 1) return collapse_part_rest(c, gi, in, out, t, dmeta, 1);
         return collapse_part_rest(c, gi, in, out, t, dmeta);
     }
     if (stage == 1) return 0;
@@ -147,9 +152,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         CHECK(dalloc(c, &t.rep, tsize));
         CHECK(dalloc(c, &t.firstj, tsize));
         CHECK(dalloc(c, &t.cnt, (size_t)tsize * S));
-        HIPOK(hipMemsetAsync(t.rep, 0xFF, (size_t)tsize * 4, c->cur));
-        HIPOK(hipMemsetAsync(t.firstj, 0xFF, (size_t)tsize * 4, c->cur));
-        HIPOK(hipMemsetAsync(t.cnt, 0, (size_t)tsize * S * 4, c->cur));
+        hipLaunchKernelGGL(k_collapse_init, dim3(grid_for(c, (size_t)tsize * S)), dim3(MIRGE_BLOCK), 0, c->cur, t.rep, t.firstj, t.cnt,
+                           tsize, (uint32_t)((size_t)tsize * S));
         std::snprintf(name, sizeof(name), "k_collapse_insert%s", group_tag(gi));
         LaunchScope ls(c, name, in.n);
         // at most 2 workgroups per CU: each sees enough of the group for its LDS cell cache to merge hot reads
