@@ -189,7 +189,9 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
                 unsigned long long cur = lds_a[s];
                 if (cur == 0ull) cur = atomicCAS(&lds_a[s], 0ull, key);
                 if (cur == 0ull || cur == key) {
-                    atomicMin(&c_min[s], jr);
+                    // the slot's minimum only falls: a plain read that is already below ours proves the atomic would
+                    // change nothing (indices grow with the loop, so this skips it for every later copy of a read)
+                    if (*(volatile uint32_t*)&c_min[s] > jr) atomicMin(&c_min[s], jr);
                     atomicAdd(&c_cnt[s], 1u);
                     direct = false;
                     break;
@@ -293,7 +295,7 @@ k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket
             if (*(volatile uint32_t*)&n_distinct >= CAP - 32) break;  // table full: flagged, results discarded
             s = (s + 1) & (CAP - 1);
         }
-        atomicMin(&lds_min[s], j);
+        if (*(volatile uint32_t*)&lds_min[s] > j) atomicMin(&lds_min[s], j);
         atomicAdd(&lds_cnt[s], rec.w);  // a record stands for rec.w identical reads of one workgroup's chunk
     }
     __syncthreads();
