@@ -79,6 +79,9 @@ int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, 
  * filter (`count`, digest.py:326).  Reads come out in file order. */
 int mirge_reads_parse(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                       mirge_reads** out, int64_t* n_records);
+/* 1 when some read of the set held an IUPAC ambiguity code other than N: such a base is packed -- and later printed --
+ * as N (bowtie aligns it as N too; the reference's dictionary would have kept the letter). */
+int32_t mirge_reads_iupac_seen(const mirge_reads* reads);
 /* The same with the read modifiers the reference runs through cutadapt before it counts a read (digest.py:59-101; SURVEY.md
  * 8f row N4), applied on the device between record finding and the length filter: NextSeq quality trimming, quality
  * trimming, 3' adapter removal, N trimming, unconditional cuts -- in that order, each present when its field says so.

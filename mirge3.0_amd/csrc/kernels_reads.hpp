@@ -2,8 +2,15 @@
 #pragma once
 // ------------------------------------------------------------------------------------------
 // k_pack: ASCII -> 2-bit.  One thread per read; the read's bytes are contiguous in `ascii`.
-// flags[0] |= 1 if any N was seen, flags[1] |= 1 if a byte outside ACGTN (any case) was seen.
+// flags[0] |= 1 if any ambiguous call was seen (|= 2: an IUPAC code other than N among them), flags[1] |= 1 if a byte
+// that is no nucleotide code was seen.
 // ------------------------------------------------------------------------------------------
+// IUPAC ambiguity codes other than N (upper case): bowtie turns every one of them into N, and so does the packing --
+// the collapsed sequence then prints N where the read had the code (flagged, so that the host can say so)
+__device__ __forceinline__ bool is_iupac_code(uint8_t c) {
+    return c == 'R' || c == 'Y' || c == 'S' || c == 'W' || c == 'K' || c == 'M' || c == 'B' || c == 'D' || c == 'H' || c == 'V';
+}
+
 template <int W>
 __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ starts, const int64_t* __restrict__ ends,
                        const uint32_t* __restrict__ idx, uint32_t n, uint64_t* __restrict__ seq,
@@ -16,7 +23,7 @@ __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restr
         uint64_t w[W], nm[W];
 #pragma unroll
         for (int i = 0; i < W; i++) { w[i] = 0; nm[i] = 0; }
-        uint32_t sawN = 0, bad = 0;
+        uint32_t sawN = 0, bad = 0, iupac = 0;
         for (int p = 0; p < L; p++) {
             uint8_t c = ascii[b + p] & 0xDF;  // upper-case
             uint64_t code = 0, isn = 0;
@@ -27,7 +34,7 @@ __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restr
                 case 'T': code = 3; break;
                 case 'U': code = 3; break;
                 case 'N': isn = 1; break;
-                default: isn = 1; bad = 1; break;
+                default: isn = 1; if (is_iupac_code(c)) iupac = 1; else bad = 1; break;
             }
             sawN |= (uint32_t)isn;
 #pragma unroll
@@ -40,7 +47,7 @@ __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restr
             nmask[(size_t)i * n + j] = nm[i];
         }
         len[j] = (uint8_t)L;
-        if (sawN) atomicOr(&flags[0], 1u);
+        if (sawN) atomicOr(&flags[0], 1u | (iupac << 1));
         if (bad) atomicOr(&flags[1], 1u);
     }
 }
@@ -238,14 +245,16 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __r
         } else if (L < (int64_t)min_len) {
             c = MIRGE_CLS_DROP;
         } else {
-            uint32_t amb = 0, bad = 0;
+            uint32_t amb = 0, bad = 0, iu = 0;
             for (int p = 0; p < (int)L; p++) {
                 const uint8_t ch = text[b + p] & 0xDF;
                 const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'U';
                 amb |= !acgt;
-                bad |= !acgt && ch != 'N';
+                bad |= !acgt && ch != 'N' && !is_iupac_code(ch);
+                iu |= is_iupac_code(ch);
             }
             if (bad) atomicOr(&flags[0], 1u);
+            if (iu) atomicOr(&flags[4], 1u);
             c = (L <= 31 ? 0 : (L <= 64 ? 1 : (L <= 128 ? 2 : 3))) + (amb ? MIRGE_NCLS / 2 : 0);
             atomicAdd(&s_hist[L], 1u);
         }

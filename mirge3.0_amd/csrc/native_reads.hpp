@@ -42,6 +42,7 @@ struct mirge_reads {
     ReadGroup g[MIRGE_NGROUPS];
     int32_t len_hist[MIRGE_MAX_READ_LEN + 1];  // lengths present (host), for table preparation
     bool hist_valid = false;
+    bool iupac_seen = false;  // some read held an IUPAC code other than N: packed (and printed) as N
 };
 
 static int largest_group(const mirge_reads* R) {
@@ -77,6 +78,7 @@ extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts,
     if (total >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
     auto R = std::make_unique<mirge_reads>();
     R->ctx = c; R->n = total; R->hist_valid = true;
+    for (int p = 0; p < n_parts; p++) R->iupac_seen = R->iupac_seen || (parts[p] && parts[p]->iupac_seen);
     std::memset(R->len_hist, 0, sizeof(R->len_hist));
     for (int p = 0; p < n_parts; p++) {
         R->total_bases += parts[p]->total_bases;
@@ -129,6 +131,7 @@ extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts,
 extern "C" int64_t mirge_reads_count(const mirge_reads* r) { return r ? r->n : -1; }
 extern "C" int64_t mirge_reads_total_bases(const mirge_reads* r) { return r ? r->total_bases : -1; }
 extern "C" int32_t mirge_reads_n_samples(const mirge_reads* r) { return r ? r->n_samples : -1; }
+extern "C" int32_t mirge_reads_iupac_seen(const mirge_reads* r) { return r ? (r->iupac_seen ? 1 : 0) : -1; }
 
 template <int W>
 static int launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstart, const int64_t* dend, const uint32_t* didx,
@@ -224,8 +227,9 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         if (c->pinned[2 * gi + 1]) {
             mirge_reads_destroy(R.release());
-            return fail(-7, "a read contains a character other than A/C/G/T/U/N");
+            return fail(-7, "a read contains a character that is no nucleotide code (A/C/G/T/U/N or an IUPAC ambiguity code)");
         }
+        if (c->pinned[2 * gi] & 2u) R->iupac_seen = true;
         if (!c->pinned[2 * gi] && R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
     }
     *out = R.release();
@@ -379,7 +383,8 @@ extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nb
         if (c->pinned[3]) { rc = fail(-9, std::string("mirge_reads_parse: a record does not start with '") + (format == 1 ? "@' / its third line with '+'" : ">'") +
                                             " (truncated file, blank line, or a FASTA with wrapped sequences)"); break; }
         if (c->pinned[1]) { rc = fail(-6, "a read is " + std::to_string(c->pinned[2]) + " nt; the limit is " + std::to_string(MIRGE_MAX_READ_LEN)); break; }
-        if (c->pinned[0]) { rc = fail(-7, "a read contains a character other than A/C/G/T/U/N"); break; }
+        if (c->pinned[0]) { rc = fail(-7, "a read contains a character that is no nucleotide code (A/C/G/T/U/N or an IUPAC ambiguity code)"); break; }
+        R->iupac_seen = c->pinned[4] != 0;
         const uint32_t kept = bounds[MIRGE_NGROUPS];
         R->n = kept;
         for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {

@@ -80,6 +80,8 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         del text
         t_parse += time.perf_counter() - t1
         sampleReadCounts[name], trimmedReadCounts[name] = n_rec, len(raw)
+        if raw.iupac_seen:
+            say(f'WARNING: {name} holds IUPAC ambiguity codes other than N; they are aligned -- and printed -- as N')
         parsed.append(raw)
         say(f'Cutadapt finished for file {name} in {round(time.perf_counter() - t, 4)} second(s)')
     tm["read_files_s"], tm["parse_s"] = t_read, t_parse

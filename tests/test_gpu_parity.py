@@ -339,8 +339,18 @@ def test_edge_cases(ctx, ci_libs, ci_cascade):
     r_ok, n_rec = _ffi.DeviceReads.parse(ctx, unwrap_fasta(b">a\nACGTACGTACGT\nACGTACGT\n>b x\nACGTACGTACGTACGTAC\r\nGG\r\n"), 0, 16)
     assert n_rec == 2 and r_ok.unpack().to_list() == ["ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGG"]
     r_ok.close()
-    with pytest.raises(RuntimeError, match="character other than"):
-        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGTRYACGTACGTACGT"]))
+    with pytest.raises(RuntimeError, match="no nucleotide code"):
+        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGT5*ACGTACGTACGT"]))
+    # IUPAC ambiguity codes are what bowtie makes of them: N (flagged on the read set)
+    iu = _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGTRYACGTACGTACGT", "ACGTACGTACGTACGTAC"]))
+    assert iu.iupac_seen and iu.unpack().to_list() == ["ACGTNNACGTACGTACGT", "ACGTACGTACGTACGTAC"]
+    iu.close()
+    iu, _ = _ffi.DeviceReads.parse(ctx, b"ACGTACGTKCGTACGTAC\nACGTACGTACGTACGTAC\n", 3, 16)
+    assert iu.iupac_seen and iu.unpack().to_list()[0] == "ACGTACGTNCGTACGTAC"
+    iu.close()
+    plain = _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGTNACGTACGTACGTA"]))
+    assert not plain.iupac_seen
+    plain.close()
     # lower-case and U are accepted as their upper-case / T
     a = ci_cascade.annotate(FlatSeqs.from_list([ci_libs.libs["mirna"].seqs.get(3).lower().replace("t", "u")]))
     b = ci_cascade.annotate(FlatSeqs.from_list([ci_libs.libs["mirna"].seqs.get(3)]))
@@ -434,7 +444,7 @@ def test_device_text_parser_equals_host_parser(ctx, ci_libs, tmp_path):
     assert len(dr) == 0 and n_rec == 1 and len(dr.collapse()) == 0
     with pytest.raises(RuntimeError, match="limit is 255"):
         _ffi.DeviceReads.parse(ctx, ("A" * 256 + "\n").encode(), 3, 0)
-    with pytest.raises(RuntimeError, match="other than"):
+    with pytest.raises(RuntimeError, match="no nucleotide code"):
         _ffi.DeviceReads.parse(ctx, b"ACGTACGTACGTACGTXACGT\n", 3, 0)
 
 
