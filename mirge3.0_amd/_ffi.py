@@ -404,10 +404,10 @@ def variant_tally(ctx: Context, uniq: DeviceReads, res: CascadeResult, exact_pas
     assert freq.shape[0] == S
     ret = None if retained is None else np.ascontiguousarray(retained, dtype=np.uint8)
     assert ret is None or ret.shape[0] == n
-    tabs = np.zeros((5, max(n_fam, 1), S), dtype=np.int64)
-    cen = np.zeros((max(n_fam, 1), TALLY_POSITIONS, 4, 4, 3, S), dtype=np.int64)
-    diag = np.zeros(max(n, 1), dtype=np.int8) if per_read else None
-    state = np.zeros(max(n, 1), dtype=np.int8) if per_read else None
+    tabs = np.empty((5, max(n_fam, 1), S), dtype=np.int64)  # every cell is written by the call
+    cen = np.empty((max(n_fam, 1), TALLY_POSITIONS, 4, 4, 3, S), dtype=np.int64)
+    diag = np.empty(max(n, 1), dtype=np.int8) if per_read else None
+    state = np.empty(max(n, 1), dtype=np.int8) if per_read else None
     if n_fam == 0:
         tabs = np.zeros((5, 0, S), dtype=np.int64)
     _check(load().mirge_variant_tally(ctx._h, uniq._h, res._h, C.c_int32(exact_pass), C.c_int32(iso_pass), _p(fam_of_ref),

@@ -163,15 +163,14 @@ extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mir
                            (const uint32_t*)rg.orig, g.pass, g.ref, rg.counts, S, exact_pass, iso_pass, dfam, dtb, dtl,
                            (const uint8_t*)dret, dfreq, o);
     }
-    std::vector<unsigned long long> h(n_words);
-    HIPOK(hipMemcpyAsync(h.data(), d, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+    // straight into the caller's arrays (the census alone is 12 KiB per family and sample: no staging copy of it)
+    for (int t = 0; t < 5 && n_fam; t++)  // the device block is sized for max(n_fam, 1)
+        HIPOK(hipMemcpyAsync(fam_tables + (size_t)t * n_fam * S, d + (size_t)t * n_fs, (size_t)n_fam * S * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_fam) HIPOK(hipMemcpyAsync(census, d + 5 * n_fs, (size_t)n_fam * S * MIRGE_TALLY_MAXPOS * 16 * 3 * 8, hipMemcpyDeviceToHost, c->stream));
     if (diag_out && U->n) HIPOK(hipMemcpyAsync(diag_out, ddiag, (size_t)U->n, hipMemcpyDeviceToHost, c->stream));
     if (state_out && U->n) HIPOK(hipMemcpyAsync(state_out, dstate, (size_t)U->n, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
     c->drain();
-    for (int t = 0; t < 5; t++)  // the device block is sized for max(n_fam, 1)
-        std::memcpy(fam_tables + (size_t)t * n_fam * S, h.data() + (size_t)t * n_fs, (size_t)n_fam * S * 8);
-    std::memcpy(census, h.data() + 5 * n_fs, (size_t)n_fam * S * MIRGE_TALLY_MAXPOS * 16 * 3 * 8);
     c->release(d); c->release(dtb); c->release(dtl); c->release(dfam); c->release(dret); c->release(dfreq);
     c->release(ddiag); c->release(dstate);
     return 0;
