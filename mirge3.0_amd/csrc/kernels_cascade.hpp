@@ -92,7 +92,7 @@ __device__ __forceinline__ int window_mm_regs(const TextWin<W>& tw, uint64_t g, 
 template <int W, int N>
 __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
                                                const MirgeRead<W>& r, gptr_u32 pos, const uint32_t (&c)[N],
-                                               uint32_t hi, int a) {
+                                               uint32_t hi, int a, uint64_t known = MIRGE_NO_HIT) {
     uint32_t pz[N];
     bool ok[N];
 #pragma unroll
@@ -104,7 +104,9 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
     uint64_t g[N];
 #pragma unroll
     for (int u = 0; u < N; u++) {
-        ok[u] = ok[u] && pz[u] >= (uint32_t)a;
+        // the window the lane already holds as its best is found again by every probe whose blocks miss its mismatches:
+        // its text is not fetched a second time (the low word of NO_HIT is no position)
+        ok[u] = ok[u] && pz[u] >= (uint32_t)a && (pz[u] - (uint32_t)a) != (uint32_t)known;
         g[u] = ok[u] ? (uint64_t)pz[u] - (uint64_t)a : 0ull;
         load_window<W>((gptr_u64)lib.T, g[u], ok[u] ? r.len : 0, tw[u]);
     }
@@ -178,7 +180,7 @@ __device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const Mirg
             uint32_t c[MIRGE_LIGHT];
 #pragma unroll
             for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
-            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a);
+            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a, best);
             if (cand < best) best = cand;
         }
     }
