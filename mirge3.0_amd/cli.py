@@ -154,16 +154,12 @@ def main(argv=None):
         dist.init_process_group("gloo")  # tables of a few kB: host-side gather, no device collective
         casc = get_cascade(args, ref_db, args.device)
 
-        def process(i):
-            d, src, trimmed, uniq = baking(args, [files[i]], [base_names[i]], str(workDir), ctx=casc.ctx)
-            d = bwt_align(args, d, str(workDir), ref_db)
-            m = d[d.annotFlag.eq(1)]
-            m.to_csv(workDir / f"mapped.{base_names[i]}.csv")
-            d[d.annotFlag.eq(0)].to_csv(workDir / f"unmapped.{base_names[i]}.csv")
-            tabs = summarize(args, None, ref_db, [base_names[i]], m, src, trimmed, uniq)
-            return multigpu.SampleTables(i, base_names[i], src[base_names[i]], trimmed[base_names[i]],
-                                         uniq[base_names[i]], tabs["raw"][0][:, 0], tabs["raw"][1][:, 0],
-                                         tabs["raw"][2][:, 0])
+        if not fastpath.eligible(args) or args.AtoI or args.gff_out or args.isoform_entropy:
+            sys.exit("the sharded run (one sample per GPU) covers the count tables and the per-sample mapped/unmapped files; "
+                     "-umi / -tcf / -ie / -gff / -ai run in one process")
+
+        def process(i):  # device-resident per sample (fastpath.run_sample_tables); only a few kB per sample leave the rank
+            return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc)
 
         tables = multigpu.run_sharded(len(files), rank, world, process, dist)
         if rank == 0:

@@ -51,6 +51,34 @@ def row_order(seqs: FlatSeqs, first: np.ndarray, n_samples: int) -> np.ndarray:
     return np.argsort(mat.view(f"S{width}").reshape(-1), kind="stable")
 
 
+def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None):
+    """One sample on this process's GPU, for the sharded CLI (one sample per rank, multigpu.py): device-resident parse ->
+    collapse + cascade -> count join; writes ``mapped.<name>.csv`` / ``unmapped.<name>.csv`` and returns the sample's
+    ``SampleTables`` (a few kB: what rank 0 gathers)."""
+    from . import multigpu
+    from .cascade import EXACT_PASS, ISO_PASS
+    workDir = Path(workDir)
+    casc = casc or get_cascade(args, ref_db, getattr(args, "device", 0))
+    ctx = casc.ctx
+    raw, n_rec = _ffi.DeviceReads.parse(ctx, read_text(str(file)), 0, int(getattr(args, "minimum_length", 16)), trim_from_args(args))
+    n_trimmed = len(raw)
+    uniq, res = casc.collapse_and_run(raw)
+    raw.close()
+    cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS, len(casc.libs["mirna"]))
+    counts, first = uniq.counts()
+    seqs = uniq.unpack()
+    ps, ref, _, _ = res.fetch()
+    n_cols = 10 if args.spikeIn else 9
+    header = ",".join(["Sequence", "annotFlag"] + PASS_COLUMNS[:n_cols] + [name]) + "\n"
+    names_by_pass = [FlatSeqs.from_list(casc.libs[PASSES[p][1]].names) if PASSES[p][1] in casc.libs else None
+                     for p in range(casc.n_pass)]
+    _ffi.annotation_csv(workDir / f"mapped.{name}.csv", workDir / f"unmapped.{name}.csv", header, seqs, ps, ref, counts,
+                        row_order(seqs, first, 1), list(range(casc.n_pass)), n_cols, names_by_pass)
+    out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
+    res.close(); uniq.close()
+    return out
+
+
 def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, timings: Dict[str, float] = None):
     """FASTQ files -> every output file of the hot path.  Returns the dict of ``finish_tables``."""
     t0 = time.perf_counter()
