@@ -166,3 +166,40 @@ def test_isomir_entropy_tables_equal_the_reference(name, tmp_path):
     isomir_entropy_tables(mapped, case.samples, filtered, tmp_path)
     for f in ("isomirs.csv", "isomirs.samples.csv"):
         assert (tmp_path / f).read_text() == case.text(f), f
+
+
+def test_gff_name_resolution_tables(tmp_path):
+    """What create_gff looks up per miRNA NAME (summary.py:96-186), for both annotation layouts: miRBase (primary
+    transcript lines name the precursor by their last ';' field, mature lines by their third) and MirGeneDB (pre_miRNA
+    lines / ID= fields); '.SNP' suffixes and -3p/-5p fallbacks; the last precursor's empty sequence."""
+    from mirge3_amd import gff
+    from mirge3_amd.seqio import FlatSeqs, Library
+    mb = tmp_path / "mb.gff3"
+    mb.write_text("##gff-version 3\n"
+                  "chr1\t.\tmiRNA_primary_transcript\t100\t180\t.\t+\t.\tID=MI1;Alias=MI1;Name=hsa-mir-1\n"
+                  "chr1\t.\tmiRNA\t110\t131\t.\t+\t.\tID=MIMAT1;Alias=MIMAT1;Name=hsa-miR-1-5p;Derives_from=MI1\n"
+                  "chr1\t.\tmiRNA\t150\t171\t.\t+\t.\tID=MIMAT2;Alias=MIMAT2;Name=hsa-miR-1;Derives_from=MI1\n"
+                  "chr2\t.\tmiRNA_primary_transcript\t500\t580\t.\t-\t.\tID=MI2;Alias=MI2;Name=hsa-mir-2\n"
+                  "chr2\t.\tmiRNA\t510\t531\t.\t-\t.\tID=MIMAT3;Alias=MIMAT3;Name=hsa-miR-2-3p;Derives_from=MI2\n"
+                  "chr2\t.\tmiRNA\t510\t531\t.\t-\t.\tID=MIMAT9;Alias=MIMAT9;Name=hsa-miR-1-5p;Derives_from=MI2\n")
+    pre_of = gff.read_annotation(mb, "miRBase")
+    assert pre_of == {"hsa-miR-1-5p": "hsa-mir-1", "hsa-miR-1": "hsa-mir-1", "hsa-miR-2-3p": "hsa-mir-2"}
+    mg = tmp_path / "mg.gff3"
+    mg.write_text("chr1\t.\tpre_miRNA\t100\t160\t.\t+\t.\tID=Hsa-Mir-1_pre;Alias=MI1\n"
+                  "chr1\t.\tmiRNA\t110\t131\t.\t+\t.\tID=Hsa-Mir-1_5p;Alias=MIMAT1\n"
+                  "chr1\t.\tmiRNA\t140\t160\t.\t+\t.\tID=Hsa-Mir-1_3p*;Alias=MIMAT2\n")
+    assert gff.read_annotation(mg, "MirGeneDB") == {"Hsa-Mir-1_5p": "Hsa-Mir-1_pre", "Hsa-Mir-1_3p*": "Hsa-Mir-1_pre"}
+    hp = Library(["hsa-mir-1", "hsa-mir-2"], FlatSeqs.from_list(["GGGGACGTACGTACGTACGTACGGGG", "CCCCTTTTGGGGAAAACCCC"]),
+                 ["hsa-mir-1 extra words", "hsa-mir-2"])
+    pre = gff.precursor_dict(hp)
+    assert pre == {"hsa-mir-1": "GGGGACGTACGTACGTACGTACGGGG", "hsa-mir-2": ""}  # the last one is emptied (summary.py:819-826)
+    mirDict = {"hsa-miR-1-5p": "ACGTACGTACGTACGTACG", "hsa-miR-1": "TTTTGGGG", "hsa-miR-2-3p": "TTTTGGGGAAAA"}
+    names = ["hsa-miR-1-5p", "hsa-miR-1-5p.SNP3", "hsa-miR-1-3p", "hsa-miR-2-3p", "hsa-miR-7-5p"]
+    t = gff.resolve_names(names, mirDict, pre_of, pre)
+    assert t["master_of_ref"].tolist() == [0, 0, 1, 2, -1]
+    assert [t["printed"][i] for i in t["name_of_ref"][:4]] == ["hsa-miR-1-5p", "hsa-miR-1-5p", "hsa-miR-1", "hsa-miR-2-3p"]
+    assert t["start0"].tolist() == [5, 0, 1]  # found at 4 (+1); not in its precursor -> find() = -1 -> 0; empty precursor -> 1
+    assert [t["parents"][i] for i in t["pre_of_master"]] == ["hsa-mir-1", "hsa-mir-1", "hsa-mir-2"]
+    fa = tmp_path / "m.fa"
+    fa.write_text(">a\nACGT\n>b desc\nGG\nTT\n")
+    assert gff.read_mature_fasta(fa) == {"a": "ACGT", "b desc": "TT"}
