@@ -1210,3 +1210,42 @@ def test_cli_with_adapter_trimming_end_to_end(tmp_path):
     a = (tmp_path / "trimmed" / "annotation.report.csv").read_text().splitlines()[1].split(",")
     b = (tmp_path / "untrimmed" / "annotation.report.csv").read_text().splitlines()[1].split(",")
     assert a[1:] == b[1:] and int(a[2]) > 1000
+
+
+def test_cli_route_edge_inputs(tmp_path):
+    """The device-resident CLI route on degenerate inputs: an empty file beside a normal one, a file whose reads are
+    all below --minimum-length, and a sample without a single miRNA read under -gff / -ai / -ie -- files are written,
+    nothing crashes, counts are what the reads say."""
+    from mirge3_amd import fastpath
+    case = GoldenCase("case4_gff_a2i")
+    work = tmp_path / "out"
+    work.mkdir()
+    good = tmp_path / "A.fastq"
+    with open(good, "w") as fh:
+        for seq, row in list(zip(case.seqs, case.counts))[:300]:
+            fh.write(f"@r\n{seq}\n+\n{'I' * len(seq)}\n" * min(int(row[1]) + 1, 3))
+    empty = tmp_path / "B.fastq"
+    empty.write_text("")
+    short = tmp_path / "C.fastq"
+    short.write_text("@r\nACGTACGT\n+\nIIIIIIII\n" * 5)
+    nomir = tmp_path / "D.fastq"
+    nomir.write_text("".join(f"@r\n{s}\n+\n{'I' * len(s)}\n" for s in ["GATTACAGATTACAGATTACAGATT", "CCCCCCCCCCCCCCCCCCCCCC"] * 3))
+    base = dict(libraries_path=case.libdir, organism_name=ORG, spikeIn=False, quiet=True, minimum_length=16, crThreshold="0.1",
+                device=0, threads=1, bowtieVersion="True", phred64=False,
+                bowtie_path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fake_bowtie"))
+    out = fastpath.run(SimpleNamespace(isoform_entropy=False, **base), [str(good), str(empty), str(short)], ["A", "B", "C"], str(work), "miRBase")
+    rep = list(csv.DictReader(open(work / "annotation.report.csv")))
+    assert [r["Sample name(s)"] for r in rep] == ["A", "B", "C"]
+    assert (int(rep[1]["Total Input Reads"]), int(rep[1]["Trimmed Reads (all)"])) == (0, 0)
+    assert (int(rep[2]["Total Input Reads"]), int(rep[2]["Trimmed Reads (all)"])) == (5, 0)
+    assert int(rep[0]["Trimmed Reads (all)"]) > 300
+    mapped = (work / "mapped.csv").read_text().splitlines()
+    assert mapped[0].endswith(",A,B,C") and all(ln.endswith(",0,0") for ln in mapped[1:])
+    for h in ("uniq", "res"):
+        out["device"][h].close()
+    work2 = tmp_path / "out2"
+    work2.mkdir()
+    out = fastpath.run(SimpleNamespace(isoform_entropy=True, gff_out=True, AtoI=True, **base), [str(nomir)], ["D"], str(work2), "miRBase")
+    assert (work2 / "sample_miRge3.gff").read_text().count("\n") == 4  # the four header lines
+    assert (work2 / "a2IEditing.report.csv").read_text().count("\n") == 1 and (work2 / "isomirs.csv").exists()
+    assert int(list(csv.DictReader(open(work2 / "annotation.report.csv")))[0]["All miRNA Reads"]) == 0
