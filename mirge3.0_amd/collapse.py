@@ -66,11 +66,16 @@ def read_text(path: str) -> bytes:
     """The file's bytes (gunzipped if .gz) for the device-side parser (``mirge_reads_parse``).  A FASTA whose sequences
     are wrapped over several lines (dnaio reads those) is unwrapped here: the device parser finds records by line
     number and refuses anything else."""
-    opener = gzip.open if str(path).endswith(".gz") else open
-    with opener(path, "rb") as fh:
-        data = fh.read()
-    if data[:1] == b">":
-        data = unwrap_fasta(data)
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "rb") as fh:
+            data = fh.read()
+    else:
+        import os
+        if os.path.getsize(path) == 0:
+            return b""
+        data = np.memmap(path, dtype=np.uint8, mode="r")  # the pages go from the page cache to the GPU: no read() copy
+    if bytes(data[:1]) == b">":
+        data = unwrap_fasta(bytes(data))
     return data
 
 

@@ -82,14 +82,30 @@ extern "C" int mirge_annotation_csv(const char* mapped_path, const char* unmappe
     for (int which = 0; which < 2; which++) {
         const char* path = which == 0 ? mapped_path : unmapped_path;
         if (!path) continue;
-        FILE* f = std::fopen(path, "wb");
-        if (!f) return fail(-8, std::string("cannot write ") + path);
-        bool ok = std::fputs(header, f) >= 0;
-        for (int t = 0; t < T && ok; t++) {
+        // every thread writes its own chunk at its own offset (pwrite): a 200 MB table is bound by the copy into the
+        // page cache, which one thread does at a fraction of the machine's memory bandwidth
+        const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return fail(-8, std::string("cannot write ") + path);
+        const size_t hl = std::strlen(header);
+        std::vector<size_t> at((size_t)T + 1, hl);
+        for (int t = 0; t < T; t++) at[(size_t)t + 1] = at[(size_t)t] + (which == 0 ? bufm[(size_t)t] : bufu[(size_t)t]).size();
+        std::vector<int> werr((size_t)T, 0);
+        auto put = [&](int t) {
             const std::string& b = which == 0 ? bufm[(size_t)t] : bufu[(size_t)t];
-            ok = b.empty() || std::fwrite(b.data(), 1, b.size(), f) == b.size();
-        }
-        ok = (std::fclose(f) == 0) && ok;
+            size_t done = 0;
+            while (done < b.size()) {
+                const ssize_t w = ::pwrite(fd, b.data() + done, b.size() - done, (off_t)(at[(size_t)t] + done));
+                if (w <= 0) { werr[(size_t)t] = 1; return; }
+                done += (size_t)w;
+            }
+        };
+        bool ok = ::pwrite(fd, header, hl, 0) == (ssize_t)hl;
+        std::vector<std::thread> wt;
+        for (int t = 1; t < T; t++) wt.emplace_back(put, t);
+        put(0);
+        for (auto& x : wt) x.join();
+        for (int t = 0; t < T; t++) ok = ok && !werr[(size_t)t];
+        ok = (::close(fd) == 0) && ok;
         if (!ok) return fail(-8, std::string("write error on ") + path);
     }
     return 0;

@@ -40,9 +40,9 @@ def row_order(seqs: FlatSeqs, first: np.ndarray, n_samples: int) -> np.ndarray:
         # `first` holds distinct raw-read indices: ranking them is one scatter and one compress, not a sort
         if len(first) == 0:
             return np.zeros(0, dtype=np.int64)
-        slot = np.full(int(first.max()) + 1, -1, dtype=np.int64)
-        slot[first] = np.arange(len(first), dtype=np.int64)
-        return slot[slot >= 0]
+        slot = np.full(int(first.max()) + 1, -1, dtype=np.int32)
+        slot[first] = np.arange(len(first), dtype=np.int32)
+        return slot[slot >= 0].astype(np.int64)
     ln = seqs.lengths
     width = int(ln.max()) if len(seqs) else 1
     mat = np.zeros((len(seqs), width), dtype=np.uint8)  # NUL-padded: a prefix sorts before its extensions, as str does
