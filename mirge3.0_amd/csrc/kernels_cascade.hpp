@@ -54,11 +54,45 @@ __device__ __forceinline__ uint64_t class_key(const MergeInfo& mi, uint64_t g) {
 template <int W>
 struct TextWin { uint64_t w[W + 1]; };
 
+// Two adjacent 8-byte words fetched as ONE 16-byte access (4-byte alignment is all a global load needs): the passes are
+// bound by the number of vector-memory instructions and cache accesses a CU's texture addresser can take (TA busy 56-69 %
+// of the kernel time in every k_pass, profiles/README.md round 2), so paired loads are merged wherever two words sit
+// side by side -- the window's text, its invalid bits, a bucket's two CSR bounds.
+typedef uint32_t QuadU32 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t DuoU32 __attribute__((ext_vector_type(2), aligned(4)));
+typedef const __attribute__((address_space(1))) QuadU32* gptr_quad32;
+typedef const __attribute__((address_space(1))) DuoU32* gptr_duo32;
+struct PairU64 { uint64_t a, b; };
+struct PairU32 { uint32_t a, b; };
+__device__ __forceinline__ PairU64 load_pair64(gptr_u64 p) {
+    const QuadU32 v = *(gptr_quad32)p;
+    return PairU64{(uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32)};
+}
+__device__ __forceinline__ PairU32 load_pair32(gptr_u32 p) {
+    const DuoU32 v = *(gptr_duo32)p;
+    return PairU32{v.x, v.y};
+}
+
 template <int W>
 __device__ __forceinline__ void load_window(gptr_u64 T, uint64_t g, int L, TextWin<W>& tw) {
     const uint64_t q = g >> 5;
+    if (W == 1) {
+        const PairU64 p = load_pair64(T + q);
+        tw.w[0] = p.a; tw.w[1] = p.b;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i <= W; i++) tw.w[i] = (i == 0 || 32 * (i - 1) < L) ? T[q + i] : 0ull;
+}
+
+// mirge_window_invalid for windows of up to 64 bases (W == 1: <= 31): the two bitmap words in one access
+__device__ __forceinline__ bool window_invalid_pair(gptr_u64 inv, uint64_t g, int L) {
+    const PairU64 p = load_pair64(inv + (g >> 6));
+    const int s = (int)(g & 63);
+    uint64_t lo = p.a >> s;
+    if (s) lo |= p.b << (64 - s);
+    if (L < 64) lo &= (1ull << L) - 1ull;
+    return lo != 0ull;
 }
 
 // same arithmetic as mirge_window_mm, on words that are already in registers
@@ -116,7 +150,7 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
         if (!ok[u]) continue;
         const int m = window_mm_regs<W>(tw[u], g[u], r, pol);
         if (m < 0) continue;
-        if (mirge_window_invalid(lib.inv, g[u], r.len)) continue;
+        if (W == 1 ? window_invalid_pair((gptr_u64)lib.inv, g[u], r.len) : mirge_window_invalid(lib.inv, g[u], r.len)) continue;
         const uint64_t cand = class_key(mi, g[u]) | ((uint64_t)m << 32) | g[u];
         if (cand < best) best = cand;
     }
@@ -166,24 +200,12 @@ __device__ __forceinline__ bool probe_setup(const MirgeLibView& lib, const PlanS
     return true;
 }
 
-// the candidate list [lo, hi) of one probe, verified: short lists by their own lane, long ones by the whole wave
+// long candidate lists (repeats, poly-A), one at a time by the whole wave: the owner's read is broadcast, the 64 lanes
+// stride through the bucket (coalesced pos[] loads), the few lanes that found a valid window are read back
 template <int W>
-__device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const MirgeRead<W>& r,
-                                             gptr_u32 pos, uint32_t lo, uint32_t hi, int a, uint64_t& best) {
+__device__ __forceinline__ void verify_heavy(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const MirgeRead<W>& r,
+                                             gptr_u32 pos, uint32_t lo, uint32_t hi, int a, bool heavy, uint64_t& best) {
     const int lane = threadIdx.x & 63;
-    // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
-    // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
-    // per list and many such lanes per probe the lane-serial batches are several times cheaper)
-    const bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
-    if (!heavy) {
-        for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
-            uint32_t c[MIRGE_LIGHT];
-#pragma unroll
-            for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
-            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a, best);
-            if (cand < best) best = cand;
-        }
-    }
     unsigned long long hb = __ballot(heavy);
     while (hb) {
         const int src = __ffsll(hb) - 1;
@@ -221,6 +243,26 @@ __device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const Mirg
     }
 }
 
+// the candidate list [lo, hi) of one probe, verified: short lists by their own lane, long ones by the whole wave
+template <int W>
+__device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const MirgeRead<W>& r,
+                                             gptr_u32 pos, uint32_t lo, uint32_t hi, int a, uint64_t& best) {
+    // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
+    // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
+    // per list and many such lanes per probe the lane-serial batches are several times cheaper)
+    const bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
+    if (!heavy) {
+        for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
+            uint32_t c[MIRGE_LIGHT];
+#pragma unroll
+            for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
+            const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a, best);
+            if (cand < best) best = cand;
+        }
+    }
+    verify_heavy<W>(lib, pol, mi, r, pos, lo, hi, a, heavy, best);
+}
+
 template <int W, bool LDS>
 __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
                                              const PlanSrc<LDS>& ps, const MirgeRead<W>& r, bool active, uint64_t& best) {
@@ -245,10 +287,10 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
                 hi = lo + cnt;
                 pos = cnt == 1 ? nullptr : (gptr_u32)tb.pos;  // one window: `lo` is its position
             } else if ((bits[key >> 5] >> (key & 31)) & 1u) {  // small table: L2-resident "bucket is non-empty" bit, then CSR bounds
-                gptr_u32 bucket = (gptr_u32)tb.bucket;
+                const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key);
                 pos = (gptr_u32)tb.pos;
-                lo = bucket[key];
-                hi = bucket[key + 1];
+                lo = bd.a;
+                hi = bd.b;
             }
             a = pr.a1;
         }
