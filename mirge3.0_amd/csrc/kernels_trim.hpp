@@ -29,26 +29,35 @@ struct TrimOpts {
 };
 
 // Aligner.locate for a regular 3' adapter on read[0, n): returns the read position where the adapter starts, or n.
-// One DP column lives in registers: entry = cost << 16 | matches << 8 | origin, MAXM + 1 of them, the row loop fully
-// unrolled (MAXM = 32 covers the adapters in use -- TruSeq small RNA is 29 nt; 64 is the general form).
-template <int MAXM>
+// One DP column lives in registers, one 32-bit entry per adapter row:
+//     cost << 24 | choice << 22 | matches << 15 | origin          (cost, matches <= 64; origin <= 32767)
+// `choice` is 0 in a stored entry; a mismatching cell takes min3(diagonal, insertion | 1 << 22, deletion | 2 << 22), which is
+// the lowest cost with cutadapt's preference diagonal > insertion > deletion on ties in ONE v_min3_u32, then clears the
+// choice bits and adds one to the cost.  The row loop is fully unrolled (MAXM = 32 covers the adapters in use -- TruSeq
+// small RNA is 29 nt; 64 is the general form, a separate kernel so that the common one keeps its registers).
+#define MIRGE_TRIM_COST_SHIFT 24
+#define MIRGE_TRIM_MATCH_ONE (1u << 15)
+#define MIRGE_TRIM_CHOICE_MASK (3u << 22)
+// EXACT: the adapter has exactly MAXM bases and no N -- no per-row predicate is left in the unrolled loop (a kernel per
+// adapter length, 1-64).  Otherwise MAXM is a capacity (64) and rows beyond o.alen / wildcard rows are tested at run time.
+template <int MAXM, bool EXACT>
 __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_t* __restrict__ read, int n) {
-    const int m = o.alen;
+    const int m = EXACT ? MAXM : o.alen;
     uint32_t e[MAXM + 1];
     uint8_t nw[MAXM + 1];
     nw[0] = 0;
 #pragma unroll
     for (int i = 0; i <= MAXM; i++) {
-        e[i] = (uint32_t)i << 16;
-        if (i) nw[i] = (uint8_t)(nw[i - 1] + (i <= m ? o.wild[i - 1] : 0));
+        e[i] = (uint32_t)i << MIRGE_TRIM_COST_SHIFT;
+        if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o.wild[i - 1] : 0));
     }
     int b_mat = -1, b_cost = 0, b_org = 0;
     bool found = false, exact = false;
     auto consider = [&](uint32_t ent, int i) {
-        const int cost = (int)(ent >> 16), mat = (int)((ent >> 8) & 0xFF);
+        const int cost = (int)(ent >> MIRGE_TRIM_COST_SHIFT), mat = (int)((ent >> 15) & 0x7F);
         if (i >= o.min_overlap && (double)cost <= (double)(i - nw[i]) * o.rate &&
             (!found || mat > b_mat || (mat == b_mat && cost < b_cost))) {
-            found = true; b_mat = mat; b_cost = cost; b_org = (int)(ent & 0xFF);
+            found = true; b_mat = mat; b_cost = cost; b_org = (int)(ent & 0x7FFF);
         }
     };
     for (int j = 1; j <= n && !exact; j++) {
@@ -58,18 +67,15 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
         uint32_t last = e[0];
 #pragma unroll
         for (int i = 1; i <= MAXM; i++) {
-            if (i <= m) {
+            if (EXACT || i <= m) {
                 const uint32_t left = e[i];  // previous column, same row
-                uint32_t v;
-                if (o.wild[i - 1] || o.adapter[i - 1] == ch) v = diag + 0x100u;  // a match: cost and origin of the diagonal
-                else {
-                    const uint32_t cd = diag >> 16, cdel = left >> 16, cins = e[i - 1] >> 16;
-                    const uint32_t src = (cd <= cdel && cd <= cins) ? diag : (cins <= cdel ? e[i - 1] : left);
-                    v = src + 0x10000u;
-                }
+                const uint32_t best3 = min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22));
+                const uint32_t miss = (best3 & ~MIRGE_TRIM_CHOICE_MASK) + (1u << MIRGE_TRIM_COST_SHIFT);
+                const bool hit = EXACT ? o.adapter[i - 1] == ch : (o.wild[i - 1] || o.adapter[i - 1] == ch);
+                const uint32_t v = hit ? diag + MIRGE_TRIM_MATCH_ONE : miss;
                 diag = left;
                 e[i] = v;
-                if (i == m) last = v;
+                if (EXACT ? i == MAXM : i == m) last = v;
             }
         }
         consider(last, m);
@@ -78,13 +84,14 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
     if (!exact) {  // the adapter may run off the read's end: every prefix of it, in the last column
 #pragma unroll
         for (int i = 0; i <= MAXM; i++)
-            if (i <= m) consider(e[i], i);
+            if (EXACT || i <= m) consider(e[i], i);
     }
     return found ? b_org : n;
 }
 
 // lstart/lend: the sequence line of every record (after '\r' stripping here); qstart: its quality line (FASTQ) or null.
 // vstart/vend[r * stages_out + s]: the read after modifier s (stages_out == n_mods) or after the last one.
+template <int MAXM, bool EXACT>
 __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, const int64_t* __restrict__ lend,
                        const int64_t* __restrict__ qstart, uint32_t n_seq, TrimOpts o, int64_t* __restrict__ vstart,
                        int64_t* __restrict__ vend) {
@@ -130,7 +137,7 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
             emit();
         }
         if (o.alen > 0) {
-            a1 = a0 + (o.alen <= 32 ? adapter_cut_point<32>(o, s + a0, a1 - a0) : adapter_cut_point<MIRGE_TRIM_MAX_ADAPTER>(o, s + a0, a1 - a0));
+            a1 = a0 + adapter_cut_point<MAXM, EXACT>(o, s + a0, a1 - a0);
             emit();
         }
         if (o.trim_n) {

@@ -265,6 +265,30 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
     return 0;
 }
 
+// k_trim<M, true>: one kernel per adapter length without N (the unrolled DP rows carry no run-time test);
+// k_trim<64, false>: any adapter of up to 64 bases, N included
+template <int M>
+static int launch_trim_exact(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, const int64_t* lstart, const int64_t* lend,
+                             const int64_t* qstart, uint32_t n_raw, int64_t* dstart, int64_t* dend) {
+    if constexpr (M > MIRGE_TRIM_MAX_ADAPTER) {
+        return fail(-1, "mirge_reads_parse_trim: adapter length");
+    } else {
+        if (o.alen == M) {
+            hipLaunchKernelGGL((k_trim<M, true>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+            return 0;
+        }
+        return launch_trim_exact<M + 1>(c, o, dtext, lstart, lend, qstart, n_raw, dstart, dend);
+    }
+}
+static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, const int64_t* lstart, const int64_t* lend,
+                       const int64_t* qstart, uint32_t n_raw, int64_t* dstart, int64_t* dend) {
+    bool wild = false;
+    for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
+    if (o.alen >= 1 && !wild) return launch_trim_exact<1>(c, o, dtext, lstart, lend, qstart, n_raw, dstart, dend);
+    hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+    return 0;
+}
+
 extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                                       const mirge_trim* trim, mirge_reads** out, int64_t* n_records);
 extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
@@ -362,7 +386,8 @@ extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nb
                            trimming ? lstart : dstart, trimming ? lend : dend, (uint64_t)n_raw, (int)format, dmeta, qstart);
         if (trimming) {
             LaunchScope ls(c, "k_trim", n_raw);
-            hipLaunchKernelGGL(k_trim, dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, topt, dstart, dend);
+            rc = launch_trim(c, topt, dtext, lstart, lend, qstart, n_raw, dstart, dend);
+            if (rc) break;
         }
         hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dtext, dstart, dend, n_seq, min_len, dcls, blk,
                            keep, nblk, dmeta + 8, dmeta);

@@ -1180,6 +1180,54 @@ def test_trimming_equals_the_restated_cutadapt_chain(ctx, opts, per_modifier):
         uniq.close(); raw.close()
 
 
+def test_trimming_300_cycle_lines_and_every_adapter_length(ctx):
+    """Lines longer than 255 characters (the origin column of the DP entry is 15 bits wide, the packed read still <= 255 nt
+    after trimming) and one adapter of every length 1-64 (k_trim<M, true> is a kernel per length; with an N the general
+    k_trim<64, false>) against the oracle's full-matrix restatement."""
+    rng = np.random.default_rng(300)
+    full = "TGGAATTCTCGGGTGCCAAGGAACTCCAGTCACACGTCTGAACTCCAGTCACGATCGGAAGAGCAC"[:64]
+    def collapsed(recs, trim):
+        text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+        raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 10, trim)
+        assert n_rec == len(recs)
+        uniq = raw.collapse()
+        cnt, first = uniq.counts()
+        seqs = uniq.unpack().to_list()
+        order = np.argsort(first, kind="stable")
+        got = [(seqs[i], int(cnt[i, 0])) for i in order]
+        uniq.close(); raw.close()
+        return got
+    # 300-cycle lines: insert + adapter + read-through (a chance match of the adapter's first bases inside the tail is
+    # a legitimate earlier/later candidate for both sides), and lines without the adapter at all
+    ad = full[:29]
+    recs = []
+    for i in range(1500):
+        L = int(rng.choice([18, 22, 30, 120, 250, 254]))
+        ins = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=L))
+        tail = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=300))
+        seq = (ins + ad + tail)[:300] if i % 7 else ins
+        recs.append((seq, "I" * len(seq)))
+    opts = dict(adapter=ad, q_back=10)
+    want = oracle.trimmed_counts(recs, opts, 10, False)
+    got = collapsed(recs, _ffi.MirgeTrim.make(adapter=ad, quality_back=10, count_per_modifier=False))
+    assert got == list(want.items()) and len(got) > 500
+    for m in list(range(1, 65)) + ["N"]:
+        a = full[:m] if m != "N" else full[:12] + "NN" + full[14:40]
+        recs = []
+        for i in range(300):
+            ins = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(15, 36))))
+            x = list(a)
+            if i % 3 == 1 and len(x) > 4:
+                x[int(rng.integers(0, len(x)))] = "ACGT"[int(rng.integers(0, 4))]
+            if i % 5 == 2 and len(x) > 6:
+                del x[int(rng.integers(1, len(x) - 1))]
+            seq = (ins + "".join(x) + "ACGTTGCA")[:int(rng.integers(40, 110))]
+            recs.append((seq, "I" * len(seq)))
+        want = oracle.trimmed_counts(recs, dict(adapter=a, q_back=10), 10, False)
+        got = collapsed(recs, _ffi.MirgeTrim.make(adapter=a, quality_back=10, count_per_modifier=False))
+        assert got == list(want.items()), m
+
+
 def test_cli_with_adapter_trimming_end_to_end(tmp_path):
     """`-a illumina` end to end: golden case 1's reads with the adapter appended and cut at 50 nt come out as the
     reference's tables when the fully trimmed read is counted once (--trim-count once)."""
