@@ -25,13 +25,13 @@ template <int W>
 __global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, uint32_t* __restrict__ firstj,
                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of,
                                   uint32_t mask, const int32_t* __restrict__ sample_ids,
-                                  const uint32_t* __restrict__ orig, uint32_t base, int32_t S) {
+                                  const uint32_t* __restrict__ orig, uint32_t base, int32_t S, uint32_t j_lo, uint32_t j_hi) {
     __shared__ unsigned long long c_key[MIRGE_CELL_CACHE];
     __shared__ uint32_t c_min[MIRGE_CELL_CACHE];
     __shared__ uint32_t c_cnt[MIRGE_CELL_CACHE];
     for (uint32_t i = threadIdx.x; i < MIRGE_CELL_CACHE; i += blockDim.x) { c_key[i] = 0ull; c_min[i] = 0xFFFFFFFFu; c_cnt[i] = 0; }
     __syncthreads();
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g.n; j += gridDim.x * blockDim.x) {
+    for (uint32_t j = j_lo + blockIdx.x * blockDim.x + threadIdx.x; j < j_hi; j += gridDim.x * blockDim.x) {
         MirgeRead<W> r;
         load_read<W>(g, j, r);
         uint64_t h = mirge_mix64(r.w[0] ^ ((uint64_t)r.len << 56));
@@ -172,9 +172,16 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
     const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, g.n);
     uint4* out = recs + (size_t)blockIdx.x * chunk;
     const int lane = threadIdx.x & 63;
+    // keys this wave has put into the cache; the waves insert at the same rate, so x waves = the cache's fill.  Once it is
+    // three quarters full a read looks at its home slot only: the hot keys, which the cache is for, arrived early and sit
+    // there, and the other ~95 % of a chunk's reads no longer pay four failing LDS probes each (the kernel is bound by
+    // LDS instructions: 17 per 64 reads before, profiles/r02_mem_counters.txt)
+    uint32_t wave_ins = 0;
+    const uint32_t n_waves = blockDim.x >> 6;
     for (uint32_t j0 = lo; j0 < hi; j0 += blockDim.x) {
         const uint32_t j = j0 + threadIdx.x;
-        bool direct = false;
+        const int tmax = wave_ins * n_waves * 4 > CS * 3 ? 1 : 4;
+        bool direct = false, inserted = false;
         unsigned long long key = 0ull;
         uint64_t h = 0;
         uint32_t jr = 0;  // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
@@ -185,9 +192,9 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
             h = mirge_mix64(key);
             uint32_t s = (uint32_t)(h >> 9) & (CS - 1);
             direct = true;
-            for (int t = 0; t < 4; t++) {
+            for (int t = 0; t < tmax; t++) {
                 unsigned long long cur = lds_a[s];
-                if (cur == 0ull) cur = atomicCAS(&lds_a[s], 0ull, key);
+                if (cur == 0ull) { cur = atomicCAS(&lds_a[s], 0ull, key); inserted = cur == 0ull; }
                 if (cur == 0ull || cur == key) {
                     // the slot's minimum only falls: a plain read that is already below ours proves the atomic would
                     // change nothing (indices grow with the loop, so this skips it for every later copy of a read)
@@ -199,6 +206,7 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
                 s = (s + 1) & (CS - 1);
             }
         }
+        wave_ins += (uint32_t)__popcll(__ballot(inserted));
         const unsigned long long bal = __ballot(direct);  // cache full around this key: emit the read itself
         if (bal) {
             uint32_t wb = 0;
@@ -280,6 +288,9 @@ k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket
     for (uint32_t i = threadIdx.x; i < 32 + 32; i += blockDim.x) lds_x[i] = 0;  // key-path reads are <= 31 nt
     __syncthreads();
     const uint32_t lo = bucket_start[blockIdx.x], hi = bucket_start[blockIdx.x + 1];
+    // a bucket with fewer records than the table has slots cannot fill it: the distinct-key counter (one LDS atomic on a
+    // single address per new key, serialised over the lanes) is kept for the oversized buckets only
+    const bool counted = hi - lo >= (uint32_t)(CAP - 64);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint4 rec = part[i];
         const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
@@ -289,10 +300,10 @@ k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket
             unsigned long long cur = lds_k[s];
             if (cur == 0ull) {
                 cur = atomicCAS(&lds_k[s], 0ull, key);
-                if (cur == 0ull && atomicAdd(&n_distinct, 1u) >= CAP - 64) atomicOr(overflow, 1u);
+                if (counted && cur == 0ull && atomicAdd(&n_distinct, 1u) >= CAP - 64) atomicOr(overflow, 1u);
             }
             if (cur == 0ull || cur == key) break;
-            if (*(volatile uint32_t*)&n_distinct >= CAP - 32) break;  // table full: flagged, results discarded
+            if (counted && *(volatile uint32_t*)&n_distinct >= CAP - 32) break;  // table full: flagged, results discarded
             s = (s + 1) & (CAP - 1);
         }
         if (*(volatile uint32_t*)&lds_min[s] > j) atomicMin(&lds_min[s], j);

@@ -12,6 +12,9 @@
 #define MIRGE_BLOCK 256
 #define MIRGE_MAX_PASSES_K 16
 #define MIRGE_EMPTY 0xFFFFFFFFu
+#ifndef MIRGE_COLLAPSE_SEED
+#define MIRGE_COLLAPSE_SEED 2048  // reads of a group inserted ahead of the rest (general collapse path)
+#endif
 #define MIRGE_CELL_CACHE 2048  // per-workgroup LDS cache of (slot, sample) cells in the general collapse path
 
 template <int W>

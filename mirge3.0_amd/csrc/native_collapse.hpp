@@ -158,8 +158,15 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         LaunchScope ls(c, name, in.n);
         // at most 2 workgroups per CU: each sees enough of the group for its LDS cell cache to merge hot reads
         const int ins_grid = std::min(grid_for(c, in.n), c->n_cu * 2);
-        hipLaunchKernelGGL(k_collapse_insert<W>, dim3(ins_grid), dim3(MIRGE_BLOCK), 0, c->cur,
-                           v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S);
+        // the first reads go in ahead of the rest, by a few workgroups: a sequence that makes up a percent of the group is
+        // among them, so when the whole chip arrives its slot is already claimed and found by a plain load -- otherwise
+        // every copy in the first wave of threads sees the slot empty and they all compare-and-swap ONE address
+        const uint32_t seed = std::min<uint32_t>(in.n, MIRGE_COLLAPSE_SEED);
+        hipLaunchKernelGGL(k_collapse_insert<W>, dim3((seed + MIRGE_BLOCK - 1) / MIRGE_BLOCK), dim3(MIRGE_BLOCK), 0, c->cur,
+                           v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S, 0u, seed);
+        if (in.n > seed)
+            hipLaunchKernelGGL(k_collapse_insert<W>, dim3(ins_grid), dim3(MIRGE_BLOCK), 0, c->cur,
+                               v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S, seed, in.n);
         first_base = t.firstj; first_stride = 1;
         t.cnt_base = t.cnt; t.cnt_stride = (uint32_t)S;
     }
