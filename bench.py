@@ -33,8 +33,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (s
 ALGO_BYTES = {
     "k_collapse_insert": 9 + 4,      # read in, slot id out, per raw read
     "k_collapse_insert_key": 9 + 4,  # same, 64-bit-key table (<=31 nt, no N, one sample)
-    "k_part_agg": 9 + 12, "k_part_scatter": 9 + 12, "k_part_dedup": 12 + 17,  # 17 = key + len + count + first per unique (bound: per raw read)
-    "k_part_prefix": 8,
+    "k_part_agg": 9 + 16, "k_part_split": 16 + 16, "k_part_dedup": 16 + 17,  # 17 = key + len + count + first per unique (bound: per raw read)
     "k_heads_blocksum": 4 + 4 + 1,   # slot id + first-index in, head flag out, per raw read
     "k_collapse_scatter": 1 + 4 + 13,  # head flag + slot id in; key+len+count out (upper bound: per raw read)
     "k_pass": 4 + 9 + 5,             # active index + read in, annotation or survivor index out, per read handed to the pass

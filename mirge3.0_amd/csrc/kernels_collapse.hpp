@@ -128,22 +128,58 @@ __global__ void k_collapse_init(uint32_t* __restrict__ rep, uint32_t* __restrict
 // Partitioned collapse for the key path (<=31 nt, no N, one sample).  Scattered device-scope atomics
 // run at ~20 G/s chip-wide, which is what bounds k_collapse_insert_key (2.4 atomics per read).  Here
 // equal keys are first brought together: reads are partitioned by the top bits of their hash into
-// buckets of ~1-2 k reads (histogram per workgroup -> column prefix -> scatter, no global atomics),
-// then ONE workgroup de-duplicates a bucket entirely in LDS (ds_cmpst / ds_min / ds_add) and emits the
-// bucket's distinct reads with their counts.
-//   k_part_agg    : per workgroup chunk: LDS cache merges equal reads -> records {key, min j, count};
-//                   hist[g][b] = records of chunk g that fall into bucket b
-//   k_part_prefix : off[g][b]   = sum over g' < g of hist[g'][b];  total[b] = column sum
-//   (k_scan_blocksums over total[] -> bucket_start[])
-//   k_part_scatter: part[bucket_start[b] + off[g][b] + local cursor] = record (16 B)
-//   k_part_dedup  : per bucket, LDS table (key -> min j, count); the bucket's distinct reads are written
-//                   to the output at a range reserved with one global atomicAdd per workgroup (so the order
-//                   of the unique reads of this path is unspecified; first[] carries the first raw index)
+// buckets of ~1-2 k reads, then ONE workgroup de-duplicates a bucket entirely in LDS (ds_cmpst / ds_min /
+// ds_add) and emits the bucket's distinct reads with their counts.
+// The partition is a radix split in one or two levels whose writes are APPEND STREAMS: a writer workgroup appends
+// 16-byte records to one stream per bin through an LDS cursor.  A workgroup keeps 64-512 such streams open, so a CU's
+// open 128-byte lines (<= 64 KiB) stay in L2 until they are full and HBM sees whole lines -- round 1's one-level scatter
+// had 256 workgroups x 8192 buckets = 2 M open streams, every 16-byte record its own sector write (the random-sector
+// ceiling, 0.17-0.18 ms of the step), behind a column prefix over a 2 M-cell histogram and a scan.
+//   k_part_agg   : per workgroup chunk g: LDS cache merges equal reads -> records {key, min j, count}, appended to the
+//                  workgroup's region of the record's level-1 bin b1 (fixed capacity: mean x 1.25 + 8 sigma; the hash is
+//                  uniform and the cache has taken the hot keys out; a region that would overflow raises the flag that
+//                  already sends a call to the global-atomic path)              rec1[(b1 * G + g) * cap1 + i]
+//                  and counted per FINAL bucket                                 hist[g][b]
+//   k_part_split : (two levels, B > 64) workgroup (b1, w) owns G / W2 of bin b1's regions: their hist rows give the
+//                  exact size of every bucket's share, so the records are appended at exact offsets inside the
+//                  workgroup's slab -- no capacity to overflow, however many copies of a read there are
+//                                                                               rec2[(b1 * W2 + w) * slab + off[b2] + i]
+//   k_part_dedup : per bucket, LDS table (key -> min j, count) over the bucket's R shares (R = G regions of level 1, or W2
+//                  slab ranges); the bucket's distinct reads are written to the output at a range reserved with one global
+//                  atomicAdd per workgroup (so the order of the unique reads of this path is unspecified; first[]
+//                  carries the first raw index)
 // ------------------------------------------------------------------------------------------
+#ifndef MIRGE_PART_CAP
 #define MIRGE_PART_CAP 4096  // largest LDS table per bucket (16 B per slot = 64 KiB)
+#endif
+#define MIRGE_PART_B1 64       // level-1 bins (and the largest one-level partition)
+#define MIRGE_PART_MAXREG 256  // regions a consumer workgroup reads (G <= 256 writers, or W2 splitters)
 
 __device__ __forceinline__ unsigned long long read_key64(const GroupView<1>& g, uint32_t j) {
     return g.seq[j] | (1ull << (2 * g.len[j]));
+}
+
+// item i of a list of regions whose fill counts have the inclusive prefix pre[0..R): region and offset inside it
+__device__ __forceinline__ uint32_t region_of(const uint32_t* pre, uint32_t R, uint32_t i, uint32_t& within) {
+    uint32_t lo = 0, hi = R;  // first r with pre[r] > i
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pre[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    within = i - (lo ? pre[lo - 1] : 0u);
+    return lo;
+}
+
+// inclusive prefix of up to MIRGE_PART_MAXREG region counts (clamped to cap) into LDS, by the first wave(s); returns total
+__device__ __forceinline__ uint32_t region_prefix(const uint32_t* __restrict__ cnt, uint32_t R, uint32_t cap, uint32_t* pre) {
+    for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) pre[r] = min(cnt[r], cap);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // R <= 256: a serial pass over LDS costs less than the barriers of a block scan
+        uint32_t run = 0;
+        for (uint32_t r = 0; r < R; r++) { run += pre[r]; pre[r] = run; }
+    }
+    __syncthreads();
+    return R ? pre[R - 1] : 0u;
 }
 
 // k_part_agg: a workgroup walks its chunk of reads through a small LDS cache (key -> min index,
@@ -152,50 +188,51 @@ __device__ __forceinline__ unsigned long long read_key64(const GroupView<1>& g, 
 // and every LDS atomic on it is a 64-way conflict (measured on a Zipf sample: 10.9 ms per step against
 // 2.8 ms on unskewed reads).  With it a key contributes at most one record per workgroup.  The cache is
 // best effort: a read that finds no slot within 4 probes is emitted as a record of count 1.
-// Output: recs[blockIdx * chunk ...] (compacted, nrec[blockIdx] of them) and hist[blockIdx][bucket].
-// One workgroup per CU (the LDS cache + histogram take most of a CU's LDS), so the workgroup itself must bring
+// One workgroup per CU (the LDS cache takes a good part of a CU's LDS), so the workgroup itself must bring
 // the waves that hide its load and LDS latencies: 1024 threads = 16 waves per CU (256 threads: 0.26 ms, 2x slower)
 #ifndef MIRGE_PART_THREADS
 #define MIRGE_PART_THREADS 1024
 #endif
 __global__ void __launch_bounds__(MIRGE_PART_THREADS)
-k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uint32_t chunk, uint32_t bshift, uint32_t B,
-           uint32_t CS, uint4* __restrict__ recs, uint32_t* __restrict__ nrec, uint32_t* __restrict__ hist) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_a[];  // [CS] keys | [CS] minj | [CS] cnt | [B] hist | cursor
+k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uint32_t chunk, uint32_t shift1, uint32_t NB1,
+           uint32_t bshift, uint32_t B, uint32_t CS, uint32_t cap1, uint4* __restrict__ rec1, uint32_t* __restrict__ cnt1,
+           uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds_a[];  // [CS] keys | [CS] minj | [CS] cnt | [NB1] cursors | [B] hist
     uint32_t* c_min = reinterpret_cast<uint32_t*>(lds_a + CS);
     uint32_t* c_cnt = c_min + CS;
-    uint32_t* lds_h = c_cnt + CS;
-    uint32_t& cursor = lds_h[B];
+    uint32_t* cur = c_cnt + CS;
+    uint32_t* lds_h = cur + NB1;  // records per final bucket (two levels only: hist != nullptr)
     for (uint32_t i = threadIdx.x; i < CS; i += blockDim.x) { lds_a[i] = 0ull; c_min[i] = 0xFFFFFFFFu; c_cnt[i] = 0; }
-    for (uint32_t b = threadIdx.x; b <= B; b += blockDim.x) lds_h[b] = 0;
+    for (uint32_t b = threadIdx.x; b < NB1; b += blockDim.x) cur[b] = 0;
+    if (hist) for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lds_h[b] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, g.n);
-    uint4* out = recs + (size_t)blockIdx.x * chunk;
-    const int lane = threadIdx.x & 63;
-    // keys this wave has put into the cache; the waves insert at the same rate, so x waves = the cache's fill.  Once it is
-    // three quarters full a read looks at its home slot only: the hot keys, which the cache is for, arrived early and sit
-    // there, and the other ~95 % of a chunk's reads no longer pay four failing LDS probes each (the kernel is bound by
-    // LDS instructions: 17 per 64 reads before, profiles/r02_mem_counters.txt)
-    uint32_t wave_ins = 0;
-    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t G = gridDim.x;
+    auto append = [&](unsigned long long key, uint64_t h, uint32_t jr, uint32_t count) {
+        const uint32_t b1 = (uint32_t)(h >> shift1);
+        const uint32_t p = atomicAdd(&cur[b1], 1u);
+        if (p < cap1) {
+            rec1[((size_t)b1 * G + blockIdx.x) * cap1 + p] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), jr, count);
+            if (hist) atomicAdd(&lds_h[(uint32_t)(h >> bshift)], 1u);
+        }
+    };
     for (uint32_t j0 = lo; j0 < hi; j0 += blockDim.x) {
         const uint32_t j = j0 + threadIdx.x;
-        const int tmax = wave_ins * n_waves * 4 > CS * 3 ? 1 : 4;
-        bool direct = false, inserted = false;
-        unsigned long long key = 0ull;
-        uint64_t h = 0;
-        uint32_t jr = 0;  // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
-                          // instead of gathered per unique read at the end)
         if (j < hi) {
-            key = read_key64(g, j);
-            jr = orig ? orig[j] : base + j;
-            h = mirge_mix64(key);
+            const unsigned long long key = read_key64(g, j);
+            // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
+            // instead of gathered per unique read at the end)
+            const uint32_t jr = orig ? orig[j] : base + j;
+            const uint64_t h = mirge_mix64(key);
             uint32_t s = (uint32_t)(h >> 9) & (CS - 1);
-            direct = true;
-            for (int t = 0; t < tmax; t++) {
-                unsigned long long cur = lds_a[s];
-                if (cur == 0ull) { cur = atomicCAS(&lds_a[s], 0ull, key); inserted = cur == 0ull; }
-                if (cur == 0ull || cur == key) {
+            bool direct = true;
+            // four probes, always: a hot key that was displaced from its home slot when it arrived must still be found by its
+            // later copies (looking at the home slot only once the cache is full was 6 % faster on unskewed reads and sent
+            // every copy of such a key to its bin as a record of its own on a Zipf sample)
+            for (int t = 0; t < 4; t++) {
+                unsigned long long c0 = lds_a[s];
+                if (c0 == 0ull) c0 = atomicCAS(&lds_a[s], 0ull, key);
+                if (c0 == 0ull || c0 == key) {
                     // the slot's minimum only falls: a plain read that is already below ours proves the atomic would
                     // change nothing (indices grow with the loop, so this skips it for every later copy of a read)
                     if (*(volatile uint32_t*)&c_min[s] > jr) atomicMin(&c_min[s], jr);
@@ -205,109 +242,133 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
                 }
                 s = (s + 1) & (CS - 1);
             }
-        }
-        wave_ins += (uint32_t)__popcll(__ballot(inserted));
-        const unsigned long long bal = __ballot(direct);  // cache full around this key: emit the read itself
-        if (bal) {
-            uint32_t wb = 0;
-            if (lane == 0) wb = atomicAdd(&cursor, (uint32_t)__popcll(bal));
-            wb = __shfl(wb, 0, 64);
-            if (direct) {
-                out[wb + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), jr, 1u);
-                atomicAdd(&lds_h[(uint32_t)(h >> bshift)], 1u);
-            }
+            if (direct) append(key, h, jr, 1u);  // cache full around this key: the read itself is the record
         }
     }
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < CS; i0 += blockDim.x) {  // flush the cache
-        const uint32_t i = i0 + threadIdx.x;
-        const unsigned long long key = i < CS ? lds_a[i] : 0ull;
-        const bool has = key != 0ull;
-        const unsigned long long bal = __ballot(has);
-        if (bal) {
-            uint32_t wb = 0;
-            if (lane == 0) wb = atomicAdd(&cursor, (uint32_t)__popcll(bal));
-            wb = __shfl(wb, 0, 64);
-            if (has) {
-                out[wb + __popcll(bal & ((1ull << lane) - 1ull))] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), c_min[i], c_cnt[i]);
-                atomicAdd(&lds_h[(uint32_t)(mirge_mix64(key) >> bshift)], 1u);
-            }
-        }
+    for (uint32_t i = threadIdx.x; i < CS; i += blockDim.x) {  // flush the cache
+        const unsigned long long key = lds_a[i];
+        if (key != 0ull) append(key, mirge_mix64(key), c_min[i], c_cnt[i]);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[(size_t)blockIdx.x * B + b] = lds_h[b];
-    if (threadIdx.x == 0) nrec[blockIdx.x] = cursor;
-}
-
-__global__ void k_part_prefix(const uint32_t* __restrict__ hist, uint32_t G, uint32_t B, uint32_t* __restrict__ off,
-                              uint32_t* __restrict__ total) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    uint32_t run = 0;
-#pragma unroll 8
-    for (uint32_t gq = 0; gq < G; gq++) {
-        const uint32_t v = hist[(size_t)gq * B + b];
-        off[(size_t)gq * B + b] = run;
-        run += v;
+    for (uint32_t b = threadIdx.x; b < NB1; b += blockDim.x) {
+        const uint32_t n = cur[b];
+        cnt1[(size_t)b * G + blockIdx.x] = min(n, cap1);
+        if (n > cap1) atomicOr(overflow, 1u);
     }
-    total[b] = run;
+    if (hist) for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[(size_t)blockIdx.x * B + b] = lds_h[b];
 }
 
+// k_part_split: second radix level.  Workgroup (b1 = blockIdx / W2, w = blockIdx % W2) takes the regions
+// [w * RPW, (w + 1) * RPW) of level-1 bin b1 (coalesced reads of ~0.6 k records each).  The hist rows of those writers
+// give the exact number of records per final bucket b1 * NB2 + b2, so every record is appended at an exact offset of
+// the workgroup's slab; the bucket's share is published as (offset, count) for k_part_dedup.
 __global__ void __launch_bounds__(MIRGE_PART_THREADS)
-k_part_scatter(const uint4* __restrict__ recs, const uint32_t* __restrict__ nrec, uint32_t chunk,
-                               uint32_t bshift, uint32_t B, const uint32_t* __restrict__ off,
-                               const uint32_t* __restrict__ bucket_start, uint4* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_c[];
-    for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) lds_c[b] = bucket_start[b] + off[(size_t)blockIdx.x * B + b];
-    __syncthreads();
-    const uint4* in = recs + (size_t)blockIdx.x * chunk;
-    const uint32_t n = nrec[blockIdx.x];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint4 rec = in[i];
-        const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
-        const uint32_t p = atomicAdd(&lds_c[(uint32_t)(mirge_mix64(key) >> bshift)], 1u);
-        part[p] = rec;  // {key, min index, count}: one 16-B store per record
+k_part_split(const uint4* __restrict__ rec1, const uint32_t* __restrict__ cnt1, const uint32_t* __restrict__ hist, uint32_t G,
+             uint32_t B, uint32_t cap1, uint32_t W2, uint32_t RPW, uint32_t shift2, uint32_t NB2, uint64_t slab,
+             uint4* __restrict__ rec2, uint32_t* __restrict__ off2, uint32_t* __restrict__ cnt2) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_s[];  // [MAXREG] prefix | [NB2] cursors (start at the bucket's offset)
+    uint32_t* pre = lds_s;
+    uint32_t* cur = lds_s + MIRGE_PART_MAXREG;
+    __shared__ uint32_t scan_tmp[MIRGE_PART_THREADS / 64 + 1];
+    const uint32_t b1 = blockIdx.x / W2, w = blockIdx.x % W2;
+    const uint32_t r0 = w * RPW, R = r0 < G ? min(RPW, G - r0) : 0u;
+    // this workgroup's records per bucket, then their exclusive prefix = the buckets' offsets in the slab (NB2 <= 512 <= threads)
+    uint32_t mine = 0;
+    if (threadIdx.x < NB2)
+        for (uint32_t r = 0; r < R; r++) mine += hist[(size_t)(r0 + r) * B + (size_t)b1 * NB2 + threadIdx.x];
+    uint32_t tot_all;
+    const uint32_t off = block_excl_scan<MIRGE_PART_THREADS / 64>(mine, tot_all, scan_tmp);
+    if (threadIdx.x < NB2) {
+        cur[threadIdx.x] = off;
+        const size_t cell = ((size_t)b1 * NB2 + threadIdx.x) * W2 + w;
+        off2[cell] = off;
+        cnt2[cell] = mine;
+    }
+    for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) pre[r] = min(cnt1[(size_t)b1 * G + r0 + r], cap1);
+    __syncthreads();  // publishes cur[] and the regions' fill counts
+    const uint4* in = rec1 + ((size_t)b1 * G + r0) * cap1;
+    uint4* out = rec2 + (size_t)blockIdx.x * slab;
+    // a wave takes whole regions: 64 consecutive records per load, no search for the region of an item
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+    for (uint32_t r = wave; r < R; r += n_waves) {
+        const uint32_t n = pre[r];
+        const uint4* src = in + (size_t)r * cap1;
+        // four loads in flight per lane: with 16 waves on a CU the kernel is a chain of load -> LDS atomic -> store
+        // latencies, not bandwidth
+        for (uint32_t i0 = lane; i0 < n; i0 += 256) {
+            uint4 rec[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (i0 + 64 * u < n) rec[u] = src[i0 + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (i0 + 64 * u >= n) continue;
+                const unsigned long long key = ((unsigned long long)rec[u].y << 32) | rec[u].x;
+                const uint32_t b2 = (uint32_t)(mirge_mix64(key) >> shift2) & (NB2 - 1);
+                out[atomicAdd(&cur[b2], 1u)] = rec[u];
+            }
+        }
     }
 }
 
 // CAP = LDS table slots (16 B each): 2048 when the buckets hold <= 1024 records (4 workgroups per CU), else 4096
 // The table takes 32-64 KiB of LDS, so only 2-4 workgroups fit a CU: 1024-thread workgroups bring the waves.
+// The bucket's records lie in R shares: share r holds cnt[bucket * R + r] records (clamped to rcap) from
+// rec[(bucket * R + r) * rcap]  (off == nullptr: level-1 regions), or from rec[((bucket / NB2) * R + r) * rcap + off[bucket * R + r]]
+// (ranges inside the level-2 slabs of capacity rcap).
 #define MIRGE_DEDUP_THREADS 1024
 template <int CAP>
 __global__ void __launch_bounds__(MIRGE_DEDUP_THREADS)
-k_part_dedup(const uint4* __restrict__ part, const uint32_t* __restrict__ bucket_start,
-             uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
+k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t R,
+             uint64_t rcap, uint32_t NB2, uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
              uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst, uint32_t* __restrict__ cursor,
              uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
     uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + CAP);
     uint32_t* lds_cnt = lds_min + CAP;
     uint32_t* lds_x = lds_cnt + CAP;  // [0] distinct keys, [1] output base, [2..17] scan scratch, [32..63] lengths (<= 31 nt)
+    uint32_t* pre = lds_x + 64;       // [MAXREG] inclusive prefix of the regions' fill counts
     uint32_t& n_distinct = lds_x[0];
     for (uint32_t i = threadIdx.x; i < CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
     for (uint32_t i = threadIdx.x; i < 32 + 32; i += blockDim.x) lds_x[i] = 0;  // key-path reads are <= 31 nt
+    const uint32_t total_in = region_prefix(cnt + (size_t)blockIdx.x * R, R, (uint32_t)min(rcap, (uint64_t)0xFFFFFFFFu), pre);  // (its barriers cover the clears)
+    const uint4* in = rec + (size_t)(off ? blockIdx.x / NB2 : blockIdx.x) * R * rcap;
+    uint32_t* roff = pre + MIRGE_PART_MAXREG;  // where share r starts inside its region / slab
+    for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) roff[r] = off ? off[(size_t)blockIdx.x * R + r] : 0u;
     __syncthreads();
-    const uint32_t lo = bucket_start[blockIdx.x], hi = bucket_start[blockIdx.x + 1];
     // a bucket with fewer records than the table has slots cannot fill it: the distinct-key counter (one LDS atomic on a
     // single address per new key, serialised over the lanes) is kept for the oversized buckets only
-    const bool counted = hi - lo >= (uint32_t)(CAP - 64);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint4 rec = part[i];
-        const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
-        const uint32_t j = rec.z;
+    const bool counted = total_in >= (uint32_t)(CAP - 64);
+    // up to four shares (the two-level partition): their bounds in registers, no search through LDS per record
+    const bool few = R <= 4;
+    const uint32_t e0 = pre[0], e1 = R > 1 ? pre[1] : e0, e2 = R > 2 ? pre[2] : e1;
+    const uint32_t o0 = roff[0], o1 = R > 1 ? roff[1] : 0u, o2 = R > 2 ? roff[2] : 0u, o3 = R > 3 ? roff[3] : 0u;
+    for (uint32_t i = threadIdx.x; i < total_in; i += blockDim.x) {
+        size_t at;
+        if (few) {
+            at = i < e0 ? (size_t)o0 + i : i < e1 ? rcap + o1 + (i - e0) : i < e2 ? 2 * rcap + o2 + (i - e1) : 3 * rcap + o3 + (i - e2);
+        } else {
+            uint32_t k;
+            const uint32_t r = region_of(pre, R, i, k);
+            at = (size_t)r * rcap + roff[r] + k;
+        }
+        const uint4 rc = in[at];
+        const unsigned long long key = ((unsigned long long)rc.y << 32) | rc.x;
+        const uint32_t j = rc.z;
         uint32_t s = (uint32_t)(mirge_mix64(key) >> 7) & (CAP - 1);
         while (true) {
-            unsigned long long cur = lds_k[s];
-            if (cur == 0ull) {
-                cur = atomicCAS(&lds_k[s], 0ull, key);
-                if (counted && cur == 0ull && atomicAdd(&n_distinct, 1u) >= CAP - 64) atomicOr(overflow, 1u);
+            unsigned long long c0 = lds_k[s];
+            if (c0 == 0ull) {
+                c0 = atomicCAS(&lds_k[s], 0ull, key);
+                if (counted && c0 == 0ull && atomicAdd(&n_distinct, 1u) >= CAP - 64) atomicOr(overflow, 1u);
             }
-            if (cur == 0ull || cur == key) break;
+            if (c0 == 0ull || c0 == key) break;
             if (counted && *(volatile uint32_t*)&n_distinct >= CAP - 32) break;  // table full: flagged, results discarded
             s = (s + 1) & (CAP - 1);
         }
         if (*(volatile uint32_t*)&lds_min[s] > j) atomicMin(&lds_min[s], j);
-        atomicAdd(&lds_cnt[s], rec.w);  // a record stands for rec.w identical reads of one workgroup's chunk
+        atomicAdd(&lds_cnt[s], rc.w);  // a record stands for rc.w identical reads of one workgroup's chunk
     }
     __syncthreads();
     // emit the bucket's distinct reads: one global cursor add per workgroup reserves their output range

@@ -12,11 +12,12 @@ struct CollapseTmp {
     uint8_t* flag = nullptr;
     const uint32_t* cnt_base = nullptr;
     uint32_t cnt_stride = 1, nb = 0;
-    // partitioned key path
+    // partitioned key path: level-1 regions rec1[(b1 * G + g) * cap1 + i], level-2 slabs rec2[(b1 * W2 + w) * slab + off2[..] + i]
     bool partitioned = false;
-    uint32_t *hist = nullptr, *off = nullptr, *btotal = nullptr, *nrec = nullptr;
-    uint4 *part = nullptr, *recs = nullptr;
-    uint32_t G = 0, chunk = 0, bshift = 0, B = 0, cap = MIRGE_PART_CAP;
+    uint4 *rec1 = nullptr, *rec2 = nullptr;
+    uint32_t *cnt1 = nullptr, *cnt2 = nullptr, *off2 = nullptr, *hist = nullptr;
+    uint32_t G = 0, B = 0, NB1 = 0, NB2 = 1, W2 = 1, RPW = 0, cap1 = 0, shift2 = 0, cap = MIRGE_PART_CAP;
+    uint64_t slab = 0;
 };
 // dmeta: [0..7] U of each group, [8] partition overflow flag, [16 .. 16+255] length histogram
 #define MIRGE_META_OVERFLOW 8
@@ -28,35 +29,37 @@ static const char* group_tag(int gi) {
     return t[gi];
 }
 
-// partitioned key path after k_part_agg.  `part` 1: bucket offsets + scatter (k_part_scatter is one workgroup per CU
-// like k_part_agg: the small groups' kernels, enqueued while these run, find room beside them); 2: the per-bucket
-// de-duplication (8192 workgroups: takes the machine); 0: both.  The main queue used to idle ~0.1 ms between
-// k_part_agg and k_part_prefix while the host enqueued the small groups' launches (profiles/r02_timeline.txt).
+// capacity of a level-1 region for `mean` expected records: a quarter above the mean for reads the chunk cache
+// missed, 8 sigma of a uniform hash, slack; a multiple of 4 records
+static uint32_t part_region_cap(double mean) {
+    const double c = 1.25 * mean + 8.0 * std::sqrt(mean) + 64.0;
+    return ((uint32_t)c + 3u) & ~3u;
+}
+
+// partitioned key path after k_part_agg.  `part` 1: the second radix level (k_part_split is one workgroup per CU like
+// k_part_agg: the small groups' kernels, enqueued while these run, find room beside them); 2: the per-bucket
+// de-duplication (8192 workgroups: takes the machine); 0: both.  The main queue used to idle ~0.1 ms behind
+// k_part_agg while the host enqueued the small groups' launches (profiles/r02_timeline.txt).
 static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, uint32_t* dmeta, int part = 0) {
-    const uint32_t G = t.G, B = t.B;
-    if (part != 2) {
-    {
-        LaunchScope ls(c, "k_part_prefix.w1", (double)G * B);
-        hipLaunchKernelGGL(k_part_prefix, dim3((B + 63) / 64), dim3(64), 0, c->cur, t.hist, G, B, t.off, t.btotal);
-    }
-    {
-        LaunchScope ls(c, "k_scan_blocksums", B);
-        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.btotal, B, t.btotal + B);
-    }
-    {
-        LaunchScope ls(c, "k_part_scatter.w1", in.n);
-        hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(MIRGE_PART_THREADS), B * 4, c->cur, t.recs, t.nrec, t.chunk, t.bshift, B, t.off,
-                           t.btotal, t.part);
-    }
+    const bool two = t.NB2 > 1;
+    if (part != 2 && two) {
+        LaunchScope ls(c, "k_part_split.w1", in.n);
+        hipLaunchKernelGGL(k_part_split, dim3(t.NB1 * t.W2), dim3(MIRGE_PART_THREADS), (MIRGE_PART_MAXREG + t.NB2) * 4, c->cur,
+                           t.rec1, t.cnt1, t.hist, t.G, t.B, t.cap1, t.W2, t.RPW, t.shift2, t.NB2, t.slab, t.rec2, t.off2, t.cnt2);
     }
     if (part != 1) {
         LaunchScope ls(c, "k_part_dedup.w1", in.n);
+        const uint4* rec = two ? t.rec2 : t.rec1;
+        const uint32_t* cnt = two ? t.cnt2 : t.cnt1;
+        const uint32_t* off = two ? t.off2 : nullptr;
+        const uint32_t R = two ? t.W2 : t.G;
+        const uint64_t rcap = two ? t.slab : (uint64_t)t.cap1;
         if (t.cap == 2048)
-            hipLaunchKernelGGL(k_part_dedup<2048>, dim3(B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 1024, c->cur, t.part, t.btotal,
+            hipLaunchKernelGGL(k_part_dedup<2048>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 4096, c->cur, rec, cnt, off, R, rcap, t.NB2,
                                out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST, dmeta + MIRGE_META_OVERFLOW);
         else
-            hipLaunchKernelGGL(k_part_dedup<MIRGE_PART_CAP>, dim3(B), dim3(MIRGE_DEDUP_THREADS), MIRGE_PART_CAP * 16 + 1024, c->cur, t.part,
-                               t.btotal, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
+            hipLaunchKernelGGL(k_part_dedup<MIRGE_PART_CAP>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), MIRGE_PART_CAP * 16 + 4096, c->cur, rec,
+                               cnt, off, R, rcap, t.NB2, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
                                dmeta + MIRGE_META_OVERFLOW);
     }
     return 0;
@@ -94,8 +97,9 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         // buckets of <= 1024 records get a 2048-slot LDS table in k_part_dedup (4 workgroups per CU instead of 2).
         // Forcing that by doubling B was measured slower overall: k_part_agg/k_part_scatter pay for the larger B
         t.cap = (!small_part && (uint64_t)B * 1024 >= in.n) ? 2048u : (uint32_t)MIRGE_PART_CAP;
+        const uint32_t NB1 = std::min<uint32_t>(B, MIRGE_PART_B1), NB2 = B / NB1;
         const uint32_t CS = B > 16384 ? 1024 : 2048;  // chunk-level LDS cache slots (16 B each)
-        const int agg_lds = (int)(CS * 16 + (B + 1) * 4 + 64);
+        const int agg_lds = (int)(CS * 16 + NB1 * 4 + (NB2 > 1 ? B * 4 : 0) + 64);
         // dynamic-LDS ceilings, raised once per process and device to the largest configuration (B = 32768)
         static std::mutex attr_mu;
         static std::vector<int> attr_done;
@@ -103,24 +107,32 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
             std::lock_guard<std::mutex> lk(attr_mu);
             if (std::find(attr_done.begin(), attr_done.end(), c->device) == attr_done.end()) {
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          1024 * 16 + (32768 + 1) * 4 + 64));  // CS = 1024 at B = 32768; 2048 * 16 + 16385 * 4 + 64 is smaller
-                HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4));
+                                          1024 * 16 + MIRGE_PART_B1 * 4 + 32768 * 4 + 64));  // CS = 1024 at B = 32768; 2048 * 16 + 16384 * 4 is smaller
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup<MIRGE_PART_CAP>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, MIRGE_PART_CAP * 16 + 1024));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, MIRGE_PART_CAP * 16 + 4096));
                 attr_done.push_back(c->device);
             }
         }
         int lg = 0; while ((1u << lg) < B) lg++;
-        const uint32_t bshift = 64 - lg;
+        int lg1 = 0; while ((1u << lg1) < NB1) lg1++;
         const uint32_t G = std::min<uint32_t>(256, (in.n + 2047) / 2048);
         uint32_t chunk = (in.n + G - 1) / G;
         chunk = (chunk + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
-        CHECK(dalloc(c, &t.hist, (size_t)G * B));
-        CHECK(dalloc(c, &t.off, (size_t)G * B));
-        CHECK(dalloc(c, &t.btotal, (size_t)B + 1));
-        CHECK(dalloc(c, &t.part, (size_t)in.n));
-        CHECK(dalloc(c, &t.recs, (size_t)G * chunk));
-        CHECK(dalloc(c, &t.nrec, (size_t)G));
+        // the level-1 bin is the top lg1 bits of the hash, the level-2 bin the next lg - lg1 bits
+        const uint32_t shift1 = 64 - lg1, shift2 = 64 - lg;
+        const uint32_t W2 = NB2 > 1 ? std::min<uint32_t>(4, G) : 1, RPW = (G + W2 - 1) / W2;
+        // test hook: MIRGE_TEST_SMALL_REGION=1 halves the level-1 regions so that they overflow and the call falls back
+        static const bool small_region = std::getenv("MIRGE_TEST_SMALL_REGION") != nullptr;
+        const uint32_t cap1 = small_region ? std::max<uint32_t>(4, chunk / NB1 / 2 & ~3u) : part_region_cap((double)chunk / NB1);
+        const uint64_t slab = (uint64_t)RPW * cap1;  // a splitter's input can never exceed the capacity of its regions
+        CHECK(dalloc(c, &t.rec1, (size_t)NB1 * G * cap1));
+        CHECK(dalloc(c, &t.cnt1, (size_t)NB1 * G));
+        if (NB2 > 1) {
+            CHECK(dalloc(c, &t.hist, (size_t)G * B));
+            CHECK(dalloc(c, &t.rec2, (size_t)NB1 * W2 * slab));
+            CHECK(dalloc(c, &t.cnt2, (size_t)B * W2));
+            CHECK(dalloc(c, &t.off2, (size_t)B * W2));
+        }
         // outputs at capacity n (U is not known yet): the bucket workgroups emit the unique reads themselves
         out.W = 1;
         CHECK(dalloc(c, &out.seq, (size_t)in.n));
@@ -130,9 +142,10 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         GroupView<1> v1 = view_of<1>(in);
         {
             LaunchScope ls(c, "k_part_agg.w1", in.n);
-            hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_PART_THREADS), agg_lds, c->cur, v1, in.orig, in.base, chunk, bshift, B, CS, t.recs, t.nrec, t.hist);
+            hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_PART_THREADS), agg_lds, c->cur, v1, in.orig, in.base, chunk, shift1, NB1,
+                               shift2, B, CS, cap1, t.rec1, t.cnt1, t.hist, dmeta + MIRGE_META_OVERFLOW);
         }
-        t.G = G; t.chunk = chunk; t.bshift = bshift; t.B = B;
+        t.G = G; t.B = B; t.NB1 = NB1; t.NB2 = NB2; t.W2 = W2; t.RPW = RPW; t.cap1 = cap1; t.slab = slab; t.shift2 = shift2;
         if (stage == 1) return collapse_part_rest(c, gi, in, out, t, dmeta, 1);
         return collapse_part_rest(c, gi, in, out, t, dmeta);
     }
@@ -206,7 +219,7 @@ static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
 static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
     c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
     c->defer(t.flag); c->defer(t.blocksum);
-    c->defer(t.hist); c->defer(t.off); c->defer(t.btotal); c->defer(t.part); c->defer(t.recs); c->defer(t.nrec);
+    c->defer(t.rec1); c->defer(t.cnt1); c->defer(t.rec2); c->defer(t.cnt2); c->defer(t.off2); c->defer(t.hist);
     t = CollapseTmp();
 }
 

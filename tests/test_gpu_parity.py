@@ -748,9 +748,11 @@ def test_integration_md_stub_runs(tmp_path):
     assert (tmp_path / "mapped.csv").read_text() == case.text("mapped.csv")
 
 
-def test_collapse_partition_overflow_falls_back(tmp_path):
+@pytest.mark.parametrize("hook", ["MIRGE_TEST_SMALL_PART", "MIRGE_TEST_SMALL_REGION"])
+def test_collapse_partition_overflow_falls_back(tmp_path, hook):
     """A bucket holding more distinct reads than its LDS table raises the overflow flag and the call is redone
-    with the global-atomic tables: forced here with the MIRGE_TEST_SMALL_PART hook in a fresh process."""
+    with the global-atomic tables: forced here with the MIRGE_TEST_SMALL_PART hook in a fresh process.  The same flag is
+    raised when a level-1 region of the radix split would overflow its fixed capacity (MIRGE_TEST_SMALL_REGION halves them)."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -778,7 +780,7 @@ got = dict(zip(u.unpack().to_list(), cnt[:, 0].tolist()))
 assert got == dict(exp), (len(got), len(exp))
 print("OK", len(got))
 """ % root
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MIRGE_TEST_SMALL_PART="1"),
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{hook: "1"}),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
