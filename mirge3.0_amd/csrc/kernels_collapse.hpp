@@ -153,6 +153,12 @@ __global__ void k_collapse_init(uint32_t* __restrict__ rep, uint32_t* __restrict
 #define MIRGE_PART_CAP 4096  // largest LDS table per bucket (16 B per slot = 64 KiB)
 #endif
 #define MIRGE_PART_B1 64       // level-1 bins (and the largest one-level partition)
+#ifndef MIRGE_PART_SMALL
+#define MIRGE_PART_SMALL 1600  // reads per bucket up to which k_part_dedup uses its 2048-slot table
+#endif
+#ifndef MIRGE_PART_W2
+#define MIRGE_PART_W2 4       // splitter workgroups per level-1 bin (64 x 4 = one per CU)
+#endif
 #define MIRGE_PART_MAXREG 256  // regions a consumer workgroup reads (G <= 256 writers, or W2 splitters)
 
 __device__ __forceinline__ unsigned long long read_key64(const GroupView<1>& g, uint32_t j) {
@@ -330,7 +336,15 @@ k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, co
     uint32_t* lds_x = lds_cnt + CAP;  // [0] distinct keys, [1] output base, [2..17] scan scratch, [32..63] lengths (<= 31 nt)
     uint32_t* pre = lds_x + 64;       // [MAXREG] inclusive prefix of the regions' fill counts
     uint32_t& n_distinct = lds_x[0];
-    for (uint32_t i = threadIdx.x; i < CAP; i += blockDim.x) { lds_k[i] = 0ull; lds_min[i] = 0xFFFFFFFFu; lds_cnt[i] = 0; }
+    {   // clear with 16-byte stores: keys and counts to 0, first indices to ~0 (the table's set-up and read-out are most of
+        // this kernel's LDS instructions: a bucket fills a tenth of its table)
+        uint4* k4 = reinterpret_cast<uint4*>(lds_k);
+        for (uint32_t i = threadIdx.x; i < CAP / 2; i += blockDim.x) k4[i] = make_uint4(0u, 0u, 0u, 0u);
+        uint4* m4 = reinterpret_cast<uint4*>(lds_min);
+        for (uint32_t i = threadIdx.x; i < CAP / 4; i += blockDim.x) m4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        uint4* c4 = reinterpret_cast<uint4*>(lds_cnt);
+        for (uint32_t i = threadIdx.x; i < CAP / 4; i += blockDim.x) c4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     for (uint32_t i = threadIdx.x; i < 32 + 32; i += blockDim.x) lds_x[i] = 0;  // key-path reads are <= 31 nt
     const uint32_t total_in = region_prefix(cnt + (size_t)blockIdx.x * R, R, (uint32_t)min(rcap, (uint64_t)0xFFFFFFFFu), pre);  // (its barriers cover the clears)
     const uint4* in = rec + (size_t)(off ? blockIdx.x / NB2 : blockIdx.x) * R * rcap;

@@ -96,7 +96,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         while (!small_part && B < 32768 && (uint64_t)B * 2048 < in.n) B <<= 1;  // ~1-2 k reads per bucket (up to 64 M reads)
         // buckets of <= 1024 records get a 2048-slot LDS table in k_part_dedup (4 workgroups per CU instead of 2).
         // Forcing that by doubling B was measured slower overall: k_part_agg/k_part_scatter pay for the larger B
-        t.cap = (!small_part && (uint64_t)B * 1024 >= in.n) ? 2048u : (uint32_t)MIRGE_PART_CAP;
+        // (a bucket of up to MIRGE_PART_SMALL reads + 8 sigma stays below the 2048 - 64 distinct keys that table takes)
+        t.cap = (!small_part && (uint64_t)B * MIRGE_PART_SMALL >= in.n) ? 2048u : (uint32_t)MIRGE_PART_CAP;
         const uint32_t NB1 = std::min<uint32_t>(B, MIRGE_PART_B1), NB2 = B / NB1;
         const uint32_t CS = B > 16384 ? 1024 : 2048;  // chunk-level LDS cache slots (16 B each)
         const int agg_lds = (int)(CS * 16 + NB1 * 4 + (NB2 > 1 ? B * 4 : 0) + 64);
@@ -120,7 +121,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         chunk = (chunk + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
         // the level-1 bin is the top lg1 bits of the hash, the level-2 bin the next lg - lg1 bits
         const uint32_t shift1 = 64 - lg1, shift2 = 64 - lg;
-        const uint32_t W2 = NB2 > 1 ? std::min<uint32_t>(4, G) : 1, RPW = (G + W2 - 1) / W2;
+        const uint32_t W2 = NB2 > 1 ? std::min<uint32_t>(MIRGE_PART_W2, G) : 1, RPW = (G + W2 - 1) / W2;
         // test hook: MIRGE_TEST_SMALL_REGION=1 halves the level-1 regions so that they overflow and the call falls back
         static const bool small_region = std::getenv("MIRGE_TEST_SMALL_REGION") != nullptr;
         const uint32_t cap1 = small_region ? std::max<uint32_t>(4, chunk / NB1 / 2 & ~3u) : part_region_cap((double)chunk / NB1);
