@@ -337,9 +337,9 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
     const std::vector<PassStep>& steps = c->casc_steps;
     const ResolveTable& rt = c->casc_rt;
     const FusedSteps* dsteps = c->casc_dsteps;
-    // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests).  Beyond ~0.25 M reads
+    // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests).  Beyond ~0.5 M reads
     // the staged passes' compaction pays for their launches (20 M-read sample, 0.7 M reads of 32-64 nt: 3.17 -> 3.08 ms)
-    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 18);
+    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
     int rc = 0;
     const int big = largest_group(R);
     CHECK(stream_fork(c));
