@@ -748,6 +748,43 @@ def test_integration_md_stub_runs(tmp_path):
     assert (tmp_path / "mapped.csv").read_text() == case.text("mapped.csv")
 
 
+@pytest.mark.parametrize("n", [65535, 65536, 65537, 131073, 300001, 2500000])
+@pytest.mark.parametrize("shape", ["uniform", "zipf", "one_third"])
+def test_partitioned_collapse_sizes_and_skew(ctx, n, shape):
+    """The key path of collapse around its thresholds (global-atomic table below 65536 reads, one radix level up to
+    64 buckets, two levels beyond) on duplicates that are uniform, Zipf-distributed, or one sequence in every third read
+    (the chunk cache of k_part_agg, the append regions and the exact second level all see their worst case): the
+    dictionary -- sequence -> (count, first index) -- must equal numpy's."""
+    rng = np.random.default_rng(n % 1000 + len(shape))
+    n_tmpl = max(n // 3, 1000)
+    lens = rng.integers(16, 32, size=n_tmpl)
+    off = np.zeros(n_tmpl + 1, np.int64); np.cumsum(lens, out=off[1:])
+    tmpl = FlatSeqs(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(off[-1]))], off)
+    if shape == "uniform":
+        idx = rng.integers(0, n_tmpl, size=n)
+    elif shape == "zipf":
+        idx = np.minimum(rng.zipf(1.2, size=n) - 1, n_tmpl - 1)
+    else:
+        idx = np.where(rng.random(n) < 0.33, 7, rng.integers(0, n_tmpl, size=n))
+    reads = tmpl.take(idx)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    u = raw.collapse()
+    cnt, first = u.counts()
+    got_seqs = u.unpack().to_list()
+    # templates may coincide by chance: the expectation goes through the sequences, not the template ids
+    tl = tmpl.to_list()
+    canon = {}
+    key_of = np.empty(n_tmpl, np.int64)
+    for t, sq in enumerate(tl):
+        key_of[t] = canon.setdefault(sq, t)
+    keys = key_of[idx]
+    uk, ufirst, ucnt = np.unique(keys, return_index=True, return_counts=True)
+    want = {tl[k]: (int(c), int(f)) for k, f, c in zip(uk, ufirst, ucnt)}
+    got = {sq: (int(c), int(f)) for sq, c, f in zip(got_seqs, cnt[:, 0], first)}
+    assert len(got_seqs) == len(want) and got == want
+    u.close(); raw.close()
+
+
 @pytest.mark.parametrize("hook", ["MIRGE_TEST_SMALL_PART", "MIRGE_TEST_SMALL_REGION"])
 def test_collapse_partition_overflow_falls_back(tmp_path, hook):
     """A bucket holding more distinct reads than its LDS table raises the overflow flag and the call is redone
