@@ -84,7 +84,8 @@ int mirge_reads_parse(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t 
 int32_t mirge_reads_iupac_seen(const mirge_reads* reads);
 /* The same with the read modifiers the reference runs through cutadapt before it counts a read (digest.py:59-101; SURVEY.md
  * 8f row N4), applied on the device between record finding and the length filter: NextSeq quality trimming, quality
- * trimming, 3' adapter removal, N trimming, unconditional cuts -- in that order, each present when its field says so.
+ * trimming, adapter removal (one 3' or one 5' adapter), N trimming, unconditional cuts -- in that order, each present
+ * when its field says so.
  * count_per_modifier = 1 reproduces the reference's worker at HEAD, which tests the length and counts the read after
  * EVERY modifier (digest.py:354-373); 0 counts the fully trimmed read once.  *n_records stays the number of records of
  * the text.  trim == NULL: mirge_reads_parse.  Restated from cutadapt's published algorithms: parity unpinned. */
@@ -93,7 +94,7 @@ typedef struct mirge_trim {
     int32_t quality_front;    /* -q 5'CUTOFF (0 when only one value is given)                */
     int32_t quality_back;     /* -q 3'CUTOFF (the reference's default: 10), -1 = off         */
     int32_t phred_base;       /* 33 (or 64)                                                  */
-    const char* adapter;      /* -a: 3' adapter, A/C/G/T/N, or NULL                          */
+    const char* adapter;      /* -a: 3' adapter, A/C/G/T/N (or -g, see adapter_front), or NULL */
     int32_t adapter_len;
     int32_t min_overlap;      /* --overlap (3)                                               */
     double error_rate;        /* --error-rate (0.12), of the aligned adapter length          */
@@ -101,6 +102,7 @@ typedef struct mirge_trim {
     int32_t n_cut;            /* -u, up to two values: > 0 from the 5' end, < 0 from the 3'  */
     int32_t cut[2];
     int32_t count_per_modifier;
+    int32_t adapter_front;    /* 1: `adapter` is a 5' adapter (-g): the read keeps what follows it; no N */
 } mirge_trim;
 int mirge_reads_parse_trim(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                            const mirge_trim* trim, mirge_reads** out, int64_t* n_records);

@@ -41,12 +41,12 @@ class MirgeTrim(C.Structure):
     _fields_ = [("nextseq_cutoff", C.c_int32), ("quality_front", C.c_int32), ("quality_back", C.c_int32),
                 ("phred_base", C.c_int32), ("adapter", C.c_char_p), ("adapter_len", C.c_int32), ("min_overlap", C.c_int32),
                 ("error_rate", C.c_double), ("trim_n", C.c_int32), ("n_cut", C.c_int32), ("cut", C.c_int32 * 2),
-                ("count_per_modifier", C.c_int32)]
+                ("count_per_modifier", C.c_int32), ("adapter_front", C.c_int32)]
 
     @staticmethod
     def make(adapter: Optional[str] = None, quality_back: int = -1, quality_front: int = 0, nextseq: int = -1,
              phred_base: int = 33, min_overlap: int = 3, error_rate: float = 0.12, trim_n: bool = False,
-             cut: Sequence[int] = (), count_per_modifier: bool = True) -> "MirgeTrim":
+             cut: Sequence[int] = (), count_per_modifier: bool = True, front: bool = False) -> "MirgeTrim":
         t = MirgeTrim()
         t.nextseq_cutoff, t.quality_front, t.quality_back, t.phred_base = nextseq, quality_front, quality_back, phred_base
         a = adapter.encode() if adapter else None
@@ -57,6 +57,7 @@ class MirgeTrim(C.Structure):
         for k, v in enumerate(cut[:2]):
             t.cut[k] = v
         t.count_per_modifier = 1 if count_per_modifier else 0
+        t.adapter_front = 1 if front else 0
         return t
 
 

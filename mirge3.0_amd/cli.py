@@ -53,6 +53,8 @@ def parse_args(argv=None):
                     help="write isomirs.csv and isomirs.samples.csv (isomiR RPMs and entropies)")
     ap.add_argument("-a", "--adapter", dest="adapters", action="append", default=None,
                     help="3' adapter removed from every read (cutadapt's regular 3' adapter; 'illumina' = TGGAATTCTCGGGTGCCAAGGAACTCCAG)")
+    ap.add_argument("-g", "--front", dest="front", action="append", default=None,
+                    help="5' adapter: the adapter and everything in front of it are removed (cutadapt's regular 5' adapter; one of -a / -g)")
     ap.add_argument("-q", "--quality-cutoff", dest="quality_cutoff", default="10", help="[5'CUTOFF,]3'CUTOFF (default 10, as the reference)")
     ap.add_argument("-nxt", "--nextseq-trim", dest="nextseq_trim", type=int, default=None)
     ap.add_argument("-NX", "--trim-n", dest="trim_n", action="store_true")
@@ -76,7 +78,7 @@ def parse_args(argv=None):
                     help="-ai without bowtie: file of the edited canonical sequences that align to the genome")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted; only -ai's bowtie runs use it")
     ap.add_argument("--device", type=int, default=None)
-    for flag in ("-g", "-qumi", "-nmir", "-bam", "-trf", "-mEC", "-dex"):
+    for flag in ("-qumi", "-nmir", "-bam", "-trf", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -88,7 +90,7 @@ def parse_args(argv=None):
     args.bowtieVersion = "True"
     if (args.AtoI or args.gff_out) and (args.uniq_mol_ids or args.tcf_out or args.save_pkl or args.resume):
         ap.error("-ai / -gff run on the device-resident route: not together with -umi / -tcf / -spl / -rr")
-    args.front = args.qiagenumi = None
+    args.qiagenumi = None
     return args
 
 

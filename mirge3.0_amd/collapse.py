@@ -106,16 +106,19 @@ ILLUMINA_3P = 'TGGAATTCTCGGGTGCCAAGGAACTCCAG'  # what `-a illumina` stands for (
 def trim_from_args(args):
     """The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) as the options of ``mirge_reads_parse_trim``:
     ``-q`` (default "10": quality trimming is ALWAYS in the reference's chain), ``-a`` (one 3' adapter; 'illumina' =
-    the TruSeq small-RNA adapter), ``-nxt``, ``-NX``, ``-u``, ``--overlap``, ``--error-rate``, ``-phr``.  5' adapters
-    (``-g``), several adapters, ``-n > 1`` and ``--action`` other than trim are refused."""
-    if getattr(args, "front", None):
-        raise NotImplementedError("5' adapters (-g) are not part of the MI355X path: only one 3' adapter (-a)")
+    the TruSeq small-RNA adapter) or ``-g`` (one 5' adapter), ``-nxt``, ``-NX``, ``-u``, ``--overlap``, ``--error-rate``,
+    ``-phr``.  Several adapters, ``-n > 1`` and ``--action`` other than trim are refused."""
     adapters = getattr(args, "adapters", None) or []
     if isinstance(adapters, str):
         adapters = [("back", adapters)]
     adapters = [(a if isinstance(a, (tuple, list)) else ("back", a)) for a in adapters]
-    if len(adapters) > 1 or any(kind != "back" for kind, _ in adapters):
-        raise NotImplementedError("one 3' adapter (-a) is supported; several adapters / 5' adapters are not")
+    front = getattr(args, "front", None) or []
+    if isinstance(front, str):
+        front = [front]
+    adapters += [(f if isinstance(f, (tuple, list)) else ("front", f)) for f in front]
+    if len(adapters) > 1 or any(kind not in ("back", "front") for kind, _ in adapters):
+        raise NotImplementedError("one adapter is supported: one 3' adapter (-a) or one 5' adapter (-g), not several")
+    is_front = bool(adapters) and adapters[0][0] == "front"
     adapter = adapters[0][1] if adapters else None
     if adapter == "illumina":
         adapter = ILLUMINA_3P
@@ -139,7 +142,7 @@ def trim_from_args(args):
     return _ffi.MirgeTrim.make(adapter=adapter, quality_back=qb, quality_front=qf, nextseq=-1 if nxt is None else int(nxt),
                                phred_base=base, min_overlap=int(getattr(args, "overlap", 3)),
                                error_rate=float(getattr(args, "error_rate", 0.12)), trim_n=bool(getattr(args, "trim_n", False)),
-                               cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once")
+                               cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once", front=is_front)
 
 
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:

@@ -2,8 +2,8 @@
 // it counts a read (mirge/libs/digest.py:59-101,320-375), on the text in HBM between k_nl_mark and
 // k_seq_class: a record's [start, end) is narrowed, nothing is copied.
 //   modifiers, in the reference's order: NextSeq quality trimming, quality trimming (-q, default 10 at the 3' end),
-//   3' adapter removal (-a; error rate 0.12 of the aligned adapter length, minimum overlap 3, indels allowed), N
-//   trimming at both ends, unconditional cuts (-u).
+//   adapter removal (one 3' adapter, -a, or one 5' adapter, -g; error rate 0.12 of the aligned adapter length, minimum
+//   overlap 3, indels allowed), N trimming at both ends, unconditional cuts (-u).
 //   The reference's worker tests the length and counts the read INSIDE its loop over the modifiers (digest.py:354-373):
 //   a read is counted once after EVERY modifier.  stages_out = number of modifiers reproduces that (virtual record
 //   r * stages_out + s = read r after modifier s); stages_out = 1 keeps only the fully trimmed read.
@@ -17,7 +17,8 @@ struct TrimOpts {
     int32_t nextseq;        // cutoff, -1 = off
     int32_t q_front, q_back;  // q_back -1 = off
     int32_t base;           // 33 / 64
-    int32_t alen;           // 3' adapter length, 0 = none
+    int32_t alen;           // adapter length, 0 = none
+    int32_t front;          // 1: the adapter is a 5' adapter (-g), everything up to its end is removed; N is not accepted in it
     int32_t min_overlap;
     double rate;            // maximum error rate
     int32_t trim_n;
@@ -30,17 +31,21 @@ struct TrimOpts {
 
 // Aligner.locate for a regular 3' adapter on read[0, n): returns the read position where the adapter starts, or n.
 // One DP column lives in registers, one 32-bit entry per adapter row:
-//     cost << 24 | choice << 22 | matches << 15 | origin          (cost, matches <= 64; origin <= 32767)
+//     cost << 24 | choice << 22 | matches << 15 | origin + 64     (cost, matches <= 64; -64 <= origin <= 32703)
 // `choice` is 0 in a stored entry; a mismatching cell takes min3(diagonal, insertion | 1 << 22, deletion | 2 << 22), which is
 // the lowest cost with cutadapt's preference diagonal > insertion > deletion on ties in ONE v_min3_u32, then clears the
 // choice bits and adds one to the cost.  The row loop is fully unrolled (MAXM = 32 covers the adapters in use -- TruSeq
 // small RNA is 29 nt; 64 is the general form, a separate kernel so that the common one keeps its registers).
+// FRONT (a regular 5' adapter): the alignment may also start inside the adapter -- row i starts at cost 0 with origin -i --
+// and must reach the adapter's last base; every column is a candidate end, its aligned adapter length is
+// m + min(origin, 0); returns the read position where the adapter ENDS, or 0.
+#define MIRGE_TRIM_ORIGIN_BIAS 64u
 #define MIRGE_TRIM_COST_SHIFT 24
 #define MIRGE_TRIM_MATCH_ONE (1u << 15)
 #define MIRGE_TRIM_CHOICE_MASK (3u << 22)
 // EXACT: the adapter has exactly MAXM bases and no N -- no per-row predicate is left in the unrolled loop (a kernel per
 // adapter length, 1-64).  Otherwise MAXM is a capacity (64) and rows beyond o.alen / wildcard rows are tested at run time.
-template <int MAXM, bool EXACT>
+template <int MAXM, bool EXACT, bool FRONT>
 __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_t* __restrict__ read, int n) {
     const int m = EXACT ? MAXM : o.alen;
     uint32_t e[MAXM + 1];
@@ -48,22 +53,25 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
     nw[0] = 0;
 #pragma unroll
     for (int i = 0; i <= MAXM; i++) {
-        e[i] = (uint32_t)i << MIRGE_TRIM_COST_SHIFT;
+        e[i] = FRONT ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i : (((uint32_t)i << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
         if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o.wild[i - 1] : 0));
     }
-    int b_mat = -1, b_cost = 0, b_org = 0;
+    int b_mat = -1, b_cost = 0, b_val = 0;
     bool found = false, exact = false;
-    auto consider = [&](uint32_t ent, int i) {
+    // i: adapter rows the entry has passed; j: read column it ends in (FRONT only)
+    auto consider = [&](uint32_t ent, int i, int j) {
         const int cost = (int)(ent >> MIRGE_TRIM_COST_SHIFT), mat = (int)((ent >> 15) & 0x7F);
-        if (i >= o.min_overlap && (double)cost <= (double)(i - nw[i]) * o.rate &&
+        const int origin = (int)(ent & 0x7FFF) - (int)MIRGE_TRIM_ORIGIN_BIAS;
+        const int length = FRONT ? i + (origin < 0 ? origin : 0) : i;
+        if (length >= o.min_overlap && (double)cost <= (double)(length - (FRONT ? 0 : nw[i])) * o.rate &&
             (!found || mat > b_mat || (mat == b_mat && cost < b_cost))) {
-            found = true; b_mat = mat; b_cost = cost; b_org = (int)(ent & 0x7FFF);
+            found = true; b_mat = mat; b_cost = cost; b_val = FRONT ? j : origin;
         }
     };
     for (int j = 1; j <= n && !exact; j++) {
         const uint8_t ch = read[j - 1] & 0xDF;
         uint32_t diag = e[0];
-        e[0] = (uint32_t)j;  // cost 0, matches 0, origin j
+        e[0] = (uint32_t)j + MIRGE_TRIM_ORIGIN_BIAS;  // cost 0, matches 0, origin j
         uint32_t last = e[0];
 #pragma unroll
         for (int i = 1; i <= MAXM; i++) {
@@ -78,20 +86,20 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
                 if (EXACT ? i == MAXM : i == m) last = v;
             }
         }
-        consider(last, m);
+        consider(last, m, j);
         exact = found && b_cost == 0 && b_mat == m;
     }
-    if (!exact) {  // the adapter may run off the read's end: every prefix of it, in the last column
+    if (!exact && !FRONT) {  // the adapter may run off the read's end: every prefix of it, in the last column
 #pragma unroll
         for (int i = 0; i <= MAXM; i++)
-            if (EXACT || i <= m) consider(e[i], i);
+            if (EXACT || i <= m) consider(e[i], i, n);
     }
-    return found ? b_org : n;
+    return found ? b_val : (FRONT ? 0 : n);
 }
 
 // lstart/lend: the sequence line of every record (after '\r' stripping here); qstart: its quality line (FASTQ) or null.
 // vstart/vend[r * stages_out + s]: the read after modifier s (stages_out == n_mods) or after the last one.
-template <int MAXM, bool EXACT>
+template <int MAXM, bool EXACT, bool FRONT>
 __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, const int64_t* __restrict__ lend,
                        const int64_t* __restrict__ qstart, uint32_t n_seq, TrimOpts o, int64_t* __restrict__ vstart,
                        int64_t* __restrict__ vend) {
@@ -99,7 +107,7 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
         int64_t b = lstart[r], e = lend[r];
         if (e > b && text[e - 1] == 13) e--;
         const uint8_t* q = qstart ? text + qstart[r] : nullptr;  // quality of base k of the LINE: q[k]
-        int a0 = 0, a1 = (int)((e - b) > 0x7FFF ? 0x7FFF : (e - b));  // current read = line[a0, a1)
+        int a0 = 0, a1 = (int)((e - b) > 0x7F00 ? 0x7F00 : (e - b));  // current read = line[a0, a1)
         const uint8_t* s = text + b;
         int stage = 0;
         auto emit = [&]() {
@@ -137,7 +145,8 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
             emit();
         }
         if (o.alen > 0) {
-            a1 = a0 + adapter_cut_point<MAXM, EXACT>(o, s + a0, a1 - a0);
+            if (FRONT) a0 = a0 + adapter_cut_point<MAXM, EXACT, true>(o, s + a0, a1 - a0);
+            else a1 = a0 + adapter_cut_point<MAXM, EXACT, false>(o, s + a0, a1 - a0);
             emit();
         }
         if (o.trim_n) {

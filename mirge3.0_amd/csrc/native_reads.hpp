@@ -249,10 +249,12 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
     if (t->adapter_len < 0 || t->adapter_len > MIRGE_TRIM_MAX_ADAPTER || (t->adapter_len > 0 && !t->adapter))
         return fail(-1, "mirge_reads_parse_trim: the 3' adapter must be 1-" + std::to_string(MIRGE_TRIM_MAX_ADAPTER) + " nt");
     o.alen = t->adapter_len;
+    o.front = t->adapter_front ? 1 : 0;
     for (int i = 0; i < o.alen; i++) {
         const char ch = (char)(t->adapter[i] & 0xDF);
         if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N')
             return fail(-1, "mirge_reads_parse_trim: adapter characters other than A/C/G/T/N are not supported");
+        if (ch == 'N' && o.front) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
         o.adapter[i] = (uint8_t)ch; o.wild[i] = ch == 'N';
     }
     if (o.alen && (!(o.rate >= 0.0) || o.rate > 1.0 || o.min_overlap < 1)) return fail(-1, "mirge_reads_parse_trim: error rate / overlap out of range");
@@ -265,8 +267,8 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
     return 0;
 }
 
-// k_trim<M, true>: one kernel per adapter length without N (the unrolled DP rows carry no run-time test);
-// k_trim<64, false>: any adapter of up to 64 bases, N included
+// k_trim<M, true, false>: one kernel per 3' adapter length without N (the unrolled DP rows carry no run-time test);
+// k_trim<64, false, *>: any adapter of up to 64 bases -- a 3' adapter with N, or a 5' adapter
 template <int M>
 static int launch_trim_exact(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, const int64_t* lstart, const int64_t* lend,
                              const int64_t* qstart, uint32_t n_raw, int64_t* dstart, int64_t* dend) {
@@ -274,7 +276,7 @@ static int launch_trim_exact(mirge_ctx* c, const TrimOpts& o, const uint8_t* dte
         return fail(-1, "mirge_reads_parse_trim: adapter length");
     } else {
         if (o.alen == M) {
-            hipLaunchKernelGGL((k_trim<M, true>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+            hipLaunchKernelGGL((k_trim<M, true, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
             return 0;
         }
         return launch_trim_exact<M + 1>(c, o, dtext, lstart, lend, qstart, n_raw, dstart, dend);
@@ -284,8 +286,12 @@ static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, co
                        const int64_t* qstart, uint32_t n_raw, int64_t* dstart, int64_t* dend) {
     bool wild = false;
     for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
+    if (o.front) {  // a 5' adapter is the rare case: the general kernel
+        hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, true>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+        return 0;
+    }
     if (o.alen >= 1 && !wild) return launch_trim_exact<1>(c, o, dtext, lstart, lend, qstart, n_raw, dstart, dend);
-    hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+    hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
     return 0;
 }
 

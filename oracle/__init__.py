@@ -682,9 +682,46 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
     return best
 
 
+def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3):
+    """Aligner.locate for a regular 5' adapter (flags START_WITHIN_SEQ1 | START_WITHIN_SEQ2 | STOP_WITHIN_SEQ2: the
+    alignment may start anywhere in the read AND inside the adapter -- row i of the first column costs 0 and has origin
+    -i -- but must reach the adapter's last base): every read column is a candidate end; aligned adapter length =
+    m + min(origin, 0); same acceptance (cost <= length * max_error_rate, length >= min_overlap) and the same order of
+    preference as the 3' form (most matches, then lowest cost, first found).  No N in the adapter here.
+    -> (astart, astop, rstart, rstop, matches, errors) or None; the read keeps read[rstop:]."""
+    m, n = len(adapter), len(read)
+    assert "N" not in adapter.upper()
+    prev = [(0, 0, -i) for i in range(m + 1)]  # (cost, matches, origin)
+    best = None
+    for j in range(1, n + 1):
+        cur = [(0, 0, j)] + [None] * m
+        for i in range(1, m + 1):
+            d, up, left = prev[i - 1], cur[i - 1], prev[i]
+            if adapter[i - 1] == read[j - 1]:
+                cur[i] = (d[0], d[1] + 1, d[2])
+            else:
+                cd, cdel, cins = d[0] + 1, left[0] + 1, up[0] + 1
+                if cd <= cdel and cd <= cins:
+                    cur[i] = (cd, d[1], d[2])
+                elif cins <= cdel:
+                    cur[i] = (cins, up[1], up[2])
+                else:
+                    cur[i] = (cdel, left[1], left[2])
+        prev = cur
+        cost, matches, origin = cur[m]
+        length = m + min(origin, 0)
+        if length >= min_overlap and cost <= length * max_error_rate and \
+                (best is None or matches > best[4] or (matches == best[4] and cost < best[5])):
+            best = (max(-origin, 0), m, max(origin, 0), j, matches, cost)
+            if cost == 0 and matches == m:
+                break
+    return best
+
+
 def trim_stages(seq: str, qual, opts: dict):
     """The read after each modifier of the chain (digest.py:59-101 builds it in this order): NextSeq quality trimming,
-    quality trimming, 3' adapter removal, N trimming at both ends, unconditional cuts."""
+    quality trimming, adapter removal (a 3' adapter, or with opts["front"] a 5' adapter), N trimming at both ends,
+    unconditional cuts."""
     out = []
     if opts.get("nextseq") is not None and qual is not None:
         stop = nextseq_trim_index(seq, qual, opts["nextseq"], opts.get("base", 33))
@@ -694,7 +731,13 @@ def trim_stages(seq: str, qual, opts: dict):
         a, b = quality_trim_index(qual, opts.get("q_front", 0), opts["q_back"], opts.get("base", 33))
         seq, qual = seq[a:b], qual[a:b]
         out.append(seq)
-    if opts.get("adapter"):
+    if opts.get("adapter") and opts.get("front"):
+        hit = adapter_locate_front(opts["adapter"], seq.upper(), opts.get("error_rate", 0.12), opts.get("overlap", 3))
+        if hit is not None:
+            seq = seq[hit[3]:]
+            qual = qual[hit[3]:] if qual is not None else None
+        out.append(seq)
+    elif opts.get("adapter"):
         hit = adapter_locate_back(opts["adapter"], seq, opts.get("error_rate", 0.12), opts.get("overlap", 3))
         if hit is not None:
             seq = seq[:hit[2]]

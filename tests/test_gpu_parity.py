@@ -1219,6 +1219,62 @@ def test_trimming_equals_the_restated_cutadapt_chain(ctx, opts, per_modifier):
         uniq.close(); raw.close()
 
 
+@pytest.mark.parametrize("per_modifier", [True, False])
+def test_five_prime_adapter_equals_the_restated_search(ctx, per_modifier):
+    """-g: k_trim<64, false, true> against oracle.adapter_locate_front inside the modifier chain -- the adapter whole,
+    with its first bases missing, with a substitution / a missing / an extra base, behind a few other bases, absent, twice,
+    and at the read's end; adapters of several lengths; with quality trimming in front and N trimming + a cut behind."""
+    rng = np.random.default_rng(11 + per_modifier)
+    full = "GTTCAGAGTTCTACAGTCCGACGATCTGGAATTCTCGGGTGCCAAGGAACTCCAGTCACACGTC"
+    for m in (5, 12, 26, 33, 64):
+        ad = full[:m]
+        recs = []
+        for i in range(1500):
+            ins = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(14, 41))))
+            x = list(ad)
+            kind = i % 9
+            if kind == 1:
+                x = x[int(rng.integers(1, max(2, m - 2))):]
+            elif kind == 2 and m > 4:
+                x[int(rng.integers(0, m))] = "ACGT"[int(rng.integers(0, 4))]
+            elif kind == 3 and m > 6:
+                del x[int(rng.integers(1, m - 1))]
+            elif kind == 4 and m > 6:
+                x.insert(int(rng.integers(1, m - 1)), "ACGT"[int(rng.integers(0, 4))])
+            x = "".join(x)
+            if kind == 5:
+                seq = ins
+            elif kind == 6:
+                seq = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(1, 7)))) + x + ins
+            elif kind == 7:
+                seq = x + ins[:10] + x + ins
+            elif kind == 8:
+                seq = ins + x
+            else:
+                seq = x + ins
+            if rng.random() < 0.05:
+                seq = seq + "NN"
+            q = np.full(len(seq), ord("I"), dtype=np.uint8)
+            if rng.random() < 0.2:
+                q[-int(rng.integers(1, 6)):] = 34
+            recs.append((seq, q.tobytes().decode()))
+        text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+        trim = _ffi.MirgeTrim.make(adapter=ad, front=True, quality_back=10, trim_n=True, cut=[-1], count_per_modifier=per_modifier)
+        raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 12, trim)
+        assert n_rec == len(recs)
+        uniq = raw.collapse()
+        cnt, first = uniq.counts()
+        seqs = uniq.unpack().to_list()
+        order = np.argsort(first, kind="stable")
+        got = [(seqs[i], int(cnt[i, 0])) for i in order]
+        want = oracle.trimmed_counts(recs, dict(q_back=10, adapter=ad, front=True, trim_n=True, cut=[-1]), 12, per_modifier)
+        assert got == list(want.items()), m
+        assert len(got) > 800
+        uniq.close(); raw.close()
+    with pytest.raises(RuntimeError):
+        _ffi.DeviceReads.parse(ctx, b"@r\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n", 1, 12, _ffi.MirgeTrim.make(adapter="ACGNT", front=True))
+
+
 def test_trimming_300_cycle_lines_and_every_adapter_length(ctx):
     """Lines longer than 255 characters (the origin column of the DP entry is 15 bits wide, the packed read still <= 255 nt
     after trimming) and one adapter of every length 1-64 (k_trim<M, true> is a kernel per length; with an N the general

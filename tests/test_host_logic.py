@@ -137,7 +137,11 @@ def test_cli_flags_in_and_out_of_scope():
     assert d.adapter_len == 0 and d.quality_back == 10 and d.count_per_modifier == 1
     with pytest.raises(NotImplementedError):
         trim_from_args(parse_args(base + ["-a", "AAAA", "-a", "CCCC"]))
-    for bad in (["-udd"], ["-qumi"], ["-g", "ACGT"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"]):
+    g = trim_from_args(parse_args(base + ["-g", "GTTCAGAGTTCTACAGTCCGACGATC", "--overlap", "5"]))  # one 5' adapter
+    assert g.adapter_front == 1 and g.adapter == b"GTTCAGAGTTCTACAGTCCGACGATC" and g.min_overlap == 5 and tr.adapter_front == 0
+    with pytest.raises(NotImplementedError):  # AdapterCutter would pick the better of the two per read: not built
+        trim_from_args(parse_args(base + ["-a", "AAAA", "-g", "CCCC"]))
+    for bad in (["-udd"], ["-qumi"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"]):
         with pytest.raises(SystemExit):
             parse_args(base + bad)
 

@@ -1,0 +1,67 @@
+"""Known-answer tests of the oracle's restatement of cutadapt's adapter search (oracle.adapter_locate_back / _front):
+the cases of cutadapt's user guide for a regular 3' adapter (-a) and a regular 5' adapter (-g), written with DNA letters.
+cutadapt itself is absent from the image, so these pin the restatement to the published behaviour, not to the program
+(parity of row N4 is unpinned)."""
+import numpy as np
+
+import oracle
+
+AD = "TGGAATTCTCGG"  # 12 nt: floor(12 * 0.12) = 1 error over the full length, 0 over a part of up to 8 nt
+INS = "ACGTTGCATCAGGCATTACG"  # shares no 3-mer run with the adapter's ends
+
+
+def back(read, **kw):
+    hit = oracle.adapter_locate_back(AD, read, kw.get("rate", 0.12), kw.get("overlap", 3))
+    return read if hit is None else read[:hit[2]]
+
+
+def front(read, **kw):
+    hit = oracle.adapter_locate_front(AD, read, kw.get("rate", 0.12), kw.get("overlap", 3))
+    return read if hit is None else read[hit[3]:]
+
+
+def test_regular_three_prime_adapter_cases():
+    assert back(INS + AD) == INS                       # full adapter at the end
+    assert back(INS + AD + "AAAC") == INS              # full adapter inside: it and what follows go
+    assert back(INS + AD[:5]) == INS                   # partial adapter at the end
+    assert back(INS + AD[:2]) == INS + AD[:2]          # ... shorter than the minimum overlap: kept
+    assert back(AD + INS) == ""                        # adapter at the start: nothing is left
+    one = AD[:6] + "A" + AD[7:]                        # one substitution in the full adapter: within 12 % of 12
+    assert back(INS + one + "CC") == INS
+    two = one[:2] + "T" + one[3:]
+    assert back(INS + two + "CC") == INS + two + "CC"  # two errors: not an occurrence
+    assert back(INS + AD[:3] + AD[4:] + "CC") == INS   # one deleted adapter base
+    assert back(INS) == INS
+
+
+def test_regular_five_prime_adapter_cases():
+    assert front(AD + INS) == INS                      # full adapter at the start
+    assert front(AD[4:] + INS) == INS                  # partial adapter at the start (its first bases are missing)
+    assert front("CCA" + AD + INS) == INS              # full adapter inside: it and what precedes it go
+    assert front(AD[-2:] + INS) == AD[-2:] + INS       # two bases of overlap: below the minimum, kept
+    assert front(INS + AD) == ""                       # adapter at the end: everything up to its end goes
+    assert front(INS + AD[:6]) == INS + AD[:6]         # a 5' adapter must reach its last base
+    one = AD[:6] + "A" + AD[7:]
+    assert front(one + INS) == INS                     # one substitution over the full length
+    assert front(one[5:] + INS) == one[5:] + INS       # ... but none allowed over 7 aligned bases (7 * 0.12 < 1)
+    assert front("CCA" + AD[:3] + AD[4:] + INS) == INS  # one deleted adapter base
+    assert front(INS) == INS
+
+
+def test_first_exact_occurrence_wins_for_both_kinds():
+    rng = np.random.default_rng(3)
+    ad = "TGGAATTCTCGGGTGCCAAGGAACTCCAG"
+    for _ in range(200):
+        a = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(5, 40))))
+        b = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(5, 40))))
+        read = a + ad + b + ad + a
+        hit = oracle.adapter_locate_back(ad, read)
+        assert hit is not None and hit[2] == len(a) and hit[4] == len(ad) and hit[5] == 0
+        hit = oracle.adapter_locate_front(ad, read)
+        assert hit is not None and hit[3] == len(a) + len(ad) and hit[4] == len(ad) and hit[5] == 0
+
+
+def test_trim_stages_with_a_five_prime_adapter():
+    read = "CC" + AD + INS + "NN"
+    stages = oracle.trim_stages(read, "I" * len(read), dict(q_back=10, adapter=AD, front=True, trim_n=True, cut=[-2]))
+    assert stages == [read, INS + "NN", INS, INS[:-2]]
