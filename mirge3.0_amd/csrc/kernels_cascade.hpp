@@ -402,18 +402,28 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
 }
 
 // global position -> (reference index, offset) by binary search in ref_start of the pass's library
+// coarse[b] = last reference that starts at or before position b << MIRGE_COARSE_SHIFT: the reference of a position in
+// block b lies in [coarse[b], coarse[b + 1]], two or three candidates instead of a 12-17-step search through ref_start
+// (k_resolve spent 3 lane-level cache accesses per read on it: profiles/r02_mem_counters.txt)
+#define MIRGE_COARSE_SHIFT 6
 struct ResolveTable {
     const uint32_t* ref_start[MIRGE_MAX_PASSES_K];
+    const uint32_t* coarse[MIRGE_MAX_PASSES_K];
     uint32_t n_refs[MIRGE_MAX_PASSES_K];
 };
 
 __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint32_t g, int32_t& ref, int32_t& off) {
     const uint32_t* rs = nullptr;
+    const uint32_t* cs = nullptr;
     uint32_t nr = 0;
 #pragma unroll
     for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
-        if (q == p) { rs = tb.ref_start[q]; nr = tb.n_refs[q]; }
+        if (q == p) { rs = tb.ref_start[q]; cs = tb.coarse[q]; nr = tb.n_refs[q]; }
     uint32_t lo = 0, hi = nr;  // last t with rs[t] <= g
+    if (cs) {
+        const PairU32 c = load_pair32((gptr_u32)cs + (g >> MIRGE_COARSE_SHIFT));
+        lo = c.a; hi = c.b + 1;
+    }
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
         if (rs[mid] <= g) lo = mid; else hi = mid;

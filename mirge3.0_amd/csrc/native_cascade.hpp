@@ -220,7 +220,7 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
 // one (libraries, policies, read-length set) configuration
 static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass,
                            const int32_t* hist, std::vector<PassStep>& steps, ResolveTable& rt, const FusedSteps** dsteps_out) {
-    for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.n_refs[p] = 0; }
+    for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.coarse[p] = nullptr; rt.n_refs[p] = 0; }
     steps.clear();
     for (int32_t p = 0; p < n_pass; p++) {
         if (!libs[p]) continue;
@@ -228,6 +228,7 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         if (pol[p].mm < 0 || pol[p].mm > 3 || pol[p].trim5 < 0 || pol[p].trim5 > 31 || pol[p].trim3 < 0)
             return fail(-1, "unsupported policy");
         rt.ref_start[p] = libs[p]->dref_start;
+        rt.coarse[p] = libs[p]->dcoarse;
         rt.n_refs[p] = (uint32_t)libs[p]->n_refs;
     }
     for (int32_t p = 0; p < n_pass;) {

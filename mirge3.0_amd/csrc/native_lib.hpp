@@ -13,6 +13,7 @@ struct mirge_lib {
     uint64_t* dT = nullptr;
     uint64_t* dinv = nullptr;
     uint32_t* dref_start = nullptr;
+    uint32_t* dcoarse = nullptr;               // [(total >> MIRGE_COARSE_SHIFT) + 2]: see ResolveTable
     MirgeKTable* dtables = nullptr;           // [MIRGE_SHAPE_SLOTS] on the device
     std::vector<MirgeKTable> htables;          // host mirror (device pointers), by mirge_shape_id
     size_t device_bytes = 0;
@@ -49,7 +50,20 @@ extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* of
     HIPOK(hipMemcpy(L->dinv, L->h.inv.data(), nI, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(L->dref_start, L->h.ref_start.data(), nR, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(L->dtables, L->htables.data(), sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS, hipMemcpyHostToDevice));
-    L->device_bytes = nT + nI + nR + sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS;
+    size_t nC = 0;
+    if (n_refs > 0) {  // coarse[b] = last reference starting at or before b << MIRGE_COARSE_SHIFT
+        std::vector<uint32_t> coarse((size_t)(L->h.total >> MIRGE_COARSE_SHIFT) + 2);
+        uint32_t t = 0;
+        for (size_t b = 0; b < coarse.size(); b++) {
+            const uint64_t x = (uint64_t)b << MIRGE_COARSE_SHIFT;
+            while ((int64_t)t + 1 < n_refs && L->h.ref_start[(size_t)t + 1] <= x) t++;
+            coarse[b] = t;
+        }
+        nC = coarse.size() * 4;
+        HIPOK(hipMalloc((void**)&L->dcoarse, nC));
+        HIPOK(hipMemcpy(L->dcoarse, coarse.data(), nC, hipMemcpyHostToDevice));
+    }
+    L->device_bytes = nT + nI + nR + nC + sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS;
     *out = L.release();
     return 0;
 }
@@ -58,7 +72,7 @@ extern "C" void mirge_lib_destroy(mirge_lib* L) {
     if (!L) return;
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
-    (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dtables);
+    (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dcoarse); (void)hipFree(L->dtables);
     for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); (void)hipFree((void*)t.bits); }
     delete L;
 }
