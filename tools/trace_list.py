@@ -1,3 +1,5 @@
+"""List the long launches (> 2 ms) and every launch of the isomiR pass of a rocprofv3 --kernel-trace run, in time order:
+python tools/trace_list.py gpurun_out/<dir>   (used to find the one 28 ms launch of profiles/r02_kernel_stats.csv)"""
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
