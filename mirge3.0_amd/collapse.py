@@ -79,6 +79,27 @@ def read_text(path: str) -> bytes:
     return data
 
 
+def read_texts(paths, depth: int = 4):
+    """``read_text`` of every file, in order, read ahead by up to ``depth`` files on worker threads: gunzipping a sample
+    (zlib releases the GIL) then runs beside the previous sample's transfer and parse, and several .gz samples inflate
+    on several cores -- a single inflate stream is the slowest stage of a run from compressed FASTQ."""
+    from concurrent.futures import ThreadPoolExecutor
+    paths = [str(p) for p in paths]
+    if len(paths) <= 1:
+        for p in paths:
+            yield read_text(p)
+        return
+    with ThreadPoolExecutor(max_workers=max(1, min(depth, len(paths)))) as pool:
+        pending = [pool.submit(read_text, p) for p in paths[:depth]]
+        nxt = len(pending)
+        while pending:
+            text = pending.pop(0).result()
+            if nxt < len(paths):
+                pending.append(pool.submit(read_text, paths[nxt]))
+                nxt += 1
+            yield text
+
+
 def unwrap_fasta(data: bytes) -> bytes:
     """FASTA text -> one sequence line per record.  A newline stays when it ends a header line or when the next line
     is a header (or the text ends); every other newline (and '\\r') sits inside a sequence and is dropped."""
@@ -210,10 +231,11 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
     device_parse = not umi
     uniq = None
     parsed: List[_ffi.DeviceReads] = []
+    texts = read_texts(inFileArray) if device_parse else None  # read (and gunzipped) ahead on worker threads
     for FQfile, name in zip(inFileArray, inFileBaseArray):
         start = time.perf_counter()
         if device_parse:
-            raw, n_rec = _ffi.DeviceReads.parse(ctx, read_text(str(FQfile)), 0, min_len, trim)
+            raw, n_rec = _ffi.DeviceReads.parse(ctx, next(texts), 0, min_len, trim)
             sampleReadCounts[name] = n_rec
             trimmedReadCounts[name] = len(raw)
             parsed.append(raw)

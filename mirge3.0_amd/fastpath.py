@@ -22,7 +22,7 @@ import numpy as np
 
 from . import PASS_COLUMNS, _ffi
 from .cascade import PASSES, get_cascade
-from .collapse import read_text, trim_from_args
+from .collapse import read_text, read_texts, trim_from_args
 from .countjoin import summarize_device
 from .seqio import FlatSeqs, load_merges
 
@@ -99,9 +99,10 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     parsed = []
     t_read = t_parse = 0.0
+    texts = read_texts(files)  # files are read (and gunzipped) ahead on worker threads
     for f, name in zip(files, base_names):
         t = time.perf_counter()
-        text = read_text(str(f))
+        text = next(texts)
         t_read += time.perf_counter() - t
         t1 = time.perf_counter()
         raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 0, min_len, trim)

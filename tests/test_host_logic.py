@@ -207,3 +207,25 @@ def test_gff_name_resolution_tables(tmp_path):
     fa = tmp_path / "m.fa"
     fa.write_text(">a\nACGT\n>b desc\nGG\nTT\n")
     assert gff.read_mature_fasta(fa) == {"a": "ACGT", "b desc": "TT"}
+
+
+def test_read_texts_keeps_file_order_and_inflates_gz(tmp_path):
+    """collapse.read_texts: the files' bytes in the order given, whatever the worker threads' finishing order; .gz inflated,
+    wrapped FASTA unwrapped, an empty file an empty text."""
+    import gzip
+    from mirge3_amd.collapse import read_texts, read_text
+    paths, want = [], []
+    for k in range(7):
+        body = b"".join(b"@r%d\nACGT%s\n+\nIIII%s\n" % (i, b"A" * (k + i % 3), b"I" * (k + i % 3)) for i in range(50 * (7 - k)))
+        p = tmp_path / (f"s{k}.fastq.gz" if k % 2 else f"s{k}.fastq")
+        if k % 2:
+            with gzip.open(p, "wb") as fh:
+                fh.write(body)
+        else:
+            p.write_bytes(body)
+        paths.append(p); want.append(body)
+    fa = tmp_path / "w.fa"; fa.write_bytes(b">a\nACGT\nACGT\n>b\nTT\n"); paths.append(fa); want.append(b">a\nACGTACGT\n>b\nTT\n")
+    empty = tmp_path / "e.fastq"; empty.write_bytes(b""); paths.append(empty); want.append(b"")
+    got = [bytes(t) for t in read_texts(paths, depth=3)]
+    assert got == want
+    assert [bytes(t) for t in read_texts(paths[:1])] == want[:1] and bytes(read_text(str(paths[1]))) == want[1]
