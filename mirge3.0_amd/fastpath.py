@@ -51,6 +51,17 @@ def row_order(seqs: FlatSeqs, first: np.ndarray, n_samples: int) -> np.ndarray:
     return np.argsort(mat.view(f"S{width}").reshape(-1), kind="stable")
 
 
+def names_by_pass(casc) -> list:
+    """Reference names of every pass's library as flat arrays (what ``mirge_annotation_csv`` prints from); built once per
+    cascade -- a human library set holds ~0.2 M names, and joining them costs as much as formatting a sample's table."""
+    cached = getattr(casc, "_names_by_pass", None)
+    if cached is None:
+        cached = [FlatSeqs.from_list(casc.libs[PASSES[p][1]].names) if PASSES[p][1] in casc.libs else None
+                  for p in range(casc.n_pass)]
+        casc._names_by_pass = cached
+    return cached
+
+
 def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None):
     """One sample on this process's GPU, for the sharded CLI (one sample per rank, multigpu.py): device-resident parse ->
     collapse + cascade -> count join; writes ``mapped.<name>.csv`` / ``unmapped.<name>.csv`` and returns the sample's
@@ -70,10 +81,8 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     ps, ref, _, _ = res.fetch()
     n_cols = 10 if args.spikeIn else 9
     header = ",".join(["Sequence", "annotFlag"] + PASS_COLUMNS[:n_cols] + [name]) + "\n"
-    names_by_pass = [FlatSeqs.from_list(casc.libs[PASSES[p][1]].names) if PASSES[p][1] in casc.libs else None
-                     for p in range(casc.n_pass)]
     _ffi.annotation_csv(workDir / f"mapped.{name}.csv", workDir / f"unmapped.{name}.csv", header, seqs, ps, ref, counts,
-                        row_order(seqs, first, 1), list(range(casc.n_pass)), n_cols, names_by_pass)
+                        row_order(seqs, first, 1), list(range(casc.n_pass)), n_cols, names_by_pass(casc))
     out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
     res.close(); uniq.close()
     return out
@@ -148,12 +157,8 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     n_cols = 10 if args.spikeIn else 9  # bwtAlign drops the 'spike-in' column when -spk is off (manifoldAlign.py:137-138)
     cols = PASS_COLUMNS[:n_cols]
     header = ",".join(["Sequence", "annotFlag"] + cols + list(base_names)) + "\n"
-    names_by_pass = []
-    for p in range(casc.n_pass):
-        key = PASSES[p][1]
-        names_by_pass.append(FlatSeqs.from_list(casc.libs[key].names) if key in casc.libs else None)
     _ffi.annotation_csv(workDir / "mapped.csv", workDir / "unmapped.csv", header, seqs, ps, ref, counts, order,
-                        list(range(casc.n_pass)), n_cols, names_by_pass)
+                        list(range(casc.n_pass)), n_cols, names_by_pass(casc))
     tm["per_read_csv_s"] = time.perf_counter() - t
     if getattr(args, "gff_out", False):  # -gff (summary.py:800-837)
         from .gff import write_gff
