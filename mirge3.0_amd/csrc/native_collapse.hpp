@@ -20,6 +20,9 @@ struct CollapseTmp {
     uint64_t slab = 0;
 };
 // dmeta: [0..7] U of each group, [8] partition overflow flag, [16 .. 16+255] length histogram
+#ifndef MIRGE_PART_RETRY_BYTES
+#define MIRGE_PART_RETRY_BYTES (64ull << 30)  // memory the second partitioned attempt may take (2 KiB per read)
+#endif
 #define MIRGE_META_OVERFLOW 8
 #define MIRGE_META_HIST 16
 #define MIRGE_META_WORDS (MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1)
@@ -67,7 +70,11 @@ static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGro
 
 template <int W>
 static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t,
-                            const int32_t* dsample, int32_t S, uint32_t* dmeta, bool force_atomic, int stage = 0) {
+                            const int32_t* dsample, int32_t S, uint32_t* dmeta, int attempt, int stage = 0) {
+    // attempt 0: partitioned key path, level-1 regions sized for a uniform hash; 1: the same with regions as large as a
+    // writer's chunk (nothing can overflow them: a burst of one sequence that arrives after the chunk cache has filled
+    // then costs memory -- 1 KiB per read -- not the global-atomic path); 2: global-atomic tables
+    const bool force_atomic = attempt >= 2 || (attempt == 1 && (uint64_t)in.n * 2048ull > MIRGE_PART_RETRY_BYTES);
     // stage 0 = everything; 1 = only the first kernel of the partitioned path; 2 = what stage 1 left
     if (!in.n) return 0;
     if (stage == 2 && t.partitioned) return collapse_part_rest(c, gi, in, out, t, dmeta, 2);
@@ -124,7 +131,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         const uint32_t W2 = NB2 > 1 ? std::min<uint32_t>(MIRGE_PART_W2, G) : 1, RPW = (G + W2 - 1) / W2;
         // test hook: MIRGE_TEST_SMALL_REGION=1 halves the level-1 regions so that they overflow and the call falls back
         static const bool small_region = std::getenv("MIRGE_TEST_SMALL_REGION") != nullptr;
-        const uint32_t cap1 = small_region ? std::max<uint32_t>(4, chunk / NB1 / 2 & ~3u) : part_region_cap((double)chunk / NB1);
+        const uint32_t cap1 = attempt == 1 ? chunk
+                                           : small_region ? std::max<uint32_t>(4, chunk / NB1 / 2 & ~3u) : part_region_cap((double)chunk / NB1);
         const uint64_t slab = (uint64_t)RPW * cap1;  // a splitter's input can never exceed the capacity of its regions
         CHECK(dalloc(c, &t.rec1, (size_t)NB1 * G * cap1));
         CHECK(dalloc(c, &t.cnt1, (size_t)NB1 * G));
@@ -261,9 +269,9 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
     CollapseTmp tmp[MIRGE_NGROUPS];
     int rc = 0;
     const int big = largest_group(raw);
-    // attempt 0 may use the partitioned LDS path; if one of its buckets overflows its LDS table
-    // (pathological hash skew) everything is redone with the global-atomic tables
-    for (int attempt = 0; attempt < 2 && rc == 0; attempt++) {
+    // attempts 0 and 1 may use the partitioned LDS path (collapse_phase_a); if a level-1 region (attempt 0) or a bucket's
+    // LDS table (pathological hash skew) overflows, everything is redone -- at last with the global-atomic tables
+    for (int attempt = 0; attempt < 3 && rc == 0; attempt++) {
         hipError_t e0 = hipMemsetAsync(dmeta, 0, MIRGE_META_WORDS * 4, c->stream);
         if (e0 != hipSuccess) { rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e0)); break; }
         rc = stream_fork(c);
@@ -277,7 +285,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
             const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
             c->cur = gi == big ? c->stream : c->aux;
-            MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt == 1, stage));
+            MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage));
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         hc.lap("enqueue A");
@@ -294,7 +302,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         }
         if (hooked && (rc != 0 || c->pinned[MIRGE_META_OVERFLOW])) { hook->discard(); hooked = false; }
         if (hook) hook->ran = hooked;
-        if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt == 0) {
+        if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt < 2) {
             for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
                 collapse_tmp_release(c, tmp[gi]);
                 ReadGroup& og = R->g[gi];  // outputs the partitioned attempt had allocated at capacity n

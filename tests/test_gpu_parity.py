@@ -749,11 +749,12 @@ def test_integration_md_stub_runs(tmp_path):
 
 
 @pytest.mark.parametrize("n", [65535, 65536, 65537, 131073, 300001, 2500000])
-@pytest.mark.parametrize("shape", ["uniform", "zipf", "one_third"])
+@pytest.mark.parametrize("shape", ["uniform", "zipf", "one_third", "burst"])
 def test_partitioned_collapse_sizes_and_skew(ctx, n, shape):
     """The key path of collapse around its thresholds (global-atomic table below 65536 reads, one radix level up to
-    64 buckets, two levels beyond) on duplicates that are uniform, Zipf-distributed, or one sequence in every third read
-    (the chunk cache of k_part_agg, the append regions and the exact second level all see their worst case): the
+    64 buckets, two levels beyond) on duplicates that are uniform, Zipf-distributed, one sequence in every third read, or
+    bursts of one sequence behind distinct reads (the chunk cache of k_part_agg, the append regions -- overflowing in the
+    last case -- and the exact second level all see their worst case): the
     dictionary -- sequence -> (count, first index) -- must equal numpy's."""
     rng = np.random.default_rng(n % 1000 + len(shape))
     n_tmpl = max(n // 3, 1000)
@@ -764,8 +765,15 @@ def test_partitioned_collapse_sizes_and_skew(ctx, n, shape):
         idx = rng.integers(0, n_tmpl, size=n)
     elif shape == "zipf":
         idx = np.minimum(rng.zipf(1.2, size=n) - 1, n_tmpl - 1)
-    else:
+    elif shape == "one_third":
         idx = np.where(rng.random(n) < 0.33, 7, rng.integers(0, n_tmpl, size=n))
+    else:  # every writer's chunk starts with distinct reads (its cache fills) and ends with a burst of ONE sequence: the
+        # burst's copies are records of their own, all for one level-1 region -> it overflows, the call is redone with
+        # chunk-sized regions (collapse_phase_a, attempt 1)
+        idx = rng.integers(0, n_tmpl, size=n)
+        chunk = max(n // 256, 2048)
+        pos = np.arange(n) % chunk
+        idx[pos >= chunk // 2] = 11
     reads = tmpl.take(idx)
     raw = _ffi.DeviceReads.pack(ctx, reads)
     u = raw.collapse()

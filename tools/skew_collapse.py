@@ -20,3 +20,20 @@ for name, idx in (("uniform", rng.integers(0, 30_000, size=n)),
         u.close(); best = min(best, dt)
     print(f"{name:10s} reads {len(raw)} unique {nu} collapse {best*1e3:.3f} ms")
     raw.close()
+
+# bursts of one <= 31-nt sequence behind distinct reads, in every writer's chunk: the level-1 regions of the partitioned
+# key path overflow and the call is redone with chunk-sized regions
+n = 10_000_000
+tm = rng.integers(0, 4, size=(n // 2, 22), dtype=np.uint8)
+idx = rng.integers(0, n // 2, size=n)
+chunk = n // 256
+idx[(np.arange(n) % chunk) >= chunk // 2] = 11
+from mirge3_amd.seqio import FlatSeqs
+seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[tm[idx]]
+reads = FlatSeqs(seqs.reshape(-1).copy(), np.arange(n + 1, dtype=np.int64) * 22)
+raw = _ffi.DeviceReads.pack(ctx, reads)
+best = 1e9
+for _ in range(4):
+    t0 = time.perf_counter(); u = raw.collapse(); nu = len(u); dt = time.perf_counter() - t0
+    u.close(); best = min(best, dt)
+print(f"burst      reads {n} unique {nu} collapse {best*1e3:.3f} ms")
