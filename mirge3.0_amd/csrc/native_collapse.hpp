@@ -20,6 +20,9 @@ struct CollapseTmp {
     uint64_t slab = 0;
 };
 // dmeta: [0..7] U of each group, [8] partition overflow flag, [16 .. 16+255] length histogram
+#ifndef MIRGE_PART_CACHE
+#define MIRGE_PART_CACHE 4096  // slots of the chunk cache of k_part_agg (2048: 3 % more records for split and dedup on the default sample)
+#endif
 #ifndef MIRGE_PART_RETRY_BYTES
 #define MIRGE_PART_RETRY_BYTES (64ull << 30)  // memory the second partitioned attempt may take (2 KiB per read)
 #endif
@@ -106,7 +109,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         // (a bucket of up to MIRGE_PART_SMALL reads + 8 sigma stays below the 2048 - 64 distinct keys that table takes)
         t.cap = (!small_part && (uint64_t)B * MIRGE_PART_SMALL >= in.n) ? 2048u : (uint32_t)MIRGE_PART_CAP;
         const uint32_t NB1 = std::min<uint32_t>(B, MIRGE_PART_B1), NB2 = B / NB1;
-        const uint32_t CS = B > 16384 ? 1024 : 2048;  // chunk-level LDS cache slots (16 B each)
+        const uint32_t CS = B > 16384 ? 1024 : MIRGE_PART_CACHE;  // chunk-level LDS cache slots (16 B each)
         const int agg_lds = (int)(CS * 16 + NB1 * 4 + (NB2 > 1 ? B * 4 : 0) + 64);
         // dynamic-LDS ceilings, raised once per process and device to the largest configuration (B = 32768)
         static std::mutex attr_mu;
