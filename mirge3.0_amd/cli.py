@@ -78,6 +78,21 @@ def parse_args(argv=None):
                     help="-ai without bowtie: file of the edited canonical sequences that align to the genome")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted; only -ai's bowtie runs use it")
     ap.add_argument("--device", type=int, default=None)
+    # flags of mirge/libs/parse.py that the reference itself never reads (-M, -l, --gc-content, -cms, --compression-level,
+    # -op, --numba-*), that only size its worker chunks (--buffer-size), that name tools or carry parameters of the
+    # subsystems refused below (-psam, -prf, -mdt, -kh/-ks/-ke, -minl ... -clc), or that it fills in itself (-cuv, -buv):
+    # accepted and ignored, so that a reference command line keeps working
+    for flags in (("-M", "--maximum-length"), ("-l", "--length"), ("--gc-content",), ("-cms", "--chunkmbs"), ("--compression-level",),
+                  ("-op", "--output"), ("--buffer-size",), ("-cuv", "--cutadaptVersion"), ("-buv", "--bowtieVersion"),
+                  ("-psam", "--samtools-path"), ("-prf", "--RNAfold-path"), ("-mdt", "--metadata"), ("-kh", "--threshold"),
+                  ("-ks", "--kmer-start"), ("-ke", "--kmer-end"), ("-minl", "--minLength"), ("-maxl", "--maxLength"),
+                  ("-c", "--minReadCounts"), ("-mloc", "--maxMappingLoci"), ("-sl", "--seedLength"), ("-olc",), ("-clc",)):
+        ap.add_argument(*flags, dest="ignored_" + flags[0].strip("-").replace("-", "_"), default=None, help=argparse.SUPPRESS)
+    for flag in ("--numba-pll", "--numba-cuda"):
+        ap.add_argument(flag, dest="ignored_" + flag.strip("-").replace("-", "_"), action="store_true", help=argparse.SUPPRESS)
+    # cutadapt's adapter options: the defaults are what k_trim implements; anything else is refused, not ignored
+    ap.add_argument("-n", "--times", dest="times", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--action", dest="action", default="trim", help=argparse.SUPPRESS)
     for flag in ("-qumi", "-nmir", "-bam", "-trf", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
@@ -85,6 +100,8 @@ def parse_args(argv=None):
     for k, v in vars(args).items():
         if k.startswith("oos_") and v is not None:
             ap.error(f"-{k[4:]} belongs to a miRge3.0 subsystem outside the MI355X hot path (DESIGN.md section 0)")
+    if args.times != 1 or args.action != "trim":
+        ap.error("-n / --action: only cutadapt's defaults (one adapter occurrence, removed) are part of the MI355X path")
     if args.umiDedup and not args.uniq_mol_ids:
         ap.error("-udd requires -umi f,b")
     args.bowtieVersion = "True"

@@ -141,7 +141,12 @@ def test_cli_flags_in_and_out_of_scope():
     assert g.adapter_front == 1 and g.adapter == b"GTTCAGAGTTCTACAGTCCGACGATC" and g.min_overlap == 5 and tr.adapter_front == 0
     with pytest.raises(NotImplementedError):  # AdapterCutter would pick the better of the two per read: not built
         trim_from_args(parse_args(base + ["-a", "AAAA", "-g", "CCCC"]))
-    for bad in (["-udd"], ["-qumi"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"]):
+    # flags the reference never reads, or that belong to tools / subsystems outside the path: accepted, ignored
+    k = parse_args(base + ["-M", "40", "-l", "3", "--gc-content", "50", "-cms", "256", "--buffer-size", "4000000", "-cuv", "2.7",
+                           "-psam", "/opt/samtools", "-minl", "16", "-olc", "14", "--numba-pll", "-n", "1", "--action", "trim"])
+    assert k.minimum_length == 16 and k.adapters is None
+    for bad in (["-udd"], ["-qumi"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"], ["-n", "2"], ["--action", "mask"],
+                ["--no-indels"], ["--match-read-wildcards"]):
         with pytest.raises(SystemExit):
             parse_args(base + bad)
 
