@@ -17,9 +17,16 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     HIPOK(hipSetDevice(c->device));
     const int32_t S = U->n_samples, P = res->n_pass;
     const size_t n_cls = (size_t)P * S, n_tab = (size_t)std::max<int64_t>(n_mirna, 1) * S;
-    unsigned long long* d = nullptr;
-    CHECK(dalloc(c, &d, n_cls + 2 * n_tab));
-    HIPOK(hipMemsetAsync(d, 0, (n_cls + 2 * n_tab) * 8, c->stream));
+    const size_t words = n_cls + 2 * n_tab;
+    if (c->join_dev_words < words) {
+        if (c->join_dev) { HIPOK(hipStreamSynchronize(c->stream)); (void)hipFree(c->join_dev); }
+        c->join_dev = nullptr; c->join_dev_words = 0; c->join_dev_clean = false;
+        HIPOK(hipMalloc((void**)&c->join_dev, words * 8));
+        c->join_dev_words = words;
+    }
+    unsigned long long* d = c->join_dev;
+    if (!c->join_dev_clean) HIPOK(hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream));
+    c->join_dev_clean = false;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
         if (!g.n) continue;
@@ -28,7 +35,6 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
                            U->g[gi].counts, g.n, S, P, exact_pass, iso_pass, d, d + n_cls, d + n_cls + n_tab);
     }
     // one device-to-host copy through pinned memory for all three tables (they are contiguous)
-    const size_t words = n_cls + 2 * n_tab;
     if (words * 8 > c->join_pinned_bytes) {
         if (c->join_pinned) (void)hipHostFree(c->join_pinned);
         c->join_pinned = nullptr; c->join_pinned_bytes = 0;
@@ -36,14 +42,17 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
         c->join_pinned_bytes = words * 8 * 2;
     }
     HIPOK(hipMemcpyAsync(c->join_pinned, d, words * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));
+    HIPOK(hipEventRecord(c->ev_meta, c->stream));
+    // cleared for the next call now, behind the copy: the host waits for the copy only
+    const bool cleared = hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream) == hipSuccess;
+    HIPOK(hipEventSynchronize(c->ev_meta));
+    c->join_dev_clean = cleared;
     std::memcpy(class_sums, c->join_pinned, n_cls * 8);
     if (n_mirna) {
         std::memcpy(exact, c->join_pinned + n_cls, (size_t)n_mirna * S * 8);
         std::memcpy(iso, c->join_pinned + n_cls + n_tab, (size_t)n_mirna * S * 8);
     }
     c->drain();
-    c->release(d);
     return 0;
 }
 
