@@ -162,15 +162,29 @@ extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mir
     TallyOut o;
     o.n_seqs = d; o.seq_true = d + n_fs; o.count_true = d + 2 * n_fs; o.canon = d + 3 * n_fs; o.kept_exact = d + 4 * n_fs;
     o.census = d + 5 * n_fs; o.diag = ddiag; o.state = dstate;
+    std::vector<uint32_t*> lists;  // member lists of the groups, released behind the synchronisation below
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         if (kGroupW[gi] != 1) continue;  // a read annotated to a miRNA is at most 3 nt longer than it: the <= 31-nt groups
         const ResGroup& g = res->g[gi];
         const ReadGroup& rg = U->g[gi];
         if (!g.n) continue;
+        // both kernels run one workgroup per chunk of reads: the members of chunk b are list[b * chunk ...], n_list[b] of them
+        const uint32_t tgrid = (uint32_t)grid_for(c, g.n);
+        uint32_t chunk = ((uint32_t)g.n + tgrid - 1) / tgrid;
+        chunk = (chunk + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
+        uint32_t* dlist = nullptr;
+        CHECK(dalloc(c, &dlist, (size_t)tgrid * chunk + tgrid));
+        uint32_t* dnlist = dlist + (size_t)tgrid * chunk;
+        {
+            LaunchScope ls(c, "k_tally_members", g.n);
+            hipLaunchKernelGGL(k_tally_members, dim3(tgrid), dim3(MIRGE_BLOCK), 0, c->stream, (uint32_t)g.n, chunk, g.pass, g.ref,
+                               rg.counts, S, exact_pass, iso_pass, dfam, dfreq, dlist, dnlist);
+        }
         LaunchScope ls(c, "k_tally", g.n);
-        hipLaunchKernelGGL(k_tally, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(rg), rg.base,
+        hipLaunchKernelGGL(k_tally, dim3(tgrid), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(rg), rg.base,
                            (const uint32_t*)rg.orig, g.pass, g.ref, rg.counts, S, exact_pass, iso_pass, dfam, dtb, dtl,
-                           (const uint8_t*)dret, dfreq, o);
+                           (const uint8_t*)dret, dfreq, o, (const uint32_t*)dlist, (const uint32_t*)dnlist, chunk);
+        lists.push_back(dlist);
     }
     // straight into the caller's arrays (the census alone is 12 KiB per family and sample: no staging copy of it)
     for (int t = 0; t < 5 && n_fam; t++)  // the device block is sized for max(n_fam, 1)
@@ -182,5 +196,6 @@ extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mir
     c->drain();
     c->release(d); c->release(dtb); c->release(dtl); c->release(dfam); c->release(dret); c->release(dfreq);
     c->release(ddiag); c->release(dstate);
+    for (uint32_t* l : lists) c->release(l);
     return 0;
 }
