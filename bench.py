@@ -40,7 +40,7 @@ ALGO_BYTES = {
     "k_cascade_fused": 9 + 6 + 8,   # small groups, whole cascade in one launch: read in; pass+position+mismatches, ref+offset out
     "k_resolve": 5 + 8,              # pass+position in, ref+offset out
     "k_join": 5 + 4,                 # pass+ref + one count in (S = 1)
-    "k_tally_members": 5 + 4 + 4,    # pass+ref and the count in, member index out, per read of the group
+    "k_member_list": 5 + 4 + 4,      # pass+ref (+ count or slot) in, member index out, per read of the group
     "k_tally": 5 + 9 + 4,            # pass+ref, read, one count in per read of the group (S = 1); the tables are a few MB per launch
     "k_isotype": 5 + 9 + 336,        # pass+ref, read in; one typed record out per miRNA read
     "k_trim": 2 * 50 + 16,           # sequence + quality bytes of a 50-cycle record in, new bounds out

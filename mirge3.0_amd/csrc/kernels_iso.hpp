@@ -15,15 +15,16 @@ struct IsoTables {
 };
 
 template <int W>
-__global__ void k_isotype(GroupView<W> g, uint32_t base, const uint32_t* __restrict__ orig, const int8_t* __restrict__ res_pass,
-                          const int32_t* __restrict__ res_ref, int32_t exact_pass, int32_t iso_pass, IsoTables tb,
-                          const int32_t* __restrict__ slot_of_read, MirgeIsoRec* __restrict__ out) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
-        const int p = res_pass[i];
-        if (p != exact_pass && p != iso_pass) continue;
+__global__ void k_isotype(GroupView<W> g, uint32_t base, const uint32_t* __restrict__ orig,
+                          const int32_t* __restrict__ res_ref, IsoTables tb,
+                          const int32_t* __restrict__ slot_of_read, MirgeIsoRec* __restrict__ out,
+                          const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, uint32_t chunk) {
+    // the workgroup's chunk of reads, compacted to its miRNA rows (k_member_list<IsoMember>: kernels_join.hpp)
+    const uint32_t n_rows = n_list[blockIdx.x];
+    for (uint32_t k = threadIdx.x; k < n_rows; k += blockDim.x) {
+        const uint32_t i = list[(size_t)blockIdx.x * chunk + k];
         const uint32_t h = orig ? orig[i] : base + i;
         const int32_t slot = slot_of_read[h];
-        if (slot < 0) continue;
         MirgeIsoRec rec;
         rec.kind = 0; rec.reserved = 0; rec.start = rec.end = 0; rec.vlen = rec.clen = 0;
         const int32_t mi = tb.master_of_ref[res_ref[i]];

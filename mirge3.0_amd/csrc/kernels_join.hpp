@@ -74,37 +74,48 @@ struct TallyOut {
     int8_t *diag, *state;  // per read, handle order: diagonal; 1 accepted / 0 rejected / -1 not a member
 };
 
-// the reads k_tally works on, compacted: under half of a sample's unique reads are members of a family's list, and a wave of
-// k_tally costs what its busiest lane costs (the alignment is ~2 000 instructions of loops whose trip counts differ per
-// read: 10 % lane utilisation when it walked every read itself, 66 % of the kernel's time in VALU issue)
-__global__ void k_tally_members(uint32_t n, uint32_t chunk, const int8_t* __restrict__ res_pass, const int32_t* __restrict__ res_ref,
-                                const uint32_t* __restrict__ counts, int32_t S, int32_t exact_pass, int32_t iso_pass,
-                                const int32_t* __restrict__ fam_of_ref, const double* __restrict__ freq,
-                                uint32_t* __restrict__ list, uint32_t* __restrict__ n_list) {
-    // workgroup b compacts the reads [b * chunk, (b + 1) * chunk) in place: list[b * chunk ...], n_list[b] of them --
-    // no global cursor (one returning atomic per 256 reads on one address cost more than the alignment it saved)
-    __shared__ uint32_t s_wave[MIRGE_BLOCK / 64 + 1];
+// The reads a heavy per-read kernel works on, compacted.  k_tally and k_isotype run ~2 000 and more instructions of loops
+// per read whose trip counts differ, on the minority of a sample's unique reads that are miRNA rows: a wave costs what
+// its busiest lane costs, and skipping the other reads lane by lane left k_tally at 10 % lane utilisation with 66 % of its
+// time in VALU issue.  Workgroup b compacts the reads [b * chunk, (b + 1) * chunk) that satisfy `pred` in place:
+// list[b * chunk ...], n_list[b] of them -- no global cursor (one returning atomic per 256 reads on one address cost
+// more than the work it saved); the consumer runs one workgroup per chunk.
+struct TallyMember {  // a member of its family's list: an exact-miRNA read, or an isomiR read with count * freq[s] >= 1 somewhere
+    const int8_t* res_pass; const int32_t* res_ref; const uint32_t* counts; int32_t S, exact_pass, iso_pass;
+    const int32_t* fam_of_ref; const double* freq;
+    __device__ __forceinline__ bool operator()(uint32_t i) const {
+        const int p = res_pass[i];
+        if (p != exact_pass && p != iso_pass) return false;
+        const int32_t f = fam_of_ref[res_ref[i]];
+        bool member = f >= 0 && p == exact_pass;
+        if (f >= 0 && p == iso_pass)
+            for (int32_t s = 0; s < S; s++) member |= (double)counts[(size_t)i * S + s] * freq[s] >= 1.0;
+        return member;
+    }
+};
+struct IsoMember {  // a miRNA row of the GFF: annotated by one of the two miRNA passes and given an output slot by the host
+    const int8_t* res_pass; int32_t exact_pass, iso_pass; const uint32_t* orig; uint32_t base; const int32_t* slot_of_read;
+    __device__ __forceinline__ bool operator()(uint32_t i) const {
+        const int p = res_pass[i];
+        return (p == exact_pass || p == iso_pass) && slot_of_read[orig ? orig[i] : base + i] >= 0;
+    }
+};
+
+template <class Pred, int BLOCK>
+__global__ void k_member_list(uint32_t n, uint32_t chunk, Pred pred, uint32_t* __restrict__ list, uint32_t* __restrict__ n_list) {
+    __shared__ uint32_t s_wave[BLOCK / 64 + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
     uint32_t run = 0;
-    for (uint32_t i0 = lo; i0 < hi; i0 += blockDim.x) {
+    for (uint32_t i0 = lo; i0 < hi; i0 += BLOCK) {
         const uint32_t i = i0 + threadIdx.x;
-        bool member = false;
-        if (i < hi) {
-            const int p = res_pass[i];
-            if (p == exact_pass || p == iso_pass) {
-                const int32_t f = fam_of_ref[res_ref[i]];
-                member = f >= 0 && p == exact_pass;
-                if (f >= 0 && p == iso_pass)
-                    for (int32_t s = 0; s < S; s++) member |= (double)counts[(size_t)i * S + s] * freq[s] >= 1.0;
-            }
-        }
+        const bool member = i < hi && pred(i);
         const unsigned long long bal = __ballot(member);
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
         __syncthreads();
         uint32_t before = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < MIRGE_BLOCK / 64; w++) { const uint32_t c = s_wave[w]; if (w < wave) before += c; tot += c; }
+        for (int w = 0; w < BLOCK / 64; w++) { const uint32_t c = s_wave[w]; if (w < wave) before += c; tot += c; }
         if (member) list[lo + run + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
         run += tot;
         __syncthreads();
@@ -120,7 +131,7 @@ __global__ void k_tally(GroupView<1> g, uint32_t base, const uint32_t* __restric
                         const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, uint32_t chunk) {
     const uint32_t n_members = n_list[blockIdx.x];
     for (uint32_t k = threadIdx.x; k < n_members; k += blockDim.x) {
-        const uint32_t i = list[(size_t)blockIdx.x * chunk + k];  // a member of its family's list (k_tally_members); every other read keeps state -1
+        const uint32_t i = list[(size_t)blockIdx.x * chunk + k];  // a member of its family's list (TallyMember); every other read keeps state -1
         const int p = res_pass[i];
         const uint32_t h = orig ? orig[i] : base + i;
         const int32_t f = fam_of_ref[res_ref[i]];

@@ -51,17 +51,31 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
     IsoTables tb;
     tb.master_of_ref = d_mof; tb.master = d_m; tb.master_off = d_moff; tb.pre_of_master = d_pom; tb.start0 = d_s0;
     tb.pre = d_p; tb.pre_off = d_poff;
+    std::vector<uint32_t*> lists;  // the groups' row lists, released behind the synchronisation below
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
         const ReadGroup& rg = U->g[gi];
         if (!g.n || kGroupW[gi] > 2) continue;  // a read annotated to a miRNA is at most 3 nt longer than it
+        // one 64-thread workgroup per chunk of reads, in both kernels: chunk b's miRNA rows are list[b * chunk ...]
+        const uint32_t tgrid = (uint32_t)grid_for(c, g.n, 64);
+        uint32_t chunk = ((uint32_t)g.n + tgrid - 1) / tgrid;
+        chunk = (chunk + 63) / 64 * 64;
+        uint32_t* dlist = nullptr;
+        CHECK(dalloc(c, &dlist, (size_t)tgrid * chunk + tgrid));
+        uint32_t* dnlist = dlist + (size_t)tgrid * chunk;
+        lists.push_back(dlist);
+        {
+            LaunchScope ls(c, "k_member_list.iso", g.n);
+            const IsoMember pred{g.pass, exact_pass, iso_pass, (const uint32_t*)rg.orig, rg.base, d_slot};
+            hipLaunchKernelGGL((k_member_list<IsoMember, 64>), dim3(tgrid), dim3(64), 0, c->stream, (uint32_t)g.n, chunk, pred, dlist, dnlist);
+        }
         LaunchScope ls(c, "k_isotype", g.n);
         if (kGroupW[gi] == 1)
-            hipLaunchKernelGGL(k_isotype<1>, dim3(grid_for(c, g.n, 64)), dim3(64), 0, c->stream, view_of<1>(rg), rg.base, (const uint32_t*)rg.orig,
-                               g.pass, g.ref, exact_pass, iso_pass, tb, d_slot, d_out);
+            hipLaunchKernelGGL(k_isotype<1>, dim3(tgrid), dim3(64), 0, c->stream, view_of<1>(rg), rg.base, (const uint32_t*)rg.orig,
+                               g.ref, tb, d_slot, d_out, (const uint32_t*)dlist, (const uint32_t*)dnlist, chunk);
         else
-            hipLaunchKernelGGL(k_isotype<2>, dim3(grid_for(c, g.n, 64)), dim3(64), 0, c->stream, view_of<2>(rg), rg.base, (const uint32_t*)rg.orig,
-                               g.pass, g.ref, exact_pass, iso_pass, tb, d_slot, d_out);
+            hipLaunchKernelGGL(k_isotype<2>, dim3(tgrid), dim3(64), 0, c->stream, view_of<2>(rg), rg.base, (const uint32_t*)rg.orig,
+                               g.ref, tb, d_slot, d_out, (const uint32_t*)dlist, (const uint32_t*)dnlist, chunk);
     }
     if (n_rows) HIPOK(hipMemcpyAsync(records_out, d_out, (size_t)n_rows * sizeof(MirgeIsoRec), hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
@@ -69,6 +83,7 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
     c->drain();
     c->release(d_mof); c->release(d_moff); c->release(d_pom); c->release(d_s0); c->release(d_poff); c->release(d_slot);
     c->release(d_m); c->release(d_p); c->release(d_out);
+    for (uint32_t* l : lists) c->release(l);
     return 0;
 }
 

@@ -176,9 +176,10 @@ extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mir
         CHECK(dalloc(c, &dlist, (size_t)tgrid * chunk + tgrid));
         uint32_t* dnlist = dlist + (size_t)tgrid * chunk;
         {
-            LaunchScope ls(c, "k_tally_members", g.n);
-            hipLaunchKernelGGL(k_tally_members, dim3(tgrid), dim3(MIRGE_BLOCK), 0, c->stream, (uint32_t)g.n, chunk, g.pass, g.ref,
-                               rg.counts, S, exact_pass, iso_pass, dfam, dfreq, dlist, dnlist);
+            LaunchScope ls(c, "k_member_list.tally", g.n);
+            const TallyMember pred{g.pass, g.ref, rg.counts, S, exact_pass, iso_pass, dfam, dfreq};
+            hipLaunchKernelGGL((k_member_list<TallyMember, MIRGE_BLOCK>), dim3(tgrid), dim3(MIRGE_BLOCK), 0, c->stream, (uint32_t)g.n, chunk,
+                               pred, dlist, dnlist);
         }
         LaunchScope ls(c, "k_tally", g.n);
         hipLaunchKernelGGL(k_tally, dim3(tgrid), dim3(MIRGE_BLOCK), 0, c->stream, view_of<1>(rg), rg.base,
