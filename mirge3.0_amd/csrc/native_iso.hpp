@@ -65,7 +65,7 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
         uint32_t* dnlist = dlist + (size_t)tgrid * chunk;
         lists.push_back(dlist);
         {
-            LaunchScope ls(c, "k_member_list.iso", g.n);
+            LaunchScope ls(c, "k_member_list", g.n);
             const IsoMember pred{g.pass, exact_pass, iso_pass, (const uint32_t*)rg.orig, rg.base, d_slot};
             hipLaunchKernelGGL((k_member_list<IsoMember, 64>), dim3(tgrid), dim3(64), 0, c->stream, (uint32_t)g.n, chunk, pred, dlist, dnlist);
         }

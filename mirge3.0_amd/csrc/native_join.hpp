@@ -176,7 +176,7 @@ extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mir
         CHECK(dalloc(c, &dlist, (size_t)tgrid * chunk + tgrid));
         uint32_t* dnlist = dlist + (size_t)tgrid * chunk;
         {
-            LaunchScope ls(c, "k_member_list.tally", g.n);
+            LaunchScope ls(c, "k_member_list", g.n);
             const TallyMember pred{g.pass, g.ref, rg.counts, S, exact_pass, iso_pass, dfam, dfreq};
             hipLaunchKernelGGL((k_member_list<TallyMember, MIRGE_BLOCK>), dim3(tgrid), dim3(MIRGE_BLOCK), 0, c->stream, (uint32_t)g.n, chunk,
                                pred, dlist, dnlist);
