@@ -126,6 +126,9 @@ int mirge_collapse(mirge_ctx* ctx, const mirge_reads* raw, const int32_t* sample
 /* counts_out[U * n_samples] (row-major), first_index_out[U] (index of the first raw read, may be NULL) */
 int mirge_collapse_fetch(mirge_ctx* ctx, const mirge_reads* uniq, uint32_t* counts_out,
                          int64_t* first_index_out);
+/* order_out[k] (k < U) = index of the unique read that appeared k-th in the raw reads: the row order of the reference's
+ * per-sample dictionary (insertion order, digest.py:158-163), from one device sort of the first indices. */
+int mirge_collapse_order(mirge_ctx* ctx, const mirge_reads* uniq, int64_t* order_out);
 /* attach a caller-made count matrix (U x n_samples, host) to a packed read set, e.g. after -rr */
 int mirge_reads_set_counts(mirge_ctx* ctx, mirge_reads* reads, const uint32_t* counts, int32_t n_samples);
 

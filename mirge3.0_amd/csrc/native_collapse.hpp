@@ -371,3 +371,35 @@ extern "C" int mirge_collapse_fetch(mirge_ctx* c, const mirge_reads* U, uint32_t
     HIPOK(hipStreamSynchronize(c->stream));
     return 0;
 }
+
+// order_out[k] = handle index of the unique read that appeared k-th in the raw reads: the row order of the reference's
+// per-sample dictionary (digest.py:158-163) without a host-side ranking of U first-indices -- one device radix sort of
+// (first index, handle index) pairs over all groups.
+extern "C" int mirge_collapse_order(mirge_ctx* c, const mirge_reads* U, int64_t* order_out) {
+    if (!c || !U || (!order_out && U->n)) return fail(-1, "mirge_collapse_order: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    const size_t n = (size_t)U->n;
+    if (!n) return 0;
+    uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
+    CHECK(dalloc(c, &keys, n)); CHECK(dalloc(c, &vals, n)); CHECK(dalloc(c, &keys2, n)); CHECK(dalloc(c, &vals2, n));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = U->g[gi];
+        if (!g.n) continue;
+        if (g.orig || !g.first) return fail(-1, "mirge_collapse_order: handle is not a collapse result");
+        HIPOK(hipMemcpyAsync(keys + g.base, g.first, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_index_shift, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, (const uint32_t*)nullptr, 0u,
+                           (uint32_t)g.n, g.base, vals + g.base);
+    }
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIPOK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 32, c->stream));
+    CHECK(dalloc(c, (uint8_t**)&tmp, std::max<size_t>(tmp_bytes, 16)));
+    HIPOK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 32, c->stream));
+    std::vector<uint32_t> h(n);
+    HIPOK(hipMemcpyAsync(h.data(), vals2, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < n; k++) order_out[k] = (int64_t)h[k];
+    c->release(keys); c->release(vals); c->release(keys2); c->release(vals2); c->release(tmp);
+    return 0;
+}
+

@@ -82,7 +82,7 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     n_cols = 10 if args.spikeIn else 9
     header = ",".join(["Sequence", "annotFlag"] + PASS_COLUMNS[:n_cols] + [name]) + "\n"
     _ffi.annotation_csv(workDir / f"mapped.{name}.csv", workDir / f"unmapped.{name}.csv", header, seqs, ps, ref, counts,
-                        row_order(seqs, first, 1), list(range(casc.n_pass)), n_cols, names_by_pass(casc))
+                        uniq.first_appearance_order(), list(range(casc.n_pass)), n_cols, names_by_pass(casc))
     out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
     res.close(); uniq.close()
     return out
@@ -152,7 +152,7 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     seqs = uniq.unpack()
     ps, ref, off, mm = res.fetch()
     tm["fetch_reads_annotation_s"] = time.perf_counter() - t
-    order = row_order(seqs, first, S)
+    order = uniq.first_appearance_order() if S == 1 else row_order(seqs, first, S)  # one sample: sorted on the device
     tm["row_order_s"] = time.perf_counter() - t - tm["fetch_reads_annotation_s"]
     n_cols = 10 if args.spikeIn else 9  # bwtAlign drops the 'spike-in' column when -spk is off (manifoldAlign.py:137-138)
     cols = PASS_COLUMNS[:n_cols]

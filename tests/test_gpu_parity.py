@@ -1400,3 +1400,16 @@ def test_cli_route_edge_inputs(tmp_path):
     assert (work2 / "sample_miRge3.gff").read_text().count("\n") == 4  # the four header lines
     assert (work2 / "a2IEditing.report.csv").read_text().count("\n") == 1 and (work2 / "isomirs.csv").exists()
     assert int(list(csv.DictReader(open(work2 / "annotation.report.csv")))[0]["All miRNA Reads"]) == 0
+
+
+def test_first_appearance_order_on_the_device(ctx):
+    """mirge_collapse_order == ranking the first indices on the host (fastpath.row_order), over several read groups."""
+    from mirge3_amd.fastpath import row_order
+    sl = synth.make_libraries(seed=20260101, scale="small")
+    reads = synth.make_reads(sl, 300000, seed=9, n_frac=0.02)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq = raw.collapse()
+    cnt, first = uniq.counts()
+    got = uniq.first_appearance_order()
+    assert np.array_equal(got, row_order(uniq.unpack(), first, 1)) and len(got) == len(uniq) > 1000
+    uniq.close(); raw.close()
