@@ -25,6 +25,14 @@ while a > 0 and "k_join" not in rows[a - 1]["Kernel_Name"]:
     a -= 1
 while b > 0 and "k_join" not in rows[b - 1]["Kernel_Name"]:
     b -= 1
+# what sits right behind the previous k_join belongs to that step (its read-back, the clear of its tables for the next
+# call); the host's pause between two steps follows: start behind the largest gap in front of this step's k_part_agg
+fa = next(i for i in range(a, b) if "k_part_agg" in rows[i]["Kernel_Name"])
+if fa > a:
+    gaps = [(int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]), i) for i in range(a + 1, fa + 1)]
+    g, at = max(gaps)
+    if g > 100_000:
+        a = at
 t0 = int(rows[a]["Start_Timestamp"])
 end_by_q, busy_by_q = {}, {}
 print(f"# one step = dispatches {a}..{b - 1}; times in us from the step's first kernel")
