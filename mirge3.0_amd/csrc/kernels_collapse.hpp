@@ -152,7 +152,9 @@ __global__ void k_collapse_init(uint32_t* __restrict__ rep, uint32_t* __restrict
 #ifndef MIRGE_PART_CAP
 #define MIRGE_PART_CAP 4096  // largest LDS table per bucket (16 B per slot = 64 KiB)
 #endif
+#ifndef MIRGE_PART_B1
 #define MIRGE_PART_B1 64       // level-1 bins (and the largest one-level partition)
+#endif
 #ifndef MIRGE_PART_SMALL
 #define MIRGE_PART_SMALL 1600  // reads per bucket up to which k_part_dedup uses its 2048-slot table
 #endif
