@@ -7,9 +7,16 @@
 // ------------------------------------------------------------------------------------------
 // IUPAC ambiguity codes other than N (upper case): bowtie turns every one of them into N, and so does the packing --
 // the collapsed sequence then prints N where the read had the code (flagged, so that the host can say so)
-__device__ __forceinline__ bool is_iupac_code(uint8_t c) {
-    return c == 'R' || c == 'Y' || c == 'S' || c == 'W' || c == 'K' || c == 'M' || c == 'B' || c == 'D' || c == 'H' || c == 'V';
+// letter classes of an upper-cased sequence character as one bit test each (bit = letter - 'A'):
+// A C G T U | N | the ten other IUPAC ambiguity codes (R Y S W K M B D H V)
+#define MIRGE_LETTERS_ACGTU ((1u << 0) | (1u << 2) | (1u << 6) | (1u << 19) | (1u << 20))
+#define MIRGE_LETTERS_N (1u << 13)
+#define MIRGE_LETTERS_IUPAC ((1u << 17) | (1u << 24) | (1u << 18) | (1u << 22) | (1u << 10) | (1u << 12) | (1u << 1) | (1u << 3) | (1u << 7) | (1u << 21))
+__device__ __forceinline__ uint32_t letter_bit(uint8_t upper) {
+    const uint32_t d = (uint32_t)upper - 'A';
+    return d < 26u ? 1u << d : 0u;
 }
+__device__ __forceinline__ bool is_iupac_code(uint8_t c) { return (letter_bit(c) & MIRGE_LETTERS_IUPAC) != 0; }
 
 template <int W>
 __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ starts, const int64_t* __restrict__ ends,
@@ -25,17 +32,13 @@ __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restr
         for (int i = 0; i < W; i++) { w[i] = 0; nm[i] = 0; }
         uint32_t sawN = 0, bad = 0, iupac = 0;
         for (int p = 0; p < L; p++) {
-            uint8_t c = ascii[b + p] & 0xDF;  // upper-case
-            uint64_t code = 0, isn = 0;
-            switch (c) {
-                case 'A': code = 0; break;
-                case 'C': code = 1; break;
-                case 'G': code = 2; break;
-                case 'T': code = 3; break;
-                case 'U': code = 3; break;
-                case 'N': isn = 1; break;
-                default: isn = 1; if (is_iupac_code(c)) iupac = 1; else bad = 1; break;
-            }
+            const uint8_t c = ascii[b + p] & 0xDF;  // upper-case
+            const uint32_t bit = letter_bit(c);
+            const uint32_t x = (c >> 1) & 3u;       // A 0, C 1, G 3, T / U 2 ...
+            const uint64_t isn = (bit & MIRGE_LETTERS_ACGTU) ? 0ull : 1ull;
+            const uint64_t code = isn ? 0ull : (uint64_t)(x ^ (x >> 1));  // ... -> A 0, C 1, G 2, T / U 3
+            iupac |= (bit & MIRGE_LETTERS_IUPAC) != 0;
+            bad |= isn && !(bit & (MIRGE_LETTERS_N | MIRGE_LETTERS_IUPAC));
             sawN |= (uint32_t)isn;
 #pragma unroll
             for (int i = 0; i < W; i++)
@@ -260,11 +263,11 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __r
         } else {
             uint32_t amb = 0, bad = 0, iu = 0;
             for (int p = 0; p < (int)L; p++) {
-                const uint8_t ch = text[b + p] & 0xDF;
-                const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'U';
+                const uint32_t bit = letter_bit(text[b + p] & 0xDF);
+                const bool acgt = (bit & MIRGE_LETTERS_ACGTU) != 0;
                 amb |= !acgt;
-                bad |= !acgt && ch != 'N' && !is_iupac_code(ch);
-                iu |= is_iupac_code(ch);
+                bad |= !acgt && !(bit & (MIRGE_LETTERS_N | MIRGE_LETTERS_IUPAC));
+                iu |= (bit & MIRGE_LETTERS_IUPAC) != 0;
             }
             if (bad) atomicOr(&flags[0], 1u);
             if (iu) atomicOr(&flags[4], 1u);
