@@ -226,14 +226,18 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
     };
     for (uint32_t j0 = lo; j0 < hi; j0 += blockDim.x) {
         const uint32_t j = j0 + threadIdx.x;
+        bool direct = false;
+        unsigned long long key = 0ull;
+        uint32_t jr = 0;
+        uint64_t h = 0;
         if (j < hi) {
-            const unsigned long long key = read_key64(g, j);
+            key = read_key64(g, j);
             // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
             // instead of gathered per unique read at the end)
-            const uint32_t jr = orig ? orig[j] : base + j;
-            const uint64_t h = mirge_mix64(key);
+            jr = orig ? orig[j] : base + j;
+            h = mirge_mix64(key);
             uint32_t s = (uint32_t)(h >> 9) & (CS - 1);
-            bool direct = true;
+            direct = true;
             // four probes, always: a hot key that was displaced from its home slot when it arrived must still be found by its
             // later copies (looking at the home slot only once the cache is full was 6 % faster on unskewed reads and sent
             // every copy of such a key to its bin as a record of its own on a Zipf sample)
@@ -250,8 +254,30 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
                 }
                 s = (s + 1) & (CS - 1);
             }
-            if (direct) append(key, h, jr, 1u);  // cache full around this key: the read itself is the record
         }
+        // cache full around this key: the read itself becomes a record.  Copies of ONE sequence that meet in a wave are
+        // merged first (two rounds: the key of the first such lane, then of the first lane left) -- a burst of a sequence that
+        // arrives after the cache has filled is then one record per wave, not 64 for one level-1 region
+        uint32_t count = 1;
+        bool open = direct;  // not yet looked at as a group's key
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+            const unsigned long long ob = __ballot(open);
+            if (!ob) break;
+            const int lead = __ffsll(ob) - 1;
+            const unsigned long long k0 = __shfl(key, lead, 64);
+            const bool same = open && key == k0;
+            const unsigned long long sb = __ballot(same);
+            if (__popcll(sb) > 1) {
+                uint32_t mn = same ? jr : 0xFFFFFFFFu;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+                if ((threadIdx.x & 63) == lead) { jr = mn; count = (uint32_t)__popcll(sb); }
+                else if (same) direct = false;  // the leader carries the group
+            }
+            open = open && !same;
+        }
+        if (direct) append(key, h, jr, count);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < CS; i += blockDim.x) {  // flush the cache

@@ -768,8 +768,8 @@ def test_partitioned_collapse_sizes_and_skew(ctx, n, shape):
     elif shape == "one_third":
         idx = np.where(rng.random(n) < 0.33, 7, rng.integers(0, n_tmpl, size=n))
     else:  # every writer's chunk starts with distinct reads (its cache fills) and ends with a burst of ONE sequence: the
-        # burst's copies are records of their own, all for one level-1 region -> it overflows, the call is redone with
-        # chunk-sized regions (collapse_phase_a, attempt 1)
+        # burst's copies are turned away by the cache and merged per wave (k_part_agg); without that merge they overflow one
+        # level-1 region and the call is redone with chunk-sized regions (collapse_phase_a, attempt 1)
         idx = rng.integers(0, n_tmpl, size=n)
         chunk = max(n // 256, 2048)
         pos = np.arange(n) % chunk
