@@ -106,6 +106,29 @@ typedef struct mirge_trim {
 } mirge_trim;
 int mirge_reads_parse_trim(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                            const mirge_trim* trim, mirge_reads** out, int64_t* n_records);
+/* The same with the reference's UMI handling: replaces the UMI branches of the per-chunk worker
+ * (digest.py:334-365), `UMIParser` (:305-315) and the UMI stage of baking (:164-205) for one file.
+ *   front, back  -umi f,b: read[f : len - b] is the insert (Python's s[f:-b]; s[f:] when b == 0), the rest the UMI
+ *   qiagen       --qiagenumi (:334-352): the dictionary key is the trimmed read + the `back` bases that follow the 3'
+ *                adapter in the untrimmed line (`currentSeq.split(trimmed)[1][:len(adapter)+b][-b:]`, first occurrence,
+ *                "" when the trimmed read is empty); counted once, after the last modifier; needs trim->adapter (3')
+ *   dedup        -udd (:183-205): a count is a number of distinct UMI-tagged reads
+ * The worker's length test applies to the insert (`len(pureSeq) >= min_len`, :360), with qiagen to the trimmed read (:349),
+ * and baking's to the insert again (:173,192).
+ * *out: RAW inserts in file order -- without dedup one per counted read; with dedup one per DISTINCT tagged read whose
+ * insert passes, in the order the tagged reads first appeared, so that mirge_collapse of *out gives molecule counts and
+ * first indices that are ranks in the reference's dictionary order.  mirge_reads_count(*out) = 'Trimmed Reads (all)'.
+ * *tagged_out (dedup only; may be NULL): the distinct tagged reads with their counts (a collapse result): the rows of
+ * <sample>_umiCounts.csv (:183-197) are those whose insert passes the length test.  umi == NULL: mirge_reads_parse_trim. */
+typedef struct mirge_umi {
+    int32_t front;
+    int32_t back;
+    int32_t qiagen;
+    int32_t dedup;
+} mirge_umi;
+int mirge_reads_parse_umi(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                          const mirge_trim* trim, const mirge_umi* umi, mirge_reads** out, int64_t* n_records,
+                          mirge_reads** tagged_out);
 /* Several raw read sets as one, in the order given (the samples of a run, one file each, before the joint collapse
  * that replaces the per-file dicts and their outer join, digest.py:133-163,243).  The parts stay valid. */
 int mirge_reads_concat(mirge_ctx* ctx, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out);

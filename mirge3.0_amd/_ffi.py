@@ -22,7 +22,7 @@ SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libm
 EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
-    "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
+    "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch", "mirge_collapse_order",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
@@ -59,6 +59,17 @@ class MirgeTrim(C.Structure):
         t.count_per_modifier = 1 if count_per_modifier else 0
         t.adapter_front = 1 if front else 0
         return t
+
+
+class MirgeUmi(C.Structure):
+    """``mirge_umi`` of include/mirge_native.h: ``-umi f,b`` [``--qiagenumi``] [``-udd``] (digest.py:164-205,305-315,334-365)."""
+    _fields_ = [("front", C.c_int32), ("back", C.c_int32), ("qiagen", C.c_int32), ("dedup", C.c_int32)]
+
+    @staticmethod
+    def make(front: int, back: int, qiagen: bool = False, dedup: bool = False) -> "MirgeUmi":
+        u = MirgeUmi()
+        u.front, u.back, u.qiagen, u.dedup = int(front), int(back), 1 if qiagen else 0, 1 if dedup else 0
+        return u
 
 
 _lib = None
@@ -241,6 +252,20 @@ class DeviceReads:
                                              C.c_int32(min_len), C.byref(trim) if trim is not None else C.c_void_p(0),
                                              C.byref(h), C.byref(nrec)), "mirge_reads_parse")
         return DeviceReads(ctx, h), int(nrec.value)
+
+    @staticmethod
+    def parse_umi(ctx: Context, text, fmt: int, min_len: int, trim: Optional["MirgeTrim"], umi: "MirgeUmi"):
+        """``parse`` with the reference's UMI handling (``mirge_reads_parse_umi``) -> (raw INSERTS, records seen, the
+        distinct UMI-tagged reads with their counts -- a collapse result -- or None without ``-udd``).  With ``-udd``
+        the inserts are one per distinct tagged read, in the order the tagged reads first appeared."""
+        buf = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else \
+            np.ascontiguousarray(text, dtype=np.uint8)
+        h, ht = C.c_void_p(), C.c_void_p()
+        nrec = C.c_int64()
+        _check(load().mirge_reads_parse_umi(ctx._h, _p(buf) if buf.size else C.c_void_p(0), C.c_int64(buf.size), C.c_int32(fmt),
+                                            C.c_int32(min_len), C.byref(trim) if trim is not None else C.c_void_p(0),
+                                            C.byref(umi), C.byref(h), C.byref(nrec), C.byref(ht)), "mirge_reads_parse_umi")
+        return DeviceReads(ctx, h), int(nrec.value), (DeviceReads(ctx, ht) if ht.value else None)
 
     @staticmethod
     def concat(ctx: Context, parts: Sequence["DeviceReads"]) -> "DeviceReads":

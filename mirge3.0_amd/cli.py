@@ -93,7 +93,9 @@ def parse_args(argv=None):
     # cutadapt's adapter options: the defaults are what k_trim implements; anything else is refused, not ignored
     ap.add_argument("-n", "--times", dest="times", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--action", dest="action", default="trim", help=argparse.SUPPRESS)
-    for flag in ("-qumi", "-nmir", "-bam", "-trf", "-mEC", "-dex"):
+    ap.add_argument("-qumi", "--qiagenumi", dest="qiagenumi", action="store_true",
+                    help="with -umi 0,b and -a: the UMI is the b bases that follow the 3' adapter (Qiagen libraries)")
+    for flag in ("-nmir", "-bam", "-trf", "-mEC", "-dex"):
         ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -102,12 +104,13 @@ def parse_args(argv=None):
             ap.error(f"-{k[4:]} belongs to a miRge3.0 subsystem outside the MI355X hot path (DESIGN.md section 0)")
     if args.times != 1 or args.action != "trim":
         ap.error("-n / --action: only cutadapt's defaults (one adapter occurrence, removed) are part of the MI355X path")
-    if args.umiDedup and not args.uniq_mol_ids:
-        ap.error("-udd requires -umi f,b")
+    if (args.umiDedup or args.qiagenumi) and not args.uniq_mol_ids:
+        ap.error("-udd / --qiagenumi require -umi f,b")
+    if args.qiagenumi and not args.adapters:
+        ap.error("--qiagenumi reads the UMI behind the 3' adapter: give it with -a")
     args.bowtieVersion = "True"
-    if (args.AtoI or args.gff_out) and (args.uniq_mol_ids or args.tcf_out or args.save_pkl or args.resume):
-        ap.error("-ai / -gff run on the device-resident route: not together with -umi / -tcf / -spl / -rr")
-    args.qiagenumi = None
+    if (args.AtoI or args.gff_out) and (args.tcf_out or args.save_pkl or args.resume):
+        ap.error("-ai / -gff run on the device-resident route: not together with -tcf / -spl / -rr")
     return args
 
 

@@ -7,16 +7,17 @@ the pandas outer join of the samples (:237-245) are ONE ``mirge_collapse`` call 
 samples' reads go in together with a sample id and come back as the U distinct sequences plus a
 U x S count matrix.
 
-Scope: reads are taken as already trimmed (adapter/quality trimming is
-cutadapt's, third-party and upstream of the path).  Asking for adapter trimming raises instead of
-silently skipping it.  Only the length filter of digest.py:348,368 (``--minimum-length``) applies.
+The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) runs on the GPU too (``trim_from_args`` ->
+``mirge_reads_parse_trim``: quality / NextSeq trimming, one 3' or one 5' adapter, N ends, cuts); what is not covered
+(several adapters, ``-n``, ``--action``) raises instead of being skipped.
 
-UMI handling (digest.py:164-205,305-315,358-365): ``-umi f,b`` slices f bases off
-the front and b off the back of every read before the collapse (counts add up); with ``-udd`` the
-full reads are collapsed first (on the GPU), ``<sample>_umiCounts.csv`` is written from that result,
-and the inserts of the DISTINCT tagged reads are collapsed again, so a count is a number of molecules.
-``-qumi`` needs the adapter match of cutadapt and is refused.  ``-tcf`` writes
-``<sample>.trim.collapse.fa`` (digest.py:219-229).
+UMI handling (digest.py:164-205,305-315,334-365) is part of the same device-resident parse
+(``mirge_reads_parse_umi``): ``-umi f,b`` slices f bases off the front and b off the back of every counted read
+(counts add up); with ``-udd`` the UMI-tagged reads are collapsed first, ``<sample>_umiCounts.csv`` is written from that
+result and ONE insert per distinct tagged read goes on, so a count is a number of molecules; ``--qiagenumi`` takes the
+UMI from behind the 3' adapter of the untrimmed read (the reference's ``currentSeq.split(trimmed)[1]`` string rule).
+Both command lines of the reference's quick start (``docs/source/quick_start.md:282-314``) run this way.
+``-tcf`` writes ``<sample>.trim.collapse.fa`` (digest.py:219-229).
 """
 from __future__ import annotations
 
@@ -174,9 +175,8 @@ def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:
 
 
 def collapse_samples(ctx: _ffi.Context, samples: Sequence[FlatSeqs]):
-    """-> (DeviceReads uniq (with counts), order) where ``order`` lists the unique rows in the
-    reference's row order: first appearance for one sample (dict order, digest.py:158-163),
-    lexicographic for several (pandas ``join(how='outer')`` sorts, digest.py:243)."""
+    """Host sequences of several samples -> the DeviceReads of their joint collapse (U unique reads + a U x S count
+    matrix); the route for callers that hold sequences, not files (``baking`` parses the files' text on the GPU)."""
     S = len(samples)
     if S == 1:
         allr, sid = samples[0], None
@@ -193,106 +193,96 @@ def collapse_samples(ctx: _ffi.Context, samples: Sequence[FlatSeqs]):
     return uniq
 
 
-def _collapse_one(ctx: _ffi.Context, reads: FlatSeqs):
-    """One sample alone -> (sequences, counts) in dict order (first appearance, digest.py:158-163)."""
-    raw = _ffi.DeviceReads.pack(ctx, reads)
-    uniq = raw.collapse(None, 1)
-    raw.close()
-    counts, first = uniq.counts()
-    seqs = uniq.unpack()
-    uniq.close()
-    order = np.argsort(first, kind="stable")
-    return seqs.take(order), counts[order, 0].astype(np.int64)
+def umi_from_args(args):
+    """``-umi f,b`` / ``--qiagenumi`` / ``-udd`` as the options of ``mirge_reads_parse_umi``, or None.  The reference reads
+    ``umi.split(",")`` everywhere (digest.py:149,167,344,358): two integers."""
+    umi = getattr(args, "uniq_mol_ids", None)
+    qia = bool(getattr(args, "qiagenumi", False))
+    if not umi:
+        if qia:
+            raise SystemExit("--qiagenumi requires -umi x,y (mirge/libs/parse.py: '-umi x,y Required')")
+        return None
+    try:
+        f, b = (int(x) for x in str(umi).split(","))
+    except ValueError:
+        raise SystemExit("-umi expects two comma separated integers, e.g. 4,4 or 0,12")
+    return _ffi.MirgeUmi.make(f, b, qiagen=qia, dedup=bool(getattr(args, "umiDedup", False)))
+
+
+def write_umi_counts(path, tagged: "_ffi.DeviceReads", front: int, back: int, min_len: int) -> int:
+    """``<sample>_umiCounts.csv`` (digest.py:183-197): one line ``UMI,insert,count`` per distinct UMI-tagged read whose insert
+    has ``min_len`` bases, in the order the tagged reads first appeared; appended to, as the reference opens it.  Returns
+    the number of lines.  Formatted with numpy from the flat arrays: no per-read Python object."""
+    counts, _ = tagged.counts()
+    full = tagged.unpack().take(tagged.first_appearance_order())
+    c = counts[tagged.first_appearance_order(), 0] if len(tagged) else np.zeros(0, np.uint32)
+    pure, tag = full.umi_split(front, back)
+    keep = np.flatnonzero(pure.lengths >= int(min_len))
+    pure, tag, c = pure.take(keep), tag.take(keep), c[keep]
+    digits = FlatSeqs.from_fixed(np.char.mod("%d", c.astype(np.int64)).astype("S")) if len(c) else FlatSeqs.from_list([])
+    with open(path, "ab") as fh:
+        fh.write(b"UMISeq,transcriptSeq,UMICounts\n")
+        fh.write(FlatSeqs.join_columns([tag, pure, digits], b",,\n"))
+    return int(keep.shape[0])
+
+
+def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None, name=None):
+    """One file's text -> (raw reads as the collapse takes them, records seen): parse, the modifier chain, the length
+    filter and -- with ``umi`` -- the reference's UMI handling, all on the GPU (``mirge_reads_parse[_trim|_umi]``).
+    With ``-udd`` also writes ``<name>_umiCounts.csv``."""
+    if umi is None:
+        return _ffi.DeviceReads.parse(ctx, text, 0, min_len, trim)
+    raw, n_rec, tagged = _ffi.DeviceReads.parse_umi(ctx, text, 0, min_len, trim, umi)
+    if tagged is not None:
+        if workDir is not None:
+            write_umi_counts(Path(workDir) / (str(name) + "_umiCounts.csv"), tagged, umi.front, umi.back, min_len)
+        tagged.close()
+    return raw, n_rec
 
 
 def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None):
-    """Drop-in for ``baking`` (digest.py:105-302) on already-trimmed reads."""
+    """Drop-in for ``baking`` (digest.py:105-302): every file's text goes to the GPU as it is -- records found, trimmed,
+    UMI-sliced, filtered by length and packed there (digest.py:320-375 without a per-read host step); the samples' read
+    sets are appended on the device and collapsed together with a sample id (digest.py:141-163 + the outer join :243)."""
     import pandas as pd
-    if getattr(args, "qiagenumi", None):
-        raise NotImplementedError("-qumi reads cutadapt's adapter match object and is not part of the MI355X path")
     trim = trim_from_args(args)
-    umi = getattr(args, "uniq_mol_ids", None)
-    if umi and (trim.adapter_len or trim.trim_n or trim.n_cut or trim.nextseq_cutoff >= 0):
-        raise NotImplementedError("-umi together with adapter / N / unconditional trimming is not supported: trim first")
-    dedup = bool(getattr(args, "umiDedup", False))
-    if umi:
-        umi_f, umi_b = (int(x) for x in str(umi).split(","))
+    umi = umi_from_args(args)
     begningTime = time.perf_counter()
     runlogFile = Path(workDir) / "run.log"
     outlog = open(str(runlogFile), "a+")
     ctx = ctx or _ffi.Context(getattr(args, "device", 0))
     min_len = int(getattr(args, "minimum_length", 16))
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
-    samples: List[FlatSeqs] = []
-    # No UMI: every file's text goes to the GPU as it is (records found, filtered by length and packed there:
-    # digest.py:320-375 without a per-read host step); the samples' read sets are appended on the device and
-    # collapsed together with a sample id (digest.py:141-163 + the outer join :243).  With UMIs the sequences are
-    # cut out and sliced on the host first.
-    device_parse = not umi
-    uniq = None
     parsed: List[_ffi.DeviceReads] = []
-    texts = read_texts(inFileArray) if device_parse else None  # read (and gunzipped) ahead on worker threads
+    texts = read_texts(inFileArray)  # read (and gunzipped) ahead on worker threads
     for FQfile, name in zip(inFileArray, inFileBaseArray):
         start = time.perf_counter()
-        if device_parse:
-            raw, n_rec = _ffi.DeviceReads.parse(ctx, next(texts), 0, min_len, trim)
-            sampleReadCounts[name] = n_rec
-            trimmedReadCounts[name] = len(raw)
-            parsed.append(raw)
-            finish2 = time.perf_counter()
-            if not args.quiet:
-                print(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)')
-            outlog.write(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)\n')
-            if getattr(args, "tcf_out", False):
-                u1 = raw.collapse()
-                tc, tfirst = u1.counts()
-                tl = u1.unpack().to_list()
-                u1.close()
-                by = sorted(range(len(tl)), key=lambda i: (-int(tc[i, 0]), int(tfirst[i])))  # by count, ties in dict order
-                with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
-                    fo.write("".join(f">seq{k + 1}_{int(tc[i, 0])}\n{tl[i]}\n" for k, i in enumerate(by)))
-            continue
-        reads = read_fastq_sequences(str(FQfile))
-        sampleReadCounts[name] = len(reads)
-        if not umi:
-            reads = filter_min_length(reads, min_len)
-        else:
-            pure, _ = reads.umi_split(umi_f, umi_b)
-            keep = np.flatnonzero(pure.lengths >= min_len)  # the worker's filter is on the insert (:360)
-            if not dedup:
-                reads = pure.take(keep)  # counts add up: slicing first == slicing the collapsed dict (:168-181)
-            else:
-                full, c = _collapse_one(ctx, reads.take(keep))
-                pure, tag = full.umi_split(umi_f, umi_b)
-                with open(Path(workDir) / (name + "_umiCounts.csv"), "a+") as iumiFile:  # (:183-197)
-                    iumiFile.write("UMISeq,transcriptSeq,UMICounts\n")
-                    iumiFile.write("".join(f"{t},{p},{n}\n" for t, p, n in zip(tag.to_list(), pure.to_list(), c.tolist())))
-                reads = pure  # one entry per distinct tagged read, in dict order
-        trimmedReadCounts[name] = len(reads)
-        samples.append(reads)
+        raw, n_rec = parse_sample(ctx, next(texts), min_len, trim, umi, workDir, name)
+        sampleReadCounts[name] = n_rec
+        trimmedReadCounts[name] = len(raw)
+        parsed.append(raw)
         finish2 = time.perf_counter()
         if not args.quiet:
             print(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)')
         outlog.write(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)\n')
         if getattr(args, "tcf_out", False):  # (:219-229): by count, ties in dict order
-            tseqs, tc = _collapse_one(ctx, reads)
-            by = np.argsort(-tc, kind="stable")
-            tl = tseqs.to_list()
+            u1 = raw.collapse()
+            tc, tfirst = u1.counts()
+            tl = u1.unpack().to_list()
+            u1.close()
+            by = sorted(range(len(tl)), key=lambda i: (-int(tc[i, 0]), int(tfirst[i])))
             with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
-                fo.write("".join(f">seq{k + 1}_{int(tc[i])}\n{tl[i]}\n" for k, i in enumerate(by)))
+                fo.write("".join(f">seq{k + 1}_{int(tc[i, 0])}\n{tl[i]}\n" for k, i in enumerate(by)))
     t0 = time.perf_counter()
-    if device_parse:
-        if len(parsed) == 1:
-            uniq = parsed[0].collapse()
-        else:
-            allr = _ffi.DeviceReads.concat(ctx, parsed)
-            sid = np.repeat(np.arange(len(parsed), dtype=np.int32), [len(p) for p in parsed])
-            uniq = allr.collapse(sid, len(parsed))
-            allr.close()
-        for p in parsed:
-            p.close()
+    if len(parsed) == 1:
+        uniq = parsed[0].collapse()
     else:
-        uniq = collapse_samples(ctx, samples)
+        allr = _ffi.DeviceReads.concat(ctx, parsed)
+        sid = np.repeat(np.arange(len(parsed), dtype=np.int32), [len(p) for p in parsed])
+        uniq = allr.collapse(sid, len(parsed))
+        allr.close()
+    for p in parsed:
+        p.close()
     counts, first = uniq.counts()
     seqs = uniq.unpack().to_list()
     uniq.close()

@@ -117,8 +117,9 @@ __global__ void k_collapse_insert_key(GroupView<1> g, KeySlot* __restrict__ slot
 
 // rep[] / firstj[] = 0xFFFFFFFF, cnt[] = 0 in ONE launch (three hipMemsetAsync = six fill kernels per small group before)
 __global__ void k_collapse_init(uint32_t* __restrict__ rep, uint32_t* __restrict__ firstj, uint32_t* __restrict__ cnt,
-                                uint32_t tsize, uint32_t ncnt) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncnt; i += gridDim.x * blockDim.x) {
+                                uint32_t tsize, uint64_t ncnt) {
+    // ncnt = tsize * S cells of the count matrix: beyond 2^32 from ~24 samples x 4 M reads on, hence the 64-bit walk
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < ncnt; i += (uint64_t)gridDim.x * blockDim.x) {
         if (i < tsize) { rep[i] = MIRGE_EMPTY; firstj[i] = MIRGE_EMPTY; }
         cnt[i] = 0;
     }

@@ -22,17 +22,22 @@ template <int W>
 __global__ void k_pack(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ starts, const int64_t* __restrict__ ends,
                        const uint32_t* __restrict__ idx, uint32_t n, uint64_t* __restrict__ seq,
                        uint8_t* __restrict__ len, uint64_t* __restrict__ nmask,
-                       uint32_t* __restrict__ flags) {
+                       uint32_t* __restrict__ flags, const int64_t* __restrict__ s2start = nullptr,
+                       const int32_t* __restrict__ s2len = nullptr) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         const uint32_t src = idx[j];
         const int64_t b = starts[src];
-        const int L = (int)(ends[src] - b);  // contiguous reads: ends = starts + 1
+        const int L1 = (int)(ends[src] - b);  // contiguous reads: ends = starts + 1
+        // a record may continue in a second stretch of the text (--qiagenumi: insert + the UMI behind the adapter)
+        const int L2 = s2len ? (int)s2len[src] : 0;
+        const int64_t b2 = s2len ? s2start[src] - L1 : 0;
+        const int L = L1 + L2;
         uint64_t w[W], nm[W];
 #pragma unroll
         for (int i = 0; i < W; i++) { w[i] = 0; nm[i] = 0; }
         uint32_t sawN = 0, bad = 0, iupac = 0;
         for (int p = 0; p < L; p++) {
-            const uint8_t c = ascii[b + p] & 0xDF;  // upper-case
+            const uint8_t c = (p < L1 ? ascii[b + p] : ascii[b2 + p]) & 0xDF;  // upper-case
             const uint32_t bit = letter_bit(c);
             const uint32_t x = (c >> 1) & 3u;       // A 0, C 1, G 3, T / U 2 ...
             const uint64_t isn = (bit & MIRGE_LETTERS_ACGTU) ? 0ull : 1ull;
@@ -212,7 +217,7 @@ __global__ void k_nl_count(const uint8_t* __restrict__ text, uint64_t n, uint32_
 // number alone would otherwise return shifted garbage for the rest of the file
 __global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ tile_off, int period,
                           int sphase, int64_t* __restrict__ start, int64_t* __restrict__ end, uint64_t n_seq, int fmt,
-                          uint32_t* __restrict__ flags, int64_t* __restrict__ qstart) {
+                          uint32_t* __restrict__ flags, int64_t* __restrict__ qstart, int64_t* __restrict__ qend) {
     __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
     const uint64_t b0 = (uint64_t)blockIdx.x * MIRGE_PARSE_TILE + threadIdx.x * 16ull;
     uint32_t mask;
@@ -233,14 +238,25 @@ __global__ void k_nl_mark(const uint8_t* __restrict__ text, uint64_t n, const ui
         if ((int)(li % (uint64_t)period) == sphase && li / period < n_seq) end[li / period] = (int64_t)pos;
         if ((int)((li + 1) % (uint64_t)period) == sphase && (li + 1) / period < n_seq) start[(li + 1) / period] = (int64_t)pos + 1;
         if (qstart && fmt == 1 && (li + 1) % 4 == 3 && (li + 1) / 4 < n_seq) qstart[(li + 1) / 4] = (int64_t)pos + 1;  // quality line (k_trim)
+        if (qend && fmt == 1 && li % 4 == 3 && li / 4 < n_seq) qend[li / 4] = (int64_t)pos;
         li++;
     }
 }
 
+// What k_seq_class keeps of a record [start, end) (+ second stretch): the worker's length test on the read as the
+// modifiers left it (min_len_pre), then the UMI slice read[cut_front : len - cut_back] (`UMIParser`, digest.py:305-315:
+// Python's s[f:-b], an empty string when the cuts meet), then --minimum-length on what is left (min_len).
+struct SliceOpts {
+    int32_t min_len_pre;
+    int32_t min_len;
+    int32_t cut_front, cut_back;
+};
+
 // flags: [0] reads with N seen per group ... kept by k_pack; here [0] = byte outside ACGTUN seen, [1] = reads longer
 // than the limit, [2] = longest such read
-__global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __restrict__ start, int64_t* __restrict__ end,
-                            uint32_t n_seq, int32_t min_len, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cls,
+__global__ void k_seq_class(const uint8_t* __restrict__ text, int64_t* __restrict__ start, int64_t* __restrict__ end,
+                            int64_t* __restrict__ s2start, int32_t* __restrict__ s2len,
+                            uint32_t n_seq, SliceOpts so, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cls,
                             uint32_t* __restrict__ blk_keep, uint32_t nblk, uint32_t* __restrict__ hist, uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_cnt[MIRGE_NCLS + 2];
     __shared__ uint32_t s_hist[MIRGE_MAX_READ_LEN + 1];
@@ -250,20 +266,29 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __r
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     int c = MIRGE_NCLS + 1;  // no record
     if (r < n_seq) {
-        const int64_t b = start[r];
+        int64_t b = start[r];
         int64_t e = end[r];
-        if (e > b && text[e - 1] == 13) { e--; end[r] = e; }
-        const int64_t L = e - b;
-        if (L > MIRGE_MAX_READ_LEN) {
+        if (e > b && text[e - 1] == 13) e--;
+        const int64_t L1 = e - b, L2 = s2len ? (int64_t)s2len[r] : 0, tot = L1 + L2;
+        const int64_t x = so.cut_front < tot ? so.cut_front : tot;
+        int64_t y = tot - so.cut_back;
+        if (y < x) y = x;
+        const int64_t nb = b + (x < L1 ? x : L1), ne = b + (y < L1 ? y : L1);
+        const int64_t x2 = x > L1 ? x - L1 : 0, y2 = y > L1 ? y - L1 : 0;
+        const int64_t b2 = s2len ? s2start[r] + x2 : 0;
+        start[r] = nb; end[r] = ne;
+        if (s2len) { s2start[r] = b2; s2len[r] = (int32_t)(y2 - x2); }
+        const int64_t La = ne - nb, L = La + (y2 - x2);
+        if (L1 < (int64_t)so.min_len_pre || L < (int64_t)so.min_len) {
+            c = MIRGE_CLS_DROP;
+        } else if (L > MIRGE_MAX_READ_LEN) {
             atomicOr(&flags[1], 1u);
             atomicMax(&flags[2], (uint32_t)(L > 0xFFFFFFF ? 0xFFFFFFF : L));
-            c = MIRGE_CLS_DROP;
-        } else if (L < (int64_t)min_len) {
             c = MIRGE_CLS_DROP;
         } else {
             uint32_t amb = 0, bad = 0, iu = 0;
             for (int p = 0; p < (int)L; p++) {
-                const uint32_t bit = letter_bit(text[b + p] & 0xDF);
+                const uint32_t bit = letter_bit((p < (int)La ? text[nb + p] : text[b2 + p - La]) & 0xDF);
                 const bool acgt = (bit & MIRGE_LETTERS_ACGTU) != 0;
                 amb |= !acgt;
                 bad |= !acgt && !(bit & (MIRGE_LETTERS_N | MIRGE_LETTERS_IUPAC));
@@ -294,7 +319,7 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, const int64_t* __r
 
 __global__ void k_seq_place(const uint8_t* __restrict__ cls, uint32_t n_seq, const uint32_t* __restrict__ cls_off,
                             const uint32_t* __restrict__ keep_off, uint32_t nblk, uint32_t* __restrict__ src_all,
-                            uint32_t* __restrict__ orig_all) {
+                            uint32_t* __restrict__ orig_all, uint32_t* __restrict__ rec_of_kept) {
     __shared__ uint32_t lds4[MIRGE_BLOCK / 64];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = r < n_seq ? (int)cls[r] : MIRGE_NCLS + 1;
@@ -306,5 +331,53 @@ __global__ void k_seq_place(const uint8_t* __restrict__ cls, uint32_t n_seq, con
         const uint32_t rk = block_excl_scan(c == q ? 1u : 0u, total, lds4);
         if (c == q) slot = cls_off[(size_t)q * nblk + blockIdx.x] + rk;
     }
-    if (c < MIRGE_CLS_DROP) { src_all[slot] = r; orig_all[slot] = kr; }
+    if (c < MIRGE_CLS_DROP) {
+        src_all[slot] = r; orig_all[slot] = kr;
+        if (rec_of_kept) rec_of_kept[kr] = r;  // kept rank (= handle index of the read) -> record of the text
+    }
+}
+
+// --qiagenumi (digest.py:334-352): the worker takes `currentSeq.split(trimmed)[1]` -- what stands between the FIRST
+// occurrence of the trimmed read in the untrimmed line and its next non-overlapping occurrence (or the line's end) --,
+// keeps the first len(adapter) + b characters of it and of those the last b (all of them when b == 0: Python's s[-0:]):
+// the UMI that follows the 3' adapter.  An empty trimmed read makes split() raise ValueError: no UMI.  The stretch is
+// returned as the record's second segment; the dictionary key is trimmed + UMI.
+__global__ void k_qiagen_umi(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, const int64_t* __restrict__ lend,
+                             const int64_t* __restrict__ tstart, const int64_t* __restrict__ tend, uint32_t n_raw, int32_t alen,
+                             int32_t back, int64_t* __restrict__ s2start, int32_t* __restrict__ s2len) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_raw; r += gridDim.x * blockDim.x) {
+        const int64_t lb = lstart[r];
+        int64_t le = lend[r];
+        if (le > lb && text[le - 1] == 13) le--;
+        const int64_t tb = tstart[r], Lt = tend[r] - tb;
+        if (Lt <= 0) { s2start[r] = le; s2len[r] = 0; continue; }
+        auto occurs = [&](int64_t q) {
+            for (int64_t i = 0; i < Lt; i++) if (text[q + i] != text[tb + i]) return false;
+            return true;
+        };
+        int64_t p = tb;
+        for (int64_t q = lb; q < tb; q++) if (occurs(q)) { p = q; break; }
+        const int64_t rs = p + Lt;
+        int64_t re = le;
+        for (int64_t q = rs; q + Lt <= le; q++) if (occurs(q)) { re = q; break; }
+        const int64_t rest = re - rs;
+        const int64_t ulen = rest < (int64_t)alen + back ? rest : (int64_t)alen + back;
+        const int64_t take = back > 0 ? (ulen < back ? ulen : (int64_t)back) : ulen;
+        s2start[r] = rs + ulen - take;
+        s2len[r] = (int32_t)take;
+    }
+}
+
+// record bounds of the reads listed by kept rank (the first appearances of the distinct UMI-tagged reads, in the order of
+// those appearances): -udd's second collapse takes their inserts
+__global__ void k_gather_records(const uint32_t* __restrict__ rank, uint32_t n, const uint32_t* __restrict__ rec_of_kept,
+                                 const int64_t* __restrict__ start, const int64_t* __restrict__ end,
+                                 const int64_t* __restrict__ s2start, const int32_t* __restrict__ s2len,
+                                 int64_t* __restrict__ ostart, int64_t* __restrict__ oend, int64_t* __restrict__ os2start,
+                                 int32_t* __restrict__ os2len) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t r = rec_of_kept[rank[i]];
+        ostart[i] = start[r]; oend[i] = end[r];
+        if (os2len) { os2start[i] = s2start[r]; os2len[i] = s2len[r]; }
+    }
 }

@@ -89,24 +89,31 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
         consider(last, m, j);
         exact = found && b_cost == 0 && b_mat == m;
     }
-    if (!exact && !FRONT) {  // the adapter may run off the read's end: every prefix of it, in the last column
-#pragma unroll
-        for (int i = 0; i <= MAXM; i++)
+    if (!exact && !FRONT) {  // the adapter may run off the read's end: every prefix of it, in the last column, longest first
+#pragma unroll                // (cutadapt: `for i in reversed(range(first_i, m + 1))` -- on equal (matches, cost) the longer prefix stays)
+        for (int i = MAXM; i >= 0; i--)
             if (EXACT || i <= m) consider(e[i], i, n);
     }
     return found ? b_val : (FRONT ? 0 : n);
 }
 
-// lstart/lend: the sequence line of every record (after '\r' stripping here); qstart: its quality line (FASTQ) or null.
+// lstart/lend: the sequence line of every record (after '\r' stripping here); qstart/qend: its quality line (FASTQ) or null.
 // vstart/vend[r * stages_out + s]: the read after modifier s (stages_out == n_mods) or after the last one.
+// flags[5] |= 1: a record whose quality line is not as long as its sequence line (dnaio raises on it; here q[i] would
+// otherwise be taken from the next record's bytes).
 template <int MAXM, bool EXACT, bool FRONT>
 __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, const int64_t* __restrict__ lend,
-                       const int64_t* __restrict__ qstart, uint32_t n_seq, TrimOpts o, int64_t* __restrict__ vstart,
-                       int64_t* __restrict__ vend) {
+                       const int64_t* __restrict__ qstart, const int64_t* __restrict__ qend, uint32_t n_seq, TrimOpts o,
+                       int64_t* __restrict__ vstart, int64_t* __restrict__ vend, uint32_t* __restrict__ flags) {
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_seq; r += gridDim.x * blockDim.x) {
         int64_t b = lstart[r], e = lend[r];
         if (e > b && text[e - 1] == 13) e--;
         const uint8_t* q = qstart ? text + qstart[r] : nullptr;  // quality of base k of the LINE: q[k]
+        if (q && qend) {
+            int64_t qe = qend[r];
+            if (qe > qstart[r] && text[qe - 1] == 13) qe--;
+            if (qe - qstart[r] != e - b) { atomicOr(&flags[5], 1u); q = nullptr; }
+        }
         int a0 = 0, a1 = (int)((e - b) > 0x7F00 ? 0x7F00 : (e - b));  // current read = line[a0, a1)
         const uint8_t* s = text + b;
         int stage = 0;

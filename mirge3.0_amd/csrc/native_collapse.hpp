@@ -137,6 +137,9 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         const uint32_t cap1 = attempt == 1 ? chunk
                                            : small_region ? std::max<uint32_t>(4, chunk / NB1 / 2 & ~3u) : part_region_cap((double)chunk / NB1);
         const uint64_t slab = (uint64_t)RPW * cap1;  // a splitter's input can never exceed the capacity of its regions
+        // test hook: MIRGE_TEST_PART_OOM=1 makes the roomy second attempt fail like an exhausted device would
+        static const bool part_oom = std::getenv("MIRGE_TEST_PART_OOM") != nullptr;
+        if (part_oom && attempt == 1) return fail(-3, "hipMalloc: out of memory (MIRGE_TEST_PART_OOM)");
         CHECK(dalloc(c, &t.rec1, (size_t)NB1 * G * cap1));
         CHECK(dalloc(c, &t.cnt1, (size_t)NB1 * G));
         if (NB2 > 1) {
@@ -178,7 +181,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         CHECK(dalloc(c, &t.firstj, tsize));
         CHECK(dalloc(c, &t.cnt, (size_t)tsize * S));
         hipLaunchKernelGGL(k_collapse_init, dim3(grid_for(c, (size_t)tsize * S)), dim3(MIRGE_BLOCK), 0, c->cur, t.rep, t.firstj, t.cnt,
-                           tsize, (uint32_t)((size_t)tsize * S));
+                           tsize, (uint64_t)tsize * (uint64_t)S);
         std::snprintf(name, sizeof(name), "k_collapse_insert%s", group_tag(gi));
         LaunchScope ls(c, name, in.n);
         // at most 2 workgroups per CU: each sees enough of the group for its LDS cell cache to merge hot reads
@@ -292,6 +295,20 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         hc.lap("enqueue A");
+        if (rc == -3 && attempt < 2) {
+            // the partitioned attempts take up to 2 KiB of HBM per read (attempt 1); the global-atomic tables ~20 B.  A device
+            // that cannot give the former (a second context in flight, a fragmented pool) is no reason to fail the call.
+            (void)hipStreamSynchronize(c->aux); (void)hipStreamSynchronize(c->stream);
+            for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+                collapse_tmp_release(c, tmp[gi]);
+                ReadGroup& og = R->g[gi];
+                c->release(og.seq); c->release(og.len); c->release(og.counts); c->release(og.first);
+                og = ReadGroup();
+            }
+            c->flush_deferred();  // (alloc() hands cached blocks back to the driver by itself when a request fails)
+            rc = 0; attempt = 1;  // -> the loop's increment makes it 2
+            continue;
+        }
         bool hooked = false;
         if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
             hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);

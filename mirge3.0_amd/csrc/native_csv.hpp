@@ -83,7 +83,7 @@ extern "C" int mirge_annotation_csv(const char* mapped_path, const char* unmappe
         const int64_t lo = n_rows * t / T, hi = n_rows * (t + 1) / T;
         CsvBuf &M = bufm[(size_t)t], &U = bufu[(size_t)t];
         if (!M.room((size_t)(hi - lo) * 56)) { bad[(size_t)t] = 2; return; }
-        const size_t fixed = 2 + (size_t)n_name_cols + (size_t)S * 21 + 1 + 2;  // flag, commas, counts, newline, quotes
+        const size_t fixed = 2 + (size_t)n_name_cols + (size_t)S * 21 + 1 + 4;  // flag, commas, counts, newline, the quotes of two quoted fields
         for (int64_t k = lo; k < hi; k++) {
             // the rows come in the order of first appearance, the arrays in the order the device emitted the reads: every row
             // is four cache misses unless they are asked for ahead

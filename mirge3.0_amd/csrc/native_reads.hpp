@@ -135,10 +135,10 @@ extern "C" int32_t mirge_reads_iupac_seen(const mirge_reads* r) { return r ? (r-
 
 template <int W>
 static int launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstart, const int64_t* dend, const uint32_t* didx,
-                        ReadGroup& g, uint32_t* dflags) {
+                        ReadGroup& g, uint32_t* dflags, const int64_t* s2start = nullptr, const int32_t* s2len = nullptr) {
     LaunchScope ls(c, "k_pack", g.n);
     hipLaunchKernelGGL(k_pack<W>, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
-                       dascii, dstart, dend, didx, g.n, g.seq, g.len, g.nmask, dflags);
+                       dascii, dstart, dend, didx, g.n, g.seq, g.len, g.nmask, dflags, s2start, s2len);
     return 0;
 }
 
@@ -271,108 +271,144 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
 // k_trim<64, false, *>: any adapter of up to 64 bases -- a 3' adapter with N, or a 5' adapter
 template <int M>
 static int launch_trim_exact(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, const int64_t* lstart, const int64_t* lend,
-                             const int64_t* qstart, uint32_t n_raw, int64_t* dstart, int64_t* dend) {
+                             const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
     if constexpr (M > MIRGE_TRIM_MAX_ADAPTER) {
         return fail(-1, "mirge_reads_parse_trim: adapter length");
     } else {
         if (o.alen == M) {
-            hipLaunchKernelGGL((k_trim<M, true, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+            hipLaunchKernelGGL((k_trim<M, true, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
             return 0;
         }
-        return launch_trim_exact<M + 1>(c, o, dtext, lstart, lend, qstart, n_raw, dstart, dend);
+        return launch_trim_exact<M + 1>(c, o, dtext, lstart, lend, qstart, qend, n_raw, dstart, dend, dflags);
     }
 }
 static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, const int64_t* lstart, const int64_t* lend,
-                       const int64_t* qstart, uint32_t n_raw, int64_t* dstart, int64_t* dend) {
+                       const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
     bool wild = false;
     for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
     if (o.front) {  // a 5' adapter is the rare case: the general kernel
-        hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, true>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+        hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, true>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
         return 0;
     }
-    if (o.alen >= 1 && !wild) return launch_trim_exact<1>(c, o, dtext, lstart, lend, qstart, n_raw, dstart, dend);
-    hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, n_raw, o, dstart, dend);
+    if (o.alen >= 1 && !wild) return launch_trim_exact<1>(c, o, dtext, lstart, lend, qstart, qend, n_raw, dstart, dend, dflags);
+    hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
     return 0;
 }
 
-extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
-                                      const mirge_trim* trim, mirge_reads** out, int64_t* n_records);
-extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
-                                 mirge_reads** out, int64_t* n_records) {
-    return mirge_reads_parse_trim(c, text, nbytes, format, min_len, nullptr, out, n_records);
-}
-
-extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
-                                      const mirge_trim* trim, mirge_reads** out, int64_t* n_records) {
-    if (!c || !out || nbytes < 0 || (nbytes > 0 && !text) || format < 0 || format > 3)
-        return fail(-1, "mirge_reads_parse: bad argument");
-    HIPOK(hipSetDevice(c->device));
-    if (format == 0) format = nbytes == 0 ? 3 : (text[0] == '@' ? 1 : (text[0] == '>' ? 2 : 3));
-    TrimOpts topt;
-    bool trimming = false;
-    if (trim) {
-        CHECK(trim_options(trim, format, topt));
-        trimming = topt.n_mods > 0;
+// ------------------------------------------------------------------------------------------
+// text -> records -> packed reads, in two steps that share a ParseJob:
+//   parse_lines : the text in HBM, its lines found, the modifiers applied (k_trim): [dstart, dend) of every virtual
+//                 record (a record after every modifier, or after the last), for --qiagenumi the UMI stretch behind
+//                 the adapter as a second segment
+//   parse_pack  : length tests + UMI slice (k_seq_class), stable placement by read group (k_seq_place), 2-bit packing
+//                 straight from the text (k_pack) -> a mirge_reads
+// mirge_reads_parse[_trim] = one of each; mirge_reads_parse_umi with -udd runs parse_pack twice (the tagged reads, then
+// the inserts of the distinct ones) around a collapse.
+// ------------------------------------------------------------------------------------------
+struct ParseJob {
+    mirge_ctx* c = nullptr;
+    int format = 0;
+    uint64_t n = 0;      // bytes of dtext, with the final newline
+    uint32_t n_raw = 0;  // records of the text
+    uint32_t n_seq = 0;  // virtual records
+    uint8_t* dtext = nullptr;
+    uint32_t *tile_cnt = nullptr, *tile_off = nullptr, *lflags = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_cap = 0;
+    int64_t *dstart = nullptr, *dend = nullptr, *lstart = nullptr, *lend = nullptr, *qstart = nullptr, *qend = nullptr;
+    int64_t* s2start = nullptr;
+    int32_t* s2len = nullptr;
+    bool line_flags_checked = false;
+    ~ParseJob() {
+        if (!c) return;
+        (void)hipStreamSynchronize(c->stream);
+        c->release(dtext); c->release(tile_cnt); c->release(tile_off); c->release(lflags); c->release(tmp);
+        c->release(dstart); c->release(dend); c->release(lstart); c->release(lend); c->release(qstart); c->release(qend);
+        c->release(s2start); c->release(s2len);
     }
+};
+#define MIRGE_LFLAG_WORDS 8  // [3] record structure broken, [5] quality line length != sequence line length
+
+static int parse_lines(ParseJob& J, const char* text, int64_t nbytes, const TrimOpts* topt, const mirge_umi* umi) {
+    mirge_ctx* c = J.c;
+    const int format = J.format;
+    const bool trimming = topt && topt->n_mods > 0;
     const int period = format == 1 ? 4 : (format == 2 ? 2 : 1), sphase = format == 3 ? 0 : 1;
-    auto R = std::make_unique<mirge_reads>();
-    R->ctx = c; R->n = 0;
-    std::memset(R->len_hist, 0, sizeof(R->len_hist));
-    R->hist_valid = true;
-    R->total_bases = 0;
-    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
-    if (n_records) *n_records = 0;
-    // blank lines at the end of the file are not records (dnaio stops at them too)
-    while (nbytes > 0 && (text[nbytes - 1] == '\n' || text[nbytes - 1] == '\r' || text[nbytes - 1] == ' ' || text[nbytes - 1] == '\t')) nbytes--;
-    if (nbytes == 0) { *out = R.release(); return 0; }
     // the text, with a final newline
-    const bool add_nl = true;
-    const uint64_t n = (uint64_t)nbytes + (add_nl ? 1 : 0);
+    const uint64_t n = (uint64_t)nbytes + 1;
+    J.n = n;
     // lines are counted in 32 bits: below 8 GiB a text would need lines of less than two bytes to wrap the counter
     if (n >= (1ull << 33)) return fail(-5, "mirge_reads_parse: a text of 8 GiB or more must be passed in parts (mirge_reads_concat)");
     const uint32_t ntile = (uint32_t)((n + MIRGE_PARSE_TILE - 1) / MIRGE_PARSE_TILE);
-    uint8_t* dtext = nullptr;
-    uint32_t *tile_cnt = nullptr, *tile_off = nullptr;
-    CHECK(dalloc(c, &dtext, (size_t)n + 16));
-    CHECK(dalloc(c, &tile_cnt, (size_t)ntile + 1));
-    CHECK(dalloc(c, &tile_off, (size_t)ntile + 1));
-    HIPOK(hipMemcpyAsync(dtext, text, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
-    if (add_nl) HIPOK(hipMemsetAsync(dtext + nbytes, '\n', 1, c->stream));
-    HIPOK(hipMemsetAsync(tile_cnt + ntile, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_nl_count, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_cnt);
-    void* tmp = nullptr;
+    CHECK(dalloc(c, &J.dtext, (size_t)n + 16));
+    CHECK(dalloc(c, &J.tile_cnt, (size_t)ntile + 1));
+    CHECK(dalloc(c, &J.tile_off, (size_t)ntile + 1));
+    CHECK(dalloc(c, &J.lflags, (size_t)MIRGE_LFLAG_WORDS));
+    HIPOK(hipMemcpyAsync(J.dtext, text, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemsetAsync(J.dtext + nbytes, '\n', 1, c->stream));
+    HIPOK(hipMemsetAsync(J.tile_cnt + ntile, 0, 4, c->stream));
+    HIPOK(hipMemsetAsync(J.lflags, 0, MIRGE_LFLAG_WORDS * 4, c->stream));
+    hipLaunchKernelGGL(k_nl_count, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, J.dtext, n, J.tile_cnt);
     size_t tmp_bytes = 0;
-    HIPOK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, tile_cnt, tile_off, (int)(ntile + 1), c->stream));
-    size_t tmp_cap = std::max<size_t>(tmp_bytes, 1 << 16);
-    CHECK(dalloc(c, (uint8_t**)&tmp, tmp_cap));
-    HIPOK(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, tile_cnt, tile_off, (int)(ntile + 1), c->stream));
+    HIPOK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, J.tile_cnt, J.tile_off, (int)(ntile + 1), c->stream));
+    J.tmp_cap = std::max<size_t>(tmp_bytes, 1 << 16);
+    CHECK(dalloc(c, (uint8_t**)&J.tmp, J.tmp_cap));
+    HIPOK(hipcub::DeviceScan::ExclusiveSum(J.tmp, tmp_bytes, J.tile_cnt, J.tile_off, (int)(ntile + 1), c->stream));
     uint32_t n_lines = 0;
-    HIPOK(hipMemcpyAsync(&n_lines, tile_off + ntile, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(&n_lines, J.tile_off + ntile, 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
-    if (n_lines % (uint32_t)period != 0) {
-        c->release(dtext); c->release(tile_cnt); c->release(tile_off); c->release(tmp);
+    if (n_lines % (uint32_t)period != 0)
         return fail(-9, "mirge_reads_parse: " + std::to_string(n_lines) + " lines is not a whole number of " + std::to_string(period) +
                             "-line records (truncated file, blank line, or a FASTA with wrapped sequences)");
-    }
     // sequence lines: li in [0, n_lines) with li % period == sphase
     const uint64_t n_seq64 = n_lines > (uint32_t)sphase ? ((uint64_t)n_lines - sphase + period - 1) / period : 0;
-    int rc = n_seq64 >= 0xFFFFFFF0ull ? fail(-5, "more than 2^32 reads in one set is not supported") : 0;
-    const uint32_t n_raw = rc ? 0u : (uint32_t)n_seq64;  // records of the text
-    if (n_records) *n_records = n_raw;
+    if (n_seq64 >= 0xFFFFFFF0ull) return fail(-5, "more than 2^32 reads in one set is not supported");
+    J.n_raw = (uint32_t)n_seq64;
     // with trimming a record becomes `stages_out` virtual records (the read after every modifier, or after the last)
-    const uint64_t n_virt64 = (uint64_t)n_raw * (trimming ? (uint64_t)topt.stages_out : 1ull);
-    if (rc == 0 && n_virt64 >= 0xFFFFFFF0ull) rc = fail(-5, "more than 2^32 reads in one set is not supported");
-    const uint32_t n_seq = rc ? 0u : (uint32_t)n_virt64;
-    int64_t *dstart = nullptr, *dend = nullptr, *lstart = nullptr, *lend = nullptr, *qstart = nullptr;
+    const uint64_t n_virt64 = (uint64_t)J.n_raw * (trimming ? (uint64_t)topt->stages_out : 1ull);
+    if (n_virt64 >= 0xFFFFFFF0ull) return fail(-5, "more than 2^32 reads in one set is not supported");
+    J.n_seq = (uint32_t)n_virt64;
+    if (!J.n_seq) return 0;
+    CHECK(dalloc(c, &J.dstart, (size_t)J.n_seq));
+    CHECK(dalloc(c, &J.dend, (size_t)J.n_seq));
+    if (trimming) {
+        CHECK(dalloc(c, &J.lstart, (size_t)J.n_raw));
+        CHECK(dalloc(c, &J.lend, (size_t)J.n_raw));
+        if (format == 1) { CHECK(dalloc(c, &J.qstart, (size_t)J.n_raw)); CHECK(dalloc(c, &J.qend, (size_t)J.n_raw)); }
+    }
+    hipLaunchKernelGGL(k_nl_mark, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, J.dtext, n, J.tile_off, period, sphase,
+                       trimming ? J.lstart : J.dstart, trimming ? J.lend : J.dend, (uint64_t)J.n_raw, (int)format, J.lflags, J.qstart, J.qend);
+    if (trimming) {
+        LaunchScope ls(c, "k_trim", J.n_raw);
+        CHECK(launch_trim(c, *topt, J.dtext, J.lstart, J.lend, J.qstart, J.qend, J.n_raw, J.dstart, J.dend, J.lflags));
+    }
+    if (umi && umi->qiagen) {  // (trimming with one output stage: checked by the caller)
+        CHECK(dalloc(c, &J.s2start, (size_t)J.n_raw));
+        CHECK(dalloc(c, &J.s2len, (size_t)J.n_raw));
+        LaunchScope ls(c, "k_qiagen_umi", J.n_raw);
+        hipLaunchKernelGGL(k_qiagen_umi, dim3(grid_for(c, J.n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, J.dtext, J.lstart, J.lend, J.dstart,
+                           J.dend, J.n_raw, topt->alen, umi->back, J.s2start, J.s2len);
+    }
+    return 0;
+}
+
+// records [start, end) (+ second segments) of J's text -> R (empty on entry).  rec_of_kept (optional, caller releases): the
+// record of every read of R, by handle index.
+static int parse_pack(ParseJob& J, int64_t* start, int64_t* end, int64_t* s2start, int32_t* s2len, uint32_t n_seq, const SliceOpts& so,
+                      mirge_reads* R, uint32_t** rec_of_kept) {
+    mirge_ctx* c = J.c;
+    const int format = J.format;
+    R->n = 0; R->total_bases = 0; R->hist_valid = true;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
+    if (!n_seq) return 0;
     uint8_t* dcls = nullptr;
     uint32_t *blk = nullptr, *blk_off = nullptr, *keep = nullptr, *keep_off = nullptr, *dmeta = nullptr, *src_all = nullptr,
-             *orig_all = nullptr;
+             *orig_all = nullptr, *rok = nullptr;
     const uint32_t nblk = std::max<uint32_t>(1, (n_seq + MIRGE_BLOCK - 1) / MIRGE_BLOCK);
-    const size_t meta_words = 8 + MIRGE_MAX_READ_LEN + 1;  // [0..2] flags, [8..] length histogram
+    const size_t meta_words = 8 + MIRGE_MAX_READ_LEN + 1;  // [0..4] flags, [8..] length histogram
+    int rc = 0;
     do {
-        if (!n_seq) break;
-        if ((rc = dalloc(c, &dstart, (size_t)n_seq))) break;
-        if ((rc = dalloc(c, &dend, (size_t)n_seq))) break;
         if ((rc = dalloc(c, &dcls, (size_t)n_seq))) break;
         if ((rc = dalloc(c, &blk, (size_t)MIRGE_NGROUPS * nblk + 1))) break;
         if ((rc = dalloc(c, &blk_off, (size_t)MIRGE_NGROUPS * nblk + 1))) break;
@@ -383,36 +419,26 @@ extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nb
         if (e == hipSuccess) e = hipMemsetAsync(blk + (size_t)MIRGE_NGROUPS * nblk, 0, 4, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(keep + nblk, 0, 4, c->stream);
         if (e != hipSuccess) { rc = fail(-2, hipGetErrorString(e)); break; }
-        if (trimming) {
-            if ((rc = dalloc(c, &lstart, (size_t)n_raw))) break;
-            if ((rc = dalloc(c, &lend, (size_t)n_raw))) break;
-            if (format == 1 && (rc = dalloc(c, &qstart, (size_t)n_raw))) break;
-        }
-        hipLaunchKernelGGL(k_nl_mark, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, dtext, n, tile_off, period, sphase,
-                           trimming ? lstart : dstart, trimming ? lend : dend, (uint64_t)n_raw, (int)format, dmeta, qstart);
-        if (trimming) {
-            LaunchScope ls(c, "k_trim", n_raw);
-            rc = launch_trim(c, topt, dtext, lstart, lend, qstart, n_raw, dstart, dend);
-            if (rc) break;
-        }
-        hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dtext, dstart, dend, n_seq, min_len, dcls, blk,
+        hipLaunchKernelGGL(k_seq_class, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, J.dtext, start, end, s2start, s2len, n_seq, so, dcls, blk,
                            keep, nblk, dmeta + 8, dmeta);
         size_t need = 0;
         e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, blk, blk_off, (int)(MIRGE_NGROUPS * nblk + 1), c->stream);
-        if (e == hipSuccess && need > tmp_cap) { c->release(tmp); tmp = nullptr; tmp_cap = need; if ((rc = dalloc(c, (uint8_t**)&tmp, tmp_cap))) break; }
-        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need, blk, blk_off, (int)(MIRGE_NGROUPS * nblk + 1), c->stream);
-        size_t need2 = tmp_cap;
-        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, need2, keep, keep_off, (int)(nblk + 1), c->stream);
+        if (e == hipSuccess && need > J.tmp_cap) { c->release(J.tmp); J.tmp = nullptr; J.tmp_cap = need; if ((rc = dalloc(c, (uint8_t**)&J.tmp, J.tmp_cap))) break; }
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(J.tmp, need, blk, blk_off, (int)(MIRGE_NGROUPS * nblk + 1), c->stream);
+        size_t need2 = J.tmp_cap;
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(J.tmp, need2, keep, keep_off, (int)(nblk + 1), c->stream);
         // group bounds = blk_off at the first block of every class, and the total
         uint32_t bounds[MIRGE_NGROUPS + 1];
         for (int q = 0; q < MIRGE_NGROUPS && e == hipSuccess; q++)
             e = hipMemcpyAsync(&bounds[q], blk_off + (size_t)q * nblk, 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&bounds[MIRGE_NGROUPS], blk_off + (size_t)MIRGE_NGROUPS * nblk, 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->pinned, dmeta, meta_words * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->pinned + 512, J.lflags, MIRGE_LFLAG_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { rc = fail(-2, std::string("mirge_reads_parse: ") + hipGetErrorString(e)); break; }
-        if (c->pinned[3]) { rc = fail(-9, std::string("mirge_reads_parse: a record does not start with '") + (format == 1 ? "@' / its third line with '+'" : ">'") +
-                                            " (truncated file, blank line, or a FASTA with wrapped sequences)"); break; }
+        if (c->pinned[512 + 3]) { rc = fail(-9, std::string("mirge_reads_parse: a record does not start with '") + (format == 1 ? "@' / its third line with '+'" : ">'") +
+                                                  " (truncated file, blank line, or a FASTA with wrapped sequences)"); break; }
+        if (c->pinned[512 + 5]) { rc = fail(-9, "mirge_reads_parse: a record's quality line is not as long as its sequence line"); break; }
         if (c->pinned[1]) { rc = fail(-6, "a read is " + std::to_string(c->pinned[2]) + " nt; the limit is " + std::to_string(MIRGE_MAX_READ_LEN)); break; }
         if (c->pinned[0]) { rc = fail(-7, "a read contains a character that is no nucleotide code (A/C/G/T/U/N or an IUPAC ambiguity code)"); break; }
         R->iupac_seen = c->pinned[4] != 0;
@@ -425,8 +451,9 @@ extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nb
         if (!kept) break;
         if ((rc = dalloc(c, &src_all, (size_t)kept))) break;
         if ((rc = dalloc(c, &orig_all, (size_t)kept))) break;
+        if (rec_of_kept && (rc = dalloc(c, &rok, (size_t)kept))) break;
         hipLaunchKernelGGL(k_seq_place, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dcls, n_seq, blk_off, keep_off, nblk, src_all,
-                           orig_all);
+                           orig_all, rok);
         uint32_t* dflags = dmeta;  // reused: k_pack's per-group (saw N, bad byte) pairs
         e = hipMemsetAsync(dflags, 0, 64, c->stream);
         for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0 && e == hipSuccess; gi++) {
@@ -440,7 +467,7 @@ extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nb
             e = hipMemcpyAsync(g.orig, orig_all + bounds[gi], (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream);
             const uint32_t* src = src_all + bounds[gi];
             int prc = 0;
-            MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, dtext, dstart, dend, src, g, dflags + 2 * gi));
+            MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, J.dtext, start, end, src, g, dflags + 2 * gi, s2start, s2len));
             (void)prc;
         }
         if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -450,12 +477,127 @@ extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nb
                 if (R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
     } while (0);
     (void)hipStreamSynchronize(c->stream);
-    c->release(dtext); c->release(tile_cnt); c->release(tile_off); c->release(tmp); c->release(dstart); c->release(dend);
     c->release(dcls); c->release(blk); c->release(blk_off); c->release(keep); c->release(keep_off); c->release(dmeta);
-    c->release(src_all); c->release(orig_all); c->release(lstart); c->release(lend); c->release(qstart);
+    c->release(src_all); c->release(orig_all);
+    if (rc) { c->release(rok); return rc; }
+    if (rec_of_kept) *rec_of_kept = rok;
+    return 0;
+}
+
+static void reads_clear_groups(mirge_reads* r) {
+    for (auto& g : r->g) {
+        r->ctx->release(g.seq); r->ctx->release(g.len); r->ctx->release(g.nmask);
+        r->ctx->release(g.orig); r->ctx->release(g.counts); r->ctx->release(g.first);
+        g = ReadGroup();
+    }
+}
+
+extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S, mirge_reads** uniq, int64_t* n_uniq);
+
+extern "C" int mirge_reads_parse_umi(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                                     const mirge_trim* trim, const mirge_umi* umi, mirge_reads** out, int64_t* n_records,
+                                     mirge_reads** tagged_out) {
+    if (!c || !out || nbytes < 0 || (nbytes > 0 && !text) || format < 0 || format > 3)
+        return fail(-1, "mirge_reads_parse: bad argument");
+    if (tagged_out) *tagged_out = nullptr;
+    if (umi && (umi->front < 0 || umi->back < 0 || umi->front > MIRGE_MAX_READ_LEN || umi->back > MIRGE_MAX_READ_LEN))
+        return fail(-1, "mirge_reads_parse_umi: -umi f,b out of range");
+    HIPOK(hipSetDevice(c->device));
+    if (format == 0) format = nbytes == 0 ? 3 : (text[0] == '@' ? 1 : (text[0] == '>' ? 2 : 3));
+    TrimOpts topt;
+    std::memset(&topt, 0, sizeof(topt));
+    if (trim) CHECK(trim_options(trim, format, topt));
+    if (umi && umi->qiagen) {
+        // the reference reads the UMI behind args.adapters[0] (digest.py:120-121,342-347) and counts such a read once,
+        // after the last modifier (the length test and the dictionary update follow the loop in this branch, :349-353)
+        if (!trim || topt.alen <= 0 || topt.front) return fail(-1, "mirge_reads_parse_umi: --qiagenumi needs the 3' adapter the UMI follows (-a)");
+        topt.stages_out = 1;
+    }
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = 0;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
+    R->hist_valid = true;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
+    if (n_records) *n_records = 0;
+    // blank lines at the end of the file are not records (dnaio stops at them too)
+    while (nbytes > 0 && (text[nbytes - 1] == '\n' || text[nbytes - 1] == '\r' || text[nbytes - 1] == ' ' || text[nbytes - 1] == '\t')) nbytes--;
+    if (nbytes == 0) { *out = R.release(); return 0; }
+    ParseJob J;
+    J.c = c; J.format = format;
+    int rc = parse_lines(J, text, nbytes, trim ? &topt : nullptr, umi);
     if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    if (n_records) *n_records = J.n_raw;
+    const int32_t f = umi ? umi->front : 0, b = umi ? umi->back : 0;
+    // the worker's own length test (digest.py:348 / :360 / :368): on the read as the modifiers left it, with -umi (no
+    // --qiagenumi) on what UMIParser leaves of it, max(0, len - f - b)
+    const int32_t pre = !umi ? 0 : (umi->qiagen ? min_len : (min_len > 0 ? min_len + f + b : 0));
+    if (!umi || !umi->dedup) {
+        // counts add up: slicing every counted read == slicing the keys of the merged dictionary (digest.py:164-181)
+        const SliceOpts so{pre, min_len, f, b};
+        rc = parse_pack(J, J.dstart, J.dend, J.s2start, J.s2len, J.n_seq, so, R.get(), nullptr);
+        if (rc) { mirge_reads_destroy(R.release()); return rc; }
+        *out = R.release();
+        return 0;
+    }
+    // -udd (digest.py:183-205): the distinct UMI-tagged reads first ...
+    uint32_t* rec_of_kept = nullptr;
+    {
+        const SliceOpts so{pre, 0, 0, 0};
+        rc = parse_pack(J, J.dstart, J.dend, J.s2start, J.s2len, J.n_seq, so, R.get(), &rec_of_kept);
+    }
+    mirge_reads* T = nullptr;
+    int64_t U = 0;
+    if (rc == 0) rc = mirge_collapse(c, R.get(), nullptr, 1, &T, &U);
+    std::unique_ptr<mirge_reads, void (*)(mirge_reads*)> Tg(T, mirge_reads_destroy);
+    // ... then ONE read per distinct tagged read, its insert, in the order the tagged reads first appeared: the second
+    // collapse (the caller's) counts molecules, and its first indices are ranks in the reference's dictionary order
+    uint32_t *keys = nullptr, *keys2 = nullptr;
+    int64_t *st2 = nullptr, *en2 = nullptr, *s2s2 = nullptr;
+    int32_t* s2l2 = nullptr;
+    void* stmp = nullptr;
+    do {
+        if (rc) break;
+        reads_clear_groups(R.get());
+        if (!U) break;
+        if ((rc = dalloc(c, &keys, (size_t)U))) break;
+        if ((rc = dalloc(c, &keys2, (size_t)U))) break;
+        hipError_t e = hipSuccess;
+        for (int gi = 0; gi < MIRGE_NGROUPS && e == hipSuccess; gi++) {
+            const ReadGroup& g = T->g[gi];
+            if (g.n) e = hipMemcpyAsync(keys + g.base, g.first, (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream);
+        }
+        size_t sb = 0;
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(nullptr, sb, keys, keys2, (int)U, 0, 32, c->stream);
+        if (e == hipSuccess && (rc = dalloc(c, (uint8_t**)&stmp, std::max<size_t>(sb, 16)))) break;
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(stmp, sb, keys, keys2, (int)U, 0, 32, c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_reads_parse_umi: ") + hipGetErrorString(e)); break; }
+        if ((rc = dalloc(c, &st2, (size_t)U))) break;
+        if ((rc = dalloc(c, &en2, (size_t)U))) break;
+        if (J.s2len) {
+            if ((rc = dalloc(c, &s2s2, (size_t)U))) break;
+            if ((rc = dalloc(c, &s2l2, (size_t)U))) break;
+        }
+        hipLaunchKernelGGL(k_gather_records, dim3(grid_for(c, (size_t)U)), dim3(MIRGE_BLOCK), 0, c->stream, keys2, (uint32_t)U, rec_of_kept,
+                           J.dstart, J.dend, J.s2start, J.s2len, st2, en2, s2s2, s2l2);
+        const SliceOpts so{0, min_len, f, b};
+        rc = parse_pack(J, st2, en2, s2s2, s2l2, (uint32_t)U, so, R.get(), nullptr);
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(rec_of_kept); c->release(keys); c->release(keys2); c->release(stmp);
+    c->release(st2); c->release(en2); c->release(s2s2); c->release(s2l2);
+    if (rc) { mirge_reads_destroy(R.release()); return rc; }
+    if (tagged_out) *tagged_out = Tg.release();
     *out = R.release();
     return 0;
+}
+
+extern "C" int mirge_reads_parse_trim(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                                      const mirge_trim* trim, mirge_reads** out, int64_t* n_records) {
+    return mirge_reads_parse_umi(c, text, nbytes, format, min_len, trim, nullptr, out, n_records, nullptr);
+}
+extern "C" int mirge_reads_parse(mirge_ctx* c, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
+                                 mirge_reads** out, int64_t* n_records) {
+    return mirge_reads_parse_umi(c, text, nbytes, format, min_len, nullptr, nullptr, out, n_records, nullptr);
 }
 
 

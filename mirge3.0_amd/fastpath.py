@@ -22,15 +22,15 @@ import numpy as np
 
 from . import PASS_COLUMNS, _ffi
 from .cascade import PASSES, get_cascade
-from .collapse import read_text, read_texts, trim_from_args
+from .collapse import parse_sample, read_text, read_texts, trim_from_args, umi_from_args
 from .countjoin import summarize_device
 from .seqio import FlatSeqs, load_merges
 
 
 def eligible(args) -> bool:
-    """flags the device-resident run covers; the others take the DataFrame route (they need the frame itself)"""
-    return not (getattr(args, "uniq_mol_ids", None) or getattr(args, "tcf_out", False) or getattr(args, "save_pkl", False)
-                or getattr(args, "resume", False))
+    """flags the device-resident run covers (-umi / --qiagenumi / -udd included); the others take the DataFrame route
+    (they need the frame itself: the pickles of -spl / -rr, the per-sample dictionaries of -tcf)"""
+    return not (getattr(args, "tcf_out", False) or getattr(args, "save_pkl", False) or getattr(args, "resume", False))
 
 
 def row_order(seqs: FlatSeqs, first: np.ndarray, n_samples: int) -> np.ndarray:
@@ -71,7 +71,8 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     workDir = Path(workDir)
     casc = casc or get_cascade(args, ref_db, getattr(args, "device", 0))
     ctx = casc.ctx
-    raw, n_rec = _ffi.DeviceReads.parse(ctx, read_text(str(file)), 0, int(getattr(args, "minimum_length", 16)), trim_from_args(args))
+    raw, n_rec = parse_sample(ctx, read_text(str(file)), int(getattr(args, "minimum_length", 16)), trim_from_args(args),
+                              umi_from_args(args), workDir, name)
     n_trimmed = len(raw)
     uniq, res = casc.collapse_and_run(raw)
     raw.close()
@@ -105,6 +106,7 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     tm["libraries_s"] = time.perf_counter() - t0
     min_len = int(getattr(args, "minimum_length", 16))
     trim = trim_from_args(args)
+    umi = umi_from_args(args)
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     parsed = []
     t_read = t_parse = 0.0
@@ -114,7 +116,7 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         text = next(texts)
         t_read += time.perf_counter() - t
         t1 = time.perf_counter()
-        raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 0, min_len, trim)
+        raw, n_rec = parse_sample(ctx, text, min_len, trim, umi, workDir, name)
         del text
         t_parse += time.perf_counter() - t1
         sampleReadCounts[name], trimmedReadCounts[name] = n_rec, len(raw)

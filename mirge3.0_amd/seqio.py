@@ -42,6 +42,38 @@ class FlatSeqs:
         data = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).copy()
         return FlatSeqs(data, offsets)
 
+    @staticmethod
+    def from_fixed(arr: np.ndarray) -> "FlatSeqs":
+        """a numpy array of fixed-width byte strings ('S<k>', NUL-padded) -> ragged sequences without the padding"""
+        arr = np.ascontiguousarray(arr)
+        k = arr.dtype.itemsize
+        mat = arr.view(np.uint8).reshape(-1, k)
+        used = mat != 0
+        lens = used.sum(axis=1).astype(np.int64)
+        offsets = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        return FlatSeqs(mat[used], offsets)
+
+    @staticmethod
+    def join_columns(cols: Sequence["FlatSeqs"], seps: bytes) -> bytes:
+        """the text of a table: row i = cols[0][i] seps[0] cols[1][i] seps[1] ... (one separator byte after every
+        column, the last one usually a newline), built with numpy scatters"""
+        n = len(cols[0])
+        assert len(seps) == len(cols) and all(len(c) == n for c in cols)
+        lens = [c.lengths for c in cols]
+        row_len = sum(lens) + len(cols)
+        roff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(row_len, out=roff[1:])
+        out = np.empty(int(roff[-1]), dtype=np.uint8)
+        at = roff[:-1].copy()
+        for c, ln, sep in zip(cols, lens, seps):
+            rows = np.repeat(np.arange(n, dtype=np.int64), ln)
+            out[at[rows] + (np.arange(c.data.shape[0], dtype=np.int64) - c.offsets[:-1][rows])] = c.data
+            at = at + ln
+            out[at] = sep
+            at = at + 1
+        return out.tobytes()
+
     def _ranges(self, starts: np.ndarray, lens: np.ndarray) -> "FlatSeqs":
         offsets = np.zeros(lens.shape[0] + 1, dtype=np.int64)
         np.cumsum(lens, out=offsets[1:])

@@ -170,6 +170,57 @@ def umi_collapse(raw: List[str], f: int, b: int, min_len: int, dedup: bool):
     return list(d.items()), trimmed, (["UMISeq,transcriptSeq,UMICounts\n"] + rows if dedup else None)
 
 
+def qiagen_key(current: str, trimmed: str, adapter_len: int, b: int) -> str:
+    """The dictionary key of the worker's ``qiagenumi`` branch (digest.py:340-348): the trimmed read plus the UMI that
+    follows the 3' adapter in the untrimmed read, by the reference's own string rule --
+    ``currentSeq.split(trimmed)[1][:len(adapter)+b][-b:]`` (first occurrence of the trimmed read; the text up to its
+    next occurrence; ``ValueError`` of an empty separator -> no UMI).  [The reference would raise IndexError if the
+    trimmed read did not occur in the untrimmed one; a modifier chain that only removes bases cannot produce that.]"""
+    try:
+        umi_seq = current.split(trimmed)[1]
+        max_ad = adapter_len + int(b)
+        umi_seq = umi_seq[:max_ad][-int(b):]
+    except ValueError:
+        umi_seq = ""
+    return trimmed + umi_seq
+
+
+def umi_worker_reads(records, opts: dict, f: int, b: int, min_len: int, qiagen: bool, per_modifier: bool = True):
+    """What the per-chunk worker puts into its dictionary with ``-umi`` (digest.py:334-365), one entry per count, in
+    file order.  records: (sequence, qualities | None).  qiagen: the read after the LAST modifier + its UMI, kept when
+    the trimmed read has min_len bases (:349).  Otherwise: the read after EVERY modifier (``per_modifier``, the loop
+    body at HEAD :354-365) or after the last, kept when ``UMIParser`` leaves min_len bases (:359-360)."""
+    out = []
+    for seq, qual in records:
+        stages = trim_stages(seq, qual, opts)
+        if qiagen:
+            final = stages[-1] if stages else seq
+            if len(final) >= min_len:
+                out.append(qiagen_key(seq, final, len(opts["adapter"]), b))
+            continue
+        for st in (stages if per_modifier else stages[-1:]):
+            if len(umi_parser(st, f, b)[0]) >= min_len:
+                out.append(st)
+    return out
+
+
+def umi_baking(keys: List[str], f: int, b: int, min_len: int, dedup: bool):
+    """baking's merge (digest.py:158-163) and UMI stage (:164-205) over the worker's keys ->
+    (ordered (insert, count) pairs, trimmed, lines of <sample>_umiCounts.csv or None)."""
+    complete = {}
+    for s in keys:
+        complete[s] = complete.get(s, 0) + 1
+    d, trimmed, rows = {}, 0, []
+    for s, c in complete.items():
+        pure, tag = umi_parser(s, f, b)
+        if len(pure) >= min_len:
+            if dedup:
+                rows.append(f"{tag},{pure},{c}\n")
+            d[pure] = d.get(pure, 0) + (1 if dedup else c)
+            trimmed += 1 if dedup else c
+    return list(d.items()), trimmed, (["UMISeq,transcriptSeq,UMICounts\n"] + rows if dedup else None)
+
+
 def _fmt_float(x: float) -> str:
     return repr(float(x))
 
@@ -637,7 +688,7 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
     stop inside the adapter when it runs off the read's end): unit costs, indels allowed; of the alignments with
     cost <= aligned adapter length * max_error_rate and at least min_overlap adapter bases, the one with the most
     matches, then the lowest cost, first found (full-adapter matches in order of their end in the read, then the
-    partial ones at the read's end by growing adapter prefix).  An 'N' in the adapter matches any base and does not
+    partial ones at the read's end from the longest adapter prefix down).  An 'N' in the adapter matches any base and does not
     count towards the length the error rate applies to.  -> (astart, astop, rstart, rstop, matches, errors) or None."""
     m, n = len(adapter), len(read)
     wild = [c == "N" for c in adapter]
@@ -677,7 +728,9 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
             done = True
             break
     if not done:
-        for i in range(0, m + 1):
+        # cutadapt walks the last column from the longest adapter prefix down (`for i in reversed(range(first_i, m + 1))`):
+        # of two prefixes with equal (matches, cost) the LONGER one is kept
+        for i in range(m, -1, -1):
             consider(prev[i], i, n)
     return best
 

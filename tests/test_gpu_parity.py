@@ -446,6 +446,16 @@ def test_device_text_parser_equals_host_parser(ctx, ci_libs, tmp_path):
         _ffi.DeviceReads.parse(ctx, ("A" * 256 + "\n").encode(), 3, 0)
     with pytest.raises(RuntimeError, match="no nucleotide code"):
         _ffi.DeviceReads.parse(ctx, b"ACGTACGTACGTACGTXACGT\n", 3, 0)
+    # a record whose quality line is shorter / longer than its sequence line: dnaio raises, and so does the trimming parser
+    # (k_trim would otherwise take the missing qualities from the next record's bytes)
+    good = b"@a\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\n"
+    for bad in (b"@b\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIII\n", b"@b\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIIIIIII\n"):
+        for text in (good + bad, bad + good, good + bad + good):
+            with pytest.raises(RuntimeError, match="quality line"):
+                _ffi.DeviceReads.parse(ctx, text, 1, 16, _ffi.MirgeTrim.make(quality_back=10))
+    dr, n_rec = _ffi.DeviceReads.parse(ctx, good.replace(b"\n", b"\r\n") * 3, 1, 16, _ffi.MirgeTrim.make(quality_back=10))
+    assert len(dr) == 3 and n_rec == 3
+    dr.close()
 
 
 def test_baking_umi_against_reference_vectors(ctx, tmp_path):
@@ -485,9 +495,113 @@ def test_baking_umi_against_reference_vectors(ctx, tmp_path):
     assert list(df.index) == union
     assert df["A"].tolist() == [da.get(q, 0) for q in union] and df["B"].tolist() == [db.get(q, 0) for q in union]
     assert uniq == {"A": len(da), "B": len(db)} and trimmed == {"A": sum(da.values()), "B": sum(db.values())}
-    with pytest.raises(NotImplementedError):
-        baking(SimpleNamespace(quiet=True, minimum_length=16, adapters=None, front=None, uniq_mol_ids="4,4",
-                               qiagenumi=True), [src_file], ["reads"], str(tmp_path), ctx=ctx)
+
+
+def _umi_dict(ctx, text, fmt, min_len, trim, umi, tmp_path, name):
+    """parse_sample + collapse -> ([(insert, count)] in dictionary order, trimmed, text of <name>_umiCounts.csv or None)"""
+    from mirge3_amd.collapse import parse_sample
+    wd = tmp_path / name
+    wd.mkdir()
+    raw, n_rec = parse_sample(ctx, text, min_len, trim, umi, wd, "S")
+    uniq = raw.collapse()
+    cnt, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    order = np.argsort(first, kind="stable")
+    got = [(seqs[i], int(cnt[i, 0])) for i in order]
+    n = len(raw)
+    uniq.close(); raw.close()
+    f = wd / "S_umiCounts.csv"
+    return got, n, n_rec, (f.read_text() if f.exists() else None)
+
+
+def test_documented_umi_command_lines_known_answer(ctx, tmp_path):
+    """`-a AACTGTAGGCACCATCAAT --qiagenumi -umi 0,12 -udd` and `-a illumina -umi 4,4 -udd` (the reference's documented UMI
+    runs, docs/source/quick_start.md:286,306) on the ten reads printed below them (:294-298,310-314): let-7a-5p, five
+    molecules each -- through mirge_reads_parse_umi on the GPU, and through the CLI."""
+    from test_oracle_golden import ILLUMINA_4N_READS, LET7A, QIAGEN_READS
+    from mirge3_amd.collapse import ILLUMINA_3P
+    fq = lambda reads, k: "".join(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(r for r in reads for _ in range(k))).encode()
+    trim = _ffi.MirgeTrim.make(adapter="AACTGTAGGCACCATCAAT", quality_back=10)
+    got, n, n_rec, csv = _umi_dict(ctx, fq(QIAGEN_READS, 3), 1, 16, trim, _ffi.MirgeUmi.make(0, 12, qiagen=True, dedup=True), tmp_path, "q")
+    assert got == [(LET7A, 5)] and n == 5 and n_rec == 15
+    assert csv.splitlines()[:2] == ["UMISeq,transcriptSeq,UMICounts", f"GTTAGACCTGCA,{LET7A},3"] and len(csv.splitlines()) == 6
+    got, n, _, csv = _umi_dict(ctx, fq(QIAGEN_READS, 3), 1, 16, trim, _ffi.MirgeUmi.make(0, 12, qiagen=True), tmp_path, "q2")
+    assert got == [(LET7A, 15)] and n == 15 and csv is None
+    trim = _ffi.MirgeTrim.make(adapter=ILLUMINA_3P, quality_back=10, count_per_modifier=False)
+    got, n, _, csv = _umi_dict(ctx, fq(ILLUMINA_4N_READS, 2), 1, 16, trim, _ffi.MirgeUmi.make(4, 4, dedup=True), tmp_path, "i")
+    assert got == [(LET7A, 5)] and n == 5 and csv.splitlines()[1] == f"TACACCTC,{LET7A},2"
+    # the worker at HEAD counts after every modifier: the untrimmed read's 'insert' is a row too (oracle: same)
+    trim = _ffi.MirgeTrim.make(adapter=ILLUMINA_3P, quality_back=10, count_per_modifier=True)
+    got, n, _, _ = _umi_dict(ctx, fq(ILLUMINA_4N_READS, 2), 1, 16, trim, _ffi.MirgeUmi.make(4, 4, dedup=True), tmp_path, "i2")
+    assert got[0] == (ILLUMINA_4N_READS[0][4:-4], 1) and got[1] == (LET7A, 5) and len(got) == 5 and n == 10
+    # the two command lines themselves, on golden case 1's libraries (let-7a is not in them: the rows go to unmapped.csv)
+    case = GoldenCase("case1_single")
+    for tag, reads, extra in (("qia", QIAGEN_READS, ["-a", "AACTGTAGGCACCATCAAT", "--qiagenumi", "-umi", "0,12", "-udd"]),
+                              ("ill", ILLUMINA_4N_READS, ["-a", "illumina", "-umi", "4,4", "-udd", "--trim-count", "once"])):
+        p = tmp_path / f"{tag}.fastq"
+        p.write_bytes(fq(reads, 2))
+        _run_cli(["-s", str(p), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", tag, "-shh"] + extra)
+        rows = (tmp_path / tag / "unmapped.csv").read_text().splitlines() + (tmp_path / tag / "mapped.csv").read_text().splitlines()
+        assert [r for r in rows if r.startswith(LET7A + ",")][0].endswith(",5")
+        rep = (tmp_path / tag / "annotation.report.csv").read_text().splitlines()[1].split(",")
+        assert rep[1:4] == ["10", "5", "1"]  # Total Input Reads, Trimmed Reads (all) = molecules, Trimmed Reads (unique)
+        assert len((tmp_path / tag / f"{tag}_umiCounts.csv").read_text().splitlines()) == 6
+
+
+def _umi_records(rng, n, adapter, f, b, qiagen):
+    """FASTQ records of UMI libraries: [f nt UMI] insert [b nt UMI] adapter ... (4N layout) or insert adapter [b nt UMI]
+    external adapter (Qiagen layout), from a few inserts and UMIs so that molecules repeat; adapters with errors,
+    reads that end inside the adapter / the UMI, low-quality tails, inserts that contain themselves twice."""
+    inserts = ["".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(14, 34)))) for _ in range(60)]
+    inserts += ["ACGTACGTACGTACGTAC" + "GG" + "ACGTACGTACGTACGTAC", "A" * 20, "TGAGGTAGTAGGTTGTATAGTT"]
+    umis = ["".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=f + b)) for _ in range(9)]
+    recs = []
+    for i in range(n):
+        ins = inserts[int(rng.integers(0, len(inserts)))]
+        u = umis[int(rng.integers(0, len(umis)))]
+        ad = list(adapter)
+        kind = int(rng.integers(0, 8))
+        if kind == 1:
+            ad[int(rng.integers(0, len(ad)))] = "ACGT"[int(rng.integers(0, 4))]
+        elif kind == 2:
+            del ad[int(rng.integers(1, len(ad) - 1))]
+        ad = "".join(ad)
+        ext = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"
+        seq = (ins + ad + u[f:] + ext) if qiagen else (u[:f] + ins + u[f:] + ad + ext)
+        seq = seq[:int(rng.integers(30, 91))] if kind in (3, 4) else seq[:76]
+        if kind == 5:
+            seq = ins  # no adapter at all
+        q = np.full(len(seq), ord("I"), dtype=np.uint8)
+        if rng.random() < 0.25:
+            k = int(rng.integers(1, 12))
+            q[-k:] = rng.integers(33, 48, size=min(k, len(seq)))
+        if rng.random() < 0.05:
+            q[:int(rng.integers(1, 4))] = 35
+        recs.append((seq, q.tobytes().decode()))
+    return recs + [("ACGT", "IIII"), (adapter, "I" * len(adapter))]
+
+
+@pytest.mark.parametrize("f,b,qiagen,q_front", [(4, 4, False, 0), (0, 12, True, 0), (0, 12, True, 8), (3, 0, False, 0), (0, 5, False, 0),
+                                                 (2, 7, True, 0), (0, 0, True, 0), (6, 30, False, 0)])
+@pytest.mark.parametrize("dedup", [False, True])
+def test_umi_route_equals_the_restated_worker_and_baking(ctx, tmp_path, f, b, qiagen, q_front, dedup):
+    """mirge_reads_parse_umi + mirge_collapse against the oracle's restatement of the worker's UMI branches
+    (digest.py:334-365) and baking's UMI stage (:164-205): the final dictionary in order, 'Trimmed Reads (all)', and
+    <sample>_umiCounts.csv byte for byte; -umi f,b with either end 0, --qiagenumi incl. its first-occurrence rule and
+    b == 0, counting after every modifier (HEAD) and once."""
+    adapter = "AACTGTAGGCACCATCAAT" if qiagen else "TGGAATTCTCGGGTGCCAAGGAACTCCAG"
+    rng = np.random.default_rng(100 * f + b + qiagen)
+    recs = _umi_records(rng, 5000, adapter, f, b, qiagen)
+    text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+    for per_modifier in (True, False):
+        trim = _ffi.MirgeTrim.make(adapter=adapter, quality_back=10, quality_front=q_front, count_per_modifier=per_modifier)
+        got, n, n_rec, csv = _umi_dict(ctx, text, 1, 16, trim, _ffi.MirgeUmi.make(f, b, qiagen=qiagen, dedup=dedup), tmp_path,
+                                       f"w{int(per_modifier)}")
+        keys = oracle.umi_worker_reads(recs, dict(q_back=10, q_front=q_front, adapter=adapter), f, b, 16, qiagen, per_modifier)
+        want, trimmed, rows = oracle.umi_baking(keys, f, b, 16, dedup)
+        assert n_rec == len(recs) and n == trimmed
+        assert got == want and len(want) > 30
+        assert csv == ("".join(rows) if dedup else None)
 
 
 # ---------------------------------------------------------------- size-independent properties
@@ -793,7 +907,7 @@ def test_partitioned_collapse_sizes_and_skew(ctx, n, shape):
     u.close(); raw.close()
 
 
-@pytest.mark.parametrize("hook", ["MIRGE_TEST_SMALL_PART", "MIRGE_TEST_SMALL_REGION"])
+@pytest.mark.parametrize("hook", ["MIRGE_TEST_SMALL_PART", "MIRGE_TEST_SMALL_REGION", "MIRGE_TEST_SMALL_REGION+MIRGE_TEST_PART_OOM"])
 def test_collapse_partition_overflow_falls_back(tmp_path, hook):
     """A bucket holding more distinct reads than its LDS table raises the overflow flag and the call is redone
     with the global-atomic tables: forced here with the MIRGE_TEST_SMALL_PART hook in a fresh process.  The same flag is
@@ -825,9 +939,43 @@ got = dict(zip(u.unpack().to_list(), cnt[:, 0].tolist()))
 assert got == dict(exp), (len(got), len(exp))
 print("OK", len(got))
 """ % root
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{hook: "1"}),
+    # the third form: the roomy second attempt (2 KiB of HBM per read) cannot get its memory (MIRGE_TEST_PART_OOM makes its
+    # first allocation fail as an exhausted device would) -- the call must go on to the global-atomic tables, not fail
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{h: "1" for h in hook.split("+")}),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_collapse_count_matrix_beyond_2_to_32_cells(ctx):
+    """The general path's slot table x sample matrix passes 2^32 cells from ~24 samples x 4 M reads on (here: 2^20 slots
+    x 4100 samples = 17 GB, sized for 288 GB of HBM): every cell must start at zero -- the init kernel walks it in 64
+    bits -- or the per-sample counts come out of recycled pool memory."""
+    rng = np.random.default_rng(9)
+    S, n, T = 4100, 300_000, 500
+    tl = ["".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(L))) for L in rng.integers(16, 40, size=T)]
+    tmpl = FlatSeqs.from_list(tl)
+    # dirty the pool first: a block of the matrix's size, filled with ones, goes back to the pool
+    import ctypes as C
+    pick = rng.integers(0, T, size=n)
+    sid = rng.integers(0, S, size=n).astype(np.int32)
+    sid[:S] = np.arange(S)  # every sample occurs
+    reads = tmpl.take(pick)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    for _ in range(2):  # the second call reuses the first call's (now non-zero) matrix block
+        uniq = raw.collapse(sid, S)
+        cnt, first = uniq.counts()
+        seqs = uniq.unpack().to_list()
+        assert sorted(seqs) == sorted(set(tl[k] for k in pick)) and cnt.shape == (len(seqs), S)
+        want = np.zeros((T, S), dtype=np.int64)
+        np.add.at(want, (pick, sid), 1)
+        by_seq = {}
+        for k in range(T):
+            by_seq[tl[k]] = by_seq.get(tl[k], 0) + want[k]
+        for i, q in enumerate(seqs):
+            assert np.array_equal(cnt[i].astype(np.int64), by_seq[q]), q
+        assert int(cnt.sum()) == n
+        uniq.close()
+    raw.close()
 
 
 def test_staged_cascade_for_every_group():

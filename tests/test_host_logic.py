@@ -125,7 +125,9 @@ def test_cli_flags_in_and_out_of_scope():
     base = ["-s", "a.fq", "-lib", "/x", "-on", "human"]
     a = parse_args(base + ["-umi", "4,4", "-udd", "-tcf", "-spk", "-m", "18", "-ie"])
     assert a.uniq_mol_ids == "4,4" and a.umiDedup and a.tcf_out and a.spikeIn and a.minimum_length == 18 and a.isoform_entropy
-    assert a.adapters is None and a.qiagenumi is None and a.quality_cutoff == "10"
+    assert a.adapters is None and a.qiagenumi is False and a.quality_cutoff == "10"
+    q = parse_args(base + ["-a", "AACTGTAGGCACCATCAAT", "--qiagenumi", "-umi", "0,12", "-udd"])  # docs/source/quick_start.md:286
+    assert q.qiagenumi and q.umiDedup and q.uniq_mol_ids == "0,12"
     b = parse_args(base + ["-ai", "-pbwt", "/opt/bowtie", "--genome-retained", "r.txt"])
     assert b.AtoI and b.bowtie_path == "/opt/bowtie" and b.genome_retained == "r.txt"
     t = parse_args(base + ["-a", "illumina", "-q", "5,20", "-NX", "-u", "2", "-u", "-1", "--trim-count", "once"])

@@ -70,3 +70,69 @@ def test_umi_restatement_against_reference_vectors():
             assert [list(x) for x in d] == c[key]["dict"]
             assert trimmed == c[key]["trimmed"] and len(d) == c[key]["unique"]
             assert ("".join(rows) if rows else None) == c[key]["umiCounts_csv"]
+
+
+# the ten reads the reference's documentation prints for its two UMI command lines (docs/source/quick_start.md:290-298,
+# 306-314): hsa-let-7a-5p with five distinct UMIs each
+QIAGEN_READS = [
+    "TGAGGTAGTAGGTTGTATAGTTAACTGTAGGCACCATCAATGTTAGACCTGCAAGATCGGAAGAGCACACGTCTG",
+    "TGAGGTAGTAGGTTGTATAGTTAACTGTAGGCACCATCAATCAATGACGATTTAGATCGGAAGAGCACACGTCTG",
+    "TGAGGTAGTAGGTTGTATAGTTAACTGTAGGCACCATCAATAAACAAAGATCCAGATCGGAAGAGCACACGTCTG",
+    "TGAGGTAGTAGGTTGTATAGTTAACTGTAGGCACCATCAATCGCATCGCCGACAGATCGGAAGAGCACACGTCTG",
+    "TGAGGTAGTAGGTTGTATAGTTAACTGTAGGCACCATCAATTTTGCCATTACTAGATCGGAAGAGCACACGTCTG",
+]
+ILLUMINA_4N_READS = [
+    "TACATGAGGTAGTAGGTTGTATAGTTCCTCTGGAATTCTCGGGTGCCAAGGAACTCCAGTCACCGGAATATCTCG",
+    "TACCTGAGGTAGTAGGTTGTATAGTTACTATGGAATTCTCGGGTGCCAAGGAACTCCAGTCACCGGAATATCTCG",
+    "CAGGTGAGGTAGTAGGTTGTATAGTTGGTATGGAATTCTCGGGTGCCAAGGAACTCCAGTCACCGGAATATCTCG",
+    "AGAATGAGGTAGTAGGTTGTATAGTTACTATGGAATTCTCGGGTGACAAGGAACTCCAGTCACCGGAATATCTCG",
+    "AGGTTGAGGTAGTAGGTTGTATAGTTACTATGGAATTCTCGGGTGCCAAGGAACTCCAGTCACCGGAATATCTCG",
+]
+LET7A = "TGAGGTAGTAGGTTGTATAGTT"
+
+
+def test_documented_umi_reads_are_known_answers():
+    """The reference's two documented UMI command lines (quick_start.md:286,306) on the reads printed below them: the
+    restated worker (digest.py:334-365) + baking's UMI stage (:164-205) must give let-7a-5p with five molecules."""
+    recs = [(s, "I" * len(s)) for s in QIAGEN_READS for _ in range(3)]  # three PCR copies of every molecule
+    opts = dict(q_back=10, adapter="AACTGTAGGCACCATCAAT")
+    keys = oracle.umi_worker_reads(recs, opts, 0, 12, 16, qiagen=True)
+    assert keys[0] == LET7A + "GTTAGACCTGCA" and len(keys) == 15
+    d, trimmed, rows = oracle.umi_baking(keys, 0, 12, 16, dedup=True)
+    assert d == [(LET7A, 5)] and trimmed == 5
+    assert rows[1] == f"GTTAGACCTGCA,{LET7A},3\n" and len(rows) == 6
+    d, trimmed, _ = oracle.umi_baking(keys, 0, 12, 16, dedup=False)
+    assert d == [(LET7A, 15)] and trimmed == 15
+    # -a illumina -umi 4,4 -udd; the fourth read's adapter carries a substitution and is still found
+    recs = [(s, "I" * len(s)) for s in ILLUMINA_4N_READS for _ in range(2)]
+    opts = dict(q_back=10, adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAG")
+    keys = oracle.umi_worker_reads(recs, opts, 4, 4, 16, qiagen=False, per_modifier=False)
+    assert keys[0] == "TACA" + LET7A + "CCTC"
+    d, trimmed, rows = oracle.umi_baking(keys, 4, 4, 16, dedup=True)
+    assert d == [(LET7A, 5)] and trimmed == 5 and rows[1] == f"TACACCTC,{LET7A},2\n"
+    # at HEAD the worker counts inside its loop over the modifiers (digest.py:354-365): the quality-trimmed read, adapter
+    # still on it, is a dictionary key of its own, and its 'insert' a row of the final table
+    keys = oracle.umi_worker_reads(recs, opts, 4, 4, 16, qiagen=False, per_modifier=True)
+    d, trimmed, _ = oracle.umi_baking(keys, 4, 4, 16, dedup=True)
+    assert d[0] == (ILLUMINA_4N_READS[0][4:-4], 1) and d[1] == (LET7A, 5) and len(d) == 5 and trimmed == 10  # reads 2 and 5 share a 67-nt 'insert'
+
+
+def test_qiagen_key_follows_the_references_string_rule():
+    """digest.py:340-348 is string work on the untrimmed read: the FIRST occurrence of the trimmed read decides, the text
+    up to its next occurrence is what the UMI is cut from, an empty trimmed read gives no UMI, a short remainder a short
+    UMI -- and UMIParser then takes the missing bases from the insert's end."""
+    ad, b = "AACTGTAGGCACCATCAAT", 12
+    ins = "TGAGGTAGTAGGTTGTATAGTT"
+    umi = "GTTAGACCTGCA"
+    assert oracle.qiagen_key(ins + ad + umi + "AGATCGG", ins, len(ad), b) == ins + umi
+    assert oracle.qiagen_key(ins, ins, len(ad), b) == ins                       # nothing trimmed: split -> ['', '']
+    assert oracle.qiagen_key(ins + ad + umi[:5], ins, len(ad), b) == ins + (ad + umi[:5])[-12:]  # read ends inside the UMI
+    assert oracle.qiagen_key("ACGT", "", len(ad), b) == ""                      # ValueError: empty separator
+    rep = "ACGTACGTACGTACGTAC"                                                  # the trimmed read occurs twice:
+    cur = rep + "GG" + rep + ad + umi                                           # [1] is what stands between the two
+    assert oracle.qiagen_key(cur, rep, len(ad), b) == rep + "GG"
+    # 5' quality trimming: the first occurrence may sit in front of the real one
+    assert oracle.qiagen_key("TT" + rep + "CCC" + rep + ad, rep, len(ad), b) == rep + "CCC"
+    # b == 0: Python's s[-0:] is the whole string -- the key keeps adapter and all
+    assert oracle.qiagen_key(ins + ad + umi, ins, len(ad), 0) == ins + ad
+    assert oracle.umi_parser(ins + umi[:5], 0, 12) == (ins[:-7], ins[-7:] + umi[:5])

@@ -65,3 +65,14 @@ def test_trim_stages_with_a_five_prime_adapter():
     read = "CC" + AD + INS + "NN"
     stages = oracle.trim_stages(read, "I" * len(read), dict(q_back=10, adapter=AD, front=True, trim_n=True, cut=[-2]))
     assert stages == [read, INS + "NN", INS, INS[:-2]]
+
+
+def test_partial_adapter_ties_keep_the_longer_prefix():
+    """Last column of the alignment matrix (the adapter runs off the read's end): cutadapt walks it from the longest
+    adapter prefix down (`for i in reversed(range(first_i, m + 1))`) with a strict (matches, cost) improvement rule, so of
+    two prefixes with equal matches and cost the LONGER one is reported.  Reads where a 16- and a 17-base prefix tie
+    (one error each): the cut point is the same here, the reported adapter stretch is the longer one."""
+    for read, astop, rstart in (("TCCGGCGGTATCAGACATTGGAATTCTCGGGTGGC", 17, 18), ("CTGGCGACTTCGTCGCTGGAATTCTCGGGTGCCC", 18, 16),
+                                ("ACGTTACCCGGGGCTCTGGAATTCTCAG", 12, 16)):
+        hit = oracle.adapter_locate_back("TGGAATTCTCGGGTGCCAAGGAACTCCAG", read)
+        assert hit[1] == astop and hit[2] == rstart and hit[5] == 1, hit
