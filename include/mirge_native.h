@@ -146,6 +146,11 @@ int mirge_reads_unpack(mirge_ctx* ctx, const mirge_reads* reads, char* ascii_out
  * U x n_samples count matrix.                                                              */
 int mirge_collapse(mirge_ctx* ctx, const mirge_reads* raw, const int32_t* sample_ids,
                    int32_t n_samples, mirge_reads** uniq, int64_t* n_uniq);
+/* The same where raw read i stands for weights[i] (host, >= 1) copies: merges already collapsed dictionaries -- the
+ * per-sample results a sharded run gathers on rank 0 -- into the sample matrix (the outer join of digest.py:243)
+ * without expanding them.  first indices refer to the raw set as given. */
+int mirge_collapse_weighted(mirge_ctx* ctx, const mirge_reads* raw, const int32_t* sample_ids, int32_t n_samples,
+                            const uint32_t* weights, mirge_reads** uniq, int64_t* n_uniq);
 /* counts_out[U * n_samples] (row-major), first_index_out[U] (index of the first raw read, may be NULL) */
 int mirge_collapse_fetch(mirge_ctx* ctx, const mirge_reads* uniq, uint32_t* counts_out,
                          int64_t* first_index_out);

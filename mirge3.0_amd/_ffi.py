@@ -23,7 +23,7 @@ EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
-    "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_fetch", "mirge_collapse_order",
+    "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
@@ -294,12 +294,21 @@ class DeviceReads:
         _check(load().mirge_reads_unpack(self.ctx._h, self._h, _p(data), _p(off)), "mirge_reads_unpack")
         return FlatSeqs(data[:off[-1]].copy(), off)
 
-    def collapse(self, sample_ids: Optional[np.ndarray] = None, n_samples: int = 1) -> "DeviceReads":
+    def collapse(self, sample_ids: Optional[np.ndarray] = None, n_samples: int = 1,
+                 weights: Optional[np.ndarray] = None) -> "DeviceReads":
+        """``weights`` (uint32 per read): read i stands for that many copies (``mirge_collapse_weighted``)."""
         sid = None if sample_ids is None else np.ascontiguousarray(sample_ids, dtype=np.int32)
         h = C.c_void_p()
         nu = C.c_int64()
-        _check(load().mirge_collapse(self.ctx._h, self._h, _p(sid), C.c_int32(n_samples), C.byref(h),
-                                     C.byref(nu)), "mirge_collapse")
+        if weights is None:
+            _check(load().mirge_collapse(self.ctx._h, self._h, _p(sid), C.c_int32(n_samples), C.byref(h),
+                                         C.byref(nu)), "mirge_collapse")
+        else:
+            w = np.ascontiguousarray(weights, dtype=np.uint32)
+            if w.shape[0] != len(self):
+                raise ValueError("one weight per read")
+            _check(load().mirge_collapse_weighted(self.ctx._h, self._h, _p(sid), C.c_int32(n_samples), _p(w), C.byref(h),
+                                                  C.byref(nu)), "mirge_collapse_weighted")
         return DeviceReads(self.ctx, h)
 
     def counts(self) -> Tuple[np.ndarray, np.ndarray]:

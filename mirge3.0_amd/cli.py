@@ -2,17 +2,17 @@
 
   python -m mirge3_amd.cli -s S1.fastq,S2.fastq -lib /path/Libs -on human -db miRBase -o out
 
-Same flag names as the reference (``mirge/libs/parse.py``) for what is implemented; flags of
-subsystems that are out of scope (novel miRNA, GFF, BAM, tRF, A-to-I, DESeq2, miREC, adapter
-trimming, -qumi) are rejected instead of being ignored.  Writes the reference's files: ``run.log``,
-``mapped.csv``, ``unmapped.csv``, ``miR.Counts.csv``, ``miR.RPM.csv``, ``annotation.report.csv/html``
-(+ ``isomirs.csv`` / ``isomirs.samples.csv`` with ``-ie``).
+Same flag names as the reference (``mirge/libs/parse.py``) for what is implemented -- trimming (-a / -g / -q / -nxt / -NX /
+-u), UMIs (-umi / --qiagenumi / -udd), -spk, -tcf, -spl / -rr, -ie, -gff, -ai --; switches of subsystems that are out of
+scope (novel miRNA, BAM, tRF, DESeq2, miREC) are rejected instead of being ignored.  Writes the reference's files:
+``run.log``, ``mapped.csv``, ``unmapped.csv``, ``miR.Counts.csv``, ``miR.RPM.csv``, ``annotation.report.csv/html``
+(+ ``isomirs.csv`` / ``isomirs.samples.csv`` with ``-ie``, ``sample_miRge3.gff`` with ``-gff``, the three
+``a2IEditing.*`` files with ``-ai``, ``<sample>_umiCounts.csv`` with ``-udd``).
 
 One process: all samples on one GPU, byte-compatible outputs.  Under ``torch.distributed.run`` with N
-ranks: samples are sharded one per GPU (multigpu.py), rank 0 writes the three tables; the per-read
-``mapped.csv``/``unmapped.csv`` are then written per sample (``mapped.<sample>.csv``) by the rank that
-owns it, because the cross-sample outer join of sequences is the only step that would need an
-exchange.
+ranks: samples are sharded one per GPU (multigpu.py); rank 0 gathers each sample's count columns and its
+dictionary with the annotation, merges the dictionaries into the sample matrix on its GPU and writes the same
+files as the one-process run (``fastpath.run_sharded_rank0``).
 """
 from __future__ import annotations
 
@@ -173,22 +173,18 @@ def main(argv=None):
         from . import multigpu
         from .cascade import get_cascade, EXACT_PASS, ISO_PASS
         from .seqio import load_merges
-        dist.init_process_group("gloo")  # tables of a few kB: host-side gather, no device collective
+        dist.init_process_group("gloo")  # per-sample results of some MB: host-side gather, no device collective
         casc = get_cascade(args, ref_db, args.device)
 
-        if not fastpath.eligible(args) or args.AtoI or args.gff_out or args.isoform_entropy:
-            sys.exit("the sharded run (one sample per GPU) covers the count tables and the per-sample mapped/unmapped files; "
-                     "-umi / -tcf / -ie / -gff / -ai run in one process")
+        if not fastpath.eligible(args):
+            sys.exit("-tcf / -spl / -rr are single-process options")
 
-        def process(i):  # device-resident per sample (fastpath.run_sample_tables); only a few kB per sample leave the rank
+        def process(i):  # device-resident per sample (fastpath.run_sample_tables)
             return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc)
 
         tables = multigpu.run_sharded(len(files), rank, world, process, dist)
-        if rank == 0:
-            names, src, trimmed, uniq, cls, ex, iso = multigpu.merge_tables(tables)
-            finish_tables(cls, ex, iso, casc.libs["mirna"],
-                          load_merges(str(args.libraries_path), args.organism_name, ref_db), names, src, trimmed,
-                          uniq, float(args.crThreshold), bool(args.spikeIn), workDir=workDir)
+        if rank == 0:  # the same files as the one-process run: count tables, ONE mapped.csv / unmapped.csv, -gff / -ai / -ie
+            fastpath.run_sharded_rank0(args, tables, workDir, ref_db, casc)
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and not args.quiet:

@@ -25,7 +25,8 @@ template <int W>
 __global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, uint32_t* __restrict__ firstj,
                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of,
                                   uint32_t mask, const int32_t* __restrict__ sample_ids,
-                                  const uint32_t* __restrict__ orig, uint32_t base, int32_t S, uint32_t j_lo, uint32_t j_hi) {
+                                  const uint32_t* __restrict__ orig, uint32_t base, int32_t S, uint32_t j_lo, uint32_t j_hi,
+                                  const uint32_t* __restrict__ weight) {
     __shared__ unsigned long long c_key[MIRGE_CELL_CACHE];
     __shared__ uint32_t c_min[MIRGE_CELL_CACHE];
     __shared__ uint32_t c_cnt[MIRGE_CELL_CACHE];
@@ -47,7 +48,9 @@ __global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, ui
             s = (s + 1) & mask;
         }
         slot_of[j] = s;
-        const int32_t sid = sample_ids ? sample_ids[orig ? orig[j] : base + j] : 0;
+        const uint32_t hidx = orig ? orig[j] : base + j;
+        const int32_t sid = sample_ids ? sample_ids[hidx] : 0;
+        const uint32_t wgt = weight ? weight[hidx] : 1u;  // a read that stands for `wgt` copies (mirge_collapse_weighted)
         // The slot now identifies the read's sequence.  Its (min index, count) update goes through a
         // workgroup cache in LDS keyed by the cell (slot, sample): a hot sequence -- adapter dimers
         // are millions of identical long reads -- then costs this workgroup one pair of global
@@ -60,7 +63,7 @@ __global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, ui
             if (cur == 0ull) cur = atomicCAS(&c_key[cs], 0ull, cell);
             if (cur == 0ull || cur == cell) {
                 atomicMin(&c_min[cs], j);
-                atomicAdd(&c_cnt[cs], 1u);
+                atomicAdd(&c_cnt[cs], wgt);
                 cached = true;
                 break;
             }
@@ -68,7 +71,7 @@ __global__ void k_collapse_insert(GroupView<W> g, uint32_t* __restrict__ rep, ui
         }
         if (!cached) {
             atomicMin(&firstj[s], j);
-            atomicAdd(&cnt[(size_t)s * S + sid], 1u);
+            atomicAdd(&cnt[(size_t)s * S + sid], wgt);
         }
     }
     __syncthreads();

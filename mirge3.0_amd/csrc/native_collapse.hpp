@@ -73,7 +73,8 @@ static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGro
 
 template <int W>
 static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t,
-                            const int32_t* dsample, int32_t S, uint32_t* dmeta, int attempt, int stage = 0) {
+                            const int32_t* dsample, int32_t S, uint32_t* dmeta, int attempt, int stage = 0,
+                            const uint32_t* dweight = nullptr) {
     // attempt 0: partitioned key path, level-1 regions sized for a uniform hash; 1: the same with regions as large as a
     // writer's chunk (nothing can overflow them: a burst of one sequence that arrives after the chunk cache has filled
     // then costs memory -- 1 KiB per read -- not the global-atomic path); 2: global-atomic tables
@@ -82,7 +83,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
     if (!in.n) return 0;
     if (stage == 2 && t.partitioned) return collapse_part_rest(c, gi, in, out, t, dmeta, 2);
     // key path: <=31 nt, no ambiguous call, one sample -> the slot holds the 64-bit key itself
-    const bool key_path = (W == 1) && !in.nmask && S == 1;
+    const bool key_path = (W == 1) && !in.nmask && S == 1 && !dweight;
     // slots of the open-addressing table: next power of two above 1.5 n (key path) / 2 n, computed in 64 bits --
     // a read set near the 2^32 limit of mirge_reads_pack would wrap a 32-bit size to 0 and never terminate
     const uint64_t need = key_path ? (uint64_t)in.n + in.n / 2 : 2ull * in.n;
@@ -191,10 +192,10 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         // every copy in the first wave of threads sees the slot empty and they all compare-and-swap ONE address
         const uint32_t seed = std::min<uint32_t>(in.n, MIRGE_COLLAPSE_SEED);
         hipLaunchKernelGGL(k_collapse_insert<W>, dim3((seed + MIRGE_BLOCK - 1) / MIRGE_BLOCK), dim3(MIRGE_BLOCK), 0, c->cur,
-                           v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S, 0u, seed);
+                           v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S, 0u, seed, dweight);
         if (in.n > seed)
             hipLaunchKernelGGL(k_collapse_insert<W>, dim3(ins_grid), dim3(MIRGE_BLOCK), 0, c->cur,
-                               v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S, seed, in.n);
+                               v, t.rep, t.firstj, t.cnt, t.slot_of, tsize - 1, dsample, in.orig, in.base, S, seed, in.n, dweight);
         first_base = t.firstj; first_stride = 1;
         t.cnt_base = t.cnt; t.cnt_stride = (uint32_t)S;
     }
@@ -249,15 +250,21 @@ struct CollapseHook {
 };
 
 static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S, mirge_reads** uniq,
-                         int64_t* n_uniq, CollapseHook* hook);
+                         int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights = nullptr);
 
 extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
                               mirge_reads** uniq, int64_t* n_uniq) {
     return collapse_impl(c, raw, sample_ids, S, uniq, n_uniq, nullptr);
 }
+// every raw read stands for weights[i] copies: the merge of several already collapsed dictionaries -- the per-sample
+// results of a sharded run -- into the sample matrix (digest.py:243) without expanding them again
+extern "C" int mirge_collapse_weighted(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
+                                       const uint32_t* weights, mirge_reads** uniq, int64_t* n_uniq) {
+    return collapse_impl(c, raw, sample_ids, S, uniq, n_uniq, nullptr, weights);
+}
 
 static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S, mirge_reads** uniq,
-                         int64_t* n_uniq, CollapseHook* hook) {
+                         int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights) {
     HostClock hc("collapse");
     if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids)) return fail(-1, "mirge_collapse: bad argument");
     HIPOK(hipSetDevice(c->device));
@@ -267,6 +274,11 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             if (sample_ids[i] < 0 || sample_ids[i] >= S) return fail(-1, "sample id out of range");
         CHECK(dalloc(c, &dsample, (size_t)raw->n));
         HIPOK(hipMemcpyAsync(dsample, sample_ids, (size_t)raw->n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    uint32_t* dweight = nullptr;
+    if (weights && raw->n) {
+        CHECK(dalloc(c, &dweight, (size_t)raw->n));
+        HIPOK(hipMemcpyAsync(dweight, weights, (size_t)raw->n * 4, hipMemcpyHostToDevice, c->stream));
     }
     auto R = std::make_unique<mirge_reads>();
     R->ctx = c; R->n_samples = S;
@@ -291,7 +303,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
             const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
             c->cur = gi == big ? c->stream : c->aux;
-            MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage));
+            MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage, dweight));
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         hc.lap("enqueue A");
@@ -355,7 +367,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
     }
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
     c->flush_deferred();
-    c->release(dsample);
+    c->release(dsample); c->release(dweight);
     if (rc && hook && hook->ran) { hook->discard(); hook->ran = false; }
     if (hook && hook->ran) hook->dmeta = dmeta;  // still read by the work queued in pre_sync
     else c->release(dmeta);

@@ -64,8 +64,9 @@ def names_by_pass(casc) -> list:
 
 def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None):
     """One sample on this process's GPU, for the sharded CLI (one sample per rank, multigpu.py): device-resident parse ->
-    collapse + cascade -> count join; writes ``mapped.<name>.csv`` / ``unmapped.<name>.csv`` and returns the sample's
-    ``SampleTables`` (a few kB: what rank 0 gathers)."""
+    collapse + cascade -> count join.  Returns the sample's ``SampleTables`` (a few kB: its columns of the count tables)
+    with its ``SampleReads`` attached (unique reads in dictionary order, counts, annotation: what rank 0 needs for the
+    run's ONE mapped.csv / unmapped.csv and the per-read reports, ~15 B per unique read)."""
     from . import multigpu
     from .cascade import EXACT_PASS, ISO_PASS
     workDir = Path(workDir)
@@ -74,19 +75,39 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     raw, n_rec = parse_sample(ctx, read_text(str(file)), int(getattr(args, "minimum_length", 16)), trim_from_args(args),
                               umi_from_args(args), workDir, name)
     n_trimmed = len(raw)
+    iupac = raw.iupac_seen
     uniq, res = casc.collapse_and_run(raw)
     raw.close()
     cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS, len(casc.libs["mirna"]))
-    counts, first = uniq.counts()
-    seqs = uniq.unpack()
+    counts, _ = uniq.counts()
+    order = uniq.first_appearance_order()
+    seqs = uniq.unpack().take(order)
     ps, ref, _, _ = res.fetch()
-    n_cols = 10 if args.spikeIn else 9
-    header = ",".join(["Sequence", "annotFlag"] + PASS_COLUMNS[:n_cols] + [name]) + "\n"
-    _ffi.annotation_csv(workDir / f"mapped.{name}.csv", workDir / f"unmapped.{name}.csv", header, seqs, ps, ref, counts,
-                        uniq.first_appearance_order(), list(range(casc.n_pass)), n_cols, names_by_pass(casc))
     out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
+    out.reads = multigpu.SampleReads(seqs.data, seqs.offsets, counts[order, 0], ps[order], ref[order], iupac)
     res.close(); uniq.close()
     return out
+
+
+def merge_sample_reads(ctx: _ffi.Context, parts):
+    """The per-sample dictionaries of a sharded run (``multigpu.SampleReads``, in sample order) -> the run's sample matrix:
+    one weighted collapse on this GPU with a sample id per entry (``mirge_collapse_weighted``; the outer join of
+    digest.py:243 without expanding the dictionaries again).  -> (uniq DeviceReads with the U x S counts, pass[U], ref[U])
+    -- a read's annotation depends on its sequence alone, so the first sample that holds it supplies it."""
+    S = len(parts)
+    data = np.concatenate([p.data for p in parts]) if S else np.zeros(0, np.uint8)
+    lens = np.concatenate([np.diff(p.offsets) for p in parts]) if S else np.zeros(0, np.int64)
+    off = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    sid = np.repeat(np.arange(S, dtype=np.int32), [len(p.counts) for p in parts])
+    w = np.concatenate([p.counts for p in parts]).astype(np.uint32) if S else np.zeros(0, np.uint32)
+    raw = _ffi.DeviceReads.pack(ctx, FlatSeqs(data, off))
+    uniq = raw.collapse(sid if S > 1 else None, max(S, 1), weights=w)
+    raw.close()
+    _, first = uniq.counts()
+    ps_all = np.concatenate([p.ps for p in parts]) if S else np.zeros(0, np.int8)
+    ref_all = np.concatenate([p.ref for p in parts]) if S else np.zeros(0, np.int32)
+    return uniq, ps_all[first], ref_all[first]
 
 
 def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, timings: Dict[str, float] = None):
@@ -149,10 +170,28 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
                            list(base_names), sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique,
                            float(args.crThreshold), bool(args.spikeIn), workDir)
     tm["join_tables_s"] = time.perf_counter() - t
+    outlog.close()
+    out = reports(args, workDir, ref_db, base_names, casc, uniq, res, out, merges, counts, first, tm)
+    tm["total_s"] = time.perf_counter() - t0
+    return out
+
+
+def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges, counts, first, tm=None, ann=None):
+    """What follows the count tables, from the run's joint table (unique reads x samples): ``mapped.csv`` /
+    ``unmapped.csv`` (mirge/__main__.py:164-173) and the per-read miRNA reports (-gff, -ai, -ie).  ``ann`` = (pass, ref) per
+    unique read when the annotation came from elsewhere (the sharded run gathers it from the ranks); ``res`` may then be
+    None unless -gff / -ai ask for the device kernels."""
+    tm = tm if tm is not None else {}
+    workDir = Path(workDir)
+    ctx = casc.ctx
+    S = len(base_names)
     # ---- the per-read tables (mirge/__main__.py:164-173)
     t = time.perf_counter()
     seqs = uniq.unpack()
-    ps, ref, off, mm = res.fetch()
+    if ann is None:
+        ps, ref, off, mm = res.fetch()
+    else:
+        (ps, ref), off, mm = ann, None, None
     tm["fetch_reads_annotation_s"] = time.perf_counter() - t
     order = uniq.first_appearance_order() if S == 1 else row_order(seqs, first, S)  # one sample: sorted on the device
     tm["row_order_s"] = time.perf_counter() - t - tm["fetch_reads_annotation_s"]
@@ -180,9 +219,35 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         from .countjoin import isomir_entropy_tables
         isomir_entropy_tables(mirna_frame(seqs, ps, ref, counts, order, casc, base_names), base_names, out["filtered"], workDir)
     out["device"] = dict(ctx=ctx, casc=casc, uniq=uniq, res=res, seqs=seqs, ann=(ps, ref, off, mm), counts=counts, order=order)
-    tm["total_s"] = time.perf_counter() - t0
-    outlog.close()
     return out
+
+
+def run_sharded_rank0(args, tables, workDir, ref_db: str, casc):
+    """Rank 0 of the sharded CLI, after the gather: the count tables from the ranks' own per-sample columns, then the
+    run's joint table (``merge_sample_reads``) and everything ``reports`` writes from it -- the same files, byte for byte,
+    as the one-process run of the same samples."""
+    from . import multigpu
+    from .countjoin import finish_tables
+    workDir = Path(workDir)
+    names, src, trimmed, uniq_n, cls, ex, iso = multigpu.merge_tables(tables)
+    merges = load_merges(str(args.libraries_path), args.organism_name, ref_db)
+    out = finish_tables(cls, ex, iso, casc.libs["mirna"], merges, names, src, trimmed, uniq_n, float(args.crThreshold),
+                        bool(args.spikeIn), workDir=workDir)
+    with open(workDir / "run.log", "a+") as outlog:
+        for t in tables:
+            if t.reads.iupac:
+                outlog.write(f'WARNING: {t.name} holds IUPAC ambiguity codes other than N; they are aligned -- and printed -- as N\n')
+    uniq, ps, ref = merge_sample_reads(casc.ctx, [t.reads for t in tables])
+    counts, first = uniq.counts()
+    res = None
+    if getattr(args, "gff_out", False) or getattr(args, "AtoI", False):
+        # the two report kernels read the annotation on the device: once more over the joint table (milliseconds), which
+        # also cross-checks what the ranks sent
+        res = casc.run(uniq)
+        ps2, ref2, _, _ = res.fetch()
+        if not (np.array_equal(ps2, ps) and np.array_equal(ref2[ps2 >= 0], ref[ps >= 0])):
+            raise RuntimeError("sharded run: the annotation gathered from the ranks differs from rank 0's own")
+    return reports(args, workDir, ref_db, names, casc, uniq, res, out, merges, counts, first, ann=(ps, ref))
 
 
 def mirna_frame(seqs: FlatSeqs, ps, ref, counts, order, casc, base_names):

@@ -4,8 +4,10 @@ The reference processes samples one after the other in one process (``digest.py:
 joins their columns at the end (``digest.py:243``; every later statistic is per sample column).  So
 the path shards by sample with **no exchange step**: one process per GPU, each rank runs
 collapse -> cascade -> count join on its own samples against its own copy of the libraries, and rank 0
-gathers the per-sample tables (a few kB each) to write the run's CSVs.  The gather is result
-collection on the host side (``torch.distributed.gather_object``), not a data-path collective.
+gathers the per-sample tables (a few kB each) to write the run's CSVs -- and, for the run's one ``mapped.csv`` /
+``unmapped.csv``, each sample's dictionary with its annotation (``SampleReads``, ~15 B per unique read), which it
+merges into the sample matrix with one weighted collapse on its GPU (``fastpath.merge_sample_reads``).  The gather is
+result collection on the host side (``torch.distributed.gather_object``), not a data-path collective.
 """
 from __future__ import annotations
 
@@ -24,6 +26,18 @@ def assign_samples(n_samples: int, world: int) -> List[List[int]]:
 
 
 @dataclass
+class SampleReads:
+    """A sample's dictionary as rank 0 needs it for the run's joint per-read tables (``mapped.csv`` / ``unmapped.csv``,
+    mirge/__main__.py:164-173; -gff / -ai / -ie): unique reads in order of first appearance, their counts and annotation."""
+    data: np.ndarray     # uint8, the sequences' ASCII
+    offsets: np.ndarray  # int64 [U + 1]
+    counts: np.ndarray   # uint32 [U]
+    ps: np.ndarray       # int8 [U], pass or -1
+    ref: np.ndarray      # int32 [U], reference index in the pass's library
+    iupac: bool = False
+
+
+@dataclass
 class SampleTables:
     """What one sample contributes to the run's tables (all int64, S = 1 column)."""
     index: int
@@ -34,6 +48,7 @@ class SampleTables:
     class_sums: np.ndarray  # [n_pass]
     exact: np.ndarray       # [n_mirna]
     iso: np.ndarray         # [n_mirna]
+    reads: Optional[SampleReads] = None
 
 
 def gather_tables(local: Sequence[SampleTables], rank: int, world: int, dist=None) -> Optional[List[SampleTables]]:

@@ -44,12 +44,23 @@ def main():
             if p == 8:
                 iso[lut[nm]] += c
         nme = case.samples[i]
-        return multigpu.SampleTables(i, nme, case.sample_read_counts[nme], case.trimmed[nme],
-                                     case.trimmed_unique[nme], cls, ex, iso)
+        t = multigpu.SampleTables(i, nme, case.sample_read_counts[nme], case.trimmed[nme],
+                                  case.trimmed_unique[nme], cls, ex, iso)
+        # the sample's dictionary travels with its tables (what rank 0 merges into the run's one mapped.csv)
+        from mirge3_amd.seqio import FlatSeqs
+        mine = [(s, int(row[i])) for s, row in zip(case.seqs, case.counts) if int(row[i])]
+        fs = FlatSeqs.from_list([s for s, _ in mine])
+        t.reads = multigpu.SampleReads(fs.data, fs.offsets, np.array([c for _, c in mine], dtype=np.uint32),
+                                       np.array([exp[s][0] for s, _ in mine], dtype=np.int8),
+                                       np.array([lut.get(exp[s][1], 0) for s, _ in mine], dtype=np.int32))
+        return t
 
     assert multigpu.assign_samples(len(case.samples), world)[rank] == [rank]
     tables = multigpu.run_sharded(len(case.samples), rank, world, process, dist)
     if rank == 0:
+        for t in tables:  # every rank's dictionary arrived whole, in sample order
+            assert int(t.reads.counts.sum()) == case.trimmed[t.name] and len(t.reads.counts) == case.trimmed_unique[t.name]
+            assert t.reads.offsets.shape[0] == len(t.reads.counts) + 1 and t.reads.data.shape[0] == int(t.reads.offsets[-1])
         names, src, trimmed, uniq, cls, ex, iso = multigpu.merge_tables(tables)
         finish_tables(cls, ex, iso, mir, case.merges, names, src, trimmed, uniq, 0.1, False, workDir=out_dir)
     else:

@@ -1049,40 +1049,94 @@ print("OK", len(a[0]))
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
-def test_cli_two_ranks_one_sample_each(tmp_path):
-    """The sharded CLI (torch.distributed.run, one sample per rank, rank 0 gathers the per-sample tables over
-    gloo and writes the run's CSVs): two ranks on the single GPU of the test box, golden case 2."""
+def _run_cli_two_ranks(tmp_path, files, case, extra, port):
     import subprocess
     import sys
-    case = GoldenCase("case2_two_samples")
-    files = []
-    for s, nm in enumerate(case.samples):
-        p = tmp_path / f"{nm}.fastq"
-        with open(p, "w") as fh:
-            k = 0
-            for seq, row in zip(case.seqs, case.counts):
-                for _ in range(int(row[s])):
-                    fh.write(f"@r{k}\n{seq}\n+\n{'I' * len(seq)}\n")
-                    k += 1
-        files.append(str(p))
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     launcher = tmp_path / "run_cli.py"
     launcher.write_text("import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()\n" % root)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", str(launcher), "-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase",
-           "-o", str(tmp_path), "-dn", "out", "-shh"]
+           "--master-port", str(port), str(launcher), "-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase",
+           "-o", str(tmp_path), "-dn", "out", "-shh"] + extra
     r = subprocess.run(cmd, env=dict(os.environ, MIRGE_SHARE_GPU="1", OMP_NUM_THREADS="2"), capture_output=True, text=True,
-                       timeout=600)
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = tmp_path / "out"
-    for f in ("miR.Counts.csv", "miR.RPM.csv"):
-        assert (out / f).read_text() == case.text(f), f
+    return tmp_path / "out"
+
+
+def _same_report_but_total_input(out, case):
+    """annotation.report.csv against the golden file, but for 'Total Input Reads': the FASTQ files written from the golden
+    dictionaries hold the kept reads only, the reference's run also saw the few shorter than --minimum-length"""
     got = (out / "annotation.report.csv").read_text().splitlines()
     exp = case.text("annotation.report.csv").splitlines()
     assert got[0] == exp[0] and len(got) == len(exp)
     for g_line, e_line in zip(got[1:], exp[1:]):
-        assert g_line.split(",")[2:] == e_line.split(",")[2:]  # all but sample name-adjacent 'Total Input Reads'
-    assert (out / "mapped.S1.csv").exists() and (out / "unmapped.S2.csv").exists()
+        assert g_line.split(",")[0] == e_line.split(",")[0] and g_line.split(",")[2:] == e_line.split(",")[2:]
+
+
+def _case_fastq_files(case, tmp_path):
+    files = []
+    for s, nm in enumerate(case.samples):
+        p = tmp_path / f"{nm}.fastq"
+        with open(p, "w") as fh:
+            for seq, row in zip(case.seqs, case.counts):
+                if row[s]:
+                    fh.write(f"@r\n{seq}\n+\n{'I' * len(seq)}\n" * int(row[s]))
+        files.append(str(p))
+    return files
+
+
+def test_cli_two_ranks_one_sample_each(tmp_path):
+    """The sharded CLI (torch.distributed.run, one sample per rank; rank 0 gathers the per-sample count columns and
+    dictionaries over gloo, merges the dictionaries into the sample matrix on its GPU and writes the run's files): two
+    ranks on the single GPU of the test box, golden case 2 -- the same bytes as the one-process run, ONE mapped.csv /
+    unmapped.csv over the outer-joined frame (mirge/__main__.py:164-173, digest.py:243), -ie included."""
+    case = GoldenCase("case2_two_samples")
+    out = _run_cli_two_ranks(tmp_path, _case_fastq_files(case, tmp_path), case, ["-ie"], 29541)
+    for f in ("miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "isomirs.csv", "isomirs.samples.csv"):
+        assert (out / f).read_text() == case.text(f), f
+    _same_report_but_total_input(out, case)
+    assert not (out / "mapped.S1.csv").exists()
+
+
+def test_cli_two_ranks_gff_a2i_equal_the_reference_files(tmp_path):
+    """-gff and -ai under torch.distributed.run: golden case 4 (two samples, one per rank) -- sample_miRge3.gff and the three
+    a2IEditing files byte for byte what the reference wrote; rank 0 runs the two report kernels over the merged table."""
+    case = GoldenCase("case4_gff_a2i")
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fake_bowtie")
+    out = _run_cli_two_ranks(tmp_path, _case_fastq_files(case, tmp_path), case, ["-gff", "-ai", "-pbwt", fake, "-cpu", "1"], 29543)
+    for f in ("miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "sample_miRge3.gff",
+              "a2IEditing.report.csv", "a2IEditing.report.newform.csv", "a2IEditing.detail.txt"):
+        assert (out / f).read_text() == case.text(f), f
+    _same_report_but_total_input(out, case)
+
+
+def test_weighted_collapse_merges_dictionaries(ctx, ci_libs):
+    """mirge_collapse_weighted: three samples' dictionaries (unique reads + counts) merged == the joint collapse of their
+    raw reads (counts matrix; first index = first entry of the concatenated dictionaries)."""
+    from mirge3_amd.fastpath import merge_sample_reads
+    from mirge3_amd.multigpu import SampleReads
+    samples = [synth.make_reads(ci_libs, 20000, seed=70 + s, pool=3000, n_frac=0.02) for s in range(3)]
+    parts = []
+    for smp in samples:
+        raw = _ffi.DeviceReads.pack(ctx, smp)
+        u = raw.collapse()
+        cnt, _ = u.counts()
+        o = u.first_appearance_order()
+        sq = u.unpack().take(o)
+        parts.append(SampleReads(sq.data, sq.offsets, cnt[o, 0], np.full(len(o), -1, np.int8), np.arange(len(o), dtype=np.int32)))
+        u.close(); raw.close()
+    uniq, ps, ref = merge_sample_reads(ctx, parts)
+    cnt, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    exp = [Counter(smp.to_list()) for smp in samples]
+    assert set(seqs) == set().union(*[set(c) for c in exp]) and len(seqs) == len(set(seqs))
+    for i, q in enumerate(seqs):
+        assert [int(x) for x in cnt[i]] == [c.get(q, 0) for c in exp]
+    allseq = [q for p in parts for q in FlatSeqs(p.data, p.offsets).to_list()]
+    assert all(allseq[int(f)] == q for f, q in zip(first, seqs)) and (ps == -1).all()
+    assert all(allseq.index(q) == int(f) for f, q in list(zip(first, seqs))[:200])
+    uniq.close()
 
 
 def test_full_size_c3_properties(ctx):
