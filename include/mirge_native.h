@@ -103,6 +103,9 @@ typedef struct mirge_trim {
     int32_t cut[2];
     int32_t count_per_modifier;
     int32_t adapter_front;    /* 1: `adapter` is a 5' adapter (-g): the read keeps what follows it; no N */
+    const char* adapter2;     /* a second adapter or NULL: per read the better match of the two is removed (cutadapt's   */
+    int32_t adapter2_len;     /* AdapterCutter with times = 1: most matches, then fewest errors, then the first given)  */
+    int32_t adapter2_front;
 } mirge_trim;
 int mirge_reads_parse_trim(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                            const mirge_trim* trim, mirge_reads** out, int64_t* n_records);

@@ -29,13 +29,15 @@ DB_KEYS = {"mirbase": "miRBase", "mirgenedb": "MirGeneDB"}  # __main__.py:36
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser(prog="miRge3.0-amd", description="miRge3.0 hot path on MI355X")
-    ap.add_argument("-s", "--samples", required=True, help="comma separated FASTQ/FASTA files (already trimmed)")
+    ap.add_argument("-s", "--samples", required=True, nargs="*",
+                    help="comma separated FASTQ files (*.fastq, *.fq, also .gz), a directory of them, or a .txt / .csv file that "
+                         "lists one per line (mirge/__main__.py:88-118)")
     ap.add_argument("-o", "--outDir", default=None)
-    ap.add_argument("-dn", "--outDirName", dest="outDirName", default=None)
+    ap.add_argument("-onam", "-dn", "--outDirName", dest="outDirName", default=None)
     ap.add_argument("-lib", "--libraries-path", dest="libraries_path", required=True)
     ap.add_argument("-on", "--organism-name", dest="organism_name", required=True)
     ap.add_argument("-db", "--mir-DB", dest="mir_DB", default="miRBase")
-    ap.add_argument("-cr", "--crThreshold", dest="crThreshold", default="0.1")
+    ap.add_argument("-ex", "-cr", "--crThreshold", dest="crThreshold", default="0.1")
     ap.add_argument("-m", "--minimum-length", dest="minimum_length", type=int, default=16)
     ap.add_argument("-spk", "--spikeIn", dest="spikeIn", action="store_true")
     ap.add_argument("-shh", "--quiet", action="store_true")
@@ -51,10 +53,13 @@ def parse_args(argv=None):
                     help="write <sample>.trim.collapse.fa")
     ap.add_argument("-ie", "--isoform-entropy", dest="isoform_entropy", action="store_true",
                     help="write isomirs.csv and isomirs.samples.csv (isomiR RPMs and entropies)")
-    ap.add_argument("-a", "--adapter", dest="adapters", action="append", default=None,
+    # -a and -g fill ONE list of (kind, sequence) in command-line order, as mirge/libs/parse.py does: the order decides ties
+    # between two adapters, and what 'illumina' stands for (mirge/__main__.py:65-83)
+    ap.add_argument("-a", "--adapter", dest="adapters", action="append", default=None, type=lambda x: ("back", x),
                     help="3' adapter removed from every read (cutadapt's regular 3' adapter; 'illumina' = TGGAATTCTCGGGTGCCAAGGAACTCCAG)")
-    ap.add_argument("-g", "--front", dest="front", action="append", default=None,
-                    help="5' adapter: the adapter and everything in front of it are removed (cutadapt's regular 5' adapter; one of -a / -g)")
+    ap.add_argument("-g", "--front", dest="adapters", action="append", default=None, type=lambda x: ("front", x),
+                    help="5' adapter: the adapter and everything in front of it are removed (cutadapt's regular 5' adapter; "
+                         "'illumina' = GTTCAGAGTTCTACAGTCCGACGATC); with two adapters the better match is removed from a read")
     ap.add_argument("-q", "--quality-cutoff", dest="quality_cutoff", default="10", help="[5'CUTOFF,]3'CUTOFF (default 10, as the reference)")
     ap.add_argument("-nxt", "--nextseq-trim", dest="nextseq_trim", type=int, default=None)
     ap.add_argument("-NX", "--trim-n", dest="trim_n", action="store_true")
@@ -106,12 +111,66 @@ def parse_args(argv=None):
         ap.error("-n / --action: only cutadapt's defaults (one adapter occurrence, removed) are part of the MI355X path")
     if (args.umiDedup or args.qiagenumi) and not args.uniq_mol_ids:
         ap.error("-udd / --qiagenumi require -umi f,b")
-    if args.qiagenumi and not args.adapters:
-        ap.error("--qiagenumi reads the UMI behind the 3' adapter: give it with -a")
+    if args.qiagenumi and not (args.adapters and args.adapters[0][0] == "back"):
+        ap.error("--qiagenumi reads the UMI behind the 3' adapter: give it with -a (first)")
     args.bowtieVersion = "True"
     if (args.AtoI or args.gff_out) and (args.tcf_out or args.save_pkl or args.resume):
         ap.error("-ai / -gff run on the device-resident route: not together with -tcf / -spl / -rr")
     return args
+
+
+FASTQ_SUFFIXES = (".fastq", ".fastq.gz", ".fq", ".fq.gz")
+
+
+def validate_files(args, in_files, runlog, loud=True):
+    """``validate_files`` (mirge/libs/miRgeEssential.py:102-127): of the names given, the existing files that end in
+    .fastq / .fq (optionally .gz), resolved; a sample's name is its file name without the last extension (the last two
+    for .gz).  The others are reported and left out; no file left is an error."""
+    full, names = [], []
+    with open(runlog, "a+") as outlog:
+        for f in in_files:
+            p = Path(f)
+            filetype = "".join(p.suffixes) if p.suffix == ".gz" else p.suffix
+            if p.exists() and filetype.endswith(FASTQ_SUFFIXES):
+                full.append(str(p.resolve()))
+                parts = p.name.split(".")
+                names.append(".".join(parts[:-2]) if p.suffix == ".gz" else ".".join(parts[:-1]))
+                continue
+            why = f"\nWARNING: File {f} does not exists!" if not p.exists() else f"\nWARNING: File {f} is neither fastq or fastq.gz format!"
+            if loud and not args.quiet:
+                print(why)
+                print(f"Omitting file {f}")
+            if loud:
+                outlog.write(why + "\n" + f"Omitting file {f}\n")
+        if not full:
+            if loud:
+                outlog.write("\nERROR!: No valid input files were available!\nPlease verify miRge -s arguments\n")
+            sys.exit("\nERROR!: No valid input files were available!\nPlease verify miRge -s arguments\n")
+    return full, names
+
+
+def collect_samples(args, runlog, loud=True):
+    """The forms ``-s`` takes (mirge/__main__.py:85-118; only its first value is read, :88): a comma separated list of
+    files, a directory (its files, sorted; with -rr the directory of the pickles), or a .txt / .csv file with one name
+    per line."""
+    file_list = args.samples[0].split(",") if args.samples else []
+    if not file_list:
+        sys.exit("\nERROR!: No valid input files were available!\nPlease verify miRge -s arguments\n")
+    first = Path(file_list[0])
+    if first.is_dir():
+        if args.resume:
+            return file_list, []  # the pickles name the samples
+        file_list = sorted(str(x) for x in first.iterdir() if x.is_file())
+    elif first.exists() and first.suffix in (".txt", ".csv"):
+        with open(first) as fh:
+            file_list = [line.strip() for line in fh]
+    full, names = validate_files(args, file_list, runlog, loud)
+    if loud and not args.quiet:
+        print(f"\nmiRge3.0 will process {len(full)} out of {len(file_list)} input file(s).\n")
+    if loud:
+        with open(runlog, "a+") as outlog:
+            outlog.write(f"\nmiRge3.0 will process {len(full)} out of {len(file_list)} input file(s).\n\n")
+    return full, names
 
 
 def main(argv=None):
@@ -126,8 +185,6 @@ def main(argv=None):
     name = args.outDirName or ("miRge." + time.strftime('%Y-%m-%d_%H-%M-%S', time.localtime()))
     workDir = Path(args.outDir or Path.cwd()) / name
     workDir.mkdir(exist_ok=True, parents=True)
-    files = [f for f in args.samples.split(",") if f]
-    base_names = [Path(f).name.split(".")[0] for f in files]
     if rank == 0:
         with open(workDir / "run.log", "a+") as fh:
             fh.write(" ".join(sys.argv) + "\n")
@@ -135,6 +192,11 @@ def main(argv=None):
         sys.exit("-spl / -rr are single-process options")
     if not (Path(args.libraries_path) / args.organism_name / "index.Libs").exists():
         sys.exit("\n ERROR: The path to miRge libraries is incorrect or does not exist!\n")
+    if args.organism_name == "hamster":  # mirge/__main__.py:61-64
+        if "mirbase" in args.mir_DB.lower() and rank == 0:
+            print("Library for hamster is not developed for miRBase, therefore, MirGeneDB is used\n")
+        ref_db = "MirGeneDB"
+    files, base_names = collect_samples(args, workDir / "run.log", rank == 0)
 
     from . import fastpath
     from .cascade import bwt_align

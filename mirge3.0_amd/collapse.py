@@ -123,27 +123,38 @@ def unwrap_fasta(data: bytes) -> bytes:
 
 
 ILLUMINA_3P = 'TGGAATTCTCGGGTGCCAAGGAACTCCAG'  # what `-a illumina` stands for (mirge/__main__.py:65-83)
+ILLUMINA_5P = 'GTTCAGAGTTCTACAGTCCGACGATC'     # what `-g illumina` stands for
+
+
+def adapters_from_args(args):
+    """``args.adapters`` as the reference has it after mirge/__main__.py:65-83: a list of (kind, sequence) in command-line
+    order, 'illumina' spelled out -- with ONE adapter by its kind, with TWO by its position (the first is taken for the 3'
+    adapter, the second for the 5' one, whatever their flags were: the reference's own rule).  Plain strings (3' adapters)
+    and a separate ``front`` list are accepted from callers that build the namespace themselves."""
+    adapters = getattr(args, "adapters", None) or []
+    if isinstance(adapters, str):
+        adapters = [adapters]
+    adapters = [tuple(a) if isinstance(a, (tuple, list)) else ("back", a) for a in adapters]
+    front = getattr(args, "front", None) or []
+    if isinstance(front, str):
+        front = [front]
+    adapters += [tuple(f) if isinstance(f, (tuple, list)) else ("front", f) for f in front]
+    if len(adapters) == 2:
+        adapters = [(k, (ILLUMINA_3P, ILLUMINA_5P)[i] if q == "illumina" else q) for i, (k, q) in enumerate(adapters)]
+    elif len(adapters) == 1:
+        adapters = [(k, {"back": ILLUMINA_3P, "front": ILLUMINA_5P}.get(k, q) if q == "illumina" else q) for k, q in adapters]
+    return adapters
 
 
 def trim_from_args(args):
     """The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) as the options of ``mirge_reads_parse_trim``:
-    ``-q`` (default "10": quality trimming is ALWAYS in the reference's chain), ``-a`` (one 3' adapter; 'illumina' =
-    the TruSeq small-RNA adapter) or ``-g`` (one 5' adapter), ``-nxt``, ``-NX``, ``-u``, ``--overlap``, ``--error-rate``,
-    ``-phr``.  Several adapters, ``-n > 1`` and ``--action`` other than trim are refused."""
-    adapters = getattr(args, "adapters", None) or []
-    if isinstance(adapters, str):
-        adapters = [("back", adapters)]
-    adapters = [(a if isinstance(a, (tuple, list)) else ("back", a)) for a in adapters]
-    front = getattr(args, "front", None) or []
-    if isinstance(front, str):
-        front = [front]
-    adapters += [(f if isinstance(f, (tuple, list)) else ("front", f)) for f in front]
-    if len(adapters) > 1 or any(kind not in ("back", "front") for kind, _ in adapters):
-        raise NotImplementedError("one adapter is supported: one 3' adapter (-a) or one 5' adapter (-g), not several")
-    is_front = bool(adapters) and adapters[0][0] == "front"
-    adapter = adapters[0][1] if adapters else None
-    if adapter == "illumina":
-        adapter = ILLUMINA_3P
+    ``-q`` (default "10": quality trimming is ALWAYS in the reference's chain), ``-a`` / ``-g`` (one or two adapters, 3'
+    or 5'; with two, a read loses the better match -- AdapterCutter with times = 1), ``-nxt``, ``-NX``, ``-u``,
+    ``--overlap``, ``--error-rate``, ``-phr``.  More than two adapters, ``-n > 1`` and ``--action`` other than trim are
+    refused."""
+    adapters = adapters_from_args(args)
+    if len(adapters) > 2 or any(kind not in ("back", "front") for kind, _ in adapters):
+        raise NotImplementedError("up to two adapters are supported (-a / -g, in any combination)")
     q = getattr(args, "quality_cutoff", "10")
     qf, qb = 0, -1
     if q is not None:
@@ -161,10 +172,13 @@ def trim_from_args(args):
         raise SystemExit("You cannot remove bases from the same end twice.")
     nxt = getattr(args, "nextseq_trim", None)
     base = 64 if int(getattr(args, "phred64", 33) or 33) == 64 else 33
-    return _ffi.MirgeTrim.make(adapter=adapter, quality_back=qb, quality_front=qf, nextseq=-1 if nxt is None else int(nxt),
+    a1 = adapters[0] if adapters else (None, None)
+    a2 = adapters[1] if len(adapters) > 1 else (None, None)
+    return _ffi.MirgeTrim.make(adapter=a1[1], quality_back=qb, quality_front=qf, nextseq=-1 if nxt is None else int(nxt),
                                phred_base=base, min_overlap=int(getattr(args, "overlap", 3)),
                                error_rate=float(getattr(args, "error_rate", 0.12)), trim_n=bool(getattr(args, "trim_n", False)),
-                               cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once", front=is_front)
+                               cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once",
+                               front=a1[0] == "front", adapter2=a2[1], front2=a2[0] == "front")
 
 
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:

@@ -34,17 +34,25 @@ def _group_by_name(tab: np.ndarray, names: Sequence[str]):
     return list(uniq), out
 
 
+# annotation.report.html: pandas' table with the reference's inline styles put on every header and data cell
+# (summary.py:1279-1286; its replacement of "<table>" never matches pandas' `<table border="1" class="dataframe">`)
+_HTML_TH = '<th style ="background-color: #3f51b5; color:#ffffff; text-align:center">'
+_HTML_TD = ('<td style="vertical-align: middle;background-color: #edf6ff;font-size: 14px;font-family: Arial;font-weight: normal;'
+            'color: #000000;text-align:center; height="250";border:0; ">')
+
+
 def finish_tables(class_sums: np.ndarray, exact: np.ndarray, iso: np.ndarray, mirna: Library,
                   merges: List[List[str]], base_names: List[str], sampleReadCounts, trimmedReadCounts,
                   trimmedReadCountsUnique, cr_threshold: float, spike_in: bool, workDir=None):
-    """summary.py:700-798 and :882-901,1223-1284 on the per-miRNA tables."""
+    """summary.py:700-798 and :882-901,1223-1291 on the per-miRNA tables.  The pandas operations follow the reference's
+    one by one (same joins, fills and casts), because the printed numbers -- ``50`` or ``50.0`` -- are their dtypes."""
     import pandas as pd
-    S = len(base_names)
-    mirMergedNameDic, mirMergedDataframeDic = {}, {}
+    family_of: Dict[str, str] = {}    # member name -> merged (family) name, <org>_merges_<db>.csv
+    universe: Dict[str, str] = {}     # every row name of miR.Counts.csv, in the reference's order: families first
     for row in merges:  # summary.py:707-712
-        for item in row[1:]:
-            mirMergedNameDic[item] = row[0]
-            mirMergedDataframeDic[row[0]] = "1"
+        for member in row[1:]:
+            family_of[member] = row[0]
+            universe[row[0]] = "1"
     names, ex = _group_by_name(exact, mirna.names)
     _, iso_g = _group_by_name(iso, mirna.names)
     present = ex.sum(axis=1) > 0  # a name has an 'exact miRNA' row iff some read hit it in pass 0
@@ -64,50 +72,50 @@ def finish_tables(class_sums: np.ndarray, exact: np.ndarray, iso: np.ndarray, mi
             df[file_name] = (x + y).astype(np.int64)
         else:
             df[file_name] = np.where(ok, (x + y).astype(np.float64), np.nan)
-    df['miRNA'] = df['exact miRNA'].map(mirMergedNameDic)
+    df['miRNA'] = df['exact miRNA'].map(family_of)
     df = df.fillna(0)
     df.loc[df.miRNA == 0, 'miRNA'] = df['exact miRNA']
     df.set_index('miRNA', inplace=True)
     df = df.groupby(['miRNA']).sum()[base_names]
-    Filtered_miRNA_Reads = df.sum(axis=0, skipna=True)[base_names].to_dict()
-    miR_RPM = (df.div(df.sum(axis=0)) * 1000000).round(4)
+    filtered_reads = df.sum(axis=0, skipna=True)[base_names].to_dict()
+    rpm = (df.div(df.sum(axis=0)) * 1000000).round(4)
     for h in mirna.headers:  # `bowtie-inspect -n`, summary.py:783-788
-        srow = h.split(" ")[0] if "segs:" in h else h
-        if srow not in mirMergedNameDic:
-            mirMergedDataframeDic[srow] = "1"
-    mirMerged_df = pd.DataFrame(list(mirMergedDataframeDic.keys()), columns=['miRNA'])
-    mirMerged_df.set_index('miRNA', inplace=True)
-    mirCounts_completeSet = mirMerged_df.join(df, how='outer').fillna(0)
-    mirRPM_completeSet = mirMerged_df.join(miR_RPM, how='outer').fillna(0)
-    miRNA_counts = {fn: int(df.index[df[fn] > 0].shape[0]) for fn in base_names}
+        first_word = h.split(" ")[0] if "segs:" in h else h
+        if first_word not in family_of:
+            universe[first_word] = "1"
+    all_rows = pd.DataFrame(list(universe.keys()), columns=['miRNA'])
+    all_rows.set_index('miRNA', inplace=True)
+    counts_table = all_rows.join(df, how='outer').fillna(0)
+    rpm_table = all_rows.join(rpm, how='outer').fillna(0)
+    n_expressed = {fn: int(df.index[df[fn] > 0].shape[0]) for fn in base_names}
     classes = list(REPORT_CLASSES) + ([("Spike-in", 9)] if spike_in else [])
     all_mirna = class_sums[EXACT_PASS] + class_sums[ISO_PASS]
-    pre_summary = {
+    report_cols = {
         'Total Input Reads': sampleReadCounts, 'Trimmed Reads (all)': trimmedReadCounts,
         'Trimmed Reads (unique)': trimmedReadCountsUnique,
         'All miRNA Reads': {fn: int(all_mirna[s]) for s, fn in enumerate(base_names)},
-        'Filtered miRNA Reads': Filtered_miRNA_Reads, 'Unique miRNAs': miRNA_counts,
+        'Filtered miRNA Reads': filtered_reads, 'Unique miRNAs': n_expressed,
     }
     for col, p in classes:
-        pre_summary[col] = {fn: int(class_sums[p][s]) for s, fn in enumerate(base_names)}
-    col_tosum = ['All miRNA Reads'] + [c for c, _ in classes]
-    colRearrange = ['Total Input Reads', 'Trimmed Reads (all)', 'Trimmed Reads (unique)', 'All miRNA Reads',
+        report_cols[col] = {fn: int(class_sums[p][s]) for s, fn in enumerate(base_names)}
+    annotated = ['All miRNA Reads'] + [c for c, _ in classes]
+    column_order = ['Total Input Reads', 'Trimmed Reads (all)', 'Trimmed Reads (unique)', 'All miRNA Reads',
                     'Filtered miRNA Reads', 'Unique miRNAs'] + [c for c, _ in classes] + ['Remaining Reads']
-    summary = pd.DataFrame.from_dict(pre_summary).fillna(0).astype(int)
-    summary['Remaining Reads'] = summary['Trimmed Reads (all)'] - (summary[col_tosum].sum(axis=1))
-    summary = summary.reindex(columns=colRearrange)
+    summary = pd.DataFrame.from_dict(report_cols).fillna(0).astype(int)
+    summary['Remaining Reads'] = summary['Trimmed Reads (all)'] - (summary[annotated].sum(axis=1))
+    summary = summary.reindex(columns=column_order)
     summary.index.name = "Sample name(s)"
-    out = dict(counts=mirCounts_completeSet, rpm=mirRPM_completeSet, summary=summary,
+    out = dict(counts=counts_table, rpm=rpm_table, summary=summary,
                class_sums={c: class_sums[p] for c, p in classes}, raw=(class_sums, exact, iso),
-               filtered=Filtered_miRNA_Reads)
+               filtered=filtered_reads)
     if workDir is not None:
-        mirCounts_completeSet.to_csv(Path(workDir) / "miR.Counts.csv")
-        mirRPM_completeSet.to_csv(Path(workDir) / "miR.RPM.csv")
+        counts_table.to_csv(Path(workDir) / "miR.Counts.csv")
+        rpm_table.to_csv(Path(workDir) / "miR.RPM.csv")
         summary.to_csv(Path(workDir) / "annotation.report.csv")
         html = summary.reset_index(level=['Sample name(s)'])
         html.index += 1
         with open(Path(workDir) / "annotation.report.html", 'w') as f:
-            f.write(html.to_html(index=False))
+            f.write(html.to_html(index=False).replace("<th>", _HTML_TH).replace("<td>", _HTML_TD))
     return out
 
 

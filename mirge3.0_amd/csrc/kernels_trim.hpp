@@ -27,6 +27,11 @@ struct TrimOpts {
     int32_t stages_out;     // n_mods (count after every modifier) or 1
     uint8_t adapter[MIRGE_TRIM_MAX_ADAPTER];
     uint8_t wild[MIRGE_TRIM_MAX_ADAPTER];  // adapter position is N: matches any base, not counted in the error-rate length
+    // a second adapter (-a and -g in one run, or two of a kind): AdapterCutter with times = 1 removes, per read, the ONE
+    // adapter that matches best -- most matches, then fewest errors, then the first given (cutadapt's _best_match)
+    int32_t alen2, front2;
+    uint8_t adapter2[MIRGE_TRIM_MAX_ADAPTER];
+    uint8_t wild2[MIRGE_TRIM_MAX_ADAPTER];
 };
 
 // Aligner.locate for a regular 3' adapter on read[0, n): returns the read position where the adapter starts, or n.
@@ -45,16 +50,19 @@ struct TrimOpts {
 #define MIRGE_TRIM_CHOICE_MASK (3u << 22)
 // EXACT: the adapter has exactly MAXM bases and no N -- no per-row predicate is left in the unrolled loop (a kernel per
 // adapter length, 1-64).  Otherwise MAXM is a capacity (64) and rows beyond o.alen / wildcard rows are tested at run time.
-template <int MAXM, bool EXACT, bool FRONT>
-__device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_t* __restrict__ read, int n) {
-    const int m = EXACT ? MAXM : o.alen;
+// WHICH: 0 = o.adapter, 1 = o.adapter2.  hit (optional): {found, matches, cost} of the reported alignment.
+template <int MAXM, bool EXACT, bool FRONT, int WHICH = 0>
+__device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_t* __restrict__ read, int n, int* hit = nullptr) {
+    const uint8_t* const o_adapter = WHICH ? o.adapter2 : o.adapter;
+    const uint8_t* const o_wild = WHICH ? o.wild2 : o.wild;
+    const int m = EXACT ? MAXM : (WHICH ? o.alen2 : o.alen);
     uint32_t e[MAXM + 1];
     uint8_t nw[MAXM + 1];
     nw[0] = 0;
 #pragma unroll
     for (int i = 0; i <= MAXM; i++) {
         e[i] = FRONT ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i : (((uint32_t)i << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
-        if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o.wild[i - 1] : 0));
+        if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o_wild[i - 1] : 0));
     }
     int b_mat = -1, b_cost = 0, b_val = 0;
     bool found = false, exact = false;
@@ -79,8 +87,8 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
                 const uint32_t left = e[i];  // previous column, same row
                 const uint32_t best3 = min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22));
                 const uint32_t miss = (best3 & ~MIRGE_TRIM_CHOICE_MASK) + (1u << MIRGE_TRIM_COST_SHIFT);
-                const bool hit = EXACT ? o.adapter[i - 1] == ch : (o.wild[i - 1] || o.adapter[i - 1] == ch);
-                const uint32_t v = hit ? diag + MIRGE_TRIM_MATCH_ONE : miss;
+                const bool same = EXACT ? o_adapter[i - 1] == ch : (o_wild[i - 1] || o_adapter[i - 1] == ch);
+                const uint32_t v = same ? diag + MIRGE_TRIM_MATCH_ONE : miss;
                 diag = left;
                 e[i] = v;
                 if (EXACT ? i == MAXM : i == m) last = v;
@@ -94,6 +102,7 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
         for (int i = MAXM; i >= 0; i--)
             if (EXACT || i <= m) consider(e[i], i, n);
     }
+    if (hit) { hit[0] = found ? 1 : 0; hit[1] = b_mat; hit[2] = b_cost; }
     return found ? b_val : (FRONT ? 0 : n);
 }
 
@@ -152,8 +161,25 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
             emit();
         }
         if (o.alen > 0) {
-            if (FRONT) a0 = a0 + adapter_cut_point<MAXM, EXACT, true>(o, s + a0, a1 - a0);
-            else a1 = a0 + adapter_cut_point<MAXM, EXACT, false>(o, s + a0, a1 - a0);
+            bool done = false;
+            if constexpr (!EXACT && !FRONT) {
+                if (o.alen2 > 0) {  // two adapters: both searched, the better match removed (this kernel instance only)
+                    int h1[3], h2[3];
+                    const int v1 = o.front ? adapter_cut_point<MAXM, false, true, 0>(o, s + a0, a1 - a0, h1)
+                                           : adapter_cut_point<MAXM, false, false, 0>(o, s + a0, a1 - a0, h1);
+                    const int v2 = o.front2 ? adapter_cut_point<MAXM, false, true, 1>(o, s + a0, a1 - a0, h2)
+                                            : adapter_cut_point<MAXM, false, false, 1>(o, s + a0, a1 - a0, h2);
+                    const bool second = h2[0] && (!h1[0] || h2[1] > h1[1] || (h2[1] == h1[1] && h2[2] < h1[2]));
+                    const bool fr = second ? o.front2 != 0 : o.front != 0;
+                    const int v = second ? v2 : v1;
+                    if (second ? h2[0] : h1[0]) { if (fr) a0 = a0 + v; else a1 = a0 + v; }
+                    done = true;
+                }
+            }
+            if (!done) {
+                if (FRONT) a0 = a0 + adapter_cut_point<MAXM, EXACT, true>(o, s + a0, a1 - a0);
+                else a1 = a0 + adapter_cut_point<MAXM, EXACT, false>(o, s + a0, a1 - a0);
+            }
             emit();
         }
         if (o.trim_n) {

@@ -257,6 +257,17 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
         if (ch == 'N' && o.front) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
         o.adapter[i] = (uint8_t)ch; o.wild[i] = ch == 'N';
     }
+    if (t->adapter2_len < 0 || t->adapter2_len > MIRGE_TRIM_MAX_ADAPTER || (t->adapter2_len > 0 && (!t->adapter2 || !o.alen)))
+        return fail(-1, "mirge_reads_parse_trim: the second adapter must be 1-" + std::to_string(MIRGE_TRIM_MAX_ADAPTER) + " nt and follow a first");
+    o.alen2 = t->adapter2_len;
+    o.front2 = t->adapter2_front ? 1 : 0;
+    for (int i = 0; i < o.alen2; i++) {
+        const char ch = (char)(t->adapter2[i] & 0xDF);
+        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N')
+            return fail(-1, "mirge_reads_parse_trim: adapter characters other than A/C/G/T/N are not supported");
+        if (ch == 'N' && o.front2) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
+        o.adapter2[i] = (uint8_t)ch; o.wild2[i] = ch == 'N';
+    }
     if (o.alen && (!(o.rate >= 0.0) || o.rate > 1.0 || o.min_overlap < 1)) return fail(-1, "mirge_reads_parse_trim: error rate / overlap out of range");
     if (t->n_cut < 0 || t->n_cut > 2) return fail(-1, "mirge_reads_parse_trim: at most two unconditional cuts");
     o.n_cut = t->n_cut; o.cut[0] = t->cut[0]; o.cut[1] = t->cut[1];
@@ -286,6 +297,10 @@ static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, co
                        const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
     bool wild = false;
     for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
+    if (o.alen2 > 0) {  // two adapters: the general 3' instance carries the best-match branch
+        hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
+        return 0;
+    }
     if (o.front) {  // a 5' adapter is the rare case: the general kernel
         hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, true>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
         return 0;

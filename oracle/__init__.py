@@ -784,7 +784,22 @@ def trim_stages(seq: str, qual, opts: dict):
         a, b = quality_trim_index(qual, opts.get("q_front", 0), opts["q_back"], opts.get("base", 33))
         seq, qual = seq[a:b], qual[a:b]
         out.append(seq)
-    if opts.get("adapter") and opts.get("front"):
+    if opts.get("adapters"):
+        # AdapterCutter over several adapters, times = 1 (cutadapt's `_best_match`): every adapter is searched in the read
+        # as it stands, the match with the most matching bases wins, then the one with fewer errors, then the first in the
+        # list; only that ONE adapter is removed.  Restated from cutadapt's sources as remembered: parity unpinned.
+        best = None
+        for kind, ad in opts["adapters"]:
+            hit = (adapter_locate_front if kind == "front" else adapter_locate_back)(
+                ad, seq.upper() if kind == "front" else seq, opts.get("error_rate", 0.12), opts.get("overlap", 3))
+            if hit is not None and (best is None or hit[4] > best[1][4] or (hit[4] == best[1][4] and hit[5] < best[1][5])):
+                best = (kind, hit)
+        if best is not None:
+            lo, hi = (best[1][3], len(seq)) if best[0] == "front" else (0, best[1][2])
+            seq = seq[lo:hi]
+            qual = qual[lo:hi] if qual is not None else None
+        out.append(seq)
+    elif opts.get("adapter") and opts.get("front"):
         hit = adapter_locate_front(opts["adapter"], seq.upper(), opts.get("error_rate", 0.12), opts.get("overlap", 3))
         if hit is not None:
             seq = seq[hit[3]:]

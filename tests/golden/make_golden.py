@@ -200,7 +200,7 @@ def run_case(case, seed, n_raw, n_samples, spike_in):
     summarize(args, work, DB, base_names, pdMapped, src, trimmed, uniq)
     pdMapped.to_csv(os.path.join(work, "mapped.csv"))
     pdUnmapped.to_csv(os.path.join(work, "unmapped.csv"))
-    for f in ("mapped.csv", "unmapped.csv", "annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv",
+    for f in ("mapped.csv", "unmapped.csv", "annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv",
               "isomirs.samples.csv"):
         shutil.copy(os.path.join(work, f), os.path.join(out_dir, f))
     shutil.rmtree(tmp)
@@ -499,7 +499,7 @@ def run_gff_a2i_case(case="case4_gff_a2i", seed=14):
     assert not ambiguous, f"best score on several diagonals (stand-in tie rule would decide): {ambiguous[:3]}"
     pdMapped.to_csv(os.path.join(work, "mapped.csv"))
     pdUnmapped.to_csv(os.path.join(work, "unmapped.csv"))
-    for f in ("mapped.csv", "unmapped.csv", "annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv",
+    for f in ("mapped.csv", "unmapped.csv", "annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv",
               "sample_miRge3.gff", "a2IEditing.report.csv", "a2IEditing.report.newform.csv", "a2IEditing.detail.txt"):
         shutil.copy(os.path.join(work, f), os.path.join(out_dir, f))
     # the genome filter's answer (retainedSeqDic, :1074-1096; removedSeqList, :1310-1316), recomputed with the same

@@ -1429,6 +1429,51 @@ def test_trimming_equals_the_restated_cutadapt_chain(ctx, opts, per_modifier):
         uniq.close(); raw.close()
 
 
+@pytest.mark.parametrize("kinds", [("back", "front"), ("front", "back"), ("back", "back"), ("front", "front")])
+def test_two_adapters_best_match_equals_the_restated_adapter_cutter(ctx, kinds):
+    """-a and -g in one run (mirge/__main__.py:65-74): cutadapt's AdapterCutter with times = 1 removes, per read, the ONE
+    adapter that matches best (most matches, then fewest errors, then the first given).  k_trim's two-adapter branch
+    against the oracle's restatement on reads that carry the 5' adapter, the 3' adapter, both, damaged copies, neither."""
+    rng = np.random.default_rng(31 + len(kinds[0]) * 2 + len(kinds[1]))
+    a3, a5 = "TGGAATTCTCGGGTGCCAAGGAACTCCAG", "GTTCAGAGTTCTACAGTCCGACGATC"
+    ads = [(k, a5 if k == "front" else a3) for k in kinds]
+    if kinds[0] == kinds[1]:
+        ads[1] = (kinds[1], "ACGGTCAAGTCCATTGCA" if kinds[1] == "front" else "AGATCGGAAGAGCACACGTC")
+    recs = []
+    for i in range(4000):
+        ins = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(15, 36))))
+        parts = []
+        for kind, ad in ads:
+            x = list(ad)
+            r = rng.random()
+            if r < 0.15:
+                x[int(rng.integers(0, len(x)))] = "ACGT"[int(rng.integers(0, 4))]
+            elif r < 0.25:
+                del x[int(rng.integers(1, len(x) - 1))]
+            elif r < 0.45:
+                x = x[int(rng.integers(3, len(x) - 3)):] if kind == "front" else x[:int(rng.integers(3, len(x) - 3))]
+            elif r < 0.6:
+                x = []
+            parts.append("".join(x))
+        seq = "".join(p for (k, _), p in zip(ads, parts) if k == "front") + ins + "".join(p for (k, _), p in zip(ads, parts) if k == "back")
+        seq = seq[:int(rng.integers(40, 101))]
+        recs.append((seq, "I" * len(seq)))
+    text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+    trim = _ffi.MirgeTrim.make(adapter=ads[0][1], front=ads[0][0] == "front", adapter2=ads[1][1], front2=ads[1][0] == "front",
+                               quality_back=10, count_per_modifier=False)
+    raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 16, trim)
+    uniq = raw.collapse()
+    cnt, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    order = np.argsort(first, kind="stable")
+    want = oracle.trimmed_counts(recs, dict(q_back=10, adapters=ads), 16, False)
+    assert [(seqs[i], int(cnt[i, 0])) for i in order] == list(want.items()) and len(want) > 1000
+    # the choice is exercised: some reads lose the first adapter, some the second, and both differ from either alone
+    alone = [oracle.trimmed_counts(recs, dict(q_back=10, adapters=[a]), 16, False) for a in ads]
+    assert want != alone[0] and want != alone[1]
+    uniq.close(); raw.close()
+
+
 @pytest.mark.parametrize("per_modifier", [True, False])
 def test_five_prime_adapter_equals_the_restated_search(ctx, per_modifier):
     """-g: k_trim<64, false, true> against oracle.adapter_locate_front inside the modifier chain -- the adapter whole,

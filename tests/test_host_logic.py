@@ -78,7 +78,7 @@ def test_count_join_tail_reproduces_reference_csvs(name, tmp_path):
             iso[lut[nm]] += row
     finish_tables(cls, ex, iso, mir, case.merges, case.samples, case.sample_read_counts, case.trimmed,
                   case.trimmed_unique, 0.1, case.spike, workDir=tmp_path)
-    for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+    for f in ("annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv"):
         assert (tmp_path / f).read_text() == case.text(f), f
 
 
@@ -138,11 +138,20 @@ def test_cli_flags_in_and_out_of_scope():
     d = trim_from_args(parse_args(base))  # the reference's chain always holds the quality trimmer (-q default "10")
     assert d.adapter_len == 0 and d.quality_back == 10 and d.count_per_modifier == 1
     with pytest.raises(NotImplementedError):
-        trim_from_args(parse_args(base + ["-a", "AAAA", "-a", "CCCC"]))
+        trim_from_args(parse_args(base + ["-a", "AAAA", "-a", "CCCC", "-g", "GGGG"]))
     g = trim_from_args(parse_args(base + ["-g", "GTTCAGAGTTCTACAGTCCGACGATC", "--overlap", "5"]))  # one 5' adapter
     assert g.adapter_front == 1 and g.adapter == b"GTTCAGAGTTCTACAGTCCGACGATC" and g.min_overlap == 5 and tr.adapter_front == 0
-    with pytest.raises(NotImplementedError):  # AdapterCutter would pick the better of the two per read: not built
-        trim_from_args(parse_args(base + ["-a", "AAAA", "-g", "CCCC"]))
+    # 'illumina' (mirge/__main__.py:65-83): one adapter -- by its kind; two -- the first is the 3' one, the second the 5' one
+    from mirge3_amd.collapse import ILLUMINA_5P, adapters_from_args
+    assert trim_from_args(parse_args(base + ["-g", "illumina"])).adapter == ILLUMINA_5P.encode()
+    two = trim_from_args(parse_args(base + ["-a", "illumina", "-g", "illumina"]))
+    assert (two.adapter, two.adapter_front, two.adapter2, two.adapter2_front) == (ILLUMINA_3P.encode(), 0, ILLUMINA_5P.encode(), 1)
+    swapped = parse_args(base + ["-g", "illumina", "-a", "illumina"])  # the reference's rule goes by position, not by flag
+    assert adapters_from_args(swapped) == [("front", ILLUMINA_3P), ("back", ILLUMINA_5P)]
+    aa = trim_from_args(parse_args(base + ["-a", "AAAAC", "-a", "CCCCG"]))
+    assert (aa.adapter, aa.adapter2, aa.adapter_front, aa.adapter2_front) == (b"AAAAC", b"CCCCG", 0, 0)
+    x = parse_args(base + ["-ex", "0.2", "-onam", "run1"])  # the reference's spellings of these two flags
+    assert x.crThreshold == "0.2" and x.outDirName == "run1"
     # flags the reference never reads, or that belong to tools / subsystems outside the path: accepted, ignored
     k = parse_args(base + ["-M", "40", "-l", "3", "--gc-content", "50", "-cms", "256", "--buffer-size", "4000000", "-cuv", "2.7",
                            "-psam", "/opt/samtools", "-minl", "16", "-olc", "14", "--numba-pll", "-n", "1", "--action", "trim"])
@@ -236,3 +245,31 @@ def test_read_texts_keeps_file_order_and_inflates_gz(tmp_path):
     got = [bytes(t) for t in read_texts(paths, depth=3)]
     assert got == want
     assert [bytes(t) for t in read_texts(paths[:1])] == want[:1] and bytes(read_text(str(paths[1]))) == want[1]
+
+
+def test_sample_forms_of_the_command_line(tmp_path):
+    """``-s`` as the reference reads it (mirge/__main__.py:85-118, miRgeEssential.validate_files :102-127): a comma list, a
+    directory (sorted), a .txt / .csv list; only *.fastq / *.fq [.gz] files that exist are kept, a sample is named by its
+    file name without the last extension (two for .gz); nothing left is an error."""
+    from mirge3_amd.cli import collect_samples, parse_args
+    d = tmp_path / "in"
+    d.mkdir()
+    for n in ("b.trimmed.fastq", "a.fq.gz", "c.fastq.gz", "notes.txt", "lib.fa", "d.fq"):
+        (d / n).write_text("")
+    base = ["-lib", "/x", "-on", "human"]
+    log = tmp_path / "run.log"
+    a = parse_args(["-s", str(d)] + base + ["-shh"])
+    files, names = collect_samples(a, log)
+    assert names == ["a", "b.trimmed", "c", "d"] and files == [str((d / n).resolve()) for n in ("a.fq.gz", "b.trimmed.fastq", "c.fastq.gz", "d.fq")]
+    assert "Omitting file" in log.read_text() and "will process 4 out of 6 input file(s)" in log.read_text()
+    a = parse_args(["-s", f"{d / 'd.fq'},{d / 'missing.fastq'},{d / 'a.fq.gz'}"] + base + ["-shh"])
+    assert collect_samples(a, log)[1] == ["d", "a"]
+    for ext in (".txt", ".csv"):
+        lst = tmp_path / ("list" + ext)
+        lst.write_text(f"{d / 'c.fastq.gz'}\n  {d / 'b.trimmed.fastq'}  \n\n")
+        a = parse_args(["-s", str(lst)] + base + ["-shh"])
+        assert collect_samples(a, log)[1] == ["c", "b.trimmed"]
+    with pytest.raises(SystemExit):
+        collect_samples(parse_args(["-s", str(d / "lib.fa")] + base + ["-shh"]), log)
+    r = parse_args(["-s", str(d), "-rr"] + base)
+    assert collect_samples(r, log) == ([str(d)], [])

@@ -23,5 +23,5 @@ def test_two_ranks_gloo_merge_equals_reference(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     case = GoldenCase("case2_two_samples")
-    for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+    for f in ("annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv"):
         assert (tmp_path / f).read_text() == case.text(f), f
