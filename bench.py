@@ -89,6 +89,7 @@ def pmc_traffic(args, rec_name):
         # rocprofv3 is a python script: run it with this interpreter (no '#!/usr/bin/env' hop)
         cmd = [sys.executable, rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--pmc", "0",
+               "--min-seconds", "0", "--spinup", "0", "--cli-path", "0",
                "--reads", str(args.reads), "--scale", args.scale, "--workload", args.workload]
         try:
             subprocess.run(cmd, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
@@ -198,6 +199,24 @@ def reference_bowtie_baseline(bowtie_dir, sl, libs, reads, n_pass, ctx, casc, ar
                        "alignment predicate PINNED on this box: per-pass membership identical to " + ver)}
 
 
+def gpu_clocks_mhz():
+    """current shader clock of every GPU the driver exposes under /sys (the line pp_dpm_sclk marks with '*'), or None"""
+    import glob
+    import re
+    out = {}
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))[:16]:
+        try:
+            with open(f) as fh:
+                for line in fh:
+                    if line.rstrip().endswith("*"):
+                        m = re.search(r"(\d+)\s*[Mm][Hh][Zz]", line)
+                        if m:
+                            out[f.split("/")[4]] = int(m.group(1))
+        except OSError:
+            pass
+    return out or None
+
+
 def fastq_text(reads):
     """4-line FASTQ records (quality 'I') of a FlatSeqs as one uint8 array, built with numpy"""
     L = reads.lengths
@@ -277,6 +296,9 @@ def main():
     ap.add_argument("--pool", type=int, default=0,
                     help="draw the reads from this many templates with Zipf weights (SURVEY 8d 'realistic' U/N); 0 = independent draws")
     ap.add_argument("--cli-path", type=int, default=1, help="rank 0, N=1: also time the CLI's route from a FASTQ file on disk to all CSVs")
+    ap.add_argument("--min-seconds", dest="min_seconds", type=float, default=2.0,
+                    help="repeat the timed region of --steps steps until this much timed work has been seen (0 = one region)")
+    ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the timed region (clock state)")
     ap.add_argument("--pmc", type=int, default=1,
                     help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()
@@ -290,11 +312,41 @@ def main():
     # MIRGE_BENCH_SHARE_GPU=1 puts every rank on device 0, MIRGE_BENCH_BACKEND=gloo keeps RCCL out of it
     backend = os.environ.get("MIRGE_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("MIRGE_BENCH_SHARE_GPU") else local_rank
+    backend_note = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            # RCCL carries nothing but the barrier and one 8-byte max here.  If it cannot come up on this node (IPC mode,
+            # a missing xGMI link, a driver mismatch) the measurement must not die with it: every rank then falls back
+            # to gloo -- decided together through the rendezvous store, before any GPU work of the bench itself.
+            from torch.distributed import TCPStore
+            store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17, world,
+                             rank == 0, timeout=datetime.timedelta(seconds=300))
+            ok = True
+            try:
+                if os.environ.get("MIRGE_BENCH_FORCE_NCCL_FAIL"):  # test hook
+                    raise RuntimeError("forced (MIRGE_BENCH_FORCE_NCCL_FAIL)")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device=f"cuda:{dev_index}")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                ok = int(probe.item()) == world
+            except Exception as e:  # noqa: BLE001
+                ok = False
+                backend_note = f"nccl init failed on rank {rank}: {repr(e)[:200]}"
+            store.set(f"nccl_ok_{rank}", "1" if ok else "0")
+            all_ok = all(store.get(f"nccl_ok_{r}") == b"1" for r in range(world))
+            if not all_ok:
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:  # noqa: BLE001
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+                backend_note = backend_note or "nccl failed on another rank"
         else:
             dist.init_process_group(backend)
     n_gpus = world if world > 1 else args.gpus
@@ -368,22 +420,55 @@ def main():
     # timed region: only the dominant kernel stays bracketed (two events per launch; bracketing
     # all ~90 launches of a step costs ~0.4 ms of a ~3 ms step)
     ctx.profile_only(dom.split(".")[0] + "." if "." in dom else dom)
-    ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # clocks up before anything is timed: W warm-up steps of ~2 ms leave a GPU that idled through the setup at whatever
+    # power state it was in; untimed steps until the chip has worked for `--spinup` seconds
+    # the interpreter's cyclic collector walks every container object when its oldest generation comes due -- with the
+    # synthetic libraries' ~0.2 M names alive that is one ~45 ms pause every ~1000 steps, inside a 1.6 ms step; what exists
+    # now is set aside (gc.freeze) so that collections during the timed region only see the steps' own few objects
+    import gc
+    gc.collect()
+    gc.freeze()
+    t_spin = time.perf_counter()
+    n_spin = 0
+    while time.perf_counter() - t_spin < args.spinup:
         step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+        n_spin += 1
+    clocks_before = gpu_clocks_mhz()
+    # timed: EXACTLY K steps per region, barrier + synchronize on both sides, max over ranks.  A region of K = 20 steps is
+    # 0.04 s -- one slow launch moves it by percents -- so the region is repeated until `--min-seconds` of timed work have
+    # been seen (the same number of regions on every rank); ms_per_step = all timed time / all timed steps.
+    ctx.profile_reset()
+    region_s, step_ms = [], []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ts = time.perf_counter()
+            step()  # ends with the count tables on the host: synchronous
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+        barrier()
+        region_s.append(max_over_ranks(time.perf_counter() - t0))  # the same number on every rank: so is the decision below
+        if sum(region_s) >= args.min_seconds or len(region_s) >= 5000:
+            break
+    n_regions = len(region_s)
+    clocks_after = gpu_clocks_mhz()
+    elapsed = float(sum(region_s))
+    timed_steps = args.steps * n_regions
     recs = ctx.profile_records()
     ctx.profile(False)
     ctx.profile_only("")
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_gpus * args.reads / (elapsed / args.steps) / 1e6
+    ms_per_step = elapsed / timed_steps * 1e3
+    value = n_gpus * args.reads / (elapsed / timed_steps) / 1e6
+    per_region_ms = sorted(r / args.steps * 1e3 for r in region_s)
+    sm = np.sort(np.asarray(step_ms))
 
     # ---------------- per-kernel accounting
     # `kernels` (all launches bracketed) comes from the profiled warm-up steps; the dominant kernel's
@@ -414,6 +499,20 @@ def main():
             "library_bases": {k: v.total_len for k, v in libs.items()}, "passes": n_pass,
             "sharding": f"{n_gpus} sample(s), one per GPU, no collective",
         },
+        "timing": {
+            "timed_steps": timed_steps, "regions": n_regions, "steps_per_region": args.steps, "timed_seconds": round(elapsed, 4),
+            "region_ms_per_step": {"min": round(per_region_ms[0], 4), "median": round(per_region_ms[len(per_region_ms) // 2], 4),
+                                   "max": round(per_region_ms[-1], 4)},
+            "step_ms_rank0": {"min": round(float(sm[0]), 4), "p10": round(float(sm[int(0.1 * (len(sm) - 1))]), 4),
+                              "median": round(float(sm[len(sm) // 2]), 4), "p90": round(float(sm[int(0.9 * (len(sm) - 1))]), 4),
+                              "max": round(float(sm[-1]), 4)},
+            "first_region_ms_per_step": round(region_s[0] / args.steps * 1e3, 4),
+            "spinup_steps": n_spin, "gpu_sclk_mhz": {"before": clocks_before, "after": clocks_after},
+            "note": "every region is exactly --steps steps between barrier + synchronize pairs, max over ranks; regions are "
+                    "repeated until --min-seconds of timed work; ms_per_step / value = all regions' time / all regions' steps; "
+                    "step_ms_rank0 are host-clock times of single steps (a step ends with its count tables on the host)",
+        },
+        "barrier_backend": (backend if dist is not None else None), "barrier_backend_note": backend_note,
         "collapsed_reads_per_s_M": round(n_gpus * U / (stage_ms["cascade"] * 1e-3) / 1e6, 3) if stage_ms["cascade"] else None,
         "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
         "stage_ms_note": "sums of per-kernel HIP-event times from the profiled warm-up steps; kernels of the small read "

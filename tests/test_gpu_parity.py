@@ -656,13 +656,24 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     env = dict(os.environ, MIRGE_BENCH_SHARE_GPU="1", MIRGE_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--reads", "300000", "--scale", "ci", "--cpu-baseline", "0", "--pmc", "0"]
+           "--warmup", "1", "--reads", "300000", "--scale", "ci", "--cpu-baseline", "0", "--pmc", "0", "--min-seconds", "0.5"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    assert d["barrier_backend"] == "gloo" and d["timing"]["timed_seconds"] >= 0.5 and d["timing"]["regions"] >= 1  # --min-seconds 0.5 below
+    assert d["timing"]["timed_steps"] == d["timing"]["regions"] * 2
+    # the RCCL guard: when RCCL cannot come up (here: made to fail; on this box two ranks on one GPU would fail by themselves)
+    # every rank falls back to gloo together and the line says which backend carried the barrier
+    env2 = dict(os.environ, MIRGE_BENCH_SHARE_GPU="1", MIRGE_BENCH_FORCE_NCCL_FAIL="1", OMP_NUM_THREADS="4")
+    cmd[cmd.index("29533")] = "29571"
+    cmd[cmd.index("0.5")] = "0"
+    r = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["barrier_backend"] == "gloo" and "forced" in d["barrier_backend_note"] and d["timing"]["regions"] == 1 and d["value"] > 0
 
 
 def test_bench_single_gpu_line(tmp_path):
@@ -673,7 +684,7 @@ def test_bench_single_gpu_line(tmp_path):
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--reads", "400000", "--scale", "ci",
-           "--pmc", "0"]
+           "--pmc", "0", "--min-seconds", "0.5"]
     r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="8"), capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -683,6 +694,10 @@ def test_bench_single_gpu_line(tmp_path):
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["vs_baseline"] is None and d["dtype"] == "u64"
+    tm = d["timing"]
+    assert tm["timed_seconds"] >= 0.5 and tm["timed_steps"] == 3 * tm["regions"] and d["barrier_backend"] is None
+    assert tm["step_ms_rank0"]["min"] <= tm["step_ms_rank0"]["median"] <= tm["step_ms_rank0"]["max"]
+    assert abs(d["ms_per_step"] - tm["timed_seconds"] / tm["timed_steps"] * 1e3) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
     ro = d["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-5
