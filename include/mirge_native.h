@@ -64,6 +64,15 @@ int mirge_ctx_sync(mirge_ctx* ctx);
  * and `bowtie-build`.  seq_ascii/offsets: the reference sequences in library order.          */
 int mirge_lib_create(mirge_ctx* ctx, const char* seq_ascii, const int64_t* offsets, int64_t n_refs,
                      mirge_lib** out);
+/* The same from the packed image mirge_lib_create derives (2-bit text, invalid-base bitmap, reference starts): what a
+ * library cache next to the index holds, so that a process neither parses the FASTA / decodes the .ebwt nor packs it
+ * again.  mirge_lib_packed_sizes / _copy hand the image of a library out (sizes[4] = words of T, words of inv, total
+ * bases incl. separators, valid positions).  Probe tables are built on the device either way. */
+int mirge_lib_create_packed(mirge_ctx* ctx, const uint64_t* T, int64_t n_T, const uint64_t* inv, int64_t n_inv,
+                            const uint32_t* ref_start, int64_t n_refs, uint64_t total, int32_t kmax,
+                            uint64_t valid_positions, mirge_lib** out);
+int mirge_lib_packed_sizes(const mirge_lib* lib, int64_t* sizes, int32_t* kmax);
+int mirge_lib_packed_copy(const mirge_lib* lib, uint64_t* T, uint64_t* inv, uint32_t* ref_start);
 void mirge_lib_destroy(mirge_lib* lib);
 int64_t mirge_lib_n_refs(const mirge_lib* lib);
 int64_t mirge_lib_device_bytes(const mirge_lib* lib);
@@ -205,6 +214,14 @@ int mirge_annotation_csv(const char* mapped_path, const char* unmapped_path, con
                          const uint32_t* counts, int32_t n_samples, const int64_t* rows, int64_t n_rows,
                          int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
                          const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n);
+
+/* The same two files straight from the device-resident run (what the CLI's route calls): the rows are formatted by kernels
+ * from the packed unique reads, their count matrix and the cascade's annotation, only the files' text crosses PCIe.
+ * rows / header / columns / names as above.  Returns -4 when a reference name would need CSV quoting: format on the host. */
+int mirge_annotation_csv_device(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, const char* mapped_path,
+                                const char* unmapped_path, const char* header, const int64_t* rows, int64_t n_rows,
+                                int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n);
 
 /* ---- per-position variant tally / A-to-I counting core (BASELINE config 5): replaces
  * align2TargetSeq / judgeAllign / A2IEditing / mismatchCountAnalysis (mirge2_tRF_a2i.py:246-518) and the membership

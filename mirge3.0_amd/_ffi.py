@@ -21,11 +21,11 @@ SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libm
 
 EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
-    "mirge_lib_create", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
+    "mirge_lib_create", "mirge_lib_create_packed", "mirge_lib_packed_sizes", "mirge_lib_packed_copy", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
-    "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
+    "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
@@ -196,12 +196,32 @@ class DeviceLibrary:
 
     def __init__(self, ctx: Context, seqs: FlatSeqs):
         self.ctx = ctx
-        data = np.ascontiguousarray(seqs.data, dtype=np.uint8)
-        off = np.ascontiguousarray(seqs.offsets, dtype=np.int64)
         self._h = C.c_void_p()
-        _check(load().mirge_lib_create(ctx._h, _p(data), _p(off), C.c_int64(len(seqs)), C.byref(self._h)),
-               "mirge_lib_create")
+        packed = getattr(seqs, "packed", None)
+        if packed is not None:  # a cached library (libcache.PackedSeqs): the image itself, no letters, no packing
+            T = np.ascontiguousarray(packed["T"], dtype=np.uint64)
+            inv = np.ascontiguousarray(packed["inv"], dtype=np.uint64)
+            rs = np.ascontiguousarray(packed["ref_start"], dtype=np.uint32)
+            _check(load().mirge_lib_create_packed(ctx._h, _p(T), C.c_int64(T.shape[0]), _p(inv), C.c_int64(inv.shape[0]), _p(rs),
+                                                  C.c_int64(len(seqs)), C.c_uint64(int(packed["total"])), C.c_int32(int(packed["kmax"])),
+                                                  C.c_uint64(int(packed["valid_positions"])), C.byref(self._h)), "mirge_lib_create_packed")
+        else:
+            data = np.ascontiguousarray(seqs.data, dtype=np.uint8)
+            off = np.ascontiguousarray(seqs.offsets, dtype=np.int64)
+            _check(load().mirge_lib_create(ctx._h, _p(data), _p(off), C.c_int64(len(seqs)), C.byref(self._h)),
+                   "mirge_lib_create")
         _track(self)
+
+    def packed_image(self) -> dict:
+        """the library's packed image (2-bit text, invalid-base bitmap, reference starts) for the cache next to the index"""
+        sizes = (C.c_int64 * 4)()
+        kmax = C.c_int32()
+        _check(load().mirge_lib_packed_sizes(self._h, sizes, C.byref(kmax)), "mirge_lib_packed_sizes")
+        T = np.empty(int(sizes[0]), dtype=np.uint64)
+        inv = np.empty(int(sizes[1]), dtype=np.uint64)
+        rs = np.empty(self.n_refs + 1, dtype=np.uint32)
+        _check(load().mirge_lib_packed_copy(self._h, _p(T), _p(inv), _p(rs)), "mirge_lib_packed_copy")
+        return {"T": T, "inv": inv, "ref_start": rs, "total": int(sizes[2]), "kmax": int(kmax.value), "valid_positions": int(sizes[3])}
 
     @property
     def n_refs(self) -> int:
@@ -495,3 +515,32 @@ def annotation_csv(mapped_path, unmapped_path, header: str, seqs: FlatSeqs, ps: 
                                        _p(off), _p(ps), _p(ref), _p(counts), C.c_int32(counts.shape[1]), _p(rows),
                                        C.c_int64(rows.shape[0]), C.c_int32(n_pass), col, C.c_int32(n_name_cols), nd, no, nn),
            "mirge_annotation_csv")
+
+
+def annotation_csv_device(ctx: "Context", uniq: "DeviceReads", res: "CascadeResult", mapped_path, unmapped_path, header: str,
+                          rows: np.ndarray, col_of_pass: Sequence[int], n_name_cols: int,
+                          names_by_pass: Sequence[Optional[FlatSeqs]]) -> bool:
+    """``mapped.csv`` / ``unmapped.csv`` formatted on the GPU from the device-resident reads, counts and annotation
+    (``mirge_annotation_csv_device``).  False: a reference name needs CSV quoting -- call ``annotation_csv`` instead."""
+    n_pass = len(col_of_pass)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    col = (C.c_int32 * n_pass)(*[int(x) for x in col_of_pass])
+    keep = []
+    nd, no, nn = (C.c_void_p * n_pass)(), (C.c_void_p * n_pass)(), (C.c_int64 * n_pass)()
+    for p in range(n_pass):
+        fs = names_by_pass[p]
+        if fs is None:
+            nd[p], no[p], nn[p] = None, None, 0
+            continue
+        d = np.ascontiguousarray(fs.data, dtype=np.uint8)
+        o = np.ascontiguousarray(fs.offsets, dtype=np.int64)
+        keep += [d, o]
+        nd[p], no[p], nn[p] = d.ctypes.data if d.size else None, o.ctypes.data, len(fs)
+    enc = lambda x: None if x is None else str(x).encode()
+    rc = load().mirge_annotation_csv_device(ctx._h, uniq._h, res._h, enc(mapped_path), enc(unmapped_path), header.encode(),
+                                            _p(rows) if rows.size else C.c_void_p(0), C.c_int64(rows.shape[0]), C.c_int32(n_pass),
+                                            col, C.c_int32(n_name_cols), nd, no, nn)
+    if rc == -4:
+        return False
+    _check(rc, "mirge_annotation_csv_device")
+    return True

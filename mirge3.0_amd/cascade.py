@@ -72,6 +72,11 @@ class Cascade:
                 continue
             if key not in self._dev:  # the miRNA library serves passes 0 and 8
                 self._dev[key] = _ffi.DeviceLibrary(ctx, libs[key].seqs)
+                target = getattr(libs[key], "cache_target", None)
+                if target is not None:  # read from its FASTA / .ebwt just now: keep the packed image next to the index
+                    from . import libcache
+                    libcache.save(target[0], libs[key], self._dev[key].packed_image(), target[1])
+                    libs[key].cache_target = None
             self.dev_libs.append(self._dev[key])
         self.policies = policies(self.n_pass)
         self._prepared = _ffi.cascade_args(self.dev_libs, self.policies)

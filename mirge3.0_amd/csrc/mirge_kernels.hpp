@@ -41,3 +41,4 @@ __device__ __forceinline__ void load_read(const GroupView<W>& g, uint32_t i, Mir
 #include "kernels_cascade.hpp"
 #include "kernels_join.hpp"
 #include "kernels_iso.hpp"
+#include "kernels_csv.hpp"

@@ -164,3 +164,176 @@ extern "C" int mirge_annotation_csv(const char* mapped_path, const char* unmappe
     }
     return 0;
 }
+
+
+// The same two files from the DEVICE-resident run: rows are formatted by k_csv_rowlen / k_csv_rows from the packed unique
+// reads, their count matrix and the cascade's annotation where they lie; what crosses PCIe is the files' text (page-locked
+// staging kept in the ctx), written by several threads with positional writes while later chunks are still arriving.
+// Reference names that need CSV quoting are refused (-4): the caller then formats on the host (mirge_annotation_csv).
+extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const char* mapped_path,
+                                           const char* unmapped_path, const char* header, const int64_t* rows, int64_t n_rows,
+                                           int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                           const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n) {
+    if (!c || !U || !res || !header || (!rows && n_rows) || n_rows < 0 || n_pass < 1 || n_pass > MIRGE_MAX_PASSES || !col_of_pass ||
+        n_name_cols < 0 || !name_data || !name_off || !name_n || U->n_samples < 1 || res->n != U->n || n_rows >= 0xFFFFFFF0ll)
+        return fail(-1, "mirge_annotation_csv_device: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    HostClock hc("annotation_csv_device");
+    CsvTables t;
+    std::memset(&t, 0, sizeof(t));
+    t.n_pass = n_pass; t.n_name_cols = n_name_cols; t.S = U->n_samples;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = U->g[gi];
+        const ResGroup& r = res->g[gi];
+        if (g.orig) return fail(-1, "mirge_annotation_csv_device: the read set is not a collapse result");
+        if (g.n != r.n && !(res->dmeta)) return fail(-1, "mirge_annotation_csv_device: result and read set differ");
+        t.g[gi] = CsvGroup{g.seq, g.nmask, g.len, g.counts, r.pass, r.ref, g.base, g.n, g.W};
+    }
+    // names: one blob + 32-bit offsets per pass, uploaded per call (a human library set: ~0.2 M names, a few MB)
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> offs;
+    size_t blob_at[MIRGE_MAX_PASSES], off_at[MIRGE_MAX_PASSES];
+    for (int p = 0; p < n_pass; p++) {
+        t.col_of_pass[p] = col_of_pass[p];
+        if (col_of_pass[p] >= n_name_cols) return fail(-1, "mirge_annotation_csv_device: column index out of range");
+        blob_at[p] = blob.size(); off_at[p] = offs.size();
+        t.name_n[p] = 0;
+        if (!name_data[p] || !name_off[p] || name_n[p] <= 0) continue;
+        const int64_t nb = name_off[p][name_n[p]] - name_off[p][0];
+        if (nb >= 0xFFFFFFF0ll || name_n[p] >= 0xFFFFFFF0ll) return fail(-5, "mirge_annotation_csv_device: name table too large");
+        const char* src = name_data[p] + name_off[p][0];
+        for (int64_t x = 0; x < nb; x++)
+            if (src[x] == ',' || src[x] == '"' || src[x] == '\n' || src[x] == '\r')
+                return fail(-4, "mirge_annotation_csv_device: a reference name needs CSV quoting (host route)");
+        blob.insert(blob.end(), src, src + nb);
+        for (int64_t r = 0; r <= name_n[p]; r++) offs.push_back((uint32_t)(name_off[p][r] - name_off[p][0]));
+        t.name_n[p] = (uint32_t)name_n[p];
+    }
+    uint8_t* dblob = nullptr; uint32_t *doffs = nullptr, *drows = nullptr, *dflags = nullptr;
+    unsigned long long *len_m = nullptr, *len_u = nullptr, *off_m = nullptr, *off_u = nullptr;
+    uint8_t *out_m = nullptr, *out_u = nullptr;
+    void* tmp = nullptr;
+    std::vector<uint32_t> rows32((size_t)n_rows);
+    for (int64_t k = 0; k < n_rows; k++) {
+        if (rows[k] < 0 || rows[k] >= U->n) return fail(-1, "mirge_annotation_csv_device: row index out of range");
+        rows32[(size_t)k] = (uint32_t)rows[k];
+    }
+    int rc = 0;
+    size_t bytes_m = 0, bytes_u = 0;
+    const size_t hl = std::strlen(header);
+    do {
+        if ((rc = dalloc(c, &dblob, blob.size() + 16))) break;
+        if ((rc = dalloc(c, &doffs, offs.size() + 4))) break;
+        if ((rc = dalloc(c, &drows, (size_t)n_rows + 1))) break;
+        if ((rc = dalloc(c, &dflags, 16))) break;
+        if ((rc = dalloc(c, &len_m, (size_t)n_rows + 1))) break;
+        if ((rc = dalloc(c, &len_u, (size_t)n_rows + 1))) break;
+        if ((rc = dalloc(c, &off_m, (size_t)n_rows + 1))) break;
+        if ((rc = dalloc(c, &off_u, (size_t)n_rows + 1))) break;
+        hipError_t e = hipSuccess;
+        if (!blob.empty()) e = hipMemcpyAsync(dblob, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && !offs.empty()) e = hipMemcpyAsync(doffs, offs.data(), offs.size() * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && n_rows) e = hipMemcpyAsync(drows, rows32.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(dflags, 0, 64, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(len_m + n_rows, 0, 8, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(len_u + n_rows, 0, 8, c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_annotation_csv_device: ") + hipGetErrorString(e)); break; }
+        for (int p = 0; p < n_pass; p++)
+            if (t.name_n[p]) { t.name_data[p] = dblob + blob_at[p]; t.name_off[p] = doffs + off_at[p]; }
+        if (n_rows) {
+            LaunchScope ls(c, "k_csv_rowlen", (double)n_rows);
+            hipLaunchKernelGGL(k_csv_rowlen, dim3(grid_for(c, (size_t)n_rows)), dim3(MIRGE_BLOCK), 0, c->stream, t, drows, (uint32_t)n_rows, len_m, len_u, dflags);
+        }
+        size_t tb = 0;
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, tb, len_m, off_m, (int)(n_rows + 1), c->stream);
+        if (e == hipSuccess && (rc = dalloc(c, (uint8_t**)&tmp, std::max<size_t>(tb, 16)))) break;
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, len_m, off_m, (int)(n_rows + 1), c->stream);
+        if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, len_u, off_u, (int)(n_rows + 1), c->stream);
+        unsigned long long tot[2] = {0, 0};
+        uint32_t hflag = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&tot[0], off_m + n_rows, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&tot[1], off_u + n_rows, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&hflag, dflags, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_annotation_csv_device: ") + hipGetErrorString(e)); break; }
+        if (hflag) { rc = fail(-1, "mirge_annotation_csv_device: pass or reference index out of range"); break; }
+        bytes_m = mapped_path ? (size_t)tot[0] : 0;
+        bytes_u = unmapped_path ? (size_t)tot[1] : 0;
+        if (bytes_m && (rc = dalloc(c, &out_m, bytes_m))) break;
+        if (bytes_u && (rc = dalloc(c, &out_u, bytes_u))) break;
+        if (n_rows && (bytes_m || bytes_u)) {
+            LaunchScope ls(c, "k_csv_rows", (double)n_rows);
+            hipLaunchKernelGGL(k_csv_rows, dim3(grid_for(c, (size_t)n_rows)), dim3(MIRGE_BLOCK), 0, c->stream, t, drows, (uint32_t)n_rows, off_m, off_u, out_m, out_u);
+        }
+        hc.lap("format (device)");
+        // page-locked staging, grown when a sample needs more (the first sample of a process pays for it)
+        const size_t need = bytes_m + bytes_u;
+        if (need > c->csv_pinned_bytes) {
+            if (c->csv_pinned) (void)hipHostFree(c->csv_pinned);
+            c->csv_pinned = nullptr; c->csv_pinned_bytes = 0;
+            const size_t want = need + need / 8 + (1u << 20);
+            if (hipHostMalloc((void**)&c->csv_pinned, want, hipHostMallocDefault) != hipSuccess) {
+                rc = fail(-3, "mirge_annotation_csv_device: cannot page-lock " + std::to_string(want) + " bytes"); break;
+            }
+            c->csv_pinned_bytes = want;
+            hc.lap("page-locked staging");
+        }
+        // copies in chunks, each followed by an event; writer threads put a chunk into its file as soon as it has arrived
+        const size_t CH = 8u << 20;
+        struct Chunk { int which; size_t src_off, file_off, n; hipEvent_t ev; };
+        std::vector<Chunk> chunks;
+        for (int which = 0; which < 2; which++) {
+            const size_t nb = which == 0 ? bytes_m : bytes_u;
+            const uint8_t* dsrc = which == 0 ? out_m : out_u;
+            const size_t pin0 = which == 0 ? 0 : bytes_m;
+            for (size_t at = 0; at < nb && e == hipSuccess; at += CH) {
+                const size_t nn = std::min(CH, nb - at);
+                e = hipMemcpyAsync(c->csv_pinned + pin0 + at, dsrc + at, nn, hipMemcpyDeviceToHost, c->stream);
+                hipEvent_t ev = c->get_evt();
+                if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
+                chunks.push_back(Chunk{which, pin0 + at, hl + at, nn, ev});
+            }
+        }
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_annotation_csv_device: ") + hipGetErrorString(e)); }
+        int fd[2] = {-1, -1};
+        const char* paths[2] = {mapped_path, unmapped_path};
+        for (int which = 0; which < 2 && rc == 0; which++) {
+            if (!paths[which]) continue;
+            fd[which] = ::open(paths[which], O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd[which] < 0 || ::pwrite(fd[which], header, hl, 0) != (ssize_t)hl) rc = fail(-8, std::string("cannot write ") + paths[which]);
+        }
+        std::atomic<size_t> next{0};
+        std::atomic<int> werr{0};
+        auto writer = [&]() {
+            (void)hipSetDevice(c->device);
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= chunks.size()) return;
+                const Chunk& ck = chunks[k];
+                if (hipEventSynchronize(ck.ev) != hipSuccess) { werr = 1; continue; }
+                if (rc != 0 || fd[ck.which] < 0) continue;
+                size_t done = 0;
+                while (done < ck.n) {
+                    const ssize_t w = ::pwrite(fd[ck.which], c->csv_pinned + ck.src_off + done, ck.n - done, (off_t)(ck.file_off + done));
+                    if (w <= 0) { werr = 1; break; }
+                    done += (size_t)w;
+                }
+            }
+        };
+        const int T = (int)std::max<size_t>(1, std::min<size_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), chunks.size()));
+        std::vector<std::thread> wt;
+        for (int k = 1; k < T; k++) wt.emplace_back(writer);
+        writer();
+        for (auto& x : wt) x.join();
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& ck : chunks) c->evt_pool.push_back(ck.ev);
+        for (int which = 0; which < 2; which++)
+            if (fd[which] >= 0 && ::close(fd[which]) != 0) werr = 1;
+        if (rc == 0 && werr) rc = fail(-8, "mirge_annotation_csv_device: write error");
+        hc.lap("copy + write");
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(dblob); c->release(doffs); c->release(drows); c->release(dflags); c->release(len_m); c->release(len_u);
+    c->release(off_m); c->release(off_u); c->release(out_m); c->release(out_u); c->release(tmp);
+    return rc;
+}

@@ -29,6 +29,8 @@ struct mirge_lib {
     }
 };
 
+static int lib_upload(mirge_ctx* c, std::unique_ptr<mirge_lib>& L, int64_t n_refs, mirge_lib** out);
+
 extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* off, int64_t n_refs, mirge_lib** out) {
     if (!c || !out || (!seq && n_refs > 0) || !off || n_refs < 0) return fail(-1, "mirge_lib_create: bad argument");
     HIPOK(hipSetDevice(c->device));
@@ -38,6 +40,45 @@ extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* of
     std::string err;
     int rc = mirge_hostlib_build(L->h, seq, off, n_refs, err);
     if (rc) return fail(rc, "mirge_lib_create: " + err);
+    return lib_upload(c, L, n_refs, out);
+}
+
+// The packed image of a library -- what mirge_lib_create derives from the sequences -- handed back in: the one-time
+// conversion a library cache keeps next to the index (hard part 2), so that a process does not parse 150 MB of
+// FASTA / decode an .ebwt and pack it again before its first kernel.  T: (total + 31) / 32 + 8 words, inv:
+// (total + 63) / 64 + 4 words (padding ones), ref_start: n_refs + 1; the probe tables are still built on the device.
+extern "C" int mirge_lib_create_packed(mirge_ctx* c, const uint64_t* T, int64_t n_T, const uint64_t* inv, int64_t n_inv,
+                                       const uint32_t* ref_start, int64_t n_refs, uint64_t total, int32_t kmax,
+                                       uint64_t valid_positions, mirge_lib** out) {
+    if (!c || !out || !T || !inv || !ref_start || n_refs < 0 || total >= 0xFFFFFFF0ull || kmax < 8 || kmax > MIRGE_KMAX ||
+        n_T != (int64_t)((total + 31) / 32) + 8 || n_inv != (int64_t)((total + 63) / 64) + 4 || ref_start[n_refs] != (uint32_t)total)
+        return fail(-1, "mirge_lib_create_packed: bad argument (a cache of another layout?)");
+    HIPOK(hipSetDevice(c->device));
+    auto L = std::make_unique<mirge_lib>();
+    L->ctx = c;
+    L->uid = g_lib_uid.fetch_add(1);
+    L->h.n_refs = n_refs; L->h.total = total; L->h.kmax = kmax; L->h.valid_positions = valid_positions;
+    L->h.T.assign(T, T + n_T);
+    L->h.inv.assign(inv, inv + n_inv);
+    L->h.ref_start.assign(ref_start, ref_start + n_refs + 1);
+    return lib_upload(c, L, n_refs, out);
+}
+// sizes[4] = {words of T, words of inv, total, valid positions}; then the arrays themselves (caller-allocated)
+extern "C" int mirge_lib_packed_sizes(const mirge_lib* L, int64_t* sizes, int32_t* kmax) {
+    if (!L || !sizes || !kmax) return fail(-1, "mirge_lib_packed_sizes: bad argument");
+    sizes[0] = (int64_t)L->h.T.size(); sizes[1] = (int64_t)L->h.inv.size(); sizes[2] = (int64_t)L->h.total; sizes[3] = (int64_t)L->h.valid_positions;
+    *kmax = L->h.kmax;
+    return 0;
+}
+extern "C" int mirge_lib_packed_copy(const mirge_lib* L, uint64_t* T, uint64_t* inv, uint32_t* ref_start) {
+    if (!L || !T || !inv || !ref_start) return fail(-1, "mirge_lib_packed_copy: bad argument");
+    std::memcpy(T, L->h.T.data(), L->h.T.size() * 8);
+    std::memcpy(inv, L->h.inv.data(), L->h.inv.size() * 8);
+    std::memcpy(ref_start, L->h.ref_start.data(), L->h.ref_start.size() * 4);
+    return 0;
+}
+
+static int lib_upload(mirge_ctx* c, std::unique_ptr<mirge_lib>& L, int64_t n_refs, mirge_lib** out) {
     L->n_refs = n_refs;
     L->kmax = L->h.kmax;
     L->htables.assign(MIRGE_SHAPE_SLOTS, MirgeKTable{nullptr, nullptr, nullptr});

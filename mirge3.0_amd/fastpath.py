@@ -187,19 +187,33 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
     S = len(base_names)
     # ---- the per-read tables (mirge/__main__.py:164-173)
     t = time.perf_counter()
-    seqs = uniq.unpack()
-    if ann is None:
-        ps, ref, off, mm = res.fetch()
-    else:
-        (ps, ref), off, mm = ann, None, None
+    want_reports = any(getattr(args, k, False) for k in ("gff_out", "AtoI", "isoform_entropy"))
+    # one sample, annotation on the device, no per-read report asked for: the two files are formatted on the GPU and
+    # neither the reads nor the annotation are fetched (they are 35 B per unique read, the files' text 48 B)
+    on_device = ann is None and res is not None and S == 1 and not getattr(args, "host_csv", False)
+    seqs = ps = ref = off = mm = None
+    if not on_device or want_reports:
+        seqs = uniq.unpack()
+        if ann is None:
+            ps, ref, off, mm = res.fetch()
+        else:
+            ps, ref = ann
     tm["fetch_reads_annotation_s"] = time.perf_counter() - t
     order = uniq.first_appearance_order() if S == 1 else row_order(seqs, first, S)  # one sample: sorted on the device
     tm["row_order_s"] = time.perf_counter() - t - tm["fetch_reads_annotation_s"]
     n_cols = 10 if args.spikeIn else 9  # bwtAlign drops the 'spike-in' column when -spk is off (manifoldAlign.py:137-138)
     cols = PASS_COLUMNS[:n_cols]
     header = ",".join(["Sequence", "annotFlag"] + cols + list(base_names)) + "\n"
-    _ffi.annotation_csv(workDir / "mapped.csv", workDir / "unmapped.csv", header, seqs, ps, ref, counts, order,
-                        list(range(casc.n_pass)), n_cols, names_by_pass(casc))
+    done = False
+    if on_device:
+        done = _ffi.annotation_csv_device(ctx, uniq, res, workDir / "mapped.csv", workDir / "unmapped.csv", header, order,
+                                          list(range(casc.n_pass)), n_cols, names_by_pass(casc))
+    if not done:
+        if seqs is None:
+            seqs = uniq.unpack()
+            ps, ref, off, mm = res.fetch()
+        _ffi.annotation_csv(workDir / "mapped.csv", workDir / "unmapped.csv", header, seqs, ps, ref, counts, order,
+                            list(range(casc.n_pass)), n_cols, names_by_pass(casc))
     tm["per_read_csv_s"] = time.perf_counter() - t
     if getattr(args, "gff_out", False):  # -gff (summary.py:800-837)
         from .gff import write_gff

@@ -196,14 +196,25 @@ def load_library_dir(libraries_path: str, organism: str, ref_db: str,
     return out
 
 
-def load_index(base: str) -> Library:
-    """One library by its index base name: ``<base>.fa`` or ``<base>.{1,3,4}.ebwt[l]``."""
+def load_index(base: str, use_cache: bool = True) -> Library:
+    """One library by its index base name: ``<base>.fa`` or ``<base>.{1,3,4}.ebwt[l]`` -- or the packed image of either
+    from ``<base>.mirge3amd`` when that cache is current (libcache.py).  A library read from its source carries
+    ``cache_target``: who packs it (``Cascade``) writes the cache."""
+    from . import libcache
+    if use_cache:
+        lib = libcache.load(base)
+        if lib is not None:
+            return lib
     if os.path.exists(base + ".fa"):
-        return read_fasta(base + ".fa")
-    from . import ebwt
-    if ebwt.has_index(base):
-        return ebwt.read_ebwt(base)
-    raise FileNotFoundError(f"library missing: neither {base}.fa nor {base}.1.ebwt exists")
+        lib = read_fasta(base + ".fa")
+    else:
+        from . import ebwt
+        if not ebwt.has_index(base):
+            raise FileNotFoundError(f"library missing: neither {base}.fa nor {base}.1.ebwt exists")
+        lib = ebwt.read_ebwt(base)
+    if use_cache and libcache.enabled():
+        lib.cache_target = (base, libcache.source_stamp(base))
+    return lib
 
 
 def load_merges(libraries_path: str, organism: str, ref_db: str) -> List[List[str]]:

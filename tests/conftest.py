@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the tests read the committed golden library directories: no library caches are written next to those (the cache has its
+# own tests, which switch it on for directories of their own)
+os.environ.setdefault("MIRGE_LIB_CACHE", "0")
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

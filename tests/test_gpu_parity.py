@@ -187,6 +187,38 @@ def test_bowtie_crosscheck_real_bowtie(tmp_path):
         fh.write(out)
 
 
+def test_cutadapt_crosscheck_real_cutadapt():
+    """tools/cutadapt_crosscheck.py: the trimming restatement (oracle and k_trim) against a REAL cutadapt on ten option
+    sets -- skipped, not passed, where none is installed (row N4 then stays 'parity unpinned')."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("cutadapt") is None:
+        pytest.skip("no cutadapt on this box: the trimming restatement stays unpinned")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cutadapt_crosscheck.py"), "--gpu"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_shim_prints_the_sam_line_the_reference_quotes(tmp_path):
+    """mirge/libs/summary.py:1194 quotes bowtie's SAM line for a mature-tRNA hit with one mismatch (the only SAM output
+    the reference holds): POS 18, MAPQ 255, 20M, XA:i:1 MD:Z:17A2 NM:i:1.  The MI355X shim, asked the same way
+    (`-v 1 -f -a --best --strata --norc -S`), prints those fields for a reference that holds the window at offset 17."""
+    import subprocess
+    import sys
+    shim = os.path.join(os.path.dirname(os.path.abspath(mirge3_amd.__file__)), "shim", "bowtie")
+    read, window = "AAAACATCAGATTGTGAGTC", "AAAACATCAGATTGTGAATC"
+    ref = "GCGTTCCGTAGTCTAGC" + window + "CGGTACCATTGGA"
+    (tmp_path / "trna.fa").write_text(f">trnaMT_HisGTG_MT_+_12138_12206\n{ref}\n>other\nGGGGCCCCAAAATTTTGGGGCCCCAAAATTTT\n")
+    (tmp_path / "in.fa").write_text(f">{read}\n{read}\n")
+    r = subprocess.run([sys.executable, shim, str(tmp_path / "trna"), "-v", "1", "-f", "-a", "--best", "--strata", "--norc", "-S",
+                        "--threads", "1", str(tmp_path / "in.fa")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if not ln.startswith("@")][0].split("\t")
+    assert line == ("AAAACATCAGATTGTGAGTC 0 trnaMT_HisGTG_MT_+_12138_12206 18 255 20M * 0 0 AAAACATCAGATTGTGAGTC "
+                    "IIIIIIIIIIIIIIIIIIII XA:i:1 MD:Z:17A2 NM:i:1").split(" ")
+
+
 # ---------------------------------------------------------------- oracle on seeded inputs
 def test_cascade_vs_oracle_ci_scale(ctx, ci_libs, ci_cascade):
     reads = synth.make_reads(ci_libs, 60000, seed=5, n_frac=0.01)
@@ -1623,6 +1655,41 @@ def test_cli_with_adapter_trimming_end_to_end(tmp_path):
     a = (tmp_path / "trimmed" / "annotation.report.csv").read_text().splitlines()[1].split(",")
     b = (tmp_path / "untrimmed" / "annotation.report.csv").read_text().splitlines()[1].split(",")
     assert a[1:] == b[1:] and int(a[2]) > 1000
+
+
+def test_cli_library_cache_next_to_the_index(tmp_path):
+    """The one-time conversion kept next to the index (libcache.py): a first CLI run on a fresh copy of golden case 1's
+    library directory writes <index>.mirge3amd for every library, a second run loads them (mirge_lib_create_packed: no
+    FASTA parse, no packing) and writes the same bytes; touching an index invalidates just that cache."""
+    import shutil
+    case = GoldenCase("case1_single")
+    libdir = tmp_path / "Libs"
+    shutil.copytree(case.libdir, libdir)
+    fq = _case_fastq_files(case, tmp_path)
+    idx = libdir / ORG / "index.Libs"
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, "-c", "import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()" % root]
+
+    def run(tag):
+        r = subprocess.run(cmd + ["-s", ",".join(fq), "-lib", str(libdir), "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", tag, "-shh"],
+                           env=dict(os.environ, MIRGE_LIB_CACHE="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return {f: (tmp_path / tag / f).read_bytes() for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "annotation.report.csv")}
+
+    a = run("first")
+    caches = sorted(f for f in os.listdir(idx) if f.endswith(".mirge3amd"))
+    assert len(caches) == 8, caches
+    stamp = {f: os.stat(idx / f).st_mtime_ns for f in caches}
+    b = run("second")
+    assert a == b and {f: os.stat(idx / f).st_mtime_ns for f in caches} == stamp  # loaded, not rewritten
+    for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv"):
+        assert a[f].decode() == case.text(f), f
+    os.utime(idx / f"{ORG}_rrna.fa", ns=(5, 5))
+    c = run("third")
+    after = {f: os.stat(idx / f).st_mtime_ns for f in caches}
+    assert c == a and [f for f in caches if after[f] != stamp[f]] == [f"{ORG}_rrna.mirge3amd"]
 
 
 def test_cli_route_edge_inputs(tmp_path):

@@ -273,3 +273,72 @@ def test_sample_forms_of_the_command_line(tmp_path):
         collect_samples(parse_args(["-s", str(d / "lib.fa")] + base + ["-shh"]), log)
     r = parse_args(["-s", str(d), "-rr"] + base)
     assert collect_samples(r, log) == ([str(d)], [])
+
+
+def test_library_cache_round_trip_and_invalidation(tmp_path, monkeypatch):
+    """libcache: the packed image + names written next to an index come back as the same library (lengths at once, letters
+    decoded on demand, kept verbatim for small libraries), and the cache is ignored when the index file changed, when the
+    layout version differs, or when MIRGE_LIB_CACHE=0; an unwritable directory sends it to the user's cache directory."""
+    from mirge3_amd import libcache
+    from mirge3_amd.seqio import Library, load_index, write_fasta
+    monkeypatch.setenv("MIRGE_LIB_CACHE", "1")
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "xdg"))
+    rng = np.random.default_rng(4)
+    seqs = ["".join("ACGTN"[int(c)] for c in rng.choice(5, size=int(n), p=[.245, .245, .245, .245, .02])) for n in rng.integers(1, 300, size=60)]
+    seqs[3] = "ACGTRYACGT"  # an IUPAC code: invalid for the engine, kept as a letter for the host-side reports
+    lib = Library([f"r{i}" for i in range(len(seqs))], FlatSeqs.from_list(seqs), [f"r{i} chr1 segs:x" for i in range(len(seqs))])
+    base = str(tmp_path / "human_mrna")
+    write_fasta(base + ".fa", lib)
+    # the image mirge_lib_create derives (csrc/mirge_libbuild.hpp), in numpy
+    lens = lib.seqs.lengths
+    total = int(lens.sum() + len(seqs))
+    rs = np.zeros(len(seqs) + 1, dtype=np.uint32)
+    rs[1:] = np.cumsum(lens + 1)
+    T = np.zeros((total + 31) // 32 + 8, dtype=np.uint64)
+    inv = np.full((total + 63) // 64 + 4, np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    valid = 0
+    for t, q in enumerate(seqs):
+        for i, ch in enumerate(q):
+            if ch in "ACGT":
+                g = int(rs[t]) + i
+                T[g >> 5] |= np.uint64("ACGT".index(ch) << (2 * (g & 31)))
+                inv[g >> 6] &= ~np.uint64(1 << (g & 63))
+                valid += 1
+    packed = {"T": T, "inv": inv, "ref_start": rs, "total": total, "kmax": 9, "valid_positions": valid}
+    first = load_index(base)
+    assert first.cache_target[0] == base and not hasattr(first, "cache_path")
+    path = libcache.save(base, first, packed, first.cache_target[1])
+    assert path == base + ".mirge3amd"
+    got = load_index(base)
+    assert got.cache_path == path and got.names == first.names and got.headers == first.headers
+    assert np.array_equal(got.seqs.offsets, first.seqs.offsets)
+    assert got.seqs.to_list() == first.seqs.to_list()  # small library: the letters themselves, IUPAC code included
+    assert np.array_equal(got.seqs.packed["T"], T) and got.seqs.packed["total"] == total and got.seqs.packed["kmax"] == 9
+    dec = libcache.decode(packed, np.asarray(first.seqs.offsets))  # what a large library would decode to
+    want = "".join(q if set(q) <= set("ACGTN") else "".join(c if c in "ACGT" else "N" for c in q) for q in seqs)
+    assert dec.tobytes().decode() == want
+    # a changed index file: the cache no longer applies
+    os.utime(base + ".fa", ns=(1, 1))
+    assert not hasattr(load_index(base), "cache_path")
+    libcache.save(base, first, packed, libcache.source_stamp(base))
+    assert load_index(base).cache_path == path
+    monkeypatch.setattr(libcache, "VERSION", libcache.VERSION + 1)
+    assert not hasattr(load_index(base), "cache_path")
+    monkeypatch.undo()
+    monkeypatch.setenv("MIRGE_LIB_CACHE", "0")
+    assert not hasattr(load_index(base), "cache_path") and getattr(load_index(base), "cache_target", None) is None
+    # a library directory that cannot be written to
+    monkeypatch.setenv("MIRGE_LIB_CACHE", "1")
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "xdg"))
+    os.unlink(path)
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    write_fasta(str(ro / "human_rrna.fa"), lib)
+    os.chmod(ro, 0o555)
+    try:
+        if os.access(ro, os.W_OK):  # root ignores the mode bits: nothing to see here
+            return
+        p2 = libcache.save(str(ro / "human_rrna"), lib, packed, libcache.source_stamp(str(ro / "human_rrna")))
+        assert p2.startswith(str(tmp_path / "xdg")) and load_index(str(ro / "human_rrna")).cache_path == p2
+    finally:
+        os.chmod(ro, 0o755)

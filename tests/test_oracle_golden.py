@@ -136,3 +136,59 @@ def test_qiagen_key_follows_the_references_string_rule():
     # b == 0: Python's s[-0:] is the whole string -- the key keeps adapter and all
     assert oracle.qiagen_key(ins + ad + umi, ins, len(ad), 0) == ins + ad
     assert oracle.umi_parser(ins + umi[:5], 0, 12) == (ins[:-7], ins[-7:] + umi[:5])
+
+
+# ---- the only bowtie outputs the reference itself holds (as comments next to the code that parses them)
+def _fake_bowtie(args, cwd):
+    import subprocess
+    import sys
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fake_bowtie", "bowtie")
+    r = subprocess.run([sys.executable, exe] + args, capture_output=True, text=True, cwd=cwd, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def test_sam_line_quoted_by_the_reference(tmp_path):
+    """mirge/libs/summary.py:1194 quotes a line of bowtie's SAM output for the mature-tRNA pass (`-v 1 -a --best --strata`):
+    AAAACATCAGATTGTGAGTC at POS 18 of trnaMT_HisGTG_MT_+_12138_12206, MAPQ 255, 20M, XA:i:1 MD:Z:17A2 NM:i:1 -- one
+    mismatch, reference base A under read position 17.  The stand-in behind the golden fixtures prints those fields
+    for a reference built to hold that window at offset 17."""
+    read = "AAAACATCAGATTGTGAGTC"
+    window = "AAAACATCAGATTGTGAATC"
+    ref = "GCGTTCCGTAGTCTAGC" + window + "CGGTACCATTGGA"
+    (tmp_path / "trna.fa").write_text(f">trnaMT_HisGTG_MT_+_12138_12206\n{ref}\n>other\nGGGGCCCCAAAATTTTGGGGCCCCAAAATTTT\n")
+    (tmp_path / "in.fa").write_text(f">{read}\n{read}\n")
+    out = _fake_bowtie([str(tmp_path / "trna"), "-v", "1", "-f", "-a", "--best", "--strata", "--norc", "-S", "--threads", "1",
+                        str(tmp_path / "in.fa")], tmp_path)
+    line = [ln for ln in out.splitlines() if not ln.startswith("@")][0].split("\t")
+    quoted = ("AAAACATCAGATTGTGAGTC 0 trnaMT_HisGTG_MT_+_12138_12206 18 255 20M * 0 0 AAAACATCAGATTGTGAGTC "
+              "IIIIIIIIIIIIIIIIIIII XA:i:1 MD:Z:17A2 NM:i:1").split(" ")
+    assert line == quoted  # (the quoted line ends with XM:i:2, whose meaning for an aligned read the manual does not settle)
+    assert ref.index(window) == 17
+
+
+def test_default_format_lines_quoted_by_the_reference(tmp_path):
+    """mirge/libs/mirge2_tRF_a2i.py:1082-1085 quotes four lines of bowtie's default output for `-n 1 -f -a -3 2` against the
+    genome: the read trimmed by two bases, '+' and '-' strand hits (the '-' ones print the reverse complement), 0-based
+    offsets, and mismatch descriptors `14:T>G` = read offset from its 5' end : reference base > read base, both as they
+    stand on the forward strand.  A four-chromosome genome built to hold those alignments gives those lines."""
+    read = "AAAAACTGAGACTACTTTTG"
+    fwd = "AAAAACTGAGACTACTTT"
+    rc = "AAAGTAGTCTCAGTTTTT"
+    pad = "GCGCGTACGCGC"
+    genome = {"chr10": pad * 3 + fwd + pad, "chr2": pad + rc + pad * 2,
+              "chr14": pad * 2 + rc[:3] + "T" + rc[4:] + pad, "chr4": pad * 4 + rc[:3] + "A" + rc[4:] + pad}
+    (tmp_path / "g.fa").write_text("".join(f">{k}\n{v}\n" for k, v in genome.items()))
+    (tmp_path / "in.fa").write_text(f">{read}\n{read}\n")
+    out = _fake_bowtie([str(tmp_path / "g"), "-n", "1", "-f", "-a", "-3", "2", str(tmp_path / "in.fa")], tmp_path)
+    got = sorted(ln.split("\t") for ln in out.splitlines())
+    want = sorted([
+        [read, "+", "chr10", str(len(pad) * 3), fwd, "I" * 18, "0", ""],
+        [read, "-", "chr2", str(len(pad)), rc, "I" * 18, "0", ""],
+        [read, "-", "chr14", str(len(pad) * 2), rc, "I" * 18, "0", "14:T>G"],
+        [read, "-", "chr4", str(len(pad) * 4), rc, "I" * 18, "0", "14:A>G"],
+    ])
+    assert got == want
+    # what the reference does with them (mirge2_tRF_a2i.py:1076-1096): the read has two 0-mismatch hits -> not retained
+    counts = [ln[-1].count(":") for ln in got]
+    assert sorted(counts) == [0, 0, 1, 1]

@@ -11,7 +11,10 @@ For every pass it writes the FASTA the reference would write (name = sequence; T
 `bowtie <index> <the reference's argument string> <threads> <fasta>` verbatim (manifoldAlign.py:85), parses the SAM as
 the reference does (field 0 / field 2) and compares with ONE pass of the GPU engine on the same reads:
   * membership (aligned / not aligned) must be identical -- this is what the per-class counts depend on;
-  * the reference named may differ where several hits are equally good (reported, not an error).
+  * the reference named may differ where several hits are equally good (reported, not an error): `other-name` per
+    pass and, at the end, the TIE RATE -- the share of aligned reads whose reported name differs, i.e. how often the
+    documented tie-break (fewest mismatches, lowest reference, leftmost offset) decides something bowtie decides otherwise;
+  * the whole report is also written to gpurun_out/bowtie_crosscheck.txt (scratch, merged back by gpurun).
 Indexes: `<index>.1.ebwt` is built with `bowtie-build` from `<index>.fa` if missing (skipped when the directory has
 no bowtie-build, e.g. the shim in mirge3.0_amd/shim, which answers from `<index>.fa`).
 Exit code 0 = every pass agrees on membership.
@@ -72,6 +75,12 @@ def main(argv=None):
     pol = policies(9)
     annotated = set()
     bad = 0
+    n_both = n_other = 0
+    report = []
+
+    def say(line):
+        print(line)
+        report.append(line)
     fasta = os.path.join(tmp, "bwtInput.fasta")
     for it in range(9):
         col, key, argstr, _ = PASSES[it]
@@ -106,13 +115,24 @@ def main(argv=None):
         only_b = sorted(set(ref_hit) - set(got))
         only_g = sorted(set(got) - set(ref_hit))
         diff_name = sum(1 for q in got if q in ref_hit and ref_hit[q] != got[q])
-        print(f"pass {it} {col:14s} reads {len(recs):7d}  bowtie {len(ref_hit):7d}  gpu {len(got):7d}  only-bowtie {len(only_b)}  "
-              f"only-gpu {len(only_g)}  other-name {diff_name}")
+        say(f"pass {it} {col:14s} reads {len(recs):7d}  bowtie {len(ref_hit):7d}  gpu {len(got):7d}  only-bowtie {len(only_b)}  "
+            f"only-gpu {len(only_g)}  other-name {diff_name}")
         for q in (only_b + only_g)[:5]:
-            print("    ", q, "bowtie:", ref_hit.get(q), "gpu:", got.get(q))
+            say(f"     {q} bowtie: {ref_hit.get(q)} gpu: {got.get(q)}")
+        for q in [q for q in got if q in ref_hit and ref_hit[q] != got[q]][:3]:
+            say(f"     name differs: {q} bowtie: {ref_hit[q]} gpu: {got[q]}")
+        n_both += sum(1 for q in got if q in ref_hit)
+        n_other += diff_name
         bad += len(only_b) + len(only_g)
         annotated |= set(ref_hit)  # the cascade continues with what the REFERENCE path annotated
-    print("membership identical in every pass" if bad == 0 else f"{bad} reads differ in membership")
+    say("membership identical in every pass" if bad == 0 else f"{bad} reads differ in membership")
+    say(f"tie rate: {n_other} of {n_both} reads aligned by both carry another reference name ({100.0 * n_other / max(n_both, 1):.3f} %)")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bowtie_crosscheck.txt"), "w") as fh:
+            fh.write(f"bowtie: {bowtie}\n" + "\n".join(report) + "\n")
+    except OSError:
+        pass
     return 0 if bad == 0 else 1
 
 
