@@ -159,9 +159,14 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         res = casc.run(uniq)
     for p in parsed:
         p.close()
-    counts, first = uniq.counts()
-    for s, name in enumerate(base_names):
-        trimmedReadCountsUnique[name] = int(np.count_nonzero(counts[:, s]))
+    counts = first = None
+    if S == 1:  # every unique read of the one sample has a count: no need to fetch the matrix to know how many there are
+        trimmedReadCountsUnique[base_names[0]] = len(uniq)
+    else:
+        counts, first = uniq.counts()
+        for s, name in enumerate(base_names):
+            trimmedReadCountsUnique[name] = int(np.count_nonzero(counts[:, s]))
+    ctx.sync()
     tm["collapse_cascade_s"] = time.perf_counter() - t
     say(f'Alignment completed in {round(time.perf_counter() - t, 4)} second(s)\n')
     t = time.perf_counter()
@@ -192,6 +197,8 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
     # neither the reads nor the annotation are fetched (they are 35 B per unique read, the files' text 48 B)
     on_device = ann is None and res is not None and S == 1 and not getattr(args, "host_csv", False)
     seqs = ps = ref = off = mm = None
+    if counts is None and (not on_device or want_reports):
+        counts, first = uniq.counts()
     if not on_device or want_reports:
         seqs = uniq.unpack()
         if ann is None:
@@ -212,6 +219,8 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
         if seqs is None:
             seqs = uniq.unpack()
             ps, ref, off, mm = res.fetch()
+        if counts is None:
+            counts, first = uniq.counts()
         _ffi.annotation_csv(workDir / "mapped.csv", workDir / "unmapped.csv", header, seqs, ps, ref, counts, order,
                             list(range(casc.n_pass)), n_cols, names_by_pass(casc))
     tm["per_read_csv_s"] = time.perf_counter() - t

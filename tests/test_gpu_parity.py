@@ -413,9 +413,9 @@ def test_baking_dropin(ctx, ci_libs, tmp_path):
     df1, *_ = baking(args, files[:1], names[:1], str(tmp_path), ctx=ctx)
     seen = list(dict.fromkeys(r for r in exp[0] if len(r) >= 16))
     assert list(df1.index) == seen
-    with pytest.raises(NotImplementedError):  # one adapter per run: cutadapt's AdapterCutter would pick the better match per read
-        baking(SimpleNamespace(quiet=True, minimum_length=16, adapters=[("back", "TGGAATTC")], front=[("front", "ACGT")], uniq_mol_ids=None),
-               files, names, str(tmp_path), ctx=ctx)
+    with pytest.raises(NotImplementedError):  # up to two adapters per run (AdapterCutter's best match of two); three are refused
+        baking(SimpleNamespace(quiet=True, minimum_length=16, adapters=[("back", "TGGAATTC"), ("back", "AGATCGG")], front=[("front", "ACGT")],
+                               uniq_mol_ids=None), files, names, str(tmp_path), ctx=ctx)
     with pytest.raises(RuntimeError, match="adapter characters"):
         baking(SimpleNamespace(quiet=True, minimum_length=16, adapters=[("back", "ACGTX")], front=None, uniq_mol_ids=None),
                files, names, str(tmp_path), ctx=ctx)
