@@ -280,7 +280,7 @@ def cli_path(args, sl, libs, text, n_pass):
                 o["device"][h].close()
             sizes = {f: os.path.getsize(os.path.join(work, f)) for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv")}
             res[label] = {"wall_s": round(wall, 3), "M_reads_per_s": round(args.reads / wall / 1e6, 2),
-                          "stages_s": {k: round(v, 3) for k, v in tm.items()}, "output_bytes": sizes}
+                          "stages_s": {k: (round(v, 3) if not isinstance(v, dict) else v) for k, v in tm.items()}, "output_bytes": sizes}
         res["note"] = ("mirge3_amd.fastpath.run = what `python -m mirge3_amd.cli` executes: FASTQ file read from disk, parsed / "
                        "collapsed / annotated / joined on the GPU, per-miRNA tables by pandas on ~2.7 k rows, mapped.csv + "
                        "unmapped.csv (one line per unique read) formatted on the GPU (mirge_annotation_csv_device); first_run reads "
@@ -492,7 +492,7 @@ def main():
     stage_ms = {
         "collapse": sum(v["total_ms"] for k, v in kernels.items() if "collapse" in k or "heads" in k or "scan" in k or "hist" in k or "k_part" in k or "flags" in k) / n_tab_steps,
         "cascade": sum(v["total_ms"] for k, v in kernels.items() if k.startswith(("k_pass", "k_resolve", "k_cascade"))) / n_tab_steps,
-        "join": sum(v["total_ms"] for k, v in kernels.items() if k == "k_join") / n_tab_steps,
+        "join": sum(v["total_ms"] for k, v in kernels.items() if k.startswith("k_join")) / n_tab_steps,
     }
     U = state["U"]
     out = {

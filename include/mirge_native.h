@@ -115,6 +115,8 @@ typedef struct mirge_trim {
     const char* adapter2;     /* a second adapter or NULL: per read the better match of the two is removed (cutadapt's   */
     int32_t adapter2_len;     /* AdapterCutter with times = 1: most matches, then fewest errors, then the first given)  */
     int32_t adapter2_front;
+    int32_t times;            /* -n COUNT: remove adapters up to COUNT times (0 / 1: once)                               */
+    int32_t no_indels;        /* --no-indels: substitutions only in the adapter alignment                                 */
 } mirge_trim;
 int mirge_reads_parse_trim(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                            const mirge_trim* trim, mirge_reads** out, int64_t* n_records);

@@ -150,8 +150,8 @@ def trim_from_args(args):
     """The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) as the options of ``mirge_reads_parse_trim``:
     ``-q`` (default "10": quality trimming is ALWAYS in the reference's chain), ``-a`` / ``-g`` (one or two adapters, 3'
     or 5'; with two, a read loses the better match -- AdapterCutter with times = 1), ``-nxt``, ``-NX``, ``-u``,
-    ``--overlap``, ``--error-rate``, ``-phr``.  More than two adapters, ``-n > 1`` and ``--action`` other than trim are
-    refused."""
+    ``--overlap``, ``--error-rate``, ``-phr``, ``-n`` (repeat the removal), ``--no-indels``.  More than two adapters and
+    ``--action`` other than trim are refused."""
     adapters = adapters_from_args(args)
     if len(adapters) > 2 or any(kind not in ("back", "front") for kind, _ in adapters):
         raise NotImplementedError("up to two adapters are supported (-a / -g, in any combination)")
@@ -178,7 +178,8 @@ def trim_from_args(args):
                                phred_base=base, min_overlap=int(getattr(args, "overlap", 3)),
                                error_rate=float(getattr(args, "error_rate", 0.12)), trim_n=bool(getattr(args, "trim_n", False)),
                                cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once",
-                               front=a1[0] == "front", adapter2=a2[1], front2=a2[0] == "front")
+                               front=a1[0] == "front", adapter2=a2[1], front2=a2[0] == "front",
+                               times=int(getattr(args, "times", 1) or 1), indels=bool(getattr(args, "indels", True)))
 
 
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:

@@ -37,6 +37,59 @@ __global__ void k_join(const int8_t* __restrict__ res_pass, const int32_t* __res
     }
 }
 
+// k_join_rows / k_join_reduce (round 3): the same sums without a global atomic per read.  k_join's exact / isomiR tables take
+// one device-scope atomic per miRNA read -- 2.5 M of them on 2.9 k hot addresses for a 10 M-read sample, 74 us at the
+// chip's ~20-30 G scattered atomics/s: the last kernel of the step and 5 % of it.  Here a 1024-thread workgroup keeps ALL
+// tables (class sums + exact + isomiR, 64-bit cells) in LDS while it walks its share of the reads, writes them out as
+// one plain row of partial[workgroup][cell], and a second small kernel sums the rows column-wise into the ctx's tables.
+// Used when the tables fit 48 KiB of LDS (one sample: up to ~3 000 miRNA references); otherwise k_join.
+#define MIRGE_JOIN_ROWS_THREADS 1024
+#define MIRGE_JOIN_ROWS_CELLS 6144  // 64-bit LDS cells
+__global__ void __launch_bounds__(MIRGE_JOIN_ROWS_THREADS)
+k_join_rows(const int8_t* __restrict__ res_pass, const int32_t* __restrict__ res_ref, const uint32_t* __restrict__ counts,
+            uint32_t n, int32_t S, int32_t n_pass, int32_t exact_pass, int32_t iso_pass, uint32_t n_tab,
+            unsigned long long* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long j_acc[];  // [n_pass * S] | [n_tab] exact | [n_tab] iso
+    const uint32_t n_cls = (uint32_t)(n_pass * S), W = n_cls + 2 * n_tab;
+    for (uint32_t c = threadIdx.x; c < W; c += blockDim.x) j_acc[c] = 0ull;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int p = res_pass[i];
+        if (p < 0) continue;
+        const uint32_t ref = (uint32_t)res_ref[i];
+        for (int32_t s = 0; s < S; s++) {
+            const unsigned long long c = counts[(size_t)i * S + s];
+            if (!c) continue;
+            atomicAdd(&j_acc[p * S + s], c);
+            if (p == exact_pass) atomicAdd(&j_acc[n_cls + (size_t)ref * S + s], c);
+            else if (p == iso_pass) atomicAdd(&j_acc[n_cls + n_tab + (size_t)ref * S + s], c);
+        }
+    }
+    __syncthreads();
+    unsigned long long* row = partial + (size_t)blockIdx.x * W;
+    for (uint32_t c = threadIdx.x; c < W; c += blockDim.x) row[c] = j_acc[c];
+}
+// tables[c] += sum over rows of partial[row][c].  A workgroup owns 64 consecutive cells; its 16 waves take every 16th row each
+// (a wave's load of a row's 64 cells is one coalesced 512-byte access), then the waves' sums are added up through LDS.
+// (One thread per cell walking all 256 rows by itself took 46 us for 5.9 k cells: a chain of 256 dependent-latency loads.)
+__global__ void __launch_bounds__(1024)
+k_join_reduce(const unsigned long long* __restrict__ partial, uint32_t rows, uint32_t W, unsigned long long* __restrict__ tables) {
+    __shared__ unsigned long long s_part[16][64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 64 + lane;
+    unsigned long long sum = 0ull;
+    if (c < W)
+        for (uint32_t r = wave; r < rows; r += 16) sum += partial[(size_t)r * W + c];
+    s_part[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0 && c < W) {
+        unsigned long long tot = 0ull;
+#pragma unroll
+        for (int w = 0; w < 16; w++) tot += s_part[w][lane];
+        if (tot) tables[c] += tot;
+    }
+}
+
 // out[orig[j] or base+j] = in[j]
 template <typename T>
 __global__ void k_scatter_out(const T* __restrict__ in, uint32_t n, uint32_t base,

@@ -30,6 +30,8 @@ struct TrimOpts {
     // a second adapter (-a and -g in one run, or two of a kind): AdapterCutter with times = 1 removes, per read, the ONE
     // adapter that matches best -- most matches, then fewest errors, then the first given (cutadapt's _best_match)
     int32_t alen2, front2;
+    int32_t times;      // -n COUNT: the search is repeated on what the last removal left, until nothing matches (1 = once)
+    int32_t no_indels;  // --no-indels: substitutions only (cutadapt prices an indel at 100 000); general kernel only
     uint8_t adapter2[MIRGE_TRIM_MAX_ADAPTER];
     uint8_t wild2[MIRGE_TRIM_MAX_ADAPTER];
 };
@@ -59,9 +61,14 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
     uint32_t e[MAXM + 1];
     uint8_t nw[MAXM + 1];
     nw[0] = 0;
+    // --no-indels (general kernel): the two indel candidates of a cell are raised above every diagonal one, and a 3' adapter
+    // cannot lose bases in front of the read: rows of the first column start at cost 128 (never accepted, and 128 + 64
+    // mismatches still fit the entry's 8 cost bits)
+    const uint32_t no_indel_or = (!EXACT && o.no_indels) ? 0xFF000000u : 0u;
 #pragma unroll
     for (int i = 0; i <= MAXM; i++) {
-        e[i] = FRONT ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i : (((uint32_t)i << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
+        e[i] = FRONT ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i
+                     : (((no_indel_or && i ? 128u : (uint32_t)i) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
         if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o_wild[i - 1] : 0));
     }
     int b_mat = -1, b_cost = 0, b_val = 0;
@@ -85,7 +92,8 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
         for (int i = 1; i <= MAXM; i++) {
             if (EXACT || i <= m) {
                 const uint32_t left = e[i];  // previous column, same row
-                const uint32_t best3 = min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22));
+                const uint32_t best3 = EXACT ? min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22))
+                                             : min(min(diag, e[i - 1] | (1u << 22) | no_indel_or), left | (2u << 22) | no_indel_or);
                 const uint32_t miss = (best3 & ~MIRGE_TRIM_CHOICE_MASK) + (1u << MIRGE_TRIM_COST_SHIFT);
                 const bool same = EXACT ? o_adapter[i - 1] == ch : (o_wild[i - 1] || o_adapter[i - 1] == ch);
                 const uint32_t v = same ? diag + MIRGE_TRIM_MATCH_ONE : miss;
@@ -163,16 +171,23 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
         if (o.alen > 0) {
             bool done = false;
             if constexpr (!EXACT && !FRONT) {
-                if (o.alen2 > 0) {  // two adapters: both searched, the better match removed (this kernel instance only)
-                    int h1[3], h2[3];
-                    const int v1 = o.front ? adapter_cut_point<MAXM, false, true, 0>(o, s + a0, a1 - a0, h1)
-                                           : adapter_cut_point<MAXM, false, false, 0>(o, s + a0, a1 - a0, h1);
-                    const int v2 = o.front2 ? adapter_cut_point<MAXM, false, true, 1>(o, s + a0, a1 - a0, h2)
-                                            : adapter_cut_point<MAXM, false, false, 1>(o, s + a0, a1 - a0, h2);
-                    const bool second = h2[0] && (!h1[0] || h2[1] > h1[1] || (h2[1] == h1[1] && h2[2] < h1[2]));
-                    const bool fr = second ? o.front2 != 0 : o.front != 0;
-                    const int v = second ? v2 : v1;
-                    if (second ? h2[0] : h1[0]) { if (fr) a0 = a0 + v; else a1 = a0 + v; }
+                if (o.alen2 > 0 || o.times > 1 || o.no_indels) {
+                    // the general form (this kernel instance only): one or two adapters of either kind, the better match
+                    // removed, up to `times` times (AdapterCutter: `for _ in range(times): best_match ... break if None`)
+                    for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {
+                        int h1[3], h2[3] = {0, 0, 0};
+                        const int v1 = o.front ? adapter_cut_point<MAXM, false, true, 0>(o, s + a0, a1 - a0, h1)
+                                               : adapter_cut_point<MAXM, false, false, 0>(o, s + a0, a1 - a0, h1);
+                        int v2 = 0;
+                        if (o.alen2 > 0)
+                            v2 = o.front2 ? adapter_cut_point<MAXM, false, true, 1>(o, s + a0, a1 - a0, h2)
+                                          : adapter_cut_point<MAXM, false, false, 1>(o, s + a0, a1 - a0, h2);
+                        const bool second = h2[0] && (!h1[0] || h2[1] > h1[1] || (h2[1] == h1[1] && h2[2] < h1[2]));
+                        if (!(second ? h2[0] : h1[0])) break;
+                        const bool fr = second ? o.front2 != 0 : o.front != 0;
+                        const int v = second ? v2 : v1;
+                        if (fr) a0 = a0 + v; else a1 = a0 + v;
+                    }
                     done = true;
                 }
             }

@@ -27,9 +27,24 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     unsigned long long* d = c->join_dev;
     if (!c->join_dev_clean) HIPOK(hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream));
     c->join_dev_clean = false;
+    unsigned long long* partial = nullptr;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
         if (!g.n) continue;
+        // a big group whose tables fit LDS: per-workgroup tables in LDS, rows out, column sums (no global atomic per read)
+        static const bool rows_off = std::getenv("MIRGE_JOIN_ROWS") && std::atoi(std::getenv("MIRGE_JOIN_ROWS")) == 0;  // A/B
+        if (!rows_off && g.n >= 65536 && words <= MIRGE_JOIN_ROWS_CELLS && n_mirna * (int64_t)S < 0x7FFFFFFF) {
+            const uint32_t rows = (uint32_t)std::min<size_t>((size_t)c->n_cu, (g.n + 4095) / 4096);
+            if (!partial) CHECK(dalloc(c, &partial, (size_t)c->n_cu * words));
+            {
+                LaunchScope ls(c, "k_join", g.n);
+                hipLaunchKernelGGL(k_join_rows, dim3(rows), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, g.pass, g.ref,
+                                   U->g[gi].counts, g.n, S, P, exact_pass, iso_pass, (uint32_t)n_tab, partial);
+            }
+            LaunchScope ls(c, "k_join_reduce", (double)words);
+            hipLaunchKernelGGL(k_join_reduce, dim3((unsigned)((words + 63) / 64)), dim3(1024), 0, c->stream, partial, rows, (uint32_t)words, d);
+            continue;
+        }
         LaunchScope ls(c, "k_join", g.n);
         hipLaunchKernelGGL(k_join, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, g.pass, g.ref,
                            U->g[gi].counts, g.n, S, P, exact_pass, iso_pass, d, d + n_cls, d + n_cls + n_tab);
@@ -47,6 +62,7 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     const bool cleared = hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream) == hipSuccess;
     HIPOK(hipEventSynchronize(c->ev_meta));
     c->join_dev_clean = cleared;
+    c->release(partial);
     std::memcpy(class_sums, c->join_pinned, n_cls * 8);
     if (n_mirna) {
         std::memcpy(exact, c->join_pinned + n_cls, (size_t)n_mirna * S * 8);

@@ -268,6 +268,9 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
         if (ch == 'N' && o.front2) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
         o.adapter2[i] = (uint8_t)ch; o.wild2[i] = ch == 'N';
     }
+    o.times = t->times > 1 ? t->times : 1;
+    o.no_indels = t->no_indels ? 1 : 0;
+    if (o.times > 16) return fail(-1, "mirge_reads_parse_trim: -n above 16 is not supported");
     if (o.alen && (!(o.rate >= 0.0) || o.rate > 1.0 || o.min_overlap < 1)) return fail(-1, "mirge_reads_parse_trim: error rate / overlap out of range");
     if (t->n_cut < 0 || t->n_cut > 2) return fail(-1, "mirge_reads_parse_trim: at most two unconditional cuts");
     o.n_cut = t->n_cut; o.cut[0] = t->cut[0]; o.cut[1] = t->cut[1];
@@ -297,7 +300,7 @@ static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, co
                        const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
     bool wild = false;
     for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
-    if (o.alen2 > 0) {  // two adapters: the general 3' instance carries the best-match branch
+    if (o.alen2 > 0 || o.times > 1 || o.no_indels) {  // two adapters, -n, --no-indels: the general 3' instance carries that branch
         hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
         return 0;
     }

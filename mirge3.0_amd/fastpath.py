@@ -125,6 +125,8 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     casc = get_cascade(args, ref_db, getattr(args, "device", 0))
     ctx = casc.ctx
     tm["libraries_s"] = time.perf_counter() - t0
+    if tm["libraries_s"] > 0.005:  # this call loaded them: where the time went
+        tm["libraries_detail_s"] = {k: round(v, 4) for k, v in casc.timing.items()}
     min_len = int(getattr(args, "minimum_length", 16))
     trim = trim_from_args(args)
     umi = umi_from_args(args)

@@ -683,7 +683,7 @@ def nextseq_trim_index(seq: str, qual: str, cutoff: int, base: int = 33):
     return stop
 
 
-def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3):
+def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True):
     """Aligner.locate for a regular 3' adapter (the alignment may start anywhere in the read, stop anywhere in it, and
     stop inside the adapter when it runs off the read's end): unit costs, indels allowed; of the alignments with
     cost <= aligned adapter length * max_error_rate and at least min_overlap adapter bases, the one with the most
@@ -695,7 +695,10 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
     nwild = [0] * (m + 1)
     for i in range(m):
         nwild[i + 1] = nwild[i] + (1 if wild[i] else 0)
-    prev = [(i, 0, 0) for i in range(m + 1)]  # (cost, matches, origin)
+    # --no-indels: cutadapt keeps the same matrix and prices an insertion / a deletion at 100 000: neither is ever taken, and
+    # an alignment cannot skip adapter bases in front of the read either (first column)
+    INF = 10 ** 6
+    prev = [(i if indels or i == 0 else INF, 0, 0) for i in range(m + 1)]  # (cost, matches, origin)
     best = None
 
     def consider(entry, i, j):
@@ -715,7 +718,7 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
             if wild[i - 1] or adapter[i - 1] == read[j - 1]:
                 cur[i] = (d[0], d[1] + 1, d[2])
             else:
-                cd, cdel, cins = d[0] + 1, left[0] + 1, up[0] + 1
+                cd, cdel, cins = d[0] + 1, (left[0] + 1 if indels else INF), (up[0] + 1 if indels else INF)
                 if cd <= cdel and cd <= cins:
                     cur[i] = (cd, d[1], d[2])
                 elif cins <= cdel:
@@ -735,7 +738,7 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
     return best
 
 
-def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3):
+def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True):
     """Aligner.locate for a regular 5' adapter (flags START_WITHIN_SEQ1 | START_WITHIN_SEQ2 | STOP_WITHIN_SEQ2: the
     alignment may start anywhere in the read AND inside the adapter -- row i of the first column costs 0 and has origin
     -i -- but must reach the adapter's last base): every read column is a candidate end; aligned adapter length =
@@ -753,7 +756,7 @@ def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, 
             if adapter[i - 1] == read[j - 1]:
                 cur[i] = (d[0], d[1] + 1, d[2])
             else:
-                cd, cdel, cins = d[0] + 1, left[0] + 1, up[0] + 1
+                cd, cdel, cins = d[0] + 1, (left[0] + 1 if indels else 10 ** 6), (up[0] + 1 if indels else 10 ** 6)
                 if cd <= cdel and cd <= cins:
                     cur[i] = (cd, d[1], d[2])
                 elif cins <= cdel:
@@ -784,17 +787,23 @@ def trim_stages(seq: str, qual, opts: dict):
         a, b = quality_trim_index(qual, opts.get("q_front", 0), opts["q_back"], opts.get("base", 33))
         seq, qual = seq[a:b], qual[a:b]
         out.append(seq)
+    indels = opts.get("indels", True)
+    times = int(opts.get("times", 1))
+    if opts.get("adapter") and not opts.get("adapters") and (times > 1 or not indels):
+        opts = dict(opts, adapters=[("front" if opts.get("front") else "back", opts["adapter"])])
     if opts.get("adapters"):
         # AdapterCutter over several adapters, times = 1 (cutadapt's `_best_match`): every adapter is searched in the read
         # as it stands, the match with the most matching bases wins, then the one with fewer errors, then the first in the
         # list; only that ONE adapter is removed.  Restated from cutadapt's sources as remembered: parity unpinned.
-        best = None
-        for kind, ad in opts["adapters"]:
-            hit = (adapter_locate_front if kind == "front" else adapter_locate_back)(
-                ad, seq.upper() if kind == "front" else seq, opts.get("error_rate", 0.12), opts.get("overlap", 3))
-            if hit is not None and (best is None or hit[4] > best[1][4] or (hit[4] == best[1][4] and hit[5] < best[1][5])):
-                best = (kind, hit)
-        if best is not None:
+        for _ in range(times):  # -n COUNT: `for _ in range(self.times): match = best_match(...); if match is None: break`
+            best = None
+            for kind, ad in opts["adapters"]:
+                hit = (adapter_locate_front if kind == "front" else adapter_locate_back)(
+                    ad, seq.upper() if kind == "front" else seq, opts.get("error_rate", 0.12), opts.get("overlap", 3), indels)
+                if hit is not None and (best is None or hit[4] > best[1][4] or (hit[4] == best[1][4] and hit[5] < best[1][5])):
+                    best = (kind, hit)
+            if best is None:
+                break
             lo, hi = (best[1][3], len(seq)) if best[0] == "front" else (0, best[1][2])
             seq = seq[lo:hi]
             qual = qual[lo:hi] if qual is not None else None

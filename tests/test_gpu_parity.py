@@ -580,6 +580,63 @@ def test_documented_umi_command_lines_known_answer(ctx, tmp_path):
         assert len((tmp_path / tag / f"{tag}_umiCounts.csv").read_text().splitlines()) == 6
 
 
+def test_umi_route_at_scale(ctx, ci_libs, tmp_path):
+    """-umi 4,4 [-udd] on 3 M reads (4N layout, text of one sequence per line): the molecule counts per insert against a
+    numpy count of the distinct (UMI, insert) pairs, 'Trimmed Reads (all)', the dictionary order (an insert's rank = the
+    rank of its first tagged read), and the number of lines of <sample>_umiCounts.csv -- the two packings, the sort of the
+    first indices and the record gather of mirge_reads_parse_umi over many tiles and several read groups."""
+    from mirge3_amd.collapse import parse_sample
+    rng = np.random.default_rng(17)
+    tl = sorted(set(synth.make_reads(ci_libs, 30000, seed=3, pool=6000).to_list()))
+    tl = [t for t in tl if "N" not in t][:5000] + ["ACGTACGTACGTAC", "ACGTTGCATGCATGCATGCATGCAACGTTGCATGCATGC"]  # one too short, one long
+    tags = ["".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=8)) for _ in range(200)]
+    n = 3_000_000
+    ti = np.minimum((rng.pareto(1.2, size=n) * 40).astype(np.int64), len(tl) - 1)  # skewed: some inserts are very common
+    gi = rng.integers(0, len(tags), size=n)
+    tmpl = FlatSeqs.from_list(tl)
+    tagf, tagb = FlatSeqs.from_list([t[:4] for t in tags]), FlatSeqs.from_list([t[4:] for t in tags])
+    cols = [tagf.take(gi), tmpl.take(ti), tagb.take(gi)]
+    text = np.frombuffer(FlatSeqs.join_columns(cols, b"\x00\x00\n"), dtype=np.uint8)
+    text = text[text != 0]  # the two inner separators out: tag + insert + tag, one read per line
+    # expectations from the STRINGS (two (insert, UMI) pairs can spell the same read: the templates overlap each other)
+    full = cols[0].lengths + cols[1].lengths + cols[2].lengths
+    keep = full - 8 >= 16
+    width = int(full.max())
+    mat = np.zeros((n, width), dtype=np.uint8)
+    roff = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(full + 1, out=roff[1:])
+    rows = np.repeat(np.arange(n, dtype=np.int64), full)
+    within = np.arange(int(full.sum()), dtype=np.int64) - (roff[:-1] - np.arange(n))[rows]
+    mat[rows, within] = text[text != 10]
+    del rows, within
+    tagged = mat.view(f"S{width}").reshape(-1)
+    kept_idx = np.flatnonzero(keep)
+    u_tag, u_first, u_cnt = np.unique(tagged[kept_idx], return_index=True, return_counts=True)
+    u_first = kept_idx[u_first]  # first read that spells each distinct tagged string
+    ins_of = np.array([t[4:-4] for t in u_tag.tolist()])
+    for dedup in (True, False):
+        wd = tmp_path / f"d{int(dedup)}"
+        wd.mkdir()
+        raw, n_rec = parse_sample(ctx, text, 16, None, _ffi.MirgeUmi.make(4, 4, dedup=dedup), wd, "S")
+        assert n_rec == n
+        uniq = raw.collapse()
+        cnt, first = uniq.counts()
+        seqs = uniq.unpack().to_list()
+        order = np.argsort(first, kind="stable")
+        ins, inv = np.unique(ins_of, return_inverse=True)
+        want = np.zeros(len(ins), dtype=np.int64)
+        np.add.at(want, inv, 1 if dedup else u_cnt)
+        assert len(raw) == (len(u_tag) if dedup else int(keep.sum()))
+        if dedup:
+            assert sum(1 for _ in open(wd / "S_umiCounts.csv")) == len(u_tag) + 1
+        assert dict(zip(seqs, cnt[:, 0].tolist())) == {q.decode(): int(c) for q, c in zip(ins.tolist(), want)}
+        # dictionary order: inserts by the first appearance of any of their tagged reads
+        first_read = np.full(len(ins), n, dtype=np.int64)
+        np.minimum.at(first_read, inv, u_first)
+        assert [seqs[i] for i in order] == [ins[k].decode() for k in np.argsort(first_read, kind="stable")]
+        uniq.close(); raw.close()
+
+
 def _umi_records(rng, n, adapter, f, b, qiagen):
     """FASTQ records of UMI libraries: [f nt UMI] insert [b nt UMI] adapter ... (4N layout) or insert adapter [b nt UMI]
     external adapter (Qiagen layout), from a few inserts and UMIs so that molecules repeat; adapters with errors,
@@ -1474,6 +1531,35 @@ def test_trimming_equals_the_restated_cutadapt_chain(ctx, opts, per_modifier):
         order = np.argsort(first, kind="stable")
         assert [(seqs[i], int(cnt[i, 0])) for i in order] == list(want.items())
         uniq.close(); raw.close()
+
+
+@pytest.mark.parametrize("opts", [dict(adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAG", times=3), dict(adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAG", indels=False),
+                                  dict(adapter="GTTCAGAGTTCTACAGTCCGACGATC", front=True, indels=False, times=2),
+                                  dict(adapters=[("back", "TGGAATTCTCGGGTGCCAAGGAACTCCAG"), ("front", "GTTCAGAGTTCTACAGTCCGACGATC")], times=2)])
+def test_adapter_removal_repeated_and_without_indels(ctx, opts):
+    """cutadapt's -n COUNT (AdapterCutter removes the best match, then searches what is left, up to COUNT times) and
+    --no-indels (substitutions only): k_trim's general branch against the oracle's restatement, on the reads of the
+    trimming test (adapters whole, partial, with substitutions / indels, twice in a read)."""
+    rng = np.random.default_rng(len(str(opts)))
+    a3, a5 = "TGGAATTCTCGGGTGCCAAGGAACTCCAG", "GTTCAGAGTTCTACAGTCCGACGATC"
+    recs = _trim_fastq(rng, 3000, a3)
+    recs += [(a5[k % 7:] + s[:40], q[:len(a5[k % 7:] + s[:40])].ljust(len(a5[k % 7:] + s[:40]), "I")) for k, (s, q) in enumerate(recs[:1500])]
+    recs += [(s[:22] + a3[:12] + "AC" + a3, "I" * len(s[:22] + a3[:12] + "AC" + a3)) for s, _ in recs[:500]]  # the adapter twice
+    text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+    ads = opts.get("adapters") or [("front" if opts.get("front") else "back", opts["adapter"])]
+    a2 = ads[1] if len(ads) > 1 else (None, None)
+    trim = _ffi.MirgeTrim.make(adapter=ads[0][1], front=ads[0][0] == "front", adapter2=a2[1], front2=a2[0] == "front", quality_back=10,
+                               count_per_modifier=False, times=opts.get("times", 1), indels=opts.get("indels", True))
+    raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 16, trim)
+    uniq = raw.collapse()
+    cnt, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    order = np.argsort(first, kind="stable")
+    want = oracle.trimmed_counts(recs, dict(q_back=10, **opts), 16, False)
+    assert [(seqs[i], int(cnt[i, 0])) for i in order] == list(want.items()) and len(want) > 1000
+    plain = oracle.trimmed_counts(recs, dict(q_back=10, **{k: v for k, v in opts.items() if k not in ("times", "indels")}), 16, False)
+    assert want != plain  # the option changes something on these reads
+    uniq.close(); raw.close()
 
 
 @pytest.mark.parametrize("kinds", [("back", "front"), ("front", "back"), ("back", "back"), ("front", "front")])

@@ -156,8 +156,10 @@ def test_cli_flags_in_and_out_of_scope():
     k = parse_args(base + ["-M", "40", "-l", "3", "--gc-content", "50", "-cms", "256", "--buffer-size", "4000000", "-cuv", "2.7",
                            "-psam", "/opt/samtools", "-minl", "16", "-olc", "14", "--numba-pll", "-n", "1", "--action", "trim"])
     assert k.minimum_length == 16 and k.adapters is None
-    for bad in (["-udd"], ["-qumi"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"], ["-n", "2"], ["--action", "mask"],
-                ["--no-indels"], ["--match-read-wildcards"]):
+    r = trim_from_args(parse_args(base + ["-a", "illumina", "-n", "2", "--no-indels"]))  # cutadapt's -n / --no-indels
+    assert (r.times, r.no_indels) == (2, 1) and (tr.times, tr.no_indels) == (1, 0)
+    for bad in (["-udd"], ["-qumi"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"], ["-n", "0"], ["--action", "mask"],
+                ["--match-read-wildcards"]):
         with pytest.raises(SystemExit):
             parse_args(base + bad)
 
