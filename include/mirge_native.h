@@ -171,6 +171,12 @@ int mirge_collapse_fetch(mirge_ctx* ctx, const mirge_reads* uniq, uint32_t* coun
 /* order_out[k] (k < U) = index of the unique read that appeared k-th in the raw reads: the row order of the reference's
  * per-sample dictionary (insertion order, digest.py:158-163), from one device sort of the first indices. */
 int mirge_collapse_order(mirge_ctx* ctx, const mirge_reads* uniq, int64_t* order_out);
+/* order_out[k] (k < U) = index of the unique read in row k of the SORTED union of the sequences (Python string order): the
+ * row order of the sample matrix of several samples (pandas `join(how='outer')` sorts its index, digest.py:243), from a
+ * radix sort on the device instead of a host-side sort of U strings. */
+int mirge_collapse_order_sorted(mirge_ctx* ctx, const mirge_reads* uniq, int64_t* order_out);
+/* nonzero_out[n_samples] = unique reads with a count in each sample ('Trimmed Reads (unique)', digest.py:214) */
+int mirge_collapse_nonzero(mirge_ctx* ctx, const mirge_reads* uniq, int64_t* nonzero_out);
 /* attach a caller-made count matrix (U x n_samples, host) to a packed read set, e.g. after -rr */
 int mirge_reads_set_counts(mirge_ctx* ctx, mirge_reads* reads, const uint32_t* counts, int32_t n_samples);
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_create_packed", "mirge_lib_packed_sizes", "mirge_lib_packed_copy", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
-    "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order",
+    "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
@@ -349,6 +349,19 @@ class DeviceReads:
         order = np.zeros(len(self), dtype=np.int64)
         _check(load().mirge_collapse_order(self.ctx._h, self._h, _p(order)), "mirge_collapse_order")
         return order
+
+    def sorted_order(self) -> np.ndarray:
+        """Indices of the unique reads in the order of the sorted sequences (Python string order: the index of the reference's
+        outer-joined sample matrix, digest.py:243), from a radix sort on the device (``mirge_collapse_order_sorted``)."""
+        order = np.zeros(len(self), dtype=np.int64)
+        _check(load().mirge_collapse_order_sorted(self.ctx._h, self._h, _p(order)), "mirge_collapse_order_sorted")
+        return order
+
+    def nonzero_per_sample(self) -> np.ndarray:
+        """unique reads with a count, per sample column (``mirge_collapse_nonzero``)"""
+        out = np.zeros(max(self.n_samples, 1), dtype=np.int64)
+        _check(load().mirge_collapse_nonzero(self.ctx._h, self._h, _p(out)), "mirge_collapse_nonzero")
+        return out
 
     def set_counts(self, counts: np.ndarray):
         counts = np.ascontiguousarray(counts, dtype=np.uint32).reshape(len(self), -1)

@@ -108,3 +108,50 @@ __global__ void k_csv_rows(CsvTables t, const uint32_t* __restrict__ rows, uint3
         *o++ = '\n';
     }
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Row order of the sample matrix of SEVERAL samples: pandas' outer join sorts the union of the sequences
+// (digest.py:243), i.e. Python string order -- A < C < G < N < T, a prefix before its extensions.  A read becomes a
+// string of 3-bit digits (end 0, A 1, C 2, G 3, N 4, T 5), 21 to a 64-bit word, most significant first: comparing the
+// words in turn IS that order.  k_lexkey writes word w of the reads listed in perm; the host runs a least-significant-word-
+// first radix sort (stable pair sorts) over as many words as the longest read present needs.  Replaces a host-side
+// argsort of a U x 32-byte matrix (3 s per 3 M unique reads; the whole GPU part of such a run is 0.3 s).
+// ------------------------------------------------------------------------------------------
+#define MIRGE_LEX_BASES 21
+__global__ void k_lexkey(CsvTables t, const uint32_t* __restrict__ perm, uint32_t n, int32_t word, unsigned long long* __restrict__ keys) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t j;
+        const int gi = csv_locate(t, perm[k], j);
+        const CsvGroup& g = t.g[gi];
+        const int L = g.len[j];
+        unsigned long long key = 0ull;
+        const int p0 = word * MIRGE_LEX_BASES;
+#pragma unroll 1
+        for (int b = 0; b < MIRGE_LEX_BASES; b++) {
+            const int p = p0 + b;
+            unsigned long long d = 0ull;
+            if (p < L) {
+                const uint64_t wd = g.seq[(size_t)(p >> 5) * g.n + j];
+                const uint64_t nm = g.nmask ? g.nmask[(size_t)(p >> 5) * g.n + j] : 0ull;
+                const uint32_t code = (uint32_t)((wd >> (2 * (p & 31))) & 3ull);
+                const bool isn = (nm >> (2 * (p & 31))) & 1ull;
+                d = isn ? 4ull : (code == 3u ? 5ull : (unsigned long long)code + 1ull);
+            }
+            key = (key << 3) | d;
+        }
+        keys[k] = key;
+    }
+}
+__global__ void k_iota(uint32_t* __restrict__ out, uint32_t n) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = k;
+}
+// nz[s] = unique reads with a count in sample s ('Trimmed Reads (unique)' per sample, digest.py:214)
+__global__ void k_count_nonzero_cols(const uint32_t* __restrict__ counts, uint32_t n, int32_t S, unsigned long long* __restrict__ nz) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int32_t s = 0; s < S; s++) {
+            const bool has = counts[(size_t)i * S + s] != 0u;
+            const unsigned long long bal = __ballot(has);
+            if (bal && (threadIdx.x & 63) == (unsigned)(__ffsll(bal) - 1)) atomicAdd(&nz[s], (unsigned long long)__popcll(bal));
+        }
+}

@@ -337,3 +337,82 @@ extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, c
     c->release(off_m); c->release(off_u); c->release(out_m); c->release(out_u); c->release(tmp);
     return rc;
 }
+
+
+static void csv_tables_of(const mirge_reads* U, const mirge_result* res, CsvTables& t) {
+    std::memset(&t, 0, sizeof(t));
+    t.S = U->n_samples;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = U->g[gi];
+        t.g[gi] = CsvGroup{g.seq, g.nmask, g.len, g.counts, res ? res->g[gi].pass : nullptr, res ? res->g[gi].ref : nullptr, g.base, g.n, g.W};
+    }
+}
+
+// order_out[k] (k < U) = index of the unique read in row k of the SORTED union of the sequences: the row order of the
+// reference's sample matrix for several samples (pandas `join(how='outer')` sorts its index, digest.py:243), from a radix
+// sort on the device (k_lexkey).
+extern "C" int mirge_collapse_order_sorted(mirge_ctx* c, const mirge_reads* U, int64_t* order_out) {
+    if (!c || !U || (!order_out && U->n)) return fail(-1, "mirge_collapse_order_sorted: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    const size_t n = (size_t)U->n;
+    if (!n) return 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+        if (U->g[gi].n && U->g[gi].orig) return fail(-1, "mirge_collapse_order_sorted: handle is not a collapse result");
+    int maxlen = MIRGE_MAX_READ_LEN;
+    if (U->hist_valid) {
+        maxlen = 1;
+        for (int L = 1; L <= MIRGE_MAX_READ_LEN; L++) if (U->len_hist[L]) maxlen = L;
+    }
+    const int n_words = (maxlen + MIRGE_LEX_BASES - 1) / MIRGE_LEX_BASES;
+    CsvTables t;
+    csv_tables_of(U, nullptr, t);
+    unsigned long long *keys = nullptr, *keys2 = nullptr;
+    uint32_t *perm = nullptr, *perm2 = nullptr;
+    void* tmp = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = dalloc(c, &keys, n))) break;
+        if ((rc = dalloc(c, &keys2, n))) break;
+        if ((rc = dalloc(c, &perm, n))) break;
+        if ((rc = dalloc(c, &perm2, n))) break;
+        size_t tb = 0;
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys2, perm, perm2, (int)n, 0, 63, c->stream);
+        if (e == hipSuccess && (rc = dalloc(c, (uint8_t**)&tmp, std::max<size_t>(tb, 16)))) break;
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, perm, (uint32_t)n);
+        for (int w = n_words - 1; w >= 0 && e == hipSuccess; w--) {  // least significant word first; every pair sort is stable
+            hipLaunchKernelGGL(k_lexkey, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, t, perm, (uint32_t)n, w, keys);
+            e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys, keys2, perm, perm2, (int)n, 0, 63, c->stream);
+            std::swap(perm, perm2);
+        }
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_collapse_order_sorted: ") + hipGetErrorString(e)); break; }
+        std::vector<uint32_t> h(n);
+        e = hipMemcpyAsync(h.data(), perm, n * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_collapse_order_sorted: ") + hipGetErrorString(e)); break; }
+        for (size_t k = 0; k < n; k++) order_out[k] = (int64_t)h[k];
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(keys); c->release(keys2); c->release(perm); c->release(perm2); c->release(tmp);
+    return rc;
+}
+
+// nonzero_out[s] = unique reads with a count in sample s: 'Trimmed Reads (unique)' per sample (digest.py:214) without
+// fetching the U x S matrix
+extern "C" int mirge_collapse_nonzero(mirge_ctx* c, const mirge_reads* U, int64_t* nonzero_out) {
+    if (!c || !U || !nonzero_out || U->n_samples < 1) return fail(-1, "mirge_collapse_nonzero: bad argument");
+    HIPOK(hipSetDevice(c->device));
+    const int32_t S = U->n_samples;
+    unsigned long long* d = nullptr;
+    CHECK(dalloc(c, &d, (size_t)S));
+    HIPOK(hipMemsetAsync(d, 0, (size_t)S * 8, c->stream));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = U->g[gi];
+        if (g.n) hipLaunchKernelGGL(k_count_nonzero_cols, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, g.counts, g.n, S, d);
+    }
+    std::vector<unsigned long long> h((size_t)S);
+    HIPOK(hipMemcpyAsync(h.data(), d, (size_t)S * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));
+    for (int32_t s = 0; s < S; s++) nonzero_out[s] = (int64_t)h[(size_t)s];
+    c->release(d);
+    return 0;
+}

@@ -161,13 +161,12 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         res = casc.run(uniq)
     for p in parsed:
         p.close()
-    counts = first = None
-    if S == 1:  # every unique read of the one sample has a count: no need to fetch the matrix to know how many there are
+    counts = first = None  # fetched by `reports` only if something on the host needs the matrix
+    if S == 1:  # every unique read of the one sample has a count
         trimmedReadCountsUnique[base_names[0]] = len(uniq)
     else:
-        counts, first = uniq.counts()
-        for s, name in enumerate(base_names):
-            trimmedReadCountsUnique[name] = int(np.count_nonzero(counts[:, s]))
+        for name, nz in zip(base_names, uniq.nonzero_per_sample()):
+            trimmedReadCountsUnique[name] = int(nz)
     ctx.sync()
     tm["collapse_cascade_s"] = time.perf_counter() - t
     say(f'Alignment completed in {round(time.perf_counter() - t, 4)} second(s)\n')
@@ -195,9 +194,9 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
     # ---- the per-read tables (mirge/__main__.py:164-173)
     t = time.perf_counter()
     want_reports = any(getattr(args, k, False) for k in ("gff_out", "AtoI", "isoform_entropy"))
-    # one sample, annotation on the device, no per-read report asked for: the two files are formatted on the GPU and
-    # neither the reads nor the annotation are fetched (they are 35 B per unique read, the files' text 48 B)
-    on_device = ann is None and res is not None and S == 1 and not getattr(args, "host_csv", False)
+    # annotation on the device, no per-read report asked for: the two files are formatted on the GPU and neither the reads
+    # nor the counts nor the annotation are fetched (they are 35 B per unique read, the files' text 48 B)
+    on_device = ann is None and res is not None and not getattr(args, "host_csv", False)
     seqs = ps = ref = off = mm = None
     if counts is None and (not on_device or want_reports):
         counts, first = uniq.counts()
@@ -208,7 +207,9 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
         else:
             ps, ref = ann
     tm["fetch_reads_annotation_s"] = time.perf_counter() - t
-    order = uniq.first_appearance_order() if S == 1 else row_order(seqs, first, S)  # one sample: sorted on the device
+    # row order of the reference's frame: dictionary order for one sample (digest.py:158-163), the sorted union of the
+    # sequences for several (pandas' outer join, digest.py:243) -- both from a sort on the device
+    order = uniq.first_appearance_order() if S == 1 else uniq.sorted_order()
     tm["row_order_s"] = time.perf_counter() - t - tm["fetch_reads_annotation_s"]
     n_cols = 10 if args.spikeIn else 9  # bwtAlign drops the 'spike-in' column when -spk is off (manifoldAlign.py:137-138)
     cols = PASS_COLUMNS[:n_cols]

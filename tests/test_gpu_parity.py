@@ -1817,6 +1817,29 @@ def test_cli_route_edge_inputs(tmp_path):
     assert int(list(csv.DictReader(open(work2 / "annotation.report.csv")))[0]["All miRNA Reads"]) == 0
 
 
+def test_sorted_order_on_the_device(ctx, ci_libs):
+    """mirge_collapse_order_sorted == Python's sorted() on the sequences (the index of the reference's outer-joined frame,
+    digest.py:243): every read group at once -- reads with N (N sorts between G and T), 32-255-nt reads, reads that are
+    prefixes of other reads -- and mirge_collapse_nonzero == the matrix's non-zero counts per column."""
+    rng = np.random.default_rng(12)
+    base = synth.make_reads(ci_libs, 60000, seed=21, n_frac=0.05, pool=9000).to_list()
+    extra = []
+    for q in base[:3000]:
+        extra += [q[:16], q[:17], q + "A", q + "T", q + "N", q[:20] + "N" + q[21:]]
+    longs = ["".join("ACGTN"[int(c)] for c in rng.choice(5, size=int(L), p=[.24, .24, .24, .24, .04])) for L in rng.integers(32, 256, size=400)]
+    longs += [longs[0][:100], longs[0][:64], longs[0][:65], longs[1] + "A"][:4]
+    samples = [FlatSeqs.from_list(base + extra), FlatSeqs.from_list(extra[::3] + longs), FlatSeqs.from_list(longs[::2] + base[::5])]
+    uniq = collapse_samples(ctx, samples)
+    seqs = uniq.unpack().to_list()
+    got = uniq.sorted_order()
+    assert [seqs[i] for i in got] == sorted(seqs) and len(set(seqs)) == len(seqs) > 8000
+    cnt, _ = uniq.counts()
+    assert uniq.nonzero_per_sample().tolist() == np.count_nonzero(cnt, axis=0).tolist()
+    from mirge3_amd.fastpath import row_order
+    assert np.array_equal(got, row_order(uniq.unpack(), None, 3))
+    uniq.close()
+
+
 def test_first_appearance_order_on_the_device(ctx):
     """mirge_collapse_order == ranking the first indices on the host (fastpath.row_order), over several read groups."""
     from mirge3_amd.fastpath import row_order
