@@ -329,37 +329,34 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
-            # RCCL carries nothing but the barrier and one 8-byte max here.  If it cannot come up on this node (IPC mode,
-            # a missing xGMI link, a driver mismatch) the measurement must not die with it: every rank then falls back
-            # to gloo -- decided together through the rendezvous store, before any GPU work of the bench itself.
-            from torch.distributed import TCPStore
-            store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17, world,
-                             rank == 0, timeout=datetime.timedelta(seconds=300))
-            ok = True
+            # RCCL carries nothing but the barrier and one 8-byte max here.  If it cannot come up on this node (IPC mode, a
+            # missing xGMI link, a driver mismatch) the measurement must not die with it: the default group is gloo (always
+            # there), RCCL is a second group on top, probed with one all-reduce; the ranks agree over gloo whether every
+            # one of them got it, and fall back together -- before any GPU work of the bench itself.
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            ok = 1
             try:
                 if os.environ.get("MIRGE_BENCH_FORCE_NCCL_FAIL"):  # test hook
                     raise RuntimeError("forced (MIRGE_BENCH_FORCE_NCCL_FAIL)")
-                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=datetime.timedelta(seconds=300))
+                nccl_pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300))
                 probe = torch.ones(1, device=f"cuda:{dev_index}")
-                dist.all_reduce(probe)
+                dist.all_reduce(probe, group=nccl_pg)
                 torch.cuda.synchronize()
-                ok = int(probe.item()) == world
+                ok = int(int(probe.item()) == world)
             except Exception as e:  # noqa: BLE001
-                ok = False
-                backend_note = f"nccl init failed on rank {rank}: {repr(e)[:200]}"
-            store.set(f"nccl_ok_{rank}", "1" if ok else "0")
-            all_ok = all(store.get(f"nccl_ok_{r}") == b"1" for r in range(world))
-            if not all_ok:
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:  # noqa: BLE001
-                    pass
-                backend = "gloo"
-                dist.init_process_group("gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+                ok = 0
+                nccl_pg = None
+                backend_note = f"nccl failed on rank {rank}: {repr(e)[:200]}"
+            agree = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 1:
+                bench_pg = nccl_pg
+            else:
+                backend, bench_pg = "gloo", None
                 backend_note = backend_note or "nccl failed on another rank"
         else:
             dist.init_process_group(backend)
+            bench_pg = None
     n_gpus = world if world > 1 else args.gpus
     if world == 1 and args.gpus > 1:
         print("bench.py: --gpus > 1 needs torch.distributed.run; running rank 0 only", file=sys.stderr)
@@ -412,7 +409,7 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=bench_pg)
         torch.cuda.synchronize()
 
     # warm-up: builds the probe tables on first use and warms the buffer pool; its last two steps run
@@ -436,7 +433,7 @@ def main():
         if dist is None:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{dev_index}" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=bench_pg)
         return float(t.item())
 
     # clocks up before anything is timed: W warm-up steps of ~2 ms leave a GPU that idled through the setup at whatever

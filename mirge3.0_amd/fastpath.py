@@ -84,7 +84,9 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     seqs = uniq.unpack().take(order)
     ps, ref, _, _ = res.fetch()
     out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
-    out.reads = multigpu.SampleReads(seqs.data, seqs.offsets, counts[order, 0], ps[order], ref[order], iupac)
+    reads = multigpu.SampleReads(seqs.data, seqs.offsets, counts[order, 0], ps[order], ref[order], iupac)
+    # handed to rank 0 through files in the run's directory (same node): a sample's dictionary is tens to hundreds of MB
+    out.reads = reads.to_files(workDir / ".mirge_shards", index)
     res.close(); uniq.close()
     return out
 
@@ -259,6 +261,13 @@ def run_sharded_rank0(args, tables, workDir, ref_db: str, casc):
     merges = load_merges(str(args.libraries_path), args.organism_name, ref_db)
     out = finish_tables(cls, ex, iso, casc.libs["mirna"], merges, names, src, trimmed, uniq_n, float(args.crThreshold),
                         bool(args.spikeIn), workDir=workDir)
+    for t in tables:
+        if isinstance(t.reads, str):
+            t.reads = multigpu.SampleReads.from_files(t.reads)
+    try:
+        (workDir / ".mirge_shards").rmdir()
+    except OSError:
+        pass
     with open(workDir / "run.log", "a+") as outlog:
         for t in tables:
             if t.reads.iupac:

@@ -53,12 +53,16 @@ def main():
         t.reads = multigpu.SampleReads(fs.data, fs.offsets, np.array([c for _, c in mine], dtype=np.uint32),
                                        np.array([exp[s][0] for s, _ in mine], dtype=np.int8),
                                        np.array([lut.get(exp[s][1], 0) for s, _ in mine], dtype=np.int32))
+        if i % 2:  # the hand-over through files in the run's directory (what fastpath.run_sample_tables does), and in-band
+            t.reads = t.reads.to_files(os.path.join(out_dir, ".mirge_shards"), i)
         return t
 
     assert multigpu.assign_samples(len(case.samples), world)[rank] == [rank]
     tables = multigpu.run_sharded(len(case.samples), rank, world, process, dist)
     if rank == 0:
         for t in tables:  # every rank's dictionary arrived whole, in sample order
+            if isinstance(t.reads, str):
+                t.reads = multigpu.SampleReads.from_files(t.reads)
             assert int(t.reads.counts.sum()) == case.trimmed[t.name] and len(t.reads.counts) == case.trimmed_unique[t.name]
             assert t.reads.offsets.shape[0] == len(t.reads.counts) + 1 and t.reads.data.shape[0] == int(t.reads.offsets[-1])
         names, src, trimmed, uniq, cls, ex, iso = multigpu.merge_tables(tables)
