@@ -1215,6 +1215,39 @@ def test_cli_two_ranks_gff_a2i_equal_the_reference_files(tmp_path):
     _same_report_but_total_input(out, case)
 
 
+def test_cli_two_ranks_equal_one_process_at_scale(tmp_path, ci_libs):
+    """The sharded run against the one-process run on the same two 1.5 M-read samples (synthetic libraries written as a
+    miRge library directory): every output file byte for byte.  The one-process run formats mapped.csv / unmapped.csv on
+    the GPU from the joint collapse of the raw reads; the sharded run merges the ranks' dictionaries with the weighted
+    collapse and formats on the host -- two routes to the same sample matrix, the same row order, the same text."""
+    from mirge3_amd.seqio import index_basename, write_fasta
+    idx = tmp_path / "Libs" / ORG / "index.Libs"
+    idx.mkdir(parents=True)
+    (tmp_path / "Libs" / ORG / "annotation.Libs").mkdir()
+    for key, lib in ci_libs.libs.items():
+        write_fasta(str(idx / (index_basename(ORG, key, "miRBase") + ".fa")), lib)
+    (tmp_path / "Libs" / ORG / "annotation.Libs" / f"{ORG}_merges_miRBase.csv").write_text("".join(",".join(r) + "\n" for r in ci_libs.merges))
+    files = []
+    for s in range(2):
+        reads = synth.make_reads_chunked(ci_libs, 1_500_000, seed=900 + s)
+        L = reads.lengths
+        rec = FlatSeqs.join_columns([FlatSeqs.from_list(["@r"] * 1).take(np.zeros(len(reads), dtype=np.int64)), reads,
+                                     FlatSeqs.from_list(["+"]).take(np.zeros(len(reads), dtype=np.int64)),
+                                     FlatSeqs(np.full(int(L.sum()), ord("I"), dtype=np.uint8), reads.offsets)], b"\n\n\n\n")
+        p = tmp_path / f"S{s + 1}.fastq"
+        p.write_bytes(rec)
+        files.append(str(p))
+    case = SimpleNamespace(libdir=str(tmp_path / "Libs"))
+    _run_cli(["-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", "one", "-shh", "-ie"])
+    out2 = _run_cli_two_ranks(tmp_path, files, case, ["-ie"], 29547)
+    names = ("annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "isomirs.csv",
+             "isomirs.samples.csv")
+    for f in names:
+        a, b = (tmp_path / "one" / f).read_bytes(), (out2 / f).read_bytes()
+        assert a == b, f
+    assert (tmp_path / "one" / "mapped.csv").stat().st_size > 20_000_000 and not (out2 / ".mirge_shards").exists()
+
+
 def test_weighted_collapse_merges_dictionaries(ctx, ci_libs):
     """mirge_collapse_weighted: three samples' dictionaries (unique reads + counts) merged == the joint collapse of their
     raw reads (counts matrix; first index = first entry of the concatenated dictionaries)."""
