@@ -117,6 +117,9 @@ typedef struct mirge_trim {
     int32_t adapter2_front;
     int32_t times;            /* -n COUNT: remove adapters up to COUNT times (0 / 1: once)                               */
     int32_t no_indels;        /* --no-indels: substitutions only in the adapter alignment                                 */
+    int32_t match_read_wildcards;  /* --match-read-wildcards: an N in the read matches every adapter base                  */
+    int32_t no_adapter_wildcards;  /* -N: an N in the adapter is not a wildcard                                            */
+    int32_t action_none;      /* --action none: adapters are searched, the read is left as it is                          */
 } mirge_trim;
 int mirge_reads_parse_trim(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                            const mirge_trim* trim, mirge_reads** out, int64_t* n_records);

@@ -42,13 +42,15 @@ class MirgeTrim(C.Structure):
                 ("phred_base", C.c_int32), ("adapter", C.c_char_p), ("adapter_len", C.c_int32), ("min_overlap", C.c_int32),
                 ("error_rate", C.c_double), ("trim_n", C.c_int32), ("n_cut", C.c_int32), ("cut", C.c_int32 * 2),
                 ("count_per_modifier", C.c_int32), ("adapter_front", C.c_int32), ("adapter2", C.c_char_p),
-                ("adapter2_len", C.c_int32), ("adapter2_front", C.c_int32), ("times", C.c_int32), ("no_indels", C.c_int32)]
+                ("adapter2_len", C.c_int32), ("adapter2_front", C.c_int32), ("times", C.c_int32), ("no_indels", C.c_int32),
+                ("match_read_wildcards", C.c_int32), ("no_adapter_wildcards", C.c_int32), ("action_none", C.c_int32)]
 
     @staticmethod
     def make(adapter: Optional[str] = None, quality_back: int = -1, quality_front: int = 0, nextseq: int = -1,
              phred_base: int = 33, min_overlap: int = 3, error_rate: float = 0.12, trim_n: bool = False,
              cut: Sequence[int] = (), count_per_modifier: bool = True, front: bool = False,
-             adapter2: Optional[str] = None, front2: bool = False, times: int = 1, indels: bool = True) -> "MirgeTrim":
+             adapter2: Optional[str] = None, front2: bool = False, times: int = 1, indels: bool = True,
+             read_wildcards: bool = False, adapter_wildcards: bool = True, action: str = "trim") -> "MirgeTrim":
         t = MirgeTrim()
         t.nextseq_cutoff, t.quality_front, t.quality_back, t.phred_base = nextseq, quality_front, quality_back, phred_base
         a = adapter.encode() if adapter else None
@@ -63,6 +65,10 @@ class MirgeTrim(C.Structure):
         a2 = adapter2.encode() if adapter2 else None
         t.adapter2, t.adapter2_len, t.adapter2_front = a2, (len(a2) if a2 else 0), 1 if front2 else 0
         t.times, t.no_indels = int(times), 0 if indels else 1
+        t.match_read_wildcards, t.no_adapter_wildcards = 1 if read_wildcards else 0, 0 if adapter_wildcards else 1
+        if action not in ("trim", "none"):
+            raise NotImplementedError("--action mask / lowercase change the letters of a read, not its bounds: not part of the MI355X path")
+        t.action_none = 1 if action == "none" else 0
         return t
 
 

@@ -98,7 +98,9 @@ def parse_args(argv=None):
     # cutadapt's adapter options: the defaults are what k_trim implements; anything else is refused, not ignored
     ap.add_argument("-n", "--times", dest="times", type=int, default=1, help="remove adapters up to COUNT times from a read (cutadapt -n)")
     ap.add_argument("--no-indels", dest="indels", action="store_false", default=True, help="adapter alignment with substitutions only")
-    ap.add_argument("--action", dest="action", default="trim", help=argparse.SUPPRESS)
+    ap.add_argument("--action", dest="action", default="trim", choices=("trim", "mask", "lowercase", "none"), help=argparse.SUPPRESS)
+    ap.add_argument("--match-read-wildcards", dest="match_read_wildcards", action="store_true", default=False, help=argparse.SUPPRESS)
+    ap.add_argument("-N", "--no-match-adapter-wildcards", dest="match_adapter_wildcards", action="store_false", default=True, help=argparse.SUPPRESS)
     ap.add_argument("-qumi", "--qiagenumi", dest="qiagenumi", action="store_true",
                     help="with -umi 0,b and -a: the UMI is the b bases that follow the 3' adapter (Qiagen libraries)")
     for flag in ("-nmir", "-bam", "-trf", "-mEC", "-dex"):
@@ -108,8 +110,8 @@ def parse_args(argv=None):
     for k, v in vars(args).items():
         if k.startswith("oos_") and v is not None:
             ap.error(f"-{k[4:]} belongs to a miRge3.0 subsystem outside the MI355X hot path (DESIGN.md section 0)")
-    if args.action != "trim" or args.times < 1:
-        ap.error("--action: only cutadapt's default (the adapter is removed) is part of the MI355X path; -n must be >= 1")
+    if args.action in ("mask", "lowercase") or args.times < 1:
+        ap.error("--action mask / lowercase change a read's letters, not its bounds: not part of the MI355X path; -n must be >= 1")
     if (args.umiDedup or args.qiagenumi) and not args.uniq_mol_ids:
         ap.error("-udd / --qiagenumi require -umi f,b")
     if args.qiagenumi and not (args.adapters and args.adapters[0][0] == "back"):

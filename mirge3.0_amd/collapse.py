@@ -179,7 +179,10 @@ def trim_from_args(args):
                                error_rate=float(getattr(args, "error_rate", 0.12)), trim_n=bool(getattr(args, "trim_n", False)),
                                cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once",
                                front=a1[0] == "front", adapter2=a2[1], front2=a2[0] == "front",
-                               times=int(getattr(args, "times", 1) or 1), indels=bool(getattr(args, "indels", True)))
+                               times=int(getattr(args, "times", 1) or 1), indels=bool(getattr(args, "indels", True)),
+                               read_wildcards=bool(getattr(args, "match_read_wildcards", False)),
+                               adapter_wildcards=bool(getattr(args, "match_adapter_wildcards", True)),
+                               action=str(getattr(args, "action", "trim") or "trim"))
 
 
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:

@@ -32,6 +32,8 @@ struct TrimOpts {
     int32_t alen2, front2;
     int32_t times;      // -n COUNT: the search is repeated on what the last removal left, until nothing matches (1 = once)
     int32_t no_indels;  // --no-indels: substitutions only (cutadapt prices an indel at 100 000); general kernel only
+    int32_t read_wild;  // --match-read-wildcards: an N in the READ matches every adapter base; general kernel only
+    int32_t action_none;  // --action none: the adapter is searched but the read stays as it is (the modifier still counts)
     uint8_t adapter2[MIRGE_TRIM_MAX_ADAPTER];
     uint8_t wild2[MIRGE_TRIM_MAX_ADAPTER];
 };
@@ -95,7 +97,7 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
                 const uint32_t best3 = EXACT ? min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22))
                                              : min(min(diag, e[i - 1] | (1u << 22) | no_indel_or), left | (2u << 22) | no_indel_or);
                 const uint32_t miss = (best3 & ~MIRGE_TRIM_CHOICE_MASK) + (1u << MIRGE_TRIM_COST_SHIFT);
-                const bool same = EXACT ? o_adapter[i - 1] == ch : (o_wild[i - 1] || o_adapter[i - 1] == ch);
+                const bool same = EXACT ? o_adapter[i - 1] == ch : (o_wild[i - 1] || o_adapter[i - 1] == ch || (o.read_wild && ch == 'N'));
                 const uint32_t v = same ? diag + MIRGE_TRIM_MATCH_ONE : miss;
                 diag = left;
                 e[i] = v;
@@ -171,7 +173,8 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
         if (o.alen > 0) {
             bool done = false;
             if constexpr (!EXACT && !FRONT) {
-                if (o.alen2 > 0 || o.times > 1 || o.no_indels) {
+                if (o.action_none) done = true;
+                else if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild) {
                     // the general form (this kernel instance only): one or two adapters of either kind, the better match
                     // removed, up to `times` times (AdapterCutter: `for _ in range(times): best_match ... break if None`)
                     for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {

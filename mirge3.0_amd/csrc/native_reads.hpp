@@ -254,7 +254,7 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
         const char ch = (char)(t->adapter[i] & 0xDF);
         if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N')
             return fail(-1, "mirge_reads_parse_trim: adapter characters other than A/C/G/T/N are not supported");
-        if (ch == 'N' && o.front) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
+        if (ch == 'N' && o.front && !t->no_adapter_wildcards) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
         o.adapter[i] = (uint8_t)ch; o.wild[i] = ch == 'N';
     }
     if (t->adapter2_len < 0 || t->adapter2_len > MIRGE_TRIM_MAX_ADAPTER || (t->adapter2_len > 0 && (!t->adapter2 || !o.alen)))
@@ -265,11 +265,15 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
         const char ch = (char)(t->adapter2[i] & 0xDF);
         if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N')
             return fail(-1, "mirge_reads_parse_trim: adapter characters other than A/C/G/T/N are not supported");
-        if (ch == 'N' && o.front2) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
+        if (ch == 'N' && o.front2 && !t->no_adapter_wildcards) return fail(-1, "mirge_reads_parse_trim: N in a 5' adapter is not supported");
         o.adapter2[i] = (uint8_t)ch; o.wild2[i] = ch == 'N';
     }
     o.times = t->times > 1 ? t->times : 1;
     o.no_indels = t->no_indels ? 1 : 0;
+    o.read_wild = t->match_read_wildcards ? 1 : 0;
+    o.action_none = t->action_none ? 1 : 0;
+    if (t->no_adapter_wildcards)  // -N: an N in the adapter is a letter like any other (it matches an N of the read only)
+        for (int i = 0; i < MIRGE_TRIM_MAX_ADAPTER; i++) { o.wild[i] = 0; o.wild2[i] = 0; }
     if (o.times > 16) return fail(-1, "mirge_reads_parse_trim: -n above 16 is not supported");
     if (o.alen && (!(o.rate >= 0.0) || o.rate > 1.0 || o.min_overlap < 1)) return fail(-1, "mirge_reads_parse_trim: error rate / overlap out of range");
     if (t->n_cut < 0 || t->n_cut > 2) return fail(-1, "mirge_reads_parse_trim: at most two unconditional cuts");
@@ -300,7 +304,7 @@ static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, co
                        const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
     bool wild = false;
     for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
-    if (o.alen2 > 0 || o.times > 1 || o.no_indels) {  // two adapters, -n, --no-indels: the general 3' instance carries that branch
+    if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild || o.action_none) {  // the general 3' instance carries these branches
         hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
         return 0;
     }

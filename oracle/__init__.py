@@ -683,7 +683,8 @@ def nextseq_trim_index(seq: str, qual: str, cutoff: int, base: int = 33):
     return stop
 
 
-def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True):
+def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True,
+                        read_wildcards: bool = False, adapter_wildcards: bool = True):
     """Aligner.locate for a regular 3' adapter (the alignment may start anywhere in the read, stop anywhere in it, and
     stop inside the adapter when it runs off the read's end): unit costs, indels allowed; of the alignments with
     cost <= aligned adapter length * max_error_rate and at least min_overlap adapter bases, the one with the most
@@ -691,7 +692,7 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
     partial ones at the read's end from the longest adapter prefix down).  An 'N' in the adapter matches any base and does not
     count towards the length the error rate applies to.  -> (astart, astop, rstart, rstop, matches, errors) or None."""
     m, n = len(adapter), len(read)
-    wild = [c == "N" for c in adapter]
+    wild = [c == "N" and adapter_wildcards for c in adapter]
     nwild = [0] * (m + 1)
     for i in range(m):
         nwild[i + 1] = nwild[i] + (1 if wild[i] else 0)
@@ -715,7 +716,7 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
         cur = [(0, 0, j)] + [None] * m
         for i in range(1, m + 1):
             d, up, left = prev[i - 1], cur[i - 1], prev[i]
-            if wild[i - 1] or adapter[i - 1] == read[j - 1]:
+            if wild[i - 1] or adapter[i - 1] == read[j - 1] or (read_wildcards and read[j - 1] == "N"):
                 cur[i] = (d[0], d[1] + 1, d[2])
             else:
                 cd, cdel, cins = d[0] + 1, (left[0] + 1 if indels else INF), (up[0] + 1 if indels else INF)
@@ -738,7 +739,8 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
     return best
 
 
-def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True):
+def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True,
+                         read_wildcards: bool = False, adapter_wildcards: bool = True):
     """Aligner.locate for a regular 5' adapter (flags START_WITHIN_SEQ1 | START_WITHIN_SEQ2 | STOP_WITHIN_SEQ2: the
     alignment may start anywhere in the read AND inside the adapter -- row i of the first column costs 0 and has origin
     -i -- but must reach the adapter's last base): every read column is a candidate end; aligned adapter length =
@@ -746,14 +748,14 @@ def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, 
     preference as the 3' form (most matches, then lowest cost, first found).  No N in the adapter here.
     -> (astart, astop, rstart, rstop, matches, errors) or None; the read keeps read[rstop:]."""
     m, n = len(adapter), len(read)
-    assert "N" not in adapter.upper()
+    assert "N" not in adapter.upper() or not adapter_wildcards
     prev = [(0, 0, -i) for i in range(m + 1)]  # (cost, matches, origin)
     best = None
     for j in range(1, n + 1):
         cur = [(0, 0, j)] + [None] * m
         for i in range(1, m + 1):
             d, up, left = prev[i - 1], cur[i - 1], prev[i]
-            if adapter[i - 1] == read[j - 1]:
+            if adapter[i - 1] == read[j - 1] or (read_wildcards and read[j - 1] == "N"):
                 cur[i] = (d[0], d[1] + 1, d[2])
             else:
                 cd, cdel, cins = d[0] + 1, (left[0] + 1 if indels else 10 ** 6), (up[0] + 1 if indels else 10 ** 6)
@@ -789,7 +791,11 @@ def trim_stages(seq: str, qual, opts: dict):
         out.append(seq)
     indels = opts.get("indels", True)
     times = int(opts.get("times", 1))
-    if opts.get("adapter") and not opts.get("adapters") and (times > 1 or not indels):
+    rw, aw = bool(opts.get("read_wildcards", False)), bool(opts.get("adapter_wildcards", True))
+    if opts.get("action") == "none" and (opts.get("adapter") or opts.get("adapters")):
+        out.append(seq)  # searched, not removed: the AdapterCutter still is a modifier of the chain
+        opts = {k: v for k, v in opts.items() if k not in ("adapter", "adapters")}
+    if opts.get("adapter") and not opts.get("adapters") and (times > 1 or not indels or rw or not aw):
         opts = dict(opts, adapters=[("front" if opts.get("front") else "back", opts["adapter"])])
     if opts.get("adapters"):
         # AdapterCutter over several adapters, times = 1 (cutadapt's `_best_match`): every adapter is searched in the read
@@ -799,7 +805,7 @@ def trim_stages(seq: str, qual, opts: dict):
             best = None
             for kind, ad in opts["adapters"]:
                 hit = (adapter_locate_front if kind == "front" else adapter_locate_back)(
-                    ad, seq.upper() if kind == "front" else seq, opts.get("error_rate", 0.12), opts.get("overlap", 3), indels)
+                    ad, seq.upper() if kind == "front" else seq, opts.get("error_rate", 0.12), opts.get("overlap", 3), indels, rw, aw)
                 if hit is not None and (best is None or hit[4] > best[1][4] or (hit[4] == best[1][4] and hit[5] < best[1][5])):
                     best = (kind, hit)
             if best is None:

@@ -1568,7 +1568,10 @@ def test_trimming_equals_the_restated_cutadapt_chain(ctx, opts, per_modifier):
 
 @pytest.mark.parametrize("opts", [dict(adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAG", times=3), dict(adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAG", indels=False),
                                   dict(adapter="GTTCAGAGTTCTACAGTCCGACGATC", front=True, indels=False, times=2),
-                                  dict(adapters=[("back", "TGGAATTCTCGGGTGCCAAGGAACTCCAG"), ("front", "GTTCAGAGTTCTACAGTCCGACGATC")], times=2)])
+                                  dict(adapters=[("back", "TGGAATTCTCGGGTGCCAAGGAACTCCAG"), ("front", "GTTCAGAGTTCTACAGTCCGACGATC")], times=2),
+                                  dict(adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAG", read_wildcards=True),
+                                  dict(adapter="TGGAATTCNNGGGTGCCAAGGAACTCCAG", adapter_wildcards=False),
+                                  dict(adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAG", action="none")])
 def test_adapter_removal_repeated_and_without_indels(ctx, opts):
     """cutadapt's -n COUNT (AdapterCutter removes the best match, then searches what is left, up to COUNT times) and
     --no-indels (substitutions only): k_trim's general branch against the oracle's restatement, on the reads of the
@@ -1578,11 +1581,14 @@ def test_adapter_removal_repeated_and_without_indels(ctx, opts):
     recs = _trim_fastq(rng, 3000, a3)
     recs += [(a5[k % 7:] + s[:40], q[:len(a5[k % 7:] + s[:40])].ljust(len(a5[k % 7:] + s[:40]), "I")) for k, (s, q) in enumerate(recs[:1500])]
     recs += [(s[:22] + a3[:12] + "AC" + a3, "I" * len(s[:22] + a3[:12] + "AC" + a3)) for s, _ in recs[:500]]  # the adapter twice
+    recs += [(x, "I" * len(x)) for x in (s[:20] + a3[:5] + "N" + a3[6:9] + "NN" + a3[11:] for s, _ in recs[:500])]  # N in the adapter's copy
     text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
     ads = opts.get("adapters") or [("front" if opts.get("front") else "back", opts["adapter"])]
     a2 = ads[1] if len(ads) > 1 else (None, None)
     trim = _ffi.MirgeTrim.make(adapter=ads[0][1], front=ads[0][0] == "front", adapter2=a2[1], front2=a2[0] == "front", quality_back=10,
-                               count_per_modifier=False, times=opts.get("times", 1), indels=opts.get("indels", True))
+                               count_per_modifier=False, times=opts.get("times", 1), indels=opts.get("indels", True),
+                               read_wildcards=opts.get("read_wildcards", False), adapter_wildcards=opts.get("adapter_wildcards", True),
+                               action=opts.get("action", "trim"))
     raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 16, trim)
     uniq = raw.collapse()
     cnt, first = uniq.counts()
@@ -1590,7 +1596,7 @@ def test_adapter_removal_repeated_and_without_indels(ctx, opts):
     order = np.argsort(first, kind="stable")
     want = oracle.trimmed_counts(recs, dict(q_back=10, **opts), 16, False)
     assert [(seqs[i], int(cnt[i, 0])) for i in order] == list(want.items()) and len(want) > 1000
-    plain = oracle.trimmed_counts(recs, dict(q_back=10, **{k: v for k, v in opts.items() if k not in ("times", "indels")}), 16, False)
+    plain = oracle.trimmed_counts(recs, dict(q_back=10, **{k: v for k, v in opts.items() if k not in ("times", "indels", "read_wildcards", "adapter_wildcards", "action")}), 16, False)
     assert want != plain  # the option changes something on these reads
     uniq.close(); raw.close()
 
