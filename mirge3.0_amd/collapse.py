@@ -9,7 +9,7 @@ U x S count matrix.
 
 The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) runs on the GPU too (``trim_from_args`` ->
 ``mirge_reads_parse_trim``: quality / NextSeq trimming, one 3' or one 5' adapter, N ends, cuts); what is not covered
-(several adapters, ``-n``, ``--action``) raises instead of being skipped.
+(more than two adapters, ``--action mask`` / ``lowercase``) raises instead of being skipped.
 
 UMI handling (digest.py:164-205,305-315,334-365) is part of the same device-resident parse
 (``mirge_reads_parse_umi``): ``-umi f,b`` slices f bases off the front and b off the back of every counted read
@@ -150,8 +150,8 @@ def trim_from_args(args):
     """The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) as the options of ``mirge_reads_parse_trim``:
     ``-q`` (default "10": quality trimming is ALWAYS in the reference's chain), ``-a`` / ``-g`` (one or two adapters, 3'
     or 5'; with two, a read loses the better match -- AdapterCutter with times = 1), ``-nxt``, ``-NX``, ``-u``,
-    ``--overlap``, ``--error-rate``, ``-phr``, ``-n`` (repeat the removal), ``--no-indels``.  More than two adapters and
-    ``--action`` other than trim are refused."""
+    ``--overlap``, ``--error-rate``, ``-phr``, ``-n`` (repeat the removal), ``--no-indels``, ``--match-read-wildcards``, ``-N``,
+    ``--action none``.  More than two adapters and ``--action mask`` / ``lowercase`` are refused."""
     adapters = adapters_from_args(args)
     if len(adapters) > 2 or any(kind not in ("back", "front") for kind, _ in adapters):
         raise NotImplementedError("up to two adapters are supported (-a / -g, in any combination)")
