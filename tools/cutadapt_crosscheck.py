@@ -7,8 +7,8 @@ cutadapt, so `oracle.trim_stages` -- and `k_trim`, which equals it -- are restat
 
   python tools/cutadapt_crosscheck.py [--records 6000] [--gpu]
 
-For each of the ten option sets of tests/test_gpu_parity.py::test_trimming_equals_the_restated_cutadapt_chain (five
-chains x two adapters kinds where that applies) it writes a FASTQ file of synthetic records (adapters whole, partial,
+For each of fourteen option sets (the chains of tests/test_gpu_parity.py's trimming tests: quality / NextSeq trimming, 3' and 5'
+adapters, two adapters, -n, --no-indels, wildcards) it writes a FASTQ file of synthetic records (adapters whole, partial,
 with substitutions / indels, low-quality tails, N ends), runs `cutadapt` with the equivalent command line, and compares
 the trimmed sequence of EVERY record with the oracle's last stage -- and, with --gpu, with mirge_reads_parse_trim.
 Without cutadapt it says so and exits 0 (skip).  The report goes to stdout and gpurun_out/cutadapt_crosscheck.txt.
@@ -37,6 +37,10 @@ OPTION_SETS = [
     dict(q_back=10, adapters=[("back", A3), ("front", A5)]),
     dict(q_back=10, adapters=[("front", A5), ("back", A3)]),
     dict(q_back=15, adapter=A3, error_rate=0.05),
+    dict(q_back=10, adapter=A3, times=3),
+    dict(q_back=10, adapter=A3, indels=False),
+    dict(q_back=10, adapter=A3, read_wildcards=True),
+    dict(q_back=10, adapter="TGGAATTCNNGGGTGCCAAGGAACTCCAG", adapter_wildcards=False),
 ]
 
 
@@ -81,6 +85,14 @@ def cutadapt_argv(o, src, dst):
     for kind, ad in o.get("adapters", [("front" if o.get("front") else "back", o["adapter"])] if o.get("adapter") else []):
         a += ["-g" if kind == "front" else "-a", ad]
     a += ["-e", str(o.get("error_rate", 0.12)), "-O", str(o.get("overlap", 3))]
+    if o.get("times", 1) > 1:
+        a += ["-n", str(o["times"])]
+    if not o.get("indels", True):
+        a += ["--no-indels"]
+    if o.get("read_wildcards"):
+        a += ["--match-read-wildcards"]
+    if not o.get("adapter_wildcards", True):
+        a += ["-N"]
     if o.get("trim_n"):
         a += ["--trim-n"]
     for c in o.get("cut", []):
@@ -135,7 +147,9 @@ def main(argv=None):
                                            quality_back=o.get("q_back", -1) if o.get("q_back") is not None else -1,
                                            quality_front=o.get("q_front", 0), nextseq=o.get("nextseq", -1) if o.get("nextseq") is not None else -1,
                                            min_overlap=o.get("overlap", 3), error_rate=o.get("error_rate", 0.12),
-                                           trim_n=o.get("trim_n", False), cut=o.get("cut", []), count_per_modifier=False)
+                                           trim_n=o.get("trim_n", False), cut=o.get("cut", []), count_per_modifier=False,
+                                           times=o.get("times", 1), indels=o.get("indels", True), read_wildcards=o.get("read_wildcards", False),
+                                           adapter_wildcards=o.get("adapter_wildcards", True))
                 raw, _ = _ffi.DeviceReads.parse(ctx, open(src, "rb").read(), 1, 0, trim)
                 gpu = raw.unpack().to_list()
                 raw.close()
