@@ -117,8 +117,8 @@ def parse_args(argv=None):
     if args.qiagenumi and not (args.adapters and args.adapters[0][0] == "back"):
         ap.error("--qiagenumi reads the UMI behind the 3' adapter: give it with -a (first)")
     args.bowtieVersion = "True"
-    if (args.AtoI or args.gff_out) and (args.tcf_out or args.save_pkl or args.resume):
-        ap.error("-ai / -gff run on the device-resident route: not together with -tcf / -spl / -rr")
+    if (args.AtoI or args.gff_out) and (args.save_pkl or args.resume):
+        ap.error("-ai / -gff run on the device-resident route: not together with -spl / -rr")
     return args
 
 
@@ -246,7 +246,7 @@ def main(argv=None):
         casc = get_cascade(args, ref_db, args.device)
 
         if not fastpath.eligible(args):
-            sys.exit("-tcf / -spl / -rr are single-process options")
+            sys.exit("-spl / -rr are single-process options")
 
         def process(i):  # device-resident per sample (fastpath.run_sample_tables)
             return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc)

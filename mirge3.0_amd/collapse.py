@@ -244,6 +244,23 @@ def write_umi_counts(path, tagged: "_ffi.DeviceReads", front: int, back: int, mi
     return int(keep.shape[0])
 
 
+def write_tcf(path, raw: "_ffi.DeviceReads") -> None:
+    """``<sample>.trim.collapse.fa`` (``-tcf``, digest.py:219-229): the sample's own dictionary, most frequent first (Python's
+    stable ``sorted(..., key=count, reverse=True)``: ties stay in dictionary order), ``>seq<k>_<count>``.  One collapse of the
+    sample's raw reads on the GPU, the text assembled with numpy."""
+    u1 = raw.collapse()
+    cnt, first = u1.counts()
+    c = cnt[:, 0].astype(np.int64) if len(u1) else np.zeros(0, np.int64)
+    order = np.lexsort((first, -c))
+    seqs = u1.unpack().take(order)
+    u1.close()
+    n = len(order)
+    head = FlatSeqs.from_fixed(np.char.add(b">seq", np.char.mod("%d", np.arange(1, n + 1)).astype("S")).astype("S")) if n else FlatSeqs.from_list([])
+    num = FlatSeqs.from_fixed(np.char.mod("%d", c[order]).astype("S")) if n else FlatSeqs.from_list([])
+    with open(path, "wb") as fo:
+        fo.write(FlatSeqs.join_columns([head, num, seqs], b"_\n\n"))
+
+
 def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None, name=None):
     """One file's text -> (raw reads as the collapse takes them, records seen): parse, the modifier chain, the length
     filter and -- with ``umi`` -- the reference's UMI handling, all on the GPU (``mirge_reads_parse[_trim|_umi]``).
@@ -284,13 +301,7 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
             print(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)')
         outlog.write(f'Cutadapt finished for file {name} in {round(finish2-start, 4)} second(s)\n')
         if getattr(args, "tcf_out", False):  # (:219-229): by count, ties in dict order
-            u1 = raw.collapse()
-            tc, tfirst = u1.counts()
-            tl = u1.unpack().to_list()
-            u1.close()
-            by = sorted(range(len(tl)), key=lambda i: (-int(tc[i, 0]), int(tfirst[i])))
-            with open(Path(workDir) / (str(name) + '.trim.collapse.fa'), 'w') as fo:
-                fo.write("".join(f">seq{k + 1}_{int(tc[i, 0])}\n{tl[i]}\n" for k, i in enumerate(by)))
+            write_tcf(Path(workDir) / (str(name) + '.trim.collapse.fa'), raw)
     t0 = time.perf_counter()
     if len(parsed) == 1:
         uniq = parsed[0].collapse()

@@ -22,15 +22,15 @@ import numpy as np
 
 from . import PASS_COLUMNS, _ffi
 from .cascade import PASSES, get_cascade
-from .collapse import parse_sample, read_text, read_texts, trim_from_args, umi_from_args
+from .collapse import parse_sample, read_text, read_texts, trim_from_args, umi_from_args, write_tcf
 from .countjoin import summarize_device
 from .seqio import FlatSeqs, load_merges
 
 
 def eligible(args) -> bool:
-    """flags the device-resident run covers (-umi / --qiagenumi / -udd included); the others take the DataFrame route
-    (they need the frame itself: the pickles of -spl / -rr, the per-sample dictionaries of -tcf)"""
-    return not (getattr(args, "tcf_out", False) or getattr(args, "save_pkl", False) or getattr(args, "resume", False))
+    """flags the device-resident run covers (-umi / --qiagenumi / -udd / -tcf included); -spl / -rr take the DataFrame route:
+    their pickles ARE the frame"""
+    return not (getattr(args, "save_pkl", False) or getattr(args, "resume", False))
 
 
 def row_order(seqs: FlatSeqs, first: np.ndarray, n_samples: int) -> np.ndarray:
@@ -75,6 +75,8 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     raw, n_rec = parse_sample(ctx, read_text(str(file)), int(getattr(args, "minimum_length", 16)), trim_from_args(args),
                               umi_from_args(args), workDir, name)
     n_trimmed = len(raw)
+    if getattr(args, "tcf_out", False):
+        write_tcf(workDir / (str(name) + ".trim.collapse.fa"), raw)
     iupac = raw.iupac_seen
     uniq, res = casc.collapse_and_run(raw)
     raw.close()
@@ -145,6 +147,8 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         del text
         t_parse += time.perf_counter() - t1
         sampleReadCounts[name], trimmedReadCounts[name] = n_rec, len(raw)
+        if getattr(args, "tcf_out", False):
+            write_tcf(workDir / (str(name) + ".trim.collapse.fa"), raw)
         if raw.iupac_seen:
             say(f'WARNING: {name} holds IUPAC ambiguity codes other than N; they are aligned -- and printed -- as N')
         parsed.append(raw)

@@ -1238,10 +1238,12 @@ def test_cli_two_ranks_equal_one_process_at_scale(tmp_path, ci_libs):
         p.write_bytes(rec)
         files.append(str(p))
     case = SimpleNamespace(libdir=str(tmp_path / "Libs"))
-    _run_cli(["-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", "one", "-shh", "-ie"])
-    out2 = _run_cli_two_ranks(tmp_path, files, case, ["-ie"], 29547)
+    _run_cli(["-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", "one", "-shh", "-ie", "-tcf"])
+    out2 = _run_cli_two_ranks(tmp_path, files, case, ["-ie", "-tcf"], 29547)
     names = ("annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "isomirs.csv",
-             "isomirs.samples.csv")
+             "isomirs.samples.csv", "S1.trim.collapse.fa", "S2.trim.collapse.fa")
+    first = (tmp_path / "one" / "S1.trim.collapse.fa").read_text().split("\n", 4)
+    assert first[0].startswith(">seq1_") and first[2].startswith(">seq2_") and int(first[0][6:]) >= int(first[2][6:])
     for f in names:
         a, b = (tmp_path / "one" / f).read_bytes(), (out2 / f).read_bytes()
         assert a == b, f

@@ -160,7 +160,7 @@ def test_cli_flags_in_and_out_of_scope():
     assert (r.times, r.no_indels) == (2, 1) and (tr.times, tr.no_indels) == (1, 0)
     w = trim_from_args(parse_args(base + ["-a", "ACGTNNACGT", "--match-read-wildcards", "-N", "--action", "none"]))
     assert (w.match_read_wildcards, w.no_adapter_wildcards, w.action_none) == (1, 1, 1) and (tr.match_read_wildcards, tr.action_none) == (0, 0)
-    for bad in (["-udd"], ["-qumi"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-tcf"], ["-n", "0"], ["--action", "mask"],
+    for bad in (["-udd"], ["-qumi"], ["-bam"], ["-trf"], ["-nmir"], ["-mEC"], ["-ai", "-spl"], ["-n", "0"], ["--action", "mask"],
                 ["--action", "lowercase"]):
         with pytest.raises(SystemExit):
             parse_args(base + bad)
