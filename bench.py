@@ -53,7 +53,8 @@ def algo_bytes(name):
     base, _, w = name.partition(".w")
     w = w.rstrip("n")  # 'n' = the group of reads with an ambiguous base call
     extra = 8 * (int(w) - 1) if w.isdigit() and (base.startswith("k_pass") or base.startswith("k_collapse") or base.startswith("k_cascade")) else 0
-    return (ALGO_BYTES["k_pass"] if base.startswith("k_pass") else ALGO_BYTES.get(base, 0)) + extra
+    # k_cascade_bulk = the bulk group's passes in one launch: its unit is a read handed to a pass, as k_pass's
+    return (ALGO_BYTES["k_pass"] if base.startswith(("k_pass", "k_cascade_bulk")) else ALGO_BYTES.get(base, 0)) + extra
 
 
 def rocprof_symbol(rec_name):
@@ -62,7 +63,7 @@ def rocprof_symbol(rec_name):
     w = w.rstrip("n") or "1"
     if base.startswith("k_pass["):
         return f"k_pass<{w}, {int(base[7:-1].split('-')[0])}>"  # a merged run 'k_pass[4-6]' is launched as slot 4
-    if base in ("k_collapse_insert", "k_collapse_scatter", "k_cascade_fused"):
+    if base in ("k_collapse_insert", "k_collapse_scatter", "k_cascade_fused", "k_cascade_bulk"):
         return f"{base}<{w}>"
     return base + "("
 

@@ -323,36 +323,15 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
 #else
 #define MIRGE_PASS_ATTR
 #endif
-template <int W, int SLOT>
-__global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES) MIRGE_PASS_ATTR
-k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __restrict__ plan, GroupView<W> g,
-       const uint32_t* __restrict__ act_in,
-       const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
-       uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
-       int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
-    __shared__ uint32_t s_count;
-    constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
-    __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? sizeof(LdsPlan) : 16];
-    LdsPlan* s_plan = reinterpret_cast<LdsPlan*>(s_plan_raw);
-    if (threadIdx.x == 0) s_count = 0;
-    if (LDSP) lds_plan_fill(*s_plan, lib, plan);
-    __syncthreads();
-    PlanSrc<LDSP> psrc;
-    psrc.g = plan; psrc.l = LDSP ? s_plan : nullptr;
-    const size_t seg = (size_t)blockIdx.x * cap;  // the workgroup's slice of the survivor arrays
-    // n_dev: the read count is still on the device (a cascade enqueued behind the collapse that produces it, before
-    // the host has read U back): the first pass cuts the U reads into gridDim.x segments itself; `cap`, sized from
-    // the raw read count, only spaces the survivor slices
-    size_t seg_r = seg;
-    uint32_t n_in;
-    if (act_in) n_in = seg_n_in[blockIdx.x];
-    else {
-        const uint32_t ntot = n_dev ? *n_dev : g.n;
-        uint32_t cap_r = cap;
-        if (n_dev) cap_r = ((ntot + gridDim.x - 1) / gridDim.x + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
-        seg_r = (size_t)blockIdx.x * cap_r;
-        n_in = seg_r < ntot ? (uint32_t)((ntot - seg_r) < cap_r ? (ntot - seg_r) : cap_r) : 0u;
-    }
+// one pass of one workgroup over its n_in reads: reads [seg_r, seg_r + n_in) of the group (FIRST pass, act_in == nullptr) or
+// the survivors act_in[seg ...] its previous pass left; survivors go to act_out[seg ...], counted in s_count (LDS, reset by the
+// caller).  COHERENT: act_in was written by this workgroup earlier in the SAME kernel (k_cascade_bulk): the loads go to L2
+// (agent scope) instead of a vector L1 that may still hold the lines of two passes ago.
+template <int W, bool LDSP, bool COHERENT>
+__device__ __forceinline__ void pass_segment(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const PlanSrc<LDSP>& psrc,
+                                             const GroupView<W>& g, const uint32_t* act_in, uint32_t n_in, size_t seg, size_t seg_r,
+                                             uint32_t* __restrict__ act_out, int32_t pass_id, int8_t* __restrict__ res_pass,
+                                             uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, uint32_t* s_count) {
     const int lane = threadIdx.x & 63;
     for (uint32_t base = 0; base < n_in; base += MIRGE_BLOCK) {
         const uint32_t t = base + threadIdx.x;
@@ -360,7 +339,8 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
         bool survivor = false;
         uint32_t idx = 0;
         if (valid) {
-            idx = act_in ? act_in[seg + t] : (uint32_t)seg_r + t;
+            if (!act_in) idx = (uint32_t)seg_r + t;
+            else idx = COHERENT ? __hip_atomic_load(&act_in[seg + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : act_in[seg + t];
             survivor = true;
         }
         // the wave aligns its 64 reads together (align_hybrid balances the candidate lists)
@@ -392,11 +372,44 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
         const unsigned long long bal = __ballot(survivor);
         if (bal) {
             uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&s_count, (uint32_t)__popcll(bal));
+            if (lane == 0) wbase = atomicAdd(s_count, (uint32_t)__popcll(bal));
             wbase = __shfl(wbase, 0, 64);
             if (survivor) act_out[seg + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
         }
     }
+}
+
+// the first pass's share of workgroup b: n_dev: the read count is still on the device (a cascade enqueued behind the
+// collapse that produces it, before the host has read U back): the U reads are cut into gridDim.x segments here; `cap`,
+// sized from the raw read count, only spaces the survivor slices
+__device__ __forceinline__ uint32_t first_pass_share(uint32_t n, const uint32_t* __restrict__ n_dev, uint32_t cap, size_t& seg_r) {
+    const uint32_t ntot = n_dev ? *n_dev : n;
+    uint32_t cap_r = cap;
+    if (n_dev) cap_r = ((ntot + gridDim.x - 1) / gridDim.x + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
+    seg_r = (size_t)blockIdx.x * cap_r;
+    return seg_r < ntot ? (uint32_t)((ntot - seg_r) < cap_r ? (ntot - seg_r) : cap_r) : 0u;
+}
+
+template <int W, int SLOT>
+__global__ void __launch_bounds__(MIRGE_BLOCK, MIRGE_PASS_MIN_WAVES) MIRGE_PASS_ATTR
+k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __restrict__ plan, GroupView<W> g,
+       const uint32_t* __restrict__ act_in,
+       const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
+       uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
+       int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
+    __shared__ uint32_t s_count;
+    constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
+    __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? sizeof(LdsPlan) : 16];
+    LdsPlan* s_plan = reinterpret_cast<LdsPlan*>(s_plan_raw);
+    if (threadIdx.x == 0) s_count = 0;
+    if (LDSP) lds_plan_fill(*s_plan, lib, plan);
+    __syncthreads();
+    PlanSrc<LDSP> psrc;
+    psrc.g = plan; psrc.l = LDSP ? s_plan : nullptr;
+    const size_t seg = (size_t)blockIdx.x * cap;  // the workgroup's slice of the survivor arrays
+    size_t seg_r = seg;
+    const uint32_t n_in = act_in ? seg_n_in[blockIdx.x] : first_pass_share(g.n, n_dev, cap, seg_r);
+    pass_segment<W, LDSP, false>(lib, pol, mi, psrc, g, act_in, n_in, seg, seg_r, act_out, pass_id, res_pass, res_pos, res_mm, &s_count);
     __syncthreads();
     if (threadIdx.x == 0) seg_n_out[blockIdx.x] = s_count;
 }
@@ -432,6 +445,60 @@ __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint3
     off = (int32_t)(g - rs[lo]);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_cascade_bulk (round 3): ALL passes of the bulk read group in one launch.  A workgroup's segment and its survivor lists
+// are its own from the first pass to the last -- nothing ever crosses workgroups -- so the kernel boundaries between the
+// passes were barriers over the whole chip that nothing needed: every pass waited for its slowest workgroup, and the chip
+// was in ONE regime at a time (the merged pass waits on random sectors with its ALUs idle, the isomiR pass issues VALU and
+// cache accesses with the memory system idle).  Here a workgroup walks through the steps on its own; workgroups drift
+// apart and the regimes overlap.  Same device functions as k_pass: same answers.
+// ------------------------------------------------------------------------------------------
+struct FusedStep {
+    MirgeLibView lib;
+    MirgePolicy pol;
+    MergeInfo mi;
+    const MirgePlanTable* plan;
+    int32_t pass_id;
+};
+struct FusedSteps {
+    int32_t n;
+    FusedStep s[MIRGE_MAX_PASSES_K];
+};
+
+template <int W>
+__global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))  // 6 workgroups per CU must be resident (k_pass: 77 VGPRs)
+k_cascade_bulk(const FusedSteps* __restrict__ steps, GroupView<W> g, uint32_t* __restrict__ actA, uint32_t* __restrict__ actB,
+               uint32_t* __restrict__ seg_n, uint32_t cap, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
+               int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
+    __shared__ uint32_t s_count;
+    constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
+    __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? sizeof(LdsPlan) : 16];
+    LdsPlan* s_plan = reinterpret_cast<LdsPlan*>(s_plan_raw);
+    const int nsteps = steps->n;
+    const size_t seg = (size_t)blockIdx.x * cap;
+    size_t seg_r = seg;
+    uint32_t n_in = first_pass_share(g.n, n_dev, cap, seg_r);
+    const uint32_t* act_in = nullptr;
+    uint32_t* act_out = actA;
+    for (int si = 0; si < nsteps; si++) {
+        const FusedStep& st = steps->s[si];
+        if (threadIdx.x == 0) s_count = 0;
+        if (LDSP) lds_plan_fill(*s_plan, st.lib, st.plan);
+        __syncthreads();
+        PlanSrc<LDSP> psrc;
+        psrc.g = st.plan; psrc.l = LDSP ? s_plan : nullptr;
+        pass_segment<W, LDSP, true>(st.lib, st.pol, st.mi, psrc, g, act_in, n_in, seg, seg_r, act_out, st.pass_id, res_pass, res_pos, res_mm, &s_count);
+        __syncthreads();  // the survivors are written (and visible to this workgroup at L2), the plan is free again
+        n_in = s_count;
+        if (threadIdx.x == 0) seg_n[(size_t)si * gridDim.x + blockIdx.x] = n_in;
+        __syncthreads();  // everybody has read s_count before it is reset
+        act_in = act_out;
+        act_out = (act_out == actA) ? actB : actA;
+    }
+    // (k_resolve stays a launch of its own: done here, for the workgroup's own reads, it is a chain of dependent loads with
+    // four waves to hide it -- the kernel grew by 0.04 ms to save a 0.046 ms launch that the whole chip runs at once)
+}
+
 __global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, const uint32_t* __restrict__ res_pos,
                           uint32_t n, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off,
                           const uint32_t* __restrict__ n_dev) {
@@ -453,18 +520,6 @@ __global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, 
 // every step; a read that is annotated simply stops being eligible (no compaction: the group is small).
 // Same device functions as k_pass, so the same answers.
 // ------------------------------------------------------------------------------------------
-struct FusedStep {
-    MirgeLibView lib;
-    MirgePolicy pol;
-    MergeInfo mi;
-    const MirgePlanTable* plan;
-    int32_t pass_id;
-};
-struct FusedSteps {
-    int32_t n;
-    FusedStep s[MIRGE_MAX_PASSES_K];
-};
-
 template <int W>
 __global__ void __launch_bounds__(MIRGE_BLOCK)
 k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView<W> g, int8_t* __restrict__ res_pass,

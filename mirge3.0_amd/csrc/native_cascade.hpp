@@ -91,7 +91,7 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
 template <int W>
 static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const std::vector<PassStep>& steps,
                          const mirge_policy* pol, const ResolveTable& rt, const char* gtag,
-                         const uint32_t* n_dev = nullptr, uint32_t n_cap = 0) {
+                         const uint32_t* n_dev = nullptr, uint32_t n_cap = 0, const FusedSteps* dsteps = nullptr) {
     // n_dev != nullptr: the group's read count is not on the host yet (see k_pass); everything is sized for
     // n_cap >= the count, the caller fills out.n in later
     out.n = n_dev ? 0 : rg.n;
@@ -143,6 +143,19 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     int stage = 0;
     char name[32];
     std::vector<std::pair<int, int>> stage_of_pass;  // (profile record, stage) for unit accounting
+    // all passes in ONE launch (k_cascade_bulk): a workgroup's segment and survivor lists are its own through the whole
+    // cascade, so the launches between the passes were chip-wide barriers nothing needed.  MIRGE_BULK_FUSED=0: one launch
+    // per pass (A/B, per-pass profiles).
+    static const bool bulk_fused = !(std::getenv("MIRGE_BULK_FUSED") && std::atoi(std::getenv("MIRGE_BULK_FUSED")) == 0);
+    if (bulk_fused && dsteps && steps.size() > 1) {
+        std::snprintf(name, sizeof(name), "k_cascade_bulk%s", gtag);
+        LaunchScope ls(c, name, 0.0);
+        if (ls.rec >= 0)
+            for (size_t k = 0; k < steps.size(); k++) stage_of_pass.emplace_back(ls.rec, (int)k);  // units = reads handed to every pass
+        hipLaunchKernelGGL((k_cascade_bulk<W>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, v, actA, actB, seg_n, cap, out.pass, out.pos,
+                           out.mm, n_dev);
+        stage = (int)steps.size();
+    } else
     for (const PassStep& st : steps) {
         const int32_t p = st.p0;
         MirgePolicy mp;
@@ -358,7 +371,7 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
             MIRGE_BY_WIDTH(gi, rc, cascade_group_fused<W>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi)));
             continue;
         }
-        MIRGE_BY_WIDTH(gi, rc, cascade_group<W>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi)));
+        MIRGE_BY_WIDTH(gi, rc, cascade_group<W>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi), nullptr, 0, dsteps));
     }
     { int jr = stream_join(c); if (rc == 0) rc = jr; }
     return rc;
@@ -428,7 +441,7 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
         ReadGroup rg = partial->g[big];  // the unique reads' arrays, allocated for the raw count
         rg.n = raw->g[big].n;
         c->cur = c->stream;
-        const int rc = cascade_group<1>(c, rg, res->g[big], c->casc_steps, pol, c->casc_rt, group_tag(big), dmeta + big, raw->g[big].n);
+        const int rc = cascade_group<1>(c, rg, res->g[big], c->casc_steps, pol, c->casc_rt, group_tag(big), dmeta + big, raw->g[big].n, c->casc_dsteps);
         if (rc == 0) { hooked_group = big; c->overlap_mode = true; }
         return rc;
     };

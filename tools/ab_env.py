@@ -13,5 +13,5 @@ for r in range(rounds):
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         res[v].append(d["ms_per_step"])
         print(var, v, d["ms_per_step"], d["timing"]["step_ms_rank0"]["median"],
-              {k[6:]: round(x["avg_ms"], 3) for k, x in d["kernels"].items() if k.endswith(".w1") and "pass" in k}, flush=True)
+              {k[6:]: round(x["avg_ms"], 3) for k, x in d["kernels"].items() if k.endswith(".w1") and ("pass" in k or "cascade" in k)}, flush=True)
 print({k: (min(v), sorted(v)[len(v) // 2]) for k, v in res.items()})
