@@ -532,7 +532,10 @@ def main():
             "algorithmic_bytes_per_unit": algo_bytes(dom), "units_per_launch": round(kd["units_per_launch"], 1),
             "avg_launch_ms": round(kd["avg_ms"], 5), "launches": kd["launches"],
             "note": "latency / random-sector-bound integer kernel; HBM fraction reported as the brief requires; "
-                    "timed with HIP events on its launch stream inside the timed region",
+                    "timed with HIP events on its launch stream inside the timed region"
+                    + ("; k_cascade_bulk = ALL passes of the bulk read group in one launch: a unit is a read handed to a pass "
+                       "(k_pass's 18 B), units_per_launch their sum over the passes (per-workgroup survivor counters); "
+                       "MIRGE_BULK_FUSED=0 gives one launch per pass again" if dom.startswith("k_cascade_bulk") else ""),
         },
         "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5),
                         "units_per_launch": round(v["units_per_launch"], 1)} for k, v in sorted(kernels.items())},
