@@ -466,7 +466,7 @@ struct FusedSteps {
 };
 
 template <int W>
-__global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8)))  // 6 workgroups per CU must be resident (k_pass: 77 VGPRs)
+__global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(W == 1 ? 6 : 1, 8)))  // one-word reads: 6 workgroups per CU must be resident (80 VGPRs; k_pass: 77); wider reads keep their registers
 k_cascade_bulk(const FusedSteps* __restrict__ steps, GroupView<W> g, uint32_t* __restrict__ actA, uint32_t* __restrict__ actB,
                uint32_t* __restrict__ seg_n, uint32_t cap, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
                int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {

@@ -1082,17 +1082,19 @@ def test_collapse_count_matrix_beyond_2_to_32_cells(ctx):
     raw.close()
 
 
-def test_staged_cascade_for_every_group():
-    """Small read groups normally take k_cascade_fused (one launch for the whole cascade); MIRGE_FUSED_MAX=0
-    sends every group through the staged per-pass kernels instead.  Both must agree with the oracle: the oracle
-    parity tests of this file and the cascade fuzz are re-run in a fresh process with the hook set."""
+@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0")])
+def test_staged_cascade_for_every_group(hooks):
+    """Small read groups normally take k_cascade_fused (one launch for the whole cascade, no compaction); MIRGE_FUSED_MAX=0
+    sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch), or
+    with MIRGE_BULK_FUSED=0 one k_pass launch per pass.  All must agree with the oracle: the oracle parity tests of this
+    file and the cascade fuzz are re-run in a fresh process with the hooks set."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
                         os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k",
                         "vs_oracle or vs_bruteforce or low_complexity or edge_cases or golden_cascade or random_cascade"],
-                       env=dict(os.environ, MIRGE_FUSED_MAX="0"), capture_output=True, text=True, timeout=1500, cwd=root)
+                       env=dict(os.environ, **hooks), capture_output=True, text=True, timeout=1500, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
