@@ -363,11 +363,20 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
     int order[MIRGE_NGROUPS], no = 0;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) if (gi != big) order[no++] = gi;
     order[no++] = big;
+    // every small group's one-launch cascade on a stream of its own, behind whatever `aux` still holds for them
+    static const bool xaux_on = !(std::getenv("MIRGE_XAUX") && std::atoi(std::getenv("MIRGE_XAUX")) == 0);
+    int n_small = 0;
+    for (int k = 0; k < MIRGE_NGROUPS; k++)
+        if (order[k] != skip && order[k] != big && R->g[order[k]].n && R->g[order[k]].n <= fused_max) n_small++;
+    const bool spread = xaux_on && n_small > 1;
+    if (spread) CHECK(xaux_fork(c));
+    int slot = 0;
     for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
         const int gi = order[k];
         if (gi == skip) continue;
         c->cur = gi == big ? c->stream : c->aux;
         if (gi != big && R->g[gi].n <= fused_max) {
+            if (spread && R->g[gi].n) c->cur = c->xaux[slot++ % MIRGE_N_XAUX];
             MIRGE_BY_WIDTH(gi, rc, cascade_group_fused<W>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi)));
             continue;
         }

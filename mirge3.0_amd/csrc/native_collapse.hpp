@@ -304,6 +304,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
             c->cur = gi == big ? c->stream : c->aux;
             MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage, dweight));
+            if (k < 0) hc.lap("first kernel of the bulk group enqueued");
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }
         hc.lap("enqueue A");

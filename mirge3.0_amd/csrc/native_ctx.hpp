@@ -55,6 +55,13 @@ struct mirge_ctx {
     // cur = the stream the launch helpers currently target.
     hipStream_t aux = nullptr, cur = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_meta = nullptr;
+    // the small read groups' one-launch cascades each on a stream of their own (round 3): with the bulk group's passes in one
+    // launch they only get the chip when its workgroups retire, and on ONE stream three of them then ran one after the other
+    // (56 + 69 + 49 us behind the bulk kernel, with the join waiting); side by side they take what the longest takes
+#define MIRGE_N_XAUX 3
+    hipStream_t xaux[MIRGE_N_XAUX] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_xfork = nullptr, ev_xjoin[MIRGE_N_XAUX] = {nullptr, nullptr, nullptr};
+    bool xaux_used = false;
     // mirge_collapse_cascade: the bulk group's cascade is already queued on the main stream while the small groups'
     // collapse tail and cascades are still being enqueued on the second one.  They do not depend on it: no fork
     // wait (it would serialise them behind ~1.3 ms of kernels), and no pool block goes back into circulation
@@ -193,10 +200,24 @@ static int stream_fork(mirge_ctx* c) {
     HIPOK(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
     return 0;
 }
+// the extra streams take over from `aux` (whatever was queued there -- the small groups' collapse tail -- comes first)
+static int xaux_fork(mirge_ctx* c) {
+    HIPOK(hipEventRecord(c->ev_xfork, c->aux));
+    for (int k = 0; k < MIRGE_N_XAUX; k++) HIPOK(hipStreamWaitEvent(c->xaux[k], c->ev_xfork, 0));
+    c->xaux_used = true;
+    return 0;
+}
 static int stream_join(mirge_ctx* c) {
     c->cur = c->stream;
     hipError_t e = hipEventRecord(c->ev_join, c->aux);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (c->xaux_used) {
+        for (int k = 0; k < MIRGE_N_XAUX && e == hipSuccess; k++) {
+            e = hipEventRecord(c->ev_xjoin[k], c->xaux[k]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xjoin[k], 0);
+        }
+        c->xaux_used = false;
+    }
     c->flush_deferred();  // reused only by work queued on the main stream after the wait
     if (e != hipSuccess) return fail(-2, std::string("stream join: ") + hipGetErrorString(e));
     return 0;
@@ -252,6 +273,11 @@ extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
     else { HIPOK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->cur = c->stream;
     HIPOK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    for (int k = 0; k < MIRGE_N_XAUX; k++) {
+        HIPOK(hipStreamCreateWithFlags(&c->xaux[k], hipStreamNonBlocking));
+        HIPOK(hipEventCreateWithFlags(&c->ev_xjoin[k], hipEventDisableTiming));
+    }
+    HIPOK(hipEventCreateWithFlags(&c->ev_xfork, hipEventDisableTiming));
     HIPOK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPOK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPOK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
@@ -286,6 +312,11 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    for (int k = 0; k < MIRGE_N_XAUX; k++) {
+        if (c->xaux[k]) (void)hipStreamDestroy(c->xaux[k]);
+        if (c->ev_xjoin[k]) (void)hipEventDestroy(c->ev_xjoin[k]);
+    }
+    if (c->ev_xfork) (void)hipEventDestroy(c->ev_xfork);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

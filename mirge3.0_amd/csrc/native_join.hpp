@@ -5,6 +5,7 @@
 // ------------------------------------------------------------------------------------------
 extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, int32_t exact_pass,
                                 int32_t iso_pass, int64_t n_mirna, int64_t* class_sums, int64_t* exact, int64_t* iso) {
+    HostClock hc("count_join");
     if (!c || !U || !res || !class_sums || !exact || !iso || n_mirna < 0) return fail(-1, "mirge_count_join: bad argument");
     if (U->n_samples < 1) return fail(-1, "read set has no count matrix (collapse it or mirge_reads_set_counts)");
     if (res->n != U->n) return fail(-1, "result and read set differ in size");
@@ -60,7 +61,9 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     HIPOK(hipEventRecord(c->ev_meta, c->stream));
     // cleared for the next call now, behind the copy: the host waits for the copy only
     const bool cleared = hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream) == hipSuccess;
+    hc.lap("enqueue");
     HIPOK(hipEventSynchronize(c->ev_meta));
+    hc.lap("wait for the tables");
     c->join_dev_clean = cleared;
     c->release(partial);
     std::memcpy(class_sums, c->join_pinned, n_cls * 8);
@@ -69,6 +72,7 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
         std::memcpy(iso, c->join_pinned + n_cls + n_tab, (size_t)n_mirna * S * 8);
     }
     c->drain();
+    hc.lap("copy out + drain");
     return 0;
 }
 
