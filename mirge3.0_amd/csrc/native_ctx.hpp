@@ -209,15 +209,18 @@ static int xaux_fork(mirge_ctx* c) {
 }
 static int stream_join(mirge_ctx* c) {
     c->cur = c->stream;
-    hipError_t e = hipEventRecord(c->ev_join, c->aux);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    hipError_t e = hipSuccess;
     if (c->xaux_used) {
+        // `aux` collects the extra streams (its queue is idle by then), the main stream waits for `aux` alone: every wait is a
+        // barrier packet the main queue works through one after the other (four of them: 27 us between k_resolve and k_join)
         for (int k = 0; k < MIRGE_N_XAUX && e == hipSuccess; k++) {
             e = hipEventRecord(c->ev_xjoin[k], c->xaux[k]);
-            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xjoin[k], 0);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_xjoin[k], 0);
         }
         c->xaux_used = false;
     }
+    if (e == hipSuccess) e = hipEventRecord(c->ev_join, c->aux);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
     c->flush_deferred();  // reused only by work queued on the main stream after the wait
     if (e != hipSuccess) return fail(-2, std::string("stream join: ") + hipGetErrorString(e));
     return 0;

@@ -17,6 +17,7 @@ PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 cd /tmp && export TMPDIR=/tmp
 BENCH="$PY $REPO/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --pmc 0 --min-seconds 0.1 --spinup 0.1 ${BENCH_ARGS:-}"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/bench_kt.json" 2> "$OUT/kt.err"
+if [ -n "${KT_ONLY:-}" ]; then exit 0; fi
 i=0
 for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" \
             "SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM_RD SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
