@@ -414,14 +414,19 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
     if (threadIdx.x == 0) seg_n_out[blockIdx.x] = s_count;
 }
 
-// global position -> (reference index, offset) by binary search in ref_start of the pass's library
-// coarse[b] = last reference that starts at or before position b << MIRGE_COARSE_SHIFT: the reference of a position in
-// block b lies in [coarse[b], coarse[b + 1]], two or three candidates instead of a 12-17-step search through ref_start
-// (k_resolve spent 3 lane-level cache accesses per read on it: profiles/r02_mem_counters.txt)
-#define MIRGE_COARSE_SHIFT 6
+// global position -> (reference index, offset).  One 8-byte entry per granule of 16 positions answers it with ONE access:
+//   word 0 = (last reference that starts at or before the granule's first position) << 5 | code
+//   word 1 = that reference's start
+//   code   = 1..15: exactly one other reference starts inside the granule, at that offset;  16: none;  17: several (only
+//            references shorter than 16 nt, or empty ones, do that) -> a search through ref_start from word 0's reference on
+// Round 2 had a reference index per 64 positions and then two or three probes of ref_start plus the start itself: four or
+// five lane-level cache accesses per read, each a separate line -- k_resolve ran at the rate the texture path takes lines
+// (60 us per 4.2 M reads; four reads per thread in flight changed nothing, so it was not latency).  0.5 B per reference
+// position of device memory (T and the probe tables take ~10).
+#define MIRGE_COARSE_SHIFT 4
 struct ResolveTable {
     const uint32_t* ref_start[MIRGE_MAX_PASSES_K];
-    const uint32_t* coarse[MIRGE_MAX_PASSES_K];
+    const uint32_t* coarse[MIRGE_MAX_PASSES_K];  // [granules][2]
     uint32_t n_refs[MIRGE_MAX_PASSES_K];
 };
 
@@ -432,17 +437,22 @@ __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint3
 #pragma unroll
     for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
         if (q == p) { rs = tb.ref_start[q]; cs = tb.coarse[q]; nr = tb.n_refs[q]; }
-    uint32_t lo = 0, hi = nr;  // last t with rs[t] <= g
-    if (cs) {
-        const PairU32 c = load_pair32((gptr_u32)cs + (g >> MIRGE_COARSE_SHIFT));
-        lo = c.a; hi = c.b + 1;
-    }
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (rs[mid] <= g) lo = mid; else hi = mid;
+    const PairU32 c = load_pair32((gptr_u32)cs + 2 * (size_t)(g >> MIRGE_COARSE_SHIFT));
+    uint32_t lo = c.a >> 5, base = c.b;
+    const uint32_t code = c.a & 31u;
+    if (code < 16u) {
+        const uint32_t bpos = ((g >> MIRGE_COARSE_SHIFT) << MIRGE_COARSE_SHIFT) + code;
+        if (g >= bpos) { lo++; base = bpos; }
+    } else if (code == 17u) {
+        uint32_t hi = nr;  // last t with rs[t] <= g
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (rs[mid] <= g) lo = mid; else hi = mid;
+        }
+        base = rs[lo];
     }
     ref = (int32_t)lo;
-    off = (int32_t)(g - rs[lo]);
+    off = (int32_t)(g - base);
 }
 
 // ------------------------------------------------------------------------------------------

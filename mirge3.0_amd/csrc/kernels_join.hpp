@@ -37,6 +37,52 @@ __global__ void k_join(const int8_t* __restrict__ res_pass, const int32_t* __res
     }
 }
 
+// the small read groups of a result in ONE launch (each its own launch was 4-5 us of a step's tail, four times)
+struct JoinGroups {
+    const int8_t* pass[MIRGE_NCLS];
+    const int32_t* ref[MIRGE_NCLS];
+    const uint32_t* counts[MIRGE_NCLS];
+    uint32_t start[MIRGE_NCLS + 1];  // group k holds the items [start[k], start[k + 1]) of the launch
+    int32_t n_groups;
+};
+__global__ void k_join_multi(JoinGroups gs, int32_t S, int32_t n_pass, int32_t exact_pass, int32_t iso_pass,
+                             unsigned long long* __restrict__ class_sums, unsigned long long* __restrict__ exact,
+                             unsigned long long* __restrict__ iso) {
+    __shared__ unsigned long long acc[MIRGE_JOIN_LDS];
+    const int cells = n_pass * S;
+    const bool use_lds = cells <= MIRGE_JOIN_LDS;
+    if (use_lds) {
+        for (int c = threadIdx.x; c < cells; c += blockDim.x) acc[c] = 0ull;
+        __syncthreads();
+    }
+    const uint32_t total = gs.start[gs.n_groups];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < MIRGE_NCLS; q++) if (q < gs.n_groups && t >= gs.start[q]) k = q;
+        const uint32_t i = t - gs.start[k];
+        const int8_t* gp = nullptr; const int32_t* gr = nullptr; const uint32_t* gc = nullptr;
+#pragma unroll
+        for (int q = 0; q < MIRGE_NCLS; q++) if (q == k) { gp = gs.pass[q]; gr = gs.ref[q]; gc = gs.counts[q]; }
+        const int p = gp[i];
+        if (p < 0) continue;
+        const int32_t ref = gr[i];
+        for (int32_t s = 0; s < S; s++) {
+            const unsigned long long c = gc[(size_t)i * S + s];
+            if (!c) continue;
+            if (use_lds) atomicAdd(&acc[p * S + s], c);
+            else atomicAdd(&class_sums[p * S + s], c);
+            if (p == exact_pass) atomicAdd(&exact[(size_t)ref * S + s], c);
+            else if (p == iso_pass) atomicAdd(&iso[(size_t)ref * S + s], c);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int c = threadIdx.x; c < cells; c += blockDim.x)
+            if (acc[c]) atomicAdd(&class_sums[c], acc[c]);
+    }
+}
+
 // k_join_rows / k_join_reduce (round 3): the same sums without a global atomic per read.  k_join's exact / isomiR tables take
 // one device-scope atomic per miRNA read -- 2.5 M of them on 2.9 k hot addresses for a 10 M-read sample, 74 us at the
 // chip's ~20-30 G scattered atomics/s: the last kernel of the step and 5 % of it.  Here a 1024-thread workgroup keeps ALL

@@ -29,12 +29,34 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     if (!c->join_dev_clean) HIPOK(hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream));
     c->join_dev_clean = false;
     unsigned long long* partial = nullptr;
+    // a big group whose tables fit LDS: per-workgroup tables in LDS, rows out, column sums (no global atomic per read); the
+    // other groups together in one launch with atomics (they are small: a launch each was most of what they cost)
+    static const bool rows_off = std::getenv("MIRGE_JOIN_ROWS") && std::atoi(std::getenv("MIRGE_JOIN_ROWS")) == 0;  // A/B
+    auto by_rows = [&](const ResGroup& g) { return !rows_off && g.n >= (1u << 20) && words <= MIRGE_JOIN_ROWS_CELLS && n_mirna * (int64_t)S < 0x7FFFFFFF; };
+    {
+        JoinGroups gs;
+        std::memset(&gs, 0, sizeof(gs));
+        uint64_t total = 0;
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+            const ResGroup& g = res->g[gi];
+            if (!g.n || by_rows(g)) continue;
+            gs.pass[gs.n_groups] = g.pass; gs.ref[gs.n_groups] = g.ref; gs.counts[gs.n_groups] = U->g[gi].counts;
+            gs.start[gs.n_groups++] = (uint32_t)total;
+            total += g.n;
+        }
+        if (gs.n_groups && total < 0xFFFFFFF0ull) {
+            gs.start[gs.n_groups] = (uint32_t)total;
+            LaunchScope ls(c, "k_join", (double)total);
+            hipLaunchKernelGGL(k_join_multi, dim3(grid_for(c, (size_t)total)), dim3(MIRGE_BLOCK), 0, c->stream, gs, S, P, exact_pass, iso_pass,
+                               d, d + n_cls, d + n_cls + n_tab);
+        } else if (gs.n_groups) {
+            return fail(-5, "mirge_count_join: more than 2^32 reads outside the bulk group");
+        }
+    }
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
-        if (!g.n) continue;
-        // a big group whose tables fit LDS: per-workgroup tables in LDS, rows out, column sums (no global atomic per read)
-        static const bool rows_off = std::getenv("MIRGE_JOIN_ROWS") && std::atoi(std::getenv("MIRGE_JOIN_ROWS")) == 0;  // A/B
-        if (!rows_off && g.n >= 65536 && words <= MIRGE_JOIN_ROWS_CELLS && n_mirna * (int64_t)S < 0x7FFFFFFF) {
+        if (!g.n || !by_rows(g)) continue;
+        {
             const uint32_t rows = (uint32_t)std::min<size_t>((size_t)c->n_cu, (g.n + 4095) / 4096);
             if (!partial) CHECK(dalloc(c, &partial, (size_t)c->n_cu * words));
             {
@@ -44,11 +66,7 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
             }
             LaunchScope ls(c, "k_join_reduce", (double)words);
             hipLaunchKernelGGL(k_join_reduce, dim3((unsigned)((words + 63) / 64)), dim3(1024), 0, c->stream, partial, rows, (uint32_t)words, d);
-            continue;
         }
-        LaunchScope ls(c, "k_join", g.n);
-        hipLaunchKernelGGL(k_join, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, g.pass, g.ref,
-                           U->g[gi].counts, g.n, S, P, exact_pass, iso_pass, d, d + n_cls, d + n_cls + n_tab);
     }
     // one device-to-host copy through pinned memory for all three tables (they are contiguous)
     if (words * 8 > c->join_pinned_bytes) {

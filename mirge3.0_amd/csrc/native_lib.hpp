@@ -13,7 +13,7 @@ struct mirge_lib {
     uint64_t* dT = nullptr;
     uint64_t* dinv = nullptr;
     uint32_t* dref_start = nullptr;
-    uint32_t* dcoarse = nullptr;               // [(total >> MIRGE_COARSE_SHIFT) + 2]: see ResolveTable
+    uint32_t* dcoarse = nullptr;               // [(total >> MIRGE_COARSE_SHIFT) + 2][2]: see ResolveTable
     MirgeKTable* dtables = nullptr;           // [MIRGE_SHAPE_SLOTS] on the device
     std::vector<MirgeKTable> htables;          // host mirror (device pointers), by mirge_shape_id
     size_t device_bytes = 0;
@@ -92,13 +92,20 @@ static int lib_upload(mirge_ctx* c, std::unique_ptr<mirge_lib>& L, int64_t n_ref
     HIPOK(hipMemcpy(L->dref_start, L->h.ref_start.data(), nR, hipMemcpyHostToDevice));
     HIPOK(hipMemcpy(L->dtables, L->htables.data(), sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS, hipMemcpyHostToDevice));
     size_t nC = 0;
-    if (n_refs > 0) {  // coarse[b] = last reference starting at or before b << MIRGE_COARSE_SHIFT
-        std::vector<uint32_t> coarse((size_t)(L->h.total >> MIRGE_COARSE_SHIFT) + 2);
+    if (n_refs > 0) {  // the granule table of ResolveTable (kernels_cascade.hpp)
+        const size_t n_gran = (size_t)(L->h.total >> MIRGE_COARSE_SHIFT) + 2;
+        if ((uint64_t)n_refs >= (1ull << 27)) return fail(-1, "mirge_lib_create: more than 2^27 references");
+        std::vector<uint32_t> coarse(2 * n_gran);
+        const std::vector<uint32_t>& rs = L->h.ref_start;
         uint32_t t = 0;
-        for (size_t b = 0; b < coarse.size(); b++) {
-            const uint64_t x = (uint64_t)b << MIRGE_COARSE_SHIFT;
-            while ((int64_t)t + 1 < n_refs && L->h.ref_start[(size_t)t + 1] <= x) t++;
-            coarse[b] = t;
+        for (size_t b = 0; b < n_gran; b++) {
+            const uint64_t x = (uint64_t)b << MIRGE_COARSE_SHIFT, xe = x + (1ull << MIRGE_COARSE_SHIFT);
+            while ((int64_t)t + 1 < n_refs && rs[(size_t)t + 1] <= x) t++;
+            uint32_t inside = 0;  // references that start in (x, xe)
+            while ((int64_t)t + 1 + inside < n_refs && rs[(size_t)t + 1 + inside] < xe) inside++;
+            const uint32_t code = inside == 0 ? 16u : inside == 1 ? (uint32_t)(rs[(size_t)t + 1] - x) : 17u;
+            coarse[2 * b] = t << 5 | code;
+            coarse[2 * b + 1] = rs[t];
         }
         nC = coarse.size() * 4;
         HIPOK(hipMalloc((void**)&L->dcoarse, nC));

@@ -292,6 +292,32 @@ def test_low_complexity_libraries(ctx):
     casc.close()
 
 
+def test_references_shorter_than_a_resolve_granule(ctx):
+    """Position -> (reference, offset) reads one entry per 16 positions (ResolveTable); references of 0-15 nt between
+    the real ones put several starts into a granule -- the entry's search branch -- and a start on every offset of one."""
+    from mirge3_amd.seqio import Library
+    rng = np.random.default_rng(77)
+    sl = synth.make_libraries(seed=33, scale="tiny")
+    libs = dict(sl.libs)
+    for key in ("mirna", "hairpin", "mature_trna", "mrna"):
+        lib = libs[key]
+        names, seqs = [], []
+        for i, (nm, sq) in enumerate(zip(lib.names, lib.seqs.to_list())):
+            for k in range(int(rng.integers(0, 4))):
+                names.append(f"tiny{key}{i}_{k}")
+                seqs.append("".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(0, 16)))))
+            names.append(nm)
+            seqs.append(sq)
+        libs[key] = Library(names, FlatSeqs.from_list(seqs))
+    reads = synth.make_reads(sl, 6000, seed=5, n_frac=0.02)
+    casc = Cascade(ctx, libs)
+    g = casc.annotate(reads)
+    o = oracle.cascade(reads.data, reads.offsets, oracle_libs_from(libs), n_pass=9, indexed=False)
+    _assert_same(o, g)
+    assert (g[0] >= 0).mean() > 0.5
+    casc.close()
+
+
 def test_cascade_vs_bruteforce_oracle(ctx, ci_libs, ci_cascade):
     reads = synth.make_reads(ci_libs, 3000, seed=17, n_frac=0.03)
     g = ci_cascade.annotate(reads)
