@@ -429,6 +429,9 @@ def main():
     # timed region: only the dominant kernel stays bracketed (two events per launch; bracketing
     # all ~90 launches of a step costs ~0.4 ms of a ~3 ms step)
     ctx.profile_only(dom.split(".")[0] + "." if "." in dom else dom)
+    # ... and its units (reads handed to every pass) are those of the profiled warm-up steps -- the same batch: reading the
+    # survivor counters back is a device-to-host copy between k_resolve and the join in every step (~10 us of queue gap)
+    ctx.profile_units(False)
 
     def max_over_ranks(x):
         if dist is None:
@@ -474,6 +477,7 @@ def main():
     recs = ctx.profile_records()
     ctx.profile(False)
     ctx.profile_only("")
+    ctx.profile_units(True)
     ms_per_step = elapsed / timed_steps * 1e3
     value = n_gpus * args.reads / (elapsed / timed_steps) / 1e6
     per_region_ms = sorted(r / args.steps * 1e3 for r in region_s)
@@ -484,7 +488,9 @@ def main():
     # roofline numbers come from the HIP events recorded inside the timed region
     kernels = table
     timed = {name: dict(launches=l, avg_ms=ms / l, total_ms=ms, units_per_launch=u / l) for name, l, ms, u in recs if l}
-    kd = timed.get(dom) or table[dom]
+    kd = dict(timed.get(dom) or table[dom])
+    if not kd["units_per_launch"]:
+        kd["units_per_launch"] = table[dom]["units_per_launch"]
     achieved = algo_bytes(dom) * kd["units_per_launch"] / (kd["avg_ms"] * 1e-3) / 1e9
     n_tab_steps = n_prof
     stage_ms = {
@@ -534,7 +540,8 @@ def main():
             "note": "latency / random-sector-bound integer kernel; HBM fraction reported as the brief requires; "
                     "timed with HIP events on its launch stream inside the timed region"
                     + ("; k_cascade_bulk = ALL passes of the bulk read group in one launch: a unit is a read handed to a pass "
-                       "(k_pass's 18 B), units_per_launch their sum over the passes (per-workgroup survivor counters); "
+                       "(k_pass's 18 B), units_per_launch their sum over the passes (per-workgroup survivor counters, read back in the bracketed "
+                       "warm-up steps of the same batch: in the timed region only the kernel's duration is measured); "
                        "MIRGE_BULK_FUSED=0 gives one launch per pass again" if dom.startswith("k_cascade_bulk") else ""),
         },
         "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5),

@@ -276,6 +276,10 @@ int mirge_ctx_timer_stop(mirge_ctx* ctx, double* ms_out);
 int mirge_ctx_profile_enable(mirge_ctx* ctx, int32_t on);
 /* record only launches whose name contains `substr` (NULL or "" = every launch) */
 int mirge_ctx_profile_only(mirge_ctx* ctx, const char* substr);
+/* on = 0: the bracketed cascade launches are timed but the reads handed to each pass (their "units") are no longer read
+ * back -- a device-to-host copy per call on the critical path (bench.py's timed region: the units of the same batch are
+ * known from its profiled warm-up steps) */
+int mirge_ctx_profile_units(mirge_ctx* ctx, int32_t on);
 int mirge_ctx_profile_reset(mirge_ctx* ctx);
 int32_t mirge_ctx_profile_count(mirge_ctx* ctx);
 int mirge_ctx_profile_get(mirge_ctx* ctx, int32_t i, char* name_out, int32_t name_cap,

@@ -26,7 +26,7 @@ EXPORTS = [
     "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
-    "mirge_ctx_profile_only", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
+    "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
 
@@ -181,6 +181,10 @@ class Context:
     def profile_only(self, substr: str = ""):
         """bracket only the launches whose name contains ``substr`` ('' = all)"""
         _check(load().mirge_ctx_profile_only(self._h, substr.encode()), "profile_only")
+
+    def profile_units(self, on: bool):
+        """False: bracketed cascade launches are timed, their per-pass read counts are not copied back any more"""
+        _check(load().mirge_ctx_profile_units(self._h, C.c_int32(1 if on else 0)), "profile_units")
 
     def profile_reset(self):
         _check(load().mirge_ctx_profile_reset(self._h), "profile_reset")

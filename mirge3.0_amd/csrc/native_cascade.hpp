@@ -194,7 +194,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         LaunchScope ls(c, name, n);
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->cur, rt, out.pass, out.pos, n, out.ref, out.off, n_dev);
     }
-    if (c->profiling && stage > 0) {  // units of a pass = reads it was handed = survivors of the stage before
+    if (c->profiling && c->prof_units && stage > 0 && !stage_of_pass.empty()) {  // units of a pass = reads it was handed = survivors of the stage before
         // copied now (stream-ordered), summed after the one synchronisation at the end of the call
         const size_t words = (size_t)grid * stage;
         if (c->prof_used + words <= MIRGE_PROF_PINNED_WORDS) {
@@ -362,6 +362,8 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
     // small kernels squeeze in between them, stretching single passes of the bulk group by 30 %
     int order[MIRGE_NGROUPS], no = 0;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) if (gi != big) order[no++] = gi;
+    // the largest small group first: it gets extra stream 0, the one the main stream waits for directly (stream_join)
+    std::stable_sort(order, order + no, [&](int a, int b) { return R->g[a].n > R->g[b].n; });
     order[no++] = big;
     // every small group's one-launch cascade on a stream of its own, behind whatever `aux` still holds for them
     static const bool xaux_on = !(std::getenv("MIRGE_XAUX") && std::atoi(std::getenv("MIRGE_XAUX")) == 0);

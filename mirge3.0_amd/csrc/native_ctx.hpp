@@ -74,6 +74,7 @@ struct mirge_ctx {
     size_t pool_bytes = 0;
     // profiler
     bool profiling = false;
+    bool prof_units = true;  // read the cascade's per-pass survivor counts back (mirge_ctx_profile_units)
     std::string prof_only;  // non-empty: only launches whose name contains it are bracketed
     std::vector<ProfRec> recs;
     std::unordered_map<std::string, int> rec_of;
@@ -210,10 +211,14 @@ static int xaux_fork(mirge_ctx* c) {
 static int stream_join(mirge_ctx* c) {
     c->cur = c->stream;
     hipError_t e = hipSuccess;
-    if (c->xaux_used) {
-        // `aux` collects the extra streams (its queue is idle by then), the main stream waits for `aux` alone: every wait is a
-        // barrier packet the main queue works through one after the other (four of them: 27 us between k_resolve and k_join)
-        for (int k = 0; k < MIRGE_N_XAUX && e == hipSuccess; k++) {
+    const bool x = c->xaux_used;
+    if (x) {
+        // Every wait is a barrier packet its queue works through in order (~7 us each even when already satisfied), and a wait
+        // that is NOT yet satisfied costs a queue-to-queue hop (~15 us) once it is.  `aux` (idle by then) collects the extra
+        // streams 1.. early; the main stream waits for `aux` and then, directly, for extra stream 0 -- the one the largest
+        // small group runs on, the last to finish (one hop behind it; collected by `aux` too it was two: 35 us between the
+        // end of that group's cascade and k_join, profiles/r03_timeline.txt)
+        for (int k = 1; k < MIRGE_N_XAUX && e == hipSuccess; k++) {
             e = hipEventRecord(c->ev_xjoin[k], c->xaux[k]);
             if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_xjoin[k], 0);
         }
@@ -221,6 +226,10 @@ static int stream_join(mirge_ctx* c) {
     }
     if (e == hipSuccess) e = hipEventRecord(c->ev_join, c->aux);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (x && e == hipSuccess) {
+        e = hipEventRecord(c->ev_xjoin[0], c->xaux[0]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xjoin[0], 0);
+    }
     c->flush_deferred();  // reused only by work queued on the main stream after the wait
     if (e != hipSuccess) return fail(-2, std::string("stream join: ") + hipGetErrorString(e));
     return 0;
@@ -354,6 +363,11 @@ extern "C" int mirge_ctx_profile_enable(mirge_ctx* c, int32_t on) {
 extern "C" int mirge_ctx_profile_only(mirge_ctx* c, const char* substr) {
     if (!c) return fail(-1, "ctx is NULL");
     c->prof_only = substr ? substr : "";
+    return 0;
+}
+extern "C" int mirge_ctx_profile_units(mirge_ctx* c, int32_t on) {
+    if (!c) return fail(-1, "ctx is NULL");
+    c->prof_units = on != 0;
     return 0;
 }
 extern "C" int mirge_ctx_profile_reset(mirge_ctx* c) {
