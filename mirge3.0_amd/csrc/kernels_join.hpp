@@ -92,19 +92,26 @@ __global__ void k_join_multi(JoinGroups gs, int32_t S, int32_t n_pass, int32_t e
 #define MIRGE_JOIN_ROWS_THREADS 1024
 #define MIRGE_JOIN_ROWS_CELLS 6144  // 64-bit LDS cells
 __global__ void __launch_bounds__(MIRGE_JOIN_ROWS_THREADS)
-k_join_rows(const int8_t* __restrict__ res_pass, const int32_t* __restrict__ res_ref, const uint32_t* __restrict__ counts,
-            uint32_t n, int32_t S, int32_t n_pass, int32_t exact_pass, int32_t iso_pass, uint32_t n_tab,
+k_join_rows(JoinGroups gs, int32_t S, int32_t n_pass, int32_t exact_pass, int32_t iso_pass, uint32_t n_tab,
             unsigned long long* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long j_acc[];  // [n_pass * S] | [n_tab] exact | [n_tab] iso
     const uint32_t n_cls = (uint32_t)(n_pass * S), W = n_cls + 2 * n_tab;
     for (uint32_t c = threadIdx.x; c < W; c += blockDim.x) j_acc[c] = 0ull;
     __syncthreads();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int p = res_pass[i];
+    const uint32_t total = gs.start[gs.n_groups];
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        int k = 0;  // one group (the bulk) or the few small ones, back to back
+#pragma unroll
+        for (int q = 1; q < MIRGE_NCLS; q++) if (q < gs.n_groups && t >= gs.start[q]) k = q;
+        const int8_t* gp = gs.pass[0]; const int32_t* gr = gs.ref[0]; const uint32_t* gc = gs.counts[0];
+#pragma unroll
+        for (int q = 1; q < MIRGE_NCLS; q++) if (q == k) { gp = gs.pass[q]; gr = gs.ref[q]; gc = gs.counts[q]; }
+        const uint32_t i = t - gs.start[k];
+        const int p = gp[i];
         if (p < 0) continue;
-        const uint32_t ref = (uint32_t)res_ref[i];
+        const uint32_t ref = (uint32_t)gr[i];
         for (int32_t s = 0; s < S; s++) {
-            const unsigned long long c = counts[(size_t)i * S + s];
+            const unsigned long long c = gc[(size_t)i * S + s];
             if (!c) continue;
             atomicAdd(&j_acc[p * S + s], c);
             if (p == exact_pass) atomicAdd(&j_acc[n_cls + (size_t)ref * S + s], c);

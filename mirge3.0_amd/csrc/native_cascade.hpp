@@ -23,6 +23,7 @@ struct mirge_result {
 
 extern "C" void mirge_result_destroy(mirge_result* r) {
     if (!r) return;
+    (void)join_pending_now(r->ctx);  // the side streams may still be writing what goes back to the pool here
     for (auto& g : r->g) {
         r->ctx->release(g.pass); r->ctx->release(g.pos); r->ctx->release(g.mm);
         r->ctx->release(g.ref); r->ctx->release(g.off);
@@ -384,7 +385,11 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
         }
         MIRGE_BY_WIDTH(gi, rc, cascade_group<W>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi), nullptr, 0, dsteps));
     }
-    { int jr = stream_join(c); if (rc == 0) rc = jr; }
+    // no join here: the next entry point that needs one makes it (join_pending_now); mirge_count_join puts the bulk
+    // group's part of its work in front of it
+    c->cur = c->stream;
+    if (rc == 0) c->join_pending = true;
+    else { int jr = stream_join(c); (void)jr; }
     return rc;
 }
 
@@ -393,7 +398,7 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     HostClock hc("cascade");
     if (!c || !R || !libs || !pol || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
         return fail(-1, "mirge_cascade_run: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     // read lengths present (host histogram from pack; a collapse result asks the device once)
     int32_t hist[MIRGE_MAX_READ_LEN + 1];
     if (R->hist_valid) std::memcpy(hist, R->len_hist, sizeof(hist));
@@ -430,7 +435,7 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
                                       int32_t n_pass, mirge_reads** uniq, int64_t* n_uniq, mirge_result** out) {
     if (!c || !raw || !libs || !pol || !uniq || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
         return fail(-1, "mirge_collapse_cascade: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     static const bool presync_off = std::getenv("MIRGE_NO_PRESYNC") != nullptr;
     mirge_reads* U = nullptr;
     if (presync_off || !raw->hist_valid || raw->n == 0) {
@@ -481,9 +486,8 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
     res->n = U->n; res->reads = U; res->dmeta = hook.dmeta;
     res->g[hooked_group].n = U->g[hooked_group].n;
     for (size_t i = prof_mark; i < c->prof_pending.size(); i++) c->prof_pending[i].n_first = (double)U->g[hooked_group].n;
-    rc = cascade_launch_groups(c, U, res.get(), pol, hooked_group);  // small groups; ends with the join
+    rc = cascade_launch_groups(c, U, res.get(), pol, hooked_group);  // small groups; the join is left pending
     c->overlap_mode = false;
-    c->flush_deferred();
     if (rc) { (void)hipStreamSynchronize(c->stream); mirge_result_destroy(res.release()); mirge_reads_destroy(U); return rc; }
     *uniq = U;
     *out = res.release();
@@ -511,7 +515,7 @@ static int fetch_field(mirge_ctx* c, const mirge_result* res, T* host_out, T* Re
 extern "C" int mirge_result_fetch(mirge_ctx* c, const mirge_result* res, int8_t* pass_out, int32_t* ref_out,
                                   int32_t* off_out, int8_t* mm_out) {
     if (!c || !res) return fail(-1, "mirge_result_fetch: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     CHECK(fetch_field<int8_t>(c, res, pass_out, &ResGroup::pass));
     CHECK(fetch_field<int32_t>(c, res, ref_out, &ResGroup::ref));
     CHECK(fetch_field<int32_t>(c, res, off_out, &ResGroup::off));

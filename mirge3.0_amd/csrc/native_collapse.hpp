@@ -267,7 +267,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
                          int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights) {
     HostClock hc("collapse");
     if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids)) return fail(-1, "mirge_collapse: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     int32_t* dsample = nullptr;
     if (sample_ids && raw->n) {
         for (int64_t i = 0; i < raw->n; i++)
@@ -383,7 +383,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
 extern "C" int mirge_collapse_fetch(mirge_ctx* c, const mirge_reads* U, uint32_t* counts_out, int64_t* first_out) {
     if (!c || !U || !counts_out) return fail(-1, "mirge_collapse_fetch: bad argument");
     if (U->n_samples < 1) return fail(-1, "read set has no count matrix");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const int32_t S = U->n_samples;
     std::vector<uint32_t> tmp;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
@@ -407,7 +407,7 @@ extern "C" int mirge_collapse_fetch(mirge_ctx* c, const mirge_reads* U, uint32_t
 // (first index, handle index) pairs over all groups.
 extern "C" int mirge_collapse_order(mirge_ctx* c, const mirge_reads* U, int64_t* order_out) {
     if (!c || !U || (!order_out && U->n)) return fail(-1, "mirge_collapse_order: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const size_t n = (size_t)U->n;
     if (!n) return 0;
     uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;

@@ -177,7 +177,7 @@ extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, c
     if (!c || !U || !res || !header || (!rows && n_rows) || n_rows < 0 || n_pass < 1 || n_pass > MIRGE_MAX_PASSES || !col_of_pass ||
         n_name_cols < 0 || !name_data || !name_off || !name_n || U->n_samples < 1 || res->n != U->n || n_rows >= 0xFFFFFFF0ll)
         return fail(-1, "mirge_annotation_csv_device: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     HostClock hc("annotation_csv_device");
     CsvTables t;
     std::memset(&t, 0, sizeof(t));
@@ -353,7 +353,7 @@ static void csv_tables_of(const mirge_reads* U, const mirge_result* res, CsvTabl
 // sort on the device (k_lexkey).
 extern "C" int mirge_collapse_order_sorted(mirge_ctx* c, const mirge_reads* U, int64_t* order_out) {
     if (!c || !U || (!order_out && U->n)) return fail(-1, "mirge_collapse_order_sorted: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const size_t n = (size_t)U->n;
     if (!n) return 0;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
@@ -400,7 +400,7 @@ extern "C" int mirge_collapse_order_sorted(mirge_ctx* c, const mirge_reads* U, i
 // fetching the U x S matrix
 extern "C" int mirge_collapse_nonzero(mirge_ctx* c, const mirge_reads* U, int64_t* nonzero_out) {
     if (!c || !U || !nonzero_out || U->n_samples < 1) return fail(-1, "mirge_collapse_nonzero: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const int32_t S = U->n_samples;
     unsigned long long* d = nullptr;
     CHECK(dalloc(c, &d, (size_t)S));

@@ -62,6 +62,7 @@ struct mirge_ctx {
     hipStream_t xaux[MIRGE_N_XAUX] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_xfork = nullptr, ev_xjoin[MIRGE_N_XAUX] = {nullptr, nullptr, nullptr};
     bool xaux_used = false;
+    bool join_pending = false;  // a cascade's side streams are not joined yet: whoever touches the ctx next does it (join_pending_now)
     // mirge_collapse_cascade: the bulk group's cascade is already queued on the main stream while the small groups'
     // collapse tail and cascades are still being enqueued on the second one.  They do not depend on it: no fork
     // wait (it would serialise them behind ~1.3 ms of kernels), and no pool block goes back into circulation
@@ -234,6 +235,14 @@ static int stream_join(mirge_ctx* c) {
     if (e != hipSuccess) return fail(-2, std::string("stream join: ") + hipGetErrorString(e));
     return 0;
 }
+// mirge_cascade_run / mirge_collapse_cascade leave their side streams unjoined; every entry point that enqueues on the main
+// stream, hands buffers back to the pool or synchronises joins them first.  mirge_count_join uses the slack: the bulk
+// group's part of the join runs before the wait, beside the small groups' cascades.
+static int join_pending_now(mirge_ctx* c) {
+    if (!c->join_pending) return 0;
+    c->join_pending = false;
+    return stream_join(c);
+}
 static int largest_group(const struct mirge_reads* R);
 
 static inline int grid_for(const mirge_ctx* c, size_t n, int per_block = MIRGE_BLOCK) {
@@ -335,18 +344,20 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
 
 extern "C" int mirge_ctx_sync(mirge_ctx* c) {
     if (!c) return fail(-1, "ctx is NULL");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     HIPOK(hipStreamSynchronize(c->stream));
     c->drain();
     return 0;
 }
 
 extern "C" int mirge_ctx_timer_start(mirge_ctx* c) {
+    if (c) CHECK(join_pending_now(c));
     if (!c) return fail(-1, "ctx is NULL");
     HIPOK(hipEventRecord(c->t0, c->stream));
     return 0;
 }
 extern "C" int mirge_ctx_timer_stop(mirge_ctx* c, double* ms_out) {
+    if (c) CHECK(join_pending_now(c));
     if (!c || !ms_out) return fail(-1, "NULL argument");
     HIPOK(hipEventRecord(c->t1, c->stream));
     HIPOK(hipEventSynchronize(c->t1));

@@ -22,7 +22,7 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
         if (master_of_ref[r] >= n_master) return fail(-1, "master_of_ref out of range");
     for (int64_t m = 0; m < n_master; m++)
         if (pre_of_master[m] < 0 || pre_of_master[m] >= n_pre) return fail(-1, "pre_of_master out of range");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const size_t nm = (size_t)std::max<int64_t>(n_master, 1), np = (size_t)std::max<int64_t>(n_pre, 1);
     const size_t mbytes = (size_t)std::max<int32_t>(master_off[n_master], 1), pbytes = (size_t)std::max<int32_t>(pre_off[n_pre], 1);
     int32_t *d_mof = nullptr, *d_moff = nullptr, *d_pom = nullptr, *d_s0 = nullptr, *d_poff = nullptr, *d_slot = nullptr;

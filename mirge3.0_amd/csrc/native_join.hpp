@@ -29,43 +29,57 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     if (!c->join_dev_clean) HIPOK(hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream));
     c->join_dev_clean = false;
     unsigned long long* partial = nullptr;
-    // a big group whose tables fit LDS: per-workgroup tables in LDS, rows out, column sums (no global atomic per read); the
-    // other groups together in one launch with atomics (they are small: a launch each was most of what they cost)
+    // Tables that fit LDS (one sample, up to ~3 000 miRNA references): 1024-thread workgroups keep them there while they walk
+    // their reads, write one row each, and ONE column sum adds all rows to the ctx's tables -- no global atomic per read.
+    // The bulk group's rows are computed before the cascade's side streams are joined (its annotation is complete in the
+    // main stream's own order): k_join_rows of 4.2 M reads runs beside the tail of the small groups' cascades instead of
+    // behind the wait for them.  Otherwise: everything in one launch with atomics (k_join_multi).
     static const bool rows_off = std::getenv("MIRGE_JOIN_ROWS") && std::atoi(std::getenv("MIRGE_JOIN_ROWS")) == 0;  // A/B
-    auto by_rows = [&](const ResGroup& g) { return !rows_off && g.n >= (1u << 20) && words <= MIRGE_JOIN_ROWS_CELLS && n_mirna * (int64_t)S < 0x7FFFFFFF; };
-    {
-        JoinGroups gs;
+    const bool lazy = c->join_pending;
+    c->join_pending = false;
+    const int big = largest_group(U);
+    auto group_list = [&](bool bulk, JoinGroups& gs) -> uint64_t {
         std::memset(&gs, 0, sizeof(gs));
         uint64_t total = 0;
         for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
             const ResGroup& g = res->g[gi];
-            if (!g.n || by_rows(g)) continue;
+            if (!g.n || (gi == big) != bulk) continue;
             gs.pass[gs.n_groups] = g.pass; gs.ref[gs.n_groups] = g.ref; gs.counts[gs.n_groups] = U->g[gi].counts;
             gs.start[gs.n_groups++] = (uint32_t)total;
             total += g.n;
         }
-        if (gs.n_groups && total < 0xFFFFFFF0ull) {
-            gs.start[gs.n_groups] = (uint32_t)total;
-            LaunchScope ls(c, "k_join", (double)total);
-            hipLaunchKernelGGL(k_join_multi, dim3(grid_for(c, (size_t)total)), dim3(MIRGE_BLOCK), 0, c->stream, gs, S, P, exact_pass, iso_pass,
-                               d, d + n_cls, d + n_cls + n_tab);
-        } else if (gs.n_groups) {
-            return fail(-5, "mirge_count_join: more than 2^32 reads outside the bulk group");
+        gs.start[gs.n_groups] = (uint32_t)std::min<uint64_t>(total, 0xFFFFFFFFull);
+        return total;
+    };
+    JoinGroups gb, gsm;
+    const uint64_t n_bulk = group_list(true, gb), n_small = group_list(false, gsm);
+    if (n_small >= 0xFFFFFFF0ull) return fail(-5, "mirge_count_join: more than 2^32 reads outside the bulk group");
+    const bool by_rows = !rows_off && n_bulk + n_small >= 65536 && words <= MIRGE_JOIN_ROWS_CELLS && n_mirna * (int64_t)S < 0x7FFFFFFF;
+    if (by_rows) {
+        const uint32_t rows_b = n_bulk ? (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu, (n_bulk + 4095) / 4096) : 0u;
+        const uint32_t rows_s = n_small ? (uint32_t)std::min<uint64_t>((uint64_t)c->n_cu, (n_small + 4095) / 4096) : 0u;
+        CHECK(dalloc(c, &partial, (size_t)(rows_b + rows_s) * words));
+        if (rows_b) {
+            LaunchScope ls(c, "k_join", (double)n_bulk);
+            hipLaunchKernelGGL(k_join_rows, dim3(rows_b), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, gb, S, P, exact_pass, iso_pass,
+                               (uint32_t)n_tab, partial);
         }
-    }
-    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
-        const ResGroup& g = res->g[gi];
-        if (!g.n || !by_rows(g)) continue;
-        {
-            const uint32_t rows = (uint32_t)std::min<size_t>((size_t)c->n_cu, (g.n + 4095) / 4096);
-            if (!partial) CHECK(dalloc(c, &partial, (size_t)c->n_cu * words));
-            {
-                LaunchScope ls(c, "k_join", g.n);
-                hipLaunchKernelGGL(k_join_rows, dim3(rows), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, g.pass, g.ref,
-                                   U->g[gi].counts, g.n, S, P, exact_pass, iso_pass, (uint32_t)n_tab, partial);
-            }
-            LaunchScope ls(c, "k_join_reduce", (double)words);
-            hipLaunchKernelGGL(k_join_reduce, dim3((unsigned)((words + 63) / 64)), dim3(1024), 0, c->stream, partial, rows, (uint32_t)words, d);
+        if (lazy) CHECK(stream_join(c));
+        if (rows_s) {
+            LaunchScope ls(c, "k_join", (double)n_small);
+            hipLaunchKernelGGL(k_join_rows, dim3(rows_s), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, gsm, S, P, exact_pass, iso_pass,
+                               (uint32_t)n_tab, partial + (size_t)rows_b * words);
+        }
+        LaunchScope ls(c, "k_join_reduce", (double)words);
+        hipLaunchKernelGGL(k_join_reduce, dim3((unsigned)((words + 63) / 64)), dim3(1024), 0, c->stream, partial, rows_b + rows_s, (uint32_t)words, d);
+    } else {
+        if (lazy) CHECK(stream_join(c));
+        for (JoinGroups* gs : {&gb, &gsm}) {
+            const uint64_t total = gs == &gb ? n_bulk : n_small;
+            if (!total) continue;
+            LaunchScope ls(c, "k_join", (double)total);
+            hipLaunchKernelGGL(k_join_multi, dim3(grid_for(c, (size_t)total)), dim3(MIRGE_BLOCK), 0, c->stream, *gs, S, P, exact_pass, iso_pass,
+                               d, d + n_cls, d + n_cls + n_tab);
         }
     }
     // one device-to-host copy through pinned memory for all three tables (they are contiguous)
@@ -101,7 +115,7 @@ extern "C" int mirge_count_join_host(mirge_ctx* c, const int8_t* pass, const int
         (n > 0 && (!pass || !ref || !counts)))
         return fail(-1, "mirge_count_join_host: bad argument");
     if (n >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 rows");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     for (int64_t i = 0; i < n; i++) {
         if (pass[i] >= P) return fail(-1, "pass index out of range");
         if ((pass[i] == exact_pass || pass[i] == iso_pass) && (ref[i] < 0 || ref[i] >= n_mirna))
@@ -158,7 +172,7 @@ extern "C" int mirge_variant_tally(mirge_ctx* c, const mirge_reads* U, const mir
     for (int32_t p : {exact_pass, iso_pass})
         if (p >= 0 && p < res->n_pass && (int64_t)res->n_refs[p] > n_mirna)
             return fail(-1, "mirge_variant_tally: fam_of_ref is shorter than the miRNA library of pass " + std::to_string(p));
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const int32_t S = U->n_samples;
     // family targets, 2-bit packed on the host (a few thousand sequences of <= 32 nt)
     std::vector<uint64_t> tb((size_t)std::max<int64_t>(n_fam, 1), 0ull);

@@ -33,7 +33,7 @@ static int lib_upload(mirge_ctx* c, std::unique_ptr<mirge_lib>& L, int64_t n_ref
 
 extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* off, int64_t n_refs, mirge_lib** out) {
     if (!c || !out || (!seq && n_refs > 0) || !off || n_refs < 0) return fail(-1, "mirge_lib_create: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     auto L = std::make_unique<mirge_lib>();
     L->ctx = c;
     L->uid = g_lib_uid.fetch_add(1);
@@ -53,7 +53,7 @@ extern "C" int mirge_lib_create_packed(mirge_ctx* c, const uint64_t* T, int64_t 
     if (!c || !out || !T || !inv || !ref_start || n_refs < 0 || total >= 0xFFFFFFF0ull || kmax < 8 || kmax > MIRGE_KMAX ||
         n_T != (int64_t)((total + 31) / 32) + 8 || n_inv != (int64_t)((total + 63) / 64) + 4 || ref_start[n_refs] != (uint32_t)total)
         return fail(-1, "mirge_lib_create_packed: bad argument (a cache of another layout?)");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     auto L = std::make_unique<mirge_lib>();
     L->ctx = c;
     L->uid = g_lib_uid.fetch_add(1);

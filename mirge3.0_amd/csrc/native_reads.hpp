@@ -58,6 +58,7 @@ static GroupView<W> view_of(const ReadGroup& g) {
 
 extern "C" void mirge_reads_destroy(mirge_reads* r) {
     if (!r) return;
+    (void)join_pending_now(r->ctx);
     for (auto& g : r->g) {
         r->ctx->release(g.seq); r->ctx->release(g.len); r->ctx->release(g.nmask);
         r->ctx->release(g.orig); r->ctx->release(g.counts); r->ctx->release(g.first);
@@ -68,7 +69,7 @@ extern "C" void mirge_reads_destroy(mirge_reads* r) {
 // part p gets handle index (reads of the parts before p) + j.  No count matrices; the parts stay valid.
 extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out) {
     if (!c || !parts || n_parts < 1 || !out) return fail(-1, "mirge_reads_concat: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     int64_t total = 0;
     for (int p = 0; p < n_parts; p++) {
         if (!parts[p] || parts[p]->ctx != c) return fail(-1, "mirge_reads_concat: foreign or NULL read set");
@@ -145,7 +146,7 @@ static int launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstar
 extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads** out) {
     if (!c || !out || !off || n < 0 || (n > 0 && !ascii)) return fail(-1, "mirge_reads_pack: bad argument");
     if (n >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     auto R = std::make_unique<mirge_reads>();
     R->ctx = c; R->n = n;
     std::memset(R->len_hist, 0, sizeof(R->len_hist));
@@ -524,7 +525,7 @@ extern "C" int mirge_reads_parse_umi(mirge_ctx* c, const char* text, int64_t nby
     if (tagged_out) *tagged_out = nullptr;
     if (umi && (umi->front < 0 || umi->back < 0 || umi->front > MIRGE_MAX_READ_LEN || umi->back > MIRGE_MAX_READ_LEN))
         return fail(-1, "mirge_reads_parse_umi: -umi f,b out of range");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     if (format == 0) format = nbytes == 0 ? 3 : (text[0] == '@' ? 1 : (text[0] == '>' ? 2 : 3));
     TrimOpts topt;
     std::memset(&topt, 0, sizeof(topt));
@@ -631,7 +632,7 @@ static int launch_unpack(mirge_ctx* c, const ReadGroup& g, const int64_t* doff, 
 
 extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* ascii_out, int64_t* off_out) {
     if (!c || !R || !off_out || (R->total_bases > 0 && !ascii_out)) return fail(-1, "mirge_reads_unpack: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const int64_t n = R->n;
     int32_t* dlen = nullptr;
     CHECK(dalloc(c, &dlen, (size_t)std::max<int64_t>(n, 1)));
@@ -668,7 +669,7 @@ extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* asci
 
 extern "C" int mirge_reads_set_counts(mirge_ctx* c, mirge_reads* R, const uint32_t* counts, int32_t S) {
     if (!c || !R || !counts || S < 1) return fail(-1, "mirge_reads_set_counts: bad argument");
-    HIPOK(hipSetDevice(c->device));
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     // counts are in handle order; each group wants its rows contiguous -> gather on the host
     // through the group's orig list (small: U x S)
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
