@@ -430,14 +430,8 @@ struct ResolveTable {
     uint32_t n_refs[MIRGE_MAX_PASSES_K];
 };
 
-__device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint32_t g, int32_t& ref, int32_t& off) {
-    const uint32_t* rs = nullptr;
-    const uint32_t* cs = nullptr;
-    uint32_t nr = 0;
-#pragma unroll
-    for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
-        if (q == p) { rs = tb.ref_start[q]; cs = tb.coarse[q]; nr = tb.n_refs[q]; }
-    const PairU32 c = load_pair32((gptr_u32)cs + 2 * (size_t)(g >> MIRGE_COARSE_SHIFT));
+// (reference, offset) of position g from its granule's entry c
+__device__ __forceinline__ void resolve_entry(const PairU32 c, const uint32_t* rs, uint32_t nr, uint32_t g, int32_t& ref, int32_t& off) {
     uint32_t lo = c.a >> 5, base = c.b;
     const uint32_t code = c.a & 31u;
     if (code < 16u) {
@@ -453,6 +447,15 @@ __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint3
     }
     ref = (int32_t)lo;
     off = (int32_t)(g - base);
+}
+__device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint32_t g, int32_t& ref, int32_t& off) {
+    const uint32_t* rs = nullptr;
+    const uint32_t* cs = nullptr;
+    uint32_t nr = 0;
+#pragma unroll
+    for (int q = 0; q < MIRGE_MAX_PASSES_K; q++)
+        if (q == p) { rs = tb.ref_start[q]; cs = tb.coarse[q]; nr = tb.n_refs[q]; }
+    resolve_entry(load_pair32((gptr_u32)cs + 2 * (size_t)(g >> MIRGE_COARSE_SHIFT)), rs, nr, g, ref, off);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -509,6 +512,8 @@ k_cascade_bulk(const FusedSteps* __restrict__ steps, GroupView<W> g, uint32_t* _
     // four waves to hide it -- the kernel grew by 0.04 ms to save a 0.046 ms launch that the whole chip runs at once)
 }
 
+// (Four reads per thread with their loads issued together -- before and after the table became one access -- changed nothing:
+// 45 -> 49-53 us.  7.6 M wave-level VALU instructions per launch, most of them the 16-way pointer select, 73 MB moved.)
 __global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, const uint32_t* __restrict__ res_pos,
                           uint32_t n, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off,
                           const uint32_t* __restrict__ n_dev) {
