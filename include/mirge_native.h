@@ -187,7 +187,10 @@ int mirge_reads_set_counts(mirge_ctx* ctx, mirge_reads* reads, const uint32_t* c
  * bowtie runs, their FASTA/SAM round trips and the DataFrame updates.  libs[p] == NULL skips
  * pass p.  Every pass sees the rows no earlier pass annotated (the reference tests annotFlag only from
  * pass 2 on, :120,129, but its passes 0 and 1 are disjoint by length, :93,104, so this is the same).  Result per read: pass index (or MIRGE_NO_PASS), reference index in libs[pass],
- * 0-based offset in that reference, mismatches.                                            */
+ * 0-based offset in that reference, mismatches.
+ * The call returns with the small read groups' streams not yet joined into the ctx stream: the library's next entry point on
+ * this ctx makes the join (mirge_count_join puts the bulk read group's part of its work in front of it).  Work the CALLER
+ * enqueues on that stream is ordered behind a cascade only after such a call (mirge_ctx_sync, for one).  */
 int mirge_cascade_run(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib* const* libs,
                       const mirge_policy* policies, int32_t n_pass, mirge_result** out);
 /* mirge_collapse followed by mirge_cascade_run for ONE sample, as one call: the bulk read group's passes are queued on
