@@ -193,6 +193,11 @@ int mirge_reads_set_counts(mirge_ctx* ctx, mirge_reads* reads, const uint32_t* c
  * enqueues on that stream is ordered behind a cascade only after such a call (mirge_ctx_sync, for one).  */
 int mirge_cascade_run(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib* const* libs,
                       const mirge_policy* policies, int32_t n_pass, mirge_result** out);
+/* optional: build NOW what a cascade over `reads` (raw or collapsed: only the read lengths present matter) builds on first
+ * use -- merged libraries, probe tables, plan tables -- and wait for it.  The reference pays this as bowtie-build, once per
+ * library release; here it is device work of a process's first sample (timed separately by bench.py's cli_path). */
+int mirge_cascade_prepare(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib* const* libs, const mirge_policy* policies,
+                          int32_t n_pass);
 /* mirge_collapse followed by mirge_cascade_run for ONE sample, as one call: the bulk read group's passes are queued on
  * the GPU behind the collapse kernels before the host has read the unique counts back (the kernels take the count
  * from device memory), so the GPU does not idle across the collapse's host synchronisation.  Same results; falls

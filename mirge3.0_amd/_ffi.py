@@ -26,7 +26,7 @@ EXPORTS = [
     "mirge_reads_n_samples", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
-    "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
+    "mirge_cascade_prepare", "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
 
@@ -435,6 +435,13 @@ def cascade_run(ctx: Context, reads: DeviceReads, libs: Sequence[Optional[Device
     h = C.c_void_p()
     _check(load().mirge_cascade_run(ctx._h, reads._h, arr, pol, n_pass, C.byref(h)), "mirge_cascade_run")
     return CascadeResult(ctx, h, reads, n_pass.value)
+
+
+def cascade_prepare(ctx: Context, reads: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],
+                    policies: Sequence[MirgePolicy], prepared=None) -> None:
+    """Build the probe / plan tables a cascade over ``reads`` needs now (``mirge_cascade_prepare``) and wait for them."""
+    arr, pol, n_pass = prepared if prepared is not None else cascade_args(libs, policies)
+    _check(load().mirge_cascade_prepare(ctx._h, reads._h, arr, pol, n_pass), "mirge_cascade_prepare")
 
 
 def collapse_cascade(ctx: Context, raw: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],

@@ -92,6 +92,11 @@ class Cascade:
     def run(self, reads: _ffi.DeviceReads) -> _ffi.CascadeResult:
         return _ffi.cascade_run(self.ctx, reads, self.dev_libs, self.policies, self._prepared)
 
+    def prepare(self, reads: _ffi.DeviceReads):
+        """The tables a cascade over ``reads`` builds on first use, built now (``mirge_cascade_prepare``); a no-op once they
+        exist for these libraries, policies and read lengths."""
+        _ffi.cascade_prepare(self.ctx, reads, self.dev_libs, self.policies, self._prepared)
+
     def collapse_and_run(self, raw: _ffi.DeviceReads):
         """One sample's raw reads -> (unique reads, annotation): collapse and cascade as one call, the bulk group's
         passes queued behind the collapse kernels without waiting for the host (``mirge_collapse_cascade``)."""

@@ -393,26 +393,27 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
     return rc;
 }
 
+// read lengths present: the host histogram pack / parse / collapse keep; without one, every length the width groups in use can hold
+static void reads_lengths_present(const mirge_reads* R, int32_t* hist) {
+    if (R->hist_valid) { std::memcpy(hist, R->len_hist, sizeof(int32_t) * (MIRGE_MAX_READ_LEN + 1)); return; }
+    std::memset(hist, 0, sizeof(int32_t) * (MIRGE_MAX_READ_LEN + 1));
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+        const ReadGroup& g = R->g[gi];
+        if (!g.n) continue;
+        const int w = kGroupW[gi];
+        int lo = w == 1 ? 1 : (w == 2 ? 32 : (w == 4 ? 65 : 129)), hi = w == 1 ? 31 : (w == 2 ? 64 : (w == 4 ? 128 : MIRGE_MAX_READ_LEN));
+        for (int L = lo; L <= hi; L++) hist[L] = 1;
+    }
+}
+
 extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs,
                                  const mirge_policy* pol, int32_t n_pass, mirge_result** out) {
     HostClock hc("cascade");
     if (!c || !R || !libs || !pol || !out || n_pass < 1 || n_pass > MIRGE_MAX_PASSES)
         return fail(-1, "mirge_cascade_run: bad argument");
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
-    // read lengths present (host histogram from pack; a collapse result asks the device once)
     int32_t hist[MIRGE_MAX_READ_LEN + 1];
-    if (R->hist_valid) std::memcpy(hist, R->len_hist, sizeof(hist));
-    else {
-        std::memset(hist, 0, sizeof(hist));
-        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
-            const ReadGroup& g = R->g[gi];
-            if (!g.n) continue;
-            // conservative: every length the width group can hold is assumed present
-            const int w = kGroupW[gi];
-            int lo = w == 1 ? 1 : (w == 2 ? 32 : (w == 4 ? 65 : 129)), hi = w == 1 ? 31 : (w == 2 ? 64 : (w == 4 ? 128 : MIRGE_MAX_READ_LEN));
-            for (int L = lo; L <= hi; L++) hist[L] = 1;
-        }
-    }
+    reads_lengths_present(R, hist);
     CHECK(cascade_config(c, libs, pol, n_pass, hist));
     hc.lap("plans+fused");
     auto res = std::make_unique<mirge_result>();
@@ -422,6 +423,21 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     hc.lap("enqueue+join");
     if (rc) { mirge_result_destroy(res.release()); return rc; }
     *out = res.release();
+    return 0;
+}
+
+// What a cascade over `reads` needs besides the reads -- merged libraries, probe tables for the read lengths present, plan
+// tables, the device step list -- built now and kept in the ctx (mirge_cascade_run / mirge_collapse_cascade find it there).
+// Returns when the tables exist: callers that want to know what a process's first sample spends on them (bench.py's
+// cli_path) time this call; nobody has to make it.
+extern "C" int mirge_cascade_prepare(mirge_ctx* c, const mirge_reads* R, const mirge_lib* const* libs, const mirge_policy* pol,
+                                     int32_t n_pass) {
+    if (!c || !R || !libs || !pol || n_pass < 1 || n_pass > MIRGE_MAX_PASSES) return fail(-1, "mirge_cascade_prepare: bad argument");
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
+    int32_t hist[MIRGE_MAX_READ_LEN + 1];
+    reads_lengths_present(R, hist);
+    CHECK(cascade_config(c, libs, pol, n_pass, hist));
+    HIPOK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -132,73 +132,92 @@ struct ShapeJob {
     int k1 = 0, gap = 0, k2 = 0;
 };
 
-// build one table on the device (k_table_pass: count, scan, fill) and publish it in the library's registry
-static int lib_build_shape(mirge_lib* L, const ShapeJob& j) {
+// Build the tables of `jobs` on the device (k_table_pass: count, scan, fill; bitmap or self-contained entries) and publish them
+// in the library's registry.  Everything is queued on the ctx stream and the host waits ONCE, at the end: a table at a time
+// with two synchronisations, its own scan area and CSR bounds and a blocking registry update was 0.09 s per process for the
+// human set's 56 tables against 0.04 s of kernels (bench.py cli_path: probe_tables_s).  (One allocation for a whole batch is
+// NOT the way: a single hipMalloc of several GB took longer than all of this, 0.4-0.5 s.)
+static int lib_build_shapes(mirge_lib* L, const std::vector<ShapeJob>& jobs) {
     mirge_ctx* c = L->ctx;
-    const int sid = mirge_shape_id(j.k1, j.gap, j.k2);
-    const uint64_t nb = 1ull << (2 * (j.k1 + j.k2));
-    uint32_t *A = nullptr, *dpos = nullptr, *dbits = nullptr;
-    uint64_t* dentry = nullptr;
+    struct Built { int sid; uint64_t nb; uint32_t *A, *dpos, *dbits; uint64_t* dentry; };
+    std::vector<Built> built;
+    // what only construction needs, once for the batch (the launches of consecutive tables are ordered by the stream): the scan's
+    // work area and the CSR bounds of the tables that end up as self-contained entries (up to 1 GB each)
     void* tmp = nullptr;
-    size_t tmp_bytes = 0;
-    uint32_t npos = 0;
+    uint32_t* A_scratch = nullptr;
+    size_t tmp_cap = 0;
+    uint64_t nb_max = 0, nb_scratch = 0;
+    for (const ShapeJob& j : jobs) {
+        const uint64_t nb = 1ull << (2 * (j.k1 + j.k2));
+        nb_max = std::max(nb_max, nb);
+        if (j.k1 + j.k2 > MIRGE_BITMAP_MAXK) nb_scratch = std::max(nb_scratch, nb);
+    }
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(nullptr, tmp_cap, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)(nb_max + 2), c->stream);  // size query
+    if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_cap, 16));
+    if (e == hipSuccess && nb_scratch) e = hipMalloc((void**)&A_scratch, (nb_scratch + 2) * 4);
     const int grid = c->n_cu * 8;
-    hipError_t e = hipMalloc((void**)&A, (nb + 2) * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(A, 0, (nb + 2) * 4, c->stream);
-    if (e == hipSuccess) {
+    for (size_t k = 0; k < jobs.size() && e == hipSuccess; k++) {
+        const ShapeJob& j = jobs[k];
+        Built t{mirge_shape_id(j.k1, j.gap, j.k2), 1ull << (2 * (j.k1 + j.k2)), nullptr, nullptr, nullptr, nullptr};
+        const uint64_t nb = t.nb;
+        const bool entries = j.k1 + j.k2 > MIRGE_BITMAP_MAXK;  // a table too large for a bitmap: self-contained entries (MirgeKTable)
+        if (!entries) e = hipMalloc((void**)&t.A, (nb + 2) * 4);
+        // pos[] for every position of the text: the exact number (a few k-mers short of it) is only known after the scan
+        if (e == hipSuccess) e = hipMalloc((void**)&t.dpos, std::max<size_t>((size_t)L->h.total, 1) * 4);
+        if (e == hipSuccess && !entries) e = hipMalloc((void**)&t.dbits, (size_t)((nb + 31) / 32) * 4);
+        if (e == hipSuccess && entries) e = hipMalloc((void**)&t.dentry, nb * 8);
+        built.push_back(t);  // (whatever was allocated is freed below on failure)
+        uint32_t* A = entries ? A_scratch : t.A;
+        if (e == hipSuccess) e = hipMemsetAsync(A, 0, (nb + 2) * 4, c->stream);
+        if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_table_pass<false>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1,
                            j.gap, j.k2, A, (uint32_t*)nullptr);
-        e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream);  // size query
-    }
-    if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16));
-    if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, A, A, (int)(nb + 2), c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&npos, A + nb + 1, 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMalloc((void**)&dpos, std::max<size_t>(npos, 1) * 4);
-    if (e == hipSuccess) {
+        size_t tb = tmp_cap;
+        e = hipcub::DeviceScan::InclusiveSum(tmp, tb, A, A, (int)(nb + 2), c->stream);
+        if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_table_pass<true>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1,
-                           j.gap, j.k2, A, dpos);
-        if (j.k1 + j.k2 <= MIRGE_BITMAP_MAXK) {  // non-empty-bucket bitmap
-            const size_t words = (size_t)((nb + 31) / 32);
-            e = hipMalloc((void**)&dbits, words * 4);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, words)), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, dbits);
-        }
+                           j.gap, j.k2, A, t.dpos);
+        if (!entries)  // non-empty-bucket bitmap
+            hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, (size_t)((nb + 31) / 32))), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, t.dbits);
+        else
+            hipLaunchKernelGGL(k_table_entries, dim3(grid_for(c, nb)), dim3(MIRGE_BLOCK), 0, c->stream, A, t.dpos, nb, t.dentry);
     }
-    if (e == hipSuccess && !dbits) {  // a table too large for a bitmap: self-contained entries (MirgeKTable)
-        e = hipMalloc((void**)&dentry, nb * 8);
-        if (e == hipSuccess)
-            hipLaunchKernelGGL(k_table_entries, dim3(grid_for(c, nb)), dim3(MIRGE_BLOCK), 0, c->stream, A, dpos, nb, dentry);
-    }
-    // table complete; no kernel may be reading the registry while it changes
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    // tables complete; no kernel may be reading the registry while it changes
+    { const hipError_t e2 = hipStreamSynchronize(c->stream); if (e == hipSuccess) e = e2; }
     if (e == hipSuccess) e = hipGetLastError();
     (void)hipFree(tmp);
+    (void)hipFree(A_scratch);
     if (e != hipSuccess) {
-        (void)hipFree(A); (void)hipFree(dpos); (void)hipFree(dbits); (void)hipFree(dentry);
-        return fail(-2, std::string("probe table construction: ") + hipGetErrorString(e));
+        for (auto& t : built) { (void)hipFree(t.A); (void)hipFree(t.dpos); (void)hipFree(t.dbits); (void)hipFree(t.dentry); }
+        return fail(e == hipErrorOutOfMemory ? -3 : -2, std::string("probe table construction: ") + hipGetErrorString(e));
     }
-    if (dentry) { (void)hipFree(A); A = nullptr; }  // the CSR bounds were only the way to the entries
-    L->device_bytes += (dentry ? nb * 8 : (nb + 2) * 4) + (size_t)npos * 4 + (dbits ? (size_t)((nb + 31) / 32) * 4 : 0);
-    L->htables[sid].bucket = dentry ? (const void*)dentry : (const void*)A;
-    L->htables[sid].pos = dpos;
-    L->htables[sid].bits = dbits;
-    HIPOK(hipMemcpy(L->dtables + sid, &L->htables[sid], sizeof(MirgeKTable), hipMemcpyHostToDevice));
+    for (const Built& t : built) {
+        L->device_bytes += (t.dentry ? t.nb * 8 : (t.nb + 2) * 4) + (size_t)L->h.total * 4 + (t.dbits ? (size_t)((t.nb + 31) / 32) * 4 : 0);
+        L->htables[t.sid].bucket = t.dentry ? (const void*)t.dentry : (const void*)t.A;
+        L->htables[t.sid].pos = t.dpos;
+        L->htables[t.sid].bits = t.dbits;
+    }
+    if (!built.empty())
+        HIPOK(hipMemcpy(L->dtables, L->htables.data(), sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS, hipMemcpyHostToDevice));
     return 0;
 }
 
 // build the tables of the wanted probe shapes that do not exist yet
 static int lib_prepare_shapes(mirge_lib* L, const std::vector<ShapeJob>& wanted) {
     std::lock_guard<std::mutex> lk(L->mu);
-    bool first = true;
+    std::vector<ShapeJob> jobs;
+    std::vector<int> seen;
     for (const auto& w : wanted) {
         if (w.k1 < 1 || w.k2 < 0 || w.k1 + w.k2 > (w.k2 == 0 ? MIRGE_KMAX0 : MIRGE_KMAX) || w.gap < 0 || w.gap > 31 || (w.k2 == 0 && w.gap != 0))
             return fail(-1, "probe shape out of range");
-        if (L->htables[mirge_shape_id(w.k1, w.gap, w.k2)].bucket) continue;
-        if (first) { HIPOK(hipSetDevice(L->ctx->device)); first = false; }
-        CHECK(lib_build_shape(L, w));
+        const int sid = mirge_shape_id(w.k1, w.gap, w.k2);
+        if (L->htables[sid].bucket || std::find(seen.begin(), seen.end(), sid) != seen.end()) continue;
+        seen.push_back(sid);
+        jobs.push_back(w);
     }
-    return 0;
+    if (jobs.empty()) return 0;
+    HIPOK(hipSetDevice(L->ctx->device));
+    return lib_build_shapes(L, jobs);
 }
 
 extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {

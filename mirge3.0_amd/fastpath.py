@@ -157,6 +157,13 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     t = time.perf_counter()
     say("Alignment in progress ...")
     S = len(parsed)
+    # the probe tables for these libraries and read lengths: built once per process (0.05-0.08 s of device work for the human
+    # set), nothing afterwards -- its own stage, so that `collapse_cascade_s` is the sample's work
+    for p in parsed:
+        if len(p):
+            casc.prepare(p)
+    tm["probe_tables_s"] = time.perf_counter() - t
+    t = time.perf_counter()
     if S == 1:
         uniq, res = casc.collapse_and_run(parsed[0])
     else:

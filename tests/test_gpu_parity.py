@@ -318,6 +318,28 @@ def test_references_shorter_than_a_resolve_granule(ctx):
     casc.close()
 
 
+def test_cascade_prepare_builds_the_tables_ahead(ctx, ci_libs):
+    """mirge_cascade_prepare: the first cascade's table construction as a call of its own (the CLI times it as a stage);
+    same annotation with and without it, from raw reads (only their lengths matter) and from reads without a histogram."""
+    reads = synth.make_reads(ci_libs, 4000, seed=23, n_frac=0.02)
+    want = None
+    for ahead in (False, True):
+        casc = Cascade(ctx, ci_libs.libs)
+        raw = _ffi.DeviceReads.pack(ctx, reads)
+        if ahead:
+            casc.prepare(raw)
+            casc.prepare(raw)  # a no-op the second time
+        uniq, res = casc.collapse_and_run(raw)
+        got = (uniq.unpack().to_list(), [a.tolist() for a in res.fetch()])
+        order = np.argsort(np.array(got[0], dtype=object), kind="stable")
+        got = ([got[0][i] for i in order], [[a[i] for i in order] for a in got[1]])
+        if want is None:
+            want = got
+        else:
+            assert got == want
+        res.close(); uniq.close(); raw.close(); casc.close()
+
+
 def test_cascade_vs_bruteforce_oracle(ctx, ci_libs, ci_cascade):
     reads = synth.make_reads(ci_libs, 3000, seed=17, n_frac=0.03)
     g = ci_cascade.annotate(reads)
