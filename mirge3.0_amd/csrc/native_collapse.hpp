@@ -306,7 +306,8 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage, dweight));
             if (k < 0) hc.lap("first kernel of the bulk group enqueued");
         }
-        { int jr = stream_join(c); if (rc == 0) rc = jr; }
+        // (no join here: the second stream waits for the main one below and carries the read-back of the counts)
+        c->cur = c->stream;
         hc.lap("enqueue A");
         if (rc == -3 && attempt < 2) {
             // the partitioned attempts take up to 2 KiB of HBM per read (attempt 1); the global-atomic tables ~20 B.  A device
@@ -324,8 +325,12 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         }
         bool hooked = false;
         if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
-            hipError_t e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipEventRecord(c->ev_meta, c->stream);
+            // The counts are copied by the SECOND stream, behind its own groups' kernels and an event of the main stream (the bulk
+            // group's count comes from k_part_dedup): on the main stream the 4 us copy sat between k_part_dedup and the bulk
+            // group's cascade -- which does not need it -- with 6 + 11 us of queue gaps around it
+            rc = stream_fork(c);
+            hipError_t e = rc == 0 ? hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->aux) : hipErrorUnknown;
+            if (e == hipSuccess) e = hipEventRecord(c->ev_meta, c->aux);
             if (e == hipSuccess && hook && attempt == 0 && tmp[big].partitioned) {
                 rc = hook->pre_sync(R.get(), tmp, dmeta, big);
                 hooked = rc == 0;
