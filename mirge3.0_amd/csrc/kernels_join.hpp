@@ -149,8 +149,11 @@ k_join_rows(JoinGroups gs, int32_t S, int32_t n_pass, int32_t exact_pass, int32_
 // tables[c] += sum over rows of partial[row][c].  A workgroup owns 64 consecutive cells; its 16 waves take every 16th row each
 // (a wave's load of a row's 64 cells is one coalesced 512-byte access), then the waves' sums are added up through LDS.
 // (One thread per cell walking all 256 rows by itself took 46 us for 5.9 k cells: a chain of 256 dependent-latency loads.)
+// host_out != nullptr (page-locked host memory): the sums -- plus whatever `tables` already holds -- are written THERE and
+// `tables` stays as it is: no device-to-host copy behind the kernel, and tables that were zero need no clearing afterwards.
 __global__ void __launch_bounds__(1024)
-k_join_reduce(const unsigned long long* __restrict__ partial, uint32_t rows, uint32_t W, unsigned long long* __restrict__ tables) {
+k_join_reduce(const unsigned long long* __restrict__ partial, uint32_t rows, uint32_t W, unsigned long long* __restrict__ tables,
+              unsigned long long* __restrict__ host_out) {
     __shared__ unsigned long long s_part[16][64];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x * 64 + lane;
@@ -163,7 +166,8 @@ k_join_reduce(const unsigned long long* __restrict__ partial, uint32_t rows, uin
         unsigned long long tot = 0ull;
 #pragma unroll
         for (int w = 0; w < 16; w++) tot += s_part[w][lane];
-        if (tot) tables[c] += tot;
+        if (host_out) host_out[c] = tables[c] + tot;
+        else if (tot) tables[c] += tot;
     }
 }
 

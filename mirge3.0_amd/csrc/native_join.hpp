@@ -28,6 +28,12 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     unsigned long long* d = c->join_dev;
     if (!c->join_dev_clean) HIPOK(hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream));
     c->join_dev_clean = false;
+    if (words * 8 > c->join_pinned_bytes) {
+        if (c->join_pinned) { HIPOK(hipStreamSynchronize(c->stream)); (void)hipHostFree(c->join_pinned); }
+        c->join_pinned = nullptr; c->join_pinned_bytes = 0;
+        HIPOK(hipHostMalloc((void**)&c->join_pinned, words * 8 * 2, hipHostMallocDefault));
+        c->join_pinned_bytes = words * 8 * 2;
+    }
     unsigned long long* partial = nullptr;
     // Tables that fit LDS (one sample, up to ~3 000 miRNA references): 1024-thread workgroups keep them there while they walk
     // their reads, write one row each, and ONE column sum adds all rows to the ctx's tables -- no global atomic per read.
@@ -71,7 +77,9 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
                                (uint32_t)n_tab, partial + (size_t)rows_b * words);
         }
         LaunchScope ls(c, "k_join_reduce", (double)words);
-        hipLaunchKernelGGL(k_join_reduce, dim3((unsigned)((words + 63) / 64)), dim3(1024), 0, c->stream, partial, rows_b + rows_s, (uint32_t)words, d);
+        // ... written by the kernel into the page-locked tables the host reads (no copy behind it, nothing to clear)
+        hipLaunchKernelGGL(k_join_reduce, dim3((unsigned)((words + 63) / 64)), dim3(1024), 0, c->stream, partial, rows_b + rows_s, (uint32_t)words, d,
+                           c->join_pinned);
     } else {
         if (lazy) CHECK(stream_join(c));
         for (JoinGroups* gs : {&gb, &gsm}) {
@@ -82,17 +90,14 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
                                d, d + n_cls, d + n_cls + n_tab);
         }
     }
-    // one device-to-host copy through pinned memory for all three tables (they are contiguous)
-    if (words * 8 > c->join_pinned_bytes) {
-        if (c->join_pinned) (void)hipHostFree(c->join_pinned);
-        c->join_pinned = nullptr; c->join_pinned_bytes = 0;
-        HIPOK(hipHostMalloc((void**)&c->join_pinned, words * 8 * 2, hipHostMallocDefault));
-        c->join_pinned_bytes = words * 8 * 2;
+    bool cleared = true;  // the column sums went straight to the page-locked tables; the device tables are still zero
+    if (!by_rows) {
+        // one device-to-host copy through pinned memory for all three tables (they are contiguous)
+        HIPOK(hipMemcpyAsync(c->join_pinned, d, words * 8, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPOK(hipMemcpyAsync(c->join_pinned, d, words * 8, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipEventRecord(c->ev_meta, c->stream));
     // cleared for the next call now, behind the copy: the host waits for the copy only
-    const bool cleared = hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream) == hipSuccess;
+    if (!by_rows) cleared = hipMemsetAsync(d, 0, c->join_dev_words * 8, c->stream) == hipSuccess;
     hc.lap("enqueue");
     HIPOK(hipEventSynchronize(c->ev_meta));
     hc.lap("wait for the tables");
