@@ -22,14 +22,35 @@ def short(name):
 
 
 stats = glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True)
+# the distribution behind the --stats averages, from the kernel trace itself: a process's first launches of the cascade
+# kernels take tens of milliseconds (the whole device stalls while the first step's buffers are mapped), and one of them in
+# ~160 launches moves an average by 20 %; median / p10 / p90 and the average of the launches within 1.5 x the median say what a
+# launch takes once the process is warm (the launches bench.py times with HIP events)
+durs = defaultdict(list)
+for f in glob.glob(os.path.join(src, "kt", "**", "*kernel_trace.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            durs[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+
+def dist(name):
+    v = sorted(durs.get(name, []))
+    if not v:
+        return ["", "", "", "", ""]
+    med = v[len(v) // 2]
+    warm = [x for x in v if x <= 1.5 * med]
+    return [med, v[int(0.1 * (len(v) - 1))], v[int(0.9 * (len(v) - 1))], len(warm), f"{sum(warm) / len(warm):.0f}"]
+
+
 if stats:
     with open(stats[0]) as fh, open(os.path.join(root, f"{tag}_kernel_stats.csv"), "w", newline="") as out:
         rd = csv.DictReader(fh)
         wr = csv.writer(out)
-        wr.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent", "min_ns", "max_ns"])
+        wr.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent", "min_ns", "max_ns", "median_ns", "p10_ns", "p90_ns",
+                     "calls_within_1.5x_median", "avg_ns_of_those"])
         for r in rd:
             wr.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], f"{float(r['AverageNs']):.0f}",
-                         r['Percentage'], r['MinNs'], r['MaxNs']])
+                         r['Percentage'], r['MinNs'], r['MaxNs']] + dist(short(r['Name'])))
 acc = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(lambda: defaultdict(set))
 for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
