@@ -25,12 +25,14 @@ struct GroupView {
     uint32_t n;
 };
 
-template <int W>
+// HASN = false: the group holds no ambiguous call (its nmask is nullptr) and the caller says so at compile time -- the
+// zero masks then fold away in everything inlined behind the load (trimming, probe keys, verification)
+template <int W, bool HASN = true>
 __device__ __forceinline__ void load_read(const GroupView<W>& g, uint32_t i, MirgeRead<W>& r) {
 #pragma unroll
     for (int w = 0; w < W; w++) {
         r.w[w] = g.seq[(size_t)w * g.n + i];
-        r.nm[w] = g.nmask ? g.nmask[(size_t)w * g.n + i] : 0ull;
+        r.nm[w] = (HASN && g.nmask) ? g.nmask[(size_t)w * g.n + i] : 0ull;
     }
     r.len = g.len[i];
 }

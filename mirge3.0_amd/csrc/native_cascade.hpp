@@ -153,8 +153,13 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         LaunchScope ls(c, name, 0.0);
         if (ls.rec >= 0)
             for (size_t k = 0; k < steps.size(); k++) stage_of_pass.emplace_back(ls.rec, (int)k);  // units = reads handed to every pass
-        hipLaunchKernelGGL((k_cascade_bulk<W>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, v, actA, actB, seg_n, cap, out.pass, out.pos,
-                           out.mm, n_dev);
+        // (a group without ambiguous calls runs the build of the kernel in which the N masks are compile-time zeros)
+        if (rg.nmask)
+            hipLaunchKernelGGL((k_cascade_bulk<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, v, actA, actB, seg_n, cap, out.pass, out.pos,
+                               out.mm, n_dev);
+        else
+            hipLaunchKernelGGL((k_cascade_bulk<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, v, actA, actB, seg_n, cap, out.pass, out.pos,
+                               out.mm, n_dev);
         stage = (int)steps.size();
     } else
     for (const PassStep& st : steps) {
@@ -225,8 +230,12 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     std::snprintf(name, sizeof(name), "k_cascade_fused%s", gtag);
     LaunchScope ls(c, name, n);
     const uint32_t grid = std::min<uint32_t>((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (uint32_t)c->n_cu * 8);
-    hipLaunchKernelGGL(k_cascade_fused<W>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
-                       out.pos, out.mm, out.ref, out.off);
+    if (rg.nmask)
+        hipLaunchKernelGGL((k_cascade_fused<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
+                           out.pos, out.mm, out.ref, out.off);
+    else  // no ambiguous calls in the group: the build whose N masks are compile-time zeros
+        hipLaunchKernelGGL((k_cascade_fused<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
+                           out.pos, out.mm, out.ref, out.off);
     return 0;
 }
 
