@@ -67,6 +67,10 @@ def rocprof_symbol(rec_name):
         return f"{base}<{w}, {'true' if rec_name.endswith('n') else 'false'}>"
     if base in ("k_collapse_insert", "k_collapse_scatter"):
         return f"{base}<{w}>"
+    if base == "k_part_dedup":  # k_part_dedup<2048> / <4096>: one of them per sample size
+        return "k_part_dedup<"
+    if base == "k_join":  # the record covers the rows kernel (both launches) or the atomic forms
+        return "k_join_rows("
     return base + "("
 
 

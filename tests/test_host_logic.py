@@ -31,6 +31,26 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_bench_names_the_kernels_the_library_holds():
+    """bench.py finds the dominant kernel's PMC rows by a fragment of its demangled name (rocprof_symbol); a changed template
+    signature would turn `roofline.traffic` into null without anything failing -- every fragment must name a kernel of the
+    built library (its host-side launch stubs carry the names)."""
+    import importlib.util
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    so = os.path.join(os.path.dirname(_ffi.__file__), "csrc", "libmirge_native.so")
+    names = subprocess.run([nm, "-C", so], capture_output=True, text=True, check=True).stdout
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)  # main() is behind __name__ == "__main__"
+    for rec in ("k_cascade_bulk.w1", "k_cascade_bulk.w2", "k_cascade_fused.w2", "k_cascade_fused.w1n", "k_pass[0].w1",
+                "k_pass[4-6].w1", "k_pass[8].w2", "k_part_agg.w1", "k_part_dedup.w1", "k_part_split.w1", "k_resolve.w1",
+                "k_collapse_insert.w2", "k_collapse_scatter.w2n", "k_join", "k_join_reduce"):
+        frag = bench.rocprof_symbol(rec)
+        assert frag in names, (rec, frag)
+
+
 def test_policy_tables_agree_with_oracle():
     # the product's table and the oracle's are written independently from manifoldAlign.py:84-85
     for p, (col, key, args, kw) in enumerate(PASSES):
