@@ -27,6 +27,13 @@ import numpy as np  # noqa: E402
 
 RANDOM_SECTOR_PEAK_G = 55.0  # measured, tools/microbench_random.hip: L2-missing random loads, G/s
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+N_CU, SIMD_PER_CU, VALU_CYCLES_PER_WAVE64 = 256, 4, 4  # same guide: 256 CUs x 4 SIMD16; a wave64 vector instruction issues over 4 cycles
+SCLK_PEAK_MHZ = 2400.0
+
+# SURVEY.md 8(d), "Cascade (fused minimum)": 9 B in (8 B packed read + 1 B length) + 5 B out (1 B pass + 4 B reference id)
+# per COLLAPSED read, + 8 B per further word of a wider read.  The unit of k_cascade_bulk / k_cascade_fused -- one launch for
+# all passes of a read group -- is therefore the read of the group, not the read handed to a pass.
+CASCADE_BYTES_PER_READ = 9 + 5
 
 # Algorithmic bytes per unit (DESIGN.md "Kernels"): a packed short read is
 # 8 B + 1 B length; an annotation is pass 1 B + position 4 B (+ mismatches 1 B, not counted).
@@ -48,13 +55,24 @@ ALGO_BYTES = {
 }
 
 
-def algo_bytes(name):
-    """per-unit bytes of a profile record such as 'k_pass[6].w1' (w1/w2/w4 = 1/2/4-word reads)"""
+def algo_bytes(name, per_pass=False):
+    """per-unit bytes of a profile record such as 'k_pass[6].w1' (w1/w2/w4 = 1/2/4-word reads).  The whole-cascade kernels
+    (k_cascade_bulk, k_cascade_fused) are priced per collapsed read (14 B); per_pass=True gives k_pass's 18 B per
+    (read, pass) for the bulk kernel's secondary figure."""
     base, _, w = name.partition(".w")
     w = w.rstrip("n")  # 'n' = the group of reads with an ambiguous base call
     extra = 8 * (int(w) - 1) if w.isdigit() and (base.startswith("k_pass") or base.startswith("k_collapse") or base.startswith("k_cascade")) else 0
-    # k_cascade_bulk = the bulk group's passes in one launch: its unit is a read handed to a pass, as k_pass's
+    if base.startswith("k_cascade") and not per_pass:
+        return CASCADE_BYTES_PER_READ + extra
     return (ALGO_BYTES["k_pass"] if base.startswith(("k_pass", "k_cascade_bulk")) else ALGO_BYTES.get(base, 0)) + extra
+
+
+def group_index(rec_name):
+    """storage group of a profile record ('.w2n' -> 2-word reads with an N): index into DeviceReads.group_counts()"""
+    _, _, w = rec_name.partition(".w")
+    has_n = w.endswith("n")
+    w = w.rstrip("n")
+    return ({"1": 0, "2": 1, "4": 2, "8": 3, "16": 4}.get(w, 0), has_n)
 
 
 def rocprof_symbol(rec_name):
@@ -77,7 +95,8 @@ def rocprof_symbol(rec_name):
 def pmc_traffic(args, rec_name):
     """HBM bytes per launch of one kernel from the PMC counters, as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (no trace domains), kB units, and the gfx950
-    correction (FETCH_SIZE counts 128-B requests as 64 B -> x2).  Child processes; None on any failure."""
+    correction (FETCH_SIZE counts 128-B requests as 64 B -> x2); a third pass counts SQ_INSTS_VALU (wave-level vector
+    instructions) for the secondary, VALU-issue bound of SURVEY 8(d).  Child processes; None on any failure."""
     import csv
     import glob
     import shutil
@@ -91,7 +110,7 @@ def pmc_traffic(args, rec_name):
         return None
     frag = rocprof_symbol(rec_name)
     out = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         d = tempfile.mkdtemp(prefix="mirge_pmc_", dir="/tmp")
         # rocprofv3 is a python script: run it with this interpreter (no '#!/usr/bin/env' hop)
         cmd = [sys.executable, rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
@@ -108,16 +127,21 @@ def pmc_traffic(args, rec_name):
                         if r["Counter_Name"] == ctr and frag in r["Kernel_Name"]:
                             vals.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
             if not vals:
+                if ctr == "SQ_INSTS_VALU":  # the traffic stands without the secondary bound
+                    continue
                 return None
             gmax = max(g for g, _ in vals)  # the big read group's launches (the N / long-read groups share the symbol)
             sel = [v for g, v in vals if g == gmax]
             out[ctr] = sum(sel) / len(sel)
         except Exception:
+            if ctr == "SQ_INSTS_VALU":
+                continue
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {"fetch_kb_raw": out["FETCH_SIZE"], "write_kb": out["WRITE_SIZE"],
-            "bytes": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0}
+    return {"fetch_kb_raw": out["FETCH_SIZE"], "write_kb": out["WRITE_SIZE"], "valu_insts": out.get("SQ_INSTS_VALU"),
+            "bytes": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0,
+            "bytes_raw": (out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0}
 
 
 def reference_bowtie_dir():
@@ -305,8 +329,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
-    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--workload", default=None, choices=["c3", "c2", "c4", "c5"],
+                    help="default: c3 (BASELINE configs[2]) at N = 1, c4 (configs[3]: one 20 M-read sample per GPU) under torch.distributed.run")
+    ap.add_argument("--reads", type=int, default=None, help="raw reads per sample (default 10 M; 20 M for c4)")
     ap.add_argument("--scale", default="full", choices=["ci", "small", "full"])
     ap.add_argument("--two-calls", type=int, default=0, help="1: mirge_collapse then mirge_cascade_run instead of the one-call path")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -324,6 +349,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # BASELINE.json configs[3] is what a multi-GPU run measures: 8 samples x 20 M reads, one per GPU.  A run under
+    # torch.distributed.run that names no workload is that config (20 M reads per rank unless --reads says otherwise; the
+    # label in config.workload carries the actual numbers); N = 1 stays C3, the config `metric` is quoted on.
+    if args.workload is None:
+        args.workload = "c4" if world > 1 else "c3"
+    if args.reads is None:
+        args.reads = 20_000_000 if args.workload == "c4" else 10_000_000
     import torch
     dist = None
     # test hooks (tests/test_gpu_parity.py runs two ranks on the one GPU of the test box):
@@ -331,6 +363,7 @@ def main():
     backend = os.environ.get("MIRGE_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("MIRGE_BENCH_SHARE_GPU") else local_rank
     backend_note = None
+    rccl_ranks_seen = None
     if world > 1:
         import datetime
         import torch.distributed as dist
@@ -349,7 +382,8 @@ def main():
                 probe = torch.ones(1, device=f"cuda:{dev_index}")
                 dist.all_reduce(probe, group=nccl_pg)
                 torch.cuda.synchronize()
-                ok = int(int(probe.item()) == world)
+                rccl_ranks_seen = int(probe.item())  # the probe all-reduce's sum of ones: the ranks RCCL actually connected
+                ok = int(rccl_ranks_seen == world)
             except Exception as e:  # noqa: BLE001
                 ok = 0
                 nccl_pg = None
@@ -409,6 +443,8 @@ def main():
             state["tally"] = a2i.tally(casc, uniq, res)["count_true"]
         state["U"] = len(uniq)
         state["cls"] = cls
+        if state.get("want_groups"):
+            state["groups"] = uniq.group_counts()
         res.close()
         uniq.close()
 
@@ -427,8 +463,10 @@ def main():
     ctx.profile(True)
     ctx.profile_only("")
     ctx.profile_reset()
+    state["want_groups"] = True
     for _ in range(n_prof):
         step()
+    state["want_groups"] = False
     recs_all = ctx.profile_records()
     table = {name: dict(launches=l, avg_ms=ms / l, total_ms=ms, units_per_launch=u / l) for name, l, ms, u in recs_all if l}
     dom = max(table, key=lambda k: table[k]["total_ms"])
@@ -497,6 +535,14 @@ def main():
     kd = dict(timed.get(dom) or table[dom])
     if not kd["units_per_launch"]:
         kd["units_per_launch"] = table[dom]["units_per_launch"]
+    # the whole-cascade kernels are priced as SURVEY 8(d) prices them: 14 B per COLLAPSED read of their group (the profile
+    # record's own units are reads handed to passes, summed over the passes: kept as `per_pass_units`)
+    whole_cascade = dom.startswith("k_cascade")
+    per_pass_units = kd["units_per_launch"]
+    if whole_cascade:
+        gi, has_n = group_index(dom)
+        gc = state["groups"]
+        kd["units_per_launch"] = float(gc[gi + (len(gc) // 2 if has_n else 0)])
     achieved = algo_bytes(dom) * kd["units_per_launch"] / (kd["avg_ms"] * 1e-3) / 1e9
     n_tab_steps = n_prof
     stage_ms = {
@@ -511,9 +557,11 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {
-            "workload": {"c3": "C3: 10M-read human-like sample, collapse -> full 9-pass cascade -> count join, 1 sample per GPU",
-                         "c2": "C2: 10M-read human-like sample, collapse -> exact mature-miRNA pass only -> count join",
-                         "c5": "C5: collapse -> exact + <=2-mismatch isomiR passes vs the miRNA library -> count join -> "
+            "workload": {"c3": f"C3: {args.reads / 1e6:g}M-read human-like sample, collapse -> full 9-pass cascade -> count join, 1 sample per GPU",
+                         "c4": f"C4: {n_gpus} samples x {args.reads / 1e6:g}M reads sharded one-per-GPU (no RCCL on the data path; BASELINE "
+                               "configs[3] = 8 x 20M): every rank runs collapse -> full 9-pass cascade -> count join on its own human-like sample",
+                         "c2": f"C2: {args.reads / 1e6:g}M-read human-like sample, collapse -> exact mature-miRNA pass only -> count join",
+                         "c5": f"C5: {args.reads / 1e6:g}M reads, collapse -> exact + <=2-mismatch isomiR passes vs the miRNA library -> count join -> "
                                "per-position variant tally"}[args.workload],
             "raw_reads_per_gpu": args.reads, "unique_reads_per_gpu": U, "library_scale": args.scale,
             "read_templates": args.pool or None,
@@ -534,26 +582,39 @@ def main():
                     "step_ms_rank0 are host-clock times of single steps (a step ends with its count tables on the host)",
         },
         "barrier_backend": (backend if dist is not None else None), "barrier_backend_note": backend_note,
-        "collapsed_reads_per_s_M": round(n_gpus * U / (stage_ms["cascade"] * 1e-3) / 1e6, 3) if stage_ms["cascade"] else None,
+        "collapsed_reads_per_s_M": round(n_gpus * U / (ms_per_step * 1e-3) / 1e6, 3),
+        "collapsed_reads_note": "unique (collapsed) reads of the sample / ms_per_step: the cascade's input rate over the whole step "
+                                "(north_star's >= 50 M/s target is on this unit); `value` counts raw reads",
+        "rccl_ranks_seen": rccl_ranks_seen,
         "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
         "stage_ms_note": "sums of per-kernel HIP-event times from the profiled warm-up steps; kernels of the small read "
-                         "groups overlap the big group's on a second stream, so the sums exceed ms_per_step",
+                         "groups overlap the big group's on streams of their own, so the sums exceed ms_per_step",
         "roofline": {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
             "algorithmic_bytes_per_unit": algo_bytes(dom), "units_per_launch": round(kd["units_per_launch"], 1),
+            "unit_is": ("collapsed read of the kernel's read group (SURVEY.md 8d 'Cascade (fused minimum)': 9 B in + 5 B out); "
+                        "units_per_launch = reads of that group in the sample" if whole_cascade else
+                        "the record's own unit (DESIGN.md section 4 table)"),
             "avg_launch_ms": round(kd["avg_ms"], 5), "launches": kd["launches"],
-            "note": "latency / random-sector-bound integer kernel; HBM fraction reported as the brief requires; "
-                    "timed with HIP events on its launch stream inside the timed region"
-                    + ("; k_cascade_bulk = ALL passes of the bulk read group in one launch: a unit is a read handed to a pass "
-                       "(k_pass's 18 B), units_per_launch their sum over the passes (per-workgroup survivor counters, read back in the bracketed "
-                       "warm-up steps of the same batch: in the timed region only the kernel's duration is measured); "
-                       "MIRGE_BULK_FUSED=0 gives one launch per pass again" if dom.startswith("k_cascade_bulk") else ""),
+            "note": "integer / indexing kernel bound by random 64-B sectors and vector issue, not by streaming bandwidth; HBM "
+                    "fraction on SURVEY 8(d)'s algorithmic bytes as the brief requires; timed with HIP events on its launch stream "
+                    "inside the timed region"
+                    + ("; k_cascade_bulk = ALL passes of the bulk read group in one launch (MIRGE_BULK_FUSED=0: one launch per pass)"
+                       if dom.startswith("k_cascade_bulk") else ""),
         },
         "kernels": {k: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 5),
                         "units_per_launch": round(v["units_per_launch"], 1)} for k, v in sorted(kernels.items())},
         "setup_s": round(t_setup, 1),
     }
+    if whole_cascade and per_pass_units:
+        a18 = algo_bytes(dom, per_pass=True) * per_pass_units / (kd["avg_ms"] * 1e-3) / 1e9
+        out["roofline"]["per_pass_units"] = {
+            "units_per_launch": round(per_pass_units, 1), "algorithmic_bytes_per_unit": algo_bytes(dom, per_pass=True),
+            "achieved": round(a18, 3), "frac": round(a18 / HBM_PEAK_GBS, 6), "unit": "GB/s",
+            "note": "the same launch priced per (read, pass): a unit is a read handed to a pass (k_pass's 4 B index + 9 B read in, "
+                    "5 B out), summed over the passes from the per-workgroup survivor counters of the bracketed warm-up steps; "
+                    "rounds 1-3 reported this figure as `frac`"}
 
     # ---------------- the same from the FILE's text (never `value`): FASTQ bytes in host memory -> records parsed,
     # filtered, packed on the GPU -> collapse -> cascade -> count tables on the host
@@ -570,6 +631,7 @@ def main():
             best_dt = dt if best_dt is None else min(best_dt, dt)
             ok_t = n_rec == len(reads) and len(u_t) == state["U"] and np.array_equal(cls_t, state["cls"])
             res_t.close(); u_t.close(); r_t.close()
+        out["raw_reads_per_s_fastq_in_M"] = round(args.reads / best_dt / 1e6, 2)  # SURVEY 8(d) "raw reads/s": FASTQ records in -> counts out
         out["fastq_text_path"] = {"M_reads_per_s": round(args.reads / best_dt / 1e6, 2), "ms": round(best_dt * 1e3, 2),
                                   "text_MB": round(text.size / 1e6, 1), "same_counts_as_step": bool(ok_t),
                                   "note": "FASTQ text (4-line records, pageable host memory) over PCIe, mirge_reads_parse on the "
@@ -692,13 +754,18 @@ def main():
     if rank == 0 and n_gpus == 1 and args.pmc:
         t = pmc_traffic(args, dom)
         if t is not None:
+            algo_launch = algo_bytes(dom) * kd["units_per_launch"]
             out["roofline"]["traffic"] = round(t["bytes"], 1)
+            out["roofline"]["traffic_raw"] = round(t["bytes_raw"], 1)
             out["roofline"]["traffic_detail"] = {
                 "unit": "bytes per launch", "FETCH_SIZE_kB_raw": round(t["fetch_kb_raw"], 1),
                 "WRITE_SIZE_kB": round(t["write_kb"], 1),
-                "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B; "
-                           "calibrated for wide streaming reads only, so an upper bound for this kernel's 16-B random reads)",
-                "algorithmic_bytes_per_launch": round(algo_bytes(dom) * kd["units_per_launch"], 1),
+                "formula": "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B; the x2 is "
+                           "calibrated for wide streaming reads, so an upper bound for this kernel's 8/16-B random reads); "
+                           "traffic_raw = (FETCH_SIZE + WRITE_SIZE)*1024 (every request taken as one 64-B sector: the lower bound)",
+                "algorithmic_bytes_per_launch": round(algo_launch, 1),
+                "traffic_over_algorithmic": round(t["bytes"] / max(algo_launch, 1.0), 2),
+                "traffic_raw_over_algorithmic": round(t["bytes_raw"] / max(algo_launch, 1.0), 2),
             }
             # the resource this kernel actually consumes: L2-missing 64-B sectors of random table reads
             sectors = t["fetch_kb_raw"] * 1024.0 / 64.0
@@ -709,6 +776,20 @@ def main():
                 "note": "FETCH_SIZE raw (one 64-B request per random read) / launch time; peak = independent random "
                         "4-B loads from a 0.25-16 GB table on this chip, tools/microbench_random.hip "
                         "(profiles/r01_microbench_random.txt)"}
+            if t.get("valu_insts"):
+                # SURVEY 8(d)'s second bound: vector-instruction issue.  A wave64 VALU instruction occupies its SIMD16 for 4
+                # cycles, so the chip issues at most CUs x 4 SIMDs x sclk / 4 of them per second.
+                sclk = SCLK_PEAK_MHZ
+                ck = (clocks_after or {}).get(f"card{dev_index}") if dev_index == 0 else None  # sysfs order is only known for the first card
+                if ck and ck > 500:
+                    sclk = float(ck)
+                peak = N_CU * SIMD_PER_CU * sclk * 1e6 / VALU_CYCLES_PER_WAVE64 / 1e9
+                ach = t["valu_insts"] / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+                out["roofline"]["valu"] = {
+                    "insts_per_launch": round(t["valu_insts"], 1), "achieved": round(ach, 2), "peak": round(peak, 1),
+                    "unit": "G wave-level VALU instructions/s", "frac": round(ach / peak, 4), "sclk_mhz": sclk,
+                    "note": "SQ_INSTS_VALU (own --pmc pass) x 4 issue cycles / (256 CUs x 4 SIMDs x sclk x launch time): the share "
+                            "of the chip's vector-issue cycles the kernel uses"}
     if rank == 0:
         print(json.dumps(out))
     raw.close()

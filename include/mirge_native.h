@@ -153,6 +153,9 @@ void mirge_reads_destroy(mirge_reads* reads);
 int64_t mirge_reads_count(const mirge_reads* reads);
 int64_t mirge_reads_total_bases(const mirge_reads* reads);
 int32_t mirge_reads_n_samples(const mirge_reads* reads);
+/* reads per storage group (width class x {no ambiguous call, has an N}): out[0 .. min(cap, groups)), returns the
+ * number of groups.  Diagnostics and bench.py's units: "collapsed reads of the bulk group" is the largest entry. */
+int32_t mirge_reads_group_counts(const mirge_reads* reads, int64_t* out, int32_t cap);
 /* sequences back as ASCII: ascii_out[total_bases], offsets_out[n+1], in handle order */
 int mirge_reads_unpack(mirge_ctx* ctx, const mirge_reads* reads, char* ascii_out, int64_t* offsets_out);
 

@@ -79,7 +79,11 @@ class Cascade:
                 if target is not None:  # read from its FASTA / .ebwt just now: keep the packed image next to the index
                     from . import libcache
                     t0 = time.perf_counter()
-                    libcache.save(target[0], libs[key], self._dev[key].packed_image(), target[1])
+                    try:  # the cache is optional: whatever goes wrong while writing it must not end the run
+                        libcache.save(target[0], libs[key], self._dev[key].packed_image(), target[1])
+                    except Exception as e:  # noqa: BLE001
+                        import logging
+                        logging.getLogger("mirge3_amd").warning("library cache of %s not written: %r", target[0], e)
                     libs[key].cache_target = None
                     self.timing["cache_write_s"] = self.timing.get("cache_write_s", 0.0) + time.perf_counter() - t0
             self.dev_libs.append(self._dev[key])

@@ -133,11 +133,12 @@ def validate_files(args, in_files, runlog, loud=True):
     with open(runlog, "a+") as outlog:
         for f in in_files:
             p = Path(f)
-            filetype = "".join(p.suffixes) if p.suffix == ".gz" else p.suffix
-            if p.exists() and filetype.endswith(FASTQ_SUFFIXES):
+            # the extension the name ends in (longest first: '.fastq.gz' before '.gz'-less forms); what is in front of it -- it
+            # must not be empty -- names the sample
+            ext = next((e for e in sorted(FASTQ_SUFFIXES, key=len, reverse=True) if p.name.endswith(e)), None)
+            if p.exists() and ext is not None and len(p.name) > len(ext):
                 full.append(str(p.resolve()))
-                parts = p.name.split(".")
-                names.append(".".join(parts[:-2]) if p.suffix == ".gz" else ".".join(parts[:-1]))
+                names.append(p.name[:-len(ext)])
                 continue
             why = f"\nWARNING: File {f} does not exists!" if not p.exists() else f"\nWARNING: File {f} is neither fastq or fastq.gz format!"
             if loud and not args.quiet:
@@ -189,7 +190,12 @@ def main(argv=None):
     # MIRGE_SHARE_GPU=1 (test hook): every rank uses device 0 of a single-GPU box
     args.device = (0 if os.environ.get("MIRGE_SHARE_GPU") else local_rank) if args.device is None else args.device
     ref_db = DB_KEYS.get(args.mir_DB.lower()) or sys.exit("ERROR: Require valid database (-d miRBase or MirGeneDB)")
-    name = args.outDirName or ("miRge." + time.strftime('%Y-%m-%d_%H-%M-%S', time.localtime()))
+    dist = None
+    if world > 1:  # before the run's directory is named: the ranks must agree on it (multigpu.agree_on_run_directory)
+        import torch.distributed as dist
+        dist.init_process_group("gloo")  # per-sample results of some MB: host-side gather, no device collective
+    from . import multigpu
+    name = multigpu.agree_on_run_directory(args.outDirName, rank, world, dist)
     workDir = Path(args.outDir or Path.cwd()) / name
     workDir.mkdir(exist_ok=True, parents=True)
     if rank == 0:
@@ -238,18 +244,15 @@ def main(argv=None):
         pdMapped.to_csv(workDir / "mapped.csv")
         pdUnmapped.to_csv(workDir / "unmapped.csv")
     else:
-        import torch.distributed as dist
-        from . import multigpu
-        from .cascade import get_cascade, EXACT_PASS, ISO_PASS
-        from .seqio import load_merges
-        dist.init_process_group("gloo")  # per-sample results of some MB: host-side gather, no device collective
+        from .cascade import get_cascade
         casc = get_cascade(args, ref_db, args.device)
 
         if not fastpath.eligible(args):
             sys.exit("-spl / -rr are single-process options")
+        via_files = multigpu.directory_is_shared(workDir, rank, world, dist)  # False on a node that does not see rank 0's directory
 
         def process(i):  # device-resident per sample (fastpath.run_sample_tables)
-            return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc)
+            return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc, via_files)
 
         tables = multigpu.run_sharded(len(files), rank, world, process, dist)
         if rank == 0:  # the same files as the one-process run: count tables, ONE mapped.csv / unmapped.csv, -gff / -ai / -ie

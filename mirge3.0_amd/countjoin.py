@@ -131,69 +131,57 @@ def _calc_entropy(values) -> float:
     return e
 
 
-def isomir_entropy_tables(pdMapped, base_names, Filtered_miRNA_Reads, workDir):
-    """``-ie`` (``create_ie``, summary.py:915-1021): ``isomirs.csv`` (one line per isomiR sequence: RPM per sample and
-    its across-sample entropy, tab separated under a comma separated header, as the reference writes it) and
-    ``isomirs.samples.csv`` (per miRNA and sample: entropy of isomiRs + canonical, canonical share, canonical RPM,
-    top isomiR RPM).  Input: the mapped rows with their 'exact miRNA' / 'isomiR miRNA' names and sample counts."""
+def isomir_entropy_tables(pdMapped, base_names, filtered_totals, workDir):
+    """``-ie`` (what the reference's ``create_ie`` writes, summary.py:915-1021; outside SURVEY.md 8's rows, kept because the
+    golden cases hold its two files): ``isomirs.csv`` -- one line per isomiR sequence with its RPM per sample and its
+    across-sample entropy, tab separated under a comma separated header, as the reference writes it -- and
+    ``isomirs.samples.csv`` -- per miRNA and sample: entropy of isomiRs + canonical, canonical share, canonical RPM, top
+    isomiR RPM.  Input: the mapped rows with their 'exact miRNA' / 'isomiR miRNA' names and sample counts;
+    ``filtered_totals[sample]`` = 'Filtered miRNA Reads'.  The float expressions keep the reference's operand order: the
+    files are compared byte for byte."""
     import math
-    base_names = list(base_names)
-    seqs = [str(x) for x in pdMapped.index]
-    cnt = pdMapped[base_names].to_numpy(dtype=np.int64).tolist()
-    exact = pdMapped['exact miRNA'].tolist()
-    iso = pdMapped['isomiR miRNA'].tolist()
-    freq_list = []
-    for fname in base_names:
-        try:
-            freq_list.append(1000000 / Filtered_miRNA_Reads[fname])
-        except ZeroDivisionError:
-            freq_list.append(0)
-    maxEntropy = math.log(len(base_names), 2)
+    samples = list(base_names)
+    S = len(samples)
+    table = pdMapped[samples].to_numpy(dtype=np.int64)
+    sequences = [str(x) for x in pdMapped.index]
+    # (a Python zero gives 0, a numpy zero goes through the division and gives inf -- as the reference's expression does)
+    per_million = [0 if (type(filtered_totals[b]) is int and filtered_totals[b] == 0) else 1000000 / filtered_totals[b] for b in samples]
+    h_max = math.log(S, 2)
 
-    def strip_snp(name):
+    def family(name):  # a SNP variant counts towards its miRNA
         return name.split('.')[0] if ".SNP" in name else name
 
-    miR_can: Dict[str, list] = {}
-    for i, nm in enumerate(exact):
+    # rows of every family: canonical rows summed per sample, isomiR rows kept one by one (in table order)
+    canonical: Dict[str, np.ndarray] = {}
+    for i, nm in enumerate(pdMapped['exact miRNA'].tolist()):
         if nm:
-            miR_can.setdefault(strip_snp(nm), []).append(cnt[i])
-    for k, v in miR_can.items():
-        miR_can[k] = [sum(col) for col in zip(*v)]
-    lines1 = ['miRNA,sequence' + ''.join(',' + b for b in base_names) + ',Entropy\n']
-    miR_iso: Dict[str, list] = {}
-    for i, nm in enumerate(iso):
+            key = family(nm)
+            canonical[key] = canonical.get(key, 0) + table[i]
+    variants: Dict[str, List[int]] = {}
+    per_sequence = ['miRNA,sequence' + ''.join(',' + b for b in samples) + ',Entropy\n']
+    for i, nm in enumerate(pdMapped['isomiR miRNA'].tolist()):
         if not nm:
             continue
-        vals = cnt[i]
-        entropy = "NA" if maxEntropy == 0 else str(_calc_entropy(vals) / maxEntropy)
-        rpm = "\t".join(str(v * freq_list[k]) for k, v in enumerate(vals))
-        name = strip_snp(nm)
-        miR_iso.setdefault(name, []).append(vals)
-        lines1.append(name + "\t" + seqs[i] + "\t" + rpm + "\t" + entropy + "\n")
-    hdr2 = 'miRNA'
-    for b in base_names:
-        hdr2 += ',' + b + ' isomir+miRNA Entropy' + ',' + b + ' Canonical Sequence' + ',' + b + ' Canonical RPM' + ',' + b + ' Top Isomir RPM'
-    lines2 = [hdr2 + '\n']
-    for name, rows in miR_iso.items():
-        out = [name]
-        for k, col in enumerate(zip(*rows)):
-            vals = list(col)
-            top = max(vals) * freq_list[k]
-            iso_sum = sum(vals) * freq_list[k]
-            if name in miR_can:
-                can_rpm = miR_can[name][k] * freq_list[k]
-                e = _calc_entropy(vals + [miR_can[name][k]])
-                out.append(str(e / (math.log(len(vals), 2))) if len(vals) > 1 else 'NA')
-                combined = can_rpm + iso_sum
-                out.append(str(100.0 * can_rpm / combined) if combined > 0 else 'NA')
-                out.append(str(can_rpm))
-                out.append(str(top))
-        if len(out) > 1:
-            lines2.append(','.join(out) + '\n')
-    with open(Path(workDir) / "isomirs.csv", 'w') as fh:
-        fh.write("".join(lines1))
-    with open(Path(workDir) / "isomirs.samples.csv", 'w') as fh:
-        fh.write("".join(lines2))
+        key = family(nm)
+        variants.setdefault(key, []).append(i)
+        row = table[i].tolist()
+        spread = "NA" if h_max == 0 else str(_calc_entropy(row) / h_max)
+        per_sequence.append("\t".join([key, sequences[i]] + [str(v * per_million[k]) for k, v in enumerate(row)] + [spread]) + "\n")
+    per_mirna = ['miRNA' + ''.join(f',{b} isomir+miRNA Entropy,{b} Canonical Sequence,{b} Canonical RPM,{b} Top Isomir RPM' for b in samples) + '\n']
+    for key, members in variants.items():
+        if key not in canonical:  # isomiRs of a miRNA without canonical reads: no line (the reference's left join)
+            continue
+        can = canonical[key].tolist()
+        cells = [key]
+        for k in range(S):
+            col = table[members, k].tolist()
+            can_rpm = can[k] * per_million[k]
+            both = can_rpm + sum(col) * per_million[k]
+            cells += [str(_calc_entropy(col + [can[k]]) / math.log(len(col), 2)) if len(col) > 1 else 'NA',
+                      str(100.0 * can_rpm / both) if both > 0 else 'NA', str(can_rpm), str(max(col) * per_million[k])]
+        per_mirna.append(','.join(cells) + '\n')
+    (Path(workDir) / "isomirs.csv").write_text("".join(per_sequence))
+    (Path(workDir) / "isomirs.samples.csv").write_text("".join(per_mirna))
 
 
 def summarize_device(ctx: _ffi.Context, uniq: _ffi.DeviceReads, res: _ffi.CascadeResult, mirna: Library,

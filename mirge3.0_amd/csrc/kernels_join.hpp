@@ -103,12 +103,12 @@ k_join_rows(JoinGroups gs, int32_t S, int32_t n_pass, int32_t exact_pass, int32_
         // the bulk group of one sample: four reads per thread and sweep, their loads issued together (16 dependent
         // pass -> reference -> count walks per thread before: 23 us for 38 MB)
         const int8_t* __restrict__ gp = gs.pass[0]; const int32_t* __restrict__ gr = gs.ref[0]; const uint32_t* __restrict__ gc = gs.counts[0];
-        const uint32_t stride = gridDim.x * blockDim.x;
-        for (uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += 4 * stride) {
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;  // 64-bit: t0 + 3 * stride passes 2^32 for a group near that size
+        for (uint64_t t0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += 4 * stride) {
             int p[4]; uint32_t r[4]; unsigned long long c[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t i = t0 + (uint32_t)u * stride;
+                const uint64_t i = t0 + (uint64_t)u * stride;
                 const bool in = i < total;
                 p[u] = in ? (int)gp[i] : -1;
                 r[u] = in ? (uint32_t)gr[i] : 0u;

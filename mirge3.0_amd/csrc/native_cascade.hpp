@@ -316,6 +316,30 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         f.plan = steps[i].dplan;
         f.pass_id = steps[i].p0;
     }
+    // Where k_cascade_bulk compacts its survivor lists (FusedSteps::walk_last).  Consecutive steps of one REGIME are walked
+    // together, up to MIRGE_WALK_MAX of them: light (a library that stays in L2, at most one mismatch: the list walk costs as
+    // much as the alignment), sector-bound (a library beyond ~4 M bases: every probe is an L2-missing sector), and the
+    // <= 2-mismatch passes, whose verification runs for the whole wave and wants dense lanes.  Human set: [0 1 2 3] [4-6 7] [8].
+    // MIRGE_WALKS="4,2,1" (step counts per walk) overrides; "1,1,1,1,1,1,1" is round 3's one list per step.
+    {
+        auto regime = [&](size_t i) {
+            if (pol[steps[i].p0].mm >= 2) return 2;
+            return steps[i].lib->h.total >= (4ull << 20) ? 1 : 0;
+        };
+        std::vector<int> sizes;
+        if (const char* e = std::getenv("MIRGE_WALKS"))
+            for (const char* q = e; *q;) { sizes.push_back(std::max(1, std::atoi(q))); while (*q && *q != ',') q++; if (*q) q++; }
+        size_t i = 0, w = 0;
+        while (i < steps.size()) {
+            size_t len = 1;
+            if (w < sizes.size()) len = (size_t)std::min(sizes[w], MIRGE_WALK_MAX);
+            else if (sizes.empty())
+                while (i + len < steps.size() && len < MIRGE_WALK_MAX && regime(i + len) == regime(i)) len++;
+            len = std::min(len, steps.size() - i);
+            fs->walk_last[i + len - 1] = 1;
+            i += len; w++;
+        }
+    }
     const FusedSteps* dsteps = nullptr;
     for (auto& e : c->fused)
         if (std::memcmp(e.host.get(), fs.get(), sizeof(FusedSteps)) == 0) { dsteps = e.dev; break; }

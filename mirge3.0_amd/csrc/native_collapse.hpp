@@ -415,6 +415,7 @@ extern "C" int mirge_collapse_order(mirge_ctx* c, const mirge_reads* U, int64_t*
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const size_t n = (size_t)U->n;
     if (!n) return 0;
+    if (n >= 0x7FFFFFFFull) return fail(-5, "mirge_collapse_order: 2^31 unique reads or more (hipCUB's sort takes an int count)");
     uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
     CHECK(dalloc(c, &keys, n)); CHECK(dalloc(c, &vals, n)); CHECK(dalloc(c, &keys2, n)); CHECK(dalloc(c, &vals2, n));
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {

@@ -177,6 +177,9 @@ extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, c
     if (!c || !U || !res || !header || (!rows && n_rows) || n_rows < 0 || n_pass < 1 || n_pass > MIRGE_MAX_PASSES || !col_of_pass ||
         n_name_cols < 0 || !name_data || !name_off || !name_n || U->n_samples < 1 || res->n != U->n || n_rows >= 0xFFFFFFF0ll)
         return fail(-1, "mirge_annotation_csv_device: bad argument");
+    // hipCUB's scans take an `int` item count: beyond 2^31 - 2 rows the caller formats on the host (mirge_annotation_csv), as
+    // it does for names that need quoting
+    if (n_rows >= 0x7FFFFFFEll) return fail(-4, "mirge_annotation_csv_device: 2^31 rows or more (host route)");
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     HostClock hc("annotation_csv_device");
     CsvTables t;
@@ -356,6 +359,7 @@ extern "C" int mirge_collapse_order_sorted(mirge_ctx* c, const mirge_reads* U, i
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     const size_t n = (size_t)U->n;
     if (!n) return 0;
+    if (n >= 0x7FFFFFFFull) return fail(-5, "mirge_collapse_order_sorted: 2^31 unique reads or more (hipCUB's sort takes an int count)");
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
         if (U->g[gi].n && U->g[gi].orig) return fail(-1, "mirge_collapse_order_sorted: handle is not a collapse result");
     int maxlen = MIRGE_MAX_READ_LEN;

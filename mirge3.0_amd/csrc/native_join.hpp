@@ -41,8 +41,18 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     // main stream's own order): k_join_rows of 4.2 M reads runs beside the tail of the small groups' cascades instead of
     // behind the wait for them.  Otherwise: everything in one launch with atomics (k_join_multi).
     static const bool rows_off = std::getenv("MIRGE_JOIN_ROWS") && std::atoi(std::getenv("MIRGE_JOIN_ROWS")) == 0;  // A/B
+    // `join_pending` stays set until stream_join has actually been issued: an early return below (argument check, out of
+    // memory) then leaves the side streams to the next entry point's join_pending_now instead of unjoined for good
     const bool lazy = c->join_pending;
-    c->join_pending = false;
+    auto join_side_streams = [&]() -> int {
+        if (!lazy || !c->join_pending) return 0;
+        c->join_pending = false;
+        return stream_join(c);
+    };
+    struct PoolBlock {  // `partial` goes back to the pool on every way out
+        mirge_ctx* c; unsigned long long*& p;
+        ~PoolBlock() { c->release(p); p = nullptr; }
+    } partial_guard{c, partial};
     const int big = largest_group(U);
     auto group_list = [&](bool bulk, JoinGroups& gs) -> uint64_t {
         std::memset(&gs, 0, sizeof(gs));
@@ -70,7 +80,7 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
             hipLaunchKernelGGL(k_join_rows, dim3(rows_b), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, gb, S, P, exact_pass, iso_pass,
                                (uint32_t)n_tab, partial);
         }
-        if (lazy) CHECK(stream_join(c));
+        CHECK(join_side_streams());
         if (rows_s) {
             LaunchScope ls(c, "k_join", (double)n_small);
             hipLaunchKernelGGL(k_join_rows, dim3(rows_s), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, gsm, S, P, exact_pass, iso_pass,
@@ -81,7 +91,7 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
         hipLaunchKernelGGL(k_join_reduce, dim3((unsigned)((words + 63) / 64)), dim3(1024), 0, c->stream, partial, rows_b + rows_s, (uint32_t)words, d,
                            c->join_pinned);
     } else {
-        if (lazy) CHECK(stream_join(c));
+        CHECK(join_side_streams());
         for (JoinGroups* gs : {&gb, &gsm}) {
             const uint64_t total = gs == &gb ? n_bulk : n_small;
             if (!total) continue;
@@ -102,7 +112,6 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
     HIPOK(hipEventSynchronize(c->ev_meta));
     hc.lap("wait for the tables");
     c->join_dev_clean = cleared;
-    c->release(partial);
     std::memcpy(class_sums, c->join_pinned, n_cls * 8);
     if (n_mirna) {
         std::memcpy(exact, c->join_pinned + n_cls, (size_t)n_mirna * S * 8);

@@ -132,6 +132,11 @@ extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts,
 extern "C" int64_t mirge_reads_count(const mirge_reads* r) { return r ? r->n : -1; }
 extern "C" int64_t mirge_reads_total_bases(const mirge_reads* r) { return r ? r->total_bases : -1; }
 extern "C" int32_t mirge_reads_n_samples(const mirge_reads* r) { return r ? r->n_samples : -1; }
+extern "C" int32_t mirge_reads_group_counts(const mirge_reads* r, int64_t* out, int32_t cap) {
+    if (!r) return -1;
+    for (int gi = 0; gi < MIRGE_NGROUPS && out && gi < cap; gi++) out[gi] = r->g[gi].n;
+    return MIRGE_NGROUPS;
+}
 extern "C" int32_t mirge_reads_iupac_seen(const mirge_reads* r) { return r ? (r->iupac_seen ? 1 : 0) : -1; }
 
 template <int W>
@@ -582,6 +587,7 @@ extern "C" int mirge_reads_parse_umi(mirge_ctx* c, const char* text, int64_t nby
         if (rc) break;
         reads_clear_groups(R.get());
         if (!U) break;
+        if (U >= 0x7FFFFFFFll) { rc = fail(-5, "mirge_reads_parse_umi: 2^31 distinct tagged reads or more (hipCUB's sort takes an int count)"); break; }
         if ((rc = dalloc(c, &keys, (size_t)U))) break;
         if ((rc = dalloc(c, &keys2, (size_t)U))) break;
         hipError_t e = hipSuccess;

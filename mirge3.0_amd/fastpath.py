@@ -62,7 +62,7 @@ def names_by_pass(casc) -> list:
     return cached
 
 
-def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None):
+def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None, via_files: bool = True):
     """One sample on this process's GPU, for the sharded CLI (one sample per rank, multigpu.py): device-resident parse ->
     collapse + cascade -> count join.  Returns the sample's ``SampleTables`` (a few kB: its columns of the count tables)
     with its ``SampleReads`` attached (unique reads in dictionary order, counts, annotation: what rank 0 needs for the
@@ -87,8 +87,9 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     ps, ref, _, _ = res.fetch()
     out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
     reads = multigpu.SampleReads(seqs.data, seqs.offsets, counts[order, 0], ps[order], ref[order], iupac)
-    # handed to rank 0 through files in the run's directory (same node): a sample's dictionary is tens to hundreds of MB
-    out.reads = reads.to_files(workDir / ".mirge_shards", index)
+    # handed to rank 0 through files in the run's directory when rank 0 sees that directory (same node / shared filesystem:
+    # a sample's dictionary is tens to hundreds of MB), in-band with the tables otherwise
+    out.reads = reads.to_files(workDir / ".mirge_shards", index) if via_files else reads
     res.close(); uniq.close()
     return out
 

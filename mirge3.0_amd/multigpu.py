@@ -98,6 +98,43 @@ def merge_tables(tables: Sequence[SampleTables]):
     return names, src, trimmed, uniq, cls, ex, iso
 
 
+def agree_on_run_directory(name: Optional[str], rank: int, world: int, dist=None) -> str:
+    """The run's directory name, the same on every rank.  Without ``-onam`` it carries the start time to the second
+    (mirge/__main__.py:69-75), and ranks that start either side of a second boundary would each make up their own: rank 0
+    chooses, the others take its choice (one broadcast, right after the process group exists)."""
+    import time
+    if rank == 0 and not name:
+        name = "miRge." + time.strftime('%Y-%m-%d_%H-%M-%S', time.localtime())
+    if world == 1 or dist is None:
+        return name
+    box = [name if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def directory_is_shared(directory, rank: int, world: int, dist=None) -> bool:
+    """True on a rank that sees the files rank 0 writes into ``directory`` (same node, or a shared filesystem): rank 0 drops
+    a token file, everybody looks for it.  A rank that does not see it sends its dictionaries in-band (``gather_object``)
+    instead of through files there."""
+    import os
+    import uuid
+    if world == 1 or dist is None:
+        return True
+    box = [uuid.uuid4().hex if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    token = os.path.join(str(directory), ".mirge_probe_" + box[0])
+    if rank == 0:
+        os.makedirs(str(directory), exist_ok=True)
+        with open(token, "w") as fh:
+            fh.write("x")
+    dist.barrier()
+    seen = os.path.exists(token)
+    dist.barrier()
+    if rank == 0:
+        os.unlink(token)
+    return seen
+
+
 def run_sharded(n_samples: int, rank: int, world: int, process: Callable[[int], SampleTables], dist=None):
     """Run ``process(i)`` for this rank's samples and gather on rank 0."""
     mine = assign_samples(n_samples, world)[rank]

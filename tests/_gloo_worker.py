@@ -22,6 +22,21 @@ def main():
     out_dir = sys.argv[1]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    # the run's directory: without -onam its name carries the start time to the second; the ranks of this test reach this line
+    # more than a second apart and must still end up with rank 0's choice (multigpu.agree_on_run_directory)
+    import time
+    time.sleep(1.2 * rank)
+    name = multigpu.agree_on_run_directory(None, rank, world, dist)
+    names = [None] * world
+    dist.all_gather_object(names, name)
+    assert names == [names[0]] * world and name.startswith("miRge."), names
+    assert multigpu.agree_on_run_directory("given", rank, world, dist) == "given"
+    # a directory every rank sees rank 0's files in -> hand-over through files; one that a rank does not see them in (here: a
+    # different path per rank stands in for another node's local disk) -> that rank sends in-band
+    assert multigpu.directory_is_shared(out_dir, rank, world, dist) is True
+    private = os.path.join(out_dir, f"node{rank}")
+    os.makedirs(private, exist_ok=True)
+    assert multigpu.directory_is_shared(private, rank, world, dist) is (rank == 0)
     case = GoldenCase("case2_two_samples")
     exp = case.expected_annotation()
     mir = case.libs["mirna"]

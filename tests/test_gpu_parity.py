@@ -800,6 +800,9 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    # under torch.distributed.run without --workload the line describes BASELINE configs[3], with the numbers actually run
+    assert d["config"]["workload"].startswith("C4: 2 samples x 0.3M reads") and d["config"]["raw_reads_per_gpu"] == 300000
+    assert "rccl_ranks_seen" in d and d["rccl_ranks_seen"] is None  # gloo carried the barrier: RCCL was not probed
     assert d["barrier_backend"] == "gloo" and d["timing"]["timed_seconds"] >= 0.5 and d["timing"]["regions"] >= 1  # --min-seconds 0.5 below
     assert d["timing"]["timed_steps"] == d["timing"]["regions"] * 2
     # the RCCL guard: when RCCL cannot come up (here: made to fail; on this box two ranks on one GPU would fail by themselves)
@@ -811,6 +814,7 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["barrier_backend"] == "gloo" and "forced" in d["barrier_backend_note"] and d["timing"]["regions"] == 1 and d["value"] > 0
+    assert d["rccl_ranks_seen"] is None and d["config"]["workload"].startswith("C4:")
 
 
 def test_bench_single_gpu_line(tmp_path):
@@ -838,6 +842,15 @@ def test_bench_single_gpu_line(tmp_path):
     assert "workload" in d["config"] and "model" not in d["config"]
     ro = d["roofline"]
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-5
+    # the whole-cascade kernel is priced at 14 B per collapsed read of its group; the per-(read, pass) figure stays beside it
+    if ro["kernel"].startswith("k_cascade"):
+        assert ro["algorithmic_bytes_per_unit"] == 14 + 8 * (int(ro["kernel"].partition(".w")[2].rstrip("n")) - 1)
+        assert 0 < ro["units_per_launch"] <= d["config"]["unique_reads_per_gpu"]
+        assert abs(ro["achieved"] - ro["algorithmic_bytes_per_unit"] * ro["units_per_launch"] / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-2 * ro["achieved"] + 1e-3
+        pp = ro["per_pass_units"]
+        assert pp["units_per_launch"] >= ro["units_per_launch"] and pp["frac"] >= ro["frac"]
+    assert abs(d["collapsed_reads_per_s_M"] - d["config"]["unique_reads_per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["collapsed_reads_per_s_M"]
+    assert d["raw_reads_per_s_fastq_in_M"] == d["fastq_text_path"]["M_reads_per_s"] and d["config"]["workload"].startswith("C3: 0.4M-read")
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert d["parity_on_cpu_sample"] is True and d["fastq_text_path"]["same_counts_as_step"] is True
@@ -1130,18 +1143,20 @@ def test_collapse_count_matrix_beyond_2_to_32_cells(ctx):
     raw.close()
 
 
-@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0")])
+@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0"),
+                                   dict(MIRGE_FUSED_MAX="0", MIRGE_WALKS="1,1,1,1,1,1,1,1,1,1"), dict(MIRGE_FUSED_MAX="0", MIRGE_WALKS="2,3,1,4")])
 def test_staged_cascade_for_every_group(hooks):
     """Small read groups normally take k_cascade_fused (one launch for the whole cascade, no compaction); MIRGE_FUSED_MAX=0
-    sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch), or
-    with MIRGE_BULK_FUSED=0 one k_pass launch per pass.  All must agree with the oracle: the oracle parity tests of this
-    file and the cascade fuzz are re-run in a fresh process with the hooks set."""
+    sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch, the
+    steps taken in walks: MIRGE_WALKS forces one list per step, as round 3 had it, and an arbitrary grouping), or with
+    MIRGE_BULK_FUSED=0 one k_pass launch per pass.  All must agree with the oracle: the oracle parity tests of this file, the
+    one-call route (full cascade and the one-pass C2 cascade) and the cascade fuzz are re-run in a fresh process with the hooks set."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
                         os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k",
-                        "vs_oracle or vs_bruteforce or low_complexity or edge_cases or golden_cascade or random_cascade"],
+                        "vs_oracle or vs_bruteforce or low_complexity or edge_cases or golden_cascade or random_cascade or one_call"],
                        env=dict(os.environ, **hooks), capture_output=True, text=True, timeout=1500, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -1155,6 +1170,7 @@ def test_collapse_cascade_one_call_equals_two_calls(ctx):
     import sys
     sl = synth.make_libraries(seed=20260101, scale="small")
     casc = Cascade(ctx, sl.libs)
+    casc2 = Cascade(ctx, {"mirna": sl.libs["mirna"]}, n_pass=1)
 
     def canon(uniq, res):
         cnt, first = uniq.counts()
@@ -1174,9 +1190,29 @@ def test_collapse_cascade_one_call_equals_two_calls(ctx):
         c1 = _ffi.count_join(ctx, u1, r1, 0, 8, len(sl.libs["mirna"]))
         c2 = _ffi.count_join(ctx, u2, r2, 0, 8, len(sl.libs["mirna"]))
         assert all(np.array_equal(x, y) for x, y in zip(c1, c2))
-        for h in (r1, r2, u1, u2, raw):
+        # BASELINE configs[1] (`bench.py --workload c2`): ONE pass through the one-call route -- the only user of k_pass with the
+        # read count still on the device (a single step is never walked by k_cascade_bulk) -- against the two-call sequence,
+        # against pass 0 of the full cascade, and against the oracle's pass 0 on the first reads (manifoldAlign.py:85,93)
+        u3, r3 = casc2.collapse_and_run(raw)
+        u4 = raw.collapse(); r4 = casc2.run(u4)
+        c, d = canon(u3, r3), canon(u4, r4)
+        assert c[0] == d[0] == a[0] and np.array_equal(c[1], d[1]) and np.array_equal(c[2], d[2]) and np.array_equal(c[1], a[1])
+        assert all(np.array_equal(x, y) for x, y in zip(c[3], d[3]))
+        hit0 = a[3][0] == 0
+        assert np.array_equal(c[3][0] == 0, hit0) and ((c[3][0] == 0) | (c[3][0] == -1)).all()
+        for f in (1, 2, 3):
+            assert np.array_equal(c[3][f][hit0], a[3][f][hit0])
+        k = min(len(c[0]), 20000)
+        fs = FlatSeqs.from_list(c[0][:k])
+        o = oracle.cascade(fs.data, fs.offsets, oracle_libs_from(sl.libs)[:1], n_pass=1, indexed=True)
+        for x, y in zip(o, c[3]):
+            assert np.array_equal(x.astype(np.int64), y[:k].astype(np.int64))
+        j3 = _ffi.count_join(ctx, u3, r3, 0, -2, len(sl.libs["mirna"]))
+        j4 = _ffi.count_join(ctx, u4, r4, 0, -2, len(sl.libs["mirna"]))
+        assert all(np.array_equal(x, y) for x, y in zip(j3, j4)) and np.array_equal(j3[1], c1[1])
+        for h in (r1, r2, r3, r4, u1, u2, u3, u4, raw):
             h.close()
-    casc.close()
+    casc.close(); casc2.close()
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     code = """
 import sys, numpy as np
@@ -1326,6 +1362,49 @@ def test_weighted_collapse_merges_dictionaries(ctx, ci_libs):
     assert all(allseq[int(f)] == q for f, q in zip(first, seqs)) and (ps == -1).all()
     assert all(allseq.index(q) == int(f) for f, q in list(zip(first, seqs))[:200])
     uniq.close()
+
+
+def test_full_size_c2_route(ctx):
+    """BASELINE configs[1] at its full size through the route `bench.py --workload c2` steps: 10 M raw reads, collapse and the
+    exact mature-miRNA pass as ONE call (k_pass with the read count on the device), count join.  Conservation, the pass's
+    subset rule (len < 26, 0 mismatches: manifoldAlign.py:85,93), agreement with the two-call sequence and with pass 0 of the
+    full cascade read for read, and the oracle on a random sample."""
+    sl = synth.make_libraries(seed=20260101, scale="full")
+    c2 = Cascade(ctx, {"mirna": sl.libs["mirna"]}, n_pass=1)
+    reads = synth.make_reads_chunked(sl, 10_000_000, seed=1000)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq, res = c2.collapse_and_run(raw)
+    counts, first = uniq.counts()
+    assert int(counts.sum()) == len(reads) and len(np.unique(first)) == len(uniq)
+    ps, ref, off, mm = res.fetch()
+    cls, ex, iso = _ffi.count_join(ctx, uniq, res, 0, -2, len(sl.libs["mirna"]))
+    c = counts[:, 0].astype(np.int64)
+    assert cls[0, 0] == c[ps == 0].sum() and cls[0, 0] + c[ps < 0].sum() == len(reads) and ex.sum() == cls[0, 0] and iso.sum() == 0
+    assert set(np.unique(ps).tolist()) <= {-1, 0} and (mm[ps == 0] == 0).all()
+    useq = uniq.unpack()
+    assert (useq.lengths[ps == 0] < 26).all()
+    # the two-call sequence: same unique reads (as a set: the order of a collapse's output is unspecified), same answers
+    u2 = raw.collapse(); r2 = c2.run(u2)
+    cnt2, first2 = u2.counts()
+    o1, o2 = np.argsort(first, kind="stable"), np.argsort(first2, kind="stable")
+    assert np.array_equal(first[o1], first2[o2]) and np.array_equal(counts[o1], cnt2[o2])
+    for x, y in zip((ps, ref, off, mm), r2.fetch()):
+        assert np.array_equal(x[o1], y[o2])
+    # pass 0 of the full cascade on a random sample of the collapsed reads, and the oracle on part of it
+    rng = np.random.default_rng(4)
+    pick = rng.permutation(len(uniq))[:300000]
+    sub = useq.take(pick)
+    casc = Cascade(ctx, sl.libs)
+    g = casc.annotate(sub)
+    assert np.array_equal(g[0] == 0, ps[pick] == 0)
+    for x, y in zip(g[1:], (ref, off, mm)):
+        assert np.array_equal(x[g[0] == 0], y[pick][g[0] == 0])
+    k = 60000
+    o = oracle.cascade(sub.data[: sub.offsets[k]], sub.offsets[: k + 1], oracle_libs_from(sl.libs)[:1], n_pass=1, indexed=True)
+    for x, y in zip(o, (ps, ref, off, mm)):
+        assert np.array_equal(x.astype(np.int64), y[pick][:k].astype(np.int64))
+    for h in (res, r2, uniq, u2, raw, casc, c2):
+        h.close()
 
 
 def test_full_size_c3_properties(ctx):

@@ -346,6 +346,41 @@ def test_library_cache_round_trip_and_invalidation(tmp_path, monkeypatch):
     assert not hasattr(load_index(base), "cache_path")
     libcache.save(base, first, packed, libcache.source_stamp(base))
     assert load_index(base).cache_path == path
+    # a damaged cache (one flipped byte in any array, header intact, size and mtime of the INDEX unchanged): the array no
+    # longer matches its content hash, the cache is ignored and the next save replaces it
+    meta_len = int.from_bytes(open(path, "rb").read()[16:24], "little")
+    import json as _json
+    meta = _json.loads(open(path, "rb").read()[24:24 + meta_len])
+    body0 = (16 + 8 + meta_len + 63) & ~63
+    good = open(path, "rb").read()
+    for k in ("T", "inv", "ref_start", "names_data", "seq_offsets"):
+        d = meta["arrays"][k]
+        at = body0 + d["at"] + (np.dtype(d["dtype"]).itemsize * d["n"]) // 2
+        bad = bytearray(good)
+        bad[at] ^= 0x10
+        with open(path, "wb") as fh:
+            fh.write(bad)
+        assert not hasattr(load_index(base), "cache_path"), k
+    with open(path, "wb") as fh:
+        fh.write(good)
+    assert load_index(base).cache_path == path
+    with open(path, "wb") as fh:
+        fh.write(bad)
+    reread = load_index(base)  # ... read from the FASTA again, and its save() heals the file
+    libcache.save(base, reread, packed, reread.cache_target[1])
+    assert load_index(base).cache_path == path
+    # both hash algorithms verify what they wrote; one that is not available here makes the cache unverifiable, not trusted
+    for algo in ("xxh3_64", "blake2b8"):
+        h = libcache.content_hash(T, algo)
+        assert h is None or (h[0] == algo and libcache.content_hash(T.copy(), algo) == h and libcache.content_hash(T[::-1].copy(), algo) != h)
+    assert libcache.content_hash(T, "blake2b8") is not None and libcache.content_hash(T, "no-such-hash") is None
+    # a bare index name (no directory part) must not take save() down
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        assert libcache.save("human_mrna", first, packed, libcache.source_stamp("human_mrna")) == "human_mrna.mirge3amd"
+    finally:
+        os.chdir(cwd)
     monkeypatch.setattr(libcache, "VERSION", libcache.VERSION + 1)
     assert not hasattr(load_index(base), "cache_path")
     monkeypatch.undo()
