@@ -63,11 +63,163 @@ def read_fastq_sequences(path: str) -> FlatSeqs:
     return FlatSeqs(buf[s[rows] + within], offsets)
 
 
-def read_text(path: str) -> bytes:
-    """The file's bytes (gunzipped if .gz) for the device-side parser (``mirge_reads_parse``).  A FASTA whose sequences
-    are wrapped over several lines (dnaio reads those) is unwrapped here: the device parser finds records by line
-    number and refuses anything else."""
+import os as _os
+GZ_PIECE_BYTES = int(_os.environ.get("MIRGE_GZ_PIECE_BYTES", 8 << 20))   # text handed to the parser per piece of a streamed .fastq.gz
+GZ_QUEUE_DEPTH = 4         # inflated pieces waiting for the GPU (bounds the memory of a stream: ~ depth x piece)
+
+
+class GzipRecordStream:
+    """A ``.fastq.gz`` as pieces of text, each a whole number of 4-line records, inflated on a worker thread (zlib releases
+    the GIL) while the caller uploads and parses the piece before: what ``xopen`` + ``dnaio.read_chunks`` are to the
+    reference's worker pool (digest.py:136-140).  One inflate stream runs at 0.3-0.4 GB/s of text, twenty times slower than
+    everything behind it, so the sample costs what its inflation costs and no more; the whole text is never held.
+    Multi-member files (bgzip, pigz, cat of several .gz) are read through.  A text that does not start with '@' (FASTA, bare
+    sequences) is gathered whole instead (``whole_text``): those parsers want to see all of it."""
+
+    def __init__(self, path: str, piece_bytes: int = None, depth: int = None):
+        import queue
+        import threading
+        self.path = str(path)
+        self.piece_bytes = int(piece_bytes or GZ_PIECE_BYTES)
+        self.q: "queue.Queue" = queue.Queue(maxsize=int(depth or GZ_QUEUE_DEPTH))
+        self.inflate_s = 0.0       # the worker's time inside zlib + cutting (its wall time minus waits for the consumer)
+        self.text_bytes = 0
+        self.compressed_bytes = 0
+        self.pieces = 0
+        self._err = None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._work, name="mirge-inflate", daemon=True)
+        self._thread.start()
+
+    @staticmethod
+    def _cut(block: bytes) -> int:
+        """length of the longest prefix of `block` that is a whole number of 4-line records (0: none)"""
+        n = block.count(b"\n")
+        idx = block.rfind(b"\n")
+        for _ in range(n % 4):
+            idx = block.rfind(b"\n", 0, idx)
+        return idx + 1
+
+    def _inflated(self, fh):
+        """the file's text as blocks of at most a piece, member after member; (block, seconds inside zlib)"""
+        import zlib
+        d, fresh, buf = zlib.decompressobj(31), True, b""
+        while True:
+            if not buf:
+                buf = fh.read(1 << 20)
+                self.compressed_bytes += len(buf)
+                if not buf:
+                    if not fresh:  # the file ends inside a member: whatever zlib still holds, then the verdict
+                        t0 = time.perf_counter()
+                        out = d.flush()
+                        if out:
+                            yield out, time.perf_counter() - t0
+                        if not d.eof:
+                            raise EOFError(f"{self.path}: compressed file ended before the end-of-stream marker was reached")
+                    return
+            t0 = time.perf_counter()
+            out = d.decompress(buf, self.piece_bytes)  # at most a piece at a time, whatever the ratio
+            fresh = False
+            if d.eof:  # end of a member: the next one, if any, starts in what is left
+                buf = d.unused_data
+                d, fresh = zlib.decompressobj(31), True
+                if not buf.strip(b"\0"):  # bgzip's empty last block leaves nothing; tape padding is zeros
+                    buf = b""
+            else:
+                buf = d.unconsumed_tail  # (output still pending inside zlib comes out with the next input, or the final flush)
+            yield out, time.perf_counter() - t0
+
+    def _put(self, item) -> bool:
+        import queue
+        while not self._stop.is_set():
+            try:
+                self.q.put(item, timeout=0.2)  # blocks while the consumer is GZ_QUEUE_DEPTH pieces behind
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _work(self):
+        t_busy = 0.0
+        try:
+            parts, size, carry, fastq = [], 0, b"", None
+            with open(self.path, "rb") as fh:
+                for out, dt in self._inflated(fh):
+                    t_busy += dt
+                    if not out:
+                        continue
+                    if fastq is None:
+                        fastq = out[:1] == b"@"
+                    parts.append(out)
+                    size += len(out)
+                    if fastq and size >= self.piece_bytes:
+                        t0 = time.perf_counter()
+                        block = carry + b"".join(parts)
+                        cut = self._cut(block)
+                        piece, carry = block[:cut], block[cut:]
+                        parts, size = [], 0
+                        t_busy += time.perf_counter() - t0
+                        if piece:
+                            self.text_bytes += len(piece)
+                            self.pieces += 1
+                            if not self._put(piece):
+                                return
+            last = carry + b"".join(parts)
+            if last:
+                self.text_bytes += len(last)
+                self.pieces += 1
+                self._put(("whole", last) if not fastq else last)
+        except Exception as e:  # noqa: BLE001 -- handed to the consumer
+            self._err = e
+        finally:
+            self.inflate_s = t_busy
+            self._stop_put_none()
+
+    def _stop_put_none(self):
+        import queue
+        while True:
+            try:
+                self.q.put(None, timeout=0.2)
+                return
+            except queue.Full:
+                if self._stop.is_set():  # nobody is listening: make room
+                    try:
+                        self.q.get_nowait()
+                    except queue.Empty:
+                        pass
+
+    def close(self):
+        """stop the worker (a consumer that gives up early calls this; harmless after the end)"""
+        self._stop.set()
+        self._thread.join(timeout=5)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                self._thread.join()
+                if self._err is not None:
+                    raise self._err
+                return
+            yield item
+
+    def whole_text(self) -> bytes:
+        """everything as one text (a stream somebody needs whole: UMI handling, FASTA)"""
+        out = []
+        for item in self:
+            out.append(item[1] if isinstance(item, tuple) else item)
+        data = b"".join(out)
+        return unwrap_fasta(data) if data[:1] == b">" else data
+
+
+def read_text(path: str, stream: bool = False):
+    """The file's bytes for the device-side parser (``mirge_reads_parse``): memory-mapped when plain; a ``.gz`` inflated whole,
+    or -- ``stream=True`` -- as a ``GzipRecordStream`` whose worker has already started.  A FASTA whose sequences are wrapped
+    over several lines (dnaio reads those) is unwrapped here: the device parser finds records by line number and refuses
+    anything else."""
     if str(path).endswith(".gz"):
+        if stream:
+            return GzipRecordStream(path)
         with gzip.open(path, "rb") as fh:
             data = fh.read()
     else:
@@ -80,23 +232,24 @@ def read_text(path: str) -> bytes:
     return data
 
 
-def read_texts(paths, depth: int = 4):
+def read_texts(paths, depth: int = 4, stream: bool = False):
     """``read_text`` of every file, in order, read ahead by up to ``depth`` files on worker threads: gunzipping a sample
     (zlib releases the GIL) then runs beside the previous sample's transfer and parse, and several .gz samples inflate
-    on several cores -- a single inflate stream is the slowest stage of a run from compressed FASTQ."""
+    on several cores -- a single inflate stream is the slowest stage of a run from compressed FASTQ.  ``stream=True``: a
+    ``.gz`` comes as a ``GzipRecordStream`` (opened -- its worker inflating -- up to ``depth`` files ahead)."""
     from concurrent.futures import ThreadPoolExecutor
     paths = [str(p) for p in paths]
     if len(paths) <= 1:
         for p in paths:
-            yield read_text(p)
+            yield read_text(p, stream)
         return
     with ThreadPoolExecutor(max_workers=max(1, min(depth, len(paths)))) as pool:
-        pending = [pool.submit(read_text, p) for p in paths[:depth]]
+        pending = [pool.submit(read_text, p, stream) for p in paths[:depth]]
         nxt = len(pending)
         while pending:
             text = pending.pop(0).result()
             if nxt < len(paths):
-                pending.append(pool.submit(read_text, paths[nxt]))
+                pending.append(pool.submit(read_text, paths[nxt], stream))
                 nxt += 1
             yield text
 
@@ -261,10 +414,16 @@ def write_tcf(path, raw: "_ffi.DeviceReads") -> None:
         fo.write(FlatSeqs.join_columns([head, num, seqs], b"_\n\n"))
 
 
-def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None, name=None):
+def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None, name=None, timings: Dict[str, float] = None):
     """One file's text -> (raw reads as the collapse takes them, records seen): parse, the modifier chain, the length
     filter and -- with ``umi`` -- the reference's UMI handling, all on the GPU (``mirge_reads_parse[_trim|_umi]``).
-    With ``-udd`` also writes ``<name>_umiCounts.csv``."""
+    With ``-udd`` also writes ``<name>_umiCounts.csv``.  ``text`` may be a ``GzipRecordStream``: its pieces are uploaded and
+    parsed one by one while the next ones inflate, and appended on the device (``mirge_reads_concat``: file order kept)."""
+    if isinstance(text, GzipRecordStream):
+        if umi is not None:  # the UMI routes look at the whole sample (a collapse inside): not streamed
+            text = text.whole_text()
+        else:
+            return _parse_stream(ctx, text, min_len, trim, timings)
     if umi is None:
         return _ffi.DeviceReads.parse(ctx, text, 0, min_len, trim)
     raw, n_rec, tagged = _ffi.DeviceReads.parse_umi(ctx, text, 0, min_len, trim, umi)
@@ -272,6 +431,42 @@ def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None,
         if workDir is not None:
             write_umi_counts(Path(workDir) / (str(name) + "_umiCounts.csv"), tagged, umi.front, umi.back, min_len)
         tagged.close()
+    return raw, n_rec
+
+
+def _parse_stream(ctx: _ffi.Context, stream: "GzipRecordStream", min_len: int, trim, timings=None):
+    parts, n_rec = [], 0
+    t_wait = t_gpu = 0.0
+    t = time.perf_counter()
+    try:
+        for item in stream:
+            t1 = time.perf_counter()
+            t_wait += t1 - t
+            if isinstance(item, tuple):  # not FASTQ: the whole text at once
+                data = unwrap_fasta(item[1]) if item[1][:1] == b">" else item[1]
+                r, n = _ffi.DeviceReads.parse(ctx, data, 0, min_len, trim)
+            else:
+                r, n = _ffi.DeviceReads.parse(ctx, item, 1, min_len, trim)
+            parts.append(r)
+            n_rec += n
+            t = time.perf_counter()
+            t_gpu += t - t1
+        if not parts:
+            raw = _ffi.DeviceReads.parse(ctx, b"", 0, min_len, trim)[0]
+        elif len(parts) == 1:
+            raw = parts.pop()
+        else:
+            raw = _ffi.DeviceReads.concat(ctx, parts)
+    finally:
+        stream.close()
+        for r in parts:
+            r.close()
+    if timings is not None:
+        timings["inflate_s"] = timings.get("inflate_s", 0.0) + stream.inflate_s
+        timings["inflate_wait_s"] = timings.get("inflate_wait_s", 0.0) + t_wait   # the GPU side idle, waiting for text
+        timings["upload_parse_s"] = timings.get("upload_parse_s", 0.0) + t_gpu
+        timings["gz_text_MB"] = round(timings.get("gz_text_MB", 0.0) + stream.text_bytes / 1e6, 1)
+        timings["gz_pieces"] = timings.get("gz_pieces", 0) + stream.pieces
     return raw, n_rec
 
 
@@ -289,7 +484,7 @@ def baking(args, inFileArray, inFileBaseArray, workDir, ctx: _ffi.Context = None
     min_len = int(getattr(args, "minimum_length", 16))
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     parsed: List[_ffi.DeviceReads] = []
-    texts = read_texts(inFileArray)  # read (and gunzipped) ahead on worker threads
+    texts = read_texts(inFileArray, stream=True)  # read ahead on worker threads; a .gz inflates piece by piece beside its parse
     for FQfile, name in zip(inFileArray, inFileBaseArray):
         start = time.perf_counter()
         raw, n_rec = parse_sample(ctx, next(texts), min_len, trim, umi, workDir, name)

@@ -162,14 +162,10 @@ __device__ __forceinline__ uint64_t eval_batch(const MirgeLibView& lib, const Mi
 // uncoalesced lookups (plan entry, 24-byte table descriptor) before the first useful one -- about half of all the
 // lane-level cache lookups of the passes over the small libraries, which is what bounds them (per-CU L1 tag rate, not
 // latency and not VALU: profiles/README.md round 2).  For the one-word read group (trimmed length <= 31) a workgroup
-// therefore copies the (L, q) -> {probe, table} map into LDS and the lanes read it from there.  Round 4: a pass asks
-// for a handful of distinct tables, so the map holds a table INDEX per (L, q) and the descriptors once (2.2 KiB per pass
-// instead of 8): the plans of up to MIRGE_WALK_MAX passes are resident together, which is what lets k_cascade_bulk take a
-// read through several passes in one walk.
+// therefore copies the (L, q) -> {probe, table} map into LDS once (8 KiB) and the lanes read it from there.
 struct LdsPlan {
-    MirgeKTable tb[MIRGE_PLAN_SHAPES];
+    MirgeKTable tb[32][MIRGE_MAX_PROBES];
     MirgeProbe pr[32][MIRGE_MAX_PROBES];
-    uint8_t tid[32][MIRGE_MAX_PROBES];
     uint8_t np[32];
 };
 template <bool LDS>
@@ -181,14 +177,12 @@ struct PlanSrc {
 __device__ __forceinline__ void lds_plan_fill(LdsPlan& s, const MirgeLibView& lib, const MirgePlanTable* __restrict__ plan) {
     for (int idx = threadIdx.x; idx < 32 * MIRGE_MAX_PROBES; idx += blockDim.x) {
         const int L = idx / MIRGE_MAX_PROBES, q = idx % MIRGE_MAX_PROBES;
-        s.pr[L][q] = plan->pr[L][q];
-        s.tid[L][q] = plan->tid32[L][q];
-    }
-    for (int t = threadIdx.x; t < MIRGE_PLAN_SHAPES; t += blockDim.x) {
+        const MirgeProbe pr = plan->pr[L][q];
         MirgeKTable tb;
         tb.bucket = nullptr; tb.pos = nullptr; tb.bits = nullptr;
-        if (t < plan->nshape32) tb = lib.tables[plan->shape32[t]];
-        s.tb[t] = tb;
+        if (q < (int)plan->np[L] && pr.k1 > 0) tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+        s.pr[L][q] = pr;
+        s.tb[L][q] = tb;
     }
     for (int L = threadIdx.x; L < 32; L += blockDim.x) s.np[L] = plan->np[L];
 }
@@ -201,11 +195,8 @@ __device__ __forceinline__ bool probe_setup(const MirgeLibView& lib, const PlanS
     if (LDS) pr = ps.l->pr[r.len][q];
     else pr = ps.g->pr[r.len][q];  // tabulated mirge_probe_at(pol, len, K, q)
     if (!mirge_probe_key<W>(r, pr, key)) return false;
-    if (LDS) {
-        const uint32_t tid = ps.l->tid[r.len][q];
-        if (tid != MIRGE_PLAN_NO_TID) tb = ps.l->tb[tid];
-        else tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];  // more distinct shapes than slots: from the registry
-    } else tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+    if (LDS) tb = ps.l->tb[r.len][q];
+    else tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
     return true;
 }
 
@@ -276,6 +267,9 @@ template <int W, bool LDS>
 __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
                                              const PlanSrc<LDS>& ps, const MirgeRead<W>& r, bool active, uint64_t& best) {
     best = MIRGE_NO_HIT;
+#if defined(MIRGE_EXP_SKIP)  // timing experiments only (wrong answers): no alignment at all = what walking the lists costs (profiles/README.md, round 4)
+    return;
+#endif
     const int np = active ? (int)(LDS ? ps.l->np[r.len] : ps.g->np[r.len]) : 0;
     // wave-uniform bound on the probe count: (mm+1) plain segments or (mm+1)^2 recursive probes
     const int npmax = (pol.mm >= 1 && pol.mm <= 2) ? (pol.mm + 1) * (pol.mm + 1) : pol.mm + 1;
@@ -474,12 +468,10 @@ __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint3
 // was in ONE regime at a time (the merged pass waits on random sectors with its ALUs idle, the isomiR pass issues VALU and
 // cache accesses with the memory system idle).  Here a workgroup walks through the steps on its own; workgroups drift
 // apart and the regimes overlap.  Same device functions as k_pass: same answers.
-// Round 4: the steps are taken in WALKS.  Walking the list costs about as much as a light pass does (load the index, then the
-// read, ballot, LDS cursor, dependent store: pass 3, which aligns the 1 % of reads that end in a T run, took 0.064 ms of the
-// 1.03 ms of the nine separate launches), so a read now goes through up to MIRGE_WALK_MAX consecutive steps while the wave holds
-// it -- no compaction in between, a lane whose read is annotated sits out the rest of the walk -- and the survivors are
-// compacted only where the host marks it (FusedSteps::walk_last: where many lanes would idle or the regime changes).
 // ------------------------------------------------------------------------------------------
+#ifndef MIRGE_BULK_WAVES
+#define MIRGE_BULK_WAVES 6  // waves per SIMD = four-wave workgroups per CU the bulk kernel is built for (native_cascade.hpp sizes its grid with it)
+#endif
 struct FusedStep {
     MirgeLibView lib;
     MirgePolicy pol;
@@ -487,84 +479,21 @@ struct FusedStep {
     const MirgePlanTable* plan;
     int32_t pass_id;
 };
-#define MIRGE_WALK_MAX 4  // passes a workgroup takes a read through in one walk over its list (their plans are in LDS together)
 struct FusedSteps {
     int32_t n;
-    uint8_t walk_last[MIRGE_MAX_PASSES_K];  // 1: the survivors are compacted behind this step (k_cascade_bulk; set by the host)
     FusedStep s[MIRGE_MAX_PASSES_K];
 };
-
-// One WALK of a workgroup over its n_in reads (first walk: reads [seg_r, seg_r + n_in) of the group; later: the survivors
-// act_in[seg ...] its previous walk left): every read is taken through steps k0 .. k1 in cascade order -- a lane whose read
-// is annotated by one of them sits out the rest of the walk -- and what is still unannotated behind step k1 is appended to
-// act_out[seg ...].  s_after[k] (LDS, cleared by the caller) counts the reads still open behind step k: s_after[k1] is the
-// cursor of the survivor list, the others are the profile's "reads handed to the next pass".
-template <int W, bool LDSP, bool HASN>
-__device__ __forceinline__ void walk_segment(const FusedSteps* __restrict__ steps, int k0, int k1, const LdsPlan* plans, const GroupView<W>& g,
-                                             const uint32_t* act_in, uint32_t n_in, size_t seg, size_t seg_r, uint32_t* __restrict__ act_out,
-                                             int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm,
-                                             uint32_t* s_after) {
-    const int lane = threadIdx.x & 63;
-    for (uint32_t base = 0; base < n_in; base += MIRGE_BLOCK) {
-        const uint32_t t = base + threadIdx.x;
-        const bool valid = t < n_in;
-        uint32_t idx = 0;
-        MirgeRead<W> r0;
-        if (valid) {
-            // the list was written by this workgroup earlier in the SAME kernel: agent-scope loads (L2), see DESIGN.md 4.2
-            idx = act_in ? __hip_atomic_load(&act_in[seg + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)seg_r + t;
-            load_read<W, HASN>(g, idx, r0);
-        } else {
-#pragma unroll
-            for (int w = 0; w < W; w++) { r0.w[w] = 0; r0.nm[w] = 0; }
-            r0.len = 0;
-        }
-        bool open = valid;
-#pragma unroll 1
-        for (int k = k0; k <= k1; k++) {
-            const FusedStep& st = steps->s[k];
-            MirgeRead<W> r2 = r0;
-            const bool elig = open && mirge_effective_read<W>(r2, st.pol);
-            PlanSrc<LDSP> psrc;
-            psrc.g = st.plan; psrc.l = LDSP ? plans + (k - k0) : nullptr;
-            uint64_t best;
-            align_hybrid<W, LDSP>(st.lib, st.pol, st.mi, psrc, r2, elig, best);  // the wave aligns its 64 reads together
-            if (elig && best != MIRGE_NO_HIT) {
-                const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
-                res_pass[idx] = (int8_t)(st.pass_id + cls);
-                uint32_t b0 = 0;
-#pragma unroll
-                for (int i = 1; i < 4; i++) if (i == cls) b0 = st.mi.bound[i];
-                res_pos[idx] = (uint32_t)best - b0;  // position in that member's own text
-                res_mm[idx] = (int8_t)((best >> 32) & 0xFF);
-                open = false;
-            }
-            const unsigned long long bal = __ballot(open);
-            if (!bal) break;  // wave-uniform: nobody left for the later steps (their counters stay as they are: +0)
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&s_after[k], (uint32_t)__popcll(bal));
-            if (k == k1) {
-                wbase = __shfl(wbase, 0, 64);
-                if (open) act_out[seg + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
-            }
-        }
-        if (!act_in && open) {  // the first walk sees every read of the group: it also writes "unannotated"
-            res_pass[idx] = -1;
-            res_mm[idx] = -1;
-        }
-    }
-}
 
 // HASN = false: the build for a group without ambiguous calls -- its N masks are compile-time zeros and fold away in everything
 // inlined behind the load (7 fewer spilled scalar registers, -2 % kernel time on the bulk group)
 template <int W, bool HASN>
-__global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(W == 1 ? 6 : 1, 8)))  // one-word reads: 6 workgroups per CU must be resident (80 VGPRs; k_pass: 77); wider reads keep their registers
+__global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(W == 1 ? MIRGE_BULK_WAVES : 1, 8)))  // one-word reads: 6 workgroups per CU must be resident (80 VGPRs; k_pass: 77); wider reads keep their registers
 k_cascade_bulk(const FusedSteps* __restrict__ steps, GroupView<W> g, uint32_t* __restrict__ actA, uint32_t* __restrict__ actB,
                uint32_t* __restrict__ seg_n, uint32_t cap, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
                int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
-    __shared__ uint32_t s_after[MIRGE_MAX_PASSES_K];
+    __shared__ uint32_t s_count;
     constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
-    __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? MIRGE_WALK_MAX * sizeof(LdsPlan) : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? sizeof(LdsPlan) : 16];
     LdsPlan* s_plan = reinterpret_cast<LdsPlan*>(s_plan_raw);
     const int nsteps = steps->n;
     const size_t seg = (size_t)blockIdx.x * cap;
@@ -572,21 +501,20 @@ k_cascade_bulk(const FusedSteps* __restrict__ steps, GroupView<W> g, uint32_t* _
     uint32_t n_in = first_pass_share(g.n, n_dev, cap, seg_r);
     const uint32_t* act_in = nullptr;
     uint32_t* act_out = actA;
-    for (int k0 = 0; k0 < nsteps;) {
-        int k1 = k0;
-        while (k1 + 1 < nsteps && k1 - k0 + 1 < MIRGE_WALK_MAX && !steps->walk_last[k1]) k1++;
-        if (threadIdx.x < MIRGE_MAX_PASSES_K) s_after[threadIdx.x] = 0;
-        if (LDSP)
-            for (int k = k0; k <= k1; k++) lds_plan_fill(s_plan[k - k0], steps->s[k].lib, steps->s[k].plan);
+    for (int si = 0; si < nsteps; si++) {
+        const FusedStep& st = steps->s[si];
+        if (threadIdx.x == 0) s_count = 0;
+        if (LDSP) lds_plan_fill(*s_plan, st.lib, st.plan);
         __syncthreads();
-        walk_segment<W, LDSP, HASN>(steps, k0, k1, s_plan, g, act_in, n_in, seg, seg_r, act_out, res_pass, res_pos, res_mm, s_after);
-        __syncthreads();  // the survivors are written (and visible to this workgroup at L2), the plans are free again
-        n_in = s_after[k1];
-        if ((int)threadIdx.x >= k0 && (int)threadIdx.x <= k1) seg_n[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s_after[threadIdx.x];
-        __syncthreads();  // everybody has read the counters before they are reset
+        PlanSrc<LDSP> psrc;
+        psrc.g = st.plan; psrc.l = LDSP ? s_plan : nullptr;
+        pass_segment<W, LDSP, true, HASN>(st.lib, st.pol, st.mi, psrc, g, act_in, n_in, seg, seg_r, act_out, st.pass_id, res_pass, res_pos, res_mm, &s_count);
+        __syncthreads();  // the survivors are written (and visible to this workgroup at L2), the plan is free again
+        n_in = s_count;
+        if (threadIdx.x == 0) seg_n[(size_t)si * gridDim.x + blockIdx.x] = n_in;
+        __syncthreads();  // everybody has read s_count before it is reset
         act_in = act_out;
         act_out = (act_out == actA) ? actB : actA;
-        k0 = k1 + 1;
     }
     // (k_resolve stays a launch of its own: done here, for the workgroup's own reads, it is a chain of dependent loads with
     // four waves to hide it -- the kernel grew by 0.04 ms to save a 0.046 ms launch that the whole chip runs at once)

@@ -468,8 +468,10 @@ __global__ void k_heads_blocksum(const uint32_t* __restrict__ slot_of, const uin
             fl[i] = (inv ? 0xFFFFFFFFu - f : f) == j;
             if (fl[i]) {
                 c++;
-                const uint32_t L = len[j];
-                atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
+                if (len) {  // (nullptr: the long class, whose lengths the histogram has no room for)
+                    const uint32_t L = len[j];
+                    atomicAdd(&h[L > MIRGE_MAX_READ_LEN ? MIRGE_MAX_READ_LEN : L], 1u);
+                }
             }
         }
     }

@@ -19,7 +19,11 @@ struct CsvGroup {
     const int32_t* ref;      // [n]
     uint32_t base, n;
     int32_t W;
+    int32_t len16;           // 1: `len` holds uint16 (the long read class)
 };
+__device__ __forceinline__ int csv_len(const CsvGroup& g, uint32_t j) {
+    return g.len16 ? (int)reinterpret_cast<const uint16_t*>(g.len)[j] : (int)g.len[j];
+}
 struct CsvTables {
     CsvGroup g[MIRGE_CSV_MAXG];
     const uint8_t* name_data[MIRGE_MAX_PASSES_K];   // all names of pass p, back to back
@@ -59,7 +63,7 @@ __global__ void k_csv_rowlen(CsvTables t, const uint32_t* __restrict__ rows, uin
             if (!t.name_off[p] || r < 0 || (uint32_t)r >= t.name_n[p]) { atomicOr(&flags[0], 1u); len_m[k] = 0; len_u[k] = 0; continue; }
             nlen = t.name_off[p][r + 1] - t.name_off[p][r];
         }
-        uint32_t total = (uint32_t)g.len[j] + 2u + (uint32_t)t.n_name_cols + nlen + (uint32_t)t.S + 1u;
+        uint32_t total = (uint32_t)csv_len(g, j) + 2u + (uint32_t)t.n_name_cols + nlen + (uint32_t)t.S + 1u;
         for (int s = 0; s < t.S; s++) total += (uint32_t)csv_digits(g.counts[(size_t)j * t.S + s]);
         len_m[k] = p >= 0 ? total : 0ull;
         len_u[k] = p >= 0 ? 0ull : total;
@@ -76,7 +80,7 @@ __global__ void k_csv_rows(CsvTables t, const uint32_t* __restrict__ rows, uint3
         if (p >= t.n_pass) continue;
         uint8_t* o = p >= 0 ? (out_m ? out_m + off_m[k] : nullptr) : (out_u ? out_u + off_u[k] : nullptr);
         if (!o) continue;
-        const int L = g.len[j];
+        const int L = csv_len(g, j);
         for (int w = 0; w * 32 < L; w++) {
             uint64_t bits = g.seq[(size_t)w * g.n + j];
             uint64_t nm = g.nmask ? g.nmask[(size_t)w * g.n + j] : 0ull;
@@ -124,7 +128,7 @@ __global__ void k_lexkey(CsvTables t, const uint32_t* __restrict__ perm, uint32_
         uint32_t j;
         const int gi = csv_locate(t, perm[k], j);
         const CsvGroup& g = t.g[gi];
-        const int L = g.len[j];
+        const int L = csv_len(g, j);
         unsigned long long key = 0ull;
         const int p0 = word * MIRGE_LEX_BASES;
 #pragma unroll 1

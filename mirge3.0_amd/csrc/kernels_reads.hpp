@@ -180,8 +180,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t& total,
 // The groups are then packed by k_pack straight from the text.
 // ------------------------------------------------------------------------------------------
 #define MIRGE_PARSE_TILE (MIRGE_BLOCK * 16)
-#define MIRGE_NCLS 8      // width class (<= 31, 64, 128, 255 nt) x (no ambiguous call | has one)
-#define MIRGE_CLS_DROP 8  // shorter than --minimum-length (or longer than the engine's limit: flagged)
+#define MIRGE_NCLS 10      // width class (<= 31, 64, 128, 255 nt, longer: kernels_long.hpp) x (no ambiguous call | has one)
+#define MIRGE_CLS_DROP 10  // shorter than --minimum-length (or longer than MIRGE_LONG_MAX_LEN: flagged)
+#define MIRGE_LONG_MAX_LEN 65535  // the long class keeps a read's length in 16 bits
 
 // bit i of `mask` = byte b0 + i is a newline (b0 is a multiple of 16 and the text buffer is 256-byte aligned: one 16-byte
 // load per lane; a byte-wise loop with its bound test per byte kept the newline kernels at 1 TB/s)
@@ -253,7 +254,8 @@ struct SliceOpts {
 };
 
 // flags: [0] reads with N seen per group ... kept by k_pack; here [0] = byte outside ACGTUN seen, [1] = reads longer
-// than the limit, [2] = longest such read
+// than MIRGE_LONG_MAX_LEN, [2] = longest such read, [4] = an IUPAC code seen, [5] = longest kept read of the long class,
+// [6..7] = bases of the kept reads of the long class (64 bits; the length histogram stops at MIRGE_MAX_READ_LEN)
 __global__ void k_seq_class(const uint8_t* __restrict__ text, int64_t* __restrict__ start, int64_t* __restrict__ end,
                             int64_t* __restrict__ s2start, int32_t* __restrict__ s2len,
                             uint32_t n_seq, SliceOpts so, uint8_t* __restrict__ cls, uint32_t* __restrict__ blk_cls,
@@ -281,7 +283,7 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, int64_t* __restric
         const int64_t La = ne - nb, L = La + (y2 - x2);
         if (L1 < (int64_t)so.min_len_pre || L < (int64_t)so.min_len) {
             c = MIRGE_CLS_DROP;
-        } else if (L > MIRGE_MAX_READ_LEN) {
+        } else if (L > MIRGE_LONG_MAX_LEN) {
             atomicOr(&flags[1], 1u);
             atomicMax(&flags[2], (uint32_t)(L > 0xFFFFFFF ? 0xFFFFFFF : L));
             c = MIRGE_CLS_DROP;
@@ -296,8 +298,12 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, int64_t* __restric
             }
             if (bad) atomicOr(&flags[0], 1u);
             if (iu) atomicOr(&flags[4], 1u);
-            c = (L <= 31 ? 0 : (L <= 64 ? 1 : (L <= 128 ? 2 : 3))) + (amb ? MIRGE_NCLS / 2 : 0);
-            atomicAdd(&s_hist[L], 1u);
+            c = (L <= 31 ? 0 : (L <= 64 ? 1 : (L <= 128 ? 2 : (L <= MIRGE_MAX_READ_LEN ? 3 : 4)))) + (amb ? MIRGE_NCLS / 2 : 0);
+            if (L <= MIRGE_MAX_READ_LEN) atomicAdd(&s_hist[L], 1u);
+            else {
+                atomicMax(&flags[5], (uint32_t)L);
+                atomicAdd(reinterpret_cast<unsigned long long*>(flags + 6), (unsigned long long)L);
+            }
         }
         cls[r] = (uint8_t)c;
     }

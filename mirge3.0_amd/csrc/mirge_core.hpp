@@ -348,7 +348,16 @@ MIRGE_HD int mirge_plan_scheme(const MirgePolicy& p, int S, int K, uint64_t npos
     return best;
 }
 
-MIRGE_HD int mirge_seed_region(const MirgePolicy& p, int L) { return p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L; }
+// The region the probes are cut from: the seed (-n) or the read (-v).  Any PREFIX of it serves as well -- an alignment within
+// the budget has at most mm mismatches inside the prefix too -- which MIRGE_SEED_CAP2 uses for the two-mismatch policies
+// (experiment, profiles/README.md round 4): every read of at least that length then shares one plan and its few tables.
+MIRGE_HD int mirge_seed_region(const MirgePolicy& p, int L) {
+    int S = p.mode == 0 ? (L < p.seedlen ? L : p.seedlen) : L;
+#ifdef MIRGE_SEED_CAP2
+    if (p.mm == 2 && S > MIRGE_SEED_CAP2) S = MIRGE_SEED_CAP2;
+#endif
+    return S;
+}
 
 // An exact-seed policy (mm = 0) asks ONE table per library, so it can afford the next k when the library has
 // outgrown K = 14 (human mRNA: 130 M positions in 268 M buckets, 39 % of the lookups go on to a position list
@@ -373,18 +382,9 @@ MIRGE_HD void mirge_probe_at(const MirgePolicy& p, int L, int K, uint64_t npos, 
 
 // The plan depends only on (policy, K, trimmed length): the host tabulates it once per pass and the
 // kernels read probe q of length L with one 4-byte load instead of redoing the integer divisions.
-// For the one-word read group (lengths < 32) the table also names the DISTINCT probe tables of the pass -- a pass asks for a
-// handful of shapes (k1, gap, k2), whatever the read length -- so that a workgroup can keep the plans of several passes in
-// LDS at once: per (length, probe) one byte `tid32` into `shape32` instead of a 24-byte table descriptor
-// (MIRGE_PLAN_NO_TID: more distinct shapes than slots, the kernel takes that probe's descriptor from the library's registry).
-#define MIRGE_PLAN_SHAPES 32
-#define MIRGE_PLAN_NO_TID 0xFF
 struct MirgePlanTable {
     uint8_t np[MIRGE_MAX_READ_LEN + 1];
     MirgeProbe pr[MIRGE_MAX_READ_LEN + 1][MIRGE_MAX_PROBES];
-    uint8_t tid32[32][MIRGE_MAX_PROBES];
-    uint16_t shape32[MIRGE_PLAN_SHAPES];
-    int32_t nshape32;
 };
 static inline void mirge_plan_table_fill(const MirgePolicy& p, int K, uint64_t npos, MirgePlanTable& t) {
     for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
@@ -397,19 +397,6 @@ static inline void mirge_plan_table_fill(const MirgePolicy& p, int K, uint64_t n
             t.pr[L][q] = pr;
         }
     }
-    t.nshape32 = 0;
-    for (int i = 0; i < MIRGE_PLAN_SHAPES; i++) t.shape32[i] = 0;
-    for (int L = 0; L < 32; L++)
-        for (int q = 0; q < MIRGE_MAX_PROBES; q++) {
-            t.tid32[L][q] = MIRGE_PLAN_NO_TID;
-            const MirgeProbe pr = t.pr[L][q];
-            if (q >= (int)t.np[L] || pr.k1 <= 0) continue;
-            const int sid = mirge_shape_id(pr.k1, pr.gap, pr.k2);
-            int id = -1;
-            for (int i = 0; i < t.nshape32; i++) if ((int)t.shape32[i] == sid) { id = i; break; }
-            if (id < 0 && t.nshape32 < MIRGE_PLAN_SHAPES) { id = t.nshape32++; t.shape32[id] = (uint16_t)sid; }
-            if (id >= 0) t.tid32[L][q] = (uint8_t)id;
-        }
 }
 
 // key of a probe in the read, or false if an ambiguous call sits in a block (cannot be exact)

@@ -41,6 +41,7 @@ __device__ __forceinline__ void load_read(const GroupView<W>& g, uint32_t i, Mir
 #include "kernels_trim.hpp"
 #include "kernels_collapse.hpp"
 #include "kernels_cascade.hpp"
+#include "kernels_long.hpp"
 #include "kernels_join.hpp"
 #include "kernels_iso.hpp"
 #include "kernels_csv.hpp"

@@ -59,17 +59,21 @@ static int merged_library(mirge_ctx* c, const mirge_lib* const* members, int n, 
 }
 
 // build every probe table pass `p` can ask for, given the read lengths present
-static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t* hist) {
+static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t* hist, bool long_present) {
     MirgePolicy p;
     std::memcpy(&p, &pol, sizeof(p));
     std::vector<ShapeJob> wanted;
     std::vector<bool> seen(MIRGE_SHAPE_SLOTS, false);
-    for (int L = 1; L <= MIRGE_MAX_READ_LEN; L++) {
-        if (!hist[L]) continue;
+    // L = MIRGE_MAX_READ_LEN + 1 stands for the long class (k_cascade_long): a read of 256 nt or more is probed with the plan of
+    // its first 31 bases -- of its whole head when a T run is stripped down to less -- so lengths 31 + trims (any below with -ttail)
+    for (int L = 1; L <= MIRGE_MAX_READ_LEN + 1; L++) {
+        const bool lng = L > MIRGE_MAX_READ_LEN;
+        if (lng ? !long_present : !hist[L]) continue;
         if (p.len_lt > 0 && !(L < p.len_lt)) continue;
         if (p.len_gt > 0 && !(L > p.len_gt)) continue;
         int lo = L, hi = L;
-        if (p.ttail) { lo = 1; hi = L - 3; }  // any head length once the T run is gone
+        if (lng) lo = hi = 31 + p.trim5 + p.trim3;
+        if (p.ttail) { lo = 1; hi = (lng ? 31 + p.trim5 + p.trim3 : L - 3); }  // any head length once the T run is gone
         for (int l0 = lo; l0 <= hi; l0++) {
             const int l = l0 - p.trim5 - p.trim3;
             if (l < 1 || l <= p.mm) continue;
@@ -121,7 +125,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         HIPOK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_pass<W, 15>), MIRGE_BLOCK, 0));
         HIPOK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_pass<W, 15>)));
         const int by_regs = 512 / std::max(16, (fa.numRegs + 15) / 16 * 16);  // waves per SIMD = 4-wave workgroups per CU
-        wg_per_cu[W] = std::max(1, std::min({nb, by_regs, 6}));
+        wg_per_cu[W] = std::max(1, std::min({nb, by_regs, W == 1 ? MIRGE_BULK_WAVES : 6}));
         if (std::getenv("MIRGE_WG_PER_CU")) wg_per_cu[W] = std::max(1, std::atoi(std::getenv("MIRGE_WG_PER_CU")));
         if (std::getenv("MIRGE_HOST_TIMING"))
             std::fprintf(stderr, "[host] k_pass<%d>: %d VGPRs, occupancy query %d -> %d workgroups per CU\n", W, fa.numRegs, nb, wg_per_cu[W]);
@@ -239,10 +243,29 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     return 0;
 }
 
+// the long class (reads beyond 255 nt): one launch, one thread per read (k_cascade_long)
+static int cascade_group_long(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const FusedSteps* dsteps, const ResolveTable& rt,
+                              const char* gtag) {
+    out.n = rg.n;
+    if (!rg.n) return 0;
+    const uint32_t n = rg.n;
+    CHECK(dalloc(c, &out.pass, n));
+    CHECK(dalloc(c, &out.pos, n));
+    CHECK(dalloc(c, &out.mm, n));
+    CHECK(dalloc(c, &out.ref, n));
+    CHECK(dalloc(c, &out.off, n));
+    char name[32];
+    std::snprintf(name, sizeof(name), "k_cascade_long%s", gtag);
+    LaunchScope ls(c, name, n);
+    const uint32_t grid = std::min<uint32_t>((n + 63) / 64, (uint32_t)c->n_cu * 8);
+    hipLaunchKernelGGL(k_cascade_long, dim3(grid), dim3(64), 0, c->cur, dsteps, rt, long_view_of(rg), out.pass, out.pos, out.mm, out.ref, out.off);
+    return 0;
+}
+
 // steps (merged runs, probe tables, plan tables), resolve table and the fused kernel's device step list for
 // one (libraries, policies, read-length set) configuration
 static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass,
-                           const int32_t* hist, std::vector<PassStep>& steps, ResolveTable& rt, const FusedSteps** dsteps_out) {
+                           const int32_t* hist, bool long_present, std::vector<PassStep>& steps, ResolveTable& rt, const FusedSteps** dsteps_out) {
     for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.coarse[p] = nullptr; rt.n_refs[p] = 0; }
     steps.clear();
     for (int32_t p = 0; p < n_pass; p++) {
@@ -282,7 +305,7 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
             uint64_t b = 0;
             for (int i = 0; i < np; i++) { st.mi.bound[i] = (uint32_t)b; b += libs[p + i]->h.total; }
         }
-        CHECK(prepare_tables(const_cast<mirge_lib*>(st.lib), pol[p], hist));
+        CHECK(prepare_tables(const_cast<mirge_lib*>(st.lib), pol[p], hist, long_present));
         steps.push_back(st);
         p += np;
     }
@@ -316,30 +339,6 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         f.plan = steps[i].dplan;
         f.pass_id = steps[i].p0;
     }
-    // Where k_cascade_bulk compacts its survivor lists (FusedSteps::walk_last).  Consecutive steps of one REGIME are walked
-    // together, up to MIRGE_WALK_MAX of them: light (a library that stays in L2, at most one mismatch: the list walk costs as
-    // much as the alignment), sector-bound (a library beyond ~4 M bases: every probe is an L2-missing sector), and the
-    // <= 2-mismatch passes, whose verification runs for the whole wave and wants dense lanes.  Human set: [0 1 2 3] [4-6 7] [8].
-    // MIRGE_WALKS="4,2,1" (step counts per walk) overrides; "1,1,1,1,1,1,1" is round 3's one list per step.
-    {
-        auto regime = [&](size_t i) {
-            if (pol[steps[i].p0].mm >= 2) return 2;
-            return steps[i].lib->h.total >= (4ull << 20) ? 1 : 0;
-        };
-        std::vector<int> sizes;
-        if (const char* e = std::getenv("MIRGE_WALKS"))
-            for (const char* q = e; *q;) { sizes.push_back(std::max(1, std::atoi(q))); while (*q && *q != ',') q++; if (*q) q++; }
-        size_t i = 0, w = 0;
-        while (i < steps.size()) {
-            size_t len = 1;
-            if (w < sizes.size()) len = (size_t)std::min(sizes[w], MIRGE_WALK_MAX);
-            else if (sizes.empty())
-                while (i + len < steps.size() && len < MIRGE_WALK_MAX && regime(i + len) == regime(i)) len++;
-            len = std::min(len, steps.size() - i);
-            fs->walk_last[i + len - 1] = 1;
-            i += len; w++;
-        }
-    }
     const FusedSteps* dsteps = nullptr;
     for (auto& e : c->fused)
         if (std::memcmp(e.host.get(), fs.get(), sizeof(FusedSteps)) == 0) { dsteps = e.dev; break; }
@@ -360,7 +359,8 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
 }
 
 // (libraries, policies, read lengths present) -> c->casc_steps / casc_rt / casc_dsteps, kept between calls
-static int cascade_config(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass, const int32_t* hist) {
+static int cascade_config(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass, const int32_t* hist,
+                          bool long_present) {
     // Everything up to the launches depends only on (libraries, policies, read lengths present): it is
     // kept from the previous call and reused when those are unchanged (~45 us of host time per call otherwise,
     // on the critical path between the collapse's synchronisation and the first pass)
@@ -372,9 +372,10 @@ static int cascade_config(mirge_ctx* c, const mirge_lib* const* libs, const mirg
         key.append(reinterpret_cast<const char*>(&pol[p]), sizeof(mirge_policy));
     }
     for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) key.push_back(hist[L] ? 1 : 0);
+    key.push_back(long_present ? 1 : 0);
     if (c->casc_key != key) {
         c->casc_key.clear();
-        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, c->casc_steps, c->casc_rt, &c->casc_dsteps));
+        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, long_present, c->casc_steps, c->casc_rt, &c->casc_dsteps));
         c->casc_key = key;
     }
     return 0;
@@ -411,6 +412,10 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
         const int gi = order[k];
         if (gi == skip) continue;
         c->cur = gi == big ? c->stream : c->aux;
+        if (is_long_group(gi)) {
+            rc = cascade_group_long(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi));
+            continue;
+        }
         if (gi != big && R->g[gi].n <= fused_max) {
             if (spread && R->g[gi].n) c->cur = c->xaux[slot++ % MIRGE_N_XAUX];
             MIRGE_BY_WIDTH(gi, rc, cascade_group_fused<W>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi)));
@@ -432,7 +437,7 @@ static void reads_lengths_present(const mirge_reads* R, int32_t* hist) {
     std::memset(hist, 0, sizeof(int32_t) * (MIRGE_MAX_READ_LEN + 1));
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ReadGroup& g = R->g[gi];
-        if (!g.n) continue;
+        if (!g.n || is_long_group(gi)) continue;  // (the long class: mirge_reads::long_max)
         const int w = kGroupW[gi];
         int lo = w == 1 ? 1 : (w == 2 ? 32 : (w == 4 ? 65 : 129)), hi = w == 1 ? 31 : (w == 2 ? 64 : (w == 4 ? 128 : MIRGE_MAX_READ_LEN));
         for (int L = lo; L <= hi; L++) hist[L] = 1;
@@ -447,7 +452,7 @@ extern "C" int mirge_cascade_run(mirge_ctx* c, const mirge_reads* R, const mirge
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     int32_t hist[MIRGE_MAX_READ_LEN + 1];
     reads_lengths_present(R, hist);
-    CHECK(cascade_config(c, libs, pol, n_pass, hist));
+    CHECK(cascade_config(c, libs, pol, n_pass, hist, R->long_max > 0));
     hc.lap("plans+fused");
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n = R->n; res->n_pass = n_pass; res->reads = R;
@@ -469,7 +474,7 @@ extern "C" int mirge_cascade_prepare(mirge_ctx* c, const mirge_reads* R, const m
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     int32_t hist[MIRGE_MAX_READ_LEN + 1];
     reads_lengths_present(R, hist);
-    CHECK(cascade_config(c, libs, pol, n_pass, hist));
+    CHECK(cascade_config(c, libs, pol, n_pass, hist, R->long_max > 0));
     HIPOK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -495,7 +500,7 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
         return 0;
     }
     // the unique reads have the raw reads' lengths: the cascade can be configured before they exist
-    CHECK(cascade_config(c, libs, pol, n_pass, raw->len_hist));
+    CHECK(cascade_config(c, libs, pol, n_pass, raw->len_hist, raw->long_max > 0));
     auto res = std::make_unique<mirge_result>();
     res->ctx = c; res->n_pass = n_pass;
     for (int32_t p = 0; p < n_pass; p++) res->n_refs[p] = libs[p] ? (uint32_t)libs[p]->n_refs : 0u;

@@ -19,19 +19,21 @@ struct CollapseTmp {
     uint32_t G = 0, B = 0, NB1 = 0, NB2 = 1, W2 = 1, RPW = 0, cap1 = 0, shift2 = 0, cap = MIRGE_PART_CAP;
     uint64_t slab = 0;
 };
-// dmeta: [0..7] U of each group, [8] partition overflow flag, [16 .. 16+255] length histogram
+// dmeta: [0..9] U of each group, [10] partition overflow flag, [12..13] bases of the unique reads of the long class (64 bits),
+// [16 .. 16+255] length histogram of the unique reads of the other classes
 #ifndef MIRGE_PART_CACHE
 #define MIRGE_PART_CACHE 4096  // slots of the chunk cache of k_part_agg (2048: 3 % more records for split and dedup on the default sample)
 #endif
 #ifndef MIRGE_PART_RETRY_BYTES
 #define MIRGE_PART_RETRY_BYTES (64ull << 30)  // memory the second partitioned attempt may take (2 KiB per read)
 #endif
-#define MIRGE_META_OVERFLOW 8
+#define MIRGE_META_OVERFLOW 10
+#define MIRGE_META_LONG_BASES 12
 #define MIRGE_META_HIST 16
 #define MIRGE_META_WORDS (MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1)
 
 static const char* group_tag(int gi) {
-    static const char* t[MIRGE_NGROUPS] = {".w1", ".w2", ".w4", ".w8", ".w1n", ".w2n", ".w4n", ".w8n"};
+    static const char* t[MIRGE_NGROUPS] = {".w1", ".w2", ".w4", ".w8", ".wl", ".w1n", ".w2n", ".w4n", ".w8n", ".wln"};
     return t[gi];
 }
 
@@ -232,6 +234,67 @@ static int collapse_phase_b(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
     return 0;  // the temporaries go back to the pool in mirge_collapse, after the join
 }
 
+// the long class (reads beyond 255 nt, kernels_long.hpp): the general path's steps with kernels that take any length
+static int collapse_phase_a_long(mirge_ctx* c, int gi, const ReadGroup& in, CollapseTmp& t, const int32_t* dsample, int32_t S,
+                                 uint32_t* dmeta, int stage, const uint32_t* dweight) {
+    if (!in.n || stage == 1) return 0;
+    uint64_t tsize64 = 1024;
+    while (tsize64 < 2ull * in.n) tsize64 <<= 1;
+    if (tsize64 > (1ull << 31)) return fail(-5, "collapse: a read group of " + std::to_string(in.n) + " reads needs a hash table beyond 2^31 slots");
+    const uint32_t tsize = (uint32_t)tsize64;
+    const uint32_t per_block = MIRGE_BLOCK * MIRGE_SCAN_ITEMS;
+    t.nb = (in.n + per_block - 1) / per_block;
+    CHECK(dalloc(c, &t.slot_of, in.n));
+    CHECK(dalloc(c, &t.flag, (size_t)t.nb * per_block));
+    CHECK(dalloc(c, &t.blocksum, t.nb));
+    CHECK(dalloc(c, &t.rep, tsize));
+    CHECK(dalloc(c, &t.firstj, tsize));
+    CHECK(dalloc(c, &t.cnt, (size_t)tsize * S));
+    hipLaunchKernelGGL(k_collapse_init, dim3(grid_for(c, (size_t)tsize * S)), dim3(MIRGE_BLOCK), 0, c->cur, t.rep, t.firstj, t.cnt,
+                       tsize, (uint64_t)tsize * (uint64_t)S);
+    const LongView v = long_view_of(in);
+    char name[48];
+    {
+        std::snprintf(name, sizeof(name), "k_collapse_insert%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        hipLaunchKernelGGL(k_collapse_insert_long, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->cur, v, t.rep, t.firstj, t.cnt, t.slot_of,
+                           tsize - 1, dsample, in.orig, in.base, S, dweight);
+    }
+    t.cnt_base = t.cnt; t.cnt_stride = (uint32_t)S;
+    {
+        std::snprintf(name, sizeof(name), "k_heads_blocksum%s", group_tag(gi));
+        LaunchScope ls(c, name, in.n);
+        // (no length histogram: it stops at MIRGE_MAX_READ_LEN; the heads' bases are summed instead)
+        hipLaunchKernelGGL(k_heads_blocksum, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, t.slot_of, (const uint32_t*)t.firstj, 1u, 0u, in.n,
+                           (const uint8_t*)nullptr, t.flag, t.blocksum, dmeta + MIRGE_META_HIST);
+        hipLaunchKernelGGL(k_long_heads_bases, dim3(grid_for(c, in.n)), dim3(MIRGE_BLOCK), 0, c->cur, t.slot_of, (const uint32_t*)t.firstj, v.len, in.n,
+                           reinterpret_cast<unsigned long long*>(dmeta + MIRGE_META_LONG_BASES));
+    }
+    {
+        LaunchScope ls(c, "k_scan_blocksums", t.nb);
+        hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(MIRGE_BLOCK), 0, c->cur, t.blocksum, t.nb, dmeta + gi);
+    }
+    return 0;
+}
+
+static int collapse_phase_b_long(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup& out, CollapseTmp& t, int32_t S, uint32_t U,
+                                 uint32_t out_base, const uint32_t* dmeta) {
+    out.W = in.W; out.n = U; out.base = out_base;
+    if (!in.n) return 0;
+    CHECK(dalloc(c, &out.seq, (size_t)out.W * U));
+    CHECK(dalloc(c, &out.len, (size_t)U * 2));
+    if (in.nmask) CHECK(dalloc(c, &out.nmask, (size_t)out.W * U));
+    CHECK(dalloc(c, &out.counts, (size_t)U * S));
+    CHECK(dalloc(c, &out.first, (size_t)U));
+    char name[48];
+    std::snprintf(name, sizeof(name), "k_collapse_scatter%s", group_tag(gi));
+    LaunchScope ls(c, name, in.n);
+    hipLaunchKernelGGL(k_collapse_scatter_long, dim3(t.nb), dim3(MIRGE_BLOCK), 0, c->cur, long_view_of(in), t.slot_of, t.flag, t.cnt_base,
+                       t.cnt_stride, t.blocksum, dmeta + gi, in.orig, in.base, S, out.seq, reinterpret_cast<uint16_t*>(out.len), out.nmask,
+                       out.counts, out.first);
+    return 0;
+}
+
 static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
     c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
     c->defer(t.flag); c->defer(t.blocksum);
@@ -303,7 +366,8 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
             const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
             c->cur = gi == big ? c->stream : c->aux;
-            MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage, dweight));
+            if (is_long_group(gi)) rc = collapse_phase_a_long(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, stage, dweight);
+            else MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage, dweight));
             if (k < 0) hc.lap("first kernel of the bulk group enqueued");
         }
         // (no join here: the second stream waits for the main one below and carries the read-back of the counts)
@@ -362,11 +426,14 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             R->len_hist[L] = (int32_t)c->pinned[MIRGE_META_HIST + L];
             R->total_bases += (int64_t)L * c->pinned[MIRGE_META_HIST + L];
         }
+        R->total_bases += (int64_t)((uint64_t)c->pinned[MIRGE_META_LONG_BASES] | ((uint64_t)c->pinned[MIRGE_META_LONG_BASES + 1] << 32));
+        R->long_max = raw->long_max;
         R->hist_valid = true;
         rc = stream_fork(c);
         for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
             c->cur = gi == big ? c->stream : c->aux;
-            MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta));
+            if (is_long_group(gi)) rc = collapse_phase_b_long(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            else MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta));
             base += R->g[gi].n;
         }
         { int jr = stream_join(c); if (rc == 0) rc = jr; }

@@ -190,7 +190,7 @@ extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, c
         const ResGroup& r = res->g[gi];
         if (g.orig) return fail(-1, "mirge_annotation_csv_device: the read set is not a collapse result");
         if (g.n != r.n && !(res->dmeta)) return fail(-1, "mirge_annotation_csv_device: result and read set differ");
-        t.g[gi] = CsvGroup{g.seq, g.nmask, g.len, g.counts, r.pass, r.ref, g.base, g.n, g.W};
+        t.g[gi] = CsvGroup{g.seq, g.nmask, g.len, g.counts, r.pass, r.ref, g.base, g.n, g.W, is_long_group(gi) ? 1 : 0};
     }
     // names: one blob + 32-bit offsets per pass, uploaded per call (a human library set: ~0.2 M names, a few MB)
     std::vector<uint8_t> blob;
@@ -347,7 +347,8 @@ static void csv_tables_of(const mirge_reads* U, const mirge_result* res, CsvTabl
     t.S = U->n_samples;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ReadGroup& g = U->g[gi];
-        t.g[gi] = CsvGroup{g.seq, g.nmask, g.len, g.counts, res ? res->g[gi].pass : nullptr, res ? res->g[gi].ref : nullptr, g.base, g.n, g.W};
+        t.g[gi] = CsvGroup{g.seq, g.nmask, g.len, g.counts, res ? res->g[gi].pass : nullptr, res ? res->g[gi].ref : nullptr, g.base, g.n, g.W,
+                           is_long_group(gi) ? 1 : 0};
     }
 }
 
@@ -367,6 +368,7 @@ extern "C" int mirge_collapse_order_sorted(mirge_ctx* c, const mirge_reads* U, i
         maxlen = 1;
         for (int L = 1; L <= MIRGE_MAX_READ_LEN; L++) if (U->len_hist[L]) maxlen = L;
     }
+    maxlen = std::max(maxlen, (int)U->long_max);  // the long read class lies outside the histogram
     const int n_words = (maxlen + MIRGE_LEX_BASES - 1) / MIRGE_LEX_BASES;
     CsvTables t;
     csv_tables_of(U, nullptr, t);

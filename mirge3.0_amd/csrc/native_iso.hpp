@@ -55,7 +55,7 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
         const ReadGroup& rg = U->g[gi];
-        if (!g.n || kGroupW[gi] > 2) continue;  // a read annotated to a miRNA is at most 3 nt longer than it
+        if (!g.n || kGroupW[gi] > 2 || is_long_group(gi)) continue;  // a read annotated to a miRNA is at most 3 nt longer than it
         // one 64-thread workgroup per chunk of reads, in both kernels: chunk b's miRNA rows are list[b * chunk ...]
         const uint32_t tgrid = (uint32_t)grid_for(c, g.n, 64);
         uint32_t chunk = ((uint32_t)g.n + tgrid - 1) / tgrid;

@@ -3,22 +3,28 @@
 // ------------------------------------------------------------------------------------------
 // reads
 // ------------------------------------------------------------------------------------------
-// Eight read groups: width class (<=31, <=64, <=128, <=255 nt) x (no ambiguous call | has an N).  Reads with
+// Ten read groups: width class (<=31, <=64, <=128, <=255 nt, longer) x (no ambiguous call | has an N).  Reads with
 // an N are rare (~0.1 %); keeping them apart lets the big groups run without an nmask array and lets
-// the <=31-nt group collapse on a 64-bit key (sequence bits + length sentinel).
-#define MIRGE_NGROUPS 8
+// the <=31-nt group collapse on a 64-bit key (sequence bits + length sentinel).  The fifth class holds what the templated
+// kernels have no width for -- reads of 256 to 65535 nt, which the reference would hand to bowtie like any other (no upper
+// bound: parse.py:102, digest.py:348,368): W words per read with W set by the longest read of the set, the length in 16
+// bits, kernels of its own that take any length (kernels_long.hpp).
+#define MIRGE_NGROUPS 10
 #define MIRGE_NWIDTHS (MIRGE_NGROUPS / 2)
 static_assert(MIRGE_NGROUPS == MIRGE_NCLS, "read groups = classes of k_seq_class");
-static const int kGroupW[MIRGE_NGROUPS] = {1, 2, 4, 8, 1, 2, 4, 8};
-static inline int width_class(int64_t L) { return L <= 31 ? 0 : (L <= 64 ? 1 : (L <= 128 ? 2 : 3)); }
-// run `call` with W = the width of read group gi
+static const int kGroupW[MIRGE_NGROUPS] = {1, 2, 4, 8, 0, 1, 2, 4, 8, 0};  // 0: the long class (ReadGroup::W at run time)
+static inline bool is_long_group(int gi) { return kGroupW[gi] == 0; }
+static inline size_t len_bytes(int gi) { return is_long_group(gi) ? 2 : 1; }  // ReadGroup::len holds uint16 for the long class
+static inline int width_class(int64_t L) { return L <= 31 ? 0 : (L <= 64 ? 1 : (L <= 128 ? 2 : (L <= MIRGE_MAX_READ_LEN ? 3 : 4))); }
+// run `call` with W = the width of read group gi (the four templated classes: callers take the long class aside first)
 #define MIRGE_BY_WIDTH(gi, rc, call)                         \
     do {                                                     \
         switch (kGroupW[gi]) {                               \
             case 1: { constexpr int W = 1; rc = call; } break; \
             case 2: { constexpr int W = 2; rc = call; } break; \
             case 4: { constexpr int W = 4; rc = call; } break; \
-            default: { constexpr int W = 8; rc = call; } break; \
+            case 8: { constexpr int W = 8; rc = call; } break; \
+            default: rc = fail(-1, "internal: the long read class has no templated kernel"); break; \
         }                                                    \
     } while (0)
 
@@ -26,7 +32,7 @@ struct ReadGroup {
     int W = 1;
     uint32_t n = 0;
     uint64_t* seq = nullptr;
-    uint8_t* len = nullptr;
+    uint8_t* len = nullptr;    // [n]; the long class: uint16 [n] behind the same pointer (len_bytes)
     uint64_t* nmask = nullptr;
     uint32_t* orig = nullptr;    // handle-order index of each read (nullptr: base + j)
     uint32_t base = 0;
@@ -43,7 +49,12 @@ struct mirge_reads {
     int32_t len_hist[MIRGE_MAX_READ_LEN + 1];  // lengths present (host), for table preparation
     bool hist_valid = false;
     bool iupac_seen = false;  // some read held an IUPAC code other than N: packed (and printed) as N
+    int32_t long_max = 0;     // longest read of the long class (0: none): its groups hold (long_max + 31) / 32 words per read
 };
+
+static LongView long_view_of(const ReadGroup& g) {
+    LongView v; v.seq = g.seq; v.nmask = g.nmask; v.len = reinterpret_cast<const uint16_t*>(g.len); v.n = g.n; v.W = (uint32_t)g.W; return v;
+}
 
 static int largest_group(const mirge_reads* R) {
     int best = 0;
@@ -85,25 +96,32 @@ extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts,
         R->total_bases += parts[p]->total_bases;
         R->hist_valid = R->hist_valid && parts[p]->hist_valid;
         for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) R->len_hist[L] += parts[p]->len_hist[L];
+        R->long_max = std::max(R->long_max, parts[p]->long_max);
     }
     int rc = 0;
     for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
         ReadGroup& g = R->g[gi];
-        g.W = kGroupW[gi];
+        g.W = is_long_group(gi) ? (R->long_max + 31) / 32 : kGroupW[gi];
         uint64_t n = 0;
         bool mask = false;
         for (int p = 0; p < n_parts; p++) { n += parts[p]->g[gi].n; mask = mask || parts[p]->g[gi].nmask; }
         g.n = (uint32_t)n;
         if (!g.n) continue;
         if ((rc = dalloc(c, &g.seq, (size_t)g.W * g.n))) break;
-        if ((rc = dalloc(c, &g.len, (size_t)g.n))) break;
+        if ((rc = dalloc(c, &g.len, (size_t)g.n * len_bytes(gi)))) break;
         if ((rc = dalloc(c, &g.orig, (size_t)g.n))) break;
         if (mask && (rc = dalloc(c, &g.nmask, (size_t)g.W * g.n))) break;
         uint32_t at = 0, before = 0;
         hipError_t e = hipSuccess;
         for (int p = 0; p < n_parts && e == hipSuccess; p++) {
             const ReadGroup& q = parts[p]->g[gi];
-            if (q.n) {
+            if (q.n && is_long_group(gi)) {  // the parts may hold different numbers of words per read
+                hipLaunchKernelGGL(k_long_copy, dim3(grid_for(c, q.n)), dim3(MIRGE_BLOCK), 0, c->stream, long_view_of(q), (uint32_t)g.W, g.n, at,
+                                   g.seq, g.nmask, reinterpret_cast<uint16_t*>(g.len));
+                hipLaunchKernelGGL(k_index_shift, dim3(grid_for(c, q.n)), dim3(MIRGE_BLOCK), 0, c->stream, (const uint32_t*)q.orig, q.base,
+                                   q.n, before, g.orig + at);
+                at += q.n;
+            } else if (q.n) {
                 for (int w = 0; w < g.W && e == hipSuccess; w++) {  // word-major arrays: one copy per word plane
                     e = hipMemcpyAsync(g.seq + (size_t)w * g.n + at, q.seq + (size_t)w * q.n, (size_t)q.n * 8, hipMemcpyDeviceToDevice, c->stream);
                     if (e == hipSuccess && g.nmask) {
@@ -148,6 +166,14 @@ static int launch_pack(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstar
     return 0;
 }
 
+static int launch_pack_long(mirge_ctx* c, const uint8_t* dascii, const int64_t* dstart, const int64_t* dend, const uint32_t* didx,
+                            ReadGroup& g, uint32_t* dflags, const int64_t* s2start = nullptr, const int32_t* s2len = nullptr) {
+    LaunchScope ls(c, "k_pack_long", g.n);
+    hipLaunchKernelGGL(k_pack_long, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, dascii, dstart, dend, didx, g.n, (uint32_t)g.W,
+                       g.seq, reinterpret_cast<uint16_t*>(g.len), g.nmask, dflags, s2start, s2len);
+    return 0;
+}
+
 extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads** out) {
     if (!c || !out || !off || n < 0 || (n > 0 && !ascii)) return fail(-1, "mirge_reads_pack: bad argument");
     if (n >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
@@ -165,13 +191,14 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
         const int T = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
         std::vector<std::vector<uint32_t>> part((size_t)T * MIRGE_NGROUPS);
         std::vector<std::vector<int32_t>> hist((size_t)T, std::vector<int32_t>(MIRGE_MAX_READ_LEN + 1, 0));
-        std::vector<int64_t> bad((size_t)T, -1), badlen((size_t)T, 0);
+        std::vector<int64_t> bad((size_t)T, -1), badlen((size_t)T, 0), longest((size_t)T, 0);
         auto work = [&](int t) {
             const int64_t lo = n * t / T, hi = n * (t + 1) / T;
             for (int64_t i = lo; i < hi; i++) {
                 const int64_t L = off[i + 1] - off[i];
-                if (L < 0 || L > MIRGE_MAX_READ_LEN) { if (bad[t] < 0) { bad[t] = i; badlen[t] = L; } continue; }
-                hist[t][L]++;
+                if (L < 0 || L > MIRGE_LONG_MAX_LEN) { if (bad[t] < 0) { bad[t] = i; badlen[t] = L; } continue; }
+                if (L <= MIRGE_MAX_READ_LEN) hist[t][L]++;
+                else longest[t] = std::max<int64_t>(longest[t], L);
                 bool amb = false;
                 for (int64_t b = off[i]; b < off[i + 1]; b++) amb |= !is_acgt[(unsigned char)ascii[b]];
                 part[(size_t)t * MIRGE_NGROUPS + width_class(L) + (amb ? MIRGE_NWIDTHS : 0)].push_back((uint32_t)i);
@@ -185,9 +212,10 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
             if (bad[t] >= 0) {
                 if (badlen[t] < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
                 return fail(-6, "read " + std::to_string(bad[t]) + " is " + std::to_string(badlen[t]) + " nt; the limit is " +
-                                std::to_string(MIRGE_MAX_READ_LEN));
+                                std::to_string(MIRGE_LONG_MAX_LEN));
             }
             for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) R->len_hist[L] += hist[t][L];
+            R->long_max = std::max<int32_t>(R->long_max, (int32_t)longest[t]);
         }
         for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {  // thread ranges are consecutive: order is preserved
             size_t tot = 0;
@@ -205,29 +233,30 @@ extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* 
     uint8_t* dascii = nullptr; int64_t* doff = nullptr; uint32_t* dflags = nullptr;
     CHECK(dalloc(c, &dascii, (size_t)std::max<int64_t>(nbytes, 1)));
     CHECK(dalloc(c, &doff, (size_t)n + 1));
-    CHECK(dalloc(c, &dflags, 16));
+    CHECK(dalloc(c, &dflags, 2 * MIRGE_NGROUPS + 4));
     std::vector<int64_t> rel((size_t)n + 1);
     for (int64_t i = 0; i <= n; i++) rel[(size_t)i] = off[i] - off[0];
     if (nbytes) HIPOK(hipMemcpyAsync(dascii, ascii + off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipMemcpyAsync(doff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemsetAsync(dflags, 0, 64, c->stream));
+    HIPOK(hipMemsetAsync(dflags, 0, 2 * MIRGE_NGROUPS * 4, c->stream));
     uint32_t* didx[MIRGE_NGROUPS] = {nullptr};
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         ReadGroup& g = R->g[gi];
-        g.W = kGroupW[gi];
+        g.W = is_long_group(gi) ? (R->long_max + 31) / 32 : kGroupW[gi];
         g.n = (uint32_t)idx[gi].size();
         if (!g.n) continue;
         CHECK(dalloc(c, &g.seq, (size_t)g.W * g.n));
         CHECK(dalloc(c, &g.nmask, (size_t)g.W * g.n));
-        CHECK(dalloc(c, &g.len, (size_t)g.n));
+        CHECK(dalloc(c, &g.len, (size_t)g.n * len_bytes(gi)));
         CHECK(dalloc(c, &g.orig, (size_t)g.n));
         HIPOK(hipMemcpyAsync(g.orig, idx[gi].data(), (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream));
         didx[gi] = g.orig;
         int prc = 0;
-        MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi));
+        if (is_long_group(gi)) prc = launch_pack_long(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
+        else MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi));
         (void)prc;
     }
-    HIPOK(hipMemcpyAsync(c->pinned, dflags, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPOK(hipMemcpyAsync(c->pinned, dflags, 2 * MIRGE_NGROUPS * 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));  // idx/rel host vectors are read by the async copies
     c->release(dascii); c->release(doff); c->release(dflags);
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
@@ -467,7 +496,7 @@ static int parse_pack(ParseJob& J, int64_t* start, int64_t* end, int64_t* s2star
         if (c->pinned[512 + 3]) { rc = fail(-9, std::string("mirge_reads_parse: a record does not start with '") + (format == 1 ? "@' / its third line with '+'" : ">'") +
                                                   " (truncated file, blank line, or a FASTA with wrapped sequences)"); break; }
         if (c->pinned[512 + 5]) { rc = fail(-9, "mirge_reads_parse: a record's quality line is not as long as its sequence line"); break; }
-        if (c->pinned[1]) { rc = fail(-6, "a read is " + std::to_string(c->pinned[2]) + " nt; the limit is " + std::to_string(MIRGE_MAX_READ_LEN)); break; }
+        if (c->pinned[1]) { rc = fail(-6, "a read is " + std::to_string(c->pinned[2]) + " nt; the limit is " + std::to_string(MIRGE_LONG_MAX_LEN)); break; }
         if (c->pinned[0]) { rc = fail(-7, "a read contains a character that is no nucleotide code (A/C/G/T/U/N or an IUPAC ambiguity code)"); break; }
         R->iupac_seen = c->pinned[4] != 0;
         const uint32_t kept = bounds[MIRGE_NGROUPS];
@@ -476,6 +505,11 @@ static int parse_pack(ParseJob& J, int64_t* start, int64_t* end, int64_t* s2star
             R->len_hist[L] = (int32_t)c->pinned[8 + L];
             R->total_bases += (int64_t)L * c->pinned[8 + L];
         }
+        // the long class (reads beyond MIRGE_MAX_READ_LEN: outside the histogram): its longest read sets the words per read
+        R->long_max = (int32_t)c->pinned[5];
+        R->total_bases += (int64_t)((uint64_t)c->pinned[6] | ((uint64_t)c->pinned[7] << 32));
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+            if (is_long_group(gi)) R->g[gi].W = (R->long_max + 31) / 32;
         if (!kept) break;
         if ((rc = dalloc(c, &src_all, (size_t)kept))) break;
         if ((rc = dalloc(c, &orig_all, (size_t)kept))) break;
@@ -483,19 +517,20 @@ static int parse_pack(ParseJob& J, int64_t* start, int64_t* end, int64_t* s2star
         hipLaunchKernelGGL(k_seq_place, dim3(nblk), dim3(MIRGE_BLOCK), 0, c->stream, dcls, n_seq, blk_off, keep_off, nblk, src_all,
                            orig_all, rok);
         uint32_t* dflags = dmeta;  // reused: k_pack's per-group (saw N, bad byte) pairs
-        e = hipMemsetAsync(dflags, 0, 64, c->stream);
+        e = hipMemsetAsync(dflags, 0, 2 * MIRGE_NGROUPS * 4, c->stream);
         for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0 && e == hipSuccess; gi++) {
             ReadGroup& g = R->g[gi];
             g.n = bounds[gi + 1] - bounds[gi];
             if (!g.n) continue;
             if ((rc = dalloc(c, &g.seq, (size_t)g.W * g.n))) break;
             if ((rc = dalloc(c, &g.nmask, (size_t)g.W * g.n))) break;
-            if ((rc = dalloc(c, &g.len, (size_t)g.n))) break;
+            if ((rc = dalloc(c, &g.len, (size_t)g.n * len_bytes(gi)))) break;
             if ((rc = dalloc(c, &g.orig, (size_t)g.n))) break;
             e = hipMemcpyAsync(g.orig, orig_all + bounds[gi], (size_t)g.n * 4, hipMemcpyDeviceToDevice, c->stream);
             const uint32_t* src = src_all + bounds[gi];
             int prc = 0;
-            MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, J.dtext, start, end, src, g, dflags + 2 * gi, s2start, s2len));
+            if (is_long_group(gi)) prc = launch_pack_long(c, J.dtext, start, end, src, g, dflags + 2 * gi, s2start, s2len);
+            else MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, J.dtext, start, end, src, g, dflags + 2 * gi, s2start, s2len));
             (void)prc;
         }
         if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -646,8 +681,12 @@ extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* asci
         const ReadGroup& g = R->g[gi];
         if (!g.n) continue;
         LaunchScope ls(c, "k_scatter_len", g.n);
-        hipLaunchKernelGGL(k_scatter_len, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
-                           g.len, g.n, g.base, g.orig, dlen);
+        if (is_long_group(gi))
+            hipLaunchKernelGGL(k_scatter_len16, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                               reinterpret_cast<const uint16_t*>(g.len), g.n, g.base, g.orig, dlen);
+        else
+            hipLaunchKernelGGL(k_scatter_len, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream,
+                               g.len, g.n, g.base, g.orig, dlen);
     }
     std::vector<int32_t> hlen((size_t)std::max<int64_t>(n, 1));
     if (n) HIPOK(hipMemcpyAsync(hlen.data(), dlen, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -664,7 +703,9 @@ extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* asci
         if (!g.n) continue;
         LaunchScope ls(c, "k_unpack", g.n);
         int urc = 0;
-        MIRGE_BY_WIDTH(gi, urc, launch_unpack<W>(c, g, doff, dout));
+        if (is_long_group(gi))
+            hipLaunchKernelGGL(k_unpack_long, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, long_view_of(g), doff, g.base, g.orig, dout);
+        else MIRGE_BY_WIDTH(gi, urc, launch_unpack<W>(c, g, doff, dout));
         (void)urc;
     }
     if (total) HIPOK(hipMemcpyAsync(ascii_out, dout, (size_t)total, hipMemcpyDeviceToHost, c->stream));

@@ -72,7 +72,7 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     workDir = Path(workDir)
     casc = casc or get_cascade(args, ref_db, getattr(args, "device", 0))
     ctx = casc.ctx
-    raw, n_rec = parse_sample(ctx, read_text(str(file)), int(getattr(args, "minimum_length", 16)), trim_from_args(args),
+    raw, n_rec = parse_sample(ctx, read_text(str(file), stream=True), int(getattr(args, "minimum_length", 16)), trim_from_args(args),
                               umi_from_args(args), workDir, name)
     n_trimmed = len(raw)
     if getattr(args, "tcf_out", False):
@@ -138,13 +138,14 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     parsed = []
     t_read = t_parse = 0.0
-    texts = read_texts(files)  # files are read (and gunzipped) ahead on worker threads
+    texts = read_texts(files, stream=True)  # read ahead on worker threads; a .gz is inflated piece by piece beside its own parse
+    gz_tm: Dict[str, float] = {}
     for f, name in zip(files, base_names):
         t = time.perf_counter()
         text = next(texts)
         t_read += time.perf_counter() - t
         t1 = time.perf_counter()
-        raw, n_rec = parse_sample(ctx, text, min_len, trim, umi, workDir, name)
+        raw, n_rec = parse_sample(ctx, text, min_len, trim, umi, workDir, name, timings=gz_tm)
         del text
         t_parse += time.perf_counter() - t1
         sampleReadCounts[name], trimmedReadCounts[name] = n_rec, len(raw)
@@ -155,6 +156,8 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         parsed.append(raw)
         say(f'Cutadapt finished for file {name} in {round(time.perf_counter() - t, 4)} second(s)')
     tm["read_files_s"], tm["parse_s"] = t_read, t_parse
+    if gz_tm:  # streamed .gz input: parse_s is then bounded by the inflation (inflate_s, on its worker thread), of which
+        tm["gz_stream"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in gz_tm.items()}  # upload_parse_s is the GPU side's share
     t = time.perf_counter()
     say("Alignment in progress ...")
     S = len(parsed)

@@ -393,11 +393,11 @@ def test_edge_cases(ctx, ci_libs, ci_cascade):
     ps = ci_cascade.annotate(rnd)[0]
     o = oracle.cascade(rnd.data, rnd.offsets, oracle_libs_from(ci_libs.libs), n_pass=9)
     assert np.array_equal(ps.astype(np.int32), o[0])
-    # loud failures
-    with pytest.raises(RuntimeError, match="limit is 255"):
-        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["A" * 256]))
-    with pytest.raises(RuntimeError, match="limit is 255"):
-        _ffi.DeviceReads.parse(ctx, b"@r\n" + b"A" * 300 + b"\n+\n" + b"I" * 300 + b"\n", 1, 16)
+    # loud failures: only beyond what a 16-bit length holds (reads of 256-65535 nt are the long class: test_reads_longer_than_255_nt)
+    with pytest.raises(RuntimeError, match="limit is 65535"):
+        _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["A" * 65536]))
+    with pytest.raises(RuntimeError, match="limit is 65535"):
+        _ffi.DeviceReads.parse(ctx, b"@r\n" + b"A" * 70000 + b"\n+\n" + b"I" * 70000 + b"\n", 1, 16)
     # untrimmed Illumina lengths (150 nt) go through: the fourth width class
     long_ref = ci_libs.libs["mrna"].seqs.get(5)
     lr = [long_ref[40:190], long_ref[100:355], long_ref[7:136]]
@@ -522,8 +522,9 @@ def test_device_text_parser_equals_host_parser(ctx, ci_libs, tmp_path):
     assert len(dr) == 0 and n_rec == 0
     dr, n_rec = _ffi.DeviceReads.parse(ctx, b"@r\nACGT\n+\nIIII\n", 0, 16)
     assert len(dr) == 0 and n_rec == 1 and len(dr.collapse()) == 0
-    with pytest.raises(RuntimeError, match="limit is 255"):
-        _ffi.DeviceReads.parse(ctx, ("A" * 256 + "\n").encode(), 3, 0)
+    dr, n_rec = _ffi.DeviceReads.parse(ctx, ("A" * 256 + "\n").encode(), 3, 0)  # one base beyond the widest templated class
+    assert n_rec == 1 and dr.unpack().to_list() == ["A" * 256] and int(dr.group_counts()[4]) == 1
+    dr.close()
     with pytest.raises(RuntimeError, match="no nucleotide code"):
         _ffi.DeviceReads.parse(ctx, b"ACGTACGTACGTACGTXACGT\n", 3, 0)
     # a record whose quality line is shorter / longer than its sequence line: dnaio raises, and so does the trimming parser
@@ -1143,14 +1144,13 @@ def test_collapse_count_matrix_beyond_2_to_32_cells(ctx):
     raw.close()
 
 
-@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0"),
-                                   dict(MIRGE_FUSED_MAX="0", MIRGE_WALKS="1,1,1,1,1,1,1,1,1,1"), dict(MIRGE_FUSED_MAX="0", MIRGE_WALKS="2,3,1,4")])
+@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0")])
 def test_staged_cascade_for_every_group(hooks):
     """Small read groups normally take k_cascade_fused (one launch for the whole cascade, no compaction); MIRGE_FUSED_MAX=0
-    sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch, the
-    steps taken in walks: MIRGE_WALKS forces one list per step, as round 3 had it, and an arbitrary grouping), or with
-    MIRGE_BULK_FUSED=0 one k_pass launch per pass.  All must agree with the oracle: the oracle parity tests of this file, the
-    one-call route (full cascade and the one-pass C2 cascade) and the cascade fuzz are re-run in a fresh process with the hooks set."""
+    sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch), or
+    with MIRGE_BULK_FUSED=0 one k_pass launch per pass.  All must agree with the oracle: the oracle parity tests of this
+    file, the one-call route (full cascade and the one-pass C2 cascade) and the cascade fuzz are re-run in a fresh process with
+    the hooks set."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -1911,6 +1911,184 @@ def test_cli_with_adapter_trimming_end_to_end(tmp_path):
     a = (tmp_path / "trimmed" / "annotation.report.csv").read_text().splitlines()[1].split(",")
     b = (tmp_path / "untrimmed" / "annotation.report.csv").read_text().splitlines()[1].split(",")
     assert a[1:] == b[1:] and int(a[2]) > 1000
+
+
+def test_reads_longer_than_255_nt(ctx, ci_libs, ci_cascade, tmp_path):
+    """The reference puts no upper bound on a read (`-M` is parsed and never read, parse.py:102; the worker tests the minimum
+    only, digest.py:348,368): an untrimmed 300-cycle read, or a merged pair, goes through bowtie like any other.  Reads of
+    256 / 300 / 600 / 5000 nt -- fragments of mRNA, rRNA and ncRNA references with 0-3 mismatches placed inside and outside
+    the seed, with an N, with a T tail, a read that runs over a reference's end, random ones -- mixed into ordinary reads:
+    pack and parse, unpack, collapse (duplicates, several samples, weights), the cascade against the oracle (with and without
+    the mRNA library), the count join, the sorted order, both CSV routes and the CLI."""
+    rng = np.random.default_rng(77)
+    libs = ci_libs.libs
+
+    def mutate(q, where):
+        q = list(q)
+        for w in where:
+            q[w] = "ACGT"[("ACGT".index(q[w]) + 1 + int(rng.integers(0, 3))) % 4] if q[w] in "ACGT" else "A"
+        return "".join(q)
+
+    longs = []
+    for key, n_take in (("mrna", 14), ("rrna", 4), ("ncrna_others", 6)):
+        seqs_ = [q for q in libs[key].seqs.to_list() if len(q) >= 700]
+        for k in range(min(n_take, len(seqs_))):
+            ref = seqs_[k]
+            for L in (256, 300, 600):
+                o = int(rng.integers(0, len(ref) - L))
+                frag = ref[o:o + L]
+                longs += [frag, mutate(frag, [5]), mutate(frag, [40, 200]), mutate(frag, [3, 90]), mutate(frag, [100, 150, 250]),
+                          mutate(frag, [27]), mutate(frag, [28]), frag[:120] + "N" + frag[121:], frag[:10] + "N" + frag[11:]]
+            longs.append(ref[-300:] + "ACGTACGTAC")       # runs over the reference's end
+            longs.append(ref[:280] + "T" * 12)            # a T tail: pass 3 strips it, the others see it
+    big = [q for q in libs["mrna"].seqs.to_list() if len(q) >= 5200]
+    if big:
+        longs += [big[0][100:5100], mutate(big[0][100:5100], [4000, 4500])]
+    longs += ["".join("ACGT"[x] for x in rng.integers(0, 4, 400)) for _ in range(5)] + ["T" * 300, "A" * 256 + "TTTT", "ACGT" * 64]
+    longs = [q for q in longs if set(q) <= set("ACGTN")]
+    shorts = synth.make_reads(ci_libs, 3000, seed=5, n_frac=0.02).to_list()
+    mixed = shorts[:1500] + longs + shorts[1500:] + longs[:25] + [longs[3]] * 4   # duplicates of long reads, far apart
+    order = rng.permutation(len(mixed))
+    mixed = [mixed[i] for i in order]
+    fs = FlatSeqs.from_list(mixed)
+    # pack (host ASCII) and parse (text on the device) agree, unpack returns the letters
+    dr = _ffi.DeviceReads.pack(ctx, fs)
+    text = "".join(f"@r{i}\n{q}\n+\n{'I' * len(q)}\n" for i, q in enumerate(mixed)).encode()
+    dp, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 16)
+    assert n_rec == len(mixed) and len(dr) == len(dp) == len(mixed)
+    assert dr.unpack().to_list() == mixed and dp.unpack().to_list() == mixed
+    gc = dr.group_counts()
+    assert len(gc) == 10 and int(gc[4] + gc[9]) == sum(len(q) > 255 for q in mixed) and np.array_equal(gc, dp.group_counts())
+    # collapse: the dictionary of the reference (digest.py:141-163)
+    for raw in (dr, dp):
+        u = raw.collapse()
+        cnt, first = u.counts()
+        o_first, o_cnt, _ = oracle.collapse(fs.data, fs.offsets)
+        od = np.argsort(first, kind="stable")
+        assert len(u) == len(o_first) and np.array_equal(first[od], o_first) and np.array_equal(cnt[od, 0].astype(np.int64), o_cnt)
+        useq = u.unpack()
+        assert [useq.to_list()[i] for i in od] == [mixed[i] for i in o_first]
+        # the cascade, every field, against the oracle -- all nine passes, then without the mRNA library (pass 7 absent)
+        res = ci_cascade.run(u)
+        got = res.fetch()
+        want = oracle.cascade(useq.data, useq.offsets, oracle_libs_from(libs), n_pass=9, indexed=False)
+        for a, b in zip(want, got):
+            assert np.array_equal(a.astype(np.int64), b.astype(np.int64))
+        lens = useq.lengths
+        assert (got[0][lens > 255] >= 0).sum() > 50 and (got[0][lens > 255] < 0).sum() >= 5   # both kinds are present
+        assert set(np.unique(got[0][lens > 255]).tolist()) & {4, 5, 6, 7}
+        cls, ex, iso = _ffi.count_join(ctx, u, res, 0, 8, len(libs["mirna"]))
+        for p_ in range(9):
+            assert cls[p_, 0] == cnt[got[0] == p_, 0].sum()
+        # the rows pandas would sort (several samples) and both CSV routes
+        so = u.sorted_order()
+        ul = useq.to_list()
+        assert [ul[i] for i in so] == sorted(ul)
+        res.close(); u.close()
+    no_mrna = {k: v for k, v in libs.items() if k != "mrna"}
+    c2 = Cascade(ctx, no_mrna)
+    ul = FlatSeqs.from_list(sorted(set(longs)))
+    got = c2.annotate(ul)
+    olibs = oracle_libs_from(libs)
+    olibs[7] = (np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    want = oracle.cascade(ul.data, ul.offsets, olibs, n_pass=9, indexed=False)
+    for a, b in zip(want, got):
+        assert np.array_equal(a.astype(np.int64), b.astype(np.int64))
+    assert (got[0] == 7).sum() == 0
+    c2.close()
+    # several samples + weights (the sharded run's merge)
+    half = len(mixed) // 2
+    u2 = collapse_samples(ctx, [FlatSeqs.from_list(mixed[:half]), FlatSeqs.from_list(mixed[half:])])
+    c2_, _ = u2.counts()
+    sq = u2.unpack().to_list()
+    ca, cb = Counter(mixed[:half]), Counter(mixed[half:])
+    assert len(sq) == len(set(mixed)) and all((int(c2_[i, 0]), int(c2_[i, 1])) == (ca.get(q, 0), cb.get(q, 0)) for i, q in enumerate(sq))
+    u2.close(); dr.close(); dp.close()
+    # the CLI on a file that holds them: every row of mapped.csv / unmapped.csv as the DataFrame route writes it
+    case = GoldenCase("case1_single")
+    cl = [q for q in case.libs["mrna"].seqs.to_list() if len(q) >= 320][:3]
+    extra = [cl[0][5:305], cl[1][0:256], mutate(cl[2][10:310], [100]), "".join("ACGT"[x] for x in rng.integers(0, 4, 333))] if len(cl) == 3 else \
+        ["".join("ACGT"[x] for x in rng.integers(0, 4, 333)), "".join("ACGT"[x] for x in rng.integers(0, 4, 256))]
+    files = _case_fastqs(case, tmp_path)
+    with open(files[0], "a") as fh:
+        for k, q in enumerate(extra * 2):
+            fh.write(f"@long{k}\n{q}\n+\n{'I' * len(q)}\n")
+    _run_cli(["-s", files[0], "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", "withlong", "-shh"])
+    rows = {}
+    for f in ("mapped.csv", "unmapped.csv"):
+        for ln in (tmp_path / "withlong" / f).read_text().splitlines()[1:]:
+            rows[ln.split(",")[0]] = (f, ln)
+    ol = oracle.cascade(FlatSeqs.from_list(extra).data, FlatSeqs.from_list(extra).offsets, oracle_libs_from(case.libs), n_pass=9, indexed=False)
+    for q, p_ in zip(extra, ol[0]):
+        f, ln = rows[q]
+        assert f == ("mapped.csv" if p_ >= 0 else "unmapped.csv") and ln.endswith(",2") and ln.split(",")[1] == ("1" if p_ >= 0 else "0")
+    golden = {ln.split(",")[0]: ln for f in ("mapped.csv", "unmapped.csv") for ln in case.text(f).splitlines()[1:]}
+    assert all(rows[q][1] == ln for q, ln in golden.items()) and len(rows) == len(golden) + len(extra)
+
+
+def test_streamed_gz_equals_the_plain_file(ctx, ci_libs, tmp_path):
+    """A .fastq.gz is inflated in record-aligned pieces on a worker thread and parsed piece by piece (collapse.GzipRecordStream,
+    mirge_reads_concat): the reads, their order, the record count and everything behind them are those of the plain file --
+    with pieces of a few records, several gzip members, trimming with the count after every modifier, UMIs (not streamed:
+    the whole text), and through the CLI with one compressed and one plain sample (digest.py:136-140)."""
+    import gzip
+    from mirge3_amd import collapse
+    reads = synth.make_reads(ci_libs, 40000, seed=12, n_frac=0.01).to_list()
+    ad = collapse.ILLUMINA_3P
+    rng = np.random.default_rng(3)
+    recs = []
+    for i, q in enumerate(reads):
+        s_ = (q + ad)[:50]
+        qual = "".join(chr(33 + int(x)) for x in rng.integers(2, 41, size=len(s_)))
+        recs.append(f"@r{i} 1:N:0\n{s_}\n+\n{qual}\n")
+    text = "".join(recs).encode()
+    plain = tmp_path / "S.fastq"
+    plain.write_bytes(text)
+    gz = tmp_path / "S.fastq.gz"
+    c = len(text) // 2 + 11
+    gz.write_bytes(gzip.compress(text[:c], 6) + gzip.compress(text[c:], 6))
+    trims = [None, _ffi.MirgeTrim.make(adapter=ad, quality_back=10, count_per_modifier=True),
+             _ffi.MirgeTrim.make(adapter=ad, quality_back=20, nextseq=15, trim_n=True, count_per_modifier=False)]
+    for trim in trims:
+        want, n_want = collapse.parse_sample(ctx, collapse.read_text(str(plain)), 16, trim, None)
+        for piece in (700, 50_000, 8 << 20):
+            tm = {}
+            got, n_got = collapse.parse_sample(ctx, collapse.GzipRecordStream(str(gz), piece_bytes=piece), 16, trim, None, timings=tm)
+            assert n_got == n_want == len(reads) and len(got) == len(want)
+            assert got.unpack().to_list() == want.unpack().to_list()
+            assert np.array_equal(got.group_counts(), want.group_counts())
+            assert tm["gz_pieces"] >= 1 and tm["inflate_s"] > 0 and (piece > 1 << 20 or tm["gz_pieces"] > 10)
+            u1, u2 = got.collapse(), want.collapse()
+            (c1, f1), (c2, f2) = u1.counts(), u2.counts()
+            o1, o2 = np.argsort(f1, kind="stable"), np.argsort(f2, kind="stable")
+            assert np.array_equal(f1[o1], f2[o2]) and np.array_equal(c1[o1], c2[o2])
+            for h in (u1, u2, got):
+                h.close()
+        want.close()
+    umi = _ffi.MirgeUmi.make(4, 2)
+    a, na = collapse.parse_sample(ctx, collapse.read_text(str(plain)), 16, trims[1], umi)
+    b, nb = collapse.parse_sample(ctx, collapse.GzipRecordStream(str(gz), piece_bytes=5000), 16, trims[1], umi)
+    assert na == nb and a.unpack().to_list() == b.unpack().to_list()
+    a.close(); b.close()
+    # the CLI: golden case 2, the first sample compressed (pieces of 2 kB), against both samples plain
+    case = GoldenCase("case2_two_samples")
+    files = _case_fastqs(case, tmp_path)
+    with open(files[0], "rb") as fh:
+        (tmp_path / "gzrun").mkdir()
+        zp = tmp_path / "gzrun" / (os.path.basename(files[0]) + ".gz")
+        zp.write_bytes(gzip.compress(fh.read(), 6))
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for tag, fl, env in (("plain", files, {}), ("gz", [str(zp), files[1]], {"MIRGE_GZ_PIECE_BYTES": "2000"})):
+        cmd = [sys.executable, "-c", "import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()" % root,
+               "-s", ",".join(fl), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", tag, "-shh"]
+        r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "annotation.report.csv"):
+        assert (tmp_path / "gz" / f).read_text() == (tmp_path / "plain" / f).read_text(), f
+        # (the golden report counts the reads below --minimum-length too, which _case_fastqs does not write back)
+        assert f == "annotation.report.csv" or (tmp_path / "gz" / f).read_text() == case.text(f), f
 
 
 def test_cli_library_cache_next_to_the_index(tmp_path):

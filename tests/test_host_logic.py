@@ -271,6 +271,63 @@ def test_read_texts_keeps_file_order_and_inflates_gz(tmp_path):
     assert [bytes(t) for t in read_texts(paths[:1])] == want[:1] and bytes(read_text(str(paths[1]))) == want[1]
 
 
+def test_gzip_record_stream(tmp_path):
+    """collapse.GzipRecordStream: a .fastq.gz comes out as pieces that are whole 4-line records, in order, byte for byte the
+    file's text -- whatever the piece size, for one member, several members (bgzip / cat), an empty member and zero padding
+    behind the last, and a text without a final newline; a truncated file raises (as gzip.open does), a FASTA comes whole
+    (and unwrapped), a consumer that gives up early does not leave the worker hanging; read_texts(stream=True) opens the
+    streams ahead and keeps the files' order."""
+    import gzip
+    from mirge3_amd import collapse
+    rng = np.random.default_rng(1)
+    recs = []
+    for i in range(30000):
+        L = int(rng.integers(16, 40))
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[x] for x in rng.integers(0, 4, L)), "I" * L))
+    text = "".join(recs).encode()
+    one = tmp_path / "a.fastq.gz"
+    with gzip.open(one, "wb", compresslevel=6) as fh:
+        fh.write(text)
+    many = tmp_path / "b.fastq.gz"
+    c1, c2 = len(text) // 3 + 7, 2 * len(text) // 3 + 1
+    many.write_bytes(b"".join(gzip.compress(part, 6) for part in (text[:c1], text[c1:c2], b"", text[c2:])) + b"\0" * 100)
+    nonl = tmp_path / "c.fastq.gz"
+    with gzip.open(nonl, "wb") as fh:
+        fh.write(text[:-1])
+    for path, want in ((one, text), (many, text), (nonl, text[:-1])):
+        for piece in (1 << 12, 1 << 16, 1 << 20, 8 << 20):
+            st = collapse.GzipRecordStream(str(path), piece_bytes=piece)
+            pieces = list(st)
+            assert b"".join(pieces) == want and st.text_bytes == len(want) and st.pieces == len(pieces)
+            assert st.compressed_bytes == path.stat().st_size and st.inflate_s > 0
+            for q in pieces[:-1]:
+                assert q.count(b"\n") % 4 == 0 and q[:1] == b"@" and q[-1:] == b"\n"
+            assert len(pieces) >= min(len(want) // (2 * piece), 3)
+    cut = tmp_path / "d.fastq.gz"
+    cut.write_bytes(one.read_bytes()[: one.stat().st_size // 2])
+    with pytest.raises(EOFError):
+        list(collapse.GzipRecordStream(str(cut)))
+    with pytest.raises(Exception):
+        (tmp_path / "g.fastq.gz").write_bytes(b"this is no gzip file")
+        list(collapse.GzipRecordStream(str(tmp_path / "g.fastq.gz")))
+    fa = tmp_path / "e.fa.gz"
+    with gzip.open(fa, "wb") as fh:
+        fh.write(b">a\nACGT\nACGT\n>b\nTTTT\n")
+    assert list(collapse.GzipRecordStream(str(fa))) == [("whole", b">a\nACGT\nACGT\n>b\nTTTT\n")]
+    assert collapse.GzipRecordStream(str(fa)).whole_text() == b">a\nACGTACGT\n>b\nTTTT\n"
+    assert collapse.GzipRecordStream(str(one), piece_bytes=1 << 14).whole_text() == text
+    st = collapse.GzipRecordStream(str(one), piece_bytes=1 << 12, depth=2)
+    next(iter(st))
+    st.close()
+    assert not st._thread.is_alive()
+    plain = tmp_path / "p.fastq"
+    plain.write_bytes(text[: text.index(b"@r100\n")])
+    got = list(collapse.read_texts([one, plain, many, nonl], depth=2, stream=True))
+    assert isinstance(got[0], collapse.GzipRecordStream) and isinstance(got[2], collapse.GzipRecordStream)
+    assert bytes(got[1]) == plain.read_bytes()
+    assert [b"".join(g) for g in (got[0], got[2], got[3])] == [text, text, text[:-1]]
+
+
 def test_sample_forms_of_the_command_line(tmp_path):
     """``-s`` as the reference reads it (mirge/__main__.py:85-118, miRgeEssential.validate_files :102-127): a comma list, a
     directory (sorted), a .txt / .csv list; only *.fastq / *.fq [.gz] files that exist are kept, a sample is named by its

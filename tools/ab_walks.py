@@ -7,9 +7,13 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 settings = [("default", {}), ("1x7", {"MIRGE_WALKS": "1,1,1,1,1,1,1"}), ("4,1,1,1", {"MIRGE_WALKS": "4,1,1,1"}), ("2,2,2,1", {"MIRGE_WALKS": "2,2,2,1"}),
             ("4,3", {"MIRGE_WALKS": "4,3"}), ("2,2,1,1,1", {"MIRGE_WALKS": "2,2,1,1,1"}), ("3,1,2,1", {"MIRGE_WALKS": "3,1,2,1"})]
 if os.environ.get("AB_WALKS"):
-    settings = [("default", {})] + [(w, {"MIRGE_WALKS": w}) for w in os.environ["AB_WALKS"].split(";")]
+    settings = [("default", {})] + [(w, {"MIRGE_WALKS": w}) for w in os.environ["AB_WALKS"].split(";") if w != "x"]
 if var:
     settings.append(("variant.so", {"MIRGE_NATIVE_SO": var}))
+for item in filter(None, os.environ.get("AB_SOS", "").split(";")):  # AB_SOS="name=path.so;name2=path2.so[@ENV=VALUE...]"
+    name, _, rest = item.partition("=")
+    path, *envs = rest.split("@")
+    settings.append((name, dict([("MIRGE_NATIVE_SO", os.path.abspath(path))] + [tuple(e.split("=", 1)) for e in envs])))
 res = {n: [] for n, _ in settings}
 for r in range(rounds):
     for name, env_add in settings:
