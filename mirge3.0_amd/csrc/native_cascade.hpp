@@ -40,17 +40,10 @@ static int merged_library(mirge_ctx* c, const mirge_lib* const* members, int n, 
     for (auto& m : c->merged)
         if (m.uids == uids) { *out = m.lib; return 0; }
     std::string seq;
-    std::vector<int64_t> off{0};
-    for (int i = 0; i < n; i++) {
-        const MirgeHostLib& h = members[i]->h;
-        for (int64_t r = 0; r < h.n_refs; r++) {
-            for (uint64_t g = h.ref_start[(size_t)r]; g + 1 < h.ref_start[(size_t)r + 1]; g++) {
-                const bool bad = (h.inv[g >> 6] >> (g & 63)) & 1ull;
-                seq.push_back(bad ? 'N' : "ACGT"[(h.T[g >> 5] >> (2 * (g & 31))) & 3ull]);
-            }
-            off.push_back((int64_t)seq.size());
-        }
-    }
+    std::vector<int64_t> off;
+    std::vector<const MirgeHostLib*> hl;
+    for (int i = 0; i < n; i++) hl.push_back(&members[i]->h);
+    merged_library_text(hl.data(), n, seq, off);  // (native_host.hpp)
     mirge_lib* L = nullptr;
     CHECK(mirge_lib_create(c, seq.data(), off.data(), (int64_t)off.size() - 1, &L));
     c->merged.push_back(mirge_ctx::Merged{uids, L});

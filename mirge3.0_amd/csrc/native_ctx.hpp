@@ -1,23 +1,12 @@
 // native_ctx.hpp -- part of mirge_native.hip (one translation unit): errors, device context: streams, stream-ordered buffer pool, profiler, host timing hook.
 #pragma once
-// ------------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+// (errors -- g_err, fail, CHECK, mirge_last_error -- and HostClock: native_host.hpp)
 #define HIPOK(expr)                                                                          \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \
         if (_e != hipSuccess)                                                                \
             return fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));              \
     } while (0)
-#define CHECK(expr)            \
-    do {                       \
-        int _c = (expr);       \
-        if (_c != 0) return _c; \
-    } while (0)
-
-extern "C" const char* mirge_last_error(void) { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------
 // context: device, stream, pooled device memory, profiler
@@ -251,27 +240,6 @@ static inline int grid_for(const mirge_ctx* c, size_t n, int per_block = MIRGE_B
     size_t cap = (size_t)c->n_cu * per_cu;
     return (int)std::max<size_t>(1, std::min(blocks, cap));
 }
-
-// MIRGE_HOST_TIMING=1: host microseconds spent in the stages of a call, to stderr (enqueue-bound phases)
-static std::chrono::steady_clock::time_point g_last_exit = std::chrono::steady_clock::now();
-struct HostClock {
-    const char* what;
-    std::chrono::steady_clock::time_point t0;
-    bool on;
-    explicit HostClock(const char* w) : what(w), t0(std::chrono::steady_clock::now()) {
-        static const bool e = std::getenv("MIRGE_HOST_TIMING") != nullptr;
-        on = e;
-        if (on) std::fprintf(stderr, "[host] %s entered %.1f us after the previous call returned\n", what,
-                             std::chrono::duration<double, std::micro>(t0 - g_last_exit).count());
-    }
-    ~HostClock() { if (on) g_last_exit = std::chrono::steady_clock::now(); }
-    void lap(const char* stage) {
-        if (!on) return;
-        const auto t = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[host] %s/%s %.1f us\n", what, stage, std::chrono::duration<double, std::micro>(t - t0).count());
-        t0 = t;
-    }
-};
 
 extern "C" int mirge_device_count(void) {
     int n = 0;

@@ -87,80 +87,5 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
     return 0;
 }
 
-namespace {
-// miRgeEssential.UID (:364-370): prefix-length-, then two symbols of a 32-letter alphabet per 5-mer (value / 32,
-// value % 32, A C G T = 0..3, first base most significant); a last chunk of k < 5 bases is numbered after all shorter
-// k-mers (offsets 0, 4, 20, 84) and printed as one symbol below 32, two from there on
-inline void uid_append(std::string& out, const char* s, size_t n) {
-    static const char AL[] = "BD0EF1HI2JK3LM4NO5PQ6RS7UV8WX9YZ";
-    static const int OFFS[5] = {0, 0, 4, 20, 84};
-    for (size_t at = 0; at < n; at += 5) {
-        const size_t k = std::min<size_t>(5, n - at);
-        int v = 0;
-        for (size_t t = 0; t < k; t++) v = v * 4 + (s[at + t] == 'A' ? 0 : s[at + t] == 'C' ? 1 : s[at + t] == 'G' ? 2 : 3);
-        if (k == 5) { out.push_back(AL[v / 32]); out.push_back(AL[v % 32]); }
-        else {
-            v += OFFS[k];
-            if (v < 32) out.push_back(AL[v]);
-            else { out.push_back(AL[v / 32]); out.push_back(AL[v % 32]); }
-        }
-    }
-}
-}  // namespace
 
-// The GFF3 body: one line per row with kind != 0, in row order (summary.py:204, :465).  name_of_row / parent_of_row
-// index two string tables (the miRNA name as printed, its precursor's name); `head` = the four '#' lines.
-extern "C" int mirge_gff_write(const char* path, const char* head, const char* source, const void* records, int64_t n_rows,
-                               const char* read_ascii, const int64_t* read_off, const uint32_t* counts, int32_t S,
-                               const int32_t* name_of_row, const char* name_data, const int64_t* name_off, int64_t n_names,
-                               const int32_t* parent_of_row, const char* parent_data, const int64_t* parent_off, int64_t n_parents) {
-    if (!path || !head || !source || n_rows < 0 || S < 1 || !read_off || !name_off || !parent_off ||
-        (n_rows > 0 && (!records || !read_ascii || !counts || !name_of_row || !parent_of_row)))
-        return fail(-1, "mirge_gff_write: bad argument");
-    const MirgeIsoRec* rec = static_cast<const MirgeIsoRec*>(records);
-    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const int T = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n_rows / 8192));
-    std::vector<std::string> buf((size_t)T);
-    std::vector<int> bad((size_t)T, 0);
-    const std::string src(source);
-    auto work = [&](int t) {
-        std::string& out = buf[(size_t)t];
-        for (int64_t k = n_rows * t / T; k < n_rows * (t + 1) / T; k++) {
-            const MirgeIsoRec& r = rec[k];
-            if (r.kind == 0) continue;
-            const int32_t ni = name_of_row[k], pi = parent_of_row[k];
-            if (ni < 0 || ni >= n_names || pi < 0 || pi >= n_parents || (size_t)r.vlen + r.clen > MIRGE_ISO_TEXT) { bad[(size_t)t] = 1; continue; }
-            const char* nm = name_data + name_off[ni];
-            const size_t nl = (size_t)(name_off[ni + 1] - name_off[ni]);
-            const char* rd = read_ascii + read_off[k];
-            const size_t rl = (size_t)(read_off[k + 1] - read_off[k]);
-            out.append(nm, nl); out.push_back('\t'); out += src; out.push_back('\t');
-            out += r.kind == 1 ? "ref_miRNA" : "isomiR";
-            out.push_back('\t'); out += std::to_string(r.start); out.push_back('\t'); out += std::to_string(r.end);
-            out += "\t.\t+\t.\tRead="; out.append(rd, rl); out += "; UID=";
-            bool has_n = false;
-            for (size_t q = 0; q < rl; q++) has_n |= rd[q] == 'N';
-            if (has_n) out.push_back('.');
-            else { out += r.kind == 1 ? "ref-" : "iso-"; out += std::to_string(rl); out.push_back('-'); uid_append(out, rd, rl); }
-            out += "; Name="; out.append(nm, nl);
-            out += "; Parent="; out.append(parent_data + parent_off[pi], (size_t)(parent_off[pi + 1] - parent_off[pi]));
-            out += "; Variant="; out.append(r.text, r.vlen);
-            out += "; Cigar="; out.append(r.text + r.vlen, r.clen);
-            std::string ex;
-            for (int s = 0; s < S; s++) { if (s) ex.push_back(','); csv_uint(ex, counts[(size_t)k * S + s]); }
-            out += "; Expression="; out += ex; out += "; Filter=Pass; Hits="; out += ex; out.push_back('\n');
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
-    for (int t = 0; t < T; t++) if (bad[(size_t)t]) return fail(-1, "mirge_gff_write: name index or record out of range");
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return fail(-8, std::string("cannot write ") + path);
-    bool ok = std::fputs(head, f) >= 0;
-    for (int t = 0; t < T && ok; t++) ok = buf[(size_t)t].empty() || std::fwrite(buf[(size_t)t].data(), 1, buf[(size_t)t].size(), f) == buf[(size_t)t].size();
-    ok = (std::fclose(f) == 0) && ok;
-    if (!ok) return fail(-8, std::string("write error on ") + path);
-    return 0;
-}
+// (mirge_gff_write and the UID rule: native_host.hpp)

@@ -50,14 +50,8 @@ extern "C" int mirge_lib_create(mirge_ctx* c, const char* seq, const int64_t* of
 extern "C" int mirge_lib_create_packed(mirge_ctx* c, const uint64_t* T, int64_t n_T, const uint64_t* inv, int64_t n_inv,
                                        const uint32_t* ref_start, int64_t n_refs, uint64_t total, int32_t kmax,
                                        uint64_t valid_positions, mirge_lib** out) {
-    if (!c || !out || !T || !inv || !ref_start || n_refs < 0 || total >= 0xFFFFFFF0ull || kmax < 8 || kmax > MIRGE_KMAX ||
-        n_T != (int64_t)((total + 31) / 32) + 8 || n_inv != (int64_t)((total + 63) / 64) + 4 || ref_start[n_refs] != (uint32_t)total)
-        return fail(-1, "mirge_lib_create_packed: bad argument (a cache of another layout?)");
-    // reference t occupies [ref_start[t], ref_start[t + 1] - 1) and its separator: starts ascend by at least one, from 0
-    if (n_refs > 0 && ref_start[0] != 0) return fail(-1, "mirge_lib_create_packed: ref_start[0] is not 0 (a damaged cache?)");
-    for (int64_t t = 0; t < n_refs; t++)
-        if (ref_start[t + 1] <= ref_start[t])
-            return fail(-1, "mirge_lib_create_packed: ref_start is not ascending at reference " + std::to_string(t) + " (a damaged cache?)");
+    if (!c || !out) return fail(-1, "mirge_lib_create_packed: bad argument");
+    CHECK(lib_packed_args_check(T, n_T, inv, n_inv, ref_start, n_refs, total, kmax));  // (native_host.hpp)
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     auto L = std::make_unique<mirge_lib>();
     L->ctx = c;

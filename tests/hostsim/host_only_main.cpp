@@ -1,0 +1,200 @@
+// ASan/UBSan driver for the library's pure-host C++ (mirge3.0_amd/csrc/native_host.hpp): the mapped.csv / unmapped.csv
+// formatter, the GFF3 writer, the text of a merged library and the argument checks of mirge_lib_create_packed.
+//   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -std=c++17 -pthread host_only_main.cpp -o host_only && ./host_only <dir>
+// The GPU pool has no device sanitizer; these functions never touch the device, so the very translation unit the product
+// compiles runs here under the host sanitizers.  Cases: names that need CSV quoting (comma, quote, line break), empty libraries
+// and empty references, reads of 0, 1, 255 and 600 nt, 1 and 17 samples, unmapped-only and mapped-only outputs, row orders that are
+// permutations, out-of-range indices that must be refused, a GFF with reads that hold an N and records at the text limit.
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mirge_native.h"
+#include "../../mirge3.0_amd/csrc/mirge_core.hpp"
+#include "../../mirge3.0_amd/csrc/mirge_isotype.hpp"
+#include "../../mirge3.0_amd/csrc/mirge_libbuild.hpp"
+#include "../../mirge3.0_amd/csrc/native_host.hpp"
+
+static std::string slurp(const std::string& p) {
+    std::ifstream f(p, std::ios::binary);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+#define EXPECT(cond)                                                                   \
+    do {                                                                               \
+        if (!(cond)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
+    } while (0)
+
+// the formatter's output, restated with std::string (slow and obviously right)
+static std::string quote(const std::string& s) {
+    if (s.find_first_of(",\"\n\r") == std::string::npos) return s;
+    std::string o = "\"";
+    for (char c : s) { if (c == '"') o += '"'; o += c; }
+    return o + "\"";
+}
+
+int main(int argc, char** argv) {
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    std::mt19937_64 rng(20260104);
+    auto rnd_seq = [&](size_t L) { std::string s(L, 'A'); for (auto& c : s) c = "ACGTN"[rng() % 100 == 0 ? 4 : rng() % 4]; return s; };
+
+    // ---------------- mirge_annotation_csv
+    for (int S : {1, 17}) {
+        const int n_pass = 10, n_cols = 9;
+        int32_t col_of_pass[n_pass] = {0, 1, 2, 3, 4, 5, 6, 7, 8, -1};  // the last pass writes no column
+        std::vector<std::vector<std::string>> names(n_pass);
+        const char* awkward[] = {"plain", "with,comma", "with \"quote\"", "line\nbreak", "cr\rhere", "", "hsa-miR-1/2", ",", "\"\"", "x"};
+        for (int p = 0; p < n_pass; p++) {
+            const int nn = p == 3 ? 0 : 5 + p;  // pass 3: an empty library
+            for (int k = 0; k < nn; k++) names[p].push_back(std::string(awkward[(p + k) % 10]) + (k % 3 ? "_" + std::to_string(k) : ""));
+        }
+        std::vector<std::string> blob(n_pass);
+        std::vector<std::vector<int64_t>> off(n_pass);
+        const char* nd[n_pass]; const int64_t* no[n_pass]; int64_t nn[n_pass];
+        for (int p = 0; p < n_pass; p++) {
+            off[p].push_back(0);
+            for (auto& s : names[p]) { blob[p] += s; off[p].push_back((int64_t)blob[p].size()); }
+            nd[p] = names[p].empty() ? nullptr : blob[p].data(); no[p] = off[p].data(); nn[p] = (int64_t)names[p].size();
+        }
+        const int64_t U = 40000;
+        std::string seq; std::vector<int64_t> soff{0};
+        std::vector<int8_t> pass(U); std::vector<int32_t> ref(U); std::vector<uint32_t> cnt((size_t)U * S);
+        const size_t lens[] = {0, 1, 16, 22, 31, 32, 64, 255, 256, 600};
+        for (int64_t i = 0; i < U; i++) {
+            seq += rnd_seq(i < 2000 ? lens[i % 10] : 16 + rng() % 20); soff.push_back((int64_t)seq.size());
+            int p = (int)(rng() % (n_pass + 3)) - 3;
+            if (p == 3) p = -1;  // nothing can be annotated to the empty library
+            pass[i] = (int8_t)(p < 0 ? -1 : p);
+            ref[i] = p >= 0 ? (int32_t)(rng() % names[p].size()) : -1;
+            for (int s = 0; s < S; s++) cnt[(size_t)i * S + s] = (uint32_t)(rng() % 7 == 0 ? 4000000000u + rng() % 1000 : rng() % 1000);
+        }
+        std::vector<int64_t> rows(U);
+        for (int64_t i = 0; i < U; i++) rows[i] = i;
+        std::shuffle(rows.begin(), rows.end(), rng);
+        std::string header = "Sequence,annotFlag";
+        for (int c = 0; c < n_cols; c++) header += ",col" + std::to_string(c);
+        for (int s = 0; s < S; s++) header += ",S" + std::to_string(s);
+        header += "\n";
+        const std::string pm = dir + "/m.csv", pu = dir + "/u.csv";
+        int rc = mirge_annotation_csv(pm.c_str(), pu.c_str(), header.c_str(), seq.data(), soff.data(), pass.data(), ref.data(), cnt.data(), S,
+                                      rows.data(), U, n_pass, col_of_pass, n_cols, nd, no, nn);
+        EXPECT(rc == 0);
+        std::string wm = header, wu = header;
+        for (int64_t k = 0; k < U; k++) {
+            const int64_t i = rows[k];
+            std::string& o = pass[i] >= 0 ? wm : wu;
+            o += quote(seq.substr((size_t)soff[i], (size_t)(soff[i + 1] - soff[i]))) + "," + (pass[i] >= 0 ? "1" : "0");
+            for (int c = 0; c < n_cols; c++) { o += ","; if (pass[i] >= 0 && col_of_pass[pass[i]] == c) o += quote(names[pass[i]][ref[i]]); }
+            for (int s = 0; s < S; s++) o += "," + std::to_string(cnt[(size_t)i * S + s]);
+            o += "\n";
+        }
+        EXPECT(slurp(pm) == wm);
+        EXPECT(slurp(pu) == wu);
+        // one file only, no rows at all, and what must be refused
+        EXPECT(mirge_annotation_csv(nullptr, pu.c_str(), header.c_str(), seq.data(), soff.data(), pass.data(), ref.data(), cnt.data(), S, rows.data(), U,
+                                    n_pass, col_of_pass, n_cols, nd, no, nn) == 0 && slurp(pu) == wu);
+        EXPECT(mirge_annotation_csv(pm.c_str(), nullptr, header.c_str(), seq.data(), soff.data(), pass.data(), ref.data(), cnt.data(), S, rows.data(), 0,
+                                    n_pass, col_of_pass, n_cols, nd, no, nn) == 0 && slurp(pm) == header);
+        ref[rows[5]] = 1 << 20; pass[rows[5]] = 0;
+        EXPECT(mirge_annotation_csv(pm.c_str(), pu.c_str(), header.c_str(), seq.data(), soff.data(), pass.data(), ref.data(), cnt.data(), S, rows.data(), U,
+                                    n_pass, col_of_pass, n_cols, nd, no, nn) == -1);
+        ref[rows[5]] = 0; pass[rows[5]] = 3;  // the empty library
+        EXPECT(mirge_annotation_csv(pm.c_str(), pu.c_str(), header.c_str(), seq.data(), soff.data(), pass.data(), ref.data(), cnt.data(), S, rows.data(), U,
+                                    n_pass, col_of_pass, n_cols, nd, no, nn) == -1);
+        pass[rows[5]] = 11;
+        EXPECT(mirge_annotation_csv(pm.c_str(), pu.c_str(), header.c_str(), seq.data(), soff.data(), pass.data(), ref.data(), cnt.data(), S, rows.data(), U,
+                                    n_pass, col_of_pass, n_cols, nd, no, nn) == -1);
+        EXPECT(std::strlen(mirge_last_error()) > 0);
+    }
+
+    // ---------------- mirge_gff_write
+    {
+        const int64_t n = 30000;
+        const int S = 3;
+        std::vector<MirgeIsoRec> rec((size_t)n);
+        std::string reads; std::vector<int64_t> roff{0};
+        std::vector<uint32_t> cnt((size_t)n * S);
+        std::vector<int32_t> name_of(n), parent_of(n);
+        std::string nblob, pblob; std::vector<int64_t> noff{0}, poff{0};
+        for (int k = 0; k < 50; k++) { nblob += "hsa-miR-" + std::to_string(k) + (k % 7 ? "-5p" : ""); noff.push_back((int64_t)nblob.size()); }
+        for (int k = 0; k < 20; k++) { pblob += k ? "hsa-mir-" + std::to_string(k) : ""; poff.push_back((int64_t)pblob.size()); }
+        for (int64_t k = 0; k < n; k++) {
+            std::memset(&rec[(size_t)k], 0, sizeof(MirgeIsoRec));
+            rec[(size_t)k].kind = (int32_t)(rng() % 3);
+            rec[(size_t)k].start = (int32_t)(rng() % 100); rec[(size_t)k].end = rec[(size_t)k].start + 22;
+            const int vl = k % 97 == 0 ? 200 : (int)(rng() % 40), cl = k % 97 == 0 ? MIRGE_ISO_TEXT - 200 : (int)(rng() % 30);  // some at the text limit
+            rec[(size_t)k].vlen = vl; rec[(size_t)k].clen = cl;
+            for (int q = 0; q < vl + cl; q++) rec[(size_t)k].text[q] = "iso_snv_3pMI0-9:,"[rng() % 17];
+            reads += rnd_seq(k % 211 == 0 ? 0 : 15 + rng() % 15); roff.push_back((int64_t)reads.size());
+            for (int s = 0; s < S; s++) cnt[(size_t)k * S + s] = (uint32_t)(rng() % 100000);
+            name_of[k] = (int32_t)(rng() % 50); parent_of[k] = (int32_t)(rng() % 20);
+        }
+        const std::string pg = dir + "/s.gff";
+        EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "miRBase22", rec.data(), n, reads.data(), roff.data(), cnt.data(), S, name_of.data(), nblob.data(),
+                               noff.data(), 50, parent_of.data(), pblob.data(), poff.data(), 20) == 0);
+        const std::string g = slurp(pg);
+        int64_t lines = 0, want = 0;
+        for (char c : g) lines += c == '\n';
+        for (int64_t k = 0; k < n; k++) want += rec[(size_t)k].kind != 0;
+        EXPECT(lines == want + 1 && g.rfind("## head\n", 0) == 0);
+        EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "x", rec.data(), 0, nullptr, roff.data(), nullptr, S, nullptr, nblob.data(), noff.data(), 50, nullptr,
+                               pblob.data(), poff.data(), 20) == 0 && slurp(pg) == "## head\n");
+        name_of[7] = 50; rec[7].kind = 1;
+        EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "x", rec.data(), n, reads.data(), roff.data(), cnt.data(), S, name_of.data(), nblob.data(), noff.data(),
+                               50, parent_of.data(), pblob.data(), poff.data(), 20) == -1);
+        name_of[7] = 0; rec[7].vlen = MIRGE_ISO_TEXT; rec[7].clen = 1;
+        EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "x", rec.data(), n, reads.data(), roff.data(), cnt.data(), S, name_of.data(), nblob.data(), noff.data(),
+                               50, parent_of.data(), pblob.data(), poff.data(), 20) == -1);
+    }
+
+    // ---------------- merged_library_text: the members' letters back out of their packed images, N where the image says invalid
+    {
+        std::vector<MirgeHostLib> hl(3);
+        std::vector<std::string> seqs[3];
+        std::string all; std::vector<int64_t> alloff{0};
+        for (int m = 0; m < 3; m++) {
+            std::string s; std::vector<int64_t> off{0};
+            const int nr = m == 1 ? 0 : 40;  // an empty member library
+            for (int r = 0; r < nr; r++) {
+                const std::string q = r % 9 == 0 ? std::string() : rnd_seq(1 + rng() % 300);  // empty references too
+                seqs[m].push_back(q); s += q; off.push_back((int64_t)s.size());
+                all += q; alloff.push_back((int64_t)all.size());
+            }
+            std::string err;
+            EXPECT(mirge_hostlib_build(hl[(size_t)m], s.data(), off.data(), nr, err) == 0);
+        }
+        const MirgeHostLib* members[3] = {&hl[0], &hl[1], &hl[2]};
+        std::string seq; std::vector<int64_t> off;
+        merged_library_text(members, 3, seq, off);
+        EXPECT(seq == all && off == alloff);
+        merged_library_text(members + 1, 1, seq, off);
+        EXPECT(seq.empty() && off.size() == 1);
+        // ... and the packed image goes through mirge_lib_create_packed's checks; damaged ones do not
+        const MirgeHostLib& h = hl[0];
+        EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size(), h.inv.data(), (int64_t)h.inv.size(), h.ref_start.data(), h.n_refs, h.total, h.kmax) == 0);
+        std::vector<uint32_t> rs = h.ref_start;
+        std::swap(rs[3], rs[4]);
+        EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size(), h.inv.data(), (int64_t)h.inv.size(), rs.data(), h.n_refs, h.total, h.kmax) == -1);
+        rs = h.ref_start; rs[0] = 1;
+        EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size(), h.inv.data(), (int64_t)h.inv.size(), rs.data(), h.n_refs, h.total, h.kmax) == -1);
+        EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size() - 1, h.inv.data(), (int64_t)h.inv.size(), h.ref_start.data(), h.n_refs, h.total, h.kmax) == -1);
+        EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size(), h.inv.data(), (int64_t)h.inv.size(), h.ref_start.data(), h.n_refs, h.total + 1, h.kmax) == -1);
+        EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size(), h.inv.data(), (int64_t)h.inv.size(), h.ref_start.data(), h.n_refs, h.total, 7) == -1);
+        EXPECT(lib_packed_args_check(nullptr, 8, h.inv.data(), 4, h.ref_start.data(), 0, 0, 8) == -1);
+    }
+    std::printf("host-only functions clean\n");
+    return 0;
+}

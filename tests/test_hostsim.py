@@ -174,6 +174,18 @@ def test_core_arithmetic_is_asan_ubsan_clean(tmp_path):
     assert "rc=0" in r.stdout and "annotated=" in r.stdout
 
 
+def test_pure_host_functions_are_asan_ubsan_clean(tmp_path):
+    """native_host.hpp -- the mapped.csv / unmapped.csv formatter (mirge_annotation_csv), the GFF3 writer, the text of a merged
+    library, the argument checks of mirge_lib_create_packed: the translation unit the product compiles -- under AddressSanitizer +
+    UBSan with g++: names that need CSV quoting, empty libraries and references, reads of 0 / 255 / 600 nt, 1 and 17 samples,
+    indices that must be refused, records at the text limit; the formatter's files are compared with a std::string restatement."""
+    exe = str(tmp_path / "host_only")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-pthread",
+                           "-Wno-unknown-pragmas", os.path.join(HERE, "hostsim", "host_only_main.cpp"), "-o", exe])
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "host-only functions clean" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 def hostsim_isotype(master: str, read: str, precursor: str):
     so = _sim()
     kind, start, end = C.c_int32(), C.c_int32(), C.c_int32()
