@@ -358,12 +358,28 @@ def cli_path(args, sl, libs, text, n_pass):
             o["device"][h].close()
         same = all(open(os.path.join(work, f), "rb").read() == open(os.path.join(tmp, "libraries_resident", f), "rb").read()
                    for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "annotation.report.csv"))
+        os.environ["MIRGE_GZ_PARALLEL"] = "0"
+        try:
+            work2 = os.path.join(tmp, "gz_stream")
+            os.makedirs(work2)
+            tm2 = {}
+            t = time.perf_counter()
+            o2 = fastpath.run(a, [fq_gz], ["S1"], work2, "miRBase", timings=tm2)
+            wall2 = time.perf_counter() - t
+            for h in ("uniq", "res"):
+                o2["device"][h].close()
+        finally:
+            os.environ.pop("MIRGE_GZ_PARALLEL", None)
         res["gz_libraries_resident"] = {
             "wall_s": round(wall, 3), "M_reads_per_s": round(args.reads / wall / 1e6, 2), "gz_MB": round(gz_bytes / 1e6, 1),
             "text_MB": round(n_whole / 1e6, 1), "same_files_as_plain_fastq": bool(same),
-            "stages_s": {k: (round(v, 3) if not isinstance(v, dict) else v) for k, v in tm.items()},
+            "stages_s": {k: (round(v, 3) if not isinstance(v, (dict, list)) else v) for k, v in tm.items()},
             "python_gzip_read_whole_s": round(whole_s, 3),
-            "note": "sample.fastq.gz -> every output file; the file is inflated by zlib on a worker thread in 8 MB record-aligned "
+            "streamed_zlib": {"wall_s": round(wall2, 3), "stages_s": {k: (round(v, 3) if not isinstance(v, (dict, list)) else v) for k, v in tm2.items()}},
+            "note": "sample.fastq.gz -> every output file.  stages_s.gz_parallel: the member inflated on all host cores by mirge_gz_inflate "
+                    "(cut at deflate block starts found by search, decoded without history, resolved, verified against the file's CRC-32; "
+                    "part of read_files_s).  streamed_zlib: the same file with MIRGE_GZ_PARALLEL=0 -- "
+                    "the file is inflated by zlib on a worker thread in 8 MB record-aligned "
                     "pieces while the main thread uploads and parses the piece before (collapse.GzipRecordStream); stages_s.gz_stream: "
                     "inflate_s = the worker's time in zlib (the critical path), upload_parse_s = the GPU side's work, inflate_wait_s = "
                     "the GPU side waiting for text; python_gzip_read_whole_s = gzip.open().read() of the same file, what round 3 did "

@@ -79,6 +79,13 @@ int64_t mirge_lib_device_bytes(const mirge_lib* lib);
 /* build the k-mer table for probe length k now (otherwise built on first need) */
 int mirge_lib_prepare(mirge_lib* lib, int32_t k);
 
+/* ---- input: a whole .gz file's bytes -> its text on `threads` host threads (0: all).  What xopen's pigz / igzip threads are to the
+ * reference's reader (digest.py:136-140): one zlib stream inflates at ~0.4 GB/s of text, twenty times slower than everything
+ * behind it here.  An ordinary member is cut at deflate block starts found by search and decoded in parallel (csrc/native_gz.hpp);
+ * a BGZF file member by member.  out[cap]; 0 = done and verified against the file's own CRC-32 and length; negative = not
+ * taken by this route (several ordinary members, too small, not text, damaged, cap too small): inflate it serially. */
+int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads);
+
 /* ---- reads: replaces writing bwtInput.fasta (manifoldAlign.py:92-95) / dnaio parsing ---- */
 int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, int64_t n,
                      mirge_reads** out);

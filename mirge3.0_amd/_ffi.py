@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libmirge_native.so")
 
 EXPORTS = [
-    "mirge_last_error", "mirge_device_count", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
+    "mirge_last_error", "mirge_device_count", "mirge_gz_inflate", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_create_packed", "mirge_lib_packed_sizes", "mirge_lib_packed_copy", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_group_counts", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
@@ -138,6 +138,26 @@ def _check(rc: int, what: str) -> None:
 
 def _p(a: Optional[np.ndarray]):
     return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def gz_inflate(data, threads: int = 0) -> Optional[np.ndarray]:
+    """The text of a whole .gz file (``data``: its bytes) inflated on all host cores (``mirge_gz_inflate``), or None when the
+    file is not of a kind that route takes -- the caller then inflates it serially.  Verified against the file's CRC-32."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    if buf.size < 18:
+        return None
+    isize = int.from_bytes(bytes(buf[-4:]), "little")  # the LAST member's length mod 2^32: exact for the one-member file this is for
+    cap = isize
+    if buf[3] & 4:  # an extra field: possibly BGZF, whose members each carry their own length -> bound by the format's 64 KiB
+        cap = max(cap, (buf.size // 28 + 1) * 65536)
+    if cap <= 0 or cap > (1 << 36):
+        return None
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_int64(0)
+    rc = load().mirge_gz_inflate(_p(buf), C.c_int64(buf.size), _p(out), C.c_int64(cap), C.byref(n), C.c_int32(threads))
+    if rc != 0:
+        return None
+    return out[: n.value]
 
 
 class Context:

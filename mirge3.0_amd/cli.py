@@ -210,6 +210,15 @@ def main(argv=None):
             print("Library for hamster is not developed for miRBase, therefore, MirGeneDB is used\n")
         ref_db = "MirGeneDB"
     files, base_names = collect_samples(args, workDir / "run.log", rank == 0)
+    from .collapse import unpinned_trim_options
+    unpinned = unpinned_trim_options(args)
+    if unpinned and rank == 0:  # counted with, but not silently: these follow cutadapt's documentation, no real cutadapt has confirmed them
+        msg = ("WARNING: trimming option(s) " + "; ".join(unpinned) + " are implemented from cutadapt's documentation and have not been "
+               "compared with cutadapt itself (tools/cutadapt_crosscheck.py does that where cutadapt is installed)")
+        with open(workDir / "run.log", "a+") as fh:
+            fh.write(msg + "\n")
+        if not args.quiet:
+            print(msg)
 
     from . import fastpath
     from .cascade import bwt_align

@@ -66,6 +66,7 @@ def read_fastq_sequences(path: str) -> FlatSeqs:
 import os as _os
 GZ_PIECE_BYTES = int(_os.environ.get("MIRGE_GZ_PIECE_BYTES", 8 << 20))   # text handed to the parser per piece of a streamed .fastq.gz
 GZ_QUEUE_DEPTH = 4         # inflated pieces waiting for the GPU (bounds the memory of a stream: ~ depth x piece)
+GZ_LOG: List[dict] = []    # one entry per .gz file inflated by mirge_gz_inflate (read_text): what a run reports as its input stage
 
 
 class GzipRecordStream:
@@ -218,10 +219,23 @@ def read_text(path: str, stream: bool = False):
     over several lines (dnaio reads those) is unwrapped here: the device parser finds records by line number and refuses
     anything else."""
     if str(path).endswith(".gz"):
-        if stream:
-            return GzipRecordStream(path)
-        with gzip.open(path, "rb") as fh:
-            data = fh.read()
+        # first choice: the whole member inflated on all host cores (mirge_gz_inflate: cut at deflate block starts found by
+        # search, verified against the file's CRC-32); it declines what it is not made for -- small files, several ordinary
+        # members, anything that is not text -- and those are inflated by zlib, piece by piece beside the parse (stream) or whole
+        data = None
+        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and _os.path.getsize(path) >= (2 << 20):
+            t0 = time.perf_counter()
+            raw = np.fromfile(path, dtype=np.uint8)
+            data = _ffi.gz_inflate(raw)
+            if data is not None:
+                GZ_LOG.append({"path": str(path), "gz_MB": round(raw.size / 1e6, 1), "text_MB": round(data.size / 1e6, 1),
+                               "parallel_inflate_s": round(time.perf_counter() - t0, 4)})
+            del raw
+        if data is None:
+            if stream:
+                return GzipRecordStream(path)
+            with gzip.open(path, "rb") as fh:
+                data = fh.read()
     else:
         import os
         if os.path.getsize(path) == 0:
@@ -336,6 +350,27 @@ def trim_from_args(args):
                                read_wildcards=bool(getattr(args, "match_read_wildcards", False)),
                                adapter_wildcards=bool(getattr(args, "match_adapter_wildcards", True)),
                                action=str(getattr(args, "action", "trim") or "trim"))
+
+
+def unpinned_trim_options(args) -> List[str]:
+    """The trimming options in use whose behaviour is restated from cutadapt's documentation and sources WITHOUT a vector of a
+    real cutadapt behind it (cutadapt is absent from the image and the pool; the plain 3' adapter + quality chain has the user
+    guide's cases as known answers): the run says so in run.log instead of silently counting with them."""
+    out = []
+    adapters = adapters_from_args(args)
+    if len(adapters) == 2:
+        out.append("two adapters (the better match is removed)")
+    if int(getattr(args, "times", 1) or 1) > 1:
+        out.append("-n / --times")
+    if not bool(getattr(args, "indels", True)):
+        out.append("--no-indels")
+    if bool(getattr(args, "match_read_wildcards", False)):
+        out.append("--match-read-wildcards")
+    if not bool(getattr(args, "match_adapter_wildcards", True)):
+        out.append("-N / --no-match-adapter-wildcards")
+    if str(getattr(args, "action", "trim") or "trim") == "none":
+        out.append("--action none")
+    return out
 
 
 def filter_min_length(reads: FlatSeqs, min_len: int) -> FlatSeqs:

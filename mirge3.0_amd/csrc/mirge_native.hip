@@ -37,6 +37,7 @@ static_assert(sizeof(mirge_policy) == sizeof(MirgePolicy), "policy layout");
 static_assert(MIRGE_MAX_PASSES == MIRGE_MAX_PASSES_K, "pass cap");
 
 #include "native_host.hpp"
+#include "native_gz.hpp"
 #include "native_ctx.hpp"
 #include "native_lib.hpp"
 #include "native_reads.hpp"

@@ -1,0 +1,482 @@
+// native_gz.hpp -- pure host (no HIP): a gzip member inflated on all cores.
+//
+// Why it is here: a user's sample is `sample.fastq.gz` (mirge/libs/digest.py:136-140 reads it through xopen, which hands the
+// inflation to pigz / igzip threads when it finds them).  Everything behind the text takes 0.07 s per 10 M-read sample on the
+// GPU; ONE zlib inflate stream takes 1.2 s for the same sample (bench.py cli_path.gz_libraries_resident) -- the input, not the
+// path, is what a run from compressed FASTQ waits for.  A deflate stream has no index, but it can still be cut:
+//   1. the compressed bytes are cut into chunks; in every chunk but the first a thread FINDS the start of a deflate block (a bit
+//      position where a dynamic-Huffman header parses into complete codes, the block decodes into text and is followed by another
+//      well-formed header);
+//   2. every chunk is decoded from its block start to the next chunk's, in parallel, WITHOUT the 32 KiB of history it may refer
+//      to: output symbols are 16 bits, a byte, or -- for a copy that reaches back before the chunk -- the index of the unknown
+//      history byte (copies of such symbols copy the symbol);
+//   3. the last 32 KiB of every chunk are resolved in order (chunk 0 has no history, so its end is known; that is chunk 1's
+//      history, ...: 32 K table lookups per chunk), then all chunks are resolved to bytes in parallel, at their offsets of the text;
+//   4. the CRC-32 and length of the gzip trailer must match (per-chunk CRCs combined), else the caller inflates the ordinary way.
+// (The approach of pugz / rapidgzip, written from the deflate specification RFC 1951.)  BGZF files (bgzip: members of <= 64 KiB
+// that carry their size) and other multi-member files are inflated member by member on the same threads with zlib.
+// Nothing here decides an answer: a text that fails any check is simply inflated serially by the caller (collapse.GzipRecordStream).
+#pragma once
+#include <sys/mman.h>
+#include <zlib.h>
+
+namespace mirge_gz {
+
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t buf = 0;
+    int nbits = 0;  // valid bits in buf; negative once bits behind the end of the data have been consumed (they read as zeros)
+    BitReader(const uint8_t* data, size_t n, uint64_t start_bit) : p(data + std::min<size_t>((size_t)(start_bit >> 3), n)), end(data + n) {
+        fill();
+        drop((int)(start_bit & 7));
+    }
+    inline void fill() {
+        while (nbits <= 56 && p < end) { buf |= (uint64_t)(*p++) << nbits; nbits += 8; }
+    }
+    inline uint32_t peek(int n) { if (nbits < n) fill(); return (uint32_t)(buf & ((1ull << n) - 1ull)); }
+    inline void drop(int n) { buf >>= n; nbits -= n; }
+    inline uint32_t bits(int n) { const uint32_t v = peek(n); drop(n); return v; }
+    inline bool ran_off() const { return nbits < 0; }
+};
+
+// position (in bits from the start of `data`) of the next unread bit
+static inline uint64_t bit_position(const BitReader& br, const uint8_t* data) {
+    return (uint64_t)((int64_t)(br.p - data) * 8 - (int64_t)br.nbits);
+}
+
+#define MIRGE_GZ_PRIMARY 10  // bits of the first-level table (4 KiB: it stays in L1; a flat 2^15-entry table does not)
+struct Huff {
+    // first level: indexed by the next MIRGE_GZ_PRIMARY bits (LSB first).  An entry is (symbol << 4) | code length, or -- bit 31 --
+    // a pointer for codes longer than the first level: (offset of a second-level table << 4), indexed by the bits behind them
+    std::vector<uint32_t> table;
+    int pbits = 0, maxlen = 0;
+    bool ok = false;
+};
+
+// canonical Huffman code from code lengths (RFC 1951 3.2.2); complete codes only (a single-symbol code is allowed where zlib
+// allows it)
+static bool build_huff(const uint8_t* lens, int n, Huff& h, bool allow_single) {
+    int count[16] = {0};
+    for (int i = 0; i < n; i++) count[lens[i]]++;
+    count[0] = 0;
+    int maxlen = 0, used = 0;
+    for (int l = 1; l <= 15; l++) if (count[l]) { maxlen = l; used += count[l]; }
+    h.ok = false;
+    if (!used) return false;
+    long left = 1;
+    for (int l = 1; l <= 15; l++) { left <<= 1; left -= count[l]; if (left < 0) return false; }
+    if (left > 0 && !(allow_single && used == 1 && maxlen == 1)) return false;  // incomplete
+    uint32_t next[16]; uint32_t code = 0;
+    for (int l = 1; l <= 15; l++) { code = (code + (uint32_t)count[l - 1]) << 1; next[l] = code; }
+    const int P = std::min(maxlen, MIRGE_GZ_PRIMARY), sub = maxlen - P;
+    h.maxlen = maxlen; h.pbits = P;
+    h.table.assign((size_t)1 << P, 0u);
+    for (int s = 0; s < n; s++) {
+        const int l = lens[s];
+        if (!l) continue;
+        uint32_t c = next[l]++, r = 0;
+        for (int b = 0; b < l; b++) r |= ((c >> b) & 1u) << (l - 1 - b);  // bit-reversed: the stream is LSB first
+        const uint32_t e = ((uint32_t)s << 4) | (uint32_t)l;
+        if (l <= P) {
+            for (uint32_t k = r; k < ((uint32_t)1 << P); k += (uint32_t)1 << l) h.table[k] = e;
+        } else {
+            const uint32_t pre = r & (((uint32_t)1 << P) - 1u);
+            if (!(h.table[pre] & 0x80000000u)) {  // this prefix's second-level table: 2^sub entries behind what is there
+                const uint32_t off = (uint32_t)h.table.size();
+                h.table.resize(h.table.size() + ((size_t)1 << sub), 0u);
+                h.table[pre] = 0x80000000u | (off << 4);
+            }
+            const uint32_t off = (h.table[pre] & 0x7FFFFFFFu) >> 4;
+            for (uint32_t k = r >> P; k < ((uint32_t)1 << sub); k += (uint32_t)1 << (l - P)) h.table[off + k] = e;
+        }
+    }
+    h.ok = true;
+    return true;
+}
+static inline int decode_sym(BitReader& br, const Huff& h) {
+    uint32_t e = h.table[br.peek(h.pbits)];
+    if (e & 0x80000000u) e = h.table[((e & 0x7FFFFFFFu) >> 4) + (br.peek(h.maxlen) >> h.pbits)];
+    if (!(e & 15u)) return -1;  // (the unused half of a single-symbol code, or a hole of an -- impossible -- incomplete code)
+    br.drop((int)(e & 15u));
+    return (int)(e >> 4);
+}
+
+static const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+// the header of a dynamic block (RFC 1951 3.2.7) behind BFINAL / BTYPE; false: not a well-formed one
+static bool read_dynamic_header(BitReader& br, Huff& lit, Huff& dist) {
+    const int hlit = (int)br.bits(5) + 257, hdist = (int)br.bits(5) + 1, hclen = (int)br.bits(4) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19] = {0};
+    for (int i = 0; i < hclen; i++) cl[order[i]] = (uint8_t)br.bits(3);
+    Huff clh;
+    if (!build_huff(cl, 19, clh, false)) return false;
+    uint8_t lens[286 + 30];
+    int i = 0;
+    while (i < hlit + hdist) {
+        const int s = decode_sym(br, clh);
+        if (s < 0 || br.ran_off()) return false;
+        if (s < 16) lens[i++] = (uint8_t)s;
+        else {
+            int rep, val = 0;
+            if (s == 16) { if (i == 0) return false; val = lens[i - 1]; rep = 3 + (int)br.bits(2); }
+            else if (s == 17) rep = 3 + (int)br.bits(3);
+            else rep = 11 + (int)br.bits(7);
+            if (i + rep > hlit + hdist) return false;
+            while (rep--) lens[i++] = (uint8_t)val;
+        }
+    }
+    if (!lens[256]) return false;  // no end-of-block code
+    if (!build_huff(lens, hlit, lit, true)) return false;
+    if (!build_huff(lens + hlit, hdist, dist, true)) {
+        // zlib accepts a block without any distance code when it holds literals only
+        bool any = false;
+        for (int k = 0; k < hdist; k++) any |= lens[hlit + k] != 0;
+        if (any) return false;
+        dist.ok = false; dist.maxlen = 0; dist.table.clear();
+    }
+    return true;
+}
+static void fixed_codes(Huff& lit, Huff& dist) {
+    uint8_t l[288];
+    for (int i = 0; i < 288; i++) l[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+    build_huff(l, 288, lit, false);
+    uint8_t d[32];
+    for (int i = 0; i < 32; i++) d[i] = 5;
+    build_huff(d, 32, dist, false);
+}
+
+#define MIRGE_GZ_WINDOW 32768
+// growable array of symbols WITHOUT value-initialisation (a std::vector zero-fills twice the text's size before it is written),
+// in 2 MiB-aligned anonymous mappings that ask for huge pages: a run's first call touches ~3 bytes of fresh memory per byte of
+// text, and 4 KiB page faults from every thread at once were 0.7 s of a 0.9 s decode phase
+struct SymBuf {
+    uint16_t* p = nullptr;
+    size_t cap = 0;
+    SymBuf() = default;
+    SymBuf(const SymBuf&) = delete;
+    SymBuf& operator=(const SymBuf&) = delete;
+    ~SymBuf() { release(); }
+    size_t size() const { return cap; }
+    static size_t bytes_for(size_t n) { return (n * sizeof(uint16_t) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
+    bool resize(size_t n) {
+        if (n <= cap) return true;
+        const size_t nb = bytes_for(n);
+        void* q = ::mmap(nullptr, nb + ((size_t)2 << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) return false;
+        // keep the 2 MiB-aligned part
+        uint8_t* base = (uint8_t*)q;
+        uint8_t* al = (uint8_t*)(((uintptr_t)base + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1));
+        if (al > base) ::munmap(base, (size_t)(al - base));
+        const size_t tail = (size_t)((base + nb + ((size_t)2 << 20)) - (al + nb));
+        if (tail) ::munmap(al + nb, tail);
+#ifdef MADV_HUGEPAGE
+        (void)::madvise(al, nb, MADV_HUGEPAGE);
+#endif
+        if (p) { std::memcpy(al, p, cap * sizeof(uint16_t)); ::munmap(p, bytes_for(cap)); }
+        p = (uint16_t*)al; cap = nb / sizeof(uint16_t);
+        return true;
+    }
+    void release() { if (p) ::munmap(p, bytes_for(cap)); p = nullptr; cap = 0; }
+    uint16_t& operator[](size_t i) { return p[i]; }
+    const uint16_t& operator[](size_t i) const { return p[i]; }
+    uint16_t* data() { return p; }
+};
+// One deflate block decoded into 16-bit symbols appended to `out`: a byte, or 256 + (index into the MIRGE_GZ_WINDOW bytes in front
+// of out[0]) for what a copy took from there.  known_history: out[0] is the stream's first byte (reaching back is an error).
+// text_only: a byte outside printable ASCII / tab / line ends is an error (the block-start search's plausibility test).
+// Returns 0 = block done, 1 = it was the final block, < 0 = malformed.
+// `out` is kept AHEAD of the symbols written (`o`, the caller's running count): it grows geometrically and never shrinks here.
+static int decode_block(BitReader& br, SymBuf& out, size_t& o, bool known_history, bool text_only, size_t max_out) {
+    const uint32_t bfinal = br.bits(1), btype = br.bits(2);
+    if (btype == 3) return -1;
+    if (btype == 0) {
+        br.drop(br.nbits & 7);  // to the byte boundary
+        const uint32_t len = br.bits(16), nlen = br.bits(16);
+        if ((len ^ nlen) != 0xFFFFu || br.ran_off()) return -1;
+        if (o + len > max_out) return -1;
+        if (o + len > out.size() && !out.resize(std::max(out.size() * 2, o + len + (size_t)(1 << 16)))) return -1;
+        for (uint32_t k = 0; k < len; k++) {
+            const uint32_t c = br.bits(8);
+            if (text_only && !(c == 9 || c == 10 || c == 13 || (c >= 32 && c < 127))) return -1;
+            out[o++] = (uint16_t)c;
+        }
+        if (br.ran_off()) return -1;
+        return (int)bfinal;
+    }
+    Huff lit, dist;
+    if (btype == 2) { if (!read_dynamic_header(br, lit, dist)) return -1; }
+    else fixed_codes(lit, dist);
+    auto done = [&](int rc) { return rc; };
+    for (;;) {
+        if (o + 512 > out.size()) {
+            if (o + 512 > max_out) return done(-1);
+            if (!out.resize(std::max(out.size() * 2, o + (size_t)(1 << 16)))) return done(-1);
+        }
+        if (br.ran_off()) return done(-1);
+        const int s = decode_sym(br, lit);
+        if (s < 0) return done(-1);
+        if (s < 256) {
+            if (text_only && !(s == 9 || s == 10 || s == 13 || (s >= 32 && s < 127))) return done(-1);
+            out[o++] = (uint16_t)s;
+            continue;
+        }
+        if (s == 256) return done((int)bfinal);
+        if (s > 285 || !dist.ok) return done(-1);
+        const int len = kLenBase[s - 257] + (int)br.bits(kLenExtra[s - 257]);
+        const int ds = decode_sym(br, dist);
+        if (ds < 0 || ds > 29) return done(-1);
+        const size_t d = (size_t)kDistBase[ds] + br.bits(kDistExtra[ds]);
+        if (d > o + (known_history ? 0 : MIRGE_GZ_WINDOW)) return done(-1);
+        uint16_t* w = out.data();
+        for (int k = 0; k < len; k++, o++)
+            w[o] = o >= d ? w[o - d] : (uint16_t)(256 + (MIRGE_GZ_WINDOW + o - d));  // before out[0]: an index into the history
+    }
+}
+
+// is there a well-formed block header at this bit position (the check that follows a candidate block in the search)?
+static bool plausible_header(const uint8_t* data, size_t n, uint64_t bit) {
+    BitReader br(data, n, bit);
+    (void)br.bits(1);
+    const uint32_t btype = br.bits(2);
+    if (btype == 3) return false;
+    if (btype == 1) return true;
+    if (btype == 0) { br.drop(br.nbits & 7); const uint32_t len = br.bits(16), nlen = br.bits(16); return (len ^ nlen) == 0xFFFFu; }
+    Huff a, b;
+    return read_dynamic_header(br, a, b);
+}
+
+// first bit position >= from_bit (and < to_bit) at which a non-final dynamic block starts, decodes into text and is followed by
+// a well-formed header; UINT64_MAX if none
+static uint64_t find_block_start(const uint8_t* data, size_t n, uint64_t from_bit, uint64_t to_bit) {
+    SymBuf tmp;
+    for (uint64_t bit = from_bit; bit < to_bit; bit++) {
+        const uint64_t byte = bit >> 3;
+        if (byte + 8 >= n) break;
+        uint64_t w;
+        std::memcpy(&w, data + byte, 8);
+        const uint32_t head = (uint32_t)(w >> (bit & 7)) & 7u;
+        if (head != 4u) continue;  // BFINAL = 0, BTYPE = 10b (read LSB first: bits 0 | 0 1)
+        BitReader br(data, n, bit);
+        size_t to = 0;
+        const int rc = decode_block(br, tmp, to, false, true, (size_t)64 << 20);
+        if (rc != 0 || to < 1024) continue;  // (a real block of a text file holds thousands of symbols)
+        const uint64_t next = bit_position(br, data);
+        if (next + 64 > (uint64_t)n * 8 || !plausible_header(data, n, next)) continue;
+        return bit;
+    }
+    return ~0ull;
+}
+
+struct GzHeader { size_t body = 0; bool bgzf = false; size_t bsize = 0; };
+static bool parse_gz_header(const uint8_t* p, size_t n, GzHeader& h) {
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return false;
+    const uint8_t flg = p[3];
+    size_t at = 10;
+    if (flg & 4) {
+        if (at + 2 > n) return false;
+        const size_t xlen = p[at] | (p[at + 1] << 8);
+        at += 2;
+        if (at + xlen > n) return false;
+        for (size_t q = at; q + 4 <= at + xlen;) {  // subfields: SI1 SI2 LEN data
+            const size_t sl = p[q + 2] | (p[q + 3] << 8);
+            if (p[q] == 'B' && p[q + 1] == 'C' && sl == 2 && q + 6 <= at + xlen) { h.bgzf = true; h.bsize = (size_t)(p[q + 4] | (p[q + 5] << 8)) + 1; }
+            q += 4 + sl;
+        }
+        at += xlen;
+    }
+    if (flg & 8) { while (at < n && p[at]) at++; at++; }
+    if (flg & 16) { while (at < n && p[at]) at++; at++; }
+    if (flg & 2) at += 2;
+    if (at >= n) return false;
+    h.body = at;
+    return true;
+}
+
+template <typename F>
+static void parallel_for(int n_items, int threads, F&& fn) {
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int i; (i = next.fetch_add(1)) < n_items;) fn(i); };
+    std::vector<std::thread> th;
+    for (int t = 1; t < std::min(threads, n_items); t++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+// a BGZF / multi-member file whose members carry their sizes: every member on its own with zlib
+static int inflate_bgzf(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t* n_out, int threads) {
+    struct Member { size_t at, size, body, isize, out_at; };
+    std::vector<Member> ms;
+    size_t at = 0, total = 0;
+    while (at < n) {
+        GzHeader h;
+        if (!parse_gz_header(gz + at, n - at, h) || !h.bgzf || at + h.bsize > n || h.bsize < h.body + 8) return -1;
+        const uint8_t* tr = gz + at + h.bsize - 4;
+        const size_t isize = (size_t)tr[0] | ((size_t)tr[1] << 8) | ((size_t)tr[2] << 16) | ((size_t)tr[3] << 24);
+        ms.push_back(Member{at, h.bsize, h.body, isize, total});
+        total += isize;
+        at += h.bsize;
+    }
+    if (total > cap) return -2;
+    std::atomic<int> bad{0};
+    // members are small (64 KiB): a thread takes runs of them
+    const int run = 64, n_runs = (int)((ms.size() + run - 1) / run);
+    parallel_for(n_runs, threads, [&](int r) {
+        for (size_t k = (size_t)r * run; k < std::min(ms.size(), (size_t)(r + 1) * run); k++) {
+            const Member& m = ms[k];
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+            zs.next_in = const_cast<Bytef*>(gz + m.at + m.body);
+            zs.avail_in = (uInt)(m.size - m.body - 8);
+            zs.next_out = out + m.out_at;
+            zs.avail_out = (uInt)m.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            const bool ok = rc == Z_STREAM_END && zs.total_out == m.isize;
+            inflateEnd(&zs);
+            const uint8_t* tr = gz + m.at + m.size - 8;
+            const uint32_t want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+            if (!ok || (uint32_t)crc32(0L, out + m.out_at, (uInt)m.isize) != want) { bad = 1; return; }
+        }
+    });
+    if (bad) return -1;
+    *n_out = total;
+    return 0;
+}
+
+// one ordinary member (the usual sample.fastq.gz), cut into chunks as described at the top
+static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t* n_out, int threads) {
+    GzHeader h;
+    if (!parse_gz_header(gz, n, h) || n < h.body + 8) return -1;
+    const uint8_t* d = gz + h.body;           // the deflate stream ... and the trailer behind it, somewhere
+    const size_t dn = n - h.body;
+    // chunk starts: ~4 per thread, at least 1 MiB of compressed data each
+    int n_chunks = (int)std::min<size_t>((size_t)threads * 4, std::max<size_t>(1, dn >> 20));
+    if (n_chunks < 2) return -3;  // too small to be worth it: the caller's serial route
+    std::vector<uint64_t> start((size_t)n_chunks, ~0ull);
+    start[0] = 0;
+    parallel_for(n_chunks - 1, threads, [&](int k) {
+        const int i = k + 1;
+        const uint64_t from = (uint64_t)((dn / (size_t)n_chunks) * (size_t)i) * 8ull, to = (uint64_t)((dn / (size_t)n_chunks) * (size_t)(i + 1)) * 8ull;
+        start[(size_t)i] = find_block_start(d, dn, from, to);
+    });
+    std::vector<uint64_t> st;
+    for (uint64_t s : start) if (s != ~0ull) st.push_back(s);
+    const int C = (int)st.size();
+    if (C < 2) return -3;
+    std::vector<SymBuf> sym((size_t)C);
+    std::vector<size_t> n_sym((size_t)C, 0);
+    std::vector<int> state((size_t)C, 0);  // 0 ok, 1 ended with the final block, < 0 failed
+    std::vector<uint64_t> end_bit((size_t)C, 0);
+    parallel_for(C, threads, [&](int i) {
+        BitReader br(d, dn, st[(size_t)i]);
+        SymBuf& o = sym[(size_t)i];
+        const uint64_t stop = i + 1 < C ? st[(size_t)i + 1] : ~0ull;
+        if (!o.resize((size_t)((i + 1 < C ? (stop - st[(size_t)i]) / 8 : dn - st[(size_t)i] / 8) * 5 + (1 << 16)))) { state[(size_t)i] = -1; return; }
+        size_t& no = n_sym[(size_t)i];
+        for (;;) {
+            const int rc = decode_block(br, o, no, i == 0, false, (size_t)1 << 36);
+            const uint64_t pos = bit_position(br, d);
+            if (rc < 0) { state[(size_t)i] = -1; return; }
+            if (rc == 1) { state[(size_t)i] = 1; end_bit[(size_t)i] = pos; return; }
+            if (pos == stop) { end_bit[(size_t)i] = pos; return; }
+            if (pos > stop) { state[(size_t)i] = -2; return; }  // the next chunk's start was no block boundary of this stream
+        }
+    });
+    size_t total = 0;
+    std::vector<size_t> at((size_t)C + 1, 0);
+    for (int i = 0; i < C; i++) {
+        if (state[(size_t)i] < 0 || (state[(size_t)i] == 1) != (i == C - 1)) return -1;
+        at[(size_t)i] = total;
+        total += n_sym[(size_t)i];
+    }
+    at[(size_t)C] = total;
+    if (total > cap) return -2;
+    // the trailer: CRC-32 and length (mod 2^32) behind the final block's last byte
+    const size_t tr = (size_t)((end_bit[(size_t)C - 1] + 7) / 8);
+    if (tr + 8 > dn) return -1;
+    const uint32_t want_crc = (uint32_t)d[tr] | ((uint32_t)d[tr + 1] << 8) | ((uint32_t)d[tr + 2] << 16) | ((uint32_t)d[tr + 3] << 24);
+    const uint32_t want_len = (uint32_t)d[tr + 4] | ((uint32_t)d[tr + 5] << 8) | ((uint32_t)d[tr + 6] << 16) | ((uint32_t)d[tr + 7] << 24);
+    if ((uint32_t)total != want_len) return -1;
+    if (tr + 8 != dn) return -4;  // something follows the member (another member, padding): the caller's general route
+    // histories, in order: the last MIRGE_GZ_WINDOW bytes of chunk i - 1 are chunk i's history
+    std::vector<std::vector<uint8_t>> hist((size_t)C);
+    for (int i = 1; i < C; i++) {
+        std::vector<uint8_t>& hw = hist[(size_t)i];
+        hw.assign(MIRGE_GZ_WINDOW, 0);
+        const SymBuf& prev = sym[(size_t)i - 1];
+        const size_t n_prev = n_sym[(size_t)i - 1];
+        const std::vector<uint8_t>& ph = hist[(size_t)i - 1];
+        for (size_t k = 0; k < MIRGE_GZ_WINDOW; k++) {
+            // byte k of the window = position (n_prev - WINDOW + k) of the previous chunk, or of ITS history when that is short
+            const long long q = (long long)n_prev - MIRGE_GZ_WINDOW + (long long)k;
+            if (q >= 0) {
+                const uint16_t s = prev[(size_t)q];
+                if (s < 256) hw[k] = (uint8_t)s;
+                else { if (ph.empty()) return -1; hw[k] = ph[(size_t)s - 256]; }
+            } else {
+                if (ph.empty()) { hw[k] = 0; continue; }  // before the stream's first byte: never referenced by a valid stream
+                hw[k] = ph[(size_t)(MIRGE_GZ_WINDOW + q)];
+            }
+        }
+    }
+    std::vector<uint32_t> crcs((size_t)C, 0);
+    std::atomic<int> bad{0};
+    parallel_for(C, threads, [&](int i) {
+        const SymBuf& s = sym[(size_t)i];
+        const size_t ns = n_sym[(size_t)i];
+        const std::vector<uint8_t>& hw = hist[(size_t)i];
+        uint8_t* o = out + at[(size_t)i];
+        for (size_t k = 0; k < ns; k++) {
+            const uint16_t v = s[k];
+            if (v < 256) o[k] = (uint8_t)v;
+            else if (!hw.empty()) o[k] = hw[(size_t)v - 256];
+            else { bad = 1; return; }
+        }
+        uint32_t c = 0;
+        for (size_t done = 0; done < ns;) {  // zlib's crc32 takes a 32-bit length
+            const size_t m = std::min<size_t>(ns - done, (size_t)1 << 30);
+            c = (uint32_t)crc32(c, o + done, (uInt)m);
+            done += m;
+        }
+        crcs[(size_t)i] = c;
+        sym[(size_t)i].release();
+    });
+    if (bad) return -1;
+    uint32_t crc = crcs[0];
+    for (int i = 1; i < C; i++) crc = (uint32_t)crc32_combine(crc, crcs[(size_t)i], (z_off_t)(at[(size_t)i + 1] - at[(size_t)i]));
+    if (crc != want_crc) return -1;
+    *n_out = total;
+    return 0;
+}
+
+}  // namespace mirge_gz
+
+// A whole .gz file's bytes -> its text, on `threads` host threads (0: all).  out[cap]; *n_out = bytes written.
+// 0: done, and verified against the CRC-32 / length the file carries.  Negative: not done -- the file is not of a kind this
+// route takes (several ordinary members, too small, not text), is damaged, or `cap` is too small (-2): the caller inflates it
+// the ordinary way, which also reports what is wrong with a damaged file.
+extern "C" int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads) {
+    if (!gz || n_gz < 18 || !out || cap < 0 || !n_out) return fail(-1, "mirge_gz_inflate: bad argument");
+    int T = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    T = std::min(T, 256);
+    mirge_gz::GzHeader h;
+    if (!mirge_gz::parse_gz_header(gz, (size_t)n_gz, h)) return fail(-1, "mirge_gz_inflate: not a gzip file");
+#ifdef MADV_HUGEPAGE
+    {   // the caller's buffer is fresh memory too: huge pages for its 2 MiB-aligned interior (a hint; failure changes nothing)
+        const uintptr_t lo = ((uintptr_t)out + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), hi = ((uintptr_t)out + (uintptr_t)cap) & ~(((uintptr_t)2 << 20) - 1);
+        if (hi > lo) (void)::madvise((void*)lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+    }
+#endif
+    size_t n = 0;
+    const int rc = h.bgzf ? mirge_gz::inflate_bgzf(gz, (size_t)n_gz, out, (size_t)cap, &n, T)
+                          : mirge_gz::inflate_member_parallel(gz, (size_t)n_gz, out, (size_t)cap, &n, T);
+    if (rc) return fail(rc, "mirge_gz_inflate: not inflated in parallel (code " + std::to_string(rc) + "): the serial route applies");
+    *n_out = (int64_t)n;
+    return 0;
+}

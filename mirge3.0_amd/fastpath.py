@@ -138,7 +138,9 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     sampleReadCounts, trimmedReadCounts, trimmedReadCountsUnique = {}, {}, {}
     parsed = []
     t_read = t_parse = 0.0
-    texts = read_texts(files, stream=True)  # read ahead on worker threads; a .gz is inflated piece by piece beside its own parse
+    from . import collapse as _collapse
+    del _collapse.GZ_LOG[:]
+    texts = read_texts(files, stream=True)  # read ahead on worker threads; a .gz is inflated on all cores, or piece by piece beside its parse
     gz_tm: Dict[str, float] = {}
     for f, name in zip(files, base_names):
         t = time.perf_counter()
@@ -156,6 +158,8 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         parsed.append(raw)
         say(f'Cutadapt finished for file {name} in {round(time.perf_counter() - t, 4)} second(s)')
     tm["read_files_s"], tm["parse_s"] = t_read, t_parse
+    if _collapse.GZ_LOG:  # .gz input inflated on all host cores (mirge_gz_inflate): inside read_files_s
+        tm["gz_parallel"] = list(_collapse.GZ_LOG)
     if gz_tm:  # streamed .gz input: parse_s is then bounded by the inflation (inflate_s, on its worker thread), of which
         tm["gz_stream"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in gz_tm.items()}  # upload_parse_s is the GPU side's share
     t = time.perf_counter()

@@ -25,6 +25,8 @@
 #include "../../mirge3.0_amd/csrc/mirge_isotype.hpp"
 #include "../../mirge3.0_amd/csrc/mirge_libbuild.hpp"
 #include "../../mirge3.0_amd/csrc/native_host.hpp"
+#include <atomic>
+#include "../../mirge3.0_amd/csrc/native_gz.hpp"
 
 static std::string slurp(const std::string& p) {
     std::ifstream f(p, std::ios::binary);
@@ -194,6 +196,93 @@ int main(int argc, char** argv) {
         EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size(), h.inv.data(), (int64_t)h.inv.size(), h.ref_start.data(), h.n_refs, h.total + 1, h.kmax) == -1);
         EXPECT(lib_packed_args_check(h.T.data(), (int64_t)h.T.size(), h.inv.data(), (int64_t)h.inv.size(), h.ref_start.data(), h.n_refs, h.total, 7) == -1);
         EXPECT(lib_packed_args_check(nullptr, 8, h.inv.data(), 4, h.ref_start.data(), 0, 0, 8) == -1);
+    }
+    // ---------------- mirge_gz_inflate: gzip members cut at block starts found by search, decoded without their history, resolved
+    {
+        auto gz_compress = [&](const std::string& text, int level, int strategy, size_t flush_every) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            deflateInit2(&zs, level, Z_DEFLATED, 31, 8, strategy);
+            std::string out(compressBound((uLong)text.size()) + text.size() / 100 + 4096, '\0');
+            zs.next_out = (Bytef*)out.data(); zs.avail_out = (uInt)out.size();
+            size_t at = 0;
+            while (at < text.size()) {
+                const size_t m = std::min(text.size() - at, flush_every ? flush_every : text.size());
+                zs.next_in = (Bytef*)text.data() + at; zs.avail_in = (uInt)m;
+                at += m;
+                deflate(&zs, at == text.size() ? Z_FINISH : Z_SYNC_FLUSH);  // sync flushes: what pigz writes between its pieces
+            }
+            if (text.empty()) deflate(&zs, Z_FINISH);
+            out.resize(zs.total_out);
+            deflateEnd(&zs);
+            return out;
+        };
+        auto fastq = [&](size_t n_rec, int qual_kinds) {
+            std::string t;
+            for (size_t i = 0; i < n_rec; i++) {
+                const size_t L = 16 + rng() % 35;
+                t += "@SRR" + std::to_string(1000000 + i) + " " + std::to_string(i) + " length=" + std::to_string(L) + "\n";
+                std::string q(L, 'I');
+                for (auto& c : q) c = (char)(33 + (qual_kinds <= 1 ? 40 : rng() % qual_kinds));
+                t += (rng() % 3 ? std::string("TGAGGTAGTAGGTTGTATAGTT").substr(0, std::min<size_t>(L, 22)) + rnd_seq(L > 22 ? L - 22 : 0) : rnd_seq(L)) + "\n+\n" + q + "\n";
+            }
+            return t;
+        };
+        int taken = 0, refused = 0;
+        const std::string texts[] = {fastq(150000, 1), fastq(120000, 41), std::string(3000000, 'A'), fastq(20, 4)};
+        const int combos[][3] = {{6, 0, 8}, {1, 1 << 20, 3}, {9, 0, 2}, {6, 1 << 19, 8}, {6, 0, 1}};  // level, sync flush every, threads
+        for (const std::string& text : texts)
+            for (const auto& cb : combos) {
+                const std::string gz = gz_compress(text, cb[0], Z_DEFAULT_STRATEGY, (size_t)cb[1]);
+                std::vector<uint8_t> out(text.size() + 1);
+                int64_t n = -1;
+                const int rc = mirge_gz_inflate((const uint8_t*)gz.data(), (int64_t)gz.size(), out.data(), (int64_t)text.size(), &n, cb[2]);
+                if (rc == 0) { taken++; EXPECT(n == (int64_t)text.size() && std::memcmp(out.data(), text.data(), text.size()) == 0); }
+                else refused++;
+                if (gz.size() > (3u << 20)) EXPECT(rc == 0);  // several MiB of compressed text: the route must take it
+            }
+        EXPECT(taken >= 8);
+        // what it must not take for the truth: a flipped bit (CRC), a truncated file, a second member behind the first, too little room
+        const std::string text = fastq(150000, 41), gz = gz_compress(text, 6, Z_DEFAULT_STRATEGY, 0);
+        std::vector<uint8_t> out(text.size() + 16);
+        int64_t n = 0;
+        for (size_t where : {gz.size() / 3, gz.size() / 2, gz.size() - 20}) {
+            std::string bad = gz;
+            bad[where] ^= 0x20;
+            EXPECT(mirge_gz_inflate((const uint8_t*)bad.data(), (int64_t)bad.size(), out.data(), (int64_t)out.size(), &n, 4) != 0);
+        }
+        EXPECT(mirge_gz_inflate((const uint8_t*)gz.data(), (int64_t)gz.size() / 2, out.data(), (int64_t)out.size(), &n, 4) != 0);
+        const std::string two = gz + gz;
+        std::vector<uint8_t> out2(2 * text.size());
+        EXPECT(mirge_gz_inflate((const uint8_t*)two.data(), (int64_t)two.size(), out2.data(), (int64_t)out2.size(), &n, 4) != 0);
+        EXPECT(mirge_gz_inflate((const uint8_t*)gz.data(), (int64_t)gz.size(), out.data(), (int64_t)text.size() - 1, &n, 4) != 0);
+        EXPECT(mirge_gz_inflate((const uint8_t*)"not a gzip file at all, no", 26, out.data(), 100, &n, 4) != 0);
+        // BGZF: members of <= 64 KiB that carry their size in an extra field, an empty one at the end
+        std::string bg;
+        for (size_t at = 0; at <= text.size(); at += 60000) {
+            const std::string piece = at < text.size() ? text.substr(at, 60000) : std::string();
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+            std::string body(compressBound((uLong)piece.size()) + 64, '\0');
+            zs.next_in = (Bytef*)piece.data(); zs.avail_in = (uInt)piece.size();
+            zs.next_out = (Bytef*)body.data(); zs.avail_out = (uInt)body.size();
+            deflate(&zs, Z_FINISH);
+            body.resize(zs.total_out);
+            deflateEnd(&zs);
+            const uint32_t crc = (uint32_t)crc32(0L, (const Bytef*)piece.data(), (uInt)piece.size()), isz = (uint32_t)piece.size();
+            const uint16_t bsize = (uint16_t)(18 + body.size() + 8 - 1);
+            const unsigned char hd[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (unsigned char)(bsize & 255), (unsigned char)(bsize >> 8)};
+            bg.append((const char*)hd, 18); bg += body;
+            for (int k = 0; k < 4; k++) bg.push_back((char)((crc >> (8 * k)) & 255));
+            for (int k = 0; k < 4; k++) bg.push_back((char)((isz >> (8 * k)) & 255));
+        }
+        std::vector<uint8_t> out3(text.size() + 65536);
+        EXPECT(mirge_gz_inflate((const uint8_t*)bg.data(), (int64_t)bg.size(), out3.data(), (int64_t)out3.size(), &n, 5) == 0);
+        EXPECT(n == (int64_t)text.size() && std::memcmp(out3.data(), text.data(), text.size()) == 0);
+        bg[bg.size() / 2] ^= 1;
+        EXPECT(mirge_gz_inflate((const uint8_t*)bg.data(), (int64_t)bg.size(), out3.data(), (int64_t)out3.size(), &n, 5) != 0);
+        std::printf("gz: %d inflated in parallel and equal, %d left to the serial route\n", taken, refused);
     }
     std::printf("host-only functions clean\n");
     return 0;

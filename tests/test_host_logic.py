@@ -271,6 +271,57 @@ def test_read_texts_keeps_file_order_and_inflates_gz(tmp_path):
     assert [bytes(t) for t in read_texts(paths[:1])] == want[:1] and bytes(read_text(str(paths[1]))) == want[1]
 
 
+def test_gz_inflate_on_all_cores_equals_zlib(tmp_path):
+    """mirge_gz_inflate (csrc/native_gz.hpp; host only -- no GPU involved): a sample.fastq.gz of a few MB comes back byte for byte
+    as zlib inflates it, through `_ffi.gz_inflate` and through `collapse.read_text`; what the route does not take -- a file of two
+    members, a small file, a damaged one -- comes back as None / goes to the streamed zlib route, which reports the damage."""
+    import gzip
+    import zlib
+    from mirge3_amd import _ffi, collapse
+    rng = np.random.default_rng(9)
+    n = 120000
+    L = rng.integers(16, 51, size=n)
+    recs = []
+    for i in range(n):
+        sq = "".join("ACGT"[x] for x in rng.integers(0, 4, int(L[i])))
+        ql = "".join(chr(33 + int(x)) for x in rng.integers(2, 41, int(L[i])))
+        recs.append(f"@SRR1.{i} {i} length={L[i]}\n{sq}\n+\n{ql}\n")
+    text = "".join(recs).encode()
+    p1 = tmp_path / "S.fastq.gz"
+    p1.write_bytes(gzip.compress(text, 6))
+    assert p1.stat().st_size > (3 << 20)
+    for threads in (0, 1, 3):
+        got = _ffi.gz_inflate(p1.read_bytes(), threads)
+        assert got is not None and got.tobytes() == text
+    del collapse.GZ_LOG[:]
+    rt = collapse.read_text(str(p1), stream=True)
+    assert isinstance(rt, np.ndarray) and rt.tobytes() == text and collapse.GZ_LOG and collapse.GZ_LOG[0]["text_MB"] == round(len(text) / 1e6, 1)
+    two = tmp_path / "T.fastq.gz"
+    two.write_bytes(gzip.compress(text[: len(text) // 2], 6) + gzip.compress(text[len(text) // 2:], 6))
+    assert _ffi.gz_inflate(two.read_bytes()) is None
+    st = collapse.read_text(str(two), stream=True)
+    assert isinstance(st, collapse.GzipRecordStream) and b"".join(st) == text
+    assert _ffi.gz_inflate(gzip.compress(text[:100000], 6)) is None  # too small to cut
+    bad = bytearray(p1.read_bytes())
+    bad[len(bad) // 2] ^= 4
+    assert _ffi.gz_inflate(bytes(bad)) is None
+    (tmp_path / "B.fastq.gz").write_bytes(bytes(bad))
+    with pytest.raises((zlib.error, EOFError, OSError)):
+        b"".join(collapse.read_text(str(tmp_path / "B.fastq.gz"), stream=True))
+
+
+def test_unpinned_trimming_options_are_named():
+    """Options whose cutadapt behaviour is restated without a real cutadapt's vectors behind it are listed for the run log (the
+    advisor's finding: accepted options must not change counts silently); the plain chain (-a, -q) is not among them."""
+    from mirge3_amd.cli import parse_args
+    from mirge3_amd.collapse import unpinned_trim_options
+    base = ["-s", "x.fastq", "-lib", "/x", "-on", "human", "-shh"]
+    assert unpinned_trim_options(parse_args(base + ["-a", "illumina"])) == []
+    got = unpinned_trim_options(parse_args(base + ["-a", "illumina", "-g", "ACGTACGT", "-n", "2", "--no-indels", "--action", "none",
+                                                   "--match-read-wildcards", "-N"]))
+    assert len(got) == 6 and any("two adapters" in g for g in got) and any("--no-indels" in g for g in got)
+
+
 def test_gzip_record_stream(tmp_path):
     """collapse.GzipRecordStream: a .fastq.gz comes out as pieces that are whole 4-line records, in order, byte for byte the
     file's text -- whatever the piece size, for one member, several members (bgzip / cat), an empty member and zero padding

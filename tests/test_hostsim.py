@@ -178,12 +178,15 @@ def test_pure_host_functions_are_asan_ubsan_clean(tmp_path):
     """native_host.hpp -- the mapped.csv / unmapped.csv formatter (mirge_annotation_csv), the GFF3 writer, the text of a merged
     library, the argument checks of mirge_lib_create_packed: the translation unit the product compiles -- under AddressSanitizer +
     UBSan with g++: names that need CSV quoting, empty libraries and references, reads of 0 / 255 / 600 nt, 1 and 17 samples,
-    indices that must be refused, records at the text limit; the formatter's files are compared with a std::string restatement."""
+    indices that must be refused, records at the text limit; the formatter's files are compared with a std::string restatement.
+    Also native_gz.hpp (mirge_gz_inflate): gzip members of FASTQ-like text at levels 1 / 6 / 9, with sync flushes, on 1-8 threads,
+    BGZF files, and what it must refuse -- a flipped bit, a truncated file, a second member, too little room."""
     exe = str(tmp_path / "host_only")
     subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-pthread",
-                           "-Wno-unknown-pragmas", os.path.join(HERE, "hostsim", "host_only_main.cpp"), "-o", exe])
-    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+                           "-Wno-unknown-pragmas", os.path.join(HERE, "hostsim", "host_only_main.cpp"), "-o", exe, "-lz"])
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "host-only functions clean" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    assert "inflated in parallel and equal" in r.stdout  # native_gz.hpp: the block-start search and the history resolution ran
 
 
 def hostsim_isotype(master: str, read: str, precursor: str):
