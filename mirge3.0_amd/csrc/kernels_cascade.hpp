@@ -469,6 +469,14 @@ __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint3
 // cache accesses with the memory system idle).  Here a workgroup walks through the steps on its own; workgroups drift
 // apart and the regimes overlap.  Same device functions as k_pass: same answers.
 // ------------------------------------------------------------------------------------------
+#ifndef MIRGE_SURV_PLAIN_LOADS
+// The survivor list a workgroup wrote in one pass is read back by the SAME workgroup in the next, behind a __syncthreads(): a
+// workgroup-scope release / acquire, which covers global memory -- the waves of a workgroup share their CU's L1, and that L1
+// sees the CU's own write-through stores.  Plain loads are therefore enough.  (Round 3 used agent-scope loads "because the L1
+// may hold the lines of two passes ago"; a build with plain loads passes the oracle, brute-force, fuzz and full-size C3 tests
+// -- profiles/README.md round 4 -- and the model says it must.  MIRGE_SURV_PLAIN_LOADS=0 brings the agent-scope loads back.)
+#define MIRGE_SURV_PLAIN_LOADS 1
+#endif
 #ifndef MIRGE_BULK_WAVES
 #define MIRGE_BULK_WAVES 6  // waves per SIMD = four-wave workgroups per CU the bulk kernel is built for (native_cascade.hpp sizes its grid with it)
 #endif
@@ -508,7 +516,7 @@ k_cascade_bulk(const FusedSteps* __restrict__ steps, GroupView<W> g, uint32_t* _
         __syncthreads();
         PlanSrc<LDSP> psrc;
         psrc.g = st.plan; psrc.l = LDSP ? s_plan : nullptr;
-        pass_segment<W, LDSP, true, HASN>(st.lib, st.pol, st.mi, psrc, g, act_in, n_in, seg, seg_r, act_out, st.pass_id, res_pass, res_pos, res_mm, &s_count);
+        pass_segment<W, LDSP, !MIRGE_SURV_PLAIN_LOADS, HASN>(st.lib, st.pol, st.mi, psrc, g, act_in, n_in, seg, seg_r, act_out, st.pass_id, res_pass, res_pos, res_mm, &s_count);
         __syncthreads();  // the survivors are written (and visible to this workgroup at L2), the plan is free again
         n_in = s_count;
         if (threadIdx.x == 0) seg_n[(size_t)si * gridDim.x + blockIdx.x] = n_in;

@@ -152,6 +152,9 @@ static void fixed_codes(Huff& lit, Huff& dist) {
 }
 
 #define MIRGE_GZ_WINDOW 32768
+#ifndef MIRGE_GZ_RATIO_GUESS
+#define MIRGE_GZ_RATIO_GUESS 7  // symbols reserved per compressed byte of a chunk (FASTQ at level 6: 4-6); more grows the buffer
+#endif
 // growable array of symbols WITHOUT value-initialisation (a std::vector zero-fills twice the text's size before it is written),
 // in 2 MiB-aligned anonymous mappings that ask for huge pages: a run's first call touches ~3 bytes of fresh memory per byte of
 // text, and 4 KiB page faults from every thread at once were 0.7 s of a 0.9 s decode phase
@@ -167,7 +170,11 @@ struct SymBuf {
     bool resize(size_t n) {
         if (n <= cap) return true;
         const size_t nb = bytes_for(n);
+#ifdef MIRGE_GZ_POPULATE
+        void* q = ::mmap(nullptr, nb + ((size_t)2 << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_POPULATE, -1, 0);
+#else
         void* q = ::mmap(nullptr, nb + ((size_t)2 << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+#endif
         if (q == MAP_FAILED) return false;
         // keep the 2 MiB-aligned part
         uint8_t* base = (uint8_t*)q;
@@ -175,7 +182,7 @@ struct SymBuf {
         if (al > base) ::munmap(base, (size_t)(al - base));
         const size_t tail = (size_t)((base + nb + ((size_t)2 << 20)) - (al + nb));
         if (tail) ::munmap(al + nb, tail);
-#ifdef MADV_HUGEPAGE
+#if defined(MADV_HUGEPAGE) && !defined(MIRGE_GZ_NOHUGE)
         (void)::madvise(al, nb, MADV_HUGEPAGE);
 #endif
         if (p) { std::memcpy(al, p, cap * sizeof(uint16_t)); ::munmap(p, bytes_for(cap)); }
@@ -377,7 +384,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
         BitReader br(d, dn, st[(size_t)i]);
         SymBuf& o = sym[(size_t)i];
         const uint64_t stop = i + 1 < C ? st[(size_t)i + 1] : ~0ull;
-        if (!o.resize((size_t)((i + 1 < C ? (stop - st[(size_t)i]) / 8 : dn - st[(size_t)i] / 8) * 5 + (1 << 16)))) { state[(size_t)i] = -1; return; }
+        if (!o.resize((size_t)((i + 1 < C ? (stop - st[(size_t)i]) / 8 : dn - st[(size_t)i] / 8) * MIRGE_GZ_RATIO_GUESS + (1 << 16)))) { state[(size_t)i] = -1; return; }
         size_t& no = n_sym[(size_t)i];
         for (;;) {
             const int rc = decode_block(br, o, no, i == 0, false, (size_t)1 << 36);
@@ -463,7 +470,9 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
 // the ordinary way, which also reports what is wrong with a damaged file.
 extern "C" int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads) {
     if (!gz || n_gz < 18 || !out || cap < 0 || !n_out) return fail(-1, "mirge_gz_inflate: bad argument");
-    int T = threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    // (beyond ~64 threads nothing is gained: 82 chunks of a 10 M-read sample decode in 0.35 s on 16, 64 or 256 threads of a
+    // 2 x 64-core host -- concurrent first-touch page faults, not decoding, set the floor; profiles/README.md round 4)
+    int T = threads > 0 ? threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
     T = std::min(T, 256);
     mirge_gz::GzHeader h;
     if (!mirge_gz::parse_gz_header(gz, (size_t)n_gz, h)) return fail(-1, "mirge_gz_inflate: not a gzip file");
