@@ -115,7 +115,7 @@ def pmc_traffic(args, rec_name):
         # rocprofv3 is a python script: run it with this interpreter (no '#!/usr/bin/env' hop)
         cmd = [sys.executable, rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--pmc", "0",
-               "--min-seconds", "0", "--spinup", "0", "--cli-path", "0",
+               "--min-seconds", "0", "--spinup", "0", "--cli-path", "0", "--two-in-flight", "0",
                "--reads", str(args.reads), "--scale", args.scale, "--workload", args.workload]
         try:
             subprocess.run(cmd, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
@@ -414,6 +414,8 @@ def main():
     ap.add_argument("--min-seconds", dest="min_seconds", type=float, default=2.0,
                     help="repeat the timed region of --steps steps until this much timed work has been seen (0 = one region)")
     ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the timed region (clock state)")
+    ap.add_argument("--two-in-flight", dest="two_in_flight", type=int, default=1,
+                    help="rank 0, N=1: also measure the step with TWO samples in flight on two contexts (never `value`)")
     ap.add_argument("--pmc", type=int, default=1,
                     help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()
@@ -757,6 +759,44 @@ def main():
                 out["cli_path"] = {"error": repr(e)[:300]}
         del text
 
+    # ---------------- two samples in flight (never `value`): what a batch of samples per GPU runs at -- a second context (its own
+    # streams, its own copy of the libraries) steps a second sample from a second host thread; the collapse of one sample (LDS-
+    # and write-bound) overlaps the cascade of the other (bound by L1 misses in flight)
+    if rank == 0 and n_gpus == 1 and args.two_in_flight and args.workload in ("c3", "c4") and not args.pool:
+        try:
+            import threading
+            ctx2 = _ffi.Context(dev_index)
+            casc2 = Cascade(ctx2, libs, n_pass=n_pass)
+            raw2 = _ffi.DeviceReads.pack(ctx2, reads)
+
+            def step2():
+                u2, r2 = casc2.collapse_and_run(raw2)
+                _ffi.count_join(ctx2, u2, r2, EXACT_PASS, ISO_PASS if n_pass > ISO_PASS else -2, n_mirna)
+                r2.close(); u2.close()
+
+            for _ in range(3):
+                step2()
+            K2 = max(20, min(200, int(0.25 / max(ms_per_step * 1e-3, 1e-6))))
+            t = time.perf_counter()
+            for _ in range(K2):
+                step()
+            one = (time.perf_counter() - t) / K2
+            th = [threading.Thread(target=lambda f=f: [f() for _ in range(K2)]) for f in (step, step2)]
+            t = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            two = (time.perf_counter() - t) / (2 * K2)
+            out["two_samples_in_flight"] = {
+                "M_reads_per_s": round(args.reads / two / 1e6, 1), "ms_per_sample": round(two * 1e3, 4),
+                "one_at_a_time_ms": round(one * 1e3, 4), "speedup": round(one / two, 3), "steps_each": K2,
+                "note": "two contexts (two sets of HIP streams, two host threads) step the same workload side by side on the one "
+                        "GPU: throughput of a batch of samples per GPU; `value` stays one sample at a time"}
+            raw2.close(); casc2.close(); ctx2.close()
+        except Exception as e:  # noqa: BLE001
+            out["two_samples_in_flight"] = {"error": repr(e)[:300]}
+
     # ---------------- PCIe-inclusive rate (never `value`): host ASCII reads in, per-read annotation + counts out
     if rank == 0:
         best_dt = None
@@ -851,17 +891,17 @@ def main():
             if t.get("valu_insts"):
                 # SURVEY 8(d)'s second bound: vector-instruction issue.  A wave64 VALU instruction occupies its SIMD16 for 4
                 # cycles, so the chip issues at most CUs x 4 SIMDs x sclk / 4 of them per second.
+                # at the chip's peak shader clock: sysfs lists eight cards on these boxes without saying which one this process
+                # was given (another tenant's idle card read 642 MHz and made the fraction 1.76), and the SMI samples taken
+                # during a run show the busy card at 2.39-2.41 GHz
                 sclk = SCLK_PEAK_MHZ
-                ck = (clocks_after or {}).get(f"card{dev_index}") if dev_index == 0 else None  # sysfs order is only known for the first card
-                if ck and ck > 500:
-                    sclk = float(ck)
                 peak = N_CU * SIMD_PER_CU * sclk * 1e6 / VALU_CYCLES_PER_WAVE64 / 1e9
                 ach = t["valu_insts"] / (out["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
                 out["roofline"]["valu"] = {
                     "insts_per_launch": round(t["valu_insts"], 1), "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "G wave-level VALU instructions/s", "frac": round(ach / peak, 4), "sclk_mhz": sclk,
-                    "note": "SQ_INSTS_VALU (own --pmc pass) x 4 issue cycles / (256 CUs x 4 SIMDs x sclk x launch time): the share "
-                            "of the chip's vector-issue cycles the kernel uses"}
+                    "note": "SQ_INSTS_VALU (own --pmc pass) x 4 issue cycles / (256 CUs x 4 SIMDs x 2.4 GHz peak shader clock x launch "
+                            "time): the share of the chip's vector-issue cycles the kernel uses"}
     if rank == 0:
         print(json.dumps(out))
     raw.close()

@@ -11,7 +11,8 @@
 //      to: output symbols are 16 bits, a byte, or -- for a copy that reaches back before the chunk -- the index of the unknown
 //      history byte (copies of such symbols copy the symbol);
 //   3. the last 32 KiB of every chunk are resolved in order (chunk 0 has no history, so its end is known; that is chunk 1's
-//      history, ...: 32 K table lookups per chunk), then all chunks are resolved to bytes in parallel, at their offsets of the text;
+//      history, ...: 32 K table lookups per chunk, handed from worker to worker), and every worker turns its chunk into bytes
+//      at its offset of the text as soon as it knows its history;
 //   4. the CRC-32 and length of the gzip trailer must match (per-chunk CRCs combined), else the caller inflates the ordinary way.
 // (The approach of pugz / rapidgzip, written from the deflate specification RFC 1951.)  BGZF files (bgzip: members of <= 64 KiB
 // that carry their size) and other multi-member files are inflated member by member on the same threads with zlib.
@@ -32,6 +33,14 @@ struct BitReader {
         drop((int)(start_bit & 7));
     }
     inline void fill() {
+        if (end - p >= 8 && nbits >= 0) {  // eight bytes at once: the whole ones that fit are counted, the partial one is OR-ed again next time
+            uint64_t w;
+            std::memcpy(&w, p, 8);
+            buf |= w << nbits;
+            const int adv = (63 - nbits) >> 3;
+            p += adv; nbits += adv * 8;
+            return;
+        }
         while (nbits <= 56 && p < end) { buf |= (uint64_t)(*p++) << nbits; nbits += 8; }
     }
     inline uint32_t peek(int n) { if (nbits < n) fill(); return (uint32_t)(buf & ((1ull << n) - 1ull)); }
@@ -362,8 +371,8 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
     if (!parse_gz_header(gz, n, h) || n < h.body + 8) return -1;
     const uint8_t* d = gz + h.body;           // the deflate stream ... and the trailer behind it, somewhere
     const size_t dn = n - h.body;
-    // chunk starts: ~4 per thread, at least 1 MiB of compressed data each
-    int n_chunks = (int)std::min<size_t>((size_t)threads * 4, std::max<size_t>(1, dn >> 20));
+    // chunk starts: ~8 per thread, at least 512 KiB of compressed data each
+    int n_chunks = (int)std::min<size_t>((size_t)threads * 8, std::max<size_t>(1, dn >> 19));
     if (n_chunks < 2) return -3;  // too small to be worth it: the caller's serial route
     std::vector<uint64_t> start((size_t)n_chunks, ~0ull);
     start[0] = 0;
@@ -376,87 +385,103 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
     for (uint64_t s : start) if (s != ~0ull) st.push_back(s);
     const int C = (int)st.size();
     if (C < 2) return -3;
-    std::vector<SymBuf> sym((size_t)C);
+    // Workers take the chunks in order, each with ONE symbol buffer it keeps (fresh memory is touched once per worker, not
+    // once per chunk): decode chunk i without its history; wait until chunk i - 1 has published where chunk i's bytes go and
+    // what its history is -- it usually has, it started earlier --; publish the same for chunk i + 1 (32 K lookups through
+    // the history: microseconds, so the chain through all chunks is milliseconds); then turn the chunk's symbols into bytes at
+    // their place of the text and take their CRC-32.
+    struct Link {  // what chunk i needs from its predecessors
+        std::atomic<int> ready{0};
+        size_t at = 0;                 // offset of the chunk's first byte in the text
+        std::vector<uint8_t> hist;     // the MIRGE_GZ_WINDOW bytes in front of it (empty: the stream starts here)
+    };
+    std::vector<Link> link((size_t)C + 1);
+    link[0].ready.store(1);
+    std::vector<uint32_t> crcs((size_t)C, 0);
     std::vector<size_t> n_sym((size_t)C, 0);
-    std::vector<int> state((size_t)C, 0);  // 0 ok, 1 ended with the final block, < 0 failed
-    std::vector<uint64_t> end_bit((size_t)C, 0);
-    parallel_for(C, threads, [&](int i) {
-        BitReader br(d, dn, st[(size_t)i]);
-        SymBuf& o = sym[(size_t)i];
-        const uint64_t stop = i + 1 < C ? st[(size_t)i + 1] : ~0ull;
-        if (!o.resize((size_t)((i + 1 < C ? (stop - st[(size_t)i]) / 8 : dn - st[(size_t)i] / 8) * MIRGE_GZ_RATIO_GUESS + (1 << 16)))) { state[(size_t)i] = -1; return; }
-        size_t& no = n_sym[(size_t)i];
-        for (;;) {
-            const int rc = decode_block(br, o, no, i == 0, false, (size_t)1 << 36);
-            const uint64_t pos = bit_position(br, d);
-            if (rc < 0) { state[(size_t)i] = -1; return; }
-            if (rc == 1) { state[(size_t)i] = 1; end_bit[(size_t)i] = pos; return; }
-            if (pos == stop) { end_bit[(size_t)i] = pos; return; }
-            if (pos > stop) { state[(size_t)i] = -2; return; }  // the next chunk's start was no block boundary of this stream
+    uint64_t final_end_bit = 0;
+    std::atomic<int> failed{0}, next{0};
+    auto worker = [&]() {
+        SymBuf o;
+        for (int i; (i = next.fetch_add(1)) < C;) {
+            int st_i = 0;  // 0 ok, 1 ended with the final block, < 0 failed
+            size_t no = 0;
+            uint64_t endb = 0;
+            if (!failed.load()) {
+                BitReader br(d, dn, st[(size_t)i]);
+                const uint64_t stop = i + 1 < C ? st[(size_t)i + 1] : ~0ull;
+                if (!o.resize((size_t)((i + 1 < C ? (stop - st[(size_t)i]) / 8 : dn - st[(size_t)i] / 8) * MIRGE_GZ_RATIO_GUESS + (1 << 16)))) st_i = -1;
+                while (st_i == 0) {
+                    const int rc = decode_block(br, o, no, i == 0, false, (size_t)1 << 36);
+                    const uint64_t pos = bit_position(br, d);
+                    if (rc < 0) st_i = -1;
+                    else if (rc == 1) { st_i = 1; endb = pos; }
+                    else if (pos == stop) { endb = pos; break; }
+                    else if (pos > stop) st_i = -2;  // the next chunk's start was no block boundary of this stream
+                }
+                if (st_i < 0 || (st_i == 1) != (i == C - 1)) failed.store(1);
+            }
+            // the hand-over happens even after a failure: nobody may wait for ever
+            while (!link[(size_t)i].ready.load(std::memory_order_acquire)) std::this_thread::yield();
+            const bool ok = !failed.load();
+            const Link& me = link[(size_t)i];
+            Link& nx = link[(size_t)i + 1];
+            nx.at = me.at + (ok ? no : 0);
+            if (ok && nx.at > cap) failed.store(2);
+            if (ok && i + 1 < C) {
+                nx.hist.assign(MIRGE_GZ_WINDOW, 0);
+                for (size_t k = 0; k < MIRGE_GZ_WINDOW; k++) {
+                    // byte k of the next history = position (no - WINDOW + k) of this chunk, or of ITS history when the chunk is short
+                    const long long q = (long long)no - MIRGE_GZ_WINDOW + (long long)k;
+                    if (q >= 0) {
+                        const uint16_t sv = o[(size_t)q];
+                        if (sv < 256) nx.hist[k] = (uint8_t)sv;
+                        else if (!me.hist.empty()) nx.hist[k] = me.hist[(size_t)sv - 256];
+                        else failed.store(1);
+                    } else if (!me.hist.empty()) nx.hist[k] = me.hist[(size_t)(MIRGE_GZ_WINDOW + q)];
+                }
+            }
+            if (i == C - 1) final_end_bit = endb;
+            n_sym[(size_t)i] = no;
+            nx.ready.store(1, std::memory_order_release);
+            if (failed.load()) continue;
+            uint8_t* ob = out + me.at;
+            const uint8_t* hw = me.hist.empty() ? nullptr : me.hist.data();
+            bool bad = false;
+            for (size_t k = 0; k < no; k++) {
+                const uint16_t v = o[k];
+                if (v < 256) ob[k] = (uint8_t)v;
+                else if (hw) ob[k] = hw[(size_t)v - 256];
+                else { bad = true; break; }
+            }
+            if (bad) { failed.store(1); continue; }
+            uint32_t c = 0;
+            for (size_t done = 0; done < no;) {  // zlib's crc32 takes a 32-bit length
+                const size_t m = std::min<size_t>(no - done, (size_t)1 << 30);
+                c = (uint32_t)crc32(c, ob + done, (uInt)m);
+                done += m;
+            }
+            crcs[(size_t)i] = c;
         }
-    });
-    size_t total = 0;
-    std::vector<size_t> at((size_t)C + 1, 0);
-    for (int i = 0; i < C; i++) {
-        if (state[(size_t)i] < 0 || (state[(size_t)i] == 1) != (i == C - 1)) return -1;
-        at[(size_t)i] = total;
-        total += n_sym[(size_t)i];
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < std::min(threads, C); t++) th.emplace_back(worker);
+        worker();
+        for (auto& x : th) x.join();
     }
-    at[(size_t)C] = total;
-    if (total > cap) return -2;
+    if (failed.load() == 2) return -2;
+    if (failed.load()) return -1;
+    const size_t total = link[(size_t)C].at;
     // the trailer: CRC-32 and length (mod 2^32) behind the final block's last byte
-    const size_t tr = (size_t)((end_bit[(size_t)C - 1] + 7) / 8);
+    const size_t tr = (size_t)((final_end_bit + 7) / 8);
     if (tr + 8 > dn) return -1;
     const uint32_t want_crc = (uint32_t)d[tr] | ((uint32_t)d[tr + 1] << 8) | ((uint32_t)d[tr + 2] << 16) | ((uint32_t)d[tr + 3] << 24);
     const uint32_t want_len = (uint32_t)d[tr + 4] | ((uint32_t)d[tr + 5] << 8) | ((uint32_t)d[tr + 6] << 16) | ((uint32_t)d[tr + 7] << 24);
     if ((uint32_t)total != want_len) return -1;
     if (tr + 8 != dn) return -4;  // something follows the member (another member, padding): the caller's general route
-    // histories, in order: the last MIRGE_GZ_WINDOW bytes of chunk i - 1 are chunk i's history
-    std::vector<std::vector<uint8_t>> hist((size_t)C);
-    for (int i = 1; i < C; i++) {
-        std::vector<uint8_t>& hw = hist[(size_t)i];
-        hw.assign(MIRGE_GZ_WINDOW, 0);
-        const SymBuf& prev = sym[(size_t)i - 1];
-        const size_t n_prev = n_sym[(size_t)i - 1];
-        const std::vector<uint8_t>& ph = hist[(size_t)i - 1];
-        for (size_t k = 0; k < MIRGE_GZ_WINDOW; k++) {
-            // byte k of the window = position (n_prev - WINDOW + k) of the previous chunk, or of ITS history when that is short
-            const long long q = (long long)n_prev - MIRGE_GZ_WINDOW + (long long)k;
-            if (q >= 0) {
-                const uint16_t s = prev[(size_t)q];
-                if (s < 256) hw[k] = (uint8_t)s;
-                else { if (ph.empty()) return -1; hw[k] = ph[(size_t)s - 256]; }
-            } else {
-                if (ph.empty()) { hw[k] = 0; continue; }  // before the stream's first byte: never referenced by a valid stream
-                hw[k] = ph[(size_t)(MIRGE_GZ_WINDOW + q)];
-            }
-        }
-    }
-    std::vector<uint32_t> crcs((size_t)C, 0);
-    std::atomic<int> bad{0};
-    parallel_for(C, threads, [&](int i) {
-        const SymBuf& s = sym[(size_t)i];
-        const size_t ns = n_sym[(size_t)i];
-        const std::vector<uint8_t>& hw = hist[(size_t)i];
-        uint8_t* o = out + at[(size_t)i];
-        for (size_t k = 0; k < ns; k++) {
-            const uint16_t v = s[k];
-            if (v < 256) o[k] = (uint8_t)v;
-            else if (!hw.empty()) o[k] = hw[(size_t)v - 256];
-            else { bad = 1; return; }
-        }
-        uint32_t c = 0;
-        for (size_t done = 0; done < ns;) {  // zlib's crc32 takes a 32-bit length
-            const size_t m = std::min<size_t>(ns - done, (size_t)1 << 30);
-            c = (uint32_t)crc32(c, o + done, (uInt)m);
-            done += m;
-        }
-        crcs[(size_t)i] = c;
-        sym[(size_t)i].release();
-    });
-    if (bad) return -1;
     uint32_t crc = crcs[0];
-    for (int i = 1; i < C; i++) crc = (uint32_t)crc32_combine(crc, crcs[(size_t)i], (z_off_t)(at[(size_t)i + 1] - at[(size_t)i]));
+    for (int i = 1; i < C; i++) crc = (uint32_t)crc32_combine(crc, crcs[(size_t)i], (z_off_t)n_sym[(size_t)i]);
     if (crc != want_crc) return -1;
     *n_out = total;
     return 0;

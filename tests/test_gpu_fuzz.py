@@ -1,6 +1,6 @@
 """Differential fuzzing on the GPU: random libraries (sizes chosen so that the probe length K and the
 plain / recursive plans vary), random reads (substrings with 0-3 substitutions, N calls, T tails, junk,
-1-255 nt) and RANDOM cascades (any -n / -v budget 0..3, -5/-3 trims, length filters, T-tail rule) through
+1-255 nt, and 256-900 nt: the long class) and RANDOM cascades (any -n / -v budget 0..3, -5/-3 trims, length filters, T-tail rule) through
 mirge_cascade_run, against the brute-force oracle given the same policies.  Bit-exact on every field."""
 import numpy as np
 import pytest
@@ -66,7 +66,8 @@ def test_random_cascade_matches_bruteforce(seed):
         lib = libs[int(rng.integers(0, n_pass))]
         s = lib.get(int(rng.integers(0, len(lib))))
         kind = rng.random()
-        L = int(rng.integers(1, 256)) if rng.random() < 0.1 else int(rng.integers(12, 45))
+        u = rng.random()
+        L = int(rng.integers(256, 900)) if u < 0.03 else (int(rng.integers(1, 256)) if u < 0.12 else int(rng.integers(12, 45)))
         if kind < 0.75 and len(s) > 2:
             L = min(L, len(s))
             a = int(rng.integers(0, len(s) - L + 1))
@@ -77,9 +78,9 @@ def test_random_cascade_matches_bruteforce(seed):
                 x[int(rng.integers(0, L))] = "N"
             r = "".join(x)
             if rng.random() < 0.1:
-                r = (r + "T" * int(rng.integers(3, 8)))[:255]
+                r = (r + "T" * int(rng.integers(3, 8)))[:1000]
             if rng.random() < 0.1:
-                r = ("ACGT"[int(rng.integers(0, 4))] + r + _rand_seq(rng, 2))[:255]
+                r = ("ACGT"[int(rng.integers(0, 4))] + r + _rand_seq(rng, 2))[:1000]
         else:
             r = _rand_seq(rng, L, pn=0.02)
         reads.append(r)
@@ -107,13 +108,13 @@ def test_random_cascade_matches_bruteforce(seed):
 
 @pytest.mark.parametrize("seed,n,S", [(1, 70000, 1), (2, 150000, 1), (3, 90000, 3), (4, 1000, 2), (5, 66000, 1)])
 def test_random_collapse_matches_counter(seed, n, S):
-    """Collapse on random inputs around the partition threshold (65536 reads), all four width classes, reads
+    """Collapse on random inputs around the partition threshold (65536 reads), all five width classes, reads
     with N, one or several samples: the (sequence -> per-sample count) map and first indices must equal Python's."""
     from collections import Counter
     rng = np.random.default_rng(50 + seed)
     pool = []
     for _ in range(max(n // 6, 10)):
-        L = int(rng.choice([16, 18, 20, 22, 22, 24, 27, 30, 31, 32, 33, 40, 64, 65, 100, 128, 129, 150, 200, 255]))
+        L = int(rng.choice([16, 18, 20, 22, 22, 24, 27, 30, 31, 32, 33, 40, 64, 65, 100, 128, 129, 150, 200, 255, 256, 300, 1000]))
         pool.append(_rand_seq(rng, L, pn=0.02 if rng.random() < 0.05 else 0.0))
     w = 1.0 / np.arange(1, len(pool) + 1) ** 0.9
     pick = rng.choice(len(pool), size=n, p=w / w.sum())
@@ -139,7 +140,7 @@ def test_random_collapse_matches_counter(seed, n, S):
 
 @pytest.mark.parametrize("seed", range(max(6, N_FUZZ // 4)))
 def test_random_text_parses_like_the_host_parser(seed, tmp_path):
-    """mirge_reads_parse on random FASTQ / FASTA / line files (random lengths 0-128, N calls, lower case, CRLF or LF,
+    """mirge_reads_parse on random FASTQ / FASTA / line files (random lengths 0-400, N calls, lower case, CRLF or LF,
     with or without a final newline, tiles of the newline scan cut at every offset) against the host parser."""
     from mirge3_amd.collapse import read_fastq_sequences, filter_min_length
     rng = np.random.default_rng(500 + seed)
@@ -149,7 +150,7 @@ def test_random_text_parses_like_the_host_parser(seed, tmp_path):
     eol = "\r\n" if rng.random() < 0.3 else "\n"
     seqs = []
     for _ in range(n):
-        L = int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 64, 65, 128])) if rng.random() < 0.2 else int(rng.integers(14, 60))
+        L = int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 64, 65, 128, 255, 256, 257, 400])) if rng.random() < 0.2 else int(rng.integers(14, 60))
         s = _rand_seq(rng, L, pn=0.02 if rng.random() < 0.1 else 0.0)
         if rng.random() < 0.05:
             s = s.lower()

@@ -9,7 +9,7 @@ for r in range(rounds):
         env = dict(os.environ)
         if name == "variant": env["MIRGE_NATIVE_SO"] = var
         else: env.pop("MIRGE_NATIVE_SO", None)
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "3", "--cpu-baseline", "0", "--pmc", "0"],
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "3", "--cpu-baseline", "0", "--pmc", "0", "--two-in-flight", "0"],
                              env=env, capture_output=True, text=True)
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         res[name].append(d["ms_per_step"])

@@ -18,7 +18,7 @@ res = {n: [] for n, _ in settings}
 for r in range(rounds):
     for name, env_add in settings:
         env = dict(os.environ, **env_add)
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "3", "--cpu-baseline", "0", "--pmc", "0",
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "3", "--cpu-baseline", "0", "--pmc", "0", "--two-in-flight", "0",
                               "--cli-path", "0", "--min-seconds", "1"], env=env, capture_output=True, text=True)
         try:
             d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
