@@ -146,11 +146,12 @@ def gz_inflate(data, threads: int = 0) -> Optional[np.ndarray]:
     buf = np.frombuffer(data, dtype=np.uint8)
     if buf.size < 18:
         return None
-    isize = int.from_bytes(bytes(buf[-4:]), "little")  # the LAST member's length mod 2^32: exact for the one-member file this is for
-    cap = isize
-    if buf[3] & 4:  # an extra field: possibly BGZF, whose members each carry their own length -> bound by the format's 64 KiB
-        cap = max(cap, (buf.size // 28 + 1) * 65536)
-    if cap <= 0 or cap > (1 << 36):
+    isize = int.from_bytes(bytes(buf[-4:]), "little")  # the LAST member's length mod 2^32: exact for a one-member file below 4 GiB
+    # room: that length, or -- the file may hold several members (merged lanes, BGZF), whose lengths only the members know --
+    # twelve times the compressed size (FASTQ deflates 4-6 x; untouched pages of the buffer cost nothing).  Too little room is
+    # reported (-2) and the caller streams the file instead.
+    cap = max(isize, 12 * buf.size) + 65536
+    if cap > (1 << 37):
         return None
     out = np.empty(cap, dtype=np.uint8)
     n = C.c_int64(0)

@@ -15,7 +15,8 @@
 //      at its offset of the text as soon as it knows its history;
 //   4. the CRC-32 and length of the gzip trailer must match (per-chunk CRCs combined), else the caller inflates the ordinary way.
 // (The approach of pugz / rapidgzip, written from the deflate specification RFC 1951.)  BGZF files (bgzip: members of <= 64 KiB
-// that carry their size) and other multi-member files are inflated member by member on the same threads with zlib.
+// that carry their size) are inflated member by member on the same threads with zlib; a file of several ordinary members (lanes
+// merged with `cat`) member after member, each cut as above when it is large enough.
 // Nothing here decides an answer: a text that fails any check is simply inflated serially by the caller (collapse.GzipRecordStream).
 #pragma once
 #include <sys/mman.h>
@@ -366,7 +367,8 @@ static int inflate_bgzf(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, s
 }
 
 // one ordinary member (the usual sample.fastq.gz), cut into chunks as described at the top
-static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t* n_out, int threads) {
+// *consumed = bytes of `gz` the member occupies (another member, or padding, may follow)
+static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t* n_out, size_t* consumed, int threads) {
     GzHeader h;
     if (!parse_gz_header(gz, n, h) || n < h.body + 8) return -1;
     const uint8_t* d = gz + h.body;           // the deflate stream ... and the trailer behind it, somewhere
@@ -392,6 +394,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
     // their place of the text and take their CRC-32.
     struct Link {  // what chunk i needs from its predecessors
         std::atomic<int> ready{0};
+        bool stop = false;             // the member ended in an earlier chunk: this one belongs to what follows it, its work is dropped
         size_t at = 0;                 // offset of the chunk's first byte in the text
         std::vector<uint8_t> hist;     // the MIRGE_GZ_WINDOW bytes in front of it (empty: the stream starts here)
     };
@@ -400,6 +403,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
     std::vector<uint32_t> crcs((size_t)C, 0);
     std::vector<size_t> n_sym((size_t)C, 0);
     uint64_t final_end_bit = 0;
+    int C_eff = -1;  // chunks of THIS member (the data may go on with another member: its chunks are found, decoded and dropped)
     std::atomic<int> failed{0}, next{0};
     auto worker = [&]() {
         SymBuf o;
@@ -419,16 +423,25 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
                     else if (pos == stop) { endb = pos; break; }
                     else if (pos > stop) st_i = -2;  // the next chunk's start was no block boundary of this stream
                 }
-                if (st_i < 0 || (st_i == 1) != (i == C - 1)) failed.store(1);
             }
-            // the hand-over happens even after a failure: nobody may wait for ever
+            // the hand-over happens whatever happened: nobody may wait for ever
             while (!link[(size_t)i].ready.load(std::memory_order_acquire)) std::this_thread::yield();
-            const bool ok = !failed.load();
             const Link& me = link[(size_t)i];
             Link& nx = link[(size_t)i + 1];
+            if (me.stop) {  // behind the member's end: not this member's business (a failure here is the next member's to find)
+                nx.stop = true;
+                nx.ready.store(1, std::memory_order_release);
+                continue;
+            }
+            if (st_i < 0 || (st_i == 0 && i == C - 1)) failed.store(1);  // malformed, or the data ended without a final block
+            const bool ok = !failed.load();
             nx.at = me.at + (ok ? no : 0);
             if (ok && nx.at > cap) failed.store(2);
-            if (ok && i + 1 < C) {
+            if (ok && st_i == 1) {  // the final block: the member ends here
+                C_eff = i + 1;
+                final_end_bit = endb;
+                nx.stop = true;
+            } else if (ok) {
                 nx.hist.assign(MIRGE_GZ_WINDOW, 0);
                 for (size_t k = 0; k < MIRGE_GZ_WINDOW; k++) {
                     // byte k of the next history = position (no - WINDOW + k) of this chunk, or of ITS history when the chunk is short
@@ -441,7 +454,6 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
                     } else if (!me.hist.empty()) nx.hist[k] = me.hist[(size_t)(MIRGE_GZ_WINDOW + q)];
                 }
             }
-            if (i == C - 1) final_end_bit = endb;
             n_sym[(size_t)i] = no;
             nx.ready.store(1, std::memory_order_release);
             if (failed.load()) continue;
@@ -471,28 +483,63 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
         for (auto& x : th) x.join();
     }
     if (failed.load() == 2) return -2;
-    if (failed.load()) return -1;
-    const size_t total = link[(size_t)C].at;
+    if (failed.load() || C_eff < 1) return -1;
+    const size_t total = link[(size_t)C_eff].at;
     // the trailer: CRC-32 and length (mod 2^32) behind the final block's last byte
     const size_t tr = (size_t)((final_end_bit + 7) / 8);
     if (tr + 8 > dn) return -1;
     const uint32_t want_crc = (uint32_t)d[tr] | ((uint32_t)d[tr + 1] << 8) | ((uint32_t)d[tr + 2] << 16) | ((uint32_t)d[tr + 3] << 24);
     const uint32_t want_len = (uint32_t)d[tr + 4] | ((uint32_t)d[tr + 5] << 8) | ((uint32_t)d[tr + 6] << 16) | ((uint32_t)d[tr + 7] << 24);
     if ((uint32_t)total != want_len) return -1;
-    if (tr + 8 != dn) return -4;  // something follows the member (another member, padding): the caller's general route
     uint32_t crc = crcs[0];
-    for (int i = 1; i < C; i++) crc = (uint32_t)crc32_combine(crc, crcs[(size_t)i], (z_off_t)n_sym[(size_t)i]);
+    for (int i = 1; i < C_eff; i++) crc = (uint32_t)crc32_combine(crc, crcs[(size_t)i], (z_off_t)n_sym[(size_t)i]);
     if (crc != want_crc) return -1;
     *n_out = total;
+    *consumed = h.body + tr + 8;
+    return 0;
+}
+
+// a member too small to cut (or one the search found no second block start in): zlib, on this thread
+static int inflate_member_serial(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t* n_out, size_t* consumed) {
+    GzHeader h;
+    if (!parse_gz_header(gz, n, h) || n < h.body + 8) return -1;
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) return -1;
+    size_t in_at = h.body, out_at = 0;
+    int rc = Z_OK;
+    while (rc == Z_OK) {  // zlib's counters are 32 bits wide: feed and drain in pieces
+        const size_t in_m = std::min<size_t>(n - in_at, (size_t)1 << 30), out_m = std::min<size_t>(cap - out_at, (size_t)1 << 30);
+        zs.next_in = const_cast<Bytef*>(gz + in_at); zs.avail_in = (uInt)in_m;
+        zs.next_out = out + out_at; zs.avail_out = (uInt)out_m;
+        rc = inflate(&zs, Z_NO_FLUSH);
+        in_at += in_m - zs.avail_in; out_at += out_m - zs.avail_out;
+        if (rc == Z_OK && zs.avail_out == 0 && out_at == cap) { inflateEnd(&zs); return -2; }
+        if (rc == Z_BUF_ERROR || (rc == Z_OK && in_m - zs.avail_in == 0 && out_m - zs.avail_out == 0)) break;
+    }
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || in_at + 8 > n) return -1;
+    const uint8_t* tr = gz + in_at;
+    const uint32_t want_crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+    const uint32_t want_len = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+    uint32_t c = 0;
+    for (size_t done = 0; done < out_at;) {
+        const size_t m = std::min<size_t>(out_at - done, (size_t)1 << 30);
+        c = (uint32_t)crc32(c, out + done, (uInt)m);
+        done += m;
+    }
+    if ((uint32_t)out_at != want_len || c != want_crc) return -1;
+    *n_out = out_at;
+    *consumed = in_at + 8;
     return 0;
 }
 
 }  // namespace mirge_gz
 
 // A whole .gz file's bytes -> its text, on `threads` host threads (0: all).  out[cap]; *n_out = bytes written.
-// 0: done, and verified against the CRC-32 / length the file carries.  Negative: not done -- the file is not of a kind this
-// route takes (several ordinary members, too small, not text), is damaged, or `cap` is too small (-2): the caller inflates it
-// the ordinary way, which also reports what is wrong with a damaged file.
+// 0: done, and every member verified against the CRC-32 / length it carries.  Negative: not done -- the file is not of a kind
+// this route takes (too small, not text), is damaged, or `cap` is too small (-2): the caller inflates it the ordinary way, which
+// also reports what is wrong with a damaged file.
 extern "C" int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads) {
     if (!gz || n_gz < 18 || !out || cap < 0 || !n_out) return fail(-1, "mirge_gz_inflate: bad argument");
     // (beyond ~64 threads nothing is gained: 82 chunks of a 10 M-read sample decode in 0.35 s on 16, 64 or 256 threads of a
@@ -508,8 +555,23 @@ extern "C" int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, i
     }
 #endif
     size_t n = 0;
-    const int rc = h.bgzf ? mirge_gz::inflate_bgzf(gz, (size_t)n_gz, out, (size_t)cap, &n, T)
-                          : mirge_gz::inflate_member_parallel(gz, (size_t)n_gz, out, (size_t)cap, &n, T);
+    int rc = 0;
+    if (h.bgzf) rc = mirge_gz::inflate_bgzf(gz, (size_t)n_gz, out, (size_t)cap, &n, T);
+    else {
+        // member after member (`cat lane1.fastq.gz lane2.fastq.gz > sample.fastq.gz` is how lanes are merged): the large ones cut
+        // and decoded in parallel, the small ones by zlib; zero padding behind the last is skipped, anything else is an error
+        size_t at = 0;
+        bool any_parallel = false;
+        while (rc == 0 && at < (size_t)n_gz) {
+            if (gz[at] == 0) { at++; continue; }
+            size_t got = 0, used = 0;
+            rc = mirge_gz::inflate_member_parallel(gz + at, (size_t)n_gz - at, out + n, (size_t)cap - n, &got, &used, T);
+            if (rc == 0) any_parallel = true;
+            else if (rc == -3) rc = mirge_gz::inflate_member_serial(gz + at, (size_t)n_gz - at, out + n, (size_t)cap - n, &got, &used);
+            if (rc == 0) { n += got; at += used; }
+        }
+        if (rc == 0 && !any_parallel) rc = -3;  // nothing here was worth the threads: the caller's streamed route does as well
+    }
     if (rc) return fail(rc, "mirge_gz_inflate: not inflated in parallel (code " + std::to_string(rc) + "): the serial route applies");
     *n_out = (int64_t)n;
     return 0;

@@ -252,9 +252,18 @@ int main(int argc, char** argv) {
             EXPECT(mirge_gz_inflate((const uint8_t*)bad.data(), (int64_t)bad.size(), out.data(), (int64_t)out.size(), &n, 4) != 0);
         }
         EXPECT(mirge_gz_inflate((const uint8_t*)gz.data(), (int64_t)gz.size() / 2, out.data(), (int64_t)out.size(), &n, 4) != 0);
-        const std::string two = gz + gz;
-        std::vector<uint8_t> out2(2 * text.size());
-        EXPECT(mirge_gz_inflate((const uint8_t*)two.data(), (int64_t)two.size(), out2.data(), (int64_t)out2.size(), &n, 4) != 0);
+        // several members (lanes merged with cat): a large one, a small one (zlib on this thread), an empty one, zero padding
+        const std::string small_t = fastq(300, 41), small_gz = gz_compress(small_t, 6, Z_DEFAULT_STRATEGY, 0), empty_gz = gz_compress(std::string(), 6, Z_DEFAULT_STRATEGY, 0);
+        const std::string multi = gz + small_gz + empty_gz + gz + std::string(64, '\0'), multi_t = text + small_t + text;
+        std::vector<uint8_t> out2(multi_t.size() + 1000);
+        EXPECT(mirge_gz_inflate((const uint8_t*)multi.data(), (int64_t)multi.size(), out2.data(), (int64_t)out2.size(), &n, 4) == 0);
+        EXPECT(n == (int64_t)multi_t.size() && std::memcmp(out2.data(), multi_t.data(), multi_t.size()) == 0);
+        EXPECT(mirge_gz_inflate((const uint8_t*)multi.data(), (int64_t)multi.size(), out2.data(), (int64_t)multi_t.size() - 5, &n, 4) != 0);  // too little room
+        std::string junk = gz + "garbage behind the member";
+        EXPECT(mirge_gz_inflate((const uint8_t*)junk.data(), (int64_t)junk.size(), out2.data(), (int64_t)out2.size(), &n, 4) != 0);
+        std::string badsmall = gz + small_gz;
+        badsmall[gz.size() + small_gz.size() / 2] ^= 0x10;
+        EXPECT(mirge_gz_inflate((const uint8_t*)badsmall.data(), (int64_t)badsmall.size(), out2.data(), (int64_t)out2.size(), &n, 4) != 0);
         EXPECT(mirge_gz_inflate((const uint8_t*)gz.data(), (int64_t)gz.size(), out.data(), (int64_t)text.size() - 1, &n, 4) != 0);
         EXPECT(mirge_gz_inflate((const uint8_t*)"not a gzip file at all, no", 26, out.data(), 100, &n, 4) != 0);
         // BGZF: members of <= 64 KiB that carry their size in an extra field, an empty one at the end

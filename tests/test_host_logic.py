@@ -273,8 +273,9 @@ def test_read_texts_keeps_file_order_and_inflates_gz(tmp_path):
 
 def test_gz_inflate_on_all_cores_equals_zlib(tmp_path):
     """mirge_gz_inflate (csrc/native_gz.hpp; host only -- no GPU involved): a sample.fastq.gz of a few MB comes back byte for byte
-    as zlib inflates it, through `_ffi.gz_inflate` and through `collapse.read_text`; what the route does not take -- a file of two
-    members, a small file, a damaged one -- comes back as None / goes to the streamed zlib route, which reports the damage."""
+    as zlib inflates it, through `_ffi.gz_inflate` and through `collapse.read_text`, also a file of several members (lanes merged
+    with cat); what the route does not take -- a small file, a damaged one -- comes back as None / goes to the streamed zlib
+    route, which reports the damage."""
     import gzip
     import zlib
     from mirge3_amd import _ffi, collapse
@@ -296,11 +297,20 @@ def test_gz_inflate_on_all_cores_equals_zlib(tmp_path):
     del collapse.GZ_LOG[:]
     rt = collapse.read_text(str(p1), stream=True)
     assert isinstance(rt, np.ndarray) and rt.tobytes() == text and collapse.GZ_LOG and collapse.GZ_LOG[0]["text_MB"] == round(len(text) / 1e6, 1)
+    # lanes merged with `cat`: a large member, a small one (zlib's), an empty one, a large one, zero padding
     two = tmp_path / "T.fastq.gz"
-    two.write_bytes(gzip.compress(text[: len(text) // 2], 6) + gzip.compress(text[len(text) // 2:], 6))
-    assert _ffi.gz_inflate(two.read_bytes()) is None
-    st = collapse.read_text(str(two), stream=True)
-    assert isinstance(st, collapse.GzipRecordStream) and b"".join(st) == text
+    two.write_bytes(gzip.compress(text, 6) + gzip.compress(text[:5000], 6) + gzip.compress(b"", 6) + gzip.compress(text, 9) + b"\0" * 512)
+    got = _ffi.gz_inflate(two.read_bytes())
+    assert got is not None and got.tobytes() == text + text[:5000] + text
+    rt2 = collapse.read_text(str(two), stream=True)
+    assert isinstance(rt2, np.ndarray) and rt2.tobytes() == text + text[:5000] + text
+    os.environ["MIRGE_GZ_PARALLEL"] = "0"
+    try:
+        st = collapse.read_text(str(two), stream=True)
+        assert isinstance(st, collapse.GzipRecordStream) and b"".join(st) == text + text[:5000] + text
+    finally:
+        os.environ.pop("MIRGE_GZ_PARALLEL")
+    assert _ffi.gz_inflate(p1.read_bytes() + b"junk behind the member") is None
     assert _ffi.gz_inflate(gzip.compress(text[:100000], 6)) is None  # too small to cut
     bad = bytearray(p1.read_bytes())
     bad[len(bad) // 2] ^= 4
