@@ -116,7 +116,7 @@ def pmc_traffic(args, rec_name):
         cmd = [sys.executable, rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--pmc", "0",
                "--min-seconds", "0", "--spinup", "0", "--cli-path", "0", "--two-in-flight", "0",
-               "--reads", str(args.reads), "--scale", args.scale, "--workload", args.workload]
+               "--reads", str(args.reads), "--scale", args.scale, "--workload", args.workload, "--pool", str(args.pool)]
         try:
             subprocess.run(cmd, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
@@ -792,7 +792,8 @@ def main():
                 "M_reads_per_s": round(args.reads / two / 1e6, 1), "ms_per_sample": round(two * 1e3, 4),
                 "one_at_a_time_ms": round(one * 1e3, 4), "speedup": round(one / two, 3), "steps_each": K2,
                 "note": "two contexts (two sets of HIP streams, two host threads) step the same workload side by side on the one "
-                        "GPU: throughput of a batch of samples per GPU; `value` stays one sample at a time"}
+                        "GPU: what a batch of samples per GPU would gain from it -- nothing since round 3 (a single sample's step "
+                        "already runs on five streams; round 2 measured 1.09-1.14 x); `value` is one sample at a time"}
             raw2.close(); casc2.close(); ctx2.close()
         except Exception as e:  # noqa: BLE001
             out["two_samples_in_flight"] = {"error": repr(e)[:300]}
