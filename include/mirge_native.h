@@ -92,7 +92,9 @@ int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, 
 /* The same from the FILE's text, parsed on the device: replaces dnaio's record parsing and the length filter of the
  * per-chunk worker (digest.py:320-375, --minimum-length :348,368).  format: 1 FASTQ (4-line records), 2 FASTA (one
  * sequence line per record), 3 one sequence per line, 0 = by the first byte.  *n_records = records seen before the
- * filter (`count`, digest.py:326).  Reads come out in file order. */
+ * filter (`count`, digest.py:326).  Reads come out in file order.  A read may be up to 65 535 nt (the reference has no upper
+ * bound -- parse.py:102 `-M` is never read, digest.py:348,368 test the minimum only --; reads beyond 255 nt take kernels written
+ * for any length, csrc/kernels_long.hpp); a longer one is refused (-6). */
 int mirge_reads_parse(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                       mirge_reads** out, int64_t* n_records);
 /* 1 when some read of the set held an IUPAC ambiguity code other than N: such a base is packed -- and later printed --

@@ -5,7 +5,8 @@
 // Layout (DESIGN.md "Data layout in HBM"):
 //   * a base is 2 bits, A=0 C=1 G=2 T=3; base j of a sequence sits at bits [2j, 2j+1] of
 //     word j/32 (little-endian inside a u64), so "the first k bases" is a low-bit mask;
-//   * reads live in width groups W in {1,2,4,8} words (<=31, <=64, <=128, <=255 nt), structure of
+//   * reads live in width groups W in {1,2,4,8} words (<=31, <=64, <=128, <=255 nt; longer reads: the long class of
+//     kernels_long.hpp, W words with W set per read set and the length in 16 bits), structure of
 //     arrays, word-major: seq[w*n + i]; len[i] (u8); nmask[w*n + i] (bit 2j set = base j is
 //     an ambiguous call, its 2-bit code is 0) or nullptr when the group has no N;
 //   * a library is ONE concatenated 2-bit string T with one separator base after every
@@ -27,7 +28,7 @@
 #ifndef MIRGE_K_OVERSAMPLE
 #define MIRGE_K_OVERSAMPLE 4   // 4^K >= this x the library's positions
 #endif
-#define MIRGE_MAX_READ_LEN 255   // four width classes of 1 / 2 / 4 / 8 words; the length is stored in a byte
+#define MIRGE_MAX_READ_LEN 255   // the four TEMPLATED width classes of 1 / 2 / 4 / 8 words, whose length is a byte (longer: kernels_long.hpp)
 #define MIRGE_NO_HIT 0xFFFFFFFFFFFFFFFFull
 
 // Cascade policy of one pass: the restated bowtie-1 argument string
