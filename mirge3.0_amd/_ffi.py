@@ -153,7 +153,10 @@ def gz_inflate(data, threads: int = 0) -> Optional[np.ndarray]:
     cap = max(isize, 12 * buf.size) + 65536
     if cap > (1 << 37):
         return None
-    out = np.empty(cap, dtype=np.uint8)
+    try:
+        out = np.empty(cap, dtype=np.uint8)
+    except MemoryError:  # (a host that does not overcommit): the streamed route needs pieces only
+        return None
     n = C.c_int64(0)
     rc = load().mirge_gz_inflate(_p(buf), C.c_int64(buf.size), _p(out), C.c_int64(cap), C.byref(n), C.c_int32(threads))
     if rc != 0:

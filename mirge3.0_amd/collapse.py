@@ -223,10 +223,14 @@ def read_text(path: str, stream: bool = False):
         # search, verified against the file's CRC-32); it declines what it is not made for -- small files, several ordinary
         # members, anything that is not text -- and those are inflated by zlib, piece by piece beside the parse (stream) or whole
         data = None
-        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and _os.path.getsize(path) >= (2 << 20):
+        # (up to 1 GiB of compressed data: the parser takes a whole text of less than 8 GiB -- mirge_reads_parse -- and a larger
+        # sample is better off streamed in pieces anyway, which bounds the host memory it takes)
+        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and (2 << 20) <= _os.path.getsize(path) <= (1 << 30):
             t0 = time.perf_counter()
             raw = np.fromfile(path, dtype=np.uint8)
             data = _ffi.gz_inflate(raw)
+            if data is not None and data.size >= (7 << 30):
+                data = None
             if data is not None:
                 GZ_LOG.append({"path": str(path), "gz_MB": round(raw.size / 1e6, 1), "text_MB": round(data.size / 1e6, 1),
                                "parallel_inflate_s": round(time.perf_counter() - t0, 4)})
