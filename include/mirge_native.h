@@ -57,6 +57,8 @@ const char* mirge_last_error(void);
 int mirge_device_count(void);
 /* hip_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private one */
 int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out);
+/* Ownership: libraries, read sets and results hold device blocks of the context they were made in -- destroy them BEFORE the
+   context (the ctypes binding does that by itself: closing a Context closes what still lives in it). */
 void mirge_ctx_destroy(mirge_ctx* ctx);
 int mirge_ctx_sync(mirge_ctx* ctx);
 

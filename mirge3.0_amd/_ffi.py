@@ -178,6 +178,14 @@ class Context:
 
     def close(self):
         if self._h:
+            # whatever still lives in this context goes first -- results, read sets, libraries: their device blocks belong to the
+            # context's pool, and a handle destroyed after its context (a reference kept by a traceback, a cycle the collector
+            # reaches late) would free into released memory
+            objs = [o for o in (r() for r in _live) if o is not None and getattr(o, "ctx", None) is self]
+            for kind in (CascadeResult, DeviceReads, DeviceLibrary):
+                for o in objs:
+                    if isinstance(o, kind):
+                        o.close()
             load().mirge_ctx_destroy(self._h)
             self._h = C.c_void_p()
 

@@ -1881,6 +1881,104 @@ def test_trimming_300_cycle_lines_and_every_adapter_length(ctx):
         assert got == list(want.items()), m
 
 
+def test_trimmed_and_umi_sliced_reads_beyond_255_nt(ctx, tmp_path):
+    """What is left of a line after trimming -- or after the UMIs are cut off -- may be longer than 255 nt (a merged pair, a 2 x 300
+    run with its adapter at the very end): those reads go to the long read class instead of stopping the run.
+    Lines of 270-700 characters: insert of 200-600 nt, adapter (exact, one substitution, one deletion), read-through or none, low
+    quality at either end, duplicates; k_trim and the UMI slicing against the oracle's restatements."""
+    rng = np.random.default_rng(255)
+    ad = "TGGAATTCTCGGGTGCCAAGGAACTCCAG"
+    inserts = ["".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(L))) for L in rng.choice([200, 250, 255, 256, 257, 300, 420, 600], size=90)]
+    recs = []
+    for i in range(1400):
+        ins = inserts[int(rng.integers(0, len(inserts)))]
+        a = list(ad)
+        kind = int(rng.integers(0, 7))
+        if kind == 1:
+            a[int(rng.integers(0, len(a)))] = "ACGT"[int(rng.integers(0, 4))]
+        elif kind == 2:
+            del a[int(rng.integers(1, len(a) - 1))]
+        tail = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(0, 80))))
+        seq = ins if kind == 3 else (ins + "".join(a)[:int(rng.integers(2, 12))] if kind == 4 else ins + "".join(a) + tail)
+        q = np.full(len(seq), ord("I"), dtype=np.uint8)
+        if rng.random() < 0.3:
+            k = int(rng.integers(1, 40))
+            q[-k:] = rng.integers(33, 48, size=k)
+        if rng.random() < 0.1:
+            q[:int(rng.integers(1, 6))] = 35
+        recs.append((seq, q.tobytes().decode()))
+    text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+    for opts in (dict(adapter=ad, q_back=10), dict(adapter=ad, q_back=20, q_front=8, cut=[3, -2]), dict(q_back=15)):
+        for per_modifier in (False, True):
+            trim = _ffi.MirgeTrim.make(adapter=opts.get("adapter"), quality_back=opts["q_back"], quality_front=opts.get("q_front", 0),
+                                       cut=opts.get("cut", []), count_per_modifier=per_modifier)
+            raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 16, trim)
+            assert n_rec == len(recs)
+            gc = raw.group_counts()
+            uniq = raw.collapse()
+            cnt, first = uniq.counts()
+            seqs = uniq.unpack().to_list()
+            order = np.argsort(first, kind="stable")
+            got = [(seqs[i], int(cnt[i, 0])) for i in order]
+            want = oracle.trimmed_counts(recs, dict(opts), 16, per_modifier)
+            assert got == list(want.items())
+            n_long = sum(c for q_, c in want.items() if len(q_) > 255)
+            assert n_long > 300 and int(gc[4] + gc[9]) == n_long and sum(c for q_, c in want.items() if len(q_) <= 255) > 100
+            uniq.close(); raw.close()
+    # -umi 5,3 [-udd] on the same kind of lines: [5 nt] insert [3 nt] adapter
+    umis = ["".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=8)) for _ in range(7)]
+    urecs = []
+    for i in range(1200):
+        ins = inserts[int(rng.integers(0, 40))]
+        u = umis[int(rng.integers(0, len(umis)))]
+        seq = u[:5] + ins + u[5:] + ad + "ACGTAC"[:int(rng.integers(0, 7))]
+        q = np.full(len(seq), ord("I"), dtype=np.uint8)
+        if rng.random() < 0.2:
+            q[-int(rng.integers(1, 10)):] = 34
+        urecs.append((seq, q.tobytes().decode()))
+    utext = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(urecs)).encode()
+    for dedup in (False, True):
+        trim = _ffi.MirgeTrim.make(adapter=ad, quality_back=10, count_per_modifier=False)
+        got, n, n_rec, csv = _umi_dict(ctx, utext, 1, 16, trim, _ffi.MirgeUmi.make(5, 3, dedup=dedup), tmp_path, f"long{int(dedup)}")
+        keys = oracle.umi_worker_reads(urecs, dict(q_back=10, q_front=0, adapter=ad), 5, 3, 16, False, False)
+        want, trimmed, rows = oracle.umi_baking(keys, 5, 3, 16, dedup)
+        assert n_rec == len(urecs) and n == trimmed and got == want
+        assert sum(len(k) > 255 for k, _ in want) > 10 and csv == ("".join(rows) if dedup else None)
+
+
+def test_handles_outliving_their_context_do_not_crash(tmp_path):
+    """A read set, a result or a library still referenced when its context is closed (a traceback holds it, the collector comes
+    late) is closed with the context; its own close / finalizer afterwards is a no-op.  Found as a segmentation fault at the end of
+    a pytest run whose failing test had left two read sets open.  In a child process: a regression would take the suite down."""
+    import subprocess
+    import sys
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import mirge3_amd as m\n"
+        "from mirge3_amd import _ffi, synth\n"
+        "from mirge3_amd.cascade import Cascade\n"
+        "from mirge3_amd.seqio import FlatSeqs\n"
+        "ctx = _ffi.Context(0)\n"
+        "sl = synth.make_libraries(seed=3, scale='ci')\n"
+        "casc = Cascade(ctx, sl.libs)\n"
+        "raw = _ffi.DeviceReads.pack(ctx, synth.make_reads(sl, 5000, seed=1))\n"
+        "uniq = raw.collapse()\n"
+        "res = casc.run(uniq)\n"
+        "n = len(uniq)\n"
+        "ctx.close()\n"
+        "for o in (res, uniq, raw): o.close()\n"
+        "del res, uniq, raw, casc\n"
+        "import gc; gc.collect()\n"
+        "ctx2 = _ffi.Context(0)\n"
+        "r2 = _ffi.DeviceReads.pack(ctx2, FlatSeqs.from_list(['ACGTACGTACGTACGTACGT'] * 3))\n"
+        "assert len(r2.collapse()) == 1\n"
+        "print('alive', n)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "alive" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+
+
 def test_cli_with_adapter_trimming_end_to_end(tmp_path):
     """`-a illumina` end to end: golden case 1's reads with the adapter appended and cut at 50 nt come out as the
     reference's tables when the fully trimmed read is counted once (--trim-count once)."""
