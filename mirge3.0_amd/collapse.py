@@ -65,6 +65,8 @@ def read_fastq_sequences(path: str) -> FlatSeqs:
 
 import os as _os
 GZ_PIECE_BYTES = int(_os.environ.get("MIRGE_GZ_PIECE_BYTES", 8 << 20))   # text handed to the parser per piece of a streamed .fastq.gz
+# a text of this size or more is parsed in parts of this size (mirge_reads_parse takes less than 8 GiB at a time; tests lower it)
+TEXT_PIECE_BYTES = int(_os.environ.get("MIRGE_TEXT_PIECE_BYTES", str(2 << 30)))
 GZ_QUEUE_DEPTH = 4         # inflated pieces waiting for the GPU (bounds the memory of a stream: ~ depth x piece)
 GZ_LOG: List[dict] = []    # one entry per .gz file inflated by mirge_gz_inflate (read_text): what a run reports as its input stage
 
@@ -213,6 +215,68 @@ class GzipRecordStream:
         return unwrap_fasta(data) if data[:1] == b">" else data
 
 
+class TextRecordStream:
+    """A FASTQ text already in host memory (a memory-mapped file, an inflated ``.gz``) as pieces of whole 4-line records: what a
+    text too large for ONE ``mirge_reads_parse`` call -- 8 GiB, some 150 M reads -- is passed as.  Same protocol as
+    ``GzipRecordStream`` (iterate, ``close``, ``whole_text``, the timing fields)."""
+
+    def __init__(self, data, piece_bytes: int = None):
+        self.data = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
+        self.piece_bytes = int(piece_bytes or TEXT_PIECE_BYTES)
+        self.inflate_s = 0.0
+        self.text_bytes = 0
+        self.pieces = 0
+
+    def _newlines(self, a: int, b: int) -> int:
+        """line ends in data[a:b], counted 64 MB at a time on a few threads (numpy releases the GIL inside the comparison)"""
+        from concurrent.futures import ThreadPoolExecutor
+        step = 64 << 20
+        spans = [(x, min(b, x + step)) for x in range(a, b, step)]
+        if len(spans) <= 1:
+            return int(np.count_nonzero(self.data[a:b] == 10))
+        with ThreadPoolExecutor(max_workers=min(8, len(spans))) as pool:
+            return int(sum(pool.map(lambda ab: int(np.count_nonzero(self.data[ab[0]:ab[1]] == 10)), spans)))
+
+    def _cut(self, a: int, b: int) -> int:
+        """the largest e <= b such that data[a:e] is a whole number of 4-line records (a: none fits)"""
+        drop = self._newlines(a, b) % 4  # lines to give back, besides the partial one at the end
+        e = b
+        for _ in range(drop + 1):
+            # the last line end in front of e (searched in growing windows from the back: lines are short)
+            w, found = 1 << 16, -1
+            while found < 0 and e > a:
+                lo = max(a, e - w)
+                hits = np.flatnonzero(self.data[lo:e] == 10)
+                if hits.size:
+                    found = lo + int(hits[-1])
+                elif lo == a:
+                    return a
+                w *= 16
+            if found < 0:
+                return a
+            e = found  # exclusive: the next search looks in front of this line end
+        return e + 1
+
+    def __iter__(self):
+        n, at = int(self.data.size), 0
+        while at < n:
+            end = min(n, at + self.piece_bytes)
+            if end < n:
+                end = self._cut(at, end)
+                if end <= at:
+                    raise RuntimeError(f"a FASTQ record longer than {self.piece_bytes} bytes: not a text this parser takes in parts")
+            self.text_bytes += end - at
+            self.pieces += 1
+            yield self.data[at:end]
+            at = end
+
+    def close(self):
+        pass
+
+    def whole_text(self):
+        return self.data
+
+
 def read_text(path: str, stream: bool = False):
     """The file's bytes for the device-side parser (``mirge_reads_parse``): memory-mapped when plain; a ``.gz`` inflated whole,
     or -- ``stream=True`` -- as a ``GzipRecordStream`` whose worker has already started.  A FASTA whose sequences are wrapped
@@ -223,14 +287,14 @@ def read_text(path: str, stream: bool = False):
         # search, verified against the file's CRC-32); it declines what it is not made for -- small files, several ordinary
         # members, anything that is not text -- and those are inflated by zlib, piece by piece beside the parse (stream) or whole
         data = None
-        # (up to 1 GiB of compressed data: the parser takes a whole text of less than 8 GiB -- mirge_reads_parse -- and a larger
-        # sample is better off streamed in pieces anyway, which bounds the host memory it takes)
-        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and (2 << 20) <= _os.path.getsize(path) <= (1 << 30):
+        # (up to 8 GiB of compressed data -- the text is held whole in host memory, some 6 x that; beyond, the streamed route's
+        # few pieces bound the memory a sample takes)
+        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and (2 << 20) <= _os.path.getsize(path) <= (8 << 30):
             t0 = time.perf_counter()
             raw = np.fromfile(path, dtype=np.uint8)
             data = _ffi.gz_inflate(raw)
-            if data is not None and data.size >= (7 << 30):
-                data = None
+            if data is not None and data.size >= 3 * TEXT_PIECE_BYTES and not (stream and bytes(data[:1]) == b"@"):
+                data = None  # too large for one parse call and nobody to take it in parts: as before
             if data is not None:
                 GZ_LOG.append({"path": str(path), "gz_MB": round(raw.size / 1e6, 1), "text_MB": round(data.size / 1e6, 1),
                                "parallel_inflate_s": round(time.perf_counter() - t0, 4)})
@@ -247,6 +311,9 @@ def read_text(path: str, stream: bool = False):
         data = np.memmap(path, dtype=np.uint8, mode="r")  # the pages go from the page cache to the GPU: no read() copy
     if bytes(data[:1]) == b">":
         data = unwrap_fasta(bytes(data))
+    elif stream and len(data) >= 3 * TEXT_PIECE_BYTES and bytes(data[:1]) == b"@":
+        # mirge_reads_parse takes less than 8 GiB at a time (it says so itself): a larger FASTQ goes in parts of whole records
+        return TextRecordStream(data)
     return data
 
 
@@ -458,7 +525,7 @@ def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None,
     filter and -- with ``umi`` -- the reference's UMI handling, all on the GPU (``mirge_reads_parse[_trim|_umi]``).
     With ``-udd`` also writes ``<name>_umiCounts.csv``.  ``text`` may be a ``GzipRecordStream``: its pieces are uploaded and
     parsed one by one while the next ones inflate, and appended on the device (``mirge_reads_concat``: file order kept)."""
-    if isinstance(text, GzipRecordStream):
+    if isinstance(text, (GzipRecordStream, TextRecordStream)):
         if umi is not None:  # the UMI routes look at the whole sample (a collapse inside): not streamed
             text = text.whole_text()
         else:

@@ -2162,6 +2162,13 @@ def test_streamed_gz_equals_the_plain_file(ctx, ci_libs, tmp_path):
             assert np.array_equal(f1[o1], f2[o2]) and np.array_equal(c1[o1], c2[o2])
             for h in (u1, u2, got):
                 h.close()
+        # the plain text in parts of whole records (collapse.TextRecordStream: how a text of 8 GiB or more is parsed)
+        for piece in (900, 200_000):
+            tm = {}
+            got, n_got = collapse.parse_sample(ctx, collapse.TextRecordStream(np.memmap(plain, dtype=np.uint8, mode="r"), piece), 16, trim, None, timings=tm)
+            assert n_got == n_want and got.unpack().to_list() == want.unpack().to_list() and np.array_equal(got.group_counts(), want.group_counts())
+            assert tm["gz_pieces"] >= len(text) // piece
+            got.close()
         want.close()
     umi = _ffi.MirgeUmi.make(4, 2)
     a, na = collapse.parse_sample(ctx, collapse.read_text(str(plain)), 16, trims[1], umi)
@@ -2178,13 +2185,15 @@ def test_streamed_gz_equals_the_plain_file(ctx, ci_libs, tmp_path):
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    for tag, fl, env in (("plain", files, {}), ("gz", [str(zp), files[1]], {"MIRGE_GZ_PIECE_BYTES": "2000"})):
+    for tag, fl, env in (("plain", files, {}), ("gz", [str(zp), files[1]], {"MIRGE_GZ_PIECE_BYTES": "2000"}),
+                         ("parts", files, {"MIRGE_TEXT_PIECE_BYTES": "3000"})):  # every text of 9 kB or more in parts of 3 kB
         cmd = [sys.executable, "-c", "import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()" % root,
                "-s", ",".join(fl), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", tag, "-shh"]
         r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
     for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "annotation.report.csv"):
         assert (tmp_path / "gz" / f).read_text() == (tmp_path / "plain" / f).read_text(), f
+        assert (tmp_path / "parts" / f).read_text() == (tmp_path / "plain" / f).read_text(), f
         # (the golden report counts the reads below --minimum-length too, which _case_fastqs does not write back)
         assert f == "annotation.report.csv" or (tmp_path / "gz" / f).read_text() == case.text(f), f
 

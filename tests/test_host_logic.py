@@ -332,6 +332,53 @@ def test_unpinned_trimming_options_are_named():
     assert len(got) == 6 and any("two adapters" in g for g in got) and any("--no-indels" in g for g in got)
 
 
+def test_text_record_stream(tmp_path, monkeypatch):
+    """collapse.TextRecordStream: a FASTQ text in memory (bytes, an array, a memory-mapped file) as pieces of whole 4-line records --
+    how a text of 8 GiB or more reaches mirge_reads_parse, which takes less at a time.  Every piece size: the pieces are the text,
+    each ends a record; quality lines that start with '@' or '+' do not mislead the cut (records are counted, not guessed); a text
+    without a final newline; a record longer than a piece raises; read_text hands such a stream out only for FASTQ, only when the
+    caller streams, only beyond the size one call takes."""
+    from mirge3_amd import collapse
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(20000):
+        L = int(rng.integers(16, 60))
+        q = "".join(chr(c) for c in rng.integers(33, 75, L))
+        if i % 5 == 0:
+            q = "@" + q[1:]
+        if i % 7 == 0:
+            q = "+" + q[1:]
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[x] for x in rng.integers(0, 4, L)), q))
+    text = "".join(recs).encode()
+    starts = set(np.cumsum([0] + [len(r) for r in recs]).tolist())
+    plain = tmp_path / "a.fastq"
+    plain.write_bytes(text)
+    for data, want in ((text, text), (np.frombuffer(text, np.uint8), text), (np.memmap(plain, dtype=np.uint8, mode="r"), text), (text[:-1], text[:-1])):
+        for piece in (300, 4096, 70000, 1 << 20, 1 << 30):
+            st = collapse.TextRecordStream(data, piece_bytes=piece)
+            pieces = [bytes(p_) for p_ in st]
+            assert b"".join(pieces) == want and st.text_bytes == len(want) and st.pieces == len(pieces)
+            at = 0
+            for q in pieces:
+                assert at in starts and len(q) <= piece
+                at += len(q)
+            assert len(pieces) >= min(len(want) // piece, 1) and (piece < (1 << 20) or len(pieces) == (2 if piece == 1 << 20 else 1))
+    with pytest.raises(RuntimeError, match="record longer"):
+        list(collapse.TextRecordStream(text, piece_bytes=40))
+    assert list(collapse.TextRecordStream(b"")) == []
+    assert bytes(collapse.TextRecordStream(text).whole_text()) == text
+    # read_text: the stream only where it is needed
+    monkeypatch.setattr(collapse, "TEXT_PIECE_BYTES", 100000)
+    st = collapse.read_text(str(plain), stream=True)
+    assert isinstance(st, collapse.TextRecordStream) and b"".join(bytes(p_) for p_ in st) == text and st.pieces > 10
+    assert not isinstance(collapse.read_text(str(plain), stream=False), collapse.TextRecordStream)
+    fa = tmp_path / "a.fa"
+    fa.write_bytes(b"".join(b">s%d\n%s\n" % (i, b"ACGT" * 8) for i in range(20000)))
+    assert not isinstance(collapse.read_text(str(fa), stream=True), collapse.TextRecordStream)
+    monkeypatch.setattr(collapse, "TEXT_PIECE_BYTES", 2 << 30)
+    assert not isinstance(collapse.read_text(str(plain), stream=True), collapse.TextRecordStream)
+
+
 def test_gzip_record_stream(tmp_path):
     """collapse.GzipRecordStream: a .fastq.gz comes out as pieces that are whole 4-line records, in order, byte for byte the
     file's text -- whatever the piece size, for one member, several members (bgzip / cat), an empty member and zero padding
