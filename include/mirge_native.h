@@ -87,6 +87,11 @@ int mirge_lib_prepare(mirge_lib* lib, int32_t k);
  * a BGZF file member by member.  out[cap]; 0 = done and verified against the file's own CRC-32 and length; negative = not
  * taken by this route (several ordinary members, too small, not text, damaged, cap too small): inflate it serially. */
 int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads);
+/* the same; while it runs `*progress` (may be NULL) is advanced to the number of leading bytes of `out` that are final, so that a
+ * second thread can upload and parse whole records of that prefix beside the inflation (the reference's reader hands chunks to its
+ * workers while xopen's threads inflate, digest.py:136-140).  The CRC-32 is verified at the end: on a negative return whatever was
+ * read ahead must be dropped. */
+int mirge_gz_inflate_progress(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads, int64_t* progress);
 
 /* ---- reads: replaces writing bwtInput.fasta (manifoldAlign.py:92-95) / dnaio parsing ---- */
 int mirge_reads_pack(mirge_ctx* ctx, const char* ascii, const int64_t* offsets, int64_t n,

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("MIRGE_NATIVE_SO") or os.path.join(_HERE, "csrc", "libmirge_native.so")
 
 EXPORTS = [
-    "mirge_last_error", "mirge_device_count", "mirge_gz_inflate", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
+    "mirge_last_error", "mirge_device_count", "mirge_gz_inflate", "mirge_gz_inflate_progress", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_create_packed", "mirge_lib_packed_sizes", "mirge_lib_packed_copy", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_group_counts", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
@@ -162,6 +162,79 @@ def gz_inflate(data, threads: int = 0) -> Optional[np.ndarray]:
     if rc != 0:
         return None
     return out[: n.value]
+
+
+# The text buffer of the last finished GzInflation, kept for the next one: a fresh buffer costs a sample its page faults while it
+# inflates (the inflater's floor, profiles/README.md round 4) and an munmap of half a gigabyte when it is dropped -- 0.03-0.05 s of
+# a 0.15 s sample.  One buffer, at most MIRGE_GZ_KEEP_BYTES (default 16 GiB of address space; what a sample touched stays resident).
+_gz_kept: list = []
+_GZ_KEEP_BYTES = int(os.environ.get("MIRGE_GZ_KEEP_BYTES", str(16 << 30)))
+
+
+class GzInflation:
+    """``mirge_gz_inflate_progress`` running on a thread of its own: ``out[:done()]`` is text that will not change any more, whole
+    before ``wait()`` returns -- True when the file was inflated and its CRC-32 matched, False when this route does not take the
+    file (then whatever was read ahead must be dropped and the file inflated the serial way)."""
+
+    def __init__(self, data, threads: int = 0):
+        import threading
+        self.buf = data if isinstance(data, np.ndarray) else np.frombuffer(data, dtype=np.uint8)
+        self.out = None
+        self.ok = None
+        self._n = C.c_int64(0)
+        self._progress = C.c_int64(0)
+        self._thread = None
+        if self.buf.size < 18:
+            self.ok = False
+            return
+        isize = int.from_bytes(bytes(self.buf[-4:]), "little")
+        cap = max(isize, 12 * int(self.buf.size)) + 65536  # (see gz_inflate)
+        if cap > (1 << 37):
+            self.ok = False
+            return
+        kept = _gz_kept.pop() if _gz_kept else None
+        if kept is not None and kept.size >= cap:
+            self.out = kept
+            cap = int(kept.size)
+        else:
+            del kept
+            try:
+                self.out = np.empty(cap, dtype=np.uint8)
+            except MemoryError:
+                self.ok = False
+                return
+        lib = load()
+
+        def run():
+            rc = lib.mirge_gz_inflate_progress(_p(self.buf), C.c_int64(self.buf.size), _p(self.out), C.c_int64(cap), C.byref(self._n),
+                                               C.c_int32(threads), C.byref(self._progress))
+            self.ok = rc == 0
+
+        self._thread = threading.Thread(target=run, name="mirge-gz-inflate", daemon=True)
+        self._thread.start()
+
+    def done(self) -> int:
+        """bytes of ``out`` that are final so far"""
+        return int(self._progress.value)
+
+    def running(self) -> bool:
+        return self._thread is not None and self._thread.is_alive()
+
+    def wait(self) -> bool:
+        if self._thread is not None:
+            self._thread.join()
+        return bool(self.ok)
+
+    def text(self) -> np.ndarray:
+        """the whole text (after ``wait()`` returned True)"""
+        return self.out[: self._n.value]
+
+    def release(self):
+        """the caller is done with ``out`` and every view of it: the buffer is kept for the next inflation"""
+        self.wait()
+        out, self.out = self.out, None
+        if out is not None and out.size <= _GZ_KEEP_BYTES and not _gz_kept:
+            _gz_kept.append(out)
 
 
 class Context:

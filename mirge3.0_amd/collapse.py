@@ -67,6 +67,7 @@ import os as _os
 GZ_PIECE_BYTES = int(_os.environ.get("MIRGE_GZ_PIECE_BYTES", 8 << 20))   # text handed to the parser per piece of a streamed .fastq.gz
 # a text of this size or more is parsed in parts of this size (mirge_reads_parse takes less than 8 GiB at a time; tests lower it)
 TEXT_PIECE_BYTES = int(_os.environ.get("MIRGE_TEXT_PIECE_BYTES", str(2 << 30)))
+GZ_AHEAD_PIECE_BYTES = int(_os.environ.get("MIRGE_GZ_AHEAD_PIECE_BYTES", str(48 << 20)))  # text parsed at a time beside a parallel inflation
 GZ_QUEUE_DEPTH = 4         # inflated pieces waiting for the GPU (bounds the memory of a stream: ~ depth x piece)
 GZ_LOG: List[dict] = []    # one entry per .gz file inflated by mirge_gz_inflate (read_text): what a run reports as its input stage
 
@@ -277,6 +278,108 @@ class TextRecordStream:
         return self.data
 
 
+class GzRouteDeclined(Exception):
+    """mirge_gz_inflate did not take the file (or its CRC-32 did not match): what was parsed ahead is dropped, zlib takes over"""
+
+
+def record_cut(data: np.ndarray, at: int, end: int) -> int:
+    """The largest e in (at, end] where a FASTQ record starts (data[at] starts one), found from the text alone: a line that starts
+    with '@' and whose second successor starts with '+' is a header -- a quality line may start with '@', but two lines behind a
+    quality line stands a sequence, and sequences are letters.  ``at`` when no such line lies in data[at:end]."""
+    w = 1 << 18
+    while True:
+        lo = max(at, end - w)
+        starts = np.flatnonzero(data[lo:end] == 10) + (lo + 1)
+        if lo == at:
+            starts = np.concatenate(([at], starts))
+        starts = starts[starts < end]
+        if starts.size >= 3:
+            ok = (data[starts[:-2]] == 64) & (data[starts[2:]] == 43)
+            hit = np.flatnonzero(ok)
+            if hit.size and int(starts[hit[-1]]) > at:
+                return int(starts[hit[-1]])
+        if lo == at:
+            return at
+        w *= 8
+
+
+class ParallelGzipStream:
+    """A ``.fastq.gz`` inflated on all host cores (``mirge_gz_inflate_progress`` on a thread of its own) WHILE the caller uploads
+    and parses the part of the text that is already final: pieces of whole records, cut where ``record_cut`` finds a header.
+    The file's CRC-32 is known at the end only -- a mismatch, or a file the parallel route does not take, raises
+    ``GzRouteDeclined`` from the iteration and the caller starts over with ``GzipRecordStream``.  Same protocol as that class."""
+
+    def __init__(self, path: str, piece_bytes: int = None):
+        self.path = str(path)
+        self.piece_bytes = int(piece_bytes or GZ_AHEAD_PIECE_BYTES)
+        self.raw = np.memmap(self.path, dtype=np.uint8, mode="r")  # the compressed bytes straight from the page cache
+        self.compressed_bytes = int(self.raw.size)
+        self.inflate_s = 0.0
+        self.text_bytes = 0
+        self.pieces = 0
+        self._t0 = time.perf_counter()
+        self.job = _ffi.GzInflation(self.raw)
+        self._logged = False
+        self._whole_handed_out = False
+
+    def _finished(self) -> bool:
+        """the inflation has ended well (raises when it has ended otherwise)"""
+        ok = self.job.wait()
+        if not self._logged:
+            self._logged = True
+            self.inflate_s = time.perf_counter() - self._t0  # an upper bound when the consumer came late
+            if ok:
+                GZ_LOG.append({"path": self.path, "gz_MB": round(self.compressed_bytes / 1e6, 1), "text_MB": round(self.job.text().size / 1e6, 1),
+                               "parallel_inflate_s": round(self.inflate_s, 4), "parsed_beside": True})
+        if not ok:
+            raise GzRouteDeclined(self.path)
+        return True
+
+    def __iter__(self):
+        at, total = 0, None
+        out = self.job.out
+        while True:
+            if total is None and not self.job.running():
+                self._finished()
+                total = int(self.job.text().size)
+            done = total if total is not None else self.job.done()
+            if at == 0 and done > 0 and out[0] != 64:  # not FASTQ: those parsers want the whole text
+                self._finished()
+                self.text_bytes, self.pieces = int(self.job.text().size), 1
+                yield ("whole", bytes(self.job.text()))
+                return
+            if total is not None and at >= total:
+                return
+            want = self.piece_bytes if total is None else 1
+            if done - at >= want:
+                end = min(done, at + TEXT_PIECE_BYTES)
+                if total is None or end < total:
+                    end = record_cut(out, at, end)
+                if end > at:
+                    self.text_bytes += end - at
+                    self.pieces += 1
+                    yield out[at:end]
+                    at = end
+                    continue
+                if total is not None:
+                    raise RuntimeError(f"{self.path}: no FASTQ record starts in {TEXT_PIECE_BYTES} bytes of text")
+            time.sleep(0.0003)
+
+    def close(self):
+        """the consumer is done with every piece (they were uploaded): the text buffer goes back for the next sample"""
+        self.job.wait()  # (the buffers must outlive the worker)
+        if not self._whole_handed_out:
+            self.job.release()
+
+    def whole_text(self):
+        if not self.job.wait():
+            return GzipRecordStream(self.path).whole_text()
+        self._finished()
+        t = self.job.text()
+        self._whole_handed_out = True  # the caller keeps a view: this buffer is not reused
+        return unwrap_fasta(bytes(t)) if bytes(t[:1]) == b">" else t
+
+
 def read_text(path: str, stream: bool = False):
     """The file's bytes for the device-side parser (``mirge_reads_parse``): memory-mapped when plain; a ``.gz`` inflated whole,
     or -- ``stream=True`` -- as a ``GzipRecordStream`` whose worker has already started.  A FASTA whose sequences are wrapped
@@ -289,6 +392,8 @@ def read_text(path: str, stream: bool = False):
         data = None
         # (up to 8 GiB of compressed data -- the text is held whole in host memory, some 6 x that; beyond, the streamed route's
         # few pieces bound the memory a sample takes)
+        if stream and _os.environ.get("MIRGE_GZ_PARALLEL", "1") not in ("0", "whole") and (2 << 20) <= _os.path.getsize(path) <= (8 << 30):
+            return ParallelGzipStream(path)  # inflated on all cores, parsed beside; declines like the call below
         if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and (2 << 20) <= _os.path.getsize(path) <= (8 << 30):
             t0 = time.perf_counter()
             raw = np.fromfile(path, dtype=np.uint8)
@@ -525,7 +630,7 @@ def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None,
     filter and -- with ``umi`` -- the reference's UMI handling, all on the GPU (``mirge_reads_parse[_trim|_umi]``).
     With ``-udd`` also writes ``<name>_umiCounts.csv``.  ``text`` may be a ``GzipRecordStream``: its pieces are uploaded and
     parsed one by one while the next ones inflate, and appended on the device (``mirge_reads_concat``: file order kept)."""
-    if isinstance(text, (GzipRecordStream, TextRecordStream)):
+    if isinstance(text, (GzipRecordStream, TextRecordStream, ParallelGzipStream)):
         if umi is not None:  # the UMI routes look at the whole sample (a collapse inside): not streamed
             text = text.whole_text()
         else:
@@ -540,7 +645,14 @@ def parse_sample(ctx: _ffi.Context, text, min_len: int, trim, umi, workDir=None,
     return raw, n_rec
 
 
-def _parse_stream(ctx: _ffi.Context, stream: "GzipRecordStream", min_len: int, trim, timings=None):
+def _parse_stream(ctx: _ffi.Context, stream, min_len: int, trim, timings=None):
+    try:
+        return _parse_stream_once(ctx, stream, min_len, trim, timings)
+    except GzRouteDeclined:  # not a file for the parallel inflater: everything again through zlib (what was parsed ahead is closed)
+        return _parse_stream_once(ctx, GzipRecordStream(stream.path), min_len, trim, timings)
+
+
+def _parse_stream_once(ctx: _ffi.Context, stream, min_len: int, trim, timings=None):
     parts, n_rec = [], 0
     t_wait = t_gpu = 0.0
     t = time.perf_counter()

@@ -22,6 +22,13 @@
 #include <sys/mman.h>
 #include <zlib.h>
 
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+#include <utility>
+#include <vector>
+
 namespace mirge_gz {
 
 struct BitReader {
@@ -200,6 +207,40 @@ struct SymBuf {
         return true;
     }
     void release() { if (p) ::munmap(p, bytes_for(cap)); p = nullptr; cap = 0; }
+    // Buffers of finished calls are kept for the next one (a process inflates sample after sample): 64 workers touching 16 MiB of
+    // fresh memory each is a gigabyte of page faults per file.  At most MIRGE_GZ_KEEP_SYM_BYTES (default 2 GiB) stay mapped.
+    struct Pool {
+        std::mutex mu;
+        std::vector<std::pair<uint16_t*, size_t>> kept;
+        size_t bytes = 0, limit = (size_t)2 << 30;
+        Pool() { if (const char* e = std::getenv("MIRGE_GZ_KEEP_SYM_BYTES")) limit = (size_t)std::strtoull(e, nullptr, 10); }
+    };
+    static Pool& pool() { static Pool* pl = new Pool; return *pl; }  // (never destroyed: threads may still give back at exit)
+    void take() {  // the largest kept buffer, if any
+        Pool& pl = pool();
+        std::lock_guard<std::mutex> g(pl.mu);
+        if (p || pl.kept.empty()) return;
+        size_t best = 0;
+        for (size_t i = 1; i < pl.kept.size(); i++) if (pl.kept[i].second > pl.kept[best].second) best = i;
+        p = pl.kept[best].first; cap = pl.kept[best].second;
+        pl.bytes -= bytes_for(cap);
+        pl.kept[best] = pl.kept.back();
+        pl.kept.pop_back();
+    }
+    void give() {
+        if (!p) return;
+        Pool& pl = pool();
+        {
+            std::lock_guard<std::mutex> g(pl.mu);
+            if (pl.bytes + bytes_for(cap) <= pl.limit) {
+                pl.kept.emplace_back(p, cap);
+                pl.bytes += bytes_for(cap);
+                p = nullptr; cap = 0;
+                return;
+            }
+        }
+        release();
+    }
     uint16_t& operator[](size_t i) { return p[i]; }
     const uint16_t& operator[](size_t i) const { return p[i]; }
     uint16_t* data() { return p; }
@@ -372,7 +413,11 @@ static int inflate_bgzf(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, s
 
 // one ordinary member (the usual sample.fastq.gz), cut into chunks as described at the top
 // *consumed = bytes of `gz` the member occupies (another member, or padding, may follow)
-static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t* n_out, size_t* consumed, int threads) {
+// `progress` (may be null): advanced -- with release order -- to progress_base + the number of leading bytes of `out` that are final
+// (decoded, their history resolved, written); the CRC is only known at the end, so a consumer that reads ahead must be ready to
+// throw everything away when the call fails.
+static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t* n_out, size_t* consumed, int threads,
+                                   int64_t* progress = nullptr, int64_t progress_base = 0) {
     GzHeader h;
     if (!parse_gz_header(gz, n, h) || n < h.body + 8) return -1;
     const uint8_t* d = gz + h.body;           // the deflate stream ... and the trailer behind it, somewhere
@@ -409,8 +454,13 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
     uint64_t final_end_bit = 0;
     int C_eff = -1;  // chunks of THIS member (the data may go on with another member: its chunks are found, decoded and dropped)
     std::atomic<int> failed{0}, next{0};
+    std::vector<char> finished((size_t)C, 0);  // chunk i's bytes are in place (under front_mu)
+    int front = 0;                              // chunks 0 .. front - 1 are
+    std::mutex front_mu;
     auto worker = [&]() {
         SymBuf o;
+        o.take();
+        struct GiveBack { SymBuf& b; ~GiveBack() { b.give(); } } give_back{o};
         for (int i; (i = next.fetch_add(1)) < C;) {
             int st_i = 0;  // 0 ok, 1 ended with the final block, < 0 failed
             size_t no = 0;
@@ -478,6 +528,14 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
                 done += m;
             }
             crcs[(size_t)i] = c;
+            if (progress) {
+                std::lock_guard<std::mutex> g(front_mu);
+                finished[(size_t)i] = 1;
+                const int before = front;
+                while (front < C && finished[(size_t)front]) front++;
+                // (link[front].at was published by chunk front - 1 before it wrote its bytes)
+                if (front > before) __atomic_store_n(progress, progress_base + (int64_t)link[(size_t)front].at, __ATOMIC_RELEASE);
+            }
         }
     };
     {
@@ -544,7 +602,10 @@ static int inflate_member_serial(const uint8_t* gz, size_t n, uint8_t* out, size
 // 0: done, and every member verified against the CRC-32 / length it carries.  Negative: not done -- the file is not of a kind
 // this route takes (too small, not text), is damaged, or `cap` is too small (-2): the caller inflates it the ordinary way, which
 // also reports what is wrong with a damaged file.
-extern "C" int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads) {
+// mirge_gz_inflate_progress: the same, and `progress` (may be null) is advanced while the call runs to the number of leading bytes
+// of `out` that are final -- a caller on another thread may upload and parse whole records of that prefix meanwhile.  The file's
+// CRC-32 is only verified at the end: when the call fails, whatever was read ahead must be dropped.
+extern "C" int mirge_gz_inflate_progress(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads, int64_t* progress) {
     if (!gz || n_gz < 18 || !out || cap < 0 || !n_out) return fail(-1, "mirge_gz_inflate: bad argument");
     // (beyond ~64 threads nothing is gained: 82 chunks of a 10 M-read sample decode in 0.35 s on 16, 64 or 256 threads of a
     // 2 x 64-core host -- concurrent first-touch page faults, not decoding, set the floor; profiles/README.md round 4)
@@ -569,14 +630,22 @@ extern "C" int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, i
         while (rc == 0 && at < (size_t)n_gz) {
             if (gz[at] == 0) { at++; continue; }
             size_t got = 0, used = 0;
-            rc = mirge_gz::inflate_member_parallel(gz + at, (size_t)n_gz - at, out + n, (size_t)cap - n, &got, &used, T);
+            rc = mirge_gz::inflate_member_parallel(gz + at, (size_t)n_gz - at, out + n, (size_t)cap - n, &got, &used, T, progress, (int64_t)n);
             if (rc == 0) any_parallel = true;
             else if (rc == -3) rc = mirge_gz::inflate_member_serial(gz + at, (size_t)n_gz - at, out + n, (size_t)cap - n, &got, &used);
-            if (rc == 0) { n += got; at += used; }
+            if (rc == 0) {
+                n += got; at += used;
+                if (progress) __atomic_store_n(progress, (int64_t)n, __ATOMIC_RELEASE);
+            }
         }
         if (rc == 0 && !any_parallel) rc = -3;  // nothing here was worth the threads: the caller's streamed route does as well
     }
     if (rc) return fail(rc, "mirge_gz_inflate: not inflated in parallel (code " + std::to_string(rc) + "): the serial route applies");
     *n_out = (int64_t)n;
+    if (progress) __atomic_store_n(progress, (int64_t)n, __ATOMIC_RELEASE);
     return 0;
+}
+
+extern "C" int mirge_gz_inflate(const uint8_t* gz, int64_t n_gz, uint8_t* out, int64_t cap, int64_t* n_out, int32_t threads) {
+    return mirge_gz_inflate_progress(gz, n_gz, out, cap, n_out, threads, nullptr);
 }

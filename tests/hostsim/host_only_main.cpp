@@ -259,6 +259,32 @@ int main(int argc, char** argv) {
         EXPECT(mirge_gz_inflate((const uint8_t*)multi.data(), (int64_t)multi.size(), out2.data(), (int64_t)out2.size(), &n, 4) == 0);
         EXPECT(n == (int64_t)multi_t.size() && std::memcmp(out2.data(), multi_t.data(), multi_t.size()) == 0);
         EXPECT(mirge_gz_inflate((const uint8_t*)multi.data(), (int64_t)multi.size(), out2.data(), (int64_t)multi_t.size() - 5, &n, 4) != 0);  // too little room
+        // mirge_gz_inflate_progress: a second thread reads the prefix that is reported final WHILE the members inflate -- every
+        // byte of it must already be the text's, the reports only grow, and the last one is the whole length
+        {
+            std::fill(out2.begin(), out2.end(), (uint8_t)0);
+            int64_t progress = 0, seen_max = 0, checks = 0;
+            std::atomic<int> stop{0}, wrong{0};
+            std::thread reader([&]() {
+                int64_t last = 0;
+                while (true) {
+                    const int last_round = stop.load();
+                    const int64_t pr = __atomic_load_n(&progress, __ATOMIC_ACQUIRE);
+                    if (pr < last || pr > (int64_t)multi_t.size()) wrong = 1;
+                    if (pr > last) {
+                        if (std::memcmp(out2.data() + last, multi_t.data() + last, (size_t)(pr - last)) != 0) wrong = 1;
+                        last = pr;
+                        checks++;
+                    }
+                    if (last_round) break;
+                }
+                seen_max = last;
+            });
+            const int rc = mirge_gz_inflate_progress((const uint8_t*)multi.data(), (int64_t)multi.size(), out2.data(), (int64_t)out2.size(), &n, 4, &progress);
+            stop = 1;
+            reader.join();
+            EXPECT(rc == 0 && !wrong && seen_max == (int64_t)multi_t.size() && n == seen_max && checks >= 3);
+        }
         std::string junk = gz + "garbage behind the member";
         EXPECT(mirge_gz_inflate((const uint8_t*)junk.data(), (int64_t)junk.size(), out2.data(), (int64_t)out2.size(), &n, 4) != 0);
         std::string badsmall = gz + small_gz;

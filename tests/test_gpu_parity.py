@@ -2162,6 +2162,11 @@ def test_streamed_gz_equals_the_plain_file(ctx, ci_libs, tmp_path):
             assert np.array_equal(f1[o1], f2[o2]) and np.array_equal(c1[o1], c2[o2])
             for h in (u1, u2, got):
                 h.close()
+        # inflated on all host cores and parsed beside (collapse.ParallelGzipStream): here the two members are too small to cut, the
+        # route declines at the end and _parse_stream starts over with zlib -- same reads
+        got, n_got = collapse.parse_sample(ctx, collapse.ParallelGzipStream(str(gz), piece_bytes=1 << 16), 16, trim, None)
+        assert n_got == n_want and got.unpack().to_list() == want.unpack().to_list()
+        got.close()
         # the plain text in parts of whole records (collapse.TextRecordStream: how a text of 8 GiB or more is parsed)
         for piece in (900, 200_000):
             tm = {}
@@ -2170,8 +2175,30 @@ def test_streamed_gz_equals_the_plain_file(ctx, ci_libs, tmp_path):
             assert tm["gz_pieces"] >= len(text) // piece
             got.close()
         want.close()
+    # ... and a member large enough to be cut (3 x the text, one member): pieces parsed while the rest inflates
+    big_plain, big_gz = tmp_path / "B.fastq", tmp_path / "B.fastq.gz"
+    big_text = b"".join(text.replace(b"@r", b"@%c" % t_) for t_ in b"rst")
+    big_plain.write_bytes(big_text)
+    big_gz.write_bytes(gzip.compress(big_text, 6))
+    assert big_gz.stat().st_size > (3 << 20)
+    for trim in trims[:2]:
+        want, n_want = collapse.parse_sample(ctx, collapse.read_text(str(big_plain)), 16, trim, None)
+        for piece in (1 << 16, 4 << 20):
+            tm = {}
+            st = collapse.ParallelGzipStream(str(big_gz), piece_bytes=piece)
+            got, n_got = collapse.parse_sample(ctx, st, 16, trim, None, timings=tm)
+            assert st.job.ok and n_got == n_want == 3 * len(reads) and got.unpack().to_list() == want.unpack().to_list()
+            assert np.array_equal(got.group_counts(), want.group_counts()) and tm["gz_pieces"] >= 2
+            got.close()
+        want.close()
+    st = collapse.read_text(str(big_gz), stream=True)
+    assert isinstance(st, collapse.ParallelGzipStream)
+    st.close()
     umi = _ffi.MirgeUmi.make(4, 2)
     a, na = collapse.parse_sample(ctx, collapse.read_text(str(plain)), 16, trims[1], umi)
+    b2, nb2 = collapse.parse_sample(ctx, collapse.ParallelGzipStream(str(gz)), 16, trims[1], umi)  # UMIs: the whole text, here through zlib
+    assert na == nb2 and a.unpack().to_list() == b2.unpack().to_list()
+    b2.close()
     b, nb = collapse.parse_sample(ctx, collapse.GzipRecordStream(str(gz), piece_bytes=5000), 16, trims[1], umi)
     assert na == nb and a.unpack().to_list() == b.unpack().to_list()
     a.close(); b.close()

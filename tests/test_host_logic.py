@@ -295,15 +295,18 @@ def test_gz_inflate_on_all_cores_equals_zlib(tmp_path):
         got = _ffi.gz_inflate(p1.read_bytes(), threads)
         assert got is not None and got.tobytes() == text
     del collapse.GZ_LOG[:]
-    rt = collapse.read_text(str(p1), stream=True)
+    rt = collapse.read_text(str(p1))
     assert isinstance(rt, np.ndarray) and rt.tobytes() == text and collapse.GZ_LOG and collapse.GZ_LOG[0]["text_MB"] == round(len(text) / 1e6, 1)
+    st = collapse.read_text(str(p1), stream=True)  # a caller that streams gets the text while it inflates
+    assert isinstance(st, collapse.ParallelGzipStream) and b"".join(bytes(q) for q in st) == text
     # lanes merged with `cat`: a large member, a small one (zlib's), an empty one, a large one, zero padding
     two = tmp_path / "T.fastq.gz"
     two.write_bytes(gzip.compress(text, 6) + gzip.compress(text[:5000], 6) + gzip.compress(b"", 6) + gzip.compress(text, 9) + b"\0" * 512)
     got = _ffi.gz_inflate(two.read_bytes())
     assert got is not None and got.tobytes() == text + text[:5000] + text
-    rt2 = collapse.read_text(str(two), stream=True)
+    rt2 = collapse.read_text(str(two))
     assert isinstance(rt2, np.ndarray) and rt2.tobytes() == text + text[:5000] + text
+    assert b"".join(bytes(q) for q in collapse.read_text(str(two), stream=True)) == text + text[:5000] + text
     os.environ["MIRGE_GZ_PARALLEL"] = "0"
     try:
         st = collapse.read_text(str(two), stream=True)
@@ -316,8 +319,10 @@ def test_gz_inflate_on_all_cores_equals_zlib(tmp_path):
     bad[len(bad) // 2] ^= 4
     assert _ffi.gz_inflate(bytes(bad)) is None
     (tmp_path / "B.fastq.gz").write_bytes(bytes(bad))
+    with pytest.raises(collapse.GzRouteDeclined):  # (_parse_stream then starts over with zlib, which says what is wrong)
+        list(collapse.read_text(str(tmp_path / "B.fastq.gz"), stream=True))
     with pytest.raises((zlib.error, EOFError, OSError)):
-        b"".join(collapse.read_text(str(tmp_path / "B.fastq.gz"), stream=True))
+        list(collapse.GzipRecordStream(str(tmp_path / "B.fastq.gz")))
 
 
 def test_unpinned_trimming_options_are_named():
@@ -377,6 +382,80 @@ def test_text_record_stream(tmp_path, monkeypatch):
     assert not isinstance(collapse.read_text(str(fa), stream=True), collapse.TextRecordStream)
     monkeypatch.setattr(collapse, "TEXT_PIECE_BYTES", 2 << 30)
     assert not isinstance(collapse.read_text(str(plain), stream=True), collapse.TextRecordStream)
+
+
+def test_parallel_gzip_stream_parsed_beside_the_inflation(tmp_path):
+    """collapse.ParallelGzipStream (mirge_gz_inflate_progress on its own thread, pure host): the pieces handed out while the file
+    inflates are the text, each starts at a record -- quality lines that start with '@' included --, one member or several; a FASTA
+    comes whole; a damaged file raises GzRouteDeclined from the iteration (the caller starts over with zlib) and whole_text() falls
+    back by itself; collapse.record_cut on hand-made texts."""
+    import gzip
+    from mirge3_amd import collapse
+    rc = collapse.record_cut
+    t = np.frombuffer(b"@a\nACGT\n+\n@III\n@b\nAC\n+\nII\n@c\nA", np.uint8)
+    assert rc(t, 0, t.size) == 15 and bytes(t[15:17]) == b"@b"   # '@c' has no '+' two lines on yet; '@III' is a quality line
+    assert rc(t, 0, 14) == 0 and rc(t, 0, 3) == 0 and rc(t, 15, t.size) == 15
+    t2 = np.frombuffer(b"@a\n\n+\n\n@b\n\n+\n\n", np.uint8)             # empty reads
+    assert rc(t2, 0, t2.size) == 7
+    rng = np.random.default_rng(9)
+    recs = []
+    for i in range(120000):
+        L = int(rng.integers(16, 60))
+        q = "".join(chr(c) for c in rng.integers(33, 75, L))
+        if i % 3 == 0:
+            q = "@" + q[1:]
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[x] for x in rng.integers(0, 4, L)), q))
+    text = "".join(recs).encode()
+    starts = set(np.cumsum([0] + [len(r) for r in recs]).tolist())
+    one = tmp_path / "a.fastq.gz"
+    one.write_bytes(gzip.compress(text, 6))
+    two = tmp_path / "b.fastq.gz"
+    c = len(text) // 2 + 5
+    two.write_bytes(gzip.compress(text[:c], 6) + gzip.compress(text[c:], 1))
+    assert one.stat().st_size > (3 << 20)
+    for path in (one, two):
+        for piece in (1 << 16, 1 << 20, 48 << 20):
+            st = collapse.ParallelGzipStream(str(path), piece_bytes=piece)
+            pieces = [bytes(p_) for p_ in st]
+            st.close()
+            assert b"".join(pieces) == text and st.text_bytes == len(text) and st.pieces == len(pieces) and st.inflate_s > 0
+            at = 0
+            for q in pieces:
+                assert at in starts
+                at += len(q)
+    assert collapse.GZ_LOG and collapse.GZ_LOG[-1]["parsed_beside"] and collapse.GZ_LOG[-1]["text_MB"] == round(len(text) / 1e6, 1)
+    # the text buffer of a closed stream serves the next one (no fresh pages per sample); a text handed out whole is never reused
+    from mirge3_amd import _ffi
+    assert len(_ffi._gz_kept) == 1
+    kept = _ffi._gz_kept[0]
+    st = collapse.ParallelGzipStream(str(two))
+    assert st.job.out is kept and not _ffi._gz_kept
+    assert b"".join(bytes(p_) for p_ in st) == text
+    st.close()
+    assert _ffi._gz_kept and _ffi._gz_kept[0] is kept
+    st = collapse.ParallelGzipStream(str(one))
+    whole = st.whole_text()
+    st.close()
+    assert not _ffi._gz_kept and bytes(whole) == text
+    assert bytes(collapse.ParallelGzipStream(str(one)).whole_text()) == text
+    st = collapse.read_text(str(one), stream=True)
+    assert isinstance(st, collapse.ParallelGzipStream)
+    st.close()
+    assert bytes(collapse.read_text(str(one), stream=False)) == text
+    bad = bytearray(one.read_bytes())
+    bad[len(bad) // 2] ^= 0x10
+    (tmp_path / "bad.fastq.gz").write_bytes(bytes(bad))
+    with pytest.raises(collapse.GzRouteDeclined):
+        list(collapse.ParallelGzipStream(str(tmp_path / "bad.fastq.gz")))
+    with pytest.raises(Exception):  # ... and zlib then says what is wrong with it
+        collapse.ParallelGzipStream(str(tmp_path / "bad.fastq.gz")).whole_text()
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 150000 * 55)].tobytes()
+    fa_text = b"".join(b">s%d\n%s\n%s\n" % (i, bases[55 * i:55 * i + 40], bases[55 * i + 40:55 * i + 55]) for i in range(150000))
+    fa = tmp_path / "c.fa.gz"
+    fa.write_bytes(gzip.compress(fa_text, 6))
+    items = list(collapse.ParallelGzipStream(str(fa)))
+    assert len(items) == 1 and items[0][0] == "whole" and items[0][1] == fa_text
+    assert collapse.ParallelGzipStream(str(fa)).whole_text() == collapse.unwrap_fasta(fa_text)
 
 
 def test_gzip_record_stream(tmp_path):
