@@ -19,10 +19,13 @@
 // merged with `cat`) member after member, each cut as above when it is large enough.
 // Nothing here decides an answer: a text that fails any check is simply inflated serially by the caller (collapse.GzipRecordStream).
 #pragma once
+#include <immintrin.h>
 #include <sys/mman.h>
 #include <zlib.h>
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -271,12 +274,73 @@ static int decode_block(BitReader& br, SymBuf& out, size_t& o, bool known_histor
     if (btype == 2) { if (!read_dynamic_header(br, lit, dist)) return -1; }
     else fixed_codes(lit, dist);
     auto done = [&](int rc) { return rc; };
+    const uint32_t* const lt = lit.table.data();
+    const uint32_t* const dt = dist.ok ? dist.table.data() : nullptr;
+    const uint32_t lpm = ((uint32_t)1 << lit.pbits) - 1u, lmm = ((uint32_t)1 << lit.maxlen) - 1u;
+    const uint32_t dpm = dist.ok ? ((uint32_t)1 << dist.pbits) - 1u : 0u, dmm = dist.ok ? ((uint32_t)1 << dist.maxlen) - 1u : 0u;
+    const int lpb = lit.pbits, dpb = dist.pbits;
     for (;;) {
         if (o + 512 > out.size()) {
             if (o + 512 > max_out) return done(-1);
             if (!out.resize(std::max(out.size() * 2, o + (size_t)(1 << 16)))) return done(-1);
         }
         if (br.ran_off()) return done(-1);
+        if (!text_only && br.nbits >= 0 && br.end - br.p >= 16) {
+            // The fast loop (the real decode; the block-start search keeps to the careful step below): the reader's state in
+            // locals, ONE refill per symbol or match -- 56 bits cover a length code, its extra bits, a distance code and its extra
+            // bits (15 + 5 + 15 + 13) --, no per-symbol bounds checks: it runs while 16 bytes of input and 300 symbols of room
+            // are left and hands the rest to the careful step.
+            const uint8_t* p = br.p;
+            const uint8_t* const safe_end = br.end - 16;
+            uint64_t buf = br.buf;
+            int nb = br.nbits;
+            uint16_t* const w = out.data();
+            const size_t o_lim = out.size() - 300;
+            int rc = 2;  // 2 = out of input or room: not an end
+            while (p <= safe_end && o < o_lim) {
+                {
+                    uint64_t x;
+                    std::memcpy(&x, p, 8);
+                    buf |= x << nb;
+                    const int adv = (63 - nb) >> 3;
+                    p += adv;
+                    nb += adv * 8;
+                }
+                uint32_t e = lt[(uint32_t)buf & lpm];
+                if (e & 0x80000000u) e = lt[((e & 0x7FFFFFFFu) >> 4) + (((uint32_t)buf & lmm) >> lpb)];
+                const int l = (int)(e & 15u);
+                if (!l) { rc = -1; break; }
+                buf >>= l; nb -= l;
+                const int s = (int)(e >> 4);
+                if (s < 256) { w[o++] = (uint16_t)s; continue; }
+                if (s == 256) { rc = (int)bfinal; break; }
+                if (s > 285 || !dt) { rc = -1; break; }
+                const int xl = kLenExtra[s - 257];
+                const int len = kLenBase[s - 257] + (int)((uint32_t)buf & (((uint32_t)1 << xl) - 1u));
+                buf >>= xl; nb -= xl;
+                uint32_t de = dt[(uint32_t)buf & dpm];
+                if (de & 0x80000000u) de = dt[((de & 0x7FFFFFFFu) >> 4) + (((uint32_t)buf & dmm) >> dpb)];
+                const int dl = (int)(de & 15u), ds = (int)(de >> 4);
+                if (!dl || ds > 29) { rc = -1; break; }
+                buf >>= dl; nb -= dl;
+                const int xd = kDistExtra[ds];
+                const size_t d = (size_t)kDistBase[ds] + (size_t)((uint32_t)buf & (((uint32_t)1 << xd) - 1u));
+                buf >>= xd; nb -= xd;
+                if (d > o + (known_history ? 0 : MIRGE_GZ_WINDOW)) { rc = -1; break; }
+                if (o >= d) {
+                    const uint16_t* src = w + (o - d);
+                    uint16_t* dst = w + o;
+                    for (int k = 0; k < len; k++) dst[k] = src[k];  // forward, element by element: the ranges may overlap (d < len repeats)
+                    o += (size_t)len;
+                } else {
+                    for (int k = 0; k < len; k++, o++)
+                        w[o] = o >= d ? w[o - d] : (uint16_t)(256 + (MIRGE_GZ_WINDOW + o - d));
+                }
+            }
+            br.p = p; br.buf = buf; br.nbits = nb;
+            if (rc != 2) return done(rc);
+            if (o + 512 > out.size()) continue;  // room first, then on
+        }
         const int s = decode_sym(br, lit);
         if (s < 0) return done(-1);
         if (s < 256) {
@@ -411,6 +475,109 @@ static int inflate_bgzf(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, s
     return 0;
 }
 
+// CRC-32 (gzip polynomial, reflected) by carry-less multiplication: Gopal et al., "Fast CRC Computation for Generic Polynomials
+// Using PCLMULQDQ Instruction" (Intel, 2009).  64 bytes are folded per step with the constants x^(512+64) mod P, x^512 mod P
+// (bit-reflected), then 4 -> 1 lanes with x^(128+64), x^128, then 128 -> 64 -> 32 bits and a Barrett reduction.
+
+// n >= 64, n % 16 == 0
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_clmul_blocks(const uint8_t* buf, size_t len, uint32_t crc) {
+    // constants for the reflected polynomial 0xEDB88320
+    alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};  // fold by 512 bits
+    alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};  // fold by 128 bits
+    alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};  // 96 -> 64 bits
+    alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};  // P' and mu for the Barrett step
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
+    x2 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
+    x4 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i*)k1k2);
+    buf += 64;
+    len -= 64;
+    while (len >= 64) {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+        x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+        x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+        x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+        x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i*)(buf + 0x00));
+        y6 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i*)(buf + 0x20));
+        y8 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
+        x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
+        x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64;
+        len -= 64;
+    }
+    // four lanes -> one
+    x0 = _mm_load_si128((const __m128i*)k3k4);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    // the remaining 16-byte blocks
+    while (len >= 16) {
+        x2 = _mm_loadu_si128((const __m128i*)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16;
+        len -= 16;
+    }
+    // 128 -> 64 bits
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i*)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    // Barrett reduction 64 -> 32 bits
+    x0 = _mm_load_si128((const __m128i*)poly);
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+
+// CRC-32 (the gzip polynomial) of n bytes: carry-less multiplication where the CPU has it (5 GB/s against the 1 GB/s of this
+// image's zlib -- the checksum was 40 % of a chunk's time), zlib for the tail and for CPUs without it
+static uint32_t crc32_bytes(const uint8_t* p, size_t n) {
+    uint32_t c = 0;
+    static const bool clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1") && !std::getenv("MIRGE_GZ_NO_CLMUL");
+    if (clmul && n >= 64) {
+        const size_t m = n & ~(size_t)15;
+        c = ~crc32_clmul_blocks(p, m, ~c);
+        p += m;
+        n -= m;
+    }
+    for (size_t done = 0; done < n;) {  // zlib's crc32 takes a 32-bit length
+        const size_t m = std::min<size_t>(n - done, (size_t)1 << 30);
+        c = (uint32_t)crc32(c, p + done, (uInt)m);
+        done += m;
+    }
+    return c;
+}
+
+// MIRGE_GZ_TIMING=1: the phases of every member inflated in parallel, to stderr (seconds from the call's start)
+static bool gz_timing() { static const bool on = std::getenv("MIRGE_GZ_TIMING") != nullptr; return on; }
+static double gz_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // one ordinary member (the usual sample.fastq.gz), cut into chunks as described at the top
 // *consumed = bytes of `gz` the member occupies (another member, or padding, may follow)
 // `progress` (may be null): advanced -- with release order -- to progress_base + the number of leading bytes of `out` that are final
@@ -420,6 +587,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
                                    int64_t* progress = nullptr, int64_t progress_base = 0) {
     GzHeader h;
     if (!parse_gz_header(gz, n, h) || n < h.body + 8) return -1;
+    const double t_call = gz_now();
     const uint8_t* d = gz + h.body;           // the deflate stream ... and the trailer behind it, somewhere
     const size_t dn = n - h.body;
     // chunk starts: ~8 per thread, at least 512 KiB of compressed data each
@@ -436,6 +604,8 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
     for (uint64_t s : start) if (s != ~0ull) st.push_back(s);
     const int C = (int)st.size();
     if (C < 2) return -3;
+    const double t_search = gz_now();
+    std::vector<double> t_dec((size_t)C, 0.0), t_link((size_t)C, 0.0), t_fin((size_t)C, 0.0), t_start((size_t)C, 0.0);
     // Workers take the chunks in order, each with ONE symbol buffer it keeps (fresh memory is touched once per worker, not
     // once per chunk): decode chunk i without its history; wait until chunk i - 1 has published where chunk i's bytes go and
     // what its history is -- it usually has, it started earlier --; publish the same for chunk i + 1 (32 K lookups through
@@ -465,6 +635,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
             int st_i = 0;  // 0 ok, 1 ended with the final block, < 0 failed
             size_t no = 0;
             uint64_t endb = 0;
+            t_start[(size_t)i] = gz_now();
             if (!failed.load()) {
                 BitReader br(d, dn, st[(size_t)i]);
                 const uint64_t stop = i + 1 < C ? st[(size_t)i + 1] : ~0ull;
@@ -478,6 +649,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
                     else if (pos > stop) st_i = -2;  // the next chunk's start was no block boundary of this stream
                 }
             }
+            t_dec[(size_t)i] = gz_now();
             // the hand-over happens whatever happened: nobody may wait for ever
             while (!link[(size_t)i].ready.load(std::memory_order_acquire)) std::this_thread::yield();
             const Link& me = link[(size_t)i];
@@ -510,24 +682,40 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
             }
             n_sym[(size_t)i] = no;
             nx.ready.store(1, std::memory_order_release);
+            t_link[(size_t)i] = gz_now();
             if (failed.load()) continue;
             uint8_t* ob = out + me.at;
             const uint8_t* hw = me.hist.empty() ? nullptr : me.hist.data();
             bool bad = false;
-            for (size_t k = 0; k < no; k++) {
-                const uint16_t v = o[k];
-                if (v < 256) ob[k] = (uint8_t)v;
-                else if (hw) ob[k] = hw[(size_t)v - 256];
-                else { bad = true; break; }
+            {   // symbols -> bytes.  In FASTQ the references into the history do NOT die out -- a header is a copy of the header
+                // before it, placeholders included, to the chunk's end -- so the translation is a table look-up per symbol (a byte
+                // maps to itself, 256 + q to history byte q: 33 KiB, cache-resident) instead of a branch; runs of 64 plain bytes
+                // are narrowed without one (two loops the compiler turns into vector code)
+                const uint16_t* sy = o.data();
+                std::vector<uint8_t> tab((size_t)256 + MIRGE_GZ_WINDOW, 0);
+                for (int v = 0; v < 256; v++) tab[(size_t)v] = (uint8_t)v;
+                if (hw) std::memcpy(tab.data() + 256, hw, MIRGE_GZ_WINDOW);
+                const uint8_t* tb = tab.data();
+                size_t k = 0;
+                for (; k + 64 <= no; k += 64) {
+                    uint16_t any = 0;
+                    for (int j = 0; j < 64; j++) any |= sy[k + (size_t)j];
+                    if (any < 256) {
+                        for (int j = 0; j < 64; j++) ob[k + (size_t)j] = (uint8_t)sy[k + (size_t)j];
+                    } else {
+                        if (!hw) { bad = true; break; }  // the stream's first chunk has no history to refer to
+                        for (int j = 0; j < 64; j++) ob[k + (size_t)j] = tb[sy[k + (size_t)j]];
+                    }
+                }
+                for (; k < no && !bad; k++) {
+                    const uint16_t v = sy[k];
+                    if (v >= 256 && !hw) bad = true;
+                    else ob[k] = tb[v];
+                }
             }
             if (bad) { failed.store(1); continue; }
-            uint32_t c = 0;
-            for (size_t done = 0; done < no;) {  // zlib's crc32 takes a 32-bit length
-                const size_t m = std::min<size_t>(no - done, (size_t)1 << 30);
-                c = (uint32_t)crc32(c, ob + done, (uInt)m);
-                done += m;
-            }
-            crcs[(size_t)i] = c;
+            crcs[(size_t)i] = crc32_bytes(ob, no);
+            t_fin[(size_t)i] = gz_now();
             if (progress) {
                 std::lock_guard<std::mutex> g(front_mu);
                 finished[(size_t)i] = 1;
@@ -543,6 +731,21 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
         for (int t = 1; t < std::min(threads, C); t++) th.emplace_back(worker);
         worker();
         for (auto& x : th) x.join();
+    }
+    if (gz_timing()) {
+        double dec_sum = 0, dec_max = 0, link_last = 0, fin_last = 0, wait_sum = 0, conv_sum = 0;
+        for (int i = 0; i < C; i++) {
+            dec_sum += t_dec[(size_t)i] - t_start[(size_t)i];
+            dec_max = std::max(dec_max, t_dec[(size_t)i] - t_start[(size_t)i]);
+            link_last = std::max(link_last, t_link[(size_t)i] - t_call);
+            fin_last = std::max(fin_last, t_fin[(size_t)i] - t_call);
+            if (t_link[(size_t)i] > 0) wait_sum += t_link[(size_t)i] - t_dec[(size_t)i];
+            if (t_fin[(size_t)i] > 0) conv_sum += t_fin[(size_t)i] - t_link[(size_t)i];
+        }
+        std::fprintf(stderr, "mirge_gz: %d chunks on %d threads: search %.4f, last hand-over %.4f, last chunk in place %.4f, join %.4f | per chunk: decode avg %.4f max %.4f, "
+                             "wait+history avg %.4f, bytes+crc avg %.4f | first chunk starts %.4f, last chunk starts %.4f\n",
+                     C, threads, t_search - t_call, link_last, fin_last, gz_now() - t_call, dec_sum / C, dec_max, wait_sum / C, conv_sum / C,
+                     t_start[0] - t_call, t_start[(size_t)C - 1] - t_call);
     }
     if (failed.load() == 2) return -2;
     if (failed.load() || C_eff < 1) return -1;
