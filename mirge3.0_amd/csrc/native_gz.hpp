@@ -69,7 +69,20 @@ static inline uint64_t bit_position(const BitReader& br, const uint8_t* data) {
 struct Huff {
     // first level: indexed by the next MIRGE_GZ_PRIMARY bits (LSB first).  An entry is (symbol << 4) | code length, or -- bit 31 --
     // a pointer for codes longer than the first level: (offset of a second-level table << 4), indexed by the bits behind them
-    std::vector<uint32_t> table;
+    // (a fixed array, filled as far as the code needs: the block-start search builds some hundred codes per chunk for candidates
+    // that turn out to be noise, and a heap allocation for each was most of what was left of its time.  Room: the first level and
+    // one second-level table of 2^(15 - 10) entries for every symbol that could open one.)
+    struct Table {
+        uint32_t v[((size_t)1 << MIRGE_GZ_PRIMARY) + (size_t)288 * 32];
+        size_t used = 0;
+        const uint32_t* data() const { return v; }
+        uint32_t& operator[](size_t i) { return v[i]; }
+        const uint32_t& operator[](size_t i) const { return v[i]; }
+        size_t size() const { return used; }
+        void assign(size_t n, uint32_t x) { used = n; std::fill(v, v + n, x); }
+        bool grow(size_t n, uint32_t x) { if (used + n > sizeof(v) / sizeof(v[0])) return false; std::fill(v + used, v + used + n, x); used += n; return true; }
+        void clear() { used = 0; }
+    } table;
     int pbits = 0, maxlen = 0;
     bool ok = false;
 };
@@ -104,7 +117,7 @@ static bool build_huff(const uint8_t* lens, int n, Huff& h, bool allow_single) {
             const uint32_t pre = r & (((uint32_t)1 << P) - 1u);
             if (!(h.table[pre] & 0x80000000u)) {  // this prefix's second-level table: 2^sub entries behind what is there
                 const uint32_t off = (uint32_t)h.table.size();
-                h.table.resize(h.table.size() + ((size_t)1 << sub), 0u);
+                if (!h.table.grow((size_t)1 << sub, 0u)) return false;
                 h.table[pre] = 0x80000000u | (off << 4);
             }
             const uint32_t off = (h.table[pre] & 0x7FFFFFFFu) >> 4;
@@ -172,6 +185,9 @@ static void fixed_codes(Huff& lit, Huff& dist) {
 }
 
 #define MIRGE_GZ_WINDOW 32768
+#ifndef MIRGE_GZ_TRIAL_SYMBOLS
+#define MIRGE_GZ_TRIAL_SYMBOLS 16384  // symbols of text a candidate block must decode into before the search accepts it
+#endif
 #ifndef MIRGE_GZ_RATIO_GUESS
 #define MIRGE_GZ_RATIO_GUESS 7  // symbols reserved per compressed byte of a chunk (FASTQ at level 6: 4-6); more grows the buffer
 #endif
@@ -219,12 +235,12 @@ struct SymBuf {
         Pool() { if (const char* e = std::getenv("MIRGE_GZ_KEEP_SYM_BYTES")) limit = (size_t)std::strtoull(e, nullptr, 10); }
     };
     static Pool& pool() { static Pool* pl = new Pool; return *pl; }  // (never destroyed: threads may still give back at exit)
-    void take() {  // the largest kept buffer, if any
+    void take(bool largest = true) {  // the largest (a chunk's decode) or the smallest (a block-start search) kept buffer, if any
         Pool& pl = pool();
         std::lock_guard<std::mutex> g(pl.mu);
         if (p || pl.kept.empty()) return;
         size_t best = 0;
-        for (size_t i = 1; i < pl.kept.size(); i++) if (pl.kept[i].second > pl.kept[best].second) best = i;
+        for (size_t i = 1; i < pl.kept.size(); i++) if ((pl.kept[i].second > pl.kept[best].second) == largest && pl.kept[i].second != pl.kept[best].second) best = i;
         p = pl.kept[best].first; cap = pl.kept[best].second;
         pl.bytes -= bytes_for(cap);
         pl.kept[best] = pl.kept.back();
@@ -280,10 +296,8 @@ static int decode_block(BitReader& br, SymBuf& out, size_t& o, bool known_histor
     const uint32_t dpm = dist.ok ? ((uint32_t)1 << dist.pbits) - 1u : 0u, dmm = dist.ok ? ((uint32_t)1 << dist.maxlen) - 1u : 0u;
     const int lpb = lit.pbits, dpb = dist.pbits;
     for (;;) {
-        if (o + 512 > out.size()) {
-            if (o + 512 > max_out) return done(-1);
-            if (!out.resize(std::max(out.size() * 2, o + (size_t)(1 << 16)))) return done(-1);
-        }
+        if (o + 512 > max_out) return done(text_only ? -3 : -1);  // -3: a trial decode reached its limit without a fault
+        if (o + 512 > out.size() && !out.resize(std::max(out.size() * 2, o + (size_t)(1 << 16)))) return done(-1);
         if (br.ran_off()) return done(-1);
         if (!text_only && br.nbits >= 0 && br.end - br.p >= 16) {
             // The fast loop (the real decode; the block-start search keeps to the careful step below): the reader's state in
@@ -373,24 +387,64 @@ static bool plausible_header(const uint8_t* data, size_t n, uint64_t bit) {
     return read_dynamic_header(br, a, b);
 }
 
-// first bit position >= from_bit (and < to_bit) at which a non-final dynamic block starts, decodes into text and is followed by
-// a well-formed header; UINT64_MAX if none
+// Kraft sums (in 1/128ths) of four 3-bit code lengths at once: the code-length code of a dynamic header is complete iff its
+// (up to 19) lengths sum to 128
+struct KraftTable {
+    uint16_t v[4096];
+    KraftTable() {
+        for (uint32_t x = 0; x < 4096; x++) {
+            uint32_t k = 0;
+            for (int j = 0; j < 4; j++) { const uint32_t l = (x >> (3 * j)) & 7u; if (l) k += 128u >> l; }
+            v[x] = (uint16_t)k;
+        }
+    }
+};
+// first bit position >= from_bit (and < to_bit) at which a non-final dynamic block starts, decodes into MIRGE_GZ_TRIAL_SYMBOLS symbols
+// of text -- or, when it is shorter, into text to its end with a well-formed header behind it --; UINT64_MAX if none
 static uint64_t find_block_start(const uint8_t* data, size_t n, uint64_t from_bit, uint64_t to_bit) {
+    static const KraftTable kraft_of;
     SymBuf tmp;
-    for (uint64_t bit = from_bit; bit < to_bit; bit++) {
-        const uint64_t byte = bit >> 3;
+    tmp.take(false);  // (a mapping of its own per search was most of the search phase: 180 mmap / fault / munmap rounds at once)
+    struct GiveBack { SymBuf& b; ~GiveBack() { b.give(); } } give_back{tmp};
+    for (uint64_t byte = from_bit >> 3; byte * 8 < to_bit; byte++) {
         if (byte + 8 >= n) break;
         uint64_t w;
         std::memcpy(&w, data + byte, 8);
-        const uint32_t head = (uint32_t)(w >> (bit & 7)) & 7u;
-        if (head != 4u) continue;  // BFINAL = 0, BTYPE = 10b (read LSB first: bits 0 | 0 1)
-        BitReader br(data, n, bit);
-        size_t to = 0;
-        const int rc = decode_block(br, tmp, to, false, true, (size_t)64 << 20);
-        if (rc != 0 || to < 1024) continue;  // (a real block of a text file holds thousands of symbols)
-        const uint64_t next = bit_position(br, data);
-        if (next + 64 > (uint64_t)n * 8 || !plausible_header(data, n, next)) continue;
-        return bit;
+        // bit s of `cand`: the three bits at shift s read BFINAL = 0, BTYPE = 10b (LSB first: 0 | 0 1)
+        uint32_t cand = (uint32_t)(~w & ~(w >> 1) & (w >> 2)) & 0xFFu;
+        if (byte == (from_bit >> 3)) cand &= 0xFFu << (from_bit & 7);
+        while (cand) {
+            const unsigned sh = (unsigned)__builtin_ctz(cand);
+            cand &= cand - 1;
+            const uint64_t bit = byte * 8 + sh;
+            if (bit >= to_bit) break;
+            if (byte + 16 <= n) {
+                // the cheap part of the header test, on two words of the data and without a reader or a table: HLIT / HDIST in
+                // range and the code-length code complete (what build_huff would find out) -- 99 % of the candidates end here
+                uint64_t w2;
+                std::memcpy(&w2, data + byte + 8, 8);
+                const unsigned __int128 full = (((unsigned __int128)w2 << 64) | (unsigned __int128)w) >> sh;
+                const uint32_t lo = (uint32_t)full;
+                const uint32_t hlit = (lo >> 3) & 31u, hdist = (lo >> 8) & 31u, hclen = ((lo >> 13) & 15u) + 4u;
+                if (hlit > 29u || hdist > 29u) continue;
+                const uint64_t cl = (uint64_t)(full >> 17) & ((1ull << (3 * hclen)) - 1ull);  // the 3-bit lengths of the code-length code (<= 57 bits)
+                const uint32_t kraft = (uint32_t)kraft_of.v[cl & 4095u] + kraft_of.v[(cl >> 12) & 4095u] + kraft_of.v[(cl >> 24) & 4095u] +
+                                       kraft_of.v[(cl >> 36) & 4095u] + kraft_of.v[(cl >> 48) & 4095u];
+                if (kraft != 128u) continue;
+            }
+            BitReader br(data, n, bit);
+            size_t to = 0;
+            // (the trial decode stops after MIRGE_GZ_TRIAL_SYMBOLS symbols of text: enough to tell a block from noise, and the
+            // real decode -- and in the end the CRC-32 -- check the rest; a whole block is ~150 k symbols, a third of the
+            // search's time)
+            const int rc = decode_block(br, tmp, to, false, true, (size_t)MIRGE_GZ_TRIAL_SYMBOLS);
+            if (rc == 0) {
+                if (to < 1024) continue;  // (a real block of a text file holds thousands of symbols)
+                const uint64_t next = bit_position(br, data);
+                if (next + 64 > (uint64_t)n * 8 || !plausible_header(data, n, next)) continue;
+            } else if (rc != -3) continue;
+            return bit;
+        }
     }
     return ~0ull;
 }
