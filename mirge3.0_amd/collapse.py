@@ -380,6 +380,34 @@ class ParallelGzipStream:
         return unwrap_fasta(bytes(t)) if bytes(t[:1]) == b">" else t
 
 
+def _host_memory_available() -> int:
+    """bytes of host memory this process may still take: MemAvailable, or what is left of the cgroup's limit when that is less"""
+    avail = 1 << 62
+    try:
+        with open("/proc/meminfo") as fh:
+            for ln in fh:
+                if ln.startswith("MemAvailable"):
+                    avail = int(ln.split()[1]) * 1024
+                    break
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max":
+                avail = min(avail, int(v) - int(open(cur).read().strip()))
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def _gz_fits_in_memory(path: str) -> bool:
+    """The parallel inflater holds the whole text in host memory (FASTQ deflates 4-6 x; the streamed route holds a few pieces): it is
+    taken only when eight times the compressed size is less than half of what the host has left."""
+    return 8 * _os.path.getsize(path) < _host_memory_available() // 2
+
+
 def read_text(path: str, stream: bool = False):
     """The file's bytes for the device-side parser (``mirge_reads_parse``): memory-mapped when plain; a ``.gz`` inflated whole,
     or -- ``stream=True`` -- as a ``GzipRecordStream`` whose worker has already started.  A FASTA whose sequences are wrapped
@@ -392,9 +420,10 @@ def read_text(path: str, stream: bool = False):
         data = None
         # (up to 8 GiB of compressed data -- the text is held whole in host memory, some 6 x that; beyond, the streamed route's
         # few pieces bound the memory a sample takes)
-        if stream and _os.environ.get("MIRGE_GZ_PARALLEL", "1") not in ("0", "whole") and (2 << 20) <= _os.path.getsize(path) <= (8 << 30):
+        takes = (2 << 20) <= _os.path.getsize(path) <= (8 << 30) and _gz_fits_in_memory(path)
+        if stream and _os.environ.get("MIRGE_GZ_PARALLEL", "1") not in ("0", "whole") and takes:
             return ParallelGzipStream(path)  # inflated on all cores, parsed beside; declines like the call below
-        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and (2 << 20) <= _os.path.getsize(path) <= (8 << 30):
+        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and takes:
             t0 = time.perf_counter()
             raw = np.fromfile(path, dtype=np.uint8)
             data = _ffi.gz_inflate(raw)

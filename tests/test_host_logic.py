@@ -441,6 +441,12 @@ def test_parallel_gzip_stream_parsed_beside_the_inflation(tmp_path):
     st = collapse.read_text(str(one), stream=True)
     assert isinstance(st, collapse.ParallelGzipStream)
     st.close()
+    # the whole text in host memory only where the host has it: otherwise the streamed route, whose pieces bound the memory
+    assert 0 < collapse._host_memory_available() < (1 << 62)
+    import unittest.mock
+    with unittest.mock.patch.object(collapse, "_host_memory_available", lambda: 16 * one.stat().st_size - 1):
+        st = collapse.read_text(str(one), stream=True)
+        assert isinstance(st, collapse.GzipRecordStream) and b"".join(st) == text
     assert bytes(collapse.read_text(str(one), stream=False)) == text
     bad = bytearray(one.read_bytes())
     bad[len(bad) // 2] ^= 0x10
