@@ -2225,6 +2225,46 @@ def test_streamed_gz_equals_the_plain_file(ctx, ci_libs, tmp_path):
         assert f == "annotation.report.csv" or (tmp_path / "gz" / f).read_text() == case.text(f), f
 
 
+def test_cli_several_large_gz_samples(ci_libs, tmp_path):
+    """Three samples in one invocation, two of them .fastq.gz large enough for the parallel inflater (read ahead on worker threads:
+    their inflations overlap each other and the first sample's parse; the text buffer of one serves the next), one plain: every
+    output file equals the run on the three plain files, and run.log says nothing went through zlib."""
+    import gzip
+    import subprocess
+    import sys
+    case = GoldenCase("case2_two_samples")
+    rng = np.random.default_rng(21)
+    plain, mixed = [], []
+    for k in range(3):
+        reads = synth.make_reads(ci_libs, 120000, seed=30 + k, n_frac=0.01).to_list()
+        recs = []
+        for i, q in enumerate(reads):
+            qual = "".join(chr(33 + int(x)) for x in rng.integers(2, 41, size=len(q)))
+            recs.append(f"@s{k}_{i}\n{q}\n+\n{qual}\n")
+        text = "".join(recs).encode()
+        p_ = tmp_path / f"S{k}.fastq"
+        p_.write_bytes(text)
+        plain.append(str(p_))
+        if k != 1:
+            (tmp_path / "z").mkdir(exist_ok=True)
+            z = tmp_path / "z" / f"S{k}.fastq.gz"
+            z.write_bytes(gzip.compress(text, 6))
+            assert z.stat().st_size > (2 << 20)
+            mixed.append(str(z))
+        else:
+            mixed.append(str(p_))
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for tag, fl in (("plain", plain), ("gz", mixed)):
+        cmd = [sys.executable, "-c", "import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()" % root,
+               "-s", ",".join(fl), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", tag, "-shh"]
+        r = subprocess.run(cmd, env=dict(os.environ, MIRGE_GZ_TIMING="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        if tag == "gz":
+            assert r.stderr.count("mirge_gz:") == 2, r.stderr[-2000:]  # both compressed samples took the parallel inflater
+    for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "annotation.report.csv"):
+        assert (tmp_path / "gz" / f).read_text() == (tmp_path / "plain" / f).read_text(), f
+
+
 def test_cli_library_cache_next_to_the_index(tmp_path):
     """The one-time conversion kept next to the index (libcache.py): a first CLI run on a fresh copy of golden case 1's
     library directory writes <index>.mirge3amd for every library, a second run loads them (mirge_lib_create_packed: no
