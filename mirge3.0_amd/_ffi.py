@@ -158,7 +158,7 @@ def gz_inflate(data, threads: int = 0) -> Optional[np.ndarray]:
     except MemoryError:  # (a host that does not overcommit): the streamed route needs pieces only
         return None
     n = C.c_int64(0)
-    rc = load().mirge_gz_inflate(_p(buf), C.c_int64(buf.size), _p(out), C.c_int64(cap), C.byref(n), C.c_int32(threads))
+    rc = load().mirge_gz_inflate(_p(buf), C.c_int64(buf.size), _p(out), C.c_int64(cap), C.byref(n), C.c_int32(threads or gz_threads()))
     if rc != 0:
         return None
     return out[: n.value]
@@ -169,6 +169,16 @@ def gz_inflate(data, threads: int = 0) -> Optional[np.ndarray]:
 # a 0.15 s sample.  One buffer, at most MIRGE_GZ_KEEP_BYTES (default 16 GiB of address space; what a sample touched stays resident).
 _gz_kept: list = []
 _GZ_KEEP_BYTES = int(os.environ.get("MIRGE_GZ_KEEP_BYTES", str(16 << 30)))
+
+
+def gz_threads() -> int:
+    """host threads one inflation takes: MIRGE_GZ_THREADS, else the cores divided among the ranks of this node (one process per GPU:
+    eight samples inflate side by side), at most 64 (beyond, nothing is gained)"""
+    env = os.environ.get("MIRGE_GZ_THREADS")
+    if env:
+        return max(1, int(env))
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(64, (os.cpu_count() or 1) // ranks))
 
 
 class GzInflation:
@@ -207,7 +217,7 @@ class GzInflation:
 
         def run():
             rc = lib.mirge_gz_inflate_progress(_p(self.buf), C.c_int64(self.buf.size), _p(self.out), C.c_int64(cap), C.byref(self._n),
-                                               C.c_int32(threads), C.byref(self._progress))
+                                               C.c_int32(threads or gz_threads()), C.byref(self._progress))
             self.ok = rc == 0
 
         self._thread = threading.Thread(target=run, name="mirge-gz-inflate", daemon=True)
