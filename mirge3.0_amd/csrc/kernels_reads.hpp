@@ -251,6 +251,7 @@ struct SliceOpts {
     int32_t min_len_pre;
     int32_t min_len;
     int32_t cut_front, cut_back;
+    int32_t exact_bounds;  // 1: [start, end) are the caller's own bounds (mirge_reads_pack) -- no '\r' is stripped from the end
 };
 
 // flags: [0] reads with N seen per group ... kept by k_pack; here [0] = byte outside ACGTUN seen, [1] = reads longer
@@ -270,7 +271,7 @@ __global__ void k_seq_class(const uint8_t* __restrict__ text, int64_t* __restric
     if (r < n_seq) {
         int64_t b = start[r];
         int64_t e = end[r];
-        if (e > b && text[e - 1] == 13) e--;
+        if (!so.exact_bounds && e > b && text[e - 1] == 13) e--;
         const int64_t L1 = e - b, L2 = s2len ? (int64_t)s2len[r] : 0, tot = L1 + L2;
         const int64_t x = so.cut_front < tot ? so.cut_front : tot;
         int64_t y = tot - so.cut_back;

@@ -174,98 +174,48 @@ static int launch_pack_long(mirge_ctx* c, const uint8_t* dascii, const int64_t* 
     return 0;
 }
 
+struct ParseJob;
+static int pack_from_host_offsets(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads* R);
+
+// Reads in host memory (one ASCII buffer + n + 1 offsets) -> packed reads.  The host only checks the offsets (monotone, lengths
+// within the limit: a few ms on a few threads); the letters go to the device as they are and take the text parser's route from
+// there -- classification, stable placement by read group and 2-bit packing are k_seq_class / k_seq_place / k_pack with
+// [off[i], off[i + 1]) for the line bounds.  (Until round 4 the host classified every read on up to 32 threads and uploaded
+// an index per group: 40 of the 69 ms of the PCIe-inclusive path.)
 extern "C" int mirge_reads_pack(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads** out) {
     if (!c || !out || !off || n < 0 || (n > 0 && !ascii)) return fail(-1, "mirge_reads_pack: bad argument");
     if (n >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
-    auto R = std::make_unique<mirge_reads>();
-    R->ctx = c; R->n = n;
-    std::memset(R->len_hist, 0, sizeof(R->len_hist));
-    std::vector<uint32_t> idx[MIRGE_NGROUPS];
-    bool is_acgt[256] = {false};
-    for (const char* q = "ACGTUacgtu"; *q; q++) is_acgt[(unsigned char)*q] = true;
     {
-        // classify the reads (width class x has-an-ambiguous-call) on all host cores: this byte scan is the
-        // largest host cost of the PCIe-inclusive path
-        const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-        const int T = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
-        std::vector<std::vector<uint32_t>> part((size_t)T * MIRGE_NGROUPS);
-        std::vector<std::vector<int32_t>> hist((size_t)T, std::vector<int32_t>(MIRGE_MAX_READ_LEN + 1, 0));
-        std::vector<int64_t> bad((size_t)T, -1), badlen((size_t)T, 0), longest((size_t)T, 0);
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const int T = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 1000000));
+        std::vector<int64_t> bad((size_t)T, -1), badlen((size_t)T, 0);
         auto work = [&](int t) {
             const int64_t lo = n * t / T, hi = n * (t + 1) / T;
             for (int64_t i = lo; i < hi; i++) {
                 const int64_t L = off[i + 1] - off[i];
-                if (L < 0 || L > MIRGE_LONG_MAX_LEN) { if (bad[t] < 0) { bad[t] = i; badlen[t] = L; } continue; }
-                if (L <= MIRGE_MAX_READ_LEN) hist[t][L]++;
-                else longest[t] = std::max<int64_t>(longest[t], L);
-                bool amb = false;
-                for (int64_t b = off[i]; b < off[i + 1]; b++) amb |= !is_acgt[(unsigned char)ascii[b]];
-                part[(size_t)t * MIRGE_NGROUPS + width_class(L) + (amb ? MIRGE_NWIDTHS : 0)].push_back((uint32_t)i);
+                if ((L < 0 || L > MIRGE_LONG_MAX_LEN) && bad[(size_t)t] < 0) { bad[(size_t)t] = i; badlen[(size_t)t] = L; }
             }
         };
         std::vector<std::thread> th;
         for (int t = 1; t < T; t++) th.emplace_back(work, t);
         work(0);
         for (auto& x : th) x.join();
-        for (int t = 0; t < T; t++) {
-            if (bad[t] >= 0) {
-                if (badlen[t] < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
-                return fail(-6, "read " + std::to_string(bad[t]) + " is " + std::to_string(badlen[t]) + " nt; the limit is " +
+        for (int t = 0; t < T; t++)
+            if (bad[(size_t)t] >= 0) {
+                if (badlen[(size_t)t] < 0) return fail(-1, "mirge_reads_pack: offsets not monotone");
+                return fail(-6, "read " + std::to_string(bad[(size_t)t]) + " is " + std::to_string(badlen[(size_t)t]) + " nt; the limit is " +
                                 std::to_string(MIRGE_LONG_MAX_LEN));
             }
-            for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) R->len_hist[L] += hist[t][L];
-            R->long_max = std::max<int32_t>(R->long_max, (int32_t)longest[t]);
-        }
-        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {  // thread ranges are consecutive: order is preserved
-            size_t tot = 0;
-            for (int t = 0; t < T; t++) tot += part[(size_t)t * MIRGE_NGROUPS + gi].size();
-            idx[gi].reserve(tot);
-            for (int t = 0; t < T; t++) {
-                auto& v = part[(size_t)t * MIRGE_NGROUPS + gi];
-                idx[gi].insert(idx[gi].end(), v.begin(), v.end());
-            }
-        }
     }
+    auto R = std::make_unique<mirge_reads>();
+    R->ctx = c; R->n = 0;
+    std::memset(R->len_hist, 0, sizeof(R->len_hist));
     R->hist_valid = true;
-    R->total_bases = n ? off[n] - off[0] : 0;
-    const int64_t nbytes = R->total_bases;
-    uint8_t* dascii = nullptr; int64_t* doff = nullptr; uint32_t* dflags = nullptr;
-    CHECK(dalloc(c, &dascii, (size_t)std::max<int64_t>(nbytes, 1)));
-    CHECK(dalloc(c, &doff, (size_t)n + 1));
-    CHECK(dalloc(c, &dflags, 2 * MIRGE_NGROUPS + 4));
-    std::vector<int64_t> rel((size_t)n + 1);
-    for (int64_t i = 0; i <= n; i++) rel[(size_t)i] = off[i] - off[0];
-    if (nbytes) HIPOK(hipMemcpyAsync(dascii, ascii + off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemcpyAsync(doff, rel.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPOK(hipMemsetAsync(dflags, 0, 2 * MIRGE_NGROUPS * 4, c->stream));
-    uint32_t* didx[MIRGE_NGROUPS] = {nullptr};
-    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
-        ReadGroup& g = R->g[gi];
-        g.W = is_long_group(gi) ? (R->long_max + 31) / 32 : kGroupW[gi];
-        g.n = (uint32_t)idx[gi].size();
-        if (!g.n) continue;
-        CHECK(dalloc(c, &g.seq, (size_t)g.W * g.n));
-        CHECK(dalloc(c, &g.nmask, (size_t)g.W * g.n));
-        CHECK(dalloc(c, &g.len, (size_t)g.n * len_bytes(gi)));
-        CHECK(dalloc(c, &g.orig, (size_t)g.n));
-        HIPOK(hipMemcpyAsync(g.orig, idx[gi].data(), (size_t)g.n * 4, hipMemcpyHostToDevice, c->stream));
-        didx[gi] = g.orig;
-        int prc = 0;
-        if (is_long_group(gi)) prc = launch_pack_long(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi);
-        else MIRGE_BY_WIDTH(gi, prc, launch_pack<W>(c, dascii, doff, doff + 1, didx[gi], g, dflags + 2 * gi));
-        (void)prc;
-    }
-    HIPOK(hipMemcpyAsync(c->pinned, dflags, 2 * MIRGE_NGROUPS * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPOK(hipStreamSynchronize(c->stream));  // idx/rel host vectors are read by the async copies
-    c->release(dascii); c->release(doff); c->release(dflags);
-    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
-        if (c->pinned[2 * gi + 1]) {
-            mirge_reads_destroy(R.release());
-            return fail(-7, "a read contains a character that is no nucleotide code (A/C/G/T/U/N or an IUPAC ambiguity code)");
-        }
-        if (c->pinned[2 * gi] & 2u) R->iupac_seen = true;
-        if (!c->pinned[2 * gi] && R->g[gi].nmask) { c->release(R->g[gi].nmask); R->g[gi].nmask = nullptr; }
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
+    if (n > 0) {
+        const int rc = pack_from_host_offsets(c, ascii, off, n, R.get());
+        if (rc) { mirge_reads_destroy(R.release()); return rc; }
     }
     *out = R.release();
     return 0;
@@ -545,6 +495,33 @@ static int parse_pack(ParseJob& J, int64_t* start, int64_t* end, int64_t* s2star
     if (rc) { c->release(rok); return rc; }
     if (rec_of_kept) *rec_of_kept = rok;
     return 0;
+}
+
+static int pack_from_host_offsets(mirge_ctx* c, const char* ascii, const int64_t* off, int64_t n, mirge_reads* R) {
+    const int64_t nbytes = off[n] - off[0];
+    if ((uint64_t)nbytes + 1 >= (1ull << 33)) return fail(-5, "mirge_reads_pack: 8 GiB of letters or more must be passed in parts (mirge_reads_concat)");
+    ParseJob J;
+    J.c = c; J.format = 3;
+    J.n = (uint64_t)nbytes + 1;
+    J.n_raw = J.n_seq = (uint32_t)n;
+    CHECK(dalloc(c, &J.dtext, (size_t)nbytes + 16));
+    CHECK(dalloc(c, &J.dstart, (size_t)n + 1));  // the offsets, relative to the first letter
+    CHECK(dalloc(c, &J.dend, (size_t)n));         // (k_seq_class writes the bounds back: two arrays, not one read at two offsets)
+    CHECK(dalloc(c, &J.lflags, (size_t)MIRGE_LFLAG_WORDS));
+    HIPOK(hipMemsetAsync(J.lflags, 0, MIRGE_LFLAG_WORDS * 4, c->stream));
+    if (nbytes) HIPOK(hipMemcpyAsync(J.dtext, ascii + off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    std::vector<int64_t> rel;
+    const int64_t* src = off;
+    if (off[0] != 0) {
+        rel.resize((size_t)n + 1);
+        for (int64_t i = 0; i <= n; i++) rel[(size_t)i] = off[i] - off[0];
+        src = rel.data();
+    }
+    HIPOK(hipMemcpyAsync(J.dstart, src, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPOK(hipMemcpyAsync(J.dend, J.dstart + 1, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPOK(hipStreamSynchronize(c->stream));  // (`rel` is read by the copy)
+    const SliceOpts so{0, 0, 0, 0, 1};  // every read is kept, whatever its length, exactly as the offsets bound it
+    return parse_pack(J, J.dstart, J.dend, nullptr, nullptr, (uint32_t)n, so, R, nullptr);
 }
 
 static void reads_clear_groups(mirge_reads* r) {
