@@ -220,7 +220,8 @@ class GzInflation:
                                                C.c_int32(threads or gz_threads()), C.byref(self._progress))
             self.ok = rc == 0
 
-        self._thread = threading.Thread(target=run, name="mirge-gz-inflate", daemon=True)
+        # (not a daemon: the interpreter waits for it at exit -- a fraction of a second -- instead of freeing the buffers under it)
+        self._thread = threading.Thread(target=run, name="mirge-gz-inflate", daemon=False)
         self._thread.start()
 
     def done(self) -> int:
