@@ -336,20 +336,23 @@ struct ParseJob {
 };
 #define MIRGE_LFLAG_WORDS 8  // [3] record structure broken, [5] quality line length != sequence line length
 
-static int parse_lines(ParseJob& J, const char* text, int64_t nbytes, const TrimOpts* topt, const mirge_umi* umi) {
+// spare_blank: empty lines that stood behind text[nbytes - 1] in the caller's buffer (the entry point strips the blank end of a
+// file): as many of them as complete the last record are lines after all -- a record whose sequence (and quality) is empty, which a
+// file trimmed without a minimum length ends with now and then.
+static int parse_lines(ParseJob& J, const char* text, int64_t nbytes, const TrimOpts* topt, const mirge_umi* umi, int spare_blank = 0) {
     mirge_ctx* c = J.c;
     const int format = J.format;
     const bool trimming = topt && topt->n_mods > 0;
     const int period = format == 1 ? 4 : (format == 2 ? 2 : 1), sphase = format == 3 ? 0 : 1;
     // the text, with a final newline
-    const uint64_t n = (uint64_t)nbytes + 1;
+    uint64_t n = (uint64_t)nbytes + 1;
     J.n = n;
     // lines are counted in 32 bits: below 8 GiB a text would need lines of less than two bytes to wrap the counter
     if (n >= (1ull << 33)) return fail(-5, "mirge_reads_parse: a text of 8 GiB or more must be passed in parts (mirge_reads_concat)");
-    const uint32_t ntile = (uint32_t)((n + MIRGE_PARSE_TILE - 1) / MIRGE_PARSE_TILE);
+    uint32_t ntile = (uint32_t)((n + MIRGE_PARSE_TILE - 1) / MIRGE_PARSE_TILE);
     CHECK(dalloc(c, &J.dtext, (size_t)n + 16));
-    CHECK(dalloc(c, &J.tile_cnt, (size_t)ntile + 1));
-    CHECK(dalloc(c, &J.tile_off, (size_t)ntile + 1));
+    CHECK(dalloc(c, &J.tile_cnt, (size_t)ntile + 2));  // (+ 1: the few line ends the spare blank lines may add can open a tile)
+    CHECK(dalloc(c, &J.tile_off, (size_t)ntile + 2));
     CHECK(dalloc(c, &J.lflags, (size_t)MIRGE_LFLAG_WORDS));
     HIPOK(hipMemcpyAsync(J.dtext, text, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     HIPOK(hipMemsetAsync(J.dtext + nbytes, '\n', 1, c->stream));
@@ -364,6 +367,20 @@ static int parse_lines(ParseJob& J, const char* text, int64_t nbytes, const Trim
     uint32_t n_lines = 0;
     HIPOK(hipMemcpyAsync(&n_lines, J.tile_off + ntile, 4, hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));
+    if (n_lines % (uint32_t)period != 0 && (int)(period - n_lines % (uint32_t)period) <= spare_blank) {
+        // the last record's empty lines: give them back (they fit the 16 bytes of slack) and count again
+        const uint32_t need = (uint32_t)period - n_lines % (uint32_t)period;
+        HIPOK(hipMemsetAsync(J.dtext + n, '\n', need, c->stream));
+        n += need;
+        J.n = n;
+        ntile = (uint32_t)((n + MIRGE_PARSE_TILE - 1) / MIRGE_PARSE_TILE);
+        HIPOK(hipMemsetAsync(J.tile_cnt + ntile, 0, 4, c->stream));
+        hipLaunchKernelGGL(k_nl_count, dim3(ntile), dim3(MIRGE_BLOCK), 0, c->stream, J.dtext, n, J.tile_cnt);
+        size_t tb2 = J.tmp_cap;
+        HIPOK(hipcub::DeviceScan::ExclusiveSum(J.tmp, tb2, J.tile_cnt, J.tile_off, (int)(ntile + 1), c->stream));
+        HIPOK(hipMemcpyAsync(&n_lines, J.tile_off + ntile, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPOK(hipStreamSynchronize(c->stream));
+    }
     if (n_lines % (uint32_t)period != 0)
         return fail(-9, "mirge_reads_parse: " + std::to_string(n_lines) + " lines is not a whole number of " + std::to_string(period) +
                             "-line records (truncated file, blank line, or a FASTA with wrapped sequences)");
@@ -560,11 +577,16 @@ extern "C" int mirge_reads_parse_umi(mirge_ctx* c, const char* text, int64_t nby
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) R->g[gi].W = kGroupW[gi];
     if (n_records) *n_records = 0;
     // blank lines at the end of the file are not records (dnaio stops at them too)
-    while (nbytes > 0 && (text[nbytes - 1] == '\n' || text[nbytes - 1] == '\r' || text[nbytes - 1] == ' ' || text[nbytes - 1] == '\t')) nbytes--;
+    int tail_line_ends = 0;
+    while (nbytes > 0 && (text[nbytes - 1] == '\n' || text[nbytes - 1] == '\r' || text[nbytes - 1] == ' ' || text[nbytes - 1] == '\t')) {
+        if (text[nbytes - 1] == '\n' && tail_line_ends < 8) tail_line_ends++;
+        nbytes--;
+    }
     if (nbytes == 0) { *out = R.release(); return 0; }
     ParseJob J;
     J.c = c; J.format = format;
-    int rc = parse_lines(J, text, nbytes, trim ? &topt : nullptr, umi);
+    // (the first of the stripped line ends closed the last line with a letter in it; the others closed empty lines)
+    int rc = parse_lines(J, text, nbytes, trim ? &topt : nullptr, umi, format == 3 ? 0 : std::max(0, tail_line_ends - 1));
     if (rc) { mirge_reads_destroy(R.release()); return rc; }
     if (n_records) *n_records = J.n_raw;
     const int32_t f = umi ? umi->front : 0, b = umi ? umi->back : 0;

@@ -2225,6 +2225,44 @@ def test_streamed_gz_equals_the_plain_file(ctx, ci_libs, tmp_path):
         assert f == "annotation.report.csv" or (tmp_path / "gz" / f).read_text() == case.text(f), f
 
 
+def test_last_record_with_an_empty_read(ctx):
+    """A file trimmed without a minimum length ends with an empty read now and then: '@r' / '' / '+' / ''.  The blank end of a file
+    is stripped before the parse -- but as many of its empty lines as complete the last record are lines (dnaio reads such a record
+    too: one more input read, dropped by the length filter); blank lines beyond that are no records, and a file that ends inside a
+    record is still refused."""
+    seq = "TGAGGTAGTAGGTTGTATAGTT"
+    for eol in ("\n", "\r\n"):
+        fq = f"@a{eol}{seq}{eol}+{eol}{'I' * 22}{eol}@b{eol}{eol}+{eol}{eol}"
+        fa = f">a{eol}{seq}{eol}>b{eol}{eol}"
+        for fmt, text in ((1, fq), (2, fa)):
+            for extra in ("", eol, eol * 3, " " + eol):
+                dr, n_rec = _ffi.DeviceReads.parse(ctx, (text + extra).encode(), fmt, 0)
+                assert n_rec == 2 and dr.unpack().to_list() == [seq, ""], (fmt, eol, extra)
+                dr.close()
+                dr, n_rec = _ffi.DeviceReads.parse(ctx, (text + extra).encode(), fmt, 16)
+                assert n_rec == 2 and dr.unpack().to_list() == [seq]
+                dr.close()
+        # two empty records at the end; an empty record in the middle
+        dr, n_rec = _ffi.DeviceReads.parse(ctx, (fq + f"@c{eol}{eol}+{eol}{eol}").encode(), 1, 0)
+        assert n_rec == 3 and dr.unpack().to_list() == [seq, "", ""]
+        dr.close()
+        dr, n_rec = _ffi.DeviceReads.parse(ctx, (f"@b{eol}{eol}+{eol}{eol}" + fq[: fq.index("@b")]).encode(), 1, 0)
+        assert n_rec == 2 and dr.unpack().to_list() == ["", seq]
+        dr.close()
+        # the file ends inside a record: no final line end behind the '+' line -- three lines, refused as before
+        with pytest.raises(RuntimeError, match="whole number"):
+            _ffi.DeviceReads.parse(ctx, f"@a{eol}{seq}{eol}+{eol}{'I' * 22}{eol}@b{eol}{eol}+".encode(), 1, 0)
+        with pytest.raises(RuntimeError, match="whole number"):
+            _ffi.DeviceReads.parse(ctx, f"@a{eol}{seq}{eol}+{eol}{'I' * 22}{eol}@b{eol}".encode(), 1, 0)
+    # pieces of a stream end the same way
+    from mirge3_amd import collapse
+    text = ("".join(f"@r{i}\n{seq if i % 3 else ''}\n+\n{'I' * (22 if i % 3 else 0)}\n" for i in range(300))).encode()
+    whole, n_whole = collapse.parse_sample(ctx, text, 0, None, None)
+    parts, n_parts = collapse.parse_sample(ctx, collapse.TextRecordStream(text, 120), 0, None, None)
+    assert n_whole == n_parts == 300 and parts.unpack().to_list() == whole.unpack().to_list() == [seq if i % 3 else "" for i in range(300)]
+    whole.close(); parts.close()
+
+
 def test_cli_several_large_gz_samples(ci_libs, tmp_path):
     """Three samples in one invocation, two of them .fastq.gz large enough for the parallel inflater (read ahead on worker threads:
     their inflations overlap each other and the first sample's parse; the text buffer of one serves the next), one plain: every
