@@ -103,9 +103,11 @@ def parse_args(argv=None):
     ap.add_argument("-N", "--no-match-adapter-wildcards", dest="match_adapter_wildcards", action="store_false", default=True, help=argparse.SUPPRESS)
     ap.add_argument("-qumi", "--qiagenumi", dest="qiagenumi", action="store_true",
                     help="with -umi 0,b and -a: the UMI is the b bases that follow the 3' adapter (Qiagen libraries)")
-    for flag in ("-nmir", "-bam", "-trf", "-mEC", "-dex"):
-        ap.add_argument(flag, dest="oos_" + flag.strip("-"), default=None, nargs="?", const=True,
+    for flags in (("-nmir", "--novel-miRNA"), ("-bam", "--bam-out"), ("-trf", "--tRNA-frag"), ("-mEC", "--miREC"), ("-dex", "--diffex")):
+        ap.add_argument(*flags, dest="oos_" + flags[0].strip("-"), default=None, nargs="?", const=True,
                         help=argparse.SUPPRESS)
+    from . import __version__ as _version
+    ap.add_argument("--version", action="version", version=str(_version))
     args = ap.parse_args(argv)
     for k, v in vars(args).items():
         if k.startswith("oos_") and v is not None:
