@@ -12,9 +12,11 @@
 #define MIRGE_LETTERS_ACGTU ((1u << 0) | (1u << 2) | (1u << 6) | (1u << 19) | (1u << 20))
 #define MIRGE_LETTERS_N (1u << 13)
 #define MIRGE_LETTERS_IUPAC ((1u << 17) | (1u << 24) | (1u << 18) | (1u << 22) | (1u << 10) | (1u << 12) | (1u << 1) | (1u << 3) | (1u << 7) | (1u << 21))
+// ('.' -- the no-call of Illumina's old pipelines, which bowtie reads as N -- arrives here as 0x0E after the upper-casing mask and is
+// taken for an ambiguity code: aligned and printed as N, the run warns as it does for IUPAC codes)
 __device__ __forceinline__ uint32_t letter_bit(uint8_t upper) {
     const uint32_t d = (uint32_t)upper - 'A';
-    return d < 26u ? 1u << d : 0u;
+    return d < 26u ? 1u << d : (upper == ('.' & 0xDF) ? 1u << 17 : 0u);
 }
 __device__ __forceinline__ bool is_iupac_code(uint8_t c) { return (letter_bit(c) & MIRGE_LETTERS_IUPAC) != 0; }
 

@@ -431,6 +431,11 @@ def test_edge_cases(ctx, ci_libs, ci_cascade):
     plain = _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGTNACGTACGTACGTA"]))
     assert not plain.iupac_seen
     plain.close()
+    # '.', the no-call of Illumina's old pipelines (bowtie reads it as N): the same, through both entry points and in a long read
+    for dots in (_ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(["ACGT.ACGTACGTACGT.", "A" * 299 + "."])),
+                 _ffi.DeviceReads.parse(ctx, b"@a\nACGT.ACGTACGTACGT.\n+\nIIIIIIIIIIIIIIIIII\n@b\n" + b"A" * 299 + b".\n+\n" + b"I" * 300 + b"\n", 1, 16)[0]):
+        assert dots.iupac_seen and dots.unpack().to_list() == ["ACGTNACGTACGTACGTN", "A" * 299 + "N"]
+        dots.close()
     # lower-case and U are accepted as their upper-case / T
     a = ci_cascade.annotate(FlatSeqs.from_list([ci_libs.libs["mirna"].seqs.get(3).lower().replace("t", "u")]))
     b = ci_cascade.annotate(FlatSeqs.from_list([ci_libs.libs["mirna"].seqs.get(3)]))
