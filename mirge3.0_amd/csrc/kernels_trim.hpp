@@ -144,7 +144,7 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
             int sum = 0, mx = 0, stop = a1;
             for (int i = a1 - 1; i >= a0; i--) {
                 int qq = (int)q[i] - o.base;
-                if ((s[i] & 0xDF) == 'G') qq = o.nextseq - 1;
+                if (s[i] == 'G') qq = o.nextseq - 1;  // (cutadapt's `bases[i] == 'G'`: a lower-case g keeps its own quality)
                 sum += o.nextseq - qq;
                 if (sum < 0) break;
                 if (sum > mx) { mx = sum; stop = i; }

@@ -154,7 +154,7 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
         if getattr(args, "tcf_out", False):
             write_tcf(workDir / (str(name) + ".trim.collapse.fa"), raw)
         if raw.iupac_seen:
-            say(f'WARNING: {name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N')
+            say(f"WARNING: {name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N")
         parsed.append(raw)
         say(f'Cutadapt finished for file {name} in {round(time.perf_counter() - t, 4)} second(s)')
     tm["read_files_s"], tm["parse_s"] = t_read, t_parse
@@ -290,7 +290,7 @@ def run_sharded_rank0(args, tables, workDir, ref_db: str, casc):
     with open(workDir / "run.log", "a+") as outlog:
         for t in tables:
             if t.reads.iupac:
-                outlog.write(f'WARNING: {t.name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N\n')
+                outlog.write(f"WARNING: {t.name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N\n")
     uniq, ps, ref = merge_sample_reads(casc.ctx, [t.reads for t in tables])
     counts, first = uniq.counts()
     res = None

@@ -804,8 +804,10 @@ def trim_stages(seq: str, qual, opts: dict):
         for _ in range(times):  # -n COUNT: `for _ in range(self.times): match = best_match(...); if match is None: break`
             best = None
             for kind, ad in opts["adapters"]:
+                # (cutadapt's aligner translates lower-case letters like upper-case ones -- `_acgt_table`: "Lowercase versions are
+                # also translated" --: the search is case-blind for either kind of adapter, the read keeps its letters)
                 hit = (adapter_locate_front if kind == "front" else adapter_locate_back)(
-                    ad, seq.upper() if kind == "front" else seq, opts.get("error_rate", 0.12), opts.get("overlap", 3), indels, rw, aw)
+                    ad, seq.upper(), opts.get("error_rate", 0.12), opts.get("overlap", 3), indels, rw, aw)
                 if hit is not None and (best is None or hit[4] > best[1][4] or (hit[4] == best[1][4] and hit[5] < best[1][5])):
                     best = (kind, hit)
             if best is None:
@@ -821,7 +823,7 @@ def trim_stages(seq: str, qual, opts: dict):
             qual = qual[hit[3]:] if qual is not None else None
         out.append(seq)
     elif opts.get("adapter"):
-        hit = adapter_locate_back(opts["adapter"], seq, opts.get("error_rate", 0.12), opts.get("overlap", 3))
+        hit = adapter_locate_back(opts["adapter"], seq.upper(), opts.get("error_rate", 0.12), opts.get("overlap", 3))
         if hit is not None:
             seq = seq[:hit[2]]
             qual = qual[:hit[2]] if qual is not None else None

@@ -651,3 +651,23 @@ def test_library_cache_round_trip_and_invalidation(tmp_path, monkeypatch):
         assert p2.startswith(str(tmp_path / "xdg")) and load_index(str(ro / "human_rrna")).cache_path == p2
     finally:
         os.chmod(ro, 0o755)
+
+
+def test_every_python_file_compiles_and_imports():
+    """Every .py of the package, bench.py, __graft_entry__.py and tools/ byte-compiles, and every package module imports without a
+    GPU (several are imported lazily by the CLI -- fastpath, a2i, gff --: a syntax error there would show only on the GPU box)."""
+    import glob
+    import importlib
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    files = glob.glob(os.path.join(root, "mirge3.0_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(root, "tools", "*.py")) + \
+        glob.glob(os.path.join(root, "profiles", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 15
+    for f in files:
+        with open(f, "rb") as fh:
+            compile(fh.read(), f, "exec")  # (raises SyntaxError; nothing is written next to the sources)
+    import mirge3_amd  # noqa: F401
+    for f in sorted(glob.glob(os.path.join(root, "mirge3.0_amd", "*.py"))):
+        name = os.path.basename(f)[:-3]
+        if name not in ("__init__", "__main__"):
+            importlib.import_module("mirge3_amd." + name)
+
