@@ -295,3 +295,73 @@ def test_random_trimming_options_equal_the_restated_chain(seed):
     assert n_rec == len(recs) and got == list(want.items()), opts
     uniq.close(); raw.close(); ctx.close()
 
+
+@pytest.mark.parametrize("seed", range(max(6, N_FUZZ // 3)))
+def test_random_umi_options_equal_the_restated_worker(seed, tmp_path):
+    """mirge_reads_parse_umi under RANDOM options -- -umi f,b with f 0-8 and b 0-12, --qiagenumi, -udd, with or without the 3'
+    adapter, quality cutoffs, the count after every modifier or once, minimum length 0-16 -- on UMI-library reads (damaged or cut
+    adapters, reads that end inside the UMI, empty reads, low-quality ends; lower-case reads only without -udd: the device packs
+    letters, so 'acgt' and 'ACGT' are one molecule here and two dictionary keys in the reference) against the oracle's restatement
+    of the worker's UMI branches and baking's UMI stage: the dictionary in order, 'Trimmed Reads (all)', <sample>_umiCounts.csv."""
+    from mirge3_amd.collapse import parse_sample
+    rng = np.random.default_rng(9000 + seed)
+    ctx = _ffi.Context(0)
+    qiagen = bool(rng.random() < 0.35)
+    f = 0 if qiagen and rng.random() < 0.8 else int(rng.integers(0, 9))
+    b = int(rng.integers(0, 13))
+    dedup = bool(rng.random() < 0.5)
+    adapter = _rseq(rng, int(rng.integers(8, 30)))
+    q_back, q_front = int(rng.integers(0, 25)), int(rng.choice([0, 0, 8, 15]))
+    per_mod = bool(rng.random() < 0.5)
+    min_len = int(rng.choice([0, 1, 10, 16]))
+    use_adapter = qiagen or rng.random() < 0.8
+    inserts = [_rseq(rng, int(rng.integers(0, 40))) for _ in range(40)] + ["A" * 20, "ACGTACGTACGTACGTACGGACGTACGTACGTACGTAC"]
+    umis = [_rseq(rng, f + b) for _ in range(7)]
+    recs = []
+    for i in range(1200):
+        ins = inserts[int(rng.integers(0, len(inserts)))]
+        u = umis[int(rng.integers(0, len(umis)))]
+        ad = list(adapter)
+        kind = int(rng.integers(0, 9))
+        if kind == 1:
+            ad[int(rng.integers(0, len(ad)))] = "ACGT"[int(rng.integers(0, 4))]
+        elif kind == 2 and len(ad) > 3:
+            del ad[int(rng.integers(1, len(ad) - 1))]
+        ad = "".join(ad)
+        ext = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"
+        seq = (ins + ad + u[f:] + ext) if qiagen else (u[:f] + ins + u[f:] + ad + ext)
+        seq = seq[:int(rng.integers(10, 100))] if kind in (3, 4) else seq[:90]
+        if kind == 5:
+            seq = ins
+        if kind == 6:
+            seq = ""
+        if kind == 7 and rng.random() < 0.5 and not dedup:
+            seq = seq.lower()
+        q = np.full(len(seq), ord("I"), dtype=np.uint8)
+        if rng.random() < 0.25 and len(seq):
+            q[-int(rng.integers(1, 12)):] = rng.integers(33, 48, size=1)[0]
+        if rng.random() < 0.05 and len(seq):
+            q[:int(rng.integers(1, 4))] = 35
+        recs.append((seq, q.tobytes().decode()))
+    text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+    trim = _ffi.MirgeTrim.make(adapter=adapter if use_adapter else None, quality_back=q_back, quality_front=q_front, count_per_modifier=per_mod)
+    raw, n_rec = parse_sample(ctx, text, min_len, trim, _ffi.MirgeUmi.make(f, b, qiagen=qiagen, dedup=dedup), tmp_path, "S")
+    uniq = raw.collapse()
+    cnt, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    order = np.argsort(first, kind="stable")
+    got, n = [(seqs[i], int(cnt[i, 0])) for i in order], len(raw)
+    uniq.close(); raw.close(); ctx.close()
+    csvf = tmp_path / "S_umiCounts.csv"
+    csv = csvf.read_text() if csvf.exists() else None
+    o = dict(q_back=q_back, q_front=q_front)
+    if use_adapter:
+        o["adapter"] = adapter
+    keys = oracle.umi_worker_reads(recs, o, f, b, min_len, qiagen, per_mod)
+    want, trimmed, rows = oracle.umi_baking(keys, f, b, min_len, dedup)
+    wu = {}
+    for k, v in want:
+        wu[k.upper()] = wu.get(k.upper(), 0) + v
+    assert n_rec == len(recs) and n == trimmed and got == list(wu.items()), (f, b, qiagen, dedup, per_mod, min_len, use_adapter)
+    assert (csv is None) == (rows is None) and (csv is None or csv == "".join(rows))
+
