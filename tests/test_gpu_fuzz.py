@@ -365,3 +365,77 @@ def test_random_umi_options_equal_the_restated_worker(seed, tmp_path):
     assert n_rec == len(recs) and n == trimmed and got == list(wu.items()), (f, b, qiagen, dedup, per_mod, min_len, use_adapter)
     assert (csv is None) == (rows is None) and (csv is None or csv == "".join(rows))
 
+
+@pytest.fixture(scope="module")
+def _fz():
+    from mirge3_amd import synth
+    from mirge3_amd.cascade import Cascade
+    ctx = _ffi.Context(0)
+    sl = synth.make_libraries(seed=77, scale="ci")
+    return ctx, sl, Cascade(ctx, sl.libs)
+
+
+def _fz_reads(rng, sl, it, n):
+    from mirge3_amd import synth
+    reads = synth.make_reads(sl, n, seed=2000 + it, n_frac=0.03 if it % 3 == 0 else 0.0)
+    if it % 4 == 1:  # wide and long reads, runs of one letter, N runs
+        extra = FlatSeqs.from_list([("ACGTN"[int(rng.integers(0, 5))]) * int(rng.integers(1, 700)) for _ in range(40)] + ["ACGT" * 70])
+        reads = FlatSeqs(np.concatenate([reads.data, extra.data]), np.concatenate([reads.offsets, extra.offsets[1:] + reads.offsets[-1]]))
+    return reads
+
+
+@pytest.mark.parametrize("seed", range(max(6, N_FUZZ // 3)))
+def test_random_count_join_and_per_read_csv(seed, _fz, tmp_path):
+    """mirge_count_join (both its forms) against numpy sums, and mapped.csv / unmapped.csv formatted on the GPU against the host
+    formatter and -- small cases -- against plain Python, for random sample counts (1-16), read sets of 1 to 400 k reads with N
+    calls, wide and long reads, count matrices with zeros and cells up to 2^32 - 1, either row order, with and without the
+    spike-in column."""
+    from mirge3_amd.fastpath import names_by_pass, PASS_COLUMNS
+    ctx, sl, casc = _fz
+    rng = np.random.default_rng(15000 + seed)
+    n = int(rng.choice([1, 40, 3000, 80000, 400000]))
+    S = int(rng.choice([1, 1, 2, 3, 7, 16]))
+    reads = _fz_reads(rng, sl, seed, n)
+    n = len(reads)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq = raw.collapse(rng.integers(0, S, size=n).astype(np.int32), S) if S > 1 else raw.collapse()
+    if seed % 3 == 2:
+        w = rng.integers(0, 1 << 32, size=uniq.counts()[0].shape, dtype=np.int64).astype(np.uint32)
+        w[rng.random(w.shape) < 0.3] = 0
+        uniq.set_counts(w)
+    res = casc.run(uniq)
+    counts, first = uniq.counts()
+    ps, ref, off, mm = res.fetch()
+    nm = len(sl.libs["mirna"])
+    c = counts.astype(np.int64)
+    we, wi = np.zeros((nm, S), np.int64), np.zeros((nm, S), np.int64)
+    np.add.at(we, ref[ps == 0], c[ps == 0])
+    np.add.at(wi, ref[ps == 8], c[ps == 8])
+    for mode in ("1", "0"):
+        os.environ["MIRGE_JOIN_ROWS"] = mode
+        try:
+            cls, ex, iso = _ffi.count_join(ctx, uniq, res, 0, 8, nm)
+        finally:
+            os.environ.pop("MIRGE_JOIN_ROWS")
+        assert all(np.array_equal(cls[p], c[ps == p].sum(axis=0)) for p in range(res.n_pass)) and np.array_equal(ex, we) and np.array_equal(iso, wi)
+    order = uniq.first_appearance_order() if (S == 1 and seed % 2 == 0) else uniq.sorted_order()
+    n_cols = 10 if seed % 5 == 0 else 9
+    header = ",".join(["Sequence", "annotFlag"] + PASS_COLUMNS[:n_cols] + [f"S{k}" for k in range(S)]) + "\n"
+    nb = names_by_pass(casc)
+    dev, host = tmp_path / "dev", tmp_path / "host"
+    dev.mkdir(); host.mkdir()
+    assert _ffi.annotation_csv_device(ctx, uniq, res, dev / "mapped.csv", dev / "unmapped.csv", header, order, list(range(casc.n_pass)), n_cols, nb)
+    seqs = uniq.unpack()
+    _ffi.annotation_csv(host / "mapped.csv", host / "unmapped.csv", header, seqs, ps, ref, counts, order, list(range(casc.n_pass)), n_cols, nb)
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert (dev / f).read_bytes() == (host / f).read_bytes(), f
+    if n <= 3000:
+        sl_, lines = seqs.to_list(), {True: [header], False: [header]}
+        for i in order:
+            names = [""] * n_cols
+            if 0 <= ps[i] < n_cols:
+                names[ps[i]] = nb[ps[i]].get(int(ref[i]))
+            lines[bool(ps[i] >= 0)].append(",".join([sl_[i], "1" if ps[i] >= 0 else "0"] + names + [str(int(x)) for x in counts[i]]) + "\n")
+        assert (host / "mapped.csv").read_text() == "".join(lines[True]) and (host / "unmapped.csv").read_text() == "".join(lines[False])
+    res.close(); uniq.close(); raw.close()
+
