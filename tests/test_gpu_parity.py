@@ -2268,6 +2268,70 @@ def test_last_record_with_an_empty_read(ctx):
     whole.close(); parts.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_cli_route_equals_the_dropin_functions_on_random_samples(seed, tmp_path):
+    """The CLI's device-resident route (fastpath.run) and the reference-signature functions (baking -> bwt_align -> DataFrame.to_csv
+    -> summarize) are two implementations above the same kernels: on random samples -- 1-3 files of golden reads mutated, cut,
+    T-tailed, with random ones mixed in, with or without the 3' adapter, minimum length 12-18, the spike-in library -- every file
+    both write must be the same, byte for byte."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(31000 + seed)
+    case = GoldenCase(["case1_single", "case2_two_samples", "case3_spikein", "case4_gff_a2i"][seed % 4])
+    S = int(rng.choice([1, 2, 3]))
+    ad = "TGGAATTCTCGGGTGCCAAGGAACTCCAG"
+    use_ad = bool(rng.random() < 0.5)
+    files, names = [], []
+    pool = list(case.seqs)
+    for s_ in range(S):
+        recs = []
+        for i in range(int(rng.choice([200, 3000, 20000]))):
+            q = pool[int(rng.integers(0, len(pool)))]
+            r = rng.random()
+            if r < 0.15:
+                p_ = int(rng.integers(0, len(q)))
+                q = q[:p_] + "ACGTN"[int(rng.integers(0, 5))] + q[p_ + 1:]
+            elif r < 0.25:
+                q = q[int(rng.integers(0, 3)):len(q) - int(rng.integers(0, 3))]
+            elif r < 0.30:
+                q = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(10, 45))))
+            elif r < 0.33:
+                q = q + "TTTT"
+            if use_ad:
+                q = (q + ad)[:int(rng.integers(30, 76))]
+            qual = "".join(chr(int(c)) for c in rng.integers(40, 74, size=len(q)))
+            if rng.random() < 0.1 and len(q) > 4:
+                qual = qual[:-3] + "###"
+            recs.append(f"@r{i}\n{q}\n+\n{qual}\n")
+        p = tmp_path / f"S{s_ + 1}.fastq"
+        p.write_text("".join(recs))
+        files.append(str(p)); names.append(f"S{s_ + 1}")
+    min_len = int(rng.choice([16, 16, 18, 12]))
+    extra = (["-a", ad] if use_ad else []) + (["-spk"] if case.spike else []) + (["-m", str(min_len)] if min_len != 16 else [])
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    cmd = [sys.executable, "-c", "import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()" % root,
+           "-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", "cli", "-shh"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    wd = tmp_path / "fn"
+    wd.mkdir()
+    args = SimpleNamespace(threads=1, bowtie_path=None, bowtieVersion="True", quiet=True, bam_out=False, tRNA_frag=False, spikeIn=case.spike,
+                           organism_name=ORG, libraries_path=case.libdir, crThreshold="0.1", gff_out=False, isoform_entropy=False, AtoI=False,
+                           minimum_length=min_len, adapters=[("back", ad)] if use_ad else None, front=None, uniq_mol_ids=None,
+                           quality_cutoff="10", nextseq_trim=None, trim_n=False, cut=[], overlap=3, error_rate=0.12, phred64=33,
+                           trim_count="per-modifier", times=1, indels=True, action="trim", match_read_wildcards=False,
+                           match_adapter_wildcards=True, umiDedup=False, qiagenumi=False, tcf_out=False)
+    df, src, trimmed, uniq = baking(args, files, names, str(wd))
+    out = bwt_align(args, df, str(wd), DB)
+    mapped, unmapped = out[out.annotFlag.eq(1)], out[out.annotFlag.eq(0)]
+    mapped.to_csv(wd / "mapped.csv")
+    unmapped.to_csv(wd / "unmapped.csv")
+    summarize(args, str(wd), DB, names, mapped, src, trimmed, uniq)
+    for f in ("mapped.csv", "unmapped.csv", "annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
+        assert (tmp_path / "cli" / f).read_text() == (wd / f).read_text(), f
+    assert sum(1 for _ in open(wd / "mapped.csv")) > 100
+
+
 def test_cli_several_large_gz_samples(ci_libs, tmp_path):
     """Three samples in one invocation, two of them .fastq.gz large enough for the parallel inflater (read ahead on worker threads:
     their inflations overlap each other and the first sample's parse; the text buffer of one serves the next), one plain: every
