@@ -577,8 +577,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "case4":
         run_gff_a2i_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "case5":  # (added in round 4: three samples, spike-in library, another seed and depth)
+        run_case("case5_three_samples_spikein", seed=21, n_raw=1500, n_samples=3, spike_in=True)
+        sys.exit(0)
     run_umi_case()
     run_case("case1_single", seed=11, n_raw=1200, n_samples=1, spike_in=False)
     run_case("case2_two_samples", seed=12, n_raw=900, n_samples=2, spike_in=False)
     run_case("case3_spikein", seed=13, n_raw=600, n_samples=2, spike_in=True)
+    run_case("case5_three_samples_spikein", seed=21, n_raw=1500, n_samples=3, spike_in=True)
     run_gff_a2i_case()

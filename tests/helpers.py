@@ -8,7 +8,7 @@ import mirge3_amd  # noqa: F401
 from mirge3_amd.seqio import FlatSeqs, load_library_dir, load_merges
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["case1_single", "case2_two_samples", "case3_spikein"]
+CASES = ["case1_single", "case2_two_samples", "case3_spikein", "case5_three_samples_spikein"]
 ORG, DB = "human", "miRBase"
 PASS_LIBKEY = ["mirna", "hairpin", "mature_trna", "pre_trna", "snorna", "rrna", "ncrna_others",
                "mrna", "mirna", "spike-in"]
