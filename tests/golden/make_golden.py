@@ -577,6 +577,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "case4":
         run_gff_a2i_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "case6":  # (round 4: the -gff / -ai case again, other libraries and reads)
+        run_gff_a2i_case(case="case6_gff_a2i", seed=27)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "case5":  # (added in round 4: three samples, spike-in library, another seed and depth)
         run_case("case5_three_samples_spikein", seed=21, n_raw=1500, n_samples=3, spike_in=True)
         sys.exit(0)
@@ -586,3 +589,4 @@ if __name__ == "__main__":
     run_case("case3_spikein", seed=13, n_raw=600, n_samples=2, spike_in=True)
     run_case("case5_three_samples_spikein", seed=21, n_raw=1500, n_samples=3, spike_in=True)
     run_gff_a2i_case()
+    run_gff_a2i_case(case="case6_gff_a2i", seed=27)

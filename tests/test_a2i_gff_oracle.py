@@ -9,11 +9,12 @@ import pytest
 import oracle
 from helpers import GOLDEN
 
-CASE4 = os.path.join(GOLDEN, "case4_gff_a2i")
+GFF_A2I_CASES = ["case4_gff_a2i", "case6_gff_a2i"]  # (case 6: round 4, the same recipe on other libraries and reads)
 
 
-def test_a2i_restatement_equals_the_reference_functions():
-    d = json.load(open(os.path.join(CASE4, "a2i_direct.json")))
+@pytest.mark.parametrize("case_name", GFF_A2I_CASES)
+def test_a2i_restatement_equals_the_reference_functions(case_name):
+    d = json.load(open(os.path.join(GOLDEN, case_name, "a2i_direct.json")))
     assert len(d["groups"]) >= 30
     n_true = n_pos = 0
     for g in d["groups"]:
@@ -34,12 +35,12 @@ def test_a2i_restatement_equals_the_reference_functions():
     assert n_true > 50 and n_pos >= 5
 
 
-def _case4_gff_tables():
+def _case4_gff_tables(case_name="case4_gff_a2i"):
     """name -> canonical sequence / precursor name -> precursor sequence, read the way summarize() reads them
     (summary.py:801-837): the mature FASTA, the GFF3 annotation, and `bowtie-inspect` of the hairpin index -- whose
     output ends with a newline, so that the LAST precursor's sequence is overwritten with '' (:819-826)."""
     from helpers import GoldenCase, ORG
-    case = GoldenCase("case4_gff_a2i")
+    case = GoldenCase(case_name)
     lib = case.libdir
     mat, nm = {}, None
     for ln in open(f"{lib}/{ORG}/fasta.Libs/{ORG}_mature_miRBase.fa"):
@@ -62,8 +63,9 @@ def _case4_gff_tables():
     return case, mat, pre, pre_of
 
 
-def test_gff_restatement_equals_the_reference_file():
-    case, mat, pre, pre_of = _case4_gff_tables()
+@pytest.mark.parametrize("case_name", GFF_A2I_CASES)
+def test_gff_restatement_equals_the_reference_file(case_name):
+    case, mat, pre, pre_of = _case4_gff_tables(case_name)
     n = 0
     kinds = set()
     for ln in open(os.path.join(case.dir, "sample_miRge3.gff")):
@@ -75,4 +77,4 @@ def test_gff_restatement_equals_the_reference_file():
         assert rec == (f[2], int(f[3]), int(f[4]), attrs["Variant"], attrs["Cigar"]), (f[0], mat[f[0]], attrs["Read"])
         kinds.add(attrs["Variant"].split(":")[0].split(",")[0])
         n += 1
-    assert n > 700 and {"iso_5p", "iso_3p", "iso_add3p", "iso_add5p", "iso_snv_seed", "iso_snv", "NA"} <= kinds
+    assert n > 650 and {"iso_5p", "iso_3p", "iso_add3p", "iso_add5p", "iso_snv_seed", "iso_snv", "NA"} <= kinds

@@ -1549,10 +1549,13 @@ def test_full_size_c5_properties(ctx):
 
 
 # ---------------------------------------------------------------- -ai / -gff against the reference's own files (case4)
-def _case4_run(tmp_path, **flags):
-    """golden case 4 expanded to FASTQ files and pushed through the CLI's device-resident route"""
+GFF_A2I_CASES = ["case4_gff_a2i", "case6_gff_a2i"]  # (case 6: round 4, the same recipe on other libraries and reads)
+
+
+def _case4_run(tmp_path, case_name="case4_gff_a2i", **flags):
+    """a -gff / -ai golden case expanded to FASTQ files and pushed through the CLI's device-resident route"""
     from mirge3_amd import fastpath
-    case = GoldenCase("case4_gff_a2i")
+    case = GoldenCase(case_name)
     files = []
     for s, nm in enumerate(case.samples):
         p = tmp_path / f"{nm}.fastq"
@@ -1570,11 +1573,12 @@ def _case4_run(tmp_path, **flags):
     return case, work, out
 
 
-def test_a2i_report_equals_the_reference_files(tmp_path):
+@pytest.mark.parametrize("case_name", GFF_A2I_CASES)
+def test_a2i_report_equals_the_reference_files(tmp_path, case_name):
     """-ai: a2IEditing.report.csv, a2IEditing.report.newform.csv and a2IEditing.detail.txt byte for byte what the
     reference's a2i_editing wrote for the same reads (the two genome runs answered by the same bowtie stand-in), and
     the kernel's per-(miRNA, sample) counts against the oracle's string restatement."""
-    case, work, out = _case4_run(tmp_path, AtoI=True)
+    case, work, out = _case4_run(tmp_path, case_name, AtoI=True)
     for f in ("miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "a2IEditing.report.csv",
               "a2IEditing.report.newform.csv", "a2IEditing.detail.txt"):
         assert (work / f).read_text() == case.text(f), f
@@ -1608,14 +1612,15 @@ def test_a2i_report_equals_the_reference_files(tmp_path):
     assert checked >= 20
 
 
-def test_gff_equals_the_reference_file(tmp_path):
+@pytest.mark.parametrize("case_name", GFF_A2I_CASES)
+def test_gff_equals_the_reference_file(tmp_path, case_name):
     """-gff: sample_miRge3.gff byte for byte what the reference's create_gff wrote for the same reads (727 typed
     lines: every variant class, templated and non-templated additions, the three worked examples of
     summary.py:249-283, reads with N, names without annotation)."""
-    case, work, out = _case4_run(tmp_path, gff_out=True)
+    case, work, out = _case4_run(tmp_path, case_name, gff_out=True)
     assert (work / "sample_miRge3.gff").read_text() == case.text("sample_miRge3.gff")
     recs = out["gff"]["records"]
-    assert (recs["kind"] == 2).sum() > 600 and (recs["kind"] == 1).sum() > 40 and (recs["kind"] == 0).sum() > 0
+    assert (recs["kind"] == 2).sum() > 500 and (recs["kind"] == 1).sum() > 40 and (recs["kind"] == 0).sum() > 0
 
 
 # ---------------------------------------------------------------- read trimming (row N4)

@@ -213,10 +213,11 @@ def hostsim_isotype(master: str, read: str, precursor: str):
     return ({0: "none", 1: "ref_miRNA", 2: "isomiR"}[kind.value], start.value, end.value, var.value.decode(), cig.value.decode())
 
 
-def test_isotype_core_equals_the_oracle_on_the_reference_lines():
-    """every line of the GFF the reference wrote (golden case 4), through the header k_isotype is compiled from"""
+@pytest.mark.parametrize("case_name", ["case4_gff_a2i", "case6_gff_a2i"])
+def test_isotype_core_equals_the_oracle_on_the_reference_lines(case_name):
+    """every line of the GFF the reference wrote (golden cases 4 and 6), through the header k_isotype is compiled from"""
     from test_a2i_gff_oracle import _case4_gff_tables
-    case, mat, pre, pre_of = _case4_gff_tables()
+    case, mat, pre, pre_of = _case4_gff_tables(case_name)
     n = 0
     for ln in open(os.path.join(case.dir, "sample_miRge3.gff")):
         if ln.startswith("#"):
@@ -226,7 +227,7 @@ def test_isotype_core_equals_the_oracle_on_the_reference_lines():
         got = hostsim_isotype(mat[f[0]], attrs["Read"], pre[pre_of[f[0]]])
         assert got == (f[2], int(f[3]), int(f[4]), attrs["Variant"], attrs["Cigar"]), (f[0], mat[f[0]], attrs["Read"])
         n += 1
-    assert n > 700
+    assert n > 650
 
 
 def test_isotype_core_equals_the_oracle_on_random_pairs():
