@@ -144,7 +144,7 @@ def build_frame(sample_dicts, base_names):
     return complete_set.astype({"annotFlag": int})
 
 
-def run_case(case, seed, n_raw, n_samples, spike_in):
+def run_case(case, seed, n_raw, n_samples, spike_in, cr="0.1"):
     out_dir = os.path.join(HERE, case)
     shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(os.path.join(out_dir, "libs"))
@@ -185,7 +185,7 @@ def run_case(case, seed, n_raw, n_samples, spike_in):
     os.makedirs(work)
     args = SimpleNamespace(threads=2, bowtie_path=os.path.join(HERE, "fake_bowtie"), bowtieVersion="True",
                            quiet=True, bam_out=False, tRNA_frag=False, spikeIn=bool(spike_in),
-                           organism_name=ORG, libraries_path=libdir, crThreshold="0.1", gff_out=False,
+                           organism_name=ORG, libraries_path=libdir, crThreshold=cr, gff_out=False,
                            isoform_entropy=True, AtoI=False)  # -ie: isomirs.csv, isomirs.samples.csv (summary.py:906-1032)
     # inputs
     df[base_names].to_csv(os.path.join(out_dir, "collapsed_input.csv"))
@@ -580,6 +580,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "case6":  # (round 4: the -gff / -ai case again, other libraries and reads)
         run_gff_a2i_case(case="case6_gff_a2i", seed=27)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "case7":  # (round 4: -ex 0.4, the canonical-ratio cut well above its default)
+        run_case("case7_two_samples_cr0.4", seed=33, n_raw=1400, n_samples=2, spike_in=False, cr="0.4")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "case5":  # (added in round 4: three samples, spike-in library, another seed and depth)
         run_case("case5_three_samples_spikein", seed=21, n_raw=1500, n_samples=3, spike_in=True)
         sys.exit(0)
@@ -588,5 +591,6 @@ if __name__ == "__main__":
     run_case("case2_two_samples", seed=12, n_raw=900, n_samples=2, spike_in=False)
     run_case("case3_spikein", seed=13, n_raw=600, n_samples=2, spike_in=True)
     run_case("case5_three_samples_spikein", seed=21, n_raw=1500, n_samples=3, spike_in=True)
+    run_case("case7_two_samples_cr0.4", seed=33, n_raw=1400, n_samples=2, spike_in=False, cr="0.4")
     run_gff_a2i_case()
     run_gff_a2i_case(case="case6_gff_a2i", seed=27)

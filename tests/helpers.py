@@ -8,7 +8,7 @@ import mirge3_amd  # noqa: F401
 from mirge3_amd.seqio import FlatSeqs, load_library_dir, load_merges
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["case1_single", "case2_two_samples", "case3_spikein", "case5_three_samples_spikein"]
+CASES = ["case1_single", "case2_two_samples", "case3_spikein", "case5_three_samples_spikein", "case7_two_samples_cr0.4"]
 ORG, DB = "human", "miRBase"
 PASS_LIBKEY = ["mirna", "hairpin", "mature_trna", "pre_trna", "snorna", "rrna", "ncrna_others",
                "mrna", "mirna", "spike-in"]
@@ -21,6 +21,7 @@ class GoldenCase:
         self.name = name
         self.dir = os.path.join(GOLDEN, name)
         self.spike = "spikein" in name
+        self.cr = name.split("_cr")[1] if "_cr" in name else "0.1"  # -ex / --crThreshold the reference was run with
         self.n_pass = 10 if self.spike else 9
         self.libdir = os.path.join(self.dir, "libs")
         self.libs = load_library_dir(self.libdir, ORG, DB, with_spike=self.spike)

@@ -64,7 +64,7 @@ def test_golden_cascade_and_join(ctx, name, tmp_path):
         nm = case.lib_of_pass(p).names[int(ref[i])] if p >= 0 else ""
         assert (p, nm) == exp[s], s
     summarize_device(ctx, dr, res, case.libs["mirna"], case.merges, case.samples, case.sample_read_counts,
-                     case.trimmed, case.trimmed_unique, 0.1, case.spike, workDir=tmp_path)
+                     case.trimmed, case.trimmed_unique, float(case.cr), case.spike, workDir=tmp_path)
     for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv"):
         assert (tmp_path / f).read_text() == case.text(f), f
     # the packed reads survive a round trip
@@ -80,7 +80,7 @@ def test_golden_dropin_signatures(name, tmp_path):
     case = GoldenCase(name)
     args = SimpleNamespace(threads=1, bowtie_path=None, bowtieVersion="True", quiet=True, bam_out=False,
                            tRNA_frag=False, spikeIn=case.spike, organism_name=ORG, libraries_path=case.libdir,
-                           crThreshold="0.1", gff_out=False, isoform_entropy=True, AtoI=False)
+                           crThreshold=case.cr, gff_out=False, isoform_entropy=True, AtoI=False)
     df = pd.DataFrame(case.counts, columns=case.samples, index=pd.Index(case.seqs, name="Sequence"))
     df = df.assign(**dict.fromkeys(PASS_COLS, ''))
     df = df.assign(annotFlag=0).reindex(columns=['annotFlag'] + PASS_COLS + case.samples)

@@ -97,7 +97,7 @@ def test_count_join_tail_reproduces_reference_csvs(name, tmp_path):
         if p == 8:
             iso[lut[nm]] += row
     finish_tables(cls, ex, iso, mir, case.merges, case.samples, case.sample_read_counts, case.trimmed,
-                  case.trimmed_unique, 0.1, case.spike, workDir=tmp_path)
+                  case.trimmed_unique, float(case.cr), case.spike, workDir=tmp_path)
     for f in ("annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv"):
         assert (tmp_path / f).read_text() == case.text(f), f
 

@@ -35,7 +35,7 @@ def test_join_matches_reference_summarize(case):
                                       n_pass=case.n_pass)
     mir = case.libs["mirna"]
     j = oracle.join(ps, ref, case.counts, mir.names, mir.headers, case.merges, case.samples,
-                    case.sample_read_counts, case.trimmed, case.trimmed_unique, spike=case.spike)
+                    case.sample_read_counts, case.trimmed, case.trimmed_unique, cr_threshold=float(case.cr), spike=case.spike)
     assert j["report_csv"] == case.text("annotation.report.csv")
     assert j["counts_csv"] == case.text("miR.Counts.csv")
     assert j["rpm_csv"] == case.text("miR.RPM.csv")
