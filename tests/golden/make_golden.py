@@ -573,7 +573,32 @@ def run_gff_a2i_case(case="case4_gff_a2i", seed=14):
     print(case, "rows", len(df), "mapped", len(pdMapped), "a2i groups", len(groups), "->", out_dir)
 
 
+def run_validate_case():
+    """miRgeEssential.validate_files (:102-127), the reference's own function, on a directory of file names: which it keeps and
+    what it calls the samples -> tests/golden/validate_files.json"""
+    import json
+    from mirge.libs.miRgeEssential import validate_files  # the reference
+    present = ["a.fastq", "b.fq.gz", "c.fastq.gz", "d.fq", "e.trimmed.fastq", "f.tar.fastq.gz", "g.v2.fq", "h.1.2.fq.gz", "my.sample v1.fastq.gz",
+               "notes.txt", "lib.fa", "i.fastq.bak", "j.FASTQ", "k.fq.gz.gz", "l.xfastq", "noext", "m.gz", ".fastq", "n.fastq.gz.tmp", "o.fq.GZ",
+               "p..fastq", "q.fastq.fastq", "r.fastq.fq", "s.fq.fastq.gz"]
+    missing = ["zz.fastq", "yy.fq.gz", "xx.txt"]
+    tmp = tempfile.mkdtemp(prefix="mirge_validate_")
+    for n in present:
+        open(os.path.join(tmp, n), "w").close()
+    given = sorted(present) + missing + ["a.fastq"]  # (a name given twice is kept twice)
+    full, names = validate_files(SimpleNamespace(quiet=True), [os.path.join(tmp, n) for n in given], os.path.join(tmp, "run.log"), [], [])
+    out = {"present": present, "missing": missing, "given": given, "kept": [os.path.basename(f) for f in full], "base_names": names,
+           "made_by": "tests/golden/make_golden.py::run_validate_case -- mirge.libs.miRgeEssential.validate_files itself"}
+    with open(os.path.join(HERE, "validate_files.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    shutil.rmtree(tmp)
+    print("validate_files:", len(full), "of", len(given), "kept")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "validate":
+        run_validate_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "case4":
         run_gff_a2i_case()
         sys.exit(0)
@@ -587,6 +612,7 @@ if __name__ == "__main__":
         run_case("case5_three_samples_spikein", seed=21, n_raw=1500, n_samples=3, spike_in=True)
         sys.exit(0)
     run_umi_case()
+    run_validate_case()
     run_case("case1_single", seed=11, n_raw=1200, n_samples=1, spike_in=False)
     run_case("case2_two_samples", seed=12, n_raw=900, n_samples=2, spike_in=False)
     run_case("case3_spikein", seed=13, n_raw=600, n_samples=2, spike_in=True)

@@ -549,6 +549,22 @@ def test_sample_forms_of_the_command_line(tmp_path):
     assert collect_samples(r, log) == ([str(d)], [])
 
 
+def test_validate_files_equals_the_reference_function(tmp_path):
+    """tests/golden/validate_files.json was written by miRgeEssential.validate_files itself (make_golden.py::run_validate_case): 24
+    file names of every shape -- several dots, a blank, .gz twice, upper-case extensions, a bare '.fastq', suffixes that merely
+    contain 'fastq' -- plus missing ones; cli.validate_files keeps the same files and gives the samples the same names."""
+    import json
+    from types import SimpleNamespace
+    from mirge3_amd.cli import validate_files
+    with open(os.path.join(os.path.dirname(__file__), "golden", "validate_files.json")) as fh:
+        d = json.load(fh)
+    for n in d["present"]:
+        (tmp_path / n).write_text("")
+    full, names = validate_files(SimpleNamespace(quiet=True), [str(tmp_path / n) for n in d["given"]], tmp_path / "run.log")
+    assert [os.path.basename(f) for f in full] == d["kept"] and names == d["base_names"] and len(full) == 14
+    assert full == [str((tmp_path / n).resolve()) for n in d["kept"]]
+
+
 def test_library_cache_round_trip_and_invalidation(tmp_path, monkeypatch):
     """libcache: the packed image + names written next to an index come back as the same library (lengths at once, letters
     decoded on demand, kept verbatim for small libraries), and the cache is ignored when the index file changed, when the
