@@ -167,8 +167,10 @@ def gz_inflate(data, threads: int = 0) -> Optional[np.ndarray]:
 # The text buffer of the last finished GzInflation, kept for the next one: a fresh buffer costs a sample its page faults while it
 # inflates (the inflater's floor, profiles/README.md round 4) and an munmap of half a gigabyte when it is dropped -- 0.03-0.05 s of
 # a 0.15 s sample.  One buffer, at most MIRGE_GZ_KEEP_BYTES (default 16 GiB of address space; what a sample touched stays resident).
-_gz_kept: list = []
+_gz_kept: list = []          # (popped and appended by read-ahead threads: list.pop / append are atomic, the emptiness test is not)
 _GZ_KEEP_BYTES = int(os.environ.get("MIRGE_GZ_KEEP_BYTES", str(16 << 30)))
+import threading as _threading
+_gz_keep_lock = _threading.Lock()
 
 
 def gz_threads() -> int:
@@ -202,7 +204,10 @@ class GzInflation:
         if cap > (1 << 37):
             self.ok = False
             return
-        kept = _gz_kept.pop() if _gz_kept else None
+        try:
+            kept = _gz_kept.pop()
+        except IndexError:  # none kept, or another read-ahead thread took it between a test and the pop
+            kept = None
         if kept is not None and kept.size >= cap:
             self.out = kept
             cap = int(kept.size)
@@ -244,8 +249,10 @@ class GzInflation:
         """the caller is done with ``out`` and every view of it: the buffer is kept for the next inflation"""
         self.wait()
         out, self.out = self.out, None
-        if out is not None and out.size <= _GZ_KEEP_BYTES and not _gz_kept:
-            _gz_kept.append(out)
+        if out is not None and out.size <= _GZ_KEEP_BYTES:
+            with _gz_keep_lock:
+                if not _gz_kept:
+                    _gz_kept.append(out)
 
 
 class Context:

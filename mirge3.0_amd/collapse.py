@@ -107,7 +107,7 @@ class GzipRecordStream:
     def _inflated(self, fh):
         """the file's text as blocks of at most a piece, member after member; (block, seconds inside zlib)"""
         import zlib
-        d, fresh, buf = zlib.decompressobj(31), True, b""
+        d, fresh, buf, first = zlib.decompressobj(31), True, b"", True
         while True:
             if not buf:
                 buf = fh.read(1 << 20)
@@ -121,14 +121,19 @@ class GzipRecordStream:
                         if not d.eof:
                             raise EOFError(f"{self.path}: compressed file ended before the end-of-stream marker was reached")
                     return
+            if fresh and not first:
+                # BETWEEN members zeros are padding (tape blocks, bgzip's tools), as Python's gzip module and xopen read them
+                # -- however many reads of the file they span (a 1 MiB read that ended inside the padding used to hand the
+                # rest of it to a new decompressor: 'incorrect header check')
+                buf = buf.lstrip(b"\0")
+                if not buf:
+                    continue
             t0 = time.perf_counter()
             out = d.decompress(buf, self.piece_bytes)  # at most a piece at a time, whatever the ratio
-            fresh = False
+            fresh = first = False
             if d.eof:  # end of a member: the next one, if any, starts in what is left
                 buf = d.unused_data
                 d, fresh = zlib.decompressobj(31), True
-                if not buf.strip(b"\0"):  # bgzip's empty last block leaves nothing; tape padding is zeros
-                    buf = b""
             else:
                 buf = d.unconsumed_tail  # (output still pending inside zlib comes out with the next input, or the final flush)
             yield out, time.perf_counter() - t0
@@ -309,7 +314,7 @@ class ParallelGzipStream:
     The file's CRC-32 is known at the end only -- a mismatch, or a file the parallel route does not take, raises
     ``GzRouteDeclined`` from the iteration and the caller starts over with ``GzipRecordStream``.  Same protocol as that class."""
 
-    def __init__(self, path: str, piece_bytes: int = None):
+    def __init__(self, path: str, piece_bytes: int = None, reserved: int = 0):
         self.path = str(path)
         self.piece_bytes = int(piece_bytes or GZ_AHEAD_PIECE_BYTES)
         self.raw = np.memmap(self.path, dtype=np.uint8, mode="r")  # the compressed bytes straight from the page cache
@@ -317,8 +322,15 @@ class ParallelGzipStream:
         self.inflate_s = 0.0
         self.text_bytes = 0
         self.pieces = 0
+        self._reserved = int(reserved)  # host memory promised by _gz_reserve: given back by close()
         self._t0 = time.perf_counter()
-        self.job = _ffi.GzInflation(self.raw)
+        try:
+            # (the cores are shared by the inflations admitted side by side)
+            self.job = _ffi.GzInflation(self.raw, threads=max(1, _ffi.gz_threads() // max(1, _gz_in_flight)))
+        except BaseException:
+            _gz_release(self._reserved)
+            self._reserved = 0
+            raise
         self._logged = False
         self._whole_handed_out = False
 
@@ -370,6 +382,15 @@ class ParallelGzipStream:
         self.job.wait()  # (the buffers must outlive the worker)
         if not self._whole_handed_out:
             self.job.release()
+        need, self._reserved = self._reserved, 0
+        _gz_release(need)
+
+    def __del__(self):  # a stream nobody iterated (an exception upstream) must not hold its reservation for ever
+        try:
+            need, self._reserved = getattr(self, "_reserved", 0), 0
+            _gz_release(need)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
     def whole_text(self):
         if not self.job.wait():
@@ -402,10 +423,56 @@ def _host_memory_available() -> int:
     return avail
 
 
+import threading as _threading
+_gz_admit_lock = _threading.Lock()
+_gz_reserved = 0        # host bytes promised to the parallel inflations in flight (read_texts starts up to four at once)
+_gz_in_flight = 0
+GZ_MAX_IN_FLIGHT = int(_os.environ.get("MIRGE_GZ_MAX_IN_FLIGHT", "2"))
+
+
+def _gz_host_bytes(path: str) -> int:
+    """What one parallel inflation of this file may take from the host: the text (ISIZE of a single member -- the real size
+    modulo 2^32, so a 343:1 file of repeats is seen for what it is --, at least eight times the compressed size: FASTQ deflates
+    4-6 x and a file of several members shows the last member's size only) plus the 2-byte symbols the chunks decode into."""
+    size = _os.path.getsize(path)
+    isize = 0
+    try:
+        with open(path, "rb") as fh:
+            fh.seek(max(0, size - 4))
+            isize = int.from_bytes(fh.read(4), "little")
+    except OSError:
+        pass
+    return 3 * max(isize, 8 * size)
+
+
+def _gz_reserve(path: str) -> int:
+    """Admission of a parallel inflation: its memory is RESERVED under a lock before it starts, against what the host has left
+    minus what the inflations in flight were promised (four files admitted by four threads at the same moment, each looking at
+    the same MemAvailable before any had touched a page, could together ask for twice the host's memory: round 4's review).
+    At most GZ_MAX_IN_FLIGHT at a time.  Returns the bytes reserved (hand them to ``_gz_release``), 0 = take the streamed route."""
+    global _gz_reserved, _gz_in_flight
+    need = _gz_host_bytes(path)
+    with _gz_admit_lock:
+        if _gz_in_flight >= GZ_MAX_IN_FLIGHT or need >= (_host_memory_available() - _gz_reserved) // 2:
+            return 0
+        _gz_reserved += need
+        _gz_in_flight += 1
+        return need
+
+
+def _gz_release(need: int) -> None:
+    global _gz_reserved, _gz_in_flight
+    if need:
+        with _gz_admit_lock:
+            _gz_reserved -= need
+            _gz_in_flight -= 1
+
+
 def _gz_fits_in_memory(path: str) -> bool:
-    """The parallel inflater holds the whole text in host memory (FASTQ deflates 4-6 x; the streamed route holds a few pieces): it is
-    taken only when eight times the compressed size is less than half of what the host has left."""
-    return 8 * _os.path.getsize(path) < _host_memory_available() // 2
+    """The parallel inflater holds the whole text in host memory (the streamed route holds a few pieces): taken only when what it
+    needs (``_gz_host_bytes``) is less than half of what the host has left beside the inflations already admitted."""
+    with _gz_admit_lock:
+        return _gz_host_bytes(path) < (_host_memory_available() - _gz_reserved) // 2
 
 
 def read_text(path: str, stream: bool = False):
@@ -420,13 +487,19 @@ def read_text(path: str, stream: bool = False):
         data = None
         # (up to 8 GiB of compressed data -- the text is held whole in host memory, some 6 x that; beyond, the streamed route's
         # few pieces bound the memory a sample takes)
-        takes = (2 << 20) <= _os.path.getsize(path) <= (8 << 30) and _gz_fits_in_memory(path)
-        if stream and _os.environ.get("MIRGE_GZ_PARALLEL", "1") not in ("0", "whole") and takes:
-            return ParallelGzipStream(path)  # inflated on all cores, parsed beside; declines like the call below
-        if _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and takes:
+        sized = (2 << 20) <= _os.path.getsize(path) <= (8 << 30)
+        if stream and _os.environ.get("MIRGE_GZ_PARALLEL", "1") not in ("0", "whole") and sized:
+            need = _gz_reserve(path)  # its memory, promised under a lock; 0: the streamed route below
+            if need:
+                return ParallelGzipStream(path, reserved=need)  # inflated on all cores, parsed beside; declines like the call below
+        need = _gz_reserve(path) if (sized and _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and not stream) else 0
+        if need:
             t0 = time.perf_counter()
             raw = np.fromfile(path, dtype=np.uint8)
-            data = _ffi.gz_inflate(raw)
+            try:
+                data = _ffi.gz_inflate(raw)
+            finally:
+                _gz_release(need)
             if data is not None and data.size >= 3 * TEXT_PIECE_BYTES and not (stream and bytes(data[:1]) == b"@"):
                 data = None  # too large for one parse call and nobody to take it in parts: as before
             if data is not None:

@@ -475,6 +475,10 @@ __device__ __forceinline__ void resolve_one(const ResolveTable& tb, int p, uint3
 // sees the CU's own write-through stores.  Plain loads are therefore enough.  (Round 3 used agent-scope loads "because the L1
 // may hold the lines of two passes ago"; a build with plain loads passes the oracle, brute-force, fuzz and full-size C3 tests
 // -- profiles/README.md round 4 -- and the model says it must.  MIRGE_SURV_PLAIN_LOADS=0 brings the agent-scope loads back.)
+// ONE assumption sits under this: the waves of a workgroup run on one CU.  In threadgroup-split mode (-mtgsplit) they may
+// not, and plain loads would race.  hipcc defines no macro for the mode, so it is checked where it can be seen:
+// __graft_entry__.build() refuses the flag and reads compute_pgm_rsrc3.TG_SPLIT of every kernel descriptor of the built
+// library (mirge3.0_amd/_codeobj.py; tests/test_host_logic.py::test_no_kernel_is_built_for_threadgroup_split_mode).
 #define MIRGE_SURV_PLAIN_LOADS 1
 #endif
 #ifndef MIRGE_BULK_WAVES

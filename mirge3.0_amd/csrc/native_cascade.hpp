@@ -62,8 +62,10 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
     for (int L = 1; L <= MIRGE_MAX_READ_LEN + 1; L++) {
         const bool lng = L > MIRGE_MAX_READ_LEN;
         if (lng ? !long_present : !hist[L]) continue;
-        if (p.len_lt > 0 && !(L < p.len_lt)) continue;
-        if (p.len_gt > 0 && !(L > p.len_gt)) continue;
+        // (the long class stands for EVERY length beyond 255: it fails a `len <` rule of up to 256, and no `len >` rule at all --
+        // with len_gt >= 256 the stand-in 256 failed the test, no table was built, and a 400-nt read probed a null table)
+        if (p.len_lt > 0 && !(L < p.len_lt) && !(lng && p.len_lt > MIRGE_MAX_READ_LEN + 1)) continue;
+        if (p.len_gt > 0 && !(L > p.len_gt) && !lng) continue;
         int lo = L, hi = L;
         if (lng) lo = hi = 31 + p.trim5 + p.trim3;
         if (p.ttail) { lo = 1; hi = (lng ? 31 + p.trim5 + p.trim3 : L - 3); }  // any head length once the T run is gone

@@ -677,7 +677,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
     std::vector<size_t> n_sym((size_t)C, 0);
     uint64_t final_end_bit = 0;
     int C_eff = -1;  // chunks of THIS member (the data may go on with another member: its chunks are found, decoded and dropped)
-    std::atomic<int> failed{0}, next{0};
+    std::atomic<int> failed{0}, next{0}, over_cap{0};
     std::vector<char> finished((size_t)C, 0);  // chunk i's bytes are in place (under front_mu)
     int front = 0;                              // chunks 0 .. front - 1 are
     std::mutex front_mu;
@@ -695,7 +695,10 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
                 const uint64_t stop = i + 1 < C ? st[(size_t)i + 1] : ~0ull;
                 if (!o.resize((size_t)((i + 1 < C ? (stop - st[(size_t)i]) / 8 : dn - st[(size_t)i] / 8) * MIRGE_GZ_RATIO_GUESS + (1 << 16)))) st_i = -1;
                 while (st_i == 0) {
-                    const int rc = decode_block(br, o, no, i == 0, false, (size_t)1 << 36);
+                    // no chunk can be longer than the whole text: a hostile or very repetitive stream (deflate reaches 1032:1)
+                    // stops at cap + 1 symbols instead of mapping gigabytes per worker before the size test below
+                    const int rc = decode_block(br, o, no, i == 0, false, std::min<size_t>(cap + 1, (size_t)1 << 36));
+                    if (rc < 0 && no + 512 > cap) over_cap.store(1);
                     const uint64_t pos = bit_position(br, d);
                     if (rc < 0) st_i = -1;
                     else if (rc == 1) { st_i = 1; endb = pos; }
@@ -801,7 +804,7 @@ static int inflate_member_parallel(const uint8_t* gz, size_t n, uint8_t* out, si
                      C, threads, t_search - t_call, link_last, fin_last, gz_now() - t_call, dec_sum / C, dec_max, wait_sum / C, conv_sum / C,
                      t_start[0] - t_call, t_start[(size_t)C - 1] - t_call);
     }
-    if (failed.load() == 2) return -2;
+    if (failed.load() == 2 || over_cap.load()) return -2;  // the text does not fit `cap` (also: a chunk alone outgrew it): the caller streams the file
     if (failed.load() || C_eff < 1) return -1;
     const size_t total = link[(size_t)C_eff].at;
     // the trailer: CRC-32 and length (mod 2^32) behind the final block's last byte

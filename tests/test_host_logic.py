@@ -31,6 +31,23 @@ def test_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_no_kernel_is_built_for_threadgroup_split_mode(monkeypatch):
+    """`k_cascade_bulk` reads its workgroup's own survivor lists back with plain loads (kernels_cascade.hpp,
+    MIRGE_SURV_PLAIN_LOADS): right only while a workgroup's waves share one CU's L1.  The built code object must not ask for
+    tgsplit in any kernel descriptor (compute_pgm_rsrc3 bit 16; `_codeobj` was checked against a -mtgsplit build of a toy
+    kernel), and build() refuses the flag."""
+    import __graft_entry__ as g
+    from mirge3_amd import _codeobj
+    g.build()
+    assert _codeobj.n_kernels(_ffi.SO_PATH) > 100
+    assert _codeobj.tg_split_kernels(_ffi.SO_PATH) == []
+    monkeypatch.setenv("HIPCC_COMPILE_FLAGS_APPEND", "-mtgsplit")
+    with pytest.raises(RuntimeError, match="tgsplit"):
+        g.build()
+    monkeypatch.setenv("HIPCC_COMPILE_FLAGS_APPEND", "-mno-tgsplit")
+    g.build()
+
+
 def test_bench_names_the_kernels_the_library_holds():
     """bench.py finds the dominant kernel's PMC rows by a fragment of its demangled name (rocprof_symbol); a changed template
     signature would turn `roofline.traffic` into null without anything failing -- every fragment must name a kernel of the
@@ -496,6 +513,13 @@ def test_gzip_record_stream(tmp_path):
             for q in pieces[:-1]:
                 assert q.count(b"\n") % 4 == 0 and q[:1] == b"@" and q[-1:] == b"\n"
             assert len(pieces) >= min(len(want) // (2 * piece), 3)
+    # zero padding BETWEEN members and behind the last that spans several 1 MiB reads of the file (round 4's review: the part of
+    # it in the next read went to a fresh decompressor, 'incorrect header check'; gzip.open / xopen read such files)
+    padded = tmp_path / "pad.fastq.gz"
+    padded.write_bytes(gzip.compress(text[:c1], 6) + b"\0" * ((2 << 20) + 77) + gzip.compress(text[c1:], 6) + b"\0" * ((3 << 20) + 5))
+    with gzip.open(padded, "rb") as fh:
+        assert fh.read() == text
+    assert b"".join(collapse.GzipRecordStream(str(padded), piece_bytes=1 << 18)) == text
     cut = tmp_path / "d.fastq.gz"
     cut.write_bytes(one.read_bytes()[: one.stat().st_size // 2])
     with pytest.raises(EOFError):
@@ -519,6 +543,64 @@ def test_gzip_record_stream(tmp_path):
     assert isinstance(got[0], collapse.GzipRecordStream) and isinstance(got[2], collapse.GzipRecordStream)
     assert bytes(got[1]) == plain.read_bytes()
     assert [b"".join(g) for g in (got[0], got[2], got[3])] == [text, text, text[:-1]]
+
+
+def test_parallel_inflations_reserve_their_memory(tmp_path, monkeypatch):
+    """Admission of the whole-text inflater (round 4's review, medium): read_texts starts up to four inflations at once; each
+    used to test 8 x its size against MemAvailable before any had touched a page, so four could be admitted into twice the
+    host's memory.  Now a file's need -- 3 x max(ISIZE, 8 x size): the text plus 2-byte symbols, the real size of a very
+    repetitive file -- is RESERVED under a lock, at most GZ_MAX_IN_FLIGHT at a time, and given back by close()."""
+    import gzip
+    from mirge3_amd import collapse
+    rec = b"@r\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n"
+    rep = tmp_path / "rep.fastq.gz"          # 343:1-like: ISIZE says what 8 x the size does not
+    rep.write_bytes(gzip.compress(rec * 400000, 6))
+    assert collapse._gz_host_bytes(str(rep)) == 3 * len(rec) * 400000 > 100 * rep.stat().st_size
+    rng = np.random.default_rng(5)
+    body = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 30).astype(np.uint8)), b"I" * 30) for i in range(60000))
+    files = []
+    for k in range(4):
+        f = tmp_path / f"s{k}.fastq.gz"
+        f.write_bytes(gzip.compress(body, 1))
+        files.append(str(f))
+    need = collapse._gz_host_bytes(files[0])
+    assert need >= 3 * len(body)
+    # a host with room for exactly two such files (half of what is left must cover a file's need)
+    monkeypatch.setattr(collapse, "_host_memory_available", lambda: 4 * need - 2)
+    assert collapse._gz_reserved == 0 and collapse._gz_in_flight == 0
+    a = collapse._gz_reserve(files[0])
+    b = collapse._gz_reserve(files[1])
+    assert a == need and b == need and collapse._gz_in_flight == 2
+    assert collapse._gz_reserve(files[2]) == 0            # the third would have passed the old per-file test
+    assert not collapse._gz_fits_in_memory(files[2])
+    collapse._gz_release(a)
+    monkeypatch.setattr(collapse, "GZ_MAX_IN_FLIGHT", 1)
+    assert collapse._gz_reserve(files[2]) == 0            # one in flight is the limit now
+    collapse._gz_release(b)
+    assert collapse._gz_reserved == 0 and collapse._gz_in_flight == 0
+    # four threads at once (read_texts): never more than the limit admitted, every reservation returned, texts intact
+    monkeypatch.setattr(collapse, "GZ_MAX_IN_FLIGHT", 2)
+    monkeypatch.setattr(collapse, "_host_memory_available", lambda: 1 << 40)
+    peak = []
+    real = collapse._gz_reserve
+
+    def spy(path):
+        r = real(path)
+        peak.append(collapse._gz_in_flight)
+        return r
+    monkeypatch.setattr(collapse, "_gz_reserve", spy)
+    kinds = []
+    for st in collapse.read_texts(files, depth=4, stream=True):
+        kinds.append(type(st).__name__)
+        try:
+            got = b"".join(bytes(p) for p in st)
+        except collapse.GzRouteDeclined:
+            got = b"".join(collapse.GzipRecordStream(st.path))
+        finally:
+            st.close()
+        assert got == body
+    assert max(peak) <= 2 and "ParallelGzipStream" in kinds
+    assert collapse._gz_reserved == 0 and collapse._gz_in_flight == 0
 
 
 def test_sample_forms_of_the_command_line(tmp_path):
