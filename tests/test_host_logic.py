@@ -557,7 +557,7 @@ def test_parallel_inflations_reserve_their_memory(tmp_path, monkeypatch):
     rep.write_bytes(gzip.compress(rec * 400000, 6))
     assert collapse._gz_host_bytes(str(rep)) == 3 * len(rec) * 400000 > 100 * rep.stat().st_size
     rng = np.random.default_rng(5)
-    body = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 30).astype(np.uint8)), b"I" * 30) for i in range(60000))
+    body = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 30).astype(np.uint8)), b"I" * 30) for i in range(150000))
     files = []
     for k in range(4):
         f = tmp_path / f"s{k}.fastq.gz"
