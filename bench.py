@@ -92,6 +92,55 @@ def rocprof_symbol(rec_name):
     return base + "("
 
 
+def stage_rooflines(kernels, n_steps, raw_groups, uniq_groups, S, n_mirna, dom_roofline, tally=None):
+    """SURVEY.md 8(d) 'Algorithmic bytes' / BASELINE.md 3.4 price EVERY stage of the step, not only the dominant kernel:
+    collapse 9 B in per raw read + 13 B out per unique (+ 8 B per further word of a wider read); cascade 14 B per collapsed
+    read (the figure of `roofline`); count join (5 + 4 S) B in per collapsed read + 8 (2 R_mirna + 10) S B out; C5 tally
+    (9 + 4 S) B in per miRNA read + R_mirna * 30 * 12 * 8 B out.  Times: HIP events around every launch in the bracketed
+    warm-up steps of the same batch (`kernels`), summed over the BULK read group's kernels of the stage -- the small groups'
+    run beside them on streams of their own -- so each fraction is what the stage's critical path achieves."""
+    half = len(raw_groups) // 2
+    gi = int(np.argmax(raw_groups))
+    width = [1, 2, 4, 8, 16][gi % half]
+    sfx = f".w{width}" + ("n" if gi >= half else "")
+    extra = 8 * (width - 1)
+
+    def ms_of(pred):
+        names = [k for k in kernels if pred(k)]
+        return sum(kernels[k]["avg_ms"] * kernels[k]["launches"] for k in names) / n_steps, names
+
+    out = {}
+    coll_ms, coll_k = ms_of(lambda k: k.endswith(sfx) and k.startswith(("k_part_", "k_collapse_", "k_heads")))
+    n_raw, n_u = float(raw_groups[gi]), float(uniq_groups[gi])
+    if coll_ms > 0:
+        b = (9 + extra) * n_raw + (13 + extra) * n_u
+        out["collapse"] = {"kernels": sorted(coll_k), "ms": round(coll_ms, 5), "algorithmic_bytes": round(b, 1),
+                           "achieved": round(b / (coll_ms * 1e-3) / 1e9, 2), "frac": round(b / (coll_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                           "units": {"raw_reads": n_raw, "unique_reads": n_u},
+                           "bytes_per_unit": f"{9 + extra} in per raw read + {13 + extra} out per unique read"}
+    out["cascade"] = {"kernels": [dom_roofline["kernel"]], "ms": dom_roofline["avg_launch_ms"],
+                      "algorithmic_bytes": round(dom_roofline["algorithmic_bytes_per_unit"] * dom_roofline["units_per_launch"], 1),
+                      "achieved": dom_roofline["achieved"], "frac": dom_roofline["frac"], "bytes_per_unit": "see `roofline`"}
+    join_ms, join_k = ms_of(lambda k: k.startswith("k_join"))
+    n_all = float(sum(uniq_groups))
+    if join_ms > 0:
+        b = (5 + 4 * S) * n_all + 8 * (2 * n_mirna + 10) * S
+        out["join"] = {"kernels": sorted(join_k), "ms": round(join_ms, 5), "algorithmic_bytes": round(b, 1),
+                       "achieved": round(b / (join_ms * 1e-3) / 1e9, 2), "frac": round(b / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                       "units": {"unique_reads": n_all, "samples": S, "mirna_references": n_mirna},
+                       "bytes_per_unit": f"{5 + 4 * S} in per collapsed read (all groups) + {8 * (2 * n_mirna + 10) * S} out"}
+    tally_ms, tally_k = ms_of(lambda k: k in ("k_member_list", "k_tally"))
+    if tally is not None and tally_ms > 0:
+        b = (9 + 4 * S) * float(tally) + n_mirna * 30 * 12 * 8
+        out["c5_tally"] = {"kernels": sorted(tally_k), "ms": round(tally_ms, 5), "algorithmic_bytes": round(b, 1),
+                           "achieved": round(b / (tally_ms * 1e-3) / 1e9, 2), "frac": round(b / (tally_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                           "units": {"mirna_reads": float(tally)},
+                           "bytes_per_unit": f"{9 + 4 * S} in per miRNA read + {n_mirna * 30 * 12 * 8} out"}
+    for v in out.values():
+        v["unit"], v["peak"], v["bound"] = "GB/s", HBM_PEAK_GBS, "hbm"
+    return out
+
+
 def pmc_traffic(args, rec_name):
     """HBM bytes per launch of one kernel from the PMC counters, as MI355X_MICROARCH.md prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (no trace domains), kB units, and the gfx950
@@ -115,7 +164,7 @@ def pmc_traffic(args, rec_name):
         # rocprofv3 is a python script: run it with this interpreter (no '#!/usr/bin/env' hop)
         cmd = [sys.executable, rocprof, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "0", "--pmc", "0",
-               "--min-seconds", "0", "--spinup", "0", "--cli-path", "0", "--two-in-flight", "0",
+               "--min-seconds", "0", "--spinup", "0", "--cli-path", "0", "--two-in-flight", "0", "--read-sets", "0",
                "--reads", str(args.reads), "--scale", args.scale, "--workload", args.workload, "--pool", str(args.pool)]
         try:
             subprocess.run(cmd, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
@@ -296,6 +345,55 @@ def write_gzip_level6(text, path, piece=4 << 20):
     return os.path.getsize(path)
 
 
+def secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, ISO_PASS, out):
+    """Short legs on the two read sets SURVEY 8(d) specifies: same libraries, same step (mirge_collapse_cascade + count join), ~0.3 s
+    of steps each after 3 warm-up steps."""
+    res = {"default_draw": {"raw_reads": args.reads, "unique_reads": out["config"]["unique_reads_per_gpu"],
+                            "U_over_N": round(out["config"]["unique_reads_per_gpu"] / args.reads, 4), "ms_per_step": out["ms_per_step"],
+                            "M_raw_reads_per_s": out["value"], "M_collapsed_reads_per_s": out["collapsed_reads_per_s_M"],
+                            "note": "`value`: every read drawn independently from the class mix"}}
+    n = args.reads
+
+    def leg(reads_fs, note):
+        raw_s = _ffi.DeviceReads.pack(ctx, reads_fs)
+        u_n = [0]
+
+        def one():
+            uq, rs = casc.collapse_and_run(raw_s)
+            _ffi.count_join(ctx, uq, rs, EXACT_PASS, ISO_PASS, n_mirna)
+            u_n[0] = len(uq)
+            rs.close(); uq.close()
+        for _ in range(3):
+            one()
+        k = 0
+        t0 = time.perf_counter()
+        while k < 20 or time.perf_counter() - t0 < 0.3:
+            one(); k += 1
+        dt = (time.perf_counter() - t0) / k
+        raw_s.close()
+        return {"raw_reads": len(reads_fs), "unique_reads": u_n[0], "U_over_N": round(u_n[0] / len(reads_fs), 4), "steps": k,
+                "ms_per_step": round(dt * 1e3, 4), "M_raw_reads_per_s": round(len(reads_fs) / dt / 1e6, 1),
+                "M_collapsed_reads_per_s": round(u_n[0] / dt / 1e6, 1), "note": note}
+
+    pool = max(1000, n // 8)
+    res["zipf_pool"] = leg(synth.make_reads(sl, n, seed=2000, pool=pool),
+                           f"Zipf(s = 1.1) duplication over {pool} templates of the same class mix: SURVEY 8(d)'s 'realistic' set")
+    # all distinct: the default class mix without its duplicated exact-miRNA class, collapsed once on the GPU, its unique reads
+    # taken as the raw reads of the leg (every read once)
+    mix = dict(synth.DEFAULT_MIX, exact=0.01)
+    cand = synth.make_reads_chunked(sl, int(n * 1.25), seed=3000, mix=mix)
+    r0 = _ffi.DeviceReads.pack(ctx, cand)
+    u0 = r0.collapse()
+    distinct = u0.unpack()
+    u0.close(); r0.close()
+    del cand
+    if len(distinct) > n:
+        distinct = distinct.take(np.arange(n))
+    res["distinct"] = leg(distinct, "every read exactly once (U = N): SURVEY 8(d)'s 'stress' set -- the class mix minus its duplicated exact-miRNA "
+                                    "reads, de-duplicated; every read goes through the cascade")
+    return res
+
+
 def cli_path(args, sl, libs, text, n_pass):
     """FASTQ file -> all CSVs through the CLI's device-resident route, wall-clock: a first run (libraries read from
     their directory, packed, indexed: what a one-sample invocation pays) and a second one in the same process
@@ -430,6 +528,8 @@ def main():
     ap.add_argument("--spinup", type=float, default=0.3, help="seconds of untimed steps before the timed region (clock state)")
     ap.add_argument("--two-in-flight", dest="two_in_flight", type=int, default=1,
                     help="rank 0, N=1: also measure the step with TWO samples in flight on two contexts (never `value`)")
+    ap.add_argument("--read-sets", dest="read_sets", type=int, default=1,
+                    help="rank 0, N=1, c3: also step SURVEY 8(d)'s Zipf-pool (U/N ~ 5 %%) and all-distinct (U = N) read sets (never `value`)")
     ap.add_argument("--pmc", type=int, default=1,
                     help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()
@@ -529,6 +629,9 @@ def main():
         if args.workload == "c5":
             from mirge3_amd import a2i
             state["tally"] = a2i.tally(casc, uniq, res)["count_true"]
+            if state.get("want_groups"):  # miRNA reads (rows annotated by pass 0 or 8): the tally's unit
+                ps = res.fetch()[0]
+                state["mirna_reads"] = int(((ps == EXACT_PASS) | (ps == ISO_PASS)).sum())
         state["U"] = len(uniq)
         state["cls"] = cls
         if state.get("want_groups"):
@@ -703,6 +806,28 @@ def main():
             "note": "the same launch priced per (read, pass): a unit is a read handed to a pass (k_pass's 4 B index + 9 B read in, "
                     "5 B out), summed over the passes from the per-workgroup survivor counters of the bracketed warm-up steps; "
                     "rounds 1-3 reported this figure as `frac`"}
+
+    if rank == 0:
+        try:
+            out["roofline_stages"] = stage_rooflines(kernels, n_tab_steps, raw.group_counts(), state["groups"], 1, n_mirna, out["roofline"],
+                                                     state.get("mirna_reads") if args.workload == "c5" else None)
+            out["roofline_stages_note"] = ("every stage of the step on SURVEY 8(d)'s algorithmic bytes against the 8 TB/s HBM peak; times = HIP "
+                                           "events of the bracketed warm-up steps, bulk read group's kernels of the stage (its critical path)")
+            w = _ffi.cascade_walks(ctx)
+            out["cascade_walks"] = {"walks": w[0], "exact_lookup_passes": w[1], "passes": w[2],
+                                    "note": "bulk group of one-word reads: walks over its survivor lists; passes answered by one whole-read "
+                                            "lookup inside another pass's walk (round 5: exact miRNA, primary tRNA); merged runs count once"}
+        except Exception as e:  # noqa: BLE001 -- a secondary figure must not take the line down
+            out["roofline_stages"] = {"error": repr(e)[:300]}
+
+    # ---------------- SURVEY 8(d)'s two read sets beside the default draw (never `value`): Zipf duplication over a template pool
+    # (U/N of a few percent, the "realistic" set) and all-distinct reads (U = N, "stress").  The default sample -- every read
+    # drawn independently, U/N = 0.42 -- is neither; `value` swings 2 x between the two, so the line carries all three.
+    if rank == 0 and n_gpus == 1 and args.read_sets and args.workload == "c3" and not args.pool:
+        try:
+            out["read_sets"] = secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, ISO_PASS, out)
+        except Exception as e:  # noqa: BLE001
+            out["read_sets"] = {"error": repr(e)[:300]}
 
     # ---------------- the same from the FILE's text (never `value`): FASTQ bytes in host memory -> records parsed,
     # filtered, packed on the GPU -> collapse -> cascade -> count tables on the host

@@ -109,8 +109,8 @@ int mirge_reads_parse(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t 
 int32_t mirge_reads_iupac_seen(const mirge_reads* reads);
 /* The same with the read modifiers the reference runs through cutadapt before it counts a read (digest.py:59-101; SURVEY.md
  * 8f row N4), applied on the device between record finding and the length filter: NextSeq quality trimming, quality
- * trimming, adapter removal (one 3' or one 5' adapter), N trimming, unconditional cuts -- in that order, each present
- * when its field says so.
+ * trimming, adapter removal (one or two adapters, 3' or 5', regular or anchored, or one linked adapter), N trimming,
+ * unconditional cuts -- in that order, each present when its field says so.
  * count_per_modifier = 1 reproduces the reference's worker at HEAD, which tests the length and counts the read after
  * EVERY modifier (digest.py:354-373); 0 counts the fully trimmed read once.  *n_records stays the number of records of
  * the text.  trim == NULL: mirge_reads_parse.  Restated from cutadapt's published algorithms: parity unpinned. */
@@ -136,6 +136,13 @@ typedef struct mirge_trim {
     int32_t match_read_wildcards;  /* --match-read-wildcards: an N in the read matches every adapter base                  */
     int32_t no_adapter_wildcards;  /* -N: an N in the adapter is not a wildcard                                            */
     int32_t action_none;      /* --action none: adapters are searched, the read is left as it is                          */
+    /* anchored and linked adapters, as cutadapt's parser makes them of the specification strings the reference hands through
+     * unchanged (digest.py:66-84; docs/source/quick_start.md:213-220 shows `-g "TTAGGC...TGGAATTCTCGGGTGCCAAGGAACTCCAGT"`):  */
+    int32_t adapter_anchored; /* `-g ^ADAPTER`: the whole adapter at the read's first base / `-a ADAPTER$`: up to its last base */
+    int32_t adapter2_anchored;
+    int32_t linked;           /* 1: `adapter` (adapter_front = 1) and `adapter2` (3') are the two parts of ONE linked adapter
+                               * ADAPTER1...ADAPTER2: the 5' part is searched first, the 3' part in what follows it             */
+    int32_t linked_required;  /* bit 0: no match without the 5' part, bit 1: without the 3' part (`-a A...B`: 1, `-g A...B`: 3)  */
 } mirge_trim;
 int mirge_reads_parse_trim(mirge_ctx* ctx, const char* text, int64_t nbytes, int32_t format, int32_t min_len,
                            const mirge_trim* trim, mirge_reads** out, int64_t* n_records);
@@ -217,6 +224,11 @@ int mirge_cascade_run(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib*
  * library release; here it is device work of a process's first sample (timed separately by bench.py's cli_path). */
 int mirge_cascade_prepare(mirge_ctx* ctx, const mirge_reads* reads, const mirge_lib* const* libs, const mirge_policy* policies,
                           int32_t n_pass);
+/* How the ctx's current cascade configuration (the last mirge_cascade_prepare / _run / mirge_collapse_cascade) walks the bulk
+ * group of one-word reads: walks[0] = walks over its survivor list, walks[1] = passes answered by one whole-read lookup
+ * ("-v 0", or "-n 0" inside the seed, over a small library: manifoldAlign.py:85 passes 0 and 3) that ride in another pass's
+ * walk, walks[2] = passes in all.  Nothing in the reference corresponds to it: diagnostics for tests and bench.py. */
+int mirge_cascade_walks(mirge_ctx* ctx, int32_t* walks);
 /* mirge_collapse followed by mirge_cascade_run for ONE sample, as one call: the bulk read group's passes are queued on
  * the GPU behind the collapse kernels before the host has read the unique counts back (the kernels take the count
  * from device memory), so the GPU does not idle across the collapse's host synchronisation.  Same results; falls

@@ -26,7 +26,7 @@ EXPORTS = [
     "mirge_reads_n_samples", "mirge_reads_group_counts", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
-    "mirge_cascade_prepare", "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
+    "mirge_cascade_prepare", "mirge_cascade_walks", "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
 
@@ -43,14 +43,17 @@ class MirgeTrim(C.Structure):
                 ("error_rate", C.c_double), ("trim_n", C.c_int32), ("n_cut", C.c_int32), ("cut", C.c_int32 * 2),
                 ("count_per_modifier", C.c_int32), ("adapter_front", C.c_int32), ("adapter2", C.c_char_p),
                 ("adapter2_len", C.c_int32), ("adapter2_front", C.c_int32), ("times", C.c_int32), ("no_indels", C.c_int32),
-                ("match_read_wildcards", C.c_int32), ("no_adapter_wildcards", C.c_int32), ("action_none", C.c_int32)]
+                ("match_read_wildcards", C.c_int32), ("no_adapter_wildcards", C.c_int32), ("action_none", C.c_int32),
+                ("adapter_anchored", C.c_int32), ("adapter2_anchored", C.c_int32), ("linked", C.c_int32), ("linked_required", C.c_int32)]
 
     @staticmethod
     def make(adapter: Optional[str] = None, quality_back: int = -1, quality_front: int = 0, nextseq: int = -1,
              phred_base: int = 33, min_overlap: int = 3, error_rate: float = 0.12, trim_n: bool = False,
              cut: Sequence[int] = (), count_per_modifier: bool = True, front: bool = False,
              adapter2: Optional[str] = None, front2: bool = False, times: int = 1, indels: bool = True,
-             read_wildcards: bool = False, adapter_wildcards: bool = True, action: str = "trim") -> "MirgeTrim":
+             read_wildcards: bool = False, adapter_wildcards: bool = True, action: str = "trim",
+             anchored: bool = False, anchored2: bool = False, linked: bool = False, front_required: bool = True,
+             back_required: bool = False) -> "MirgeTrim":
         t = MirgeTrim()
         t.nextseq_cutoff, t.quality_front, t.quality_back, t.phred_base = nextseq, quality_front, quality_back, phred_base
         a = adapter.encode() if adapter else None
@@ -69,6 +72,9 @@ class MirgeTrim(C.Structure):
         if action not in ("trim", "none"):
             raise NotImplementedError("--action mask / lowercase change the letters of a read, not its bounds: not part of the MI355X path")
         t.action_none = 1 if action == "none" else 0
+        t.adapter_anchored, t.adapter2_anchored = 1 if anchored else 0, 1 if anchored2 else 0
+        t.linked = 1 if linked else 0
+        t.linked_required = (1 if front_required else 0) | (2 if back_required else 0)
         return t
 
 
@@ -571,6 +577,14 @@ def cascade_prepare(ctx: Context, reads: DeviceReads, libs: Sequence[Optional[De
     """Build the probe / plan tables a cascade over ``reads`` needs now (``mirge_cascade_prepare``) and wait for them."""
     arr, pol, n_pass = prepared if prepared is not None else cascade_args(libs, policies)
     _check(load().mirge_cascade_prepare(ctx._h, reads._h, arr, pol, n_pass), "mirge_cascade_prepare")
+
+
+def cascade_walks(ctx: "Context"):
+    """(walks over the bulk one-word group's list, passes answered by a whole-read lookup inside another pass's walk, passes) of
+    the ctx's current cascade configuration (``mirge_cascade_walks``)."""
+    w = (C.c_int32 * 3)()
+    _check(load().mirge_cascade_walks(ctx._h, w), "mirge_cascade_walks")
+    return int(w[0]), int(w[1]), int(w[2])
 
 
 def collapse_cascade(ctx: Context, raw: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],

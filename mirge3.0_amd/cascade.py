@@ -169,3 +169,81 @@ def bwt_align(args, pdDataFrame, workDir, ref_db):
     outlog.write(f'Alignment completed in {round(finish-begningTime, 4)} second(s)\n')
     outlog.close()
     return pdDataFrame
+
+
+def bwt_align_bowtie(args, pdDataFrame, workDir, ref_db):
+    """``--backend bowtie``: the reference's own cascade across its process boundary -- what ``bwtAlign`` / ``alignPlusParse`` do
+    (manifoldAlign.py:12-64,68-146): per pass the subset rule, a FASTA whose record names are the sequences (the head without
+    its T run for pass 3), ``<bowtie_path>/bowtie <index><argument string verbatim><threads> <fasta>``, every SAM line with a
+    reference name written into the pass's column (the last line of a read wins).  BASELINE.md's C1 through this build's CLI,
+    and a user-side parity switch: the same FASTQ through ``--backend gpu`` and ``--backend bowtie`` must give the same tables
+    wherever a real bowtie 1.x is installed (none in this image or on the GPU pool: tests run it against the stand-ins).
+    Indexes: ``<index>.1.ebwt`` as the reference expects; built with ``bowtie-build`` from ``<index>.fa`` when missing."""
+    import re
+    import shutil
+    import subprocess
+    begningTime = time.perf_counter()
+    outlog = open(str(Path(workDir) / "run.log"), "a+")
+    if not args.quiet:
+        print("Alignment in progress (bowtie backend) ...")
+    outlog.write("Alignment in progress (bowtie backend) ...\n")
+    bdir = getattr(args, "bowtie_path", None)
+    bowtie = str(Path(bdir) / "bowtie") if bdir else (shutil.which("bowtie") or "bowtie")
+    build = str(Path(bdir) / "bowtie-build") if bdir else shutil.which("bowtie-build")
+    threads = int(getattr(args, "threads", 0) or 0) or (os.cpu_count() or 1)
+    indexPath = Path(args.libraries_path) / args.organism_name / "index.Libs"
+    # manifoldAlign.py:84-85: index name fragments and argument strings, in pass order
+    indexNames = ['_mirna_', '_hairpin_', '_mature_trna', '_pre_trna', '_snorna', '_rrna', '_ncrna_others', '_mrna', '_mirna_', '_spike-in']
+    colnames = list(pdDataFrame.columns)
+    n_iter = 10 if args.spikeIn else 9
+    fasta = Path(workDir) / "bwtInput.fasta"
+    for it in range(n_iter):
+        name = indexNames[it] + ref_db if it in (0, 1, 8) else indexNames[it]
+        base = indexPath / (args.organism_name + name)
+        if not Path(str(base) + ".1.ebwt").exists() and not Path(str(base) + ".1.ebwtl").exists():
+            if Path(str(base) + ".fa").exists() and build and Path(build).exists():
+                subprocess.run([build, "-q", str(base) + ".fa", str(base)], check=True, stdout=subprocess.DEVNULL)
+            elif not Path(str(base) + ".fa").exists():  # (a stand-in bowtie may answer from <index>.fa; a real one says what it misses)
+                continue
+        seqs = pdDataFrame.index
+        if it == 0:
+            recs = [(q, q) for q in seqs if len(q) < 26]                      # :93
+        elif it == 1:
+            recs = [(q, q) for q in seqs if len(q) > 25]                      # :104
+        else:
+            un = pdDataFrame.index[pdDataFrame[colnames[0]].eq(0)]            # :120,129
+            if it == 3:                                                       # :118-126
+                recs = [(q, q[:re.search('T{3,}$', q).start()]) for q in un if re.search('T{3,}$', q)]
+            else:
+                recs = [(q, q) for q in un]
+        with open(fasta, "w") as fh:
+            fh.write("".join(f">{q}\n{x}\n" for q, x in recs))
+        cmd = bowtie + " " + str(base) + PASSES[it][2] + str(threads) + " " + str(fasta)
+        sam = subprocess.run(cmd, shell=True, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
+        hit = {}
+        for ln in sam.split("\n"):                                            # :50-56
+            if ln and not ln.startswith("@"):
+                f = ln.split("\t")
+                if len(f) > 2 and f[2] != "*":
+                    hit[f[0]] = f[2]
+        if hit:
+            idx = pdDataFrame.index.get_indexer(list(hit))
+            col = pdDataFrame[colnames[1 + it]].to_numpy(dtype=object).copy()
+            col[idx] = list(hit.values())
+            pdDataFrame[colnames[1 + it]] = col
+            flag = pdDataFrame[colnames[0]].to_numpy().copy()
+            flag[idx] = 1
+            pdDataFrame[colnames[0]] = flag
+    try:
+        os.remove(fasta)
+    except OSError:
+        pass
+    finish = time.perf_counter()
+    if not args.spikeIn:
+        pdDataFrame = pdDataFrame.drop(columns=['spike-in'])
+    pdDataFrame = pdDataFrame.fillna('')
+    if not args.quiet:
+        print(f'Alignment completed in {round(finish-begningTime, 4)} second(s)\n')
+    outlog.write(f'Alignment completed in {round(finish-begningTime, 4)} second(s)\n')
+    outlog.close()
+    return pdDataFrame

@@ -83,6 +83,10 @@ def parse_args(argv=None):
                     help="-ai without bowtie: file of the edited canonical sequences that align to the genome")
     ap.add_argument("-cpu", "--threads", dest="threads", type=int, default=0, help="accepted; only -ai's bowtie runs use it")
     ap.add_argument("--device", type=int, default=None)
+    ap.add_argument("--backend", choices=("gpu", "bowtie"), default="gpu",
+                    help="gpu (default): the cascade on the MI355X.  bowtie: the reference's ten bowtie runs across its process "
+                         "boundary (-pbwt / PATH; collapse and the count tables stay as they are): BASELINE's C1 configuration and a "
+                         "parity switch -- both backends must write the same tables")
     # flags of mirge/libs/parse.py that the reference itself never reads (-M, -l, --gc-content, -cms, --compression-level,
     # -op, --numba-*), that only size its worker chunks (--buffer-size), that name tools or carry parameters of the
     # subsystems refused below (-psam, -prf, -mdt, -kh/-ks/-ke, -minl ... -clc), or that it fills in itself (-cuv, -buv):
@@ -121,6 +125,8 @@ def parse_args(argv=None):
     args.bowtieVersion = "True"
     if (args.AtoI or args.gff_out) and (args.save_pkl or args.resume):
         ap.error("-ai / -gff run on the device-resident route: not together with -spl / -rr")
+    if args.backend == "bowtie" and (args.AtoI or args.gff_out or args.isoform_entropy):
+        ap.error("--backend bowtie writes the count tables and mapped.csv / unmapped.csv; -ai / -gff / -ie take per-read data of the GPU cascade")
     return args
 
 
@@ -236,7 +242,7 @@ def main(argv=None):
             df = pd.read_pickle(rootToPKL / "collapsed.pkl")
             with open(rootToPKL / "collapsed_accessories.pkl", "rb") as pklin:
                 src, trimmed, uniq, files, base_names = pickle.load(pklin)
-        elif fastpath.eligible(args):
+        elif fastpath.eligible(args) and args.backend == "gpu":
             # everything between the files' text and the count tables stays on the GPU (fastpath.py); the three
             # reference-signature functions below remain the drop-ins for the reference's own call sites
             fastpath.run(args, files, base_names, workDir, ref_db)
@@ -249,12 +255,18 @@ def main(argv=None):
             df.to_pickle(workDir / "collapsed.pkl")
             with open(workDir / "collapsed_accessories.pkl", "wb") as pklac:
                 pickle.dump([src, trimmed, uniq, files, base_names], pklac, protocol=pickle.HIGHEST_PROTOCOL)
-        df = bwt_align(args, df, str(workDir), ref_db)
+        if args.backend == "bowtie":
+            from .cascade import bwt_align_bowtie
+            df = bwt_align_bowtie(args, df, str(workDir), ref_db)
+        else:
+            df = bwt_align(args, df, str(workDir), ref_db)
         pdMapped, pdUnmapped = df[df.annotFlag.eq(1)], df[df.annotFlag.eq(0)]
         summarize(args, str(workDir), ref_db, base_names, pdMapped, src, trimmed, uniq)
         pdMapped.to_csv(workDir / "mapped.csv")
         pdUnmapped.to_csv(workDir / "unmapped.csv")
     else:
+        if args.backend == "bowtie":
+            sys.exit("--backend bowtie is a single-process option")
         from .cascade import get_cascade
         casc = get_cascade(args, ref_db, args.device)
 
@@ -265,9 +277,21 @@ def main(argv=None):
         def process(i):  # device-resident per sample (fastpath.run_sample_tables)
             return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc, via_files)
 
+        t_shard = time.perf_counter()
         tables = multigpu.run_sharded(len(files), rank, world, process, dist)
+        t_gather = time.perf_counter()
         if rank == 0:  # the same files as the one-process run: count tables, ONE mapped.csv / unmapped.csv, -gff / -ai / -ie
-            fastpath.run_sharded_rank0(args, tables, workDir, ref_db, casc)
+            tm = {}
+            fastpath.run_sharded_rank0(args, tables, workDir, ref_db, casc, timings=tm)
+            # where a sharded run's time goes: every rank's sample, then rank 0's serial tail
+            import json
+            import resource
+            line = {"ranks": world, "samples": len(files), "samples_and_gather_s": round(t_gather - t_shard, 4),
+                    "per_sample": [dict(t.timing or {}, name=t.name, index=t.index) for t in tables],
+                    "rank0_tail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items() if not isinstance(v, (list, dict))},
+                    "rank0_peak_rss_MB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)}
+            with open(workDir / "run.log", "a+") as fh:
+                fh.write("sharded run timing: " + json.dumps(line) + "\n")
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and not args.quiet:

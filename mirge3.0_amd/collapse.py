@@ -591,15 +591,59 @@ def adapters_from_args(args):
     return adapters
 
 
+def parse_adapter_spec(kind: str, spec: str) -> dict:
+    """One adapter specification as cutadapt's parser reads it (the reference hands ``args.adapters`` to
+    ``make_adapters_from_specifications`` unchanged, digest.py:66-84; docs/source/quick_start.md:213-220 shows a linked one):
+      ``SEQ``            a regular 3' (-a) / 5' (-g) adapter
+      ``^SEQ`` (-g)      anchored 5': the whole adapter at the read's first base;  ``SEQ$`` (-a): anchored 3', up to its last base
+      ``A...B``          ONE linked adapter: 5' part A, then 3' part B in what follows.  Under ``-a`` A is anchored and required
+                         and B optional; under ``-g`` A is a regular 5' adapter and BOTH are required (a read without either
+                         stays as it is).  ``^A`` / ``B$`` anchor a part explicitly.
+    Refused (NotImplementedError, as before): non-internal forms (``XSEQ`` / ``SEQX``), ``name=`` prefixes, ``;parameters``,
+    ``file:`` references, ``-b``.  -> dict(kind, seq, anchored) or dict(linked=True, front, back, front_anchored, back_anchored,
+    front_required, back_required)."""
+    if kind not in ("back", "front"):
+        raise NotImplementedError("only -a (3') and -g (5') adapters are supported (-b 'anywhere' adapters are not)")
+    if spec.startswith("file:") or "=" in spec or ";" in spec:
+        raise NotImplementedError(f"adapter specification {spec!r}: names, parameters and file: references are not supported")
+    if "..." in spec:
+        front, back = spec.split("...", 1)
+        fa, ba = front.startswith("^"), back.endswith("$")
+        front, back = front[1 if fa else 0:], back[:-1] if ba else back
+        if not front or not back:
+            raise NotImplementedError(f"adapter specification {spec!r}: a linked adapter needs both parts (A...B)")
+        if "..." in back or any(c in front + back for c in "^$"):
+            raise SystemExit(f"adapter specification {spec!r}: not a valid linked adapter")
+        if front.upper().startswith("X") or back.upper().endswith("X"):
+            raise NotImplementedError(f"adapter specification {spec!r}: non-internal adapters (X) are not supported")
+        if kind == "back":
+            return dict(linked=True, front=front, back=back, front_anchored=True, back_anchored=ba, front_required=True, back_required=False)
+        return dict(linked=True, front=front, back=back, front_anchored=fa, back_anchored=ba, front_required=True, back_required=True)
+    anchored = False
+    if kind == "front" and spec.startswith("^"):
+        spec, anchored = spec[1:], True
+    elif kind == "back" and spec.endswith("$"):
+        spec, anchored = spec[:-1], True
+    if "^" in spec or "$" in spec:
+        raise SystemExit(f"adapter specification {spec!r}: '^' belongs in front of a 5' adapter (-g), '$' behind a 3' adapter (-a)")
+    if (kind == "front" and spec.upper().startswith("X")) or (kind == "back" and spec.upper().endswith("X")):
+        raise NotImplementedError(f"adapter specification {spec!r}: non-internal adapters (X) are not supported")
+    return dict(kind=kind, seq=spec, anchored=anchored)
+
+
 def trim_from_args(args):
     """The cutadapt modifier chain of ``stipulate`` (digest.py:59-101) as the options of ``mirge_reads_parse_trim``:
     ``-q`` (default "10": quality trimming is ALWAYS in the reference's chain), ``-a`` / ``-g`` (one or two adapters, 3'
-    or 5'; with two, a read loses the better match -- AdapterCutter with times = 1), ``-nxt``, ``-NX``, ``-u``,
+    or 5', regular or anchored; with two, a read loses the better match -- AdapterCutter with times = 1 --; or ONE linked
+    adapter ``A...B``: ``parse_adapter_spec``), ``-nxt``, ``-NX``, ``-u``,
     ``--overlap``, ``--error-rate``, ``-phr``, ``-n`` (repeat the removal), ``--no-indels``, ``--match-read-wildcards``, ``-N``,
     ``--action none``.  More than two adapters and ``--action mask`` / ``lowercase`` are refused."""
     adapters = adapters_from_args(args)
     if len(adapters) > 2 or any(kind not in ("back", "front") for kind, _ in adapters):
         raise NotImplementedError("up to two adapters are supported (-a / -g, in any combination)")
+    specs = [parse_adapter_spec(k, q) for k, q in adapters]
+    if any(sp.get("linked") for sp in specs) and len(specs) > 1:
+        raise NotImplementedError("a linked adapter (A...B) beside another adapter is not supported")
     q = getattr(args, "quality_cutoff", "10")
     qf, qb = 0, -1
     if q is not None:
@@ -617,17 +661,23 @@ def trim_from_args(args):
         raise SystemExit("You cannot remove bases from the same end twice.")
     nxt = getattr(args, "nextseq_trim", None)
     base = 64 if int(getattr(args, "phred64", 33) or 33) == 64 else 33
-    a1 = adapters[0] if adapters else (None, None)
-    a2 = adapters[1] if len(adapters) > 1 else (None, None)
-    return _ffi.MirgeTrim.make(adapter=a1[1], quality_back=qb, quality_front=qf, nextseq=-1 if nxt is None else int(nxt),
-                               phred_base=base, min_overlap=int(getattr(args, "overlap", 3)),
-                               error_rate=float(getattr(args, "error_rate", 0.12)), trim_n=bool(getattr(args, "trim_n", False)),
-                               cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once",
-                               front=a1[0] == "front", adapter2=a2[1], front2=a2[0] == "front",
-                               times=int(getattr(args, "times", 1) or 1), indels=bool(getattr(args, "indels", True)),
-                               read_wildcards=bool(getattr(args, "match_read_wildcards", False)),
-                               adapter_wildcards=bool(getattr(args, "match_adapter_wildcards", True)),
-                               action=str(getattr(args, "action", "trim") or "trim"))
+    common = dict(quality_back=qb, quality_front=qf, nextseq=-1 if nxt is None else int(nxt),
+                  phred_base=base, min_overlap=int(getattr(args, "overlap", 3)),
+                  error_rate=float(getattr(args, "error_rate", 0.12)), trim_n=bool(getattr(args, "trim_n", False)),
+                  cut=cut, count_per_modifier=getattr(args, "trim_count", "per-modifier") != "once",
+                  times=int(getattr(args, "times", 1) or 1), indels=bool(getattr(args, "indels", True)),
+                  read_wildcards=bool(getattr(args, "match_read_wildcards", False)),
+                  adapter_wildcards=bool(getattr(args, "match_adapter_wildcards", True)),
+                  action=str(getattr(args, "action", "trim") or "trim"))
+    if specs and specs[0].get("linked"):
+        lk = specs[0]
+        return _ffi.MirgeTrim.make(adapter=lk["front"], front=True, anchored=lk["front_anchored"], adapter2=lk["back"], front2=False,
+                                   anchored2=lk["back_anchored"], linked=True, front_required=lk["front_required"],
+                                   back_required=lk["back_required"], **common)
+    a1 = specs[0] if specs else dict(kind=None, seq=None, anchored=False)
+    a2 = specs[1] if len(specs) > 1 else dict(kind=None, seq=None, anchored=False)
+    return _ffi.MirgeTrim.make(adapter=a1["seq"], front=a1["kind"] == "front", anchored=a1["anchored"],
+                               adapter2=a2["seq"], front2=a2["kind"] == "front", anchored2=a2["anchored"], **common)
 
 
 def unpinned_trim_options(args) -> List[str]:
@@ -638,6 +688,11 @@ def unpinned_trim_options(args) -> List[str]:
     adapters = adapters_from_args(args)
     if len(adapters) == 2:
         out.append("two adapters (the better match is removed)")
+    for kind, q in adapters:
+        if "..." in q:
+            out.append("a linked adapter (A...B)")
+        elif q.startswith("^") or q.endswith("$"):
+            out.append("an anchored adapter (^A / A$)")
     if int(getattr(args, "times", 1) or 1) > 1:
         out.append("-n / --times")
     if not bool(getattr(args, "indels", True)):

@@ -496,34 +496,283 @@ struct FusedSteps {
     FusedStep s[MIRGE_MAX_PASSES_K];
 };
 
+// ------------------------------------------------------------------------------------------
+// Exact passes as ONE lookup of the whole read (round 5).  A pass whose policy admits no mismatch anywhere in the read it is
+// handed -- "-v 0" (pass 3, primary tRNA, manifoldAlign.py:85,118-126), or "-n 0" with a length rule that keeps the read inside
+// the seed (pass 0, exact miRNA: len < 26 <= 28, :85,93) -- over a SMALL library asks one question: is this very sequence a
+// substring of some reference, and where first?  The probe path answers it with a chain of dependent requests (non-empty bit ->
+// CSR bounds -> position list -> text window -> invalid bits: 4-5 L1-missing requests for every read that shares its first 9
+// bases with a miRNA, which is most of a sample's isomiRs); k_cascade_bulk is bound by the L1 misses a CU has in flight.
+// Here every valid window of the library, for every length the batch can ask for, sits in an open-addressing table keyed by
+// the whole sequence: entry = tag (27 bits of the hash) | length (5) | lowest position + 1 (32), 8 bytes, load factor <= 1/3,
+// 2 MB for the human miRNA set at read lengths 16-25: ONE request answers a miss, a tag match is confirmed against the text
+// (one more request, for the ~0.3 % of collapsed reads that are exact miRNAs), so the answer is exact whatever the tag width.
+// The lowest position among equal sequences is the cascade's documented tie-break (fewest mismatches -- 0 --, then lowest
+// reference, then leftmost offset); the table is built with atomicMin on entries of one (tag, length, sequence).
+// Because such a step costs a lane a few instructions, it does not get a walk over the survivor list of its own: it rides in
+// front of the next pass's alignment (`pre`) or behind the previous one's (`post`) -- per read the order of the passes is kept,
+// and no read's answer depends on another read's.  Human cascade: [exact miRNA | hairpin] [mature tRNA | primary tRNA]
+// [snoRNA+rRNA+ncRNA] [mRNA] [isomiR]: five walks instead of seven.
+// ------------------------------------------------------------------------------------------
+#ifndef MIRGE_EXACT_LAUNDER
+#define MIRGE_EXACT_LAUNDER 0  // 1: the step's descriptor re-read inside the loop through an opaque pointer (measured: its loads become vector loads)
+#endif
+#ifndef MIRGE_EXACT_RIDE
+#define MIRGE_EXACT_RIDE 1     // 1: an exact step rides in a neighbouring alignment pass's walk; 0: walks of their own (a loop without alignment)
+#endif
+struct ExactStep {
+    const uint64_t* slots;  // nullptr: no such step
+    const uint64_t* T;      // the library's text (confirmation of a tag match)
+    uint32_t mask;          // slots - 1
+    int32_t pass_id;
+    int32_t step;           // index of the pass in the ordinary step list (survivor accounting)
+    MirgePolicy pol;
+};
+MIRGE_HD uint64_t mirge_exact_tagged(uint64_t key, int l, uint32_t& slot) {  // -> (tag | length) << 32, first slot (unmasked)
+    const uint64_t h = mirge_mix64(key);
+    slot = (uint32_t)h;
+    return ((h >> 37) << 37) | ((uint64_t)l << 32);
+}
+
+// bases of T from position g on, as many as 31 of them (the packed text is padded by 8 words)
+__device__ __forceinline__ uint64_t text_from(gptr_u64 T, uint64_t g) {
+    const PairU64 t = load_pair64(T + (g >> 5));
+    const int s = (int)(g & 31) * 2;
+    return s ? ((t.a >> s) | (t.b << (64 - s))) : t.a;
+}
+
+// every valid window [p, p + l) of the library for the lengths in lmask (bit l), l <= 31: counted (FILL = false: duplicates
+// included, an upper bound that sizes the table) or inserted
+template <bool FILL>
+__global__ void k_exact_table(const uint64_t* __restrict__ T, const uint64_t* __restrict__ inv, uint64_t total, uint32_t lmask,
+                              uint64_t* __restrict__ slots, uint32_t mask, unsigned long long* __restrict__ count) {
+    unsigned long long mine = 0;
+    for (uint64_t p = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = p >> 6;
+        const int s = (int)(p & 63);
+        uint64_t bad = inv[q] >> s;
+        if (s) bad |= inv[q + 1] << (64 - s);
+        const int run = bad ? (int)__builtin_ctzll(bad) : 64;  // valid bases from p on
+        if (!run) continue;
+        const uint64_t bits = text_from((gptr_u64)T, p);
+        for (int l = 1; l <= 31 && l <= run; l++) {
+            if (!((lmask >> l) & 1u)) continue;
+            if (!FILL) { mine++; continue; }
+            const uint64_t seq = bits & mirge_lowmask2(l);
+            uint32_t sl;
+            const uint64_t tl = mirge_exact_tagged(seq | (1ull << (2 * l)), l, sl);
+            const uint64_t entry = tl | (uint64_t)((uint32_t)p + 1u);
+            for (sl &= mask;; sl = (sl + 1) & mask) {
+                unsigned long long cur = __hip_atomic_load((unsigned long long*)&slots[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == 0ull) {
+                    cur = atomicCAS((unsigned long long*)&slots[sl], 0ull, (unsigned long long)entry);
+                    if (cur == 0ull) break;
+                }
+                // the same (tag, length): the same sequence?  (an entry never changes its tag or length, and every position it
+                // has ever held shows the same l bases)
+                if ((cur >> 32) == (tl >> 32) && (text_from((gptr_u64)T, (uint64_t)((uint32_t)cur - 1u)) & mirge_lowmask2(l)) == seq) {
+                    atomicMin((unsigned long long*)&slots[sl], (unsigned long long)entry);  // the lowest position stays
+                    break;
+                }
+            }
+        }
+    }
+    if (!FILL) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+    }
+}
+
+// the step's answer for one read: true + its position when the (trimmed, eligible) read is a substring of a reference
+template <bool HASN>
+__device__ __forceinline__ bool exact_lookup(const ExactStep& e_in, MirgeRead<1> r, bool open, uint32_t& pos) {
+    // the step's descriptor is read HERE, every time: hoisted out of the walk's loop its ~16 scalars would stay live across
+    // align_hybrid, which already spills scalar registers (the empty asm hides that the pointer is loop-invariant)
+    const ExactStep* ep = &e_in;
+#if MIRGE_EXACT_LAUNDER
+    asm volatile("" : "+s"(ep));
+#endif
+    const ExactStep& e = *ep;
+    if (!open || !mirge_effective_read<1>(r, e.pol)) return false;
+    if (HASN && r.nm[0]) return false;  // an ambiguous call is a mismatch wherever it is aligned
+    uint32_t sl;
+    const uint64_t tl = mirge_exact_tagged(r.w[0] | (1ull << (2 * r.len)), r.len, sl);
+    gptr_u64 slots = (gptr_u64)e.slots;
+    for (sl &= e.mask;; sl = (sl + 1) & e.mask) {
+        const uint64_t cur = slots[sl];
+        if (cur == 0ull) return false;
+        if ((cur >> 32) == (tl >> 32)) {
+            const uint32_t p = (uint32_t)cur - 1u;
+            if ((text_from((gptr_u64)e.T, p) & mirge_lowmask2(r.len)) == r.w[0]) { pos = p; return true; }
+        }
+    }
+}
+
+// One walk of a workgroup over its list: an optional exact step in front (`pre`), an optional alignment pass (`main`: the
+// FusedStep, has_main), an optional exact step behind (`post`; only behind a main policy that leaves the read as it is).
+struct BulkWalk {
+    ExactStep pre, post;
+    FusedStep main;
+    int32_t has_main;
+    int32_t main_step;  // index of the main pass in the ordinary step list
+};
+struct BulkWalks {
+    int32_t n;
+    BulkWalk w[MIRGE_MAX_PASSES_K];
+};
+
+// reads of this wave that are still open, added to a workgroup counter (survivor accounting of the steps inside a walk)
+__device__ __forceinline__ void count_open(bool open, uint32_t* ctr) {
+    const unsigned long long b = __ballot(open);
+    if (b && (threadIdx.x & 63) == 0) atomicAdd(ctr, (uint32_t)__popcll(b));
+}
+
+// pass_segment for a walk: per read pre -> main -> post, in the cascade's order
+template <int W, bool LDSP, bool COHERENT, bool HASN>
+__device__ __forceinline__ void walk_segment(const BulkWalk& wk, const PlanSrc<LDSP>& psrc, const GroupView<W>& g, const uint32_t* act_in,
+                                             uint32_t n_in, size_t seg, size_t seg_r, uint32_t* __restrict__ act_out,
+                                             int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm,
+                                             uint32_t* s_count, uint32_t* s_open) {
+    const int lane = threadIdx.x & 63;
+    const bool has_main = wk.has_main != 0;
+    if (W == 1 && !has_main) {  // a walk of exact steps only: its own short loop, nothing of the alignment's registers alive
+        if constexpr (W == 1) {
+            const bool two = wk.pre.slots != nullptr && wk.post.slots != nullptr;
+            for (uint32_t base = 0; base < n_in; base += MIRGE_BLOCK) {
+                const uint32_t t = base + threadIdx.x;
+                const bool valid = t < n_in;
+                uint32_t idx = 0;
+                if (valid) {
+                    if (!act_in) idx = (uint32_t)seg_r + t;
+                    else idx = COHERENT ? __hip_atomic_load(&act_in[seg + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : act_in[seg + t];
+                }
+                MirgeRead<1> r2;
+                r2.w[0] = 0; r2.nm[0] = 0; r2.len = 0;
+                if (valid) load_read<1, HASN>(g, idx, r2);
+                bool open = valid;
+                uint32_t p;
+                if (wk.pre.slots && exact_lookup<HASN>(wk.pre, r2, open, p)) {
+                    res_pass[idx] = (int8_t)wk.pre.pass_id; res_pos[idx] = p; res_mm[idx] = 0;
+                    open = false;
+                }
+                if (two) count_open(open, &s_open[0]);
+                if (wk.post.slots && exact_lookup<HASN>(wk.post, r2, open, p)) {
+                    res_pass[idx] = (int8_t)wk.post.pass_id; res_pos[idx] = p; res_mm[idx] = 0;
+                    open = false;
+                }
+                if (open && !act_in) { res_pass[idx] = -1; res_mm[idx] = -1; }
+                const unsigned long long bal = __ballot(open);
+                if (bal) {
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(s_count, (uint32_t)__popcll(bal));
+                    wbase = __shfl(wbase, 0, 64);
+                    if (open) act_out[seg + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+                }
+            }
+        }
+        return;
+    }
+    const bool has_pre = MIRGE_EXACT_RIDE && W == 1 && wk.pre.slots != nullptr, has_post = MIRGE_EXACT_RIDE && W == 1 && wk.post.slots != nullptr;
+    for (uint32_t base = 0; base < n_in; base += MIRGE_BLOCK) {
+        const uint32_t t = base + threadIdx.x;
+        const bool valid = t < n_in;
+        uint32_t idx = 0;
+        if (valid) {
+            if (!act_in) idx = (uint32_t)seg_r + t;
+            else idx = COHERENT ? __hip_atomic_load(&act_in[seg + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : act_in[seg + t];
+        }
+        MirgeRead<W> r2;
+        if (valid) load_read<W, HASN>(g, idx, r2);
+        else {
+#pragma unroll
+            for (int w = 0; w < W; w++) { r2.w[w] = 0; r2.nm[w] = 0; }
+            r2.len = 0;
+        }
+        bool open = valid;
+        if constexpr (W == 1 && MIRGE_EXACT_RIDE) {
+            if (has_pre) {
+                uint32_t p;
+                if (exact_lookup<HASN>(wk.pre, r2, open, p)) {
+                    res_pass[idx] = (int8_t)wk.pre.pass_id; res_pos[idx] = p; res_mm[idx] = 0;
+                    open = false;
+                }
+                if (has_main || has_post) count_open(open, &s_open[0]);
+            }
+        }
+        if (has_main) {
+            const bool elig = open && mirge_effective_read<W>(r2, wk.main.pol);  // (a policy `post` follows leaves r2 as it was)
+            uint64_t best;
+            align_hybrid<W, LDSP>(wk.main.lib, wk.main.pol, wk.main.mi, psrc, r2, elig, best);
+            if (elig && best != MIRGE_NO_HIT) {
+                const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
+                res_pass[idx] = (int8_t)(wk.main.pass_id + cls);
+                uint32_t b0 = 0;
+#pragma unroll
+                for (int i = 1; i < 4; i++) if (i == cls) b0 = wk.main.mi.bound[i];
+                res_pos[idx] = (uint32_t)best - b0;  // position in that member's own text
+                res_mm[idx] = (int8_t)((best >> 32) & 0xFF);
+                open = false;
+            }
+            if (has_post) count_open(open, &s_open[1]);
+        }
+        if constexpr (W == 1 && MIRGE_EXACT_RIDE) {
+            if (has_post) {
+                uint32_t p;
+                if (exact_lookup<HASN>(wk.post, r2, open, p)) {
+                    res_pass[idx] = (int8_t)wk.post.pass_id; res_pos[idx] = p; res_mm[idx] = 0;
+                    open = false;
+                }
+            }
+        }
+        if (open && !act_in) {     // the first walk sees every read of the group: it also writes "unannotated"
+            res_pass[idx] = -1;
+            res_mm[idx] = -1;
+        }
+        const unsigned long long bal = __ballot(open);
+        if (bal) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(s_count, (uint32_t)__popcll(bal));
+            wbase = __shfl(wbase, 0, 64);
+            if (open) act_out[seg + wbase + __popcll(bal & ((1ull << lane) - 1ull))] = idx;
+        }
+    }
+}
+
 // HASN = false: the build for a group without ambiguous calls -- its N masks are compile-time zeros and fold away in everything
 // inlined behind the load (7 fewer spilled scalar registers, -2 % kernel time on the bulk group)
 template <int W, bool HASN>
 __global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(W == 1 ? MIRGE_BULK_WAVES : 1, 8)))  // one-word reads: 6 workgroups per CU must be resident (80 VGPRs; k_pass: 77); wider reads keep their registers
-k_cascade_bulk(const FusedSteps* __restrict__ steps, GroupView<W> g, uint32_t* __restrict__ actA, uint32_t* __restrict__ actB,
+k_cascade_bulk(const BulkWalks* __restrict__ walks, GroupView<W> g, uint32_t* __restrict__ actA, uint32_t* __restrict__ actB,
                uint32_t* __restrict__ seg_n, uint32_t cap, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
                int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t s_count;
+    __shared__ uint32_t s_open[2];  // reads still open behind the walk's pre step / behind its main pass
     constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
     __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? sizeof(LdsPlan) : 16];
     LdsPlan* s_plan = reinterpret_cast<LdsPlan*>(s_plan_raw);
-    const int nsteps = steps->n;
+    const int nwalks = walks->n;
     const size_t seg = (size_t)blockIdx.x * cap;
     size_t seg_r = seg;
     uint32_t n_in = first_pass_share(g.n, n_dev, cap, seg_r);
     const uint32_t* act_in = nullptr;
     uint32_t* act_out = actA;
-    for (int si = 0; si < nsteps; si++) {
-        const FusedStep& st = steps->s[si];
-        if (threadIdx.x == 0) s_count = 0;
-        if (LDSP) lds_plan_fill(*s_plan, st.lib, st.plan);
+    for (int wi = 0; wi < nwalks; wi++) {
+        const BulkWalk& wk = walks->w[wi];
+        if (threadIdx.x == 0) { s_count = 0; s_open[0] = 0; s_open[1] = 0; }
+        if (LDSP && wk.has_main) lds_plan_fill(*s_plan, wk.main.lib, wk.main.plan);
         __syncthreads();
         PlanSrc<LDSP> psrc;
-        psrc.g = st.plan; psrc.l = LDSP ? s_plan : nullptr;
-        pass_segment<W, LDSP, !MIRGE_SURV_PLAIN_LOADS, HASN>(st.lib, st.pol, st.mi, psrc, g, act_in, n_in, seg, seg_r, act_out, st.pass_id, res_pass, res_pos, res_mm, &s_count);
+        psrc.g = wk.main.plan; psrc.l = LDSP ? s_plan : nullptr;
+        walk_segment<W, LDSP, !MIRGE_SURV_PLAIN_LOADS, HASN>(wk, psrc, g, act_in, n_in, seg, seg_r, act_out, res_pass, res_pos, res_mm, &s_count, s_open);
         __syncthreads();  // the survivors are written (and visible to this workgroup at L2), the plan is free again
         n_in = s_count;
-        if (threadIdx.x == 0) seg_n[(size_t)si * gridDim.x + blockIdx.x] = n_in;
+        if (threadIdx.x == 0) {  // seg_n[step][workgroup] = reads still open behind that pass (= handed to the next one)
+            const bool pre = W == 1 && wk.pre.slots, post = W == 1 && wk.post.slots;
+            if (pre) seg_n[(size_t)wk.pre.step * gridDim.x + blockIdx.x] = (wk.has_main || post) ? s_open[0] : n_in;  // (exact-only walk of two steps: s_open[0] too)
+            if (wk.has_main) seg_n[(size_t)wk.main_step * gridDim.x + blockIdx.x] = post ? s_open[1] : n_in;
+            if (post) seg_n[(size_t)wk.post.step * gridDim.x + blockIdx.x] = n_in;
+        }
         __syncthreads();  // everybody has read s_count before it is reset
         act_in = act_out;
         act_out = (act_out == actA) ? actB : actA;

@@ -205,6 +205,12 @@ __device__ __forceinline__ uint32_t region_prefix(const uint32_t* __restrict__ c
 #ifndef MIRGE_PART_THREADS
 #define MIRGE_PART_THREADS 1024
 #endif
+#ifndef MIRGE_AGG_BUCKET4
+#define MIRGE_AGG_BUCKET4 1
+#endif
+#ifndef MIRGE_AGG_UNROLL
+#define MIRGE_AGG_UNROLL 2  // (measured, round 5: 0.131 -> 0.122 ms per 9.6 M reads; 4 reads per trip: the same)
+#endif
 __global__ void __launch_bounds__(MIRGE_PART_THREADS)
 k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uint32_t chunk, uint32_t shift1, uint32_t NB1,
            uint32_t bshift, uint32_t B, uint32_t CS, uint32_t cap1, uint4* __restrict__ rec1, uint32_t* __restrict__ cnt1,
@@ -228,20 +234,60 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
             if (hist) atomicAdd(&lds_h[(uint32_t)(h >> bshift)], 1u);
         }
     };
-    for (uint32_t j0 = lo; j0 < hi; j0 += blockDim.x) {
-        const uint32_t j = j0 + threadIdx.x;
+    // MIRGE_AGG_UNROLL reads per thread and trip, their loads (key, length, raw index) issued together: with one workgroup per CU
+    // the kernel is a chain of load -> LDS-atomic latencies, and sixteen waves with one load each in flight do not cover HBM
+    for (uint32_t j0 = lo; j0 < hi; j0 += blockDim.x * MIRGE_AGG_UNROLL) {
+        unsigned long long keys[MIRGE_AGG_UNROLL];
+        uint32_t jrs[MIRGE_AGG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < MIRGE_AGG_UNROLL; u++) {
+            const uint32_t j = j0 + u * blockDim.x + threadIdx.x;
+            keys[u] = 0ull; jrs[u] = 0;
+            if (j < hi) {
+                keys[u] = read_key64(g, j);
+                // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
+                // instead of gathered per unique read at the end)
+                jrs[u] = orig ? orig[j] : base + j;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MIRGE_AGG_UNROLL; u++) {
+        const uint32_t j = j0 + u * blockDim.x + threadIdx.x;
         bool direct = false;
-        unsigned long long key = 0ull;
-        uint32_t jr = 0;
+        unsigned long long key = keys[u];
+        uint32_t jr = jrs[u];
         uint64_t h = 0;
         if (j < hi) {
-            key = read_key64(g, j);
-            // index among ALL raw reads (orig[] ascends with j, so min commutes; read coalesced here
-            // instead of gathered per unique read at the end)
-            jr = orig ? orig[j] : base + j;
             h = mirge_mix64(key);
-            uint32_t s = (uint32_t)(h >> 9) & (CS - 1);
             direct = true;
+#if MIRGE_AGG_BUCKET4
+            // the cache as 4-way buckets (round 5): the four keys of the read's home bucket come with ONE 32-byte read (two
+            // ds_read_b128 issued together) instead of up to four dependent probes; a key lives in the first slot of its bucket
+            // that was free when it arrived (slots never change once set, every inserter walks them in order and takes the
+            // compare-and-swap's word for what a slot holds: no key can sit in two slots), so a later copy always finds it
+            const uint32_t b0 = ((uint32_t)(h >> 9) & (CS / 4 - 1)) * 4;
+            const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(&lds_a[b0]);
+            const ulonglong2 kb = *reinterpret_cast<const ulonglong2*>(&lds_a[b0 + 2]);
+            const unsigned long long k4[4] = {ka.x, ka.y, kb.x, kb.y};
+            int slot = -1;
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (slot < 0 && k4[t] == key) slot = t;
+            if (slot < 0) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (slot >= 0 || k4[t] != 0ull) continue;  // (held by another key when read: it still is)
+                    const unsigned long long c0 = atomicCAS(&lds_a[b0 + t], 0ull, key);
+                    if (c0 == 0ull || c0 == key) slot = t;
+                }
+            }
+            if (slot >= 0) {
+                const uint32_t s = b0 + (uint32_t)slot;
+                if (*(volatile uint32_t*)&c_min[s] > jr) atomicMin(&c_min[s], jr);
+                atomicAdd(&c_cnt[s], 1u);
+                direct = false;
+            }
+#else
+            uint32_t s = (uint32_t)(h >> 9) & (CS - 1);
             // four probes, always: a hot key that was displaced from its home slot when it arrived must still be found by its
             // later copies (looking at the home slot only once the cache is full was 6 % faster on unskewed reads and sent
             // every copy of such a key to its bin as a record of its own on a Zipf sample)
@@ -258,6 +304,7 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
                 }
                 s = (s + 1) & (CS - 1);
             }
+#endif
         }
         // cache full around this key: the read itself becomes a record.  Copies of ONE sequence that meet in a wave are
         // merged first (two rounds: the key of the first such lane, then of the first lane left) -- a burst of a sequence that
@@ -282,6 +329,7 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
             open = open && !same;
         }
         if (direct) append(key, h, jr, count);
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < CS; i += blockDim.x) {  // flush the cache
@@ -355,7 +403,11 @@ k_part_split(const uint4* __restrict__ rec1, const uint32_t* __restrict__ cnt1, 
 // The bucket's records lie in R shares: share r holds cnt[bucket * R + r] records (clamped to rcap) from
 // rec[(bucket * R + r) * rcap]  (off == nullptr: level-1 regions), or from rec[((bucket / NB2) * R + r) * rcap + off[bucket * R + r]]
 // (ranges inside the level-2 slabs of capacity rcap).
-#define MIRGE_DEDUP_THREADS 1024
+#ifndef MIRGE_DEDUP_THREADS
+// 512 threads: four workgroups per CU are resident (a CU holds 2048 threads: with 1024 only two of the four the 2048-slot table
+// leaves room for), their barrier phases overlap: 0.140 -> 0.126 ms per 9.6 M reads (256 threads: 0.132)
+#define MIRGE_DEDUP_THREADS 512
+#endif
 template <int CAP>
 __global__ void __launch_bounds__(MIRGE_DEDUP_THREADS)
 k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t R,

@@ -36,6 +36,12 @@ struct TrimOpts {
     int32_t action_none;  // --action none: the adapter is searched but the read stays as it is (the modifier still counts)
     uint8_t adapter2[MIRGE_TRIM_MAX_ADAPTER];
     uint8_t wild2[MIRGE_TRIM_MAX_ADAPTER];
+    // round 5 (general kernel only): anchored adapters and ONE linked adapter (cutadapt's PrefixAdapter / SuffixAdapter /
+    // LinkedAdapter).  anch / anch2: the adapter must be taken whole at the read's first base (5': `-g ^ADAPTER`) or up to its
+    // last base (3': `-a ADAPTER$`).  linked: `adapter` is the 5' part and `adapter2` the 3' part of `ADAPTER1...ADAPTER2`;
+    // req1 / req2: the part must be found for the adapter to match at all (`-a`: 5' part anchored + required, 3' optional;
+    // `-g`: both required).
+    int32_t anch, anch2, linked, req1, req2;
 };
 
 // Aligner.locate for a regular 3' adapter on read[0, n): returns the read position where the adapter starts, or n.
@@ -60,6 +66,10 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
     const uint8_t* const o_adapter = WHICH ? o.adapter2 : o.adapter;
     const uint8_t* const o_wild = WHICH ? o.wild2 : o.wild;
     const int m = EXACT ? MAXM : (WHICH ? o.alen2 : o.alen);
+    // anchored (general kernel): FRONT = PrefixAdapter (flags STOP_WITHIN_SEQ2 alone: read and adapter both start at their
+    // first base, first row and column cost their index, candidates stay the last row's cells); back = SuffixAdapter
+    // (START_WITHIN_SEQ2 alone: the one candidate is the whole adapter ending at the read's last base)
+    const bool anch = !EXACT && (WHICH ? o.anch2 : o.anch) != 0;
     uint32_t e[MAXM + 1];
     uint8_t nw[MAXM + 1];
     nw[0] = 0;
@@ -69,8 +79,8 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
     const uint32_t no_indel_or = (!EXACT && o.no_indels) ? 0xFF000000u : 0u;
 #pragma unroll
     for (int i = 0; i <= MAXM; i++) {
-        e[i] = FRONT ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i
-                     : (((no_indel_or && i ? 128u : (uint32_t)i) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
+        e[i] = (FRONT && !anch) ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i
+                                : (((no_indel_or && i ? 128u : (uint32_t)i) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
         if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o_wild[i - 1] : 0));
     }
     int b_mat = -1, b_cost = 0, b_val = 0;
@@ -89,6 +99,9 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
         const uint8_t ch = read[j - 1] & 0xDF;
         uint32_t diag = e[0];
         e[0] = (uint32_t)j + MIRGE_TRIM_ORIGIN_BIAS;  // cost 0, matches 0, origin j
+        // (anchored 5': j read bases in front of the adapter cost j -- saturated at 128, beyond every budget and within the
+        // entry's 8 cost bits with the <= 64 a column can add --, origin 0)
+        if (FRONT && anch) e[0] = ((no_indel_or ? 128u : (uint32_t)(j < 128 ? j : 128)) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS;
         uint32_t last = e[0];
 #pragma unroll
         for (int i = 1; i <= MAXM; i++) {
@@ -104,10 +117,10 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
                 if (EXACT ? i == MAXM : i == m) last = v;
             }
         }
-        consider(last, m, j);
+        if (FRONT || !anch || j == n) consider(last, m, j);
         exact = found && b_cost == 0 && b_mat == m;
     }
-    if (!exact && !FRONT) {  // the adapter may run off the read's end: every prefix of it, in the last column, longest first
+    if (!exact && !FRONT && !anch) {  // the adapter may run off the read's end: every prefix of it, in the last column, longest first
 #pragma unroll                // (cutadapt: `for i in reversed(range(first_i, m + 1))` -- on equal (matches, cost) the longer prefix stays)
         for (int i = MAXM; i >= 0; i--)
             if (EXACT || i <= m) consider(e[i], i, n);
@@ -174,7 +187,22 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
             bool done = false;
             if constexpr (!EXACT && !FRONT) {
                 if (o.action_none) done = true;
-                else if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild) {
+                else if (o.linked) {
+                    // ONE linked adapter (LinkedAdapter.match_to): the 5' part first; required and absent = no match; the 3' part
+                    // in what follows the 5' match (the whole read when an optional 5' part is absent); no 3' match is still a
+                    // match when that part is optional and the 5' part was found; a match removes whichever parts were found
+                    for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {
+                        int h1[3], h2[3];
+                        const int v1 = adapter_cut_point<MAXM, false, true, 0>(o, s + a0, a1 - a0, h1);
+                        if (!h1[0] && o.req1) break;
+                        const int na0 = h1[0] ? a0 + v1 : a0;
+                        const int v2 = adapter_cut_point<MAXM, false, false, 1>(o, s + na0, a1 - na0, h2);
+                        if (!h2[0] && (o.req2 || !h1[0])) break;
+                        a0 = na0;
+                        if (h2[0]) a1 = na0 + v2;
+                    }
+                    done = true;
+                } else if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild || o.anch) {
                     // the general form (this kernel instance only): one or two adapters of either kind, the better match
                     // removed, up to `times` times (AdapterCutter: `for _ in range(times): best_match ... break if None`)
                     for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {

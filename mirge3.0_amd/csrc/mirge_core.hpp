@@ -105,6 +105,9 @@ MIRGE_HD int mirge_popc(uint64_t x) {
 // bases [a, a+k) of a packed sequence as an integer (k <= 32), little-endian
 template <int W>
 MIRGE_HD uint64_t mirge_extract(const uint64_t* w, int a, int k) {
+    // (one word: no run-time index into the read -- an index the compiler cannot fold keeps the read's words out of registers;
+    // in a kernel that meant a 24-byte-per-thread copy of the read in LDS, 6 KiB per workgroup)
+    if (W == 1) return (w[0] >> ((a & 31) * 2)) & mirge_lowmask2(k);
     int q = a >> 5, s = (a & 31) * 2;
     uint64_t lo = w[q] >> s;
     if (W > 1 && s != 0 && q + 1 < W) lo |= w[q + 1] << (64 - s);
@@ -137,6 +140,16 @@ MIRGE_HD void mirge_trim_read(MirgeRead<W>& r, int n5, int newlen) {
 // length of the terminal run of T (code 3, not N) -- re.search('T{3,}$') of manifoldAlign.py:122
 template <int W>
 MIRGE_HD int mirge_t_run(const MirgeRead<W>& r) {
+    if (W == 1) {  // one word: bit arithmetic instead of a loop that indexes the read at run time (see mirge_extract)
+        if (r.len <= 0) return 0;
+        const uint64_t x = r.w[0];
+        // bit 2j = base j is a T (both code bits set) and no ambiguous call; the odd bits filled with ones
+        const uint64_t t = ((x & (x >> 1) & ~r.nm[0]) & 0x5555555555555555ull) | 0xAAAAAAAAAAAAAAAAull;
+        const uint64_t top = ~(t << (64 - 2 * r.len));  // base len-1 in the two highest bits: 00 for a T, 01 otherwise; below the read: ones
+        const int lead = top ? (int)__builtin_clzll(top) : 64;
+        const int run1 = lead >> 1;
+        return run1 < r.len ? run1 : r.len;
+    }
     int run = 0;
     for (int j = r.len - 1; j >= 0; j--) {
         uint64_t b = (r.w[j >> 5] >> (2 * (j & 31))) & 3ull;

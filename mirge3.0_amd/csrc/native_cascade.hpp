@@ -91,7 +91,7 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
 template <int W>
 static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const std::vector<PassStep>& steps,
                          const mirge_policy* pol, const ResolveTable& rt, const char* gtag,
-                         const uint32_t* n_dev = nullptr, uint32_t n_cap = 0, const FusedSteps* dsteps = nullptr) {
+                         const uint32_t* n_dev = nullptr, uint32_t n_cap = 0, const BulkWalks* dwalks = nullptr) {
     // n_dev != nullptr: the group's read count is not on the host yet (see k_pass); everything is sized for
     // n_cap >= the count, the caller fills out.n in later
     out.n = n_dev ? 0 : rg.n;
@@ -147,17 +147,17 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     // cascade, so the launches between the passes were chip-wide barriers nothing needed.  MIRGE_BULK_FUSED=0: one launch
     // per pass (A/B, per-pass profiles).
     static const bool bulk_fused = !(std::getenv("MIRGE_BULK_FUSED") && std::atoi(std::getenv("MIRGE_BULK_FUSED")) == 0);
-    if (bulk_fused && dsteps && steps.size() > 1) {
+    if (bulk_fused && dwalks && steps.size() > 1) {
         std::snprintf(name, sizeof(name), "k_cascade_bulk%s", gtag);
         LaunchScope ls(c, name, 0.0);
         if (ls.rec >= 0)
             for (size_t k = 0; k < steps.size(); k++) stage_of_pass.emplace_back(ls.rec, (int)k);  // units = reads handed to every pass
         // (a group without ambiguous calls runs the build of the kernel in which the N masks are compile-time zeros)
         if (rg.nmask)
-            hipLaunchKernelGGL((k_cascade_bulk<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, v, actA, actB, seg_n, cap, out.pass, out.pos,
+            hipLaunchKernelGGL((k_cascade_bulk<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos,
                                out.mm, n_dev);
         else
-            hipLaunchKernelGGL((k_cascade_bulk<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, v, actA, actB, seg_n, cap, out.pass, out.pos,
+            hipLaunchKernelGGL((k_cascade_bulk<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos,
                                out.mm, n_dev);
         stage = (int)steps.size();
     } else
@@ -260,7 +260,8 @@ static int cascade_group_long(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, 
 // steps (merged runs, probe tables, plan tables), resolve table and the fused kernel's device step list for
 // one (libraries, policies, read-length set) configuration
 static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mirge_policy* pol, int32_t n_pass,
-                           const int32_t* hist, bool long_present, std::vector<PassStep>& steps, ResolveTable& rt, const FusedSteps** dsteps_out) {
+                           const int32_t* hist, bool long_present, std::vector<PassStep>& steps, ResolveTable& rt, const FusedSteps** dsteps_out,
+                           const BulkWalks** dwalks_out) {
     for (int p = 0; p < MIRGE_MAX_PASSES; p++) { rt.ref_start[p] = nullptr; rt.coarse[p] = nullptr; rt.n_refs[p] = 0; }
     steps.clear();
     for (int32_t p = 0; p < n_pass; p++) {
@@ -335,6 +336,7 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         f.pass_id = steps[i].p0;
     }
     const FusedSteps* dsteps = nullptr;
+    const FusedSteps* fs_host = fs.get();  // (stays valid: either `fs` itself or its new home in c->fused)
     for (auto& e : c->fused)
         if (std::memcmp(e.host.get(), fs.get(), sizeof(FusedSteps)) == 0) { dsteps = e.dev; break; }
     if (!dsteps) {
@@ -350,6 +352,77 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         dsteps = d;
     }
     *dsteps_out = dsteps;
+    // The walk lists of k_cascade_bulk (kernels_cascade.hpp): the same steps; in the list of the ONE-WORD read group every pass
+    // that one whole-read lookup can answer rides in front of the next alignment pass or behind the previous one.  Such a pass:
+    // one library (no merged run), no mismatch allowed anywhere in the read it is handed -- "-v 0", or "-n 0" when every
+    // eligible read lies inside the seed --, a library small enough (lib_exact_table).  Wider groups walk one pass per walk.
+    // MIRGE_EXACT_WALKS=0: one walk per pass for every group, as round 4 (A/B; the staged k_pass path never uses the tables).
+    static const bool exact_on = !(std::getenv("MIRGE_EXACT_WALKS") && std::atoi(std::getenv("MIRGE_EXACT_WALKS")) == 0);
+    std::vector<ExactStep> ex(steps.size());
+    std::vector<char> is_exact(steps.size(), 0);
+    for (size_t i = 0; i < steps.size() && exact_on; i++) {
+        const PassStep& st = steps[i];
+        MirgePolicy p;
+        std::memcpy(&p, &pol[st.p0], sizeof(p));
+        if (st.np != 1 || p.mm != 0) continue;
+        uint32_t lmask = 0;  // lengths the one-word reads of this batch can have when they reach the pass's lookup
+        int lmax = 0;
+        for (int L = 1; L <= 31; L++) {
+            if (!hist[L]) continue;
+            if (p.len_lt > 0 && !(L < p.len_lt)) continue;
+            if (p.len_gt > 0 && !(L > p.len_gt)) continue;
+            const int lo = p.ttail ? 1 : L, hi = p.ttail ? L - 3 : L;
+            for (int l0 = lo; l0 <= hi; l0++) {
+                const int l = l0 - p.trim5 - p.trim3;
+                if (l < 1 || l <= p.mm) continue;
+                lmask |= 1u << l;
+                lmax = std::max(lmax, l);
+            }
+        }
+        if (p.mode == 0 && lmax > p.seedlen) continue;  // "-n 0" beyond the seed admits mismatches: not exact
+        mirge_lib::ExactTab tab;
+        CHECK(lib_exact_table(const_cast<mirge_lib*>(st.lib), lmask, &tab));
+        if (!tab.slots) continue;  // no one-word read can reach the pass, or the library is too large: the probe path
+        ExactStep& e = ex[i];
+        e.slots = tab.slots; e.T = st.lib->dT; e.mask = tab.mask; e.pass_id = st.p0; e.step = (int32_t)i; e.pol = p;
+        is_exact[i] = 1;
+    }
+    if (c->walks.size() + 2 > 64) {  // callers cycling through libraries: start over (room for both lists of this configuration)
+        HIPOK(hipDeviceSynchronize());
+        for (auto& e : c->walks) (void)hipFree(e.dev);
+        c->walks.clear();
+    }
+    for (int wide = 0; wide < 2; wide++) {
+        auto bw = std::make_unique<BulkWalks>();
+        std::memset(bw.get(), 0, sizeof(BulkWalks));
+        for (size_t i = 0; i < steps.size();) {
+            BulkWalk& w = bw->w[bw->n++];
+            if (!wide && is_exact[i]) w.pre = ex[i++];
+            if (!wide && !MIRGE_EXACT_RIDE && w.pre.slots) {  // exact steps in walks of their own (two consecutive ones share one)
+                if (i < steps.size() && is_exact[i]) w.post = ex[i++];
+                continue;
+            }
+            if (i < steps.size() && (wide || !is_exact[i])) {
+                w.has_main = 1;
+                w.main_step = (int32_t)i;
+                w.main = fs_host->s[i];
+                i++;
+                const MirgePolicy& mp = w.main.pol;  // (`post` looks the read up as the main pass left it: untrimmed)
+                if (!wide && i < steps.size() && is_exact[i] && !mp.trim5 && !mp.trim3 && !mp.ttail) w.post = ex[i++];
+            }
+        }
+        const BulkWalks* dwalks = nullptr;
+        for (auto& e : c->walks)
+            if (std::memcmp(e.host.get(), bw.get(), sizeof(BulkWalks)) == 0) { dwalks = e.dev; break; }
+        if (!dwalks) {
+            BulkWalks* d = nullptr;
+            HIPOK(hipMalloc((void**)&d, sizeof(BulkWalks)));
+            HIPOK(hipMemcpy(d, bw.get(), sizeof(BulkWalks), hipMemcpyHostToDevice));
+            c->walks.push_back(mirge_ctx::WalksEntry{std::move(bw), d});
+            dwalks = d;
+        }
+        dwalks_out[wide] = dwalks;
+    }
     return 0;
 }
 
@@ -370,14 +443,14 @@ static int cascade_config(mirge_ctx* c, const mirge_lib* const* libs, const mirg
     key.push_back(long_present ? 1 : 0);
     if (c->casc_key != key) {
         c->casc_key.clear();
-        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, long_present, c->casc_steps, c->casc_rt, &c->casc_dsteps));
+        CHECK(cascade_prepare(c, libs, pol, n_pass, hist, long_present, c->casc_steps, c->casc_rt, &c->casc_dsteps, c->casc_dwalks));
         c->casc_key = key;
     }
     return 0;
 }
 
 // launches of every group but `skip` (already queued by the caller; -1 = none): small groups first, the bulk last
-static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_result* res, const mirge_policy* pol, int skip) {
+static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_result* res, const mirge_policy* pol, int skip, int big_is = -1) {
     const std::vector<PassStep>& steps = c->casc_steps;
     const ResolveTable& rt = c->casc_rt;
     const FusedSteps* dsteps = c->casc_dsteps;
@@ -385,7 +458,7 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
     // the staged passes' compaction pays for their launches (20 M-read sample, 0.7 M reads of 32-64 nt: 3.17 -> 3.08 ms)
     static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
     int rc = 0;
-    const int big = largest_group(R);
+    const int big = big_is >= 0 ? big_is : largest_group(R);  // (big_is: the bulk group of a read set whose bulk count is not known yet)
     CHECK(stream_fork(c));
     // enqueue order: the small groups first (one fused launch each, or the staged launches if a group is too
     // large for that), the bulk group last: measured, its 2048-workgroup launches otherwise hold every CU and the
@@ -416,7 +489,7 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
             MIRGE_BY_WIDTH(gi, rc, cascade_group_fused<W>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi)));
             continue;
         }
-        MIRGE_BY_WIDTH(gi, rc, cascade_group<W>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi), nullptr, 0, dsteps));
+        MIRGE_BY_WIDTH(gi, rc, cascade_group<W>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi), nullptr, 0, c->casc_dwalks[W == 1 ? 0 : 1]));
     }
     // no join here: the next entry point that needs one makes it (join_pending_now); mirge_count_join puts the bulk
     // group's part of its work in front of it
@@ -474,6 +547,21 @@ extern "C" int mirge_cascade_prepare(mirge_ctx* c, const mirge_reads* R, const m
     return 0;
 }
 
+extern "C" int mirge_cascade_walks(mirge_ctx* c, int32_t* walks) {
+    if (!c || !walks) return fail(-1, "mirge_cascade_walks: bad argument");
+    walks[0] = walks[1] = walks[2] = 0;
+    for (auto& e : c->walks) {
+        if (e.dev != c->casc_dwalks[0]) continue;
+        walks[0] = e.host->n;
+        for (int i = 0; i < e.host->n; i++) {
+            const BulkWalk& w = e.host->w[i];
+            walks[1] += (w.pre.slots != nullptr) + (w.post.slots != nullptr);
+            walks[2] += (w.pre.slots != nullptr) + (w.post.slots != nullptr) + (w.has_main != 0);
+        }
+    }
+    return 0;
+}
+
 // Collapse and cascade of one sample as ONE call: the bulk read group's passes are queued on the GPU right behind
 // the collapse kernels, BEFORE the host has read the unique counts back (the kernels take the count from device
 // memory: k_pass / k_resolve `n_dev`), so the GPU does not idle while the host wakes up, finishes the small groups'
@@ -506,16 +594,24 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
         ReadGroup rg = partial->g[big];  // the unique reads' arrays, allocated for the raw count
         rg.n = raw->g[big].n;
         c->cur = c->stream;
-        const int rc = cascade_group<1>(c, rg, res->g[big], c->casc_steps, pol, c->casc_rt, group_tag(big), dmeta + big, raw->g[big].n, c->casc_dsteps);
+        const int rc = cascade_group<1>(c, rg, res->g[big], c->casc_steps, pol, c->casc_rt, group_tag(big), dmeta + big, raw->g[big].n, c->casc_dwalks[0]);
         if (rc == 0) { hooked_group = big; c->overlap_mode = true; }
         return rc;
+    };
+    hook.small_ready = [&](mirge_reads* partial, int big) -> int {
+        // the small groups' cascades, queued while the bulk group's collapse still runs (collapse_impl, round 5)
+        return cascade_launch_groups(c, partial, res.get(), pol, big, big);
     };
     hook.discard = [&]() {
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamSynchronize(c->aux);
+        for (int k = 0; k < MIRGE_N_XAUX; k++) (void)hipStreamSynchronize(c->xaux[k]);
         c->overlap_mode = false;
-        if (hooked_group >= 0) {
-            ResGroup& g = res->g[hooked_group];
+        c->join_pending = false;  // (everything has drained: nothing is left to join)
+        c->xaux_used = false;
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+            if (gi != hooked_group && !res->g[gi].pass) continue;
+            ResGroup& g = res->g[gi];
             c->release(g.pass); c->release(g.pos); c->release(g.mm); c->release(g.ref); c->release(g.off);
             g = ResGroup();
         }
@@ -535,7 +631,7 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
     res->n = U->n; res->reads = U; res->dmeta = hook.dmeta;
     res->g[hooked_group].n = U->g[hooked_group].n;
     for (size_t i = prof_mark; i < c->prof_pending.size(); i++) c->prof_pending[i].n_first = (double)U->g[hooked_group].n;
-    rc = cascade_launch_groups(c, U, res.get(), pol, hooked_group);  // small groups; the join is left pending
+    if (!hook.small_ran) rc = cascade_launch_groups(c, U, res.get(), pol, hooked_group);  // small groups; the join is left pending
     c->overlap_mode = false;
     if (rc) { (void)hipStreamSynchronize(c->stream); mirge_result_destroy(res.release()); mirge_reads_destroy(U); return rc; }
     *uniq = U;

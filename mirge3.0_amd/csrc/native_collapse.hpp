@@ -307,8 +307,12 @@ static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
 // discard must undo it when the partitioned attempt overflowed and everything is redone.
 struct CollapseHook {
     std::function<int(mirge_reads* partial, const CollapseTmp* tmp, uint32_t* dmeta, int big)> pre_sync;
+    // (round 5) the small groups' unique reads exist (their counts came back ahead of the bulk group's, their scatter kernels are
+    // queued on `aux`): whatever the caller wants behind them -- their cascades -- while the bulk group's collapse still runs
+    std::function<int(mirge_reads* partial, int big)> small_ready;
     std::function<void()> discard;
     bool ran = false;         // pre_sync was called and its work stands
+    bool small_ran = false;   // small_ready was called and its work stands (the caller's side streams are left unjoined)
     uint32_t* dmeta = nullptr;  // handed over: the hook's kernels read the counts from it
 };
 
@@ -352,6 +356,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
     const int big = largest_group(raw);
     // attempts 0 and 1 may use the partitioned LDS path (collapse_phase_a); if a level-1 region (attempt 0) or a bucket's
     // LDS table (pathological hash skew) overflows, everything is redone -- at last with the global-atomic tables
+    bool small_done = false;  // the small groups' phase B ran ahead of the bulk group's count (their cascades may be queued too)
     for (int attempt = 0; attempt < 3 && rc == 0; attempt++) {
         hipError_t e0 = hipMemsetAsync(dmeta, 0, MIRGE_META_WORDS * 4, c->stream);
         if (e0 != hipSuccess) { rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e0)); break; }
@@ -388,6 +393,41 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             continue;
         }
         bool hooked = false;
+        // Round 5: with a caller that queues the cascades itself (mirge_collapse_cascade) the host does not wait for ALL counts at
+        // once.  The small groups' counts are final when `aux` has run their kernels (~0.3 ms into a 10 M-read step) while the
+        // bulk group's come out of k_part_dedup (~0.37 ms) -- and the bulk group does not need the host at all (its cascade takes
+        // the count from device memory).  So: the small groups' counts are copied by `aux` with nothing of the main stream in
+        // front, the host sizes their outputs, queues their scatter kernels and hands them to the caller (their cascades start
+        // ~0.14 ms earlier than behind the joint read-back: the 32-64-nt group's one-launch cascade, which runs beside the bulk
+        // kernel on whatever it leaves free, was the END of the step's critical path); only then the bulk group's count.
+        static const bool early_on = !(std::getenv("MIRGE_EARLY_SMALL") && std::atoi(std::getenv("MIRGE_EARLY_SMALL")) == 0);
+        if (rc == 0 && early_on && hook && hook->small_ready && attempt == 0 && tmp[big].partitioned && !c->overlap_mode) {
+            uint32_t* const small = c->pinned + 512;  // (the page-locked block holds 1024 words; the full copy takes the first 272)
+            hipError_t e = hipMemcpyAsync(small, dmeta, MIRGE_NGROUPS * 4, hipMemcpyDeviceToHost, c->aux);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_meta_small, c->aux);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_bulk_counted, c->stream);  // the point behind k_part_dedup
+            if (e == hipSuccess) {
+                rc = hook->pre_sync(R.get(), tmp, dmeta, big);
+                hooked = rc == 0;
+            }
+            if (e == hipSuccess && hooked) e = hipEventSynchronize(c->ev_meta_small);
+            if (e == hipSuccess && hooked) {
+                for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
+                    if (gi == big) continue;
+                    c->cur = c->aux;
+                    if (is_long_group(gi)) rc = collapse_phase_b_long(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, small[gi], 0u, dmeta);
+                    else MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, small[gi], 0u, dmeta));
+                }
+                c->cur = c->stream;
+                if (rc == 0) { rc = hook->small_ready(R.get(), big); small_done = rc == 0; }
+            }
+            // the bulk group's count, the overflow flag and the length histogram: `aux` behind the main stream's k_part_dedup
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_bulk_counted, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->aux);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_meta, c->aux);
+            if (e == hipSuccess) e = hipEventSynchronize(c->ev_meta);
+            if (e != hipSuccess && rc == 0) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
+        } else
         if (rc == 0) {  // the one host synchronisation of the call: U sizes the outputs
             // The counts are copied by the SECOND stream, behind its own groups' kernels and an event of the main stream (the bulk
             // group's count comes from k_part_dedup): on the main stream the 4 us copy sat between k_part_dedup and the bulk
@@ -402,8 +442,8 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             if (e == hipSuccess) e = hipEventSynchronize(c->ev_meta);  // the counts, not whatever was queued behind them
             if (e != hipSuccess && rc == 0) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
         }
-        if (hooked && (rc != 0 || c->pinned[MIRGE_META_OVERFLOW])) { hook->discard(); hooked = false; }
-        if (hook) hook->ran = hooked;
+        if (hooked && (rc != 0 || c->pinned[MIRGE_META_OVERFLOW])) { hook->discard(); hooked = false; small_done = false; }
+        if (hook) { hook->ran = hooked; hook->small_ran = small_done; }
         if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt < 2) {
             for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
                 collapse_tmp_release(c, tmp[gi]);
@@ -432,11 +472,14 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         rc = stream_fork(c);
         for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
             c->cur = gi == big ? c->stream : c->aux;
-            if (is_long_group(gi)) rc = collapse_phase_b_long(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
+            if (small_done && gi != big) R->g[gi].base = base;  // its unique reads were written ahead (above): only their place in the handle's order was open
+            else if (is_long_group(gi)) rc = collapse_phase_b_long(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta);
             else MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, U[gi], base, dmeta));
             base += R->g[gi].n;
         }
-        { int jr = stream_join(c); if (rc == 0) rc = jr; }
+        c->cur = c->stream;
+        // (with the small groups' cascades already on their streams the join is the caller's: mirge_count_join puts work in front of it)
+        if (!small_done) { int jr = stream_join(c); if (rc == 0) rc = jr; }
     }
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
     c->flush_deferred();

@@ -43,7 +43,7 @@ struct mirge_ctx {
     // second stream: the small read groups (long reads, reads with N) run beside the big one.
     // cur = the stream the launch helpers currently target.
     hipStream_t aux = nullptr, cur = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_meta = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_meta = nullptr, ev_meta_small = nullptr, ev_bulk_counted = nullptr;
     // the small read groups' one-launch cascades each on a stream of their own (round 3): with the bulk group's passes in one
     // launch they only get the chip when its workgroups retire, and on ONE stream three of them then ran one after the other
     // (56 + 69 + 49 us behind the bulk kernel, with the join waiting); side by side they take what the longest takes
@@ -92,6 +92,9 @@ struct mirge_ctx {
     std::vector<PassStep> casc_steps;  // ... and what was prepared for it
     ResolveTable casc_rt;
     const FusedSteps* casc_dsteps = nullptr;
+    struct WalksEntry { std::unique_ptr<BulkWalks> host; BulkWalks* dev; };
+    std::vector<WalksEntry> walks;      // walk lists of k_cascade_bulk already on the device
+    const BulkWalks* casc_dwalks[2] = {nullptr, nullptr};  // [0] the one-word group's list (exact steps ride along), [1] wider groups
     size_t prof_used = 0;
     std::vector<ProfUnits> prof_pending;
 
@@ -270,6 +273,8 @@ extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
     HIPOK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPOK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIPOK(hipEventCreateWithFlags(&c->ev_meta, hipEventDisableTiming));
+    HIPOK(hipEventCreateWithFlags(&c->ev_meta_small, hipEventDisableTiming));
+    HIPOK(hipEventCreateWithFlags(&c->ev_bulk_counted, hipEventDisableTiming));
     HIPOK(hipEventCreate(&c->t0));
     HIPOK(hipEventCreate(&c->t1));
     HIPOK(hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault));
@@ -297,9 +302,12 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->join_dev) (void)hipFree(c->join_dev);
     for (auto& e : c->plans) (void)hipFree(e.dplan);
     for (auto& e : c->fused) (void)hipFree(e.dev);
+    for (auto& e : c->walks) (void)hipFree(e.dev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_meta) (void)hipEventDestroy(c->ev_meta);
+    if (c->ev_meta_small) (void)hipEventDestroy(c->ev_meta_small);
+    if (c->ev_bulk_counted) (void)hipEventDestroy(c->ev_bulk_counted);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     for (int k = 0; k < MIRGE_N_XAUX; k++) {
         if (c->xaux[k]) (void)hipStreamDestroy(c->xaux[k]);

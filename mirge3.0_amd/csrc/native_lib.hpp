@@ -20,6 +20,9 @@ struct mirge_lib {
     std::mutex mu;
     int64_t n_refs = 0;
     int kmax = 8;
+    // whole-read tables of the exact passes (kernels_cascade.hpp, ExactStep), by the set of lengths they hold (bit l of the key)
+    struct ExactTab { uint64_t* slots = nullptr; uint32_t mask = 0; uint64_t windows = 0; };
+    std::map<uint32_t, ExactTab> exact;
 
     MirgeLibView view() const {
         MirgeLibView v;
@@ -121,6 +124,7 @@ extern "C" void mirge_lib_destroy(mirge_lib* L) {
     (void)hipStreamSynchronize(L->ctx->stream);
     (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dcoarse); (void)hipFree(L->dtables);
     for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); (void)hipFree((void*)t.bits); }
+    for (auto& e : L->exact) (void)hipFree(e.second.slots);
     delete L;
 }
 extern "C" int64_t mirge_lib_n_refs(const mirge_lib* L) { return L ? L->n_refs : -1; }
@@ -217,6 +221,59 @@ static int lib_prepare_shapes(mirge_lib* L, const std::vector<ShapeJob>& wanted)
     if (jobs.empty()) return 0;
     HIPOK(hipSetDevice(L->ctx->device));
     return lib_build_shapes(L, jobs);
+}
+
+// The whole-read table of an exact pass over this library for the read lengths in `lmask` (bit l, 1 <= l <= 31): every valid
+// window of those lengths, keyed by its sequence, lowest position kept (k_exact_table).  *out stays empty (slots == nullptr)
+// when the table would hold more than MIRGE_EXACT_MAX_WINDOWS windows: the pass then keeps its probe path.
+#ifndef MIRGE_EXACT_MAX_WINDOWS
+#define MIRGE_EXACT_MAX_WINDOWS (4u << 20)  // 4 M windows -> at most 16 M slots = 128 MB; the human miRNA / pre-tRNA sets hold 0.1 / 1.3 M
+#endif
+static int lib_exact_table(mirge_lib* L, uint32_t lmask, mirge_lib::ExactTab* out) {
+    *out = mirge_lib::ExactTab();
+    lmask &= 0xFFFFFFFEu;
+    if (!lmask) return 0;
+    std::lock_guard<std::mutex> lk(L->mu);
+    auto it = L->exact.find(lmask);
+    if (it != L->exact.end()) { *out = it->second; return 0; }
+    mirge_ctx* c = L->ctx;
+    HIPOK(hipSetDevice(c->device));
+    mirge_lib::ExactTab tab;
+    if ((uint64_t)__builtin_popcount(lmask) * L->h.valid_positions <= 4ull * MIRGE_EXACT_MAX_WINDOWS) {  // (an upper bound first: no kernel over a 130 Mb text for nothing)
+        unsigned long long* dcount = nullptr;
+        HIPOK(hipMalloc((void**)&dcount, 8));
+        HIPOK(hipMemsetAsync(dcount, 0, 8, c->stream));
+        const int grid = (int)std::min<uint64_t>((uint64_t)c->n_cu * 8, std::max<uint64_t>(1, (L->h.total + MIRGE_BLOCK - 1) / MIRGE_BLOCK));
+        hipLaunchKernelGGL(k_exact_table<false>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, lmask,
+                           (uint64_t*)nullptr, 0u, dcount);
+        unsigned long long n = 0;
+        hipError_t e = hipMemcpyAsync(&n, dcount, 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(dcount);
+        if (e != hipSuccess) return fail(-2, std::string("exact table (count): ") + hipGetErrorString(e));
+        tab.windows = n;
+        if (n <= MIRGE_EXACT_MAX_WINDOWS) {
+            uint64_t ns = 1024;
+            while (ns < 3 * n) ns <<= 1;  // load factor <= 1/3 (duplicates make it less): a miss ends at an empty slot after ~1.2 probes
+            e = hipMalloc((void**)&tab.slots, ns * 8);
+            if (e == hipSuccess) e = hipMemsetAsync(tab.slots, 0, ns * 8, c->stream);
+            if (e == hipSuccess) {
+                tab.mask = (uint32_t)(ns - 1);
+                hipLaunchKernelGGL(k_exact_table<true>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, lmask,
+                                   tab.slots, tab.mask, (unsigned long long*)nullptr);
+                e = hipStreamSynchronize(c->stream);
+                if (e == hipSuccess) e = hipGetLastError();
+            }
+            if (e != hipSuccess) {
+                (void)hipFree(tab.slots);
+                return fail(e == hipErrorOutOfMemory ? -3 : -2, std::string("exact table: ") + hipGetErrorString(e));
+            }
+            L->device_bytes += ns * 8;
+        }
+    }
+    L->exact[lmask] = tab;
+    *out = tab;
+    return 0;
 }
 
 extern "C" int mirge_lib_prepare(mirge_lib* L, int32_t k) {

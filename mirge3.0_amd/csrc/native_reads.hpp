@@ -257,6 +257,15 @@ static int trim_options(const mirge_trim* t, int32_t format, TrimOpts& o) {
     o.no_indels = t->no_indels ? 1 : 0;
     o.read_wild = t->match_read_wildcards ? 1 : 0;
     o.action_none = t->action_none ? 1 : 0;
+    o.anch = t->adapter_anchored ? 1 : 0;
+    o.anch2 = t->adapter2_anchored ? 1 : 0;
+    o.linked = t->linked ? 1 : 0;
+    if (o.linked) {
+        if (!o.alen || !o.alen2 || !o.front || o.front2)
+            return fail(-1, "mirge_reads_parse_trim: a linked adapter is a 5' part (adapter, adapter_front = 1) and a 3' part (adapter2, adapter2_front = 0)");
+        o.req1 = (t->linked_required & 1) ? 1 : 0;
+        o.req2 = (t->linked_required & 2) ? 1 : 0;
+    }
     if (t->no_adapter_wildcards)  // -N: an N in the adapter is a letter like any other (it matches an N of the read only)
         for (int i = 0; i < MIRGE_TRIM_MAX_ADAPTER; i++) { o.wild[i] = 0; o.wild2[i] = 0; }
     if (o.times > 16) return fail(-1, "mirge_reads_parse_trim: -n above 16 is not supported");
@@ -289,7 +298,7 @@ static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, co
                        const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
     bool wild = false;
     for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
-    if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild || o.action_none) {  // the general 3' instance carries these branches
+    if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild || o.action_none || o.anch || o.linked) {  // the general 3' instance carries these branches
         hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
         return 0;
     }

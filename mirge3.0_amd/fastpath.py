@@ -70,6 +70,7 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     from . import multigpu
     from .cascade import EXACT_PASS, ISO_PASS
     workDir = Path(workDir)
+    t_sample = time.perf_counter()
     casc = casc or get_cascade(args, ref_db, getattr(args, "device", 0))
     ctx = casc.ctx
     raw, n_rec = parse_sample(ctx, read_text(str(file), stream=True), int(getattr(args, "minimum_length", 16)), trim_from_args(args),
@@ -81,38 +82,46 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     uniq, res = casc.collapse_and_run(raw)
     raw.close()
     cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS, len(casc.libs["mirna"]))
+    t_tail = time.perf_counter()
     counts, _ = uniq.counts()
     order = uniq.first_appearance_order()
     seqs = uniq.unpack().take(order)
-    ps, ref, _, _ = res.fetch()
     out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
-    reads = multigpu.SampleReads(seqs.data, seqs.offsets, counts[order, 0], ps[order], ref[order], iupac)
+    # (round 5: no annotation travels -- it depends on the sequence alone, and rank 0 annotates the run's joint table on its own
+    # GPU in milliseconds, which puts that table's mapped.csv / unmapped.csv on the device-formatted route; lengths as bytes
+    # or 16-bit words instead of 64-bit offsets: 30 B per unique read instead of 47)
+    reads = multigpu.SampleReads.from_seqs(seqs, counts[order, 0], iupac)
     # handed to rank 0 through files in the run's directory when rank 0 sees that directory (same node / shared filesystem:
     # a sample's dictionary is tens to hundreds of MB), in-band with the tables otherwise
     out.reads = reads.to_files(workDir / ".mirge_shards", index) if via_files else reads
     res.close(); uniq.close()
+    out.timing = {"sample_s": round(time.perf_counter() - t_sample, 4), "handover_s": round(time.perf_counter() - t_tail, 4),
+                  "unique_reads": int(len(reads.counts))}
     return out
 
 
 def merge_sample_reads(ctx: _ffi.Context, parts):
     """The per-sample dictionaries of a sharded run (``multigpu.SampleReads``, in sample order) -> the run's sample matrix:
     one weighted collapse on this GPU with a sample id per entry (``mirge_collapse_weighted``; the outer join of
-    digest.py:243 without expanding the dictionaries again).  -> (uniq DeviceReads with the U x S counts, pass[U], ref[U])
-    -- a read's annotation depends on its sequence alone, so the first sample that holds it supplies it."""
+    digest.py:243 without expanding the dictionaries again).  Every dictionary is packed on the device by itself and the
+    packed sets are appended there (``mirge_reads_concat``): no host-side concatenation of the sequences (round 4 joined 1.7 GB
+    of ASCII and as many bytes of 64-bit offsets on the host at C4's size).  -> uniq DeviceReads with the U x S counts."""
     S = len(parts)
-    data = np.concatenate([p.data for p in parts]) if S else np.zeros(0, np.uint8)
-    lens = np.concatenate([np.diff(p.offsets) for p in parts]) if S else np.zeros(0, np.int64)
-    off = np.zeros(lens.shape[0] + 1, dtype=np.int64)
-    np.cumsum(lens, out=off[1:])
+    if not S:
+        raw = _ffi.DeviceReads.pack(ctx, FlatSeqs(np.zeros(0, np.uint8), np.zeros(1, np.int64)))
+        uniq = raw.collapse()
+        raw.close()
+        return uniq
+    packed = [_ffi.DeviceReads.pack(ctx, FlatSeqs(p.data, p.offsets)) for p in parts]
+    raw = packed[0] if S == 1 else _ffi.DeviceReads.concat(ctx, packed)
     sid = np.repeat(np.arange(S, dtype=np.int32), [len(p.counts) for p in parts])
-    w = np.concatenate([p.counts for p in parts]).astype(np.uint32) if S else np.zeros(0, np.uint32)
-    raw = _ffi.DeviceReads.pack(ctx, FlatSeqs(data, off))
-    uniq = raw.collapse(sid if S > 1 else None, max(S, 1), weights=w)
-    raw.close()
-    _, first = uniq.counts()
-    ps_all = np.concatenate([p.ps for p in parts]) if S else np.zeros(0, np.int8)
-    ref_all = np.concatenate([p.ref for p in parts]) if S else np.zeros(0, np.int32)
-    return uniq, ps_all[first], ref_all[first]
+    w = np.concatenate([p.counts for p in parts]).astype(np.uint32)
+    uniq = raw.collapse(sid if S > 1 else None, S, weights=w)
+    if S > 1:
+        raw.close()
+    for p in packed:
+        p.close()
+    return uniq
 
 
 def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, timings: Dict[str, float] = None):
@@ -269,39 +278,52 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
     return out
 
 
-def run_sharded_rank0(args, tables, workDir, ref_db: str, casc):
+def run_sharded_rank0(args, tables, workDir, ref_db: str, casc, timings: Dict[str, float] = None):
     """Rank 0 of the sharded CLI, after the gather: the count tables from the ranks' own per-sample columns, then the
     run's joint table (``merge_sample_reads``) and everything ``reports`` writes from it -- the same files, byte for byte,
-    as the one-process run of the same samples."""
+    as the one-process run of the same samples.  Round 5: the joint table is annotated HERE, by one cascade over it on rank
+    0's GPU (a read's annotation depends on its sequence alone; 67 M unique reads of eight 20 M-read samples take ~15 ms),
+    so nothing per read but the dictionaries travels, and ``mapped.csv`` / ``unmapped.csv`` of the union are formatted on the
+    GPU like a one-process run's (``reports``: no fetch of reads, counts or annotation, no formatting on host threads)."""
     from . import multigpu
     from .countjoin import finish_tables
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
     workDir = Path(workDir)
     names, src, trimmed, uniq_n, cls, ex, iso = multigpu.merge_tables(tables)
     merges = load_merges(str(args.libraries_path), args.organism_name, ref_db)
     out = finish_tables(cls, ex, iso, casc.libs["mirna"], merges, names, src, trimmed, uniq_n, float(args.crThreshold),
                         bool(args.spikeIn), workDir=workDir)
-    for t in tables:
-        if isinstance(t.reads, str):
-            t.reads = multigpu.SampleReads.from_files(t.reads)
+    tm["count_tables_s"] = time.perf_counter() - t0
+    t = time.perf_counter()
+    for tb in tables:
+        if isinstance(tb.reads, str):
+            tb.reads = multigpu.SampleReads.from_files(tb.reads)
     try:
         (workDir / ".mirge_shards").rmdir()
     except OSError:
         pass
+    tm["load_dictionaries_s"] = time.perf_counter() - t
     with open(workDir / "run.log", "a+") as outlog:
-        for t in tables:
-            if t.reads.iupac:
-                outlog.write(f"WARNING: {t.name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N\n")
-    uniq, ps, ref = merge_sample_reads(casc.ctx, [t.reads for t in tables])
-    counts, first = uniq.counts()
-    res = None
-    if getattr(args, "gff_out", False) or getattr(args, "AtoI", False):
-        # the two report kernels read the annotation on the device: once more over the joint table (milliseconds), which
-        # also cross-checks what the ranks sent
-        res = casc.run(uniq)
-        ps2, ref2, _, _ = res.fetch()
-        if not (np.array_equal(ps2, ps) and np.array_equal(ref2[ps2 >= 0], ref[ps >= 0])):
-            raise RuntimeError("sharded run: the annotation gathered from the ranks differs from rank 0's own")
-    return reports(args, workDir, ref_db, names, casc, uniq, res, out, merges, counts, first, ann=(ps, ref))
+        for tb in tables:
+            if tb.reads.iupac:
+                outlog.write(f"WARNING: {tb.name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N\n")
+    t = time.perf_counter()
+    uniq = merge_sample_reads(casc.ctx, [tb.reads for tb in tables])
+    for tb in tables:
+        tb.reads = None  # (hundreds of MB per sample at C4's size)
+    casc.ctx.sync()
+    tm["merge_sample_reads_s"] = time.perf_counter() - t
+    t = time.perf_counter()
+    res = casc.run(uniq)
+    casc.ctx.sync()
+    tm["annotate_joint_table_s"] = time.perf_counter() - t
+    tm["joint_unique_reads"] = len(uniq)
+    t = time.perf_counter()
+    out = reports(args, workDir, ref_db, names, casc, uniq, res, out, merges, None, None, tm=tm)
+    tm["reports_s"] = time.perf_counter() - t
+    tm["rank0_tail_s"] = time.perf_counter() - t0
+    return out
 
 
 def mirna_frame(seqs: FlatSeqs, ps, ref, counts, order, casc, base_names):

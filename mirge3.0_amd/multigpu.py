@@ -28,19 +28,30 @@ def assign_samples(n_samples: int, world: int) -> List[List[int]]:
 @dataclass
 class SampleReads:
     """A sample's dictionary as rank 0 needs it for the run's joint per-read tables (``mapped.csv`` / ``unmapped.csv``,
-    mirge/__main__.py:164-173; -gff / -ai / -ie): unique reads in order of first appearance, their counts and annotation."""
+    mirge/__main__.py:164-173; -gff / -ai / -ie): unique reads in order of first appearance and their counts.  (Until round 5
+    the annotation travelled too; rank 0 now annotates the joint table itself.)"""
     data: np.ndarray     # uint8, the sequences' ASCII
-    offsets: np.ndarray  # int64 [U + 1]
+    lengths: np.ndarray  # uint8 / uint16 / int64 [U]: the narrowest type that holds the longest read
     counts: np.ndarray   # uint32 [U]
-    ps: np.ndarray       # int8 [U], pass or -1
-    ref: np.ndarray      # int32 [U], reference index in the pass's library
     iupac: bool = False
 
+    FIELDS = ("data", "lengths", "counts")
 
-    FIELDS = ("data", "offsets", "counts", "ps", "ref")
+    @staticmethod
+    def from_seqs(seqs, counts, iupac: bool = False) -> "SampleReads":
+        ln = seqs.lengths
+        mx = int(ln.max()) if len(ln) else 0
+        ln = ln.astype(np.uint8 if mx < 256 else np.uint16 if mx < 65536 else np.int64)
+        return SampleReads(np.ascontiguousarray(seqs.data), ln, np.ascontiguousarray(counts, dtype=np.uint32), iupac)
+
+    @property
+    def offsets(self) -> np.ndarray:
+        off = np.zeros(self.lengths.shape[0] + 1, dtype=np.int64)
+        np.cumsum(self.lengths, out=off[1:], dtype=np.int64)
+        return off
 
     def to_files(self, directory, index: int) -> str:
-        """the arrays as plain .npy files (a rank's hand-over to rank 0 on the same node: 35 B per unique read would
+        """the arrays as plain .npy files (a rank's hand-over to rank 0 on the same node: 30 B per unique read would
         otherwise be pickled and pushed through the gather's TCP loopback); returns the stem to ``from_files``"""
         import os
         os.makedirs(directory, exist_ok=True)
@@ -72,6 +83,7 @@ class SampleTables:
     exact: np.ndarray       # [n_mirna]
     iso: np.ndarray         # [n_mirna]
     reads: Optional[object] = None  # SampleReads, or the stem of its files (SampleReads.to_files)
+    timing: Optional[dict] = None   # the rank's own stage times for this sample (run.log of the sharded run)
 
 
 def gather_tables(local: Sequence[SampleTables], rank: int, world: int, dist=None) -> Optional[List[SampleTables]]:

@@ -684,13 +684,15 @@ def nextseq_trim_index(seq: str, qual: str, cutoff: int, base: int = 33):
 
 
 def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True,
-                        read_wildcards: bool = False, adapter_wildcards: bool = True):
+                        read_wildcards: bool = False, adapter_wildcards: bool = True, anchored: bool = False):
     """Aligner.locate for a regular 3' adapter (the alignment may start anywhere in the read, stop anywhere in it, and
     stop inside the adapter when it runs off the read's end): unit costs, indels allowed; of the alignments with
     cost <= aligned adapter length * max_error_rate and at least min_overlap adapter bases, the one with the most
     matches, then the lowest cost, first found (full-adapter matches in order of their end in the read, then the
     partial ones at the read's end from the longest adapter prefix down).  An 'N' in the adapter matches any base and does not
-    count towards the length the error rate applies to.  -> (astart, astop, rstart, rstop, matches, errors) or None."""
+    count towards the length the error rate applies to.  -> (astart, astop, rstart, rstop, matches, errors) or None.
+    ``anchored`` (`-a ADAPTER$`, cutadapt's SuffixAdapter, flag START_WITHIN_SEQ2 alone): the alignment may start anywhere in the
+    read but must take the WHOLE adapter and end at the read's last base -- one candidate, cell (m, n)."""
     m, n = len(adapter), len(read)
     wild = [c == "N" and adapter_wildcards for c in adapter]
     nwild = [0] * (m + 1)
@@ -727,10 +729,13 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
                 else:
                     cur[i] = (cdel, left[1], left[2])
         prev = cur
-        consider(cur[m], m, j)
+        if not anchored or j == n:
+            consider(cur[m], m, j)
         if best is not None and best[5] == 0 and best[4] == m and best[1] == m:
             done = True
             break
+    if anchored:
+        return best
     if not done:
         # cutadapt walks the last column from the longest adapter prefix down (`for i in reversed(range(first_i, m + 1))`):
         # of two prefixes with equal (matches, cost) the LONGER one is kept
@@ -740,19 +745,23 @@ def adapter_locate_back(adapter: str, read: str, max_error_rate: float = 0.12, m
 
 
 def adapter_locate_front(adapter: str, read: str, max_error_rate: float = 0.12, min_overlap: int = 3, indels: bool = True,
-                         read_wildcards: bool = False, adapter_wildcards: bool = True):
+                         read_wildcards: bool = False, adapter_wildcards: bool = True, anchored: bool = False):
     """Aligner.locate for a regular 5' adapter (flags START_WITHIN_SEQ1 | START_WITHIN_SEQ2 | STOP_WITHIN_SEQ2: the
     alignment may start anywhere in the read AND inside the adapter -- row i of the first column costs 0 and has origin
     -i -- but must reach the adapter's last base): every read column is a candidate end; aligned adapter length =
     m + min(origin, 0); same acceptance (cost <= length * max_error_rate, length >= min_overlap) and the same order of
     preference as the 3' form (most matches, then lowest cost, first found).  No N in the adapter here.
-    -> (astart, astop, rstart, rstop, matches, errors) or None; the read keeps read[rstop:]."""
+    -> (astart, astop, rstart, rstop, matches, errors) or None; the read keeps read[rstop:].
+    ``anchored`` (`-g ^ADAPTER`, and the 5' part of `-a ADAPTER1...ADAPTER2`; cutadapt's PrefixAdapter, flag STOP_WITHIN_SEQ2
+    alone): both sequences start at their first base -- first row and first column cost their index -- and the whole adapter
+    must be taken (aligned length m); the candidates are still the last row's cells, column by column."""
     m, n = len(adapter), len(read)
     assert "N" not in adapter.upper() or not adapter_wildcards
-    prev = [(0, 0, -i) for i in range(m + 1)]  # (cost, matches, origin)
+    INF = 10 ** 6
+    prev = [((i if indels or i == 0 else INF), 0, 0) if anchored else (0, 0, -i) for i in range(m + 1)]  # (cost, matches, origin)
     best = None
     for j in range(1, n + 1):
-        cur = [(0, 0, j)] + [None] * m
+        cur = [((j if indels else INF), 0, 0) if anchored else (0, 0, j)] + [None] * m
         for i in range(1, m + 1):
             d, up, left = prev[i - 1], cur[i - 1], prev[i]
             if adapter[i - 1] == read[j - 1] or (read_wildcards and read[j - 1] == "N"):
@@ -792,22 +801,46 @@ def trim_stages(seq: str, qual, opts: dict):
     indels = opts.get("indels", True)
     times = int(opts.get("times", 1))
     rw, aw = bool(opts.get("read_wildcards", False)), bool(opts.get("adapter_wildcards", True))
-    if opts.get("action") == "none" and (opts.get("adapter") or opts.get("adapters")):
+    if opts.get("action") == "none" and (opts.get("adapter") or opts.get("adapters") or opts.get("linked")):
         out.append(seq)  # searched, not removed: the AdapterCutter still is a modifier of the chain
-        opts = {k: v for k, v in opts.items() if k not in ("adapter", "adapters")}
-    if opts.get("adapter") and not opts.get("adapters") and (times > 1 or not indels or rw or not aw):
-        opts = dict(opts, adapters=[("front" if opts.get("front") else "back", opts["adapter"])])
-    if opts.get("adapters"):
+        opts = {k: v for k, v in opts.items() if k not in ("adapter", "adapters", "linked")}
+    if opts.get("adapter") and not opts.get("adapters") and (times > 1 or not indels or rw or not aw or opts.get("anchored")):
+        opts = dict(opts, adapters=[("front" if opts.get("front") else "back", opts["adapter"], bool(opts.get("anchored")))])
+    if opts.get("linked"):
+        # ONE linked adapter (cutadapt's LinkedAdapter.match_to): the 5' part is searched first -- anchored or regular --, and
+        # when it is required and absent there is no match; the 3' part is searched in what follows the 5' match (the whole
+        # read when an optional 5' part was not found); no 3' match is still a match when the 3' part is optional AND the 5'
+        # part was found.  `-a A...B`: A anchored and required, B optional.  `-g A...B`: A regular, both required.  A match
+        # removes whichever parts were found.  Restated from cutadapt's parser.py / adapters.py as remembered: parity unpinned.
+        lk = opts["linked"]
+        for _ in range(times):
+            up = seq.upper()
+            fm = adapter_locate_front(lk["front"], up, opts.get("error_rate", 0.12), opts.get("overlap", 3), indels, rw, aw,
+                                      anchored=lk.get("front_anchored", False))
+            if fm is None and lk.get("front_required", True):
+                break
+            lo = fm[3] if fm is not None else 0
+            bm = adapter_locate_back(lk["back"], up[lo:], opts.get("error_rate", 0.12), opts.get("overlap", 3), indels, rw, aw,
+                                     anchored=lk.get("back_anchored", False))
+            if bm is None and (lk.get("back_required", False) or fm is None):
+                break
+            hi = lo + bm[2] if bm is not None else len(seq)
+            seq = seq[lo:hi]
+            qual = qual[lo:hi] if qual is not None else None
+        out.append(seq)
+    elif opts.get("adapters"):
         # AdapterCutter over several adapters, times = 1 (cutadapt's `_best_match`): every adapter is searched in the read
         # as it stands, the match with the most matching bases wins, then the one with fewer errors, then the first in the
         # list; only that ONE adapter is removed.  Restated from cutadapt's sources as remembered: parity unpinned.
         for _ in range(times):  # -n COUNT: `for _ in range(self.times): match = best_match(...); if match is None: break`
             best = None
-            for kind, ad in opts["adapters"]:
+            for spec in opts["adapters"]:
+                kind, ad = spec[0], spec[1]
+                anch = len(spec) > 2 and bool(spec[2])  # (kind, sequence, anchored): `-g ^ADAPTER` / `-a ADAPTER$`
                 # (cutadapt's aligner translates lower-case letters like upper-case ones -- `_acgt_table`: "Lowercase versions are
                 # also translated" --: the search is case-blind for either kind of adapter, the read keeps its letters)
                 hit = (adapter_locate_front if kind == "front" else adapter_locate_back)(
-                    ad, seq.upper(), opts.get("error_rate", 0.12), opts.get("overlap", 3), indels, rw, aw)
+                    ad, seq.upper(), opts.get("error_rate", 0.12), opts.get("overlap", 3), indels, rw, aw, anchored=anch)
                 if hit is not None and (best is None or hit[4] > best[1][4] or (hit[4] == best[1][4] and hit[5] < best[1][5])):
                     best = (kind, hit)
             if best is None:

@@ -1,6 +1,8 @@
-"""Worker of tests/test_multigpu_gloo.py: one rank of a world_size-2 gloo group.
+"""Worker of tests/test_multigpu_gloo.py: one rank of a world_size-2 (or -8) gloo group.
 
-Each rank owns one sample of golden case 2.  The per-sample tables are computed from the
+argv: out_dir [golden case = case2_two_samples] [samples = the case's own].  With more samples than the case holds, sample i is
+the case's column i % S under the name <name>_<i> (the 8-rank test: case 5's three samples dealt to eight ranks).
+Each rank owns one sample.  The per-sample tables are computed from the
 reference's mapped.csv (numpy stands in for the kernels: the point of this test is the
 sharding / gather / merge logic of multigpu.py, which has no GPU in it), gathered on rank 0 and
 written with finish_tables; the parent compares the CSVs with the reference's."""
@@ -37,7 +39,10 @@ def main():
     private = os.path.join(out_dir, f"node{rank}")
     os.makedirs(private, exist_ok=True)
     assert multigpu.directory_is_shared(private, rank, world, dist) is (rank == 0)
-    case = GoldenCase("case2_two_samples")
+    case = GoldenCase(sys.argv[2] if len(sys.argv) > 2 else "case2_two_samples")
+    n_samples = int(sys.argv[3]) if len(sys.argv) > 3 else len(case.samples)
+    col_of = [i % len(case.samples) for i in range(n_samples)]
+    name_of = [case.samples[c] if n_samples == len(case.samples) else f"{case.samples[c]}_{i}" for i, c in enumerate(col_of)]
     exp = case.expected_annotation()
     mir = case.libs["mirna"]
     lut = {}
@@ -48,9 +53,10 @@ def main():
         cls = np.zeros(case.n_pass, dtype=np.int64)
         ex = np.zeros(len(mir), dtype=np.int64)
         iso = np.zeros(len(mir), dtype=np.int64)
+        ci = col_of[i]
         for s, row in zip(case.seqs, case.counts):
             p, nm = exp[s]
-            c = int(row[i])
+            c = int(row[ci])
             if p < 0 or c == 0:
                 continue
             cls[p] += c
@@ -58,30 +64,31 @@ def main():
                 ex[lut[nm]] += c
             if p == 8:
                 iso[lut[nm]] += c
-        nme = case.samples[i]
-        t = multigpu.SampleTables(i, nme, case.sample_read_counts[nme], case.trimmed[nme],
-                                  case.trimmed_unique[nme], cls, ex, iso)
+        nme, src = name_of[i], case.samples[ci]
+        t = multigpu.SampleTables(i, nme, case.sample_read_counts[src], case.trimmed[src],
+                                  case.trimmed_unique[src], cls, ex, iso)
         # the sample's dictionary travels with its tables (what rank 0 merges into the run's one mapped.csv)
         from mirge3_amd.seqio import FlatSeqs
-        mine = [(s, int(row[i])) for s, row in zip(case.seqs, case.counts) if int(row[i])]
+        mine = [(s, int(row[ci])) for s, row in zip(case.seqs, case.counts) if int(row[ci])]
         fs = FlatSeqs.from_list([s for s, _ in mine])
-        t.reads = multigpu.SampleReads(fs.data, fs.offsets, np.array([c for _, c in mine], dtype=np.uint32),
-                                       np.array([exp[s][0] for s, _ in mine], dtype=np.int8),
-                                       np.array([lut.get(exp[s][1], 0) for s, _ in mine], dtype=np.int32))
+        t.reads = multigpu.SampleReads.from_seqs(fs, np.array([c for _, c in mine], dtype=np.uint32))
         if i % 2:  # the hand-over through files in the run's directory (what fastpath.run_sample_tables does), and in-band
             t.reads = t.reads.to_files(os.path.join(out_dir, ".mirge_shards"), i)
         return t
 
-    assert multigpu.assign_samples(len(case.samples), world)[rank] == [rank]
-    tables = multigpu.run_sharded(len(case.samples), rank, world, process, dist)
+    assert multigpu.assign_samples(n_samples, world)[rank] == list(range(rank, n_samples, world))
+    tables = multigpu.run_sharded(n_samples, rank, world, process, dist)
     if rank == 0:
         for t in tables:  # every rank's dictionary arrived whole, in sample order
             if isinstance(t.reads, str):
                 t.reads = multigpu.SampleReads.from_files(t.reads)
-            assert int(t.reads.counts.sum()) == case.trimmed[t.name] and len(t.reads.counts) == case.trimmed_unique[t.name]
+            src = case.samples[col_of[t.index]]
+            assert t.name == name_of[t.index]
+            assert int(t.reads.counts.sum()) == case.trimmed[src] and len(t.reads.counts) == case.trimmed_unique[src]
             assert t.reads.offsets.shape[0] == len(t.reads.counts) + 1 and t.reads.data.shape[0] == int(t.reads.offsets[-1])
         names, src, trimmed, uniq, cls, ex, iso = multigpu.merge_tables(tables)
-        finish_tables(cls, ex, iso, mir, case.merges, names, src, trimmed, uniq, 0.1, False, workDir=out_dir)
+        assert [t.index for t in tables] == list(range(n_samples)) and names == name_of
+        finish_tables(cls, ex, iso, mir, case.merges, names, src, trimmed, uniq, float(case.cr), case.spike, workDir=out_dir)
     else:
         assert tables is None
     dist.barrier()

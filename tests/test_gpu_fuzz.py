@@ -21,9 +21,23 @@ def _rand_seq(rng, L, pn=0.0):
     return out.tobytes().decode()
 
 
-def _policy(rng):
+def _policy(rng, exact_bias=False):
     mode = int(rng.integers(0, 2))
     mm = int(rng.choice([0, 1, 1, 2, 2, 3]))
+    if exact_bias and rng.random() < 0.65:
+        # the passes one whole-read lookup answers (kernels_cascade.hpp, ExactStep): "-v 0", or "-n 0" with a length rule that
+        # keeps the read inside the seed -- and their near misses: a rule one base beyond the seed, a shorter seed
+        mm = 0
+        pol = dict(mode=mode, mm=0, seedlen=int(rng.choice([28, 28, 28, 20])), maxtotal=(int(rng.integers(0, 3)) if mode == 0 else 0))
+        if mode == 0 and rng.random() < 0.8:
+            pol["len_lt"] = int(rng.integers(16, pol["seedlen"] + 3))
+        elif rng.random() < 0.3:
+            pol["len_lt"] = int(rng.integers(18, 40))
+        if rng.random() < 0.35:
+            pol["ttail"] = 1
+        if rng.random() < 0.2:
+            pol["trim5"] = int(rng.integers(0, 3)); pol["trim3"] = int(rng.integers(0, 3))
+        return pol
     pol = dict(mode=mode, mm=mm, seedlen=int(rng.choice([28, 28, 20, 12])), maxtotal=(int(rng.integers(mm, 4)) if mode == 0 else mm))
     if rng.random() < 0.3:
         pol["trim5"] = int(rng.integers(0, 3)); pol["trim3"] = int(rng.integers(0, 3))
@@ -43,7 +57,18 @@ N_FUZZ = int(os.environ.get("MIRGE_FUZZ_SEEDS", "16"))
 
 @pytest.mark.parametrize("seed", range(N_FUZZ))
 def test_random_cascade_matches_bruteforce(seed):
-    rng = np.random.default_rng(1000 + seed)
+    _random_cascade(seed, False)
+
+
+@pytest.mark.parametrize("seed", range(N_FUZZ))
+def test_random_cascade_with_exact_passes_matches_bruteforce(seed):
+    """the same with most policies drawn from the exact family: the passes k_cascade_bulk answers with one whole-read lookup
+    inside a neighbouring pass's walk (pre / post steps), in every order and mixture with alignment passes"""
+    _random_cascade(seed, True)
+
+
+def _random_cascade(seed, exact_bias):
+    rng = np.random.default_rng((5000 if exact_bias else 1000) + seed)
     ctx = _ffi.Context(0)
     n_pass = int(rng.integers(2, 9))
     libs, dev, pols = [], [], []
@@ -60,7 +85,7 @@ def test_random_cascade_matches_bruteforce(seed):
         if p > 0 and same_policy_run and rng.random() < 0.6:
             pols.append(dict(pols[-1]))
         else:
-            pols.append(_policy(rng))
+            pols.append(_policy(rng, exact_bias))
     reads = []
     for _ in range(3000):
         lib = libs[int(rng.integers(0, n_pass))]
@@ -72,7 +97,7 @@ def test_random_cascade_matches_bruteforce(seed):
             L = min(L, len(s))
             a = int(rng.integers(0, len(s) - L + 1))
             x = list(s[a:a + L])
-            for _ in range(int(rng.choice([0, 0, 1, 1, 2, 3]))):
+            for _ in range(int(rng.choice([0, 0, 0, 0, 1, 2] if exact_bias else [0, 0, 1, 1, 2, 3]))):
                 q = int(rng.integers(0, L)); x[q] = "ACGT"[int(rng.integers(0, 4))]
             if rng.random() < 0.05:
                 x[int(rng.integers(0, L))] = "N"
@@ -205,13 +230,28 @@ def test_random_trimming_options_equal_the_restated_chain(seed):
             ad = ad[:p_] + "N" + ad[p_ + 1:]
         ads.append((kind, ad))
     opts = {}
+    # round 5: anchored adapters (`-g ^A` / `-a B$`) and ONE linked adapter `A...B` (5' part required; under -a anchored with an
+    # optional 3' part, under -g regular with a required one; either part may carry an explicit anchor)
+    anch = [bool(rng.random() < 0.25) and "N" not in ad for _, ad in ads]
+    linked = None
+    if len(ads) == 2 and rng.random() < 0.45 and "N" not in ads[0][1]:
+        ads = [("front", ads[0][1]), ("back", ads[1][1])]
+        under_a = bool(rng.random() < 0.5)
+        linked = dict(front=ads[0][1], back=ads[1][1], front_anchored=under_a or anch[0], back_anchored=anch[1] and "N" not in ads[1][1],
+                      front_required=True, back_required=not under_a)
+    if linked:
+        opts["linked"] = linked
     if ads:
-        if len(ads) == 1 and rng.random() < 0.6:
+        if linked:
+            pass
+        elif len(ads) == 1 and rng.random() < 0.6:
             opts["adapter"] = ads[0][1]
             if ads[0][0] == "front":
                 opts["front"] = True
+            if anch[0]:
+                opts["anchored"] = True
         else:
-            opts["adapters"] = ads
+            opts["adapters"] = [(k, a, an) for (k, a), an in zip(ads, anch)]
         opts["error_rate"] = float(rng.choice([0.0, 0.05, 0.1, 0.12, 0.2, 0.3]))
         opts["overlap"] = int(rng.integers(1, 9))
         if rng.random() < 0.3:
@@ -277,7 +317,11 @@ def test_random_trimming_options_equal_the_restated_chain(seed):
     a2 = ads[1] if len(ads) > 1 else (None, None)
     if any(k == "front" and "N" in a for k, a in ads):
         pytest.skip("N in a 5' adapter is refused by the C ABI")
-    trim = _ffi.MirgeTrim.make(adapter=a1[1], front=a1[0] == "front", adapter2=a2[1], front2=a2[0] == "front",
+    lkw = dict(anchored=bool(ads) and anch[0], anchored2=len(ads) > 1 and anch[1])
+    if linked:
+        lkw = dict(anchored=linked["front_anchored"], anchored2=linked["back_anchored"], linked=True, front_required=True,
+                   back_required=linked["back_required"])
+    trim = _ffi.MirgeTrim.make(adapter=a1[1], front=a1[0] == "front", adapter2=a2[1], front2=a2[0] == "front", **lkw,
                                quality_back=-1 if q_back is None else q_back, quality_front=opts.get("q_front", 0), nextseq=opts.get("nextseq", -1),
                                min_overlap=opts.get("overlap", 3), error_rate=opts.get("error_rate", 0.12), trim_n=opts.get("trim_n", False),
                                cut=opts.get("cut", []), count_per_modifier=per_mod, times=opts.get("times", 1), indels=opts.get("indels", True),

@@ -1010,6 +1010,24 @@ def test_cli_on_a_library_directory_of_ebwt_indexes_only(name, tmp_path):
         assert (out / f).read_text() == case.text(f), f
 
 
+@pytest.mark.parametrize("name", ["case1_single", "case3_spikein"])
+def test_cli_backend_bowtie_crosses_the_process_boundary(name, tmp_path):
+    """`--backend bowtie` (BASELINE.md 3.5's C1 through this build's CLI; SURVEY section 5 'Config / flags'): collapse on the GPU,
+    then the reference's ten bowtie runs verbatim across its process boundary -- here against the stand-in bowtie of
+    tests/golden/fake_bowtie (no bowtie 1.x in the image or on the pool: with a real one in -pbwt this is the parity switch) --,
+    then the count tables.  Every file must equal what the reference wrote for the golden case, and what `--backend gpu` writes."""
+    case = GoldenCase(name)
+    files = _case_fastqs(case, tmp_path)
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fake_bowtie")
+    base = ["-s", ",".join(files), "-lib", str(case.libdir), "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-shh"] + (["-spk"] if case.spike else [])
+    _run_cli(base + ["-dn", "bt", "--backend", "bowtie", "-pbwt", fake, "-cpu", "2"])
+    _run_cli(base + ["-dn", "gpu"])
+    for f in ("miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv", "annotation.report.csv"):
+        assert (tmp_path / "bt" / f).read_text() == case.text(f), f
+        assert (tmp_path / "bt" / f).read_text() == (tmp_path / "gpu" / f).read_text(), f
+    assert "bowtie backend" in (tmp_path / "bt" / "run.log").read_text()
+
+
 def test_integration_md_stub_runs(tmp_path):
     """The ctypes stub printed in INTEGRATION.md section 2 is executed as written (only the library path and the
     `nine_libraries` input are supplied) on golden case 1 and must reproduce the reference's annotation."""
@@ -1149,19 +1167,97 @@ def test_collapse_count_matrix_beyond_2_to_32_cells(ctx):
     raw.close()
 
 
-@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0")])
+def test_exact_passes_are_whole_read_lookups(ctx, ci_libs, ci_cascade):
+    """Round 5: the passes that admit no mismatch anywhere in the read -- pass 0 ("-n 0", len < 26: inside the seed) and pass 3
+    ("-v 0" on the read without its T tail), manifoldAlign.py:85,93,118-126 -- are answered by ONE lookup of the whole read in
+    a table of every valid window of the library, riding in the walk of pass 1 / pass 2 (kernels_cascade.hpp, ExactStep).
+    Against the oracle on reads made for it: every substring of miRNAs at lengths 12-25 (a hit at every offset; SNP variants
+    share substrings, so the LOWEST position must win), the same with one substitution or an N (no exact hit: later passes),
+    25/26-nt reads either side of the length rule, pre-tRNA tails with heads of every length 1-28 plus 3-7 Ts, heads that are
+    no substring, all-T reads (empty head), reads of 32+ nt beside them (other read groups, other kernels)."""
+    rng = np.random.default_rng(11)
+    mir, pre, hp = ci_libs.libs["mirna"], ci_libs.libs["pre_trna"], ci_libs.libs["hairpin"]
+    reads = []
+    for r in range(0, len(mir), 7):
+        s = mir.seqs.get(r)
+        for L in range(12, len(s) + 1):
+            for o in range(len(s) - L + 1):
+                reads.append(s[o:o + L])
+                if (L + o) % 5 == 0:
+                    q = int(rng.integers(0, L))
+                    x = list(s[o:o + L]); x[q] = "ACGT"[("ACGT".index(x[q]) + 1 + int(rng.integers(0, 3))) % 4]
+                    reads.append("".join(x))
+                if (L + o) % 11 == 0:
+                    x = list(s[o:o + L]); x[int(rng.integers(0, L))] = "N"
+                    reads.append("".join(x))
+    for r in range(0, len(hp), 9):  # 25-31-nt pieces of hairpins: some contain a whole miRNA (longer than the rule allows)
+        s = hp.seqs.get(r)
+        for L in (24, 25, 26, 27, 31):
+            o = int(rng.integers(0, len(s) - L + 1))
+            reads.append(s[o:o + L])
+    for r in range(0, len(pre), 3):
+        s = pre.seqs.get(r)
+        for hl in range(1, 29):
+            for tails in (3, 4, 7):
+                if hl + tails > 31:
+                    continue
+                o = int(rng.integers(0, len(s) - hl + 1))
+                head = s[o:o + hl] if (hl + tails) % 6 else s[len(s) - hl:]
+                reads.append(head + "T" * tails)
+                if hl > 4 and (hl + r) % 4 == 0:  # a head one base off: no exact window
+                    x = list(head); x[hl // 2] = "ACGT"[("ACGT".index(x[hl // 2]) + 1) % 4]
+                    reads.append("".join(x) + "T" * tails)
+    reads += ["TTT", "TTTT", "T" * 31, "A", "ACGTTT", "NTTTT", "TTTA"]
+    reads += [hp.seqs.get(3)[:40], pre.seqs.get(2)[10:60] + "TTTT", mir.seqs.get(1) + "ACGTACGTACGTACG"]
+    reads = sorted(set(reads))
+    rng.shuffle(reads)
+    fs = FlatSeqs.from_list(reads)
+    g = ci_cascade.annotate(fs)
+    walks = _ffi.cascade_walks(ctx)
+    # exact miRNA | hairpin, mature tRNA | primary tRNA, snoRNA+rRNA+ncRNA (one merged pass), mRNA, isomiR
+    riding = {(5, 2, 7), (7, 2, 7)}  # (7: a build whose exact steps walk on their own, MIRGE_EXACT_RIDE=0)
+    assert walks in ({(7, 0, 7)} if os.environ.get("MIRGE_EXACT_WALKS") == "0" else riding), walks
+    o = oracle.cascade(fs.data, fs.offsets, oracle_libs_from(ci_libs.libs), n_pass=9)
+    _assert_same(o, g)
+    assert (g[0] == 0).sum() > 500 and (g[0] == 3).sum() > 100 and (g[0] == 8).sum() > 50 and (g[0] == 1).sum() > 5
+
+
+def test_long_reads_under_a_length_rule_beyond_255(ctx, ci_libs):
+    """A policy whose `len >` rule lies beyond 255 (round 4's review): the long class stands for every length from 256 on, so
+    its tables must be built whatever the rule says -- the 400-nt read passes `len > 300` on the device and used to probe a
+    table nobody had built."""
+    mrna = ci_libs.libs["mrna"]
+    lib = _ffi.DeviceLibrary(ctx, mrna.seqs)
+    ref = mrna.seqs.get(4)
+    reads = [ref[20:420], ref[5:280], ref[100:130], ref[7:263]]
+    pol = _ffi.MirgePolicy()
+    for k, v in dict(mode=0, mm=1, seedlen=28, maxtotal=2, len_gt=300).items():
+        setattr(pol, k, v)
+    pol2 = _ffi.MirgePolicy()
+    for k, v in dict(mode=1, mm=0, seedlen=28, maxtotal=0, len_lt=270).items():
+        setattr(pol2, k, v)
+    dr = _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list(reads))
+    res = _ffi.cascade_run(ctx, dr, [lib, lib], [pol, pol2])
+    ps, rf, of, mm = res.fetch()
+    # 400 nt: pass 0 (len > 300); 275 nt: neither rule; 30 nt and 256 nt: pass 1 (len < 270, exact)
+    assert ps.tolist() == [0, -1, 1, 1] and rf.tolist() == [4, -1, 4, 4] and of.tolist() == [20, -1, 100, 7] and mm.tolist() == [0, -1, 0, 0]
+    res.close(); dr.close(); lib.close()
+
+
+@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0"), dict(MIRGE_EXACT_WALKS="0")])
 def test_staged_cascade_for_every_group(hooks):
     """Small read groups normally take k_cascade_fused (one launch for the whole cascade, no compaction); MIRGE_FUSED_MAX=0
     sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch), or
     with MIRGE_BULK_FUSED=0 one k_pass launch per pass.  All must agree with the oracle: the oracle parity tests of this
     file, the one-call route (full cascade and the one-pass C2 cascade) and the cascade fuzz are re-run in a fresh process with
-    the hooks set."""
+    the hooks set.  With MIRGE_FUSED_MAX=0 the small groups of one-word reads WITH ambiguous calls also walk with the exact
+    steps of round 5 (the build with N masks); MIRGE_EXACT_WALKS=0 is round 4's one walk per pass, no whole-read tables."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
                         os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k",
-                        "vs_oracle or vs_bruteforce or low_complexity or edge_cases or golden_cascade or random_cascade or one_call"],
+                        "vs_oracle or vs_bruteforce or low_complexity or edge_cases or golden_cascade or random_cascade or one_call or exact_passes"],
                        env=dict(os.environ, **hooks), capture_output=True, text=True, timeout=1500, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -1354,9 +1450,10 @@ def test_weighted_collapse_merges_dictionaries(ctx, ci_libs):
         cnt, _ = u.counts()
         o = u.first_appearance_order()
         sq = u.unpack().take(o)
-        parts.append(SampleReads(sq.data, sq.offsets, cnt[o, 0], np.full(len(o), -1, np.int8), np.arange(len(o), dtype=np.int32)))
+        parts.append(SampleReads.from_seqs(sq, cnt[o, 0]))
+        assert parts[-1].lengths.dtype == np.uint8 and np.array_equal(parts[-1].offsets, sq.offsets)
         u.close(); raw.close()
-    uniq, ps, ref = merge_sample_reads(ctx, parts)
+    uniq = merge_sample_reads(ctx, parts)
     cnt, first = uniq.counts()
     seqs = uniq.unpack().to_list()
     exp = [Counter(smp.to_list()) for smp in samples]
@@ -1364,7 +1461,7 @@ def test_weighted_collapse_merges_dictionaries(ctx, ci_libs):
     for i, q in enumerate(seqs):
         assert [int(x) for x in cnt[i]] == [c.get(q, 0) for c in exp]
     allseq = [q for p in parts for q in FlatSeqs(p.data, p.offsets).to_list()]
-    assert all(allseq[int(f)] == q for f, q in zip(first, seqs)) and (ps == -1).all()
+    assert all(allseq[int(f)] == q for f, q in zip(first, seqs))
     assert all(allseq.index(q) == int(f) for f, q in list(zip(first, seqs))[:200])
     uniq.close()
 
@@ -1784,6 +1881,72 @@ def test_two_adapters_best_match_equals_the_restated_adapter_cutter(ctx, kinds):
     # the choice is exercised: some reads lose the first adapter, some the second, and both differ from either alone
     alone = [oracle.trimmed_counts(recs, dict(q_back=10, adapters=[a]), 16, False) for a in ads]
     assert want != alone[0] and want != alone[1]
+    uniq.close(); raw.close()
+
+
+@pytest.mark.parametrize("form", ["-g A...B", "-a A...B", "-g ^A...B$", "-g ^A", "-a B$", "-g ^A -a B$", "-a A...B -n 2 --no-indels"])
+def test_linked_and_anchored_adapters_equal_the_restated_cutadapt(ctx, form):
+    """Round 5: the specification strings the reference hands to cutadapt unchanged (digest.py:66-84) -- a linked adapter
+    `A...B` (docs/source/quick_start.md:213-220 shows one under -g), anchored `^A` / `B$` -- through k_trim's general branch
+    against the oracle's restatement of LinkedAdapter.match_to / PrefixAdapter / SuffixAdapter, on reads that carry the 5' part
+    at the first base, inside, damaged, partial or not at all, and the same for the 3' part.  Parity with cutadapt: unpinned."""
+    from mirge3_amd.cli import parse_args
+    from mirge3_amd.collapse import trim_from_args, parse_adapter_spec, adapters_from_args
+    rng = np.random.default_rng(sum(map(ord, form)))
+    a5, a3 = "TTAGGCACGT", "TGGAATTCTCGGGTGCCAAGGAACTCCAGT"
+    recs = []
+    for i in range(5000):
+        ins = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, size=int(rng.integers(15, 36))))
+        x5, x3 = list(a5), list(a3)
+        r = rng.random()
+        if r < 0.15:
+            x5[int(rng.integers(0, len(x5)))] = "ACGT"[int(rng.integers(0, 4))]
+        elif r < 0.25:
+            del x5[int(rng.integers(1, len(x5) - 1))]
+        elif r < 0.35:
+            x5 = x5[int(rng.integers(1, len(x5) - 2)):]
+        elif r < 0.5:
+            x5 = []
+        elif r < 0.6:
+            x5 = list("ACGT"[int(rng.integers(0, 4))] * int(rng.integers(1, 4))) + x5  # the 5' part not at the first base
+        r = rng.random()
+        if r < 0.15:
+            x3[int(rng.integers(0, len(x3)))] = "ACGT"[int(rng.integers(0, 4))]
+        elif r < 0.25:
+            del x3[int(rng.integers(1, len(x3) - 1))]
+        elif r < 0.45:
+            x3 = x3[:int(rng.integers(3, len(x3) - 3))]
+        elif r < 0.6:
+            x3 = []
+        elif r < 0.7:
+            x3 = x3 + list("ACGT"[int(rng.integers(0, 4))] * int(rng.integers(1, 5)))   # something behind the 3' part
+        seq = "".join(x5) + ins + "".join(x3)
+        recs.append((seq, "I" * len(seq)))
+    recs += [("", ""), (a5, "I" * len(a5)), (a3, "I" * len(a3)), (a5 + a3, "I" * (len(a5) + len(a3)))]
+    text = "".join(f"@r{i}\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(recs)).encode()
+    argv = ["-s", "x.fq", "-lib", "/x", "-on", "human", "--trim-count", "once"]
+    for tok in form.replace("A...B", f"{a5}...{a3}").replace("^A", "^" + a5).replace("B$", a3 + "$").split():
+        argv.append(tok)
+    args = parse_args(argv)
+    trim = trim_from_args(args)
+    specs = [parse_adapter_spec(k, q) for k, q in adapters_from_args(args)]
+    o = dict(q_back=10, times=int(args.times or 1), indels=bool(args.indels))
+    if specs[0].get("linked"):
+        o["linked"] = specs[0]
+    else:
+        o["adapters"] = [(sp["kind"], sp["seq"], sp["anchored"]) for sp in specs]
+    raw, n_rec = _ffi.DeviceReads.parse(ctx, text, 1, 16, trim)
+    assert n_rec == len(recs)
+    uniq = raw.collapse()
+    cnt, first = uniq.counts()
+    seqs = uniq.unpack().to_list()
+    order = np.argsort(first, kind="stable")
+    want = oracle.trimmed_counts(recs, o, 16, False)
+    got = [(seqs[i], int(cnt[i, 0])) for i in order]
+    assert got == list(want.items()) and len(want) > 1500
+    # the form matters: the regular two-adapter chain on the same reads counts differently
+    plain = oracle.trimmed_counts(recs, dict(q_back=10, adapters=[("front", a5), ("back", a3)]), 16, False)
+    assert want != plain
     uniq.close(); raw.close()
 
 

@@ -187,6 +187,25 @@ def test_cli_flags_in_and_out_of_scope():
     assert adapters_from_args(swapped) == [("front", ILLUMINA_3P), ("back", ILLUMINA_5P)]
     aa = trim_from_args(parse_args(base + ["-a", "AAAAC", "-a", "CCCCG"]))
     assert (aa.adapter, aa.adapter2, aa.adapter_front, aa.adapter2_front) == (b"AAAAC", b"CCCCG", 0, 0)
+    # anchored and linked specifications (cutadapt's parser; docs/source/quick_start.md:213-220 documents the linked one)
+    from mirge3_amd.collapse import parse_adapter_spec, unpinned_trim_options
+    lk = trim_from_args(parse_args(base + ["-g", "TTAGGC...TGGAATTCTCGGGTGCCAAGGAACTCCAGT"]))
+    assert (lk.linked, lk.adapter, lk.adapter_front, lk.adapter_anchored, lk.adapter2, lk.adapter2_front, lk.adapter2_anchored,
+            lk.linked_required) == (1, b"TTAGGC", 1, 0, b"TGGAATTCTCGGGTGCCAAGGAACTCCAGT", 0, 0, 3)
+    la = trim_from_args(parse_args(base + ["-a", "TTAGGC...TGGAATTC$"]))
+    assert (la.linked, la.adapter_anchored, la.adapter2_anchored, la.linked_required) == (1, 1, 1, 1)
+    an = trim_from_args(parse_args(base + ["-g", "^TTAGGC", "-a", "TGGAATTC$"]))
+    assert (an.linked, an.adapter, an.adapter_anchored, an.adapter2, an.adapter2_anchored) == (0, b"TTAGGC", 1, b"TGGAATTC", 1)
+    assert parse_adapter_spec("front", "^ACGT") == dict(kind="front", seq="ACGT", anchored=True)
+    assert "a linked adapter (A...B)" in unpinned_trim_options(parse_args(base + ["-g", "TTAGGC...TGGAATTC"]))
+    assert "an anchored adapter (^A / A$)" in unpinned_trim_options(parse_args(base + ["-a", "TGGAATTC$"]))
+    for bad in (["-a", "XACGT...TTTT"], ["-g", "XACGTACGT"], ["-a", "ACGTACGTX"], ["-a", "name=ACGT"], ["-a", "ACGT;min_overlap=5"],
+                ["-a", "file:adapters.fa"], ["-g", "AAAA...CCCC", "-a", "GGGG"], ["-a", "ACGT..."]):
+        with pytest.raises(NotImplementedError):
+            trim_from_args(parse_args(base + bad))
+    for bad in (["-a", "^ACGT"], ["-g", "ACGT$"]):
+        with pytest.raises(SystemExit):
+            trim_from_args(parse_args(base + bad))
     x = parse_args(base + ["-ex", "0.2", "-onam", "run1"])  # the reference's spellings of these two flags
     assert x.crThreshold == "0.2" and x.outDirName == "run1"
     # flags the reference never reads, or that belong to tools / subsystems outside the path: accepted, ignored

@@ -76,3 +76,60 @@ def test_partial_adapter_ties_keep_the_longer_prefix():
                                 ("ACGTTACCCGGGGCTCTGGAATTCTCAG", 12, 16)):
         hit = oracle.adapter_locate_back("TGGAATTCTCGGGTGCCAAGGAACTCCAG", read)
         assert hit[1] == astop and hit[2] == rstart and hit[5] == 1, hit
+
+
+def test_anchored_adapter_cases_of_the_user_guide():
+    """cutadapt's user guide, "Anchored 5' adapters" / "Anchored 3' adapters" (its tables, with ADAPTER -> AD, mysequence ->
+    INS): an anchored adapter is taken whole at the read's end it is anchored to, or not at all."""
+    def pre(read, rate=0.12):
+        hit = oracle.adapter_locate_front(AD, read, rate, 3, anchored=True)
+        return read if hit is None else read[hit[3]:]
+
+    def suf(read, rate=0.12):
+        hit = oracle.adapter_locate_back(AD, read, rate, 3, anchored=True)
+        return read if hit is None else read[:hit[2]]
+    assert pre(AD + INS) == INS                          # ADAPTERmysequence -> mysequence
+    assert pre(AD[1:] + INS, rate=0.0) == AD[1:] + INS   # DAPTERmysequence: no partial occurrence (it would be one deletion)
+    assert pre("C" + AD + INS, rate=0.0) == "C" + AD + INS  # something in front of it: not at the first base
+    assert pre(INS + AD) == INS + AD                     # mysequenceADAPTER: not a 5' occurrence at all
+    one = AD[:6] + "A" + AD[7:]
+    assert pre(one + INS) == INS                         # one substitution within 12 % of 12
+    assert pre(AD[:3] + AD[4:] + INS) == INS             # one deleted adapter base: an error like any other
+    assert pre("G" + AD + INS) == INS                    # one inserted read base in front: one error, the prefix goes with it
+    assert suf(INS + AD) == INS                          # mysequenceADAPTER -> mysequence
+    assert suf(INS + AD[:8]) == INS + AD[:8]             # mysequenceADAP: a partial adapter is no anchored occurrence
+    assert suf(INS + AD + "ACGT") == INS + AD + "ACGT"   # mysequenceADAPTERsomethingelse: not at the read's end
+    assert suf(INS + one) == INS
+    assert suf(AD) == ""
+
+
+def test_linked_adapter_cases_of_the_user_guide():
+    """"Linked adapters (combined 5' and 3' adapter)": `-a ADAPTER1...ADAPTER2` -- ADAPTER1 anchored and required, ADAPTER2
+    optional; `-g ADAPTER1...ADAPTER2` -- ADAPTER1 a regular 5' adapter, both required (a read without either stays)."""
+    A1, A2 = "TTAGGCAC", AD
+
+    def linked(read, kind, **kw):
+        lk = dict(front=A1, back=A2, front_anchored=kind == "back", back_anchored=False, front_required=True, back_required=kind == "front")
+        lk.update(kw)
+        return oracle.trim_stages(read, None, dict(linked=lk))[-1]
+    # -a: both found; only the 5' part (3' optional: still trimmed); 5' part absent (required): untouched, even with the 3' part there
+    assert linked(A1 + INS + A2, "back") == INS
+    assert linked(A1 + INS + A2 + "ACG", "back") == INS
+    assert linked(A1 + INS, "back") == INS
+    assert linked(INS + A2, "back") == INS + A2
+    assert linked("C" + A1 + INS + A2, "back", ) == "C" + A1 + INS + A2   # (0 errors allowed over 8 bases: not anchored at base 1)
+    # -g: regular 5' part anywhere in front, both required
+    assert linked(A1 + INS + A2, "front") == INS
+    assert linked("CCA" + A1 + INS + A2, "front") == INS
+    assert linked(A1[3:] + INS + A2, "front") == INS                      # a partial 5' part at the read's start
+    assert linked(A1 + INS, "front") == A1 + INS                         # the 3' part is required: nothing is removed
+    assert linked(INS + A2, "front") == INS + A2                         # the 5' part is required
+    # the 3' part is searched BEHIND the 5' match only: an A2 inside what the 5' part removes does not count
+    assert linked(A2[:6] + A1 + INS, "back", front_anchored=False) == INS
+    # explicit anchors of a -g linked adapter
+    assert linked(A1 + INS + A2, "front", front_anchored=True, back_anchored=True) == INS
+    assert linked(A1 + INS + A2 + "ACA", "front", front_anchored=True, back_anchored=True) == A1 + INS + A2 + "ACA"  # (one extra base would be one error: allowed)
+    # the documented command line's adapter (docs/source/quick_start.md:213-220)
+    lk = dict(front="TTAGGC", back="TGGAATTCTCGGGTGCCAAGGAACTCCAGT", front_anchored=False, back_anchored=False, front_required=True, back_required=True)
+    read = "TTAGGC" + "TGAGGTAGTAGGTTGTATAGTT" + "TGGAATTCTCGGGTGCCAAGG"
+    assert oracle.trim_stages(read, "I" * len(read), dict(q_back=10, linked=lk)) == [read, "TGAGGTAGTAGGTTGTATAGTT"]

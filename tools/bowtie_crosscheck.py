@@ -18,6 +18,18 @@ the reference does (field 0 / field 2) and compares with ONE pass of the GPU eng
 Indexes: `<index>.1.ebwt` is built with `bowtie-build` from `<index>.fa` if missing (skipped when the directory has
 no bowtie-build, e.g. the shim in mirge3.0_amd/shim, which answers from `<index>.fa`).
 Exit code 0 = every pass agrees on membership.
+
+A read on which the two disagree is printed with the open question(s) of the restatement it falls under (DESIGN.md section 3,
+SURVEY.md 8 caveats i-v, and vi of round 4's review), so that an `only-bowtie` / `only-gpu` line of the first real run explains
+itself:
+  (i)   -n mode, read longer than the 28-nt seed: Maq rounding of Q40 -> 30 with -e 70 => at most 2 mismatches overall, the
+        second only beyond the seed
+  (ii)  the read holds an N (scored as a mismatch at every alignment here)
+  (iii) what bowtie is handed is empty or no longer than the mismatch budget (pass 3 heads, -5/-3 trims): skipped here
+  (iv)  the library holds ambiguous bases: windows over them are no hits here (bowtie excludes them from its index)
+  (v)   several equally good hits: the NAME may differ (never membership) -- counted as `other-name`
+  (vi)  --maxbts, bowtie's backtracking limit ("may cause some valid alignments to be missed"), is documented for -n 2 / -n 3
+        only; the cascade's strings are -n 0 / -n 1 / -v: none of them is under it, so it explains NO line of this report
 """
 import argparse
 import os
@@ -81,6 +93,23 @@ def main(argv=None):
     def say(line):
         print(line)
         report.append(line)
+    lib_has_n = {k: bool(np.isin(v.seqs.data, np.frombuffer(b"ACGTacgtUu", np.uint8), invert=True).any()) for k, v in libs.items()}
+
+    def caveats(it, key, x):
+        """the open questions (i)-(iv) a read handed to pass `it` as `x` falls under"""
+        kw = PASSES[it][3]
+        out = []
+        eff = len(x) - kw.get("trim5", 0) - kw.get("trim3", 0)
+        if kw["mode"] == 0 and eff > kw["seedlen"]:
+            out.append("(i) longer than the seed in -n mode")
+        if "N" in x.upper():
+            out.append("(ii) N in the read")
+        if eff < 1 or eff <= kw["mm"]:
+            out.append("(iii) empty or no longer than the mismatch budget")
+        if lib_has_n[key]:
+            out.append("(iv) the library holds ambiguous bases")
+        return out or ["none of (i)-(iv): a difference in the predicate itself"]
+
     fasta = os.path.join(tmp, "bwtInput.fasta")
     for it in range(9):
         col, key, argstr, _ = PASSES[it]
@@ -117,8 +146,15 @@ def main(argv=None):
         diff_name = sum(1 for q in got if q in ref_hit and ref_hit[q] != got[q])
         say(f"pass {it} {col:14s} reads {len(recs):7d}  bowtie {len(ref_hit):7d}  gpu {len(got):7d}  only-bowtie {len(only_b)}  "
             f"only-gpu {len(only_g)}  other-name {diff_name}")
+        handed = dict(recs)
+        tally = {}
+        for q in only_b + only_g:
+            for c in caveats(it, key, handed[q]):
+                tally[c] = tally.get(c, 0) + 1
+        for c, k in sorted(tally.items()):
+            say(f"     {k:6d} of the differing reads: {c}")
         for q in (only_b + only_g)[:5]:
-            say(f"     {q} bowtie: {ref_hit.get(q)} gpu: {got.get(q)}")
+            say(f"     {q} bowtie: {ref_hit.get(q)} gpu: {got.get(q)}  [{'; '.join(caveats(it, key, handed[q]))}]")
         for q in [q for q in got if q in ref_hit and ref_hit[q] != got[q]][:3]:
             say(f"     name differs: {q} bowtie: {ref_hit[q]} gpu: {got[q]}")
         n_both += sum(1 for q in got if q in ref_hit)
@@ -126,6 +162,7 @@ def main(argv=None):
         bad += len(only_b) + len(only_g)
         annotated |= set(ref_hit)  # the cascade continues with what the REFERENCE path annotated
     say("membership identical in every pass" if bad == 0 else f"{bad} reads differ in membership")
+    say("(vi) --maxbts applies to -n 2 / -n 3 only: no argument string of the cascade is under it")
     say(f"tie rate: {n_other} of {n_both} reads aligned by both carry another reference name ({100.0 * n_other / max(n_both, 1):.3f} %)")
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
