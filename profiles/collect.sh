@@ -15,7 +15,7 @@ PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 # everything is compiled BEFORE the first profiled run (bench.py would otherwise spawn hipcc/gcc under rocprofv3)
 "$PY" "$REPO/__graft_entry__.py" || exit 1
 cd /tmp && export TMPDIR=/tmp
-BENCH="$PY $REPO/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --pmc 0 --two-in-flight 0 --min-seconds 0.1 --spinup 0.1 ${BENCH_ARGS:-}"
+BENCH="$PY $REPO/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --pmc 0 --two-in-flight 0 --read-sets 0 --min-seconds 0.1 --spinup 0.1 ${BENCH_ARGS:-}"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/bench_kt.json" 2> "$OUT/kt.err"
 if [ -n "${KT_ONLY:-}" ]; then exit 0; fi
 i=0

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 PY=$(python3 -c 'import os,sys;print(os.path.realpath(sys.executable))')
 "$PY" "$REPO/__graft_entry__.py" || exit 1
 cd /tmp && export TMPDIR=/tmp
-BENCH="$PY $REPO/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --pmc 0 --two-in-flight 0 --cli-path 0 --min-seconds 0.1 --spinup 0.1"
+BENCH="$PY $REPO/bench.py --steps 5 --warmup 2 --cpu-baseline 0 --pmc 0 --two-in-flight 0 --cli-path 0 --read-sets 0 --min-seconds 0.1 --spinup 0.1"
 i=0
 for CTRS in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" \
             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
