@@ -275,7 +275,8 @@ def main(argv=None):
         via_files = multigpu.directory_is_shared(workDir, rank, world, dist)  # False on a node that does not see rank 0's directory
 
         def process(i):  # device-resident per sample (fastpath.run_sample_tables)
-            return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc, via_files)
+            return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc, via_files,
+                                              dictionary_order=len(files) == 1)
 
         t_shard = time.perf_counter()
         tables = multigpu.run_sharded(len(files), rank, world, process, dist)

@@ -188,7 +188,12 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         std::snprintf(name, sizeof(name), "k_collapse_insert%s", group_tag(gi));
         LaunchScope ls(c, name, in.n);
         // at most 2 workgroups per CU: each sees enough of the group for its LDS cell cache to merge hot reads
-        const int ins_grid = std::min(grid_for(c, in.n), c->n_cu * 2);
+        // (round 5: up to 8 per CU for a group of under 2 M reads.  Beside the bulk group's k_part_agg / k_part_split a memory
+        // access of this kernel takes ~10 us; with 2 workgroups per CU every thread walked four reads one after the other,
+        // 166 us for the 0.5 M reads of a sample's 32-64-nt group -- the head of the small groups' path, which ends the step.
+        // A large group keeps 2: its hot sequences merge in fewer, fuller caches.)
+        static const int ins_per_cu = std::getenv("MIRGE_INSERT_WG_PER_CU") ? std::max(1, std::atoi(std::getenv("MIRGE_INSERT_WG_PER_CU"))) : 0;
+        const int ins_grid = std::min(grid_for(c, in.n), c->n_cu * (ins_per_cu ? ins_per_cu : (in.n < (2u << 20) ? 8 : 2)));
         // the first reads go in ahead of the rest, by a few workgroups: a sequence that makes up a percent of the group is
         // among them, so when the whole chip arrives its slot is already claimed and found by a plain load -- otherwise
         // every copy in the first wave of threads sees the slot empty and they all compare-and-swap ONE address
@@ -366,14 +371,39 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         // the CUs with it, then the bulk group's wide kernels.  Small groups entirely first left the GPU idle for
         // the ~0.2 ms their enqueue takes; entirely last, each of their kernels waits behind 2048-8192-workgroup
         // launches for CUs to drain and the join at the end waits for them (5.3 vs 3.8 ms).
+        // Round 5: the small groups' chains run SIDE BY SIDE -- the largest on `aux`, the others on extra streams of their own
+        // (their ~5 launches each are dispatch latencies beside the bulk group's kernels: 95 us one after the other behind the
+        // 32-64-nt group's chain); `aux` collects them before it copies the counts.  MIRGE_SPREAD_SMALL=0: all on `aux`.
+        static const bool spread_on = !(std::getenv("MIRGE_SPREAD_SMALL") && std::atoi(std::getenv("MIRGE_SPREAD_SMALL")) == 0);
+        int small_stream[MIRGE_NGROUPS];  // -1: aux, k: xaux[k]
+        int n_spread = 0;
+        {
+            int largest = -1;
+            for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+                small_stream[gi] = -1;
+                if (gi != big && raw->g[gi].n && (largest < 0 || raw->g[gi].n > raw->g[largest].n)) largest = gi;
+            }
+            if (spread_on && !c->overlap_mode && rc == 0)
+                for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+                    if (gi != big && gi != largest && raw->g[gi].n) small_stream[gi] = n_spread++ % MIRGE_N_XAUX;
+            if (n_spread && rc == 0) rc = xaux_fork(c);
+        }
         for (int k = -1; k <= MIRGE_NGROUPS && rc == 0; k++) {
             const int gi = (k < 0 || k == MIRGE_NGROUPS) ? big : k;
             if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
             const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
-            c->cur = gi == big ? c->stream : c->aux;
+            c->cur = gi == big ? c->stream : (small_stream[gi] >= 0 ? c->xaux[small_stream[gi]] : c->aux);
             if (is_long_group(gi)) rc = collapse_phase_a_long(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, stage, dweight);
             else MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage, dweight));
             if (k < 0) hc.lap("first kernel of the bulk group enqueued");
+        }
+        if (n_spread && rc == 0) {  // `aux` behind the extra streams' chains: the counts it copies next are theirs too
+            hipError_t e = hipSuccess;
+            for (int k = 0; k < std::min(n_spread, MIRGE_N_XAUX) && e == hipSuccess; k++) {
+                e = hipEventRecord(c->ev_xjoin[k], c->xaux[k]);
+                if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_xjoin[k], 0);
+            }
+            if (e != hipSuccess) rc = fail(-2, std::string("mirge_collapse: ") + hipGetErrorString(e));
         }
         // (no join here: the second stream waits for the main one below and carries the read-back of the counts)
         c->cur = c->stream;
@@ -381,6 +411,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         if (rc == -3 && attempt < 2) {
             // the partitioned attempts take up to 2 KiB of HBM per read (attempt 1); the global-atomic tables ~20 B.  A device
             // that cannot give the former (a second context in flight, a fragmented pool) is no reason to fail the call.
+            for (int k = 0; k < MIRGE_N_XAUX; k++) (void)hipStreamSynchronize(c->xaux[k]);
             (void)hipStreamSynchronize(c->aux); (void)hipStreamSynchronize(c->stream);
             for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
                 collapse_tmp_release(c, tmp[gi]);

@@ -62,11 +62,12 @@ def names_by_pass(casc) -> list:
     return cached
 
 
-def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None, via_files: bool = True):
+def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None, via_files: bool = True,
+                      dictionary_order: bool = False):
     """One sample on this process's GPU, for the sharded CLI (one sample per rank, multigpu.py): device-resident parse ->
     collapse + cascade -> count join.  Returns the sample's ``SampleTables`` (a few kB: its columns of the count tables)
-    with its ``SampleReads`` attached (unique reads in dictionary order, counts, annotation: what rank 0 needs for the
-    run's ONE mapped.csv / unmapped.csv and the per-read reports, ~15 B per unique read)."""
+    with its ``SampleReads`` attached (unique reads and counts: what rank 0 needs for the run's ONE mapped.csv /
+    unmapped.csv and the per-read reports, ~30 B per unique read; in dictionary order only when asked)."""
     from . import multigpu
     from .cascade import EXACT_PASS, ISO_PASS
     workDir = Path(workDir)
@@ -84,13 +85,18 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS, len(casc.libs["mirna"]))
     t_tail = time.perf_counter()
     counts, _ = uniq.counts()
-    order = uniq.first_appearance_order()
-    seqs = uniq.unpack().take(order)
+    seqs = uniq.unpack()
+    cnt = counts[:, 0]
+    if dictionary_order:
+        # the order of first appearance only matters when the run has ONE sample (the frame of several is the sorted union of
+        # their sequences, digest.py:243): at C4's size the host-side reordering of 7.8 M ragged reads was 2.4 of a rank's 2.9 s
+        order = uniq.first_appearance_order()
+        seqs, cnt = seqs.take(order), cnt[order]
     out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
     # (round 5: no annotation travels -- it depends on the sequence alone, and rank 0 annotates the run's joint table on its own
     # GPU in milliseconds, which puts that table's mapped.csv / unmapped.csv on the device-formatted route; lengths as bytes
     # or 16-bit words instead of 64-bit offsets: 30 B per unique read instead of 47)
-    reads = multigpu.SampleReads.from_seqs(seqs, counts[order, 0], iupac)
+    reads = multigpu.SampleReads.from_seqs(seqs, cnt, iupac)
     # handed to rank 0 through files in the run's directory when rank 0 sees that directory (same node / shared filesystem:
     # a sample's dictionary is tens to hundreds of MB), in-band with the tables otherwise
     out.reads = reads.to_files(workDir / ".mirge_shards", index) if via_files else reads

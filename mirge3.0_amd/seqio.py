@@ -107,11 +107,12 @@ class FlatSeqs:
         offsets = np.zeros(idx.shape[0] + 1, dtype=np.int64)
         np.cumsum(lens, out=offsets[1:])
         total = int(offsets[-1])
-        # gather: position j of output belongs to row r = searchsorted(offsets, j)
-        rows = np.repeat(np.arange(idx.shape[0], dtype=np.int64), lens)
-        within = np.arange(total, dtype=np.int64) - offsets[:-1][rows]
-        data = self.data[self.offsets[:-1][idx][rows] + within]
-        return FlatSeqs(data, offsets)
+        # gather: output byte j of row r comes from input byte j + (start of idx[r] in the input - start of r in the output):
+        # ONE index array of the output's size (32-bit when the input allows: half the memory traffic), built in place
+        it = np.int32 if max(total, int(self.offsets[-1])) < (1 << 31) - 1 else np.int64
+        index = np.repeat((self.offsets[:-1][idx] - offsets[:-1]).astype(it), lens)
+        index += np.arange(total, dtype=it)
+        return FlatSeqs(self.data[index], offsets)
 
 
 @dataclass

@@ -863,6 +863,19 @@ def test_bench_single_gpu_line(tmp_path):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert d["parity_on_cpu_sample"] is True and d["fastq_text_path"]["same_counts_as_step"] is True
+    # round 5: every stage priced on SURVEY 8(d)'s bytes, the two other read sets of 8(d) beside `value`, how the cascade walks
+    st = d["roofline_stages"]
+    assert {"collapse", "cascade", "join"} <= set(st) and st["cascade"]["frac"] == ro["frac"]
+    for k in ("collapse", "join"):
+        assert st[k]["ms"] > 0 and abs(st[k]["achieved"] - st[k]["algorithmic_bytes"] / (st[k]["ms"] * 1e-3) / 1e9) < 1e-2 * st[k]["achieved"] + 1e-2
+        assert abs(st[k]["frac"] - st[k]["achieved"] / 8000.0) < 1e-5 and st[k]["kernels"]
+    U, N = d["config"]["unique_reads_per_gpu"], d["config"]["raw_reads_per_gpu"]
+    assert st["join"]["algorithmic_bytes"] == 9 * U + 8 * (2 * st["join"]["units"]["mirna_references"] + 10)
+    assert st["collapse"]["units"]["raw_reads"] <= N and st["collapse"]["units"]["unique_reads"] <= U
+    rs = d["read_sets"]
+    assert rs["default_draw"]["ms_per_step"] == d["ms_per_step"] and rs["distinct"]["U_over_N"] == 1.0
+    assert rs["zipf_pool"]["U_over_N"] < rs["default_draw"]["U_over_N"] < 1.0 and rs["zipf_pool"]["raw_reads"] == N
+    assert d["cascade_walks"]["passes"] == 7 and d["cascade_walks"]["walks"] in (5, 7) and d["cascade_walks"]["exact_lookup_passes"] in (0, 2)
 
 
 def test_variant_tally_vs_oracle(ctx):
