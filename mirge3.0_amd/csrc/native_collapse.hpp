@@ -371,10 +371,11 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         // the CUs with it, then the bulk group's wide kernels.  Small groups entirely first left the GPU idle for
         // the ~0.2 ms their enqueue takes; entirely last, each of their kernels waits behind 2048-8192-workgroup
         // launches for CUs to drain and the join at the end waits for them (5.3 vs 3.8 ms).
-        // Round 5: the small groups' chains run SIDE BY SIDE -- the largest on `aux`, the others on extra streams of their own
-        // (their ~5 launches each are dispatch latencies beside the bulk group's kernels: 95 us one after the other behind the
-        // 32-64-nt group's chain); `aux` collects them before it copies the counts.  MIRGE_SPREAD_SMALL=0: all on `aux`.
-        static const bool spread_on = !(std::getenv("MIRGE_SPREAD_SMALL") && std::atoi(std::getenv("MIRGE_SPREAD_SMALL")) == 0);
+        // MIRGE_SPREAD_SMALL=1 (round 5 experiment, OFF by default): the small groups' chains SIDE BY SIDE -- the largest on
+        // `aux`, the others on extra streams of their own -- instead of one after the other on `aux`.  Measured worse: 1.29 vs
+        // 1.21 ms per C3 step (profiles/r05_ab_spread_small.txt): more kernels in flight beside k_part_split / k_part_dedup slow
+        // those, and the small groups' cascades end when the bulk kernel's workgroups retire whenever they start.
+        static const bool spread_on = std::getenv("MIRGE_SPREAD_SMALL") && std::atoi(std::getenv("MIRGE_SPREAD_SMALL")) == 1;
         int small_stream[MIRGE_NGROUPS];  // -1: aux, k: xaux[k]
         int n_spread = 0;
         {

@@ -80,11 +80,42 @@ extern "C" int mirge_count_join(mirge_ctx* c, const mirge_reads* U, const mirge_
             hipLaunchKernelGGL(k_join_rows, dim3(rows_b), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, gb, S, P, exact_pass, iso_pass,
                                (uint32_t)n_tab, partial);
         }
-        CHECK(join_side_streams());
-        if (rows_s) {
-            LaunchScope ls(c, "k_join", (double)n_small);
-            hipLaunchKernelGGL(k_join_rows, dim3(rows_s), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, gsm, S, P, exact_pass, iso_pass,
-                               (uint32_t)n_tab, partial + (size_t)rows_b * words);
+        static const bool rows_on_aux = std::getenv("MIRGE_JOIN_SMALL_ON_AUX") && std::atoi(std::getenv("MIRGE_JOIN_SMALL_ON_AUX")) == 1;
+        if (rows_s && rows_on_aux && lazy && c->join_pending) {
+            // MIRGE_JOIN_SMALL_ON_AUX=1 (round 5 experiment, OFF by default): the small groups' rows on `aux`, right behind their
+            // cascades -- `aux` collects the extra streams, runs the rows kernel, and the main stream waits for `aux` once --
+            // instead of on the main stream behind the wait.  Meant to hide the kernel and a queue-to-queue hop (~24 us) behind
+            // k_resolve; measured WORSE, 1.214 vs 1.196 ms per C3 step (profiles/r05_ab_join_on_aux.txt): the small groups'
+            // cascades end ~50 us after the bulk kernel (they run on what its workgroups free), so the rows kernel on `aux`
+            // starts no earlier, and the main stream's wait then includes it.
+            c->join_pending = false;
+            hipError_t e = hipSuccess;
+            if (c->xaux_used) {
+                for (int k = 0; k < MIRGE_N_XAUX && e == hipSuccess; k++) {
+                    e = hipEventRecord(c->ev_xjoin[k], c->xaux[k]);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_xjoin[k], 0);
+                }
+                c->xaux_used = false;
+            }
+            if (e != hipSuccess) return fail(-2, std::string("mirge_count_join: ") + hipGetErrorString(e));
+            c->cur = c->aux;
+            {
+                LaunchScope ls(c, "k_join", (double)n_small);
+                hipLaunchKernelGGL(k_join_rows, dim3(rows_s), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->aux, gsm, S, P, exact_pass, iso_pass,
+                                   (uint32_t)n_tab, partial + (size_t)rows_b * words);
+            }
+            c->cur = c->stream;
+            e = hipEventRecord(c->ev_join, c->aux);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+            if (e != hipSuccess) return fail(-2, std::string("mirge_count_join: ") + hipGetErrorString(e));
+            c->flush_deferred();  // reused only by work queued on the main stream after the wait
+        } else {
+            CHECK(join_side_streams());
+            if (rows_s) {
+                LaunchScope ls(c, "k_join", (double)n_small);
+                hipLaunchKernelGGL(k_join_rows, dim3(rows_s), dim3(MIRGE_JOIN_ROWS_THREADS), words * 8, c->stream, gsm, S, P, exact_pass, iso_pass,
+                                   (uint32_t)n_tab, partial + (size_t)rows_b * words);
+            }
         }
         LaunchScope ls(c, "k_join_reduce", (double)words);
         // ... written by the kernel into the page-locked tables the host reads (no copy behind it, nothing to clear)
