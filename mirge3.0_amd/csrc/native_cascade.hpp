@@ -360,6 +360,14 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
     static const bool exact_on = !(std::getenv("MIRGE_EXACT_WALKS") && std::atoi(std::getenv("MIRGE_EXACT_WALKS")) == 0);
     std::vector<ExactStep> ex(steps.size());
     std::vector<char> is_exact(steps.size(), 0);
+    {
+        bool dropped = false;
+        for (size_t i = 0; i < steps.size() && exact_on; i++) dropped |= lib_exact_trim(const_cast<mirge_lib*>(steps[i].lib));
+        if (dropped) {  // walk lists kept from earlier configurations point into the dropped tables
+            for (auto& e : c->walks) (void)hipFree(e.dev);
+            c->walks.clear();
+        }
+    }
     for (size_t i = 0; i < steps.size() && exact_on; i++) {
         const PassStep& st = steps[i];
         MirgePolicy p;

@@ -229,6 +229,21 @@ static int lib_prepare_shapes(mirge_lib* L, const std::vector<ShapeJob>& wanted)
 #ifndef MIRGE_EXACT_MAX_WINDOWS
 #define MIRGE_EXACT_MAX_WINDOWS (4u << 20)  // 4 M windows -> at most 16 M slots = 128 MB; the human miRNA / pre-tRNA sets hold 0.1 / 1.3 M
 #endif
+// A library keeps the tables of its last few length sets (a batch of samples has one or two; a caller cycling through many
+// would otherwise collect up to 128 MB each).  Called by cascade_prepare BEFORE it asks for any table of a new configuration:
+// beyond 6 everything goes, behind a synchronisation (walk lists on the device may still name them; the caller rebuilds its
+// lists, and a dropped table is built again when its lengths come back).  Returns true when tables were dropped.
+static bool lib_exact_trim(mirge_lib* L) {
+    std::lock_guard<std::mutex> lk(L->mu);
+    if (L->exact.size() < 6) return false;
+    (void)hipSetDevice(L->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : L->exact)
+        if (e.second.slots) { L->device_bytes -= ((size_t)e.second.mask + 1) * 8; (void)hipFree(e.second.slots); }
+    L->exact.clear();
+    return true;
+}
+
 static int lib_exact_table(mirge_lib* L, uint32_t lmask, mirge_lib::ExactTab* out) {
     *out = mirge_lib::ExactTab();
     lmask &= 0xFFFFFFFEu;

@@ -1239,6 +1239,32 @@ def test_exact_passes_are_whole_read_lookups(ctx, ci_libs, ci_cascade):
     assert (g[0] == 0).sum() > 500 and (g[0] == 3).sum() > 100 and (g[0] == 8).sum() > 50 and (g[0] == 1).sum() > 5
 
 
+def test_whole_read_tables_are_dropped_and_rebuilt(ctx, ci_libs, ci_cascade):
+    """A library keeps the whole-read tables of its last few read-length sets only (lib_exact_trim: beyond six everything is
+    dropped behind a synchronisation and the walk lists rebuilt).  Ten batches of ten different length sets through one
+    cascade, the first one again at the end: every batch equals the oracle."""
+    mir, pre = ci_libs.libs["mirna"], ci_libs.libs["pre_trna"]
+    olibs = oracle_libs_from(ci_libs.libs)
+    batches = []
+    for k in range(10):
+        L = 16 + k % 8
+        reads = []
+        for r in range(k, len(mir), 11):
+            s = mir.seqs.get(r)
+            if len(s) >= L:
+                reads.append(s[:L])
+                reads.append(s[len(s) - L:])
+            p_ = pre.seqs.get(r % len(pre))
+            reads.append(p_[len(p_) - (L - 4 - k // 8):] + "TTTT")     # a pre-tRNA tail: pass 3 at a head length of its own
+        reads.append("ACGT" * 4 + "A" * (k + 1))                          # (makes every batch's length set differ)
+        batches.append(FlatSeqs.from_list(sorted(set(reads))))
+    for fs in batches + batches[:1]:
+        g = ci_cascade.annotate(fs)
+        o = oracle.cascade(fs.data, fs.offsets, olibs, n_pass=9)
+        _assert_same(o, g)
+        assert (g[0] == 0).sum() > 10 and (g[0] == 3).sum() > 5
+
+
 def test_long_reads_under_a_length_rule_beyond_255(ctx, ci_libs):
     """A policy whose `len >` rule lies beyond 255 (round 4's review): the long class stands for every length from 256 on, so
     its tables must be built whatever the rule says -- the 400-nt read passes `len > 300` on the device and used to probe a
