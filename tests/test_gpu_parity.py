@@ -1237,6 +1237,20 @@ def test_exact_passes_are_whole_read_lookups(ctx, ci_libs, ci_cascade):
     o = oracle.cascade(fs.data, fs.offsets, oracle_libs_from(ci_libs.libs), n_pass=9)
     _assert_same(o, g)
     assert (g[0] == 0).sum() > 500 and (g[0] == 3).sum() > 100 and (g[0] == 8).sum() > 50 and (g[0] == 1).sum() > 5
+    # the same walks in the build WITH N masks: a set in which most reads hold an ambiguous call makes that group the bulk group
+    # (k_cascade_bulk<1, true>).  An N is a mismatch wherever it is aligned: no exact pass may take such a read, later passes may
+    withn = []
+    for q in reads:
+        if len(q) > 3 and rng.random() < 0.75:
+            j = int(rng.integers(0, len(q)))
+            q = q[:j] + "N" + q[j + 1:]
+        withn.append(q)
+    fs = FlatSeqs.from_list(sorted(set(withn)))
+    g = ci_cascade.annotate(fs)
+    o = oracle.cascade(fs.data, fs.offsets, oracle_libs_from(ci_libs.libs), n_pass=9)
+    _assert_same(o, g)
+    has_n = np.array(["N" in q for q in fs.to_list()])
+    assert has_n.sum() > 2 * (~has_n).sum() and not ((g[0] == 0) & has_n).any() and ((g[0] >= 1) & has_n).sum() > 100
 
 
 def test_whole_read_tables_are_dropped_and_rebuilt(ctx, ci_libs, ci_cascade):
