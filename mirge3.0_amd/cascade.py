@@ -228,7 +228,7 @@ def bwt_align_bowtie(args, pdDataFrame, workDir, ref_db):
                     hit[f[0]] = f[2]
         if hit:
             idx = pdDataFrame.index.get_indexer(list(hit))
-            if (idx < 0).any():  # a QNAME that is no row of the frame: the reference's `df.at[...]` would raise KeyError as well
+            if (idx < 0).any():  # a QNAME that is no row of the frame (the reference's `df.at[...] = ...` would silently grow the frame by a row)
                 raise KeyError(f"bowtie reported a read that was not in its input: {list(hit)[int(np.argmin(idx))]!r}")
             col = pdDataFrame[colnames[1 + it]].to_numpy(dtype=object).copy()
             col[idx] = list(hit.values())
