@@ -429,9 +429,10 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         // once.  The small groups' counts are final when `aux` has run their kernels (~0.3 ms into a 10 M-read step) while the
         // bulk group's come out of k_part_dedup (~0.37 ms) -- and the bulk group does not need the host at all (its cascade takes
         // the count from device memory).  So: the small groups' counts are copied by `aux` with nothing of the main stream in
-        // front, the host sizes their outputs, queues their scatter kernels and hands them to the caller (their cascades start
-        // ~0.14 ms earlier than behind the joint read-back: the 32-64-nt group's one-launch cascade, which runs beside the bulk
-        // kernel on whatever it leaves free, was the END of the step's critical path); only then the bulk group's count.
+        // front, the host sizes their outputs, queues their scatter kernels and hands them to the caller (their cascades); only
+        // then the bulk group's count.  Measured NEUTRAL on the 10 M-read step (1.235 vs 1.238 ms, profiles/README.md round 5):
+        // beside k_part_agg / k_part_split the small groups' own kernels end when k_part_dedup does, and their cascades end when
+        // the bulk kernel's workgroups retire, whenever they start.  Kept: it cannot lose, and the host returns no later.
         static const bool early_on = !(std::getenv("MIRGE_EARLY_SMALL") && std::atoi(std::getenv("MIRGE_EARLY_SMALL")) == 0);
         if (rc == 0 && early_on && hook && hook->small_ready && attempt == 0 && tmp[big].partitioned && !c->overlap_mode) {
             uint32_t* const small = c->pinned + 512;  // (the page-locked block holds 1024 words; the full copy takes the first 272)
