@@ -119,6 +119,28 @@ def test_count_join_tail_reproduces_reference_csvs(name, tmp_path):
         assert (tmp_path / f).read_text() == case.text(f), f
 
 
+@pytest.mark.parametrize("name", ["case1_single", "case3_spikein", "case7_two_samples_cr0.4"])
+def test_bowtie_backend_replays_the_reference_loop(name, tmp_path):
+    """`--backend bowtie` (cascade.bwt_align_bowtie): the reference's ten bowtie runs across its process boundary -- subset
+    rules, FASTA named by sequence, T-tail heads, argv strings verbatim, SAM consumption (manifoldAlign.py:12-146) -- needs no
+    GPU.  Against the stand-in bowtie that made the golden files (tests/golden/fake_bowtie answers from the oracle's matcher):
+    the frame it returns must print as the mapped.csv / unmapped.csv the reference's own bwtAlign wrote."""
+    import pandas as pd
+    from types import SimpleNamespace
+    from mirge3_amd.cascade import bwt_align_bowtie
+    case = GoldenCase(name)
+    df = pd.DataFrame(case.counts, columns=case.samples, index=pd.Index(case.seqs, name="Sequence"))
+    df = df.assign(**dict.fromkeys(PASS_COLS, '')).assign(annotFlag=0).reindex(columns=['annotFlag'] + PASS_COLS + case.samples)
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fake_bowtie")
+    args = SimpleNamespace(quiet=True, bowtie_path=fake, threads=2, libraries_path=case.libdir, organism_name="human", spikeIn=case.spike)
+    out = bwt_align_bowtie(args, df, str(tmp_path), "miRBase")
+    out[out.annotFlag.eq(1)].to_csv(tmp_path / "mapped.csv")
+    out[out.annotFlag.eq(0)].to_csv(tmp_path / "unmapped.csv")
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert (tmp_path / f).read_text() == case.text(f), f
+    assert "bowtie backend" in (tmp_path / "run.log").read_text() and not (tmp_path / "bwtInput.fasta").exists()
+
+
 def test_fastq_parsing(tmp_path):
     p = tmp_path / "x.fastq"
     p.write_text("@r1\nACGTACGTACGTACGTAC\n+\nIIIIIIIIIIIIIIIIII\n@r2\nACGT\n+\nIIII\n@r3\nTTTTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n")
