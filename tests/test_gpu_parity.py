@@ -872,6 +872,9 @@ def test_bench_single_gpu_line(tmp_path):
     U, N = d["config"]["unique_reads_per_gpu"], d["config"]["raw_reads_per_gpu"]
     assert st["join"]["algorithmic_bytes"] == 9 * U + 8 * (2 * st["join"]["units"]["mirna_references"] + 10)
     assert st["collapse"]["units"]["raw_reads"] <= N and st["collapse"]["units"]["unique_reads"] <= U
+    ca = d["collapsed_reads_annotation_on_host"]  # SURVEY 8(d)'s "collapsed reads/s" as written: annotation + tables back on the host
+    assert ca["unique_reads"] == U and ca["M_collapsed_reads_per_s"] > 0 and 0 < ca["annotated"] <= U
+    assert abs(ca["M_collapsed_reads_per_s"] - U / (ca["ms"] * 1e-3) / 1e6) < 0.02 * ca["M_collapsed_reads_per_s"] + 0.1
     rs = d["read_sets"]
     assert rs["default_draw"]["ms_per_step"] == d["ms_per_step"] and rs["distinct"]["U_over_N"] == 1.0
     assert rs["zipf_pool"]["U_over_N"] < rs["default_draw"]["U_over_N"] < 1.0 and rs["zipf_pool"]["raw_reads"] == N
