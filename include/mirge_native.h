@@ -58,7 +58,10 @@ int mirge_device_count(void);
 /* hip_stream: a hipStream_t to run on (e.g. torch's current stream) or NULL for a private one */
 int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out);
 /* Ownership: libraries, read sets and results hold device blocks of the context they were made in -- destroy them BEFORE the
-   context (the ctypes binding does that by itself: closing a Context closes what still lives in it). */
+   context (the ctypes binding does that by itself: closing a Context closes what still lives in it).  A cascade may be handed
+   a library of ANOTHER context of the same device (its probe tables are shared under the library's lock); the whole-read tables
+   of the exact passes are built, named and dropped only through the context the library was made in -- a borrower's exact
+   passes take the probe path, with the same results. */
 void mirge_ctx_destroy(mirge_ctx* ctx);
 int mirge_ctx_sync(mirge_ctx* ctx);
 

@@ -362,7 +362,10 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
     std::vector<char> is_exact(steps.size(), 0);
     {
         bool dropped = false;
-        for (size_t i = 0; i < steps.size() && exact_on; i++) dropped |= lib_exact_trim(const_cast<mirge_lib*>(steps[i].lib));
+        // (only the context a library was made in builds, names and drops its whole-read tables: a library borrowed from
+        //  another context of the same device keeps the probe path, so no other context's walk lists can name a dropped table)
+        for (size_t i = 0; i < steps.size() && exact_on; i++)
+            if (steps[i].lib->ctx == c) dropped |= lib_exact_trim(const_cast<mirge_lib*>(steps[i].lib));
         if (dropped) {  // walk lists kept from earlier configurations point into the dropped tables
             for (auto& e : c->walks) (void)hipFree(e.dev);
             c->walks.clear();
@@ -372,7 +375,7 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         const PassStep& st = steps[i];
         MirgePolicy p;
         std::memcpy(&p, &pol[st.p0], sizeof(p));
-        if (st.np != 1 || p.mm != 0) continue;
+        if (st.np != 1 || p.mm != 0 || st.lib->ctx != c) continue;
         uint32_t lmask = 0;  // lengths the one-word reads of this batch can have when they reach the pass's lookup
         int lmax = 0;
         for (int L = 1; L <= 31; L++) {

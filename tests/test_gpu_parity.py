@@ -1282,6 +1282,30 @@ def test_whole_read_tables_are_dropped_and_rebuilt(ctx, ci_libs, ci_cascade):
         assert (g[0] == 0).sum() > 10 and (g[0] == 3).sum() > 5
 
 
+def test_a_borrowed_library_keeps_the_probe_path(ctx, ci_libs, ci_cascade):
+    """A library made in one context and handed to another context of the same device (allowed: `cascade_prepare` only asks
+    for the same device): the borrower gets no whole-read tables -- only the owner builds, names and drops them, so a walk list
+    of one context can never name a table another context freed -- and its annotation equals the owner's and the oracle's."""
+    mir = ci_libs.libs["mirna"]
+    reads = sorted({mir.seqs.get(r)[o:o + L] for r in range(0, len(mir), 5) for L in (17, 21, 22) for o in (0, 1)
+                    if len(mir.seqs.get(r)) >= o + L})
+    fs = FlatSeqs.from_list(reads)
+    own = ci_cascade.annotate(fs)
+    assert _ffi.cascade_walks(ctx)[1] == (0 if os.environ.get("MIRGE_EXACT_WALKS") == "0" else 2)
+    ctx2 = _ffi.Context(0)
+    try:
+        dr = _ffi.DeviceReads.pack(ctx2, fs)
+        res = _ffi.cascade_run(ctx2, dr, ci_cascade.dev_libs, ci_cascade.policies, ci_cascade._prepared)
+        got = res.fetch()
+        assert _ffi.cascade_walks(ctx2) == (7, 0, 7)
+        res.close(); dr.close()
+    finally:
+        ctx2.close()
+    _assert_same(own, got)
+    _assert_same(oracle.cascade(fs.data, fs.offsets, oracle_libs_from(ci_libs.libs), n_pass=9), got)
+    assert (got[0] == 0).sum() > 20
+
+
 def test_long_reads_under_a_length_rule_beyond_255(ctx, ci_libs):
     """A policy whose `len >` rule lies beyond 255 (round 4's review): the long class stands for every length from 256 on, so
     its tables must be built whatever the rule says -- the 400-nt read passes `len > 300` on the device and used to probe a

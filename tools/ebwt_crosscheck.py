@@ -18,6 +18,7 @@ Exit code 0 = every library agrees.  The report is also written to gpurun_out/eb
 import argparse
 import glob
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -62,48 +63,51 @@ def main(argv=None):
         print(f"{build}: not found", file=sys.stderr)
         return 2
     tmp = tempfile.mkdtemp(prefix="mirge_ebwt_xcheck_")
-    if args.fasta_dir:
-        fastas = sorted(glob.glob(os.path.join(args.fasta_dir, "*.fa")))
-    else:
-        fastas = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "case[13]*", "libs", "*", "index.Libs", "*.fa"))) + synthetic_fastas(tmp)
-    report, bad = [], 0
+    try:
+        if args.fasta_dir:
+            fastas = sorted(glob.glob(os.path.join(args.fasta_dir, "*.fa")))
+        else:
+            fastas = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "case[13]*", "libs", "*", "index.Libs", "*.fa"))) + synthetic_fastas(tmp)
+        report, bad = [], 0
 
-    def say(line):
-        print(line)
-        report.append(line)
-    for fa in fastas:
-        lib = read_fasta(fa)
-        for large in ([False, True] if args.large else [False]):
-            base = os.path.join(tmp, os.path.basename(fa)[:-3] + ("_l" if large else ""))
-            r = subprocess.run([build, "-q"] + (["--large-index"] if large else []) + [fa, base], capture_output=True, text=True)
-            if r.returncode != 0:
-                say(f"{fa}: bowtie-build failed: {r.stderr.strip()[-200:]}")
-                bad += 1
-                continue
-            got = ebwt.read_ebwt(base)
-            seqs = lib.seqs.to_list()
-            # bowtie-build leaves out references without an unambiguous base
-            kept = [i for i, s in enumerate(seqs) if any(c in "ACGTacgt" for c in s)]
-            dropped = len(seqs) - len(kept)
-            want_h = [lib.headers[i] for i in kept]
-            want_s = [seqs[i].upper() for i in kept]
-            ok_h = got.headers == want_h
-            ok_n = got.names == [h.split()[0] if h.split() else "" for h in want_h]
-            ok_s = got.seqs.to_list() == want_s
-            line = f"{os.path.basename(fa):32s} {'ebwtl' if large else 'ebwt '} refs {len(kept):6d} (dropped by bowtie-build: {dropped})  headers {'ok' if ok_h else 'DIFFER'}  names {'ok' if ok_n else 'DIFFER'}  sequences {'ok' if ok_s else 'DIFFER'}"
-            if os.path.exists(inspect):
-                names = subprocess.run([inspect, "-n", base], capture_output=True, text=True).stdout.split("\n")
-                names = names[:-1] if names and names[-1] == "" else names
-                ok_i = names == got.headers
-                line += f"  bowtie-inspect -n {'ok' if ok_i else 'DIFFERS'}"
-                ok_h = ok_h and ok_i
-            say(line)
-            if not (ok_h and ok_n and ok_s):
-                bad += 1
-                for k, (a, b) in enumerate(zip(got.seqs.to_list(), want_s)):
-                    if a != b:
-                        say(f"     first differing sequence: reference {k} ({want_h[k][:40]}): read {a[:50]}... FASTA {b[:50]}...")
-                        break
+        def say(line):
+            print(line)
+            report.append(line)
+        for fa in fastas:
+            lib = read_fasta(fa)
+            for large in ([False, True] if args.large else [False]):
+                base = os.path.join(tmp, os.path.basename(fa)[:-3] + ("_l" if large else ""))
+                r = subprocess.run([build, "-q"] + (["--large-index"] if large else []) + [fa, base], capture_output=True, text=True)
+                if r.returncode != 0:
+                    say(f"{fa}: bowtie-build failed: {r.stderr.strip()[-200:]}")
+                    bad += 1
+                    continue
+                got = ebwt.read_ebwt(base)
+                seqs = lib.seqs.to_list()
+                # bowtie-build leaves out references without an unambiguous base
+                kept = [i for i, s in enumerate(seqs) if any(c in "ACGTacgt" for c in s)]
+                dropped = len(seqs) - len(kept)
+                want_h = [lib.headers[i] for i in kept]
+                want_s = [seqs[i].upper() for i in kept]
+                ok_h = got.headers == want_h
+                ok_n = got.names == [h.split()[0] if h.split() else "" for h in want_h]
+                ok_s = got.seqs.to_list() == want_s
+                line = f"{os.path.basename(fa):32s} {'ebwtl' if large else 'ebwt '} refs {len(kept):6d} (dropped by bowtie-build: {dropped})  headers {'ok' if ok_h else 'DIFFER'}  names {'ok' if ok_n else 'DIFFER'}  sequences {'ok' if ok_s else 'DIFFER'}"
+                if os.path.exists(inspect):
+                    names = subprocess.run([inspect, "-n", base], capture_output=True, text=True).stdout.split("\n")
+                    names = names[:-1] if names and names[-1] == "" else names
+                    ok_i = names == got.headers
+                    line += f"  bowtie-inspect -n {'ok' if ok_i else 'DIFFERS'}"
+                    ok_h = ok_h and ok_i
+                say(line)
+                if not (ok_h and ok_n and ok_s):
+                    bad += 1
+                    for k, (a, b) in enumerate(zip(got.seqs.to_list(), want_s)):
+                        if a != b:
+                            say(f"     first differing sequence: reference {k} ({want_h[k][:40]}): read {a[:50]}... FASTA {b[:50]}...")
+                            break
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     say("every index read back as its FASTA" if bad == 0 else f"{bad} libraries differ")
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
