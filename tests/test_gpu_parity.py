@@ -1342,7 +1342,8 @@ def test_staged_cascade_for_every_group(hooks):
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
                         os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k",
                         "vs_oracle or vs_bruteforce or low_complexity or edge_cases or golden_cascade or random_cascade or one_call or exact_passes"],
-                       env=dict(os.environ, **hooks), capture_output=True, text=True, timeout=1500, cwd=root)
+                       env=dict(os.environ, MIRGE_FUZZ_SEEDS=os.environ.get("MIRGE_HOOK_FUZZ_SEEDS", "5"), **hooks), capture_output=True, text=True,
+                       timeout=1500, cwd=root)  # (five seeds of each cascade fuzzer per alternate path: the suite's run time; the default path runs 16)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
