@@ -547,12 +547,14 @@ def main():
     import torch
     dist = None
     # test hooks (tests/test_gpu_parity.py runs two ranks on the one GPU of the test box):
-    # MIRGE_BENCH_SHARE_GPU=1 puts every rank on device 0, MIRGE_BENCH_BACKEND=gloo keeps RCCL out of it
+    # MIRGE_BENCH_SHARE_GPU=1 puts every rank on device 0, MIRGE_BENCH_BACKEND=gloo keeps RCCL out of it,
+    # MIRGE_BENCH_FORCE_DIST=1 takes the N > 1 route (process groups, RCCL probe, barrier, max over ranks) with ONE rank:
+    # the only way RCCL itself can be brought up on a single-GPU box
     backend = os.environ.get("MIRGE_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("MIRGE_BENCH_SHARE_GPU") else local_rank
     backend_note = None
     rccl_ranks_seen = None
-    if world > 1:
+    if world > 1 or (os.environ.get("MIRGE_BENCH_FORCE_DIST") and "RANK" in os.environ):
         import datetime
         import torch.distributed as dist
         torch.cuda.set_device(dev_index)

@@ -826,6 +826,32 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     assert d["rccl_ranks_seen"] is None and d["config"]["workload"].startswith("C4:")
 
 
+def test_bench_barrier_over_rccl_with_one_rank(tmp_path):
+    """RCCL itself on the test box: two ranks on one GPU cannot form an RCCL communicator, one rank can.  bench.py's N > 1 route
+    (gloo default group, RCCL group on top, probe all-reduce, barrier and max-over-ranks on the RCCL group) with ONE rank under
+    torch.distributed.run (MIRGE_BENCH_FORCE_DIST=1).  What it pins: librccl loads and initialises in this image on this pool's
+    hosts, and every collective call of the bench works on device tensors.  What it cannot: a second rank, xGMI."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, MIRGE_BENCH_FORCE_DIST="1", OMP_NUM_THREADS="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "300000",
+           "--scale", "ci", "--cpu-baseline", "0", "--pmc", "0", "--min-seconds", "0", "--workload", "c3", "--cli-path", "0", "--read-sets", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "rccl_one_rank.json"), "w") as fh:
+            json.dump({k: d.get(k) for k in ("barrier_backend", "barrier_backend_note", "rccl_ranks_seen", "n_gpus", "value", "ms_per_step")}, fh)
+    except OSError:
+        pass
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["barrier_backend"] == "nccl" and d["rccl_ranks_seen"] == 1, d["barrier_backend_note"]
+
+
 def test_bench_single_gpu_line(tmp_path):
     """bench.py at N = 1 on a small configuration: the ONE JSON line with the contract's fields, the oracle-checked
     sample, the roofline object of the dominant kernel and the two host-inclusive paths."""
