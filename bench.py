@@ -210,6 +210,7 @@ def reference_bowtie_baseline(bowtie_dir, sl, libs, reads, n_pass, ctx, casc, ar
     collapsed reads of a bounded sample, all host cores, index construction (bowtie-build) not timed; then the
     per-pass membership of bowtie vs the GPU engine on the same reads (tools/bowtie_crosscheck.py's comparison)."""
     import re
+    import shlex
     import subprocess
     import tempfile
     from collections import Counter
@@ -245,7 +246,7 @@ def reference_bowtie_baseline(bowtie_dir, sl, libs, reads, n_pass, ctx, casc, ar
         with open(fasta, "w") as fh:
             fh.write("".join(f">{q}\n{x}\n" for q, x in recs))
         t = time.perf_counter()
-        o = subprocess.run(os.path.join(bowtie_dir, "bowtie") + " " + idx[key] + argstr + str(cores) + " " + fasta, shell=True,
+        o = subprocess.run([os.path.join(bowtie_dir, "bowtie"), idx[key]] + shlex.split(argstr) + [str(cores), fasta],
                            check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
         dt = time.perf_counter() - t
         t_total += dt

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import math
 import os
+import shlex
 import subprocess
 from pathlib import Path
 from typing import Dict, Iterable, List, Optional, Sequence
@@ -54,18 +55,20 @@ class BowtieGenome:
 
     def __init__(self, args, workDir):
         self.workDir = Path(workDir)
-        cmd = str(Path(args.bowtie_path) / "bowtie ") if getattr(args, "bowtie_path", None) else "bowtie "
-        threads = str(getattr(args, "threads", 1) or 1)
-        cmd += (" --threads " + threads + " -x ") if getattr(args, "bowtieVersion", "True") == "False" else (" --threads " + threads + " ")
-        self.cmd = cmd + str(Path(args.libraries_path) / args.organism_name / "index.Libs" / (str(args.organism_name) + "_genome"))
-        self.tail = ' --phred64-quals ' if getattr(args, "phred64", False) else ''
+        # (the reference builds one string for a shell, mirge2_tRF_a2i.py:1056-1061; the same words as an argument list)
+        self.argv = [str(Path(args.bowtie_path) / "bowtie") if getattr(args, "bowtie_path", None) else "bowtie",
+                     "--threads", str(getattr(args, "threads", 1) or 1)]
+        if getattr(args, "bowtieVersion", "True") == "False":
+            self.argv.append("-x")
+        self.argv.append(str(Path(args.libraries_path) / args.organism_name / "index.Libs" / (str(args.organism_name) + "_genome")))
+        self.tail = ["--phred64-quals"] if getattr(args, "phred64", False) else []
 
     def _run(self, opts: str, seqs: Sequence[str], fname: str) -> str:
         fa = self.workDir / fname
         with open(fa, "w") as fh:
             fh.write("".join(f">{s}\n{s}\n" for s in seqs))
         try:
-            return subprocess.run(self.cmd + opts + str(fa) + self.tail, shell=True, check=True, stdout=subprocess.PIPE,
+            return subprocess.run(self.argv + shlex.split(opts) + [str(fa)] + self.tail, check=True, stdout=subprocess.PIPE,
                                   stderr=subprocess.PIPE, text=True).stdout
         finally:
             os.remove(fa)

@@ -9,6 +9,7 @@ the HIP kernels: ``mirge_cascade_run``.
 from __future__ import annotations
 
 import os
+import shlex
 import time
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence
@@ -218,8 +219,10 @@ def bwt_align_bowtie(args, pdDataFrame, workDir, ref_db):
                 recs = [(q, q) for q in un]
         with open(fasta, "w") as fh:
             fh.write("".join(f">{q}\n{x}\n" for q, x in recs))
-        cmd = bowtie + " " + str(base) + PASSES[it][2] + str(threads) + " " + str(fasta)
-        sam = subprocess.run(cmd, shell=True, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
+        # (the reference joins these into one string for a shell, manifoldAlign.py:19,97-99; the same words as an argument
+        #  list, so that a library path with a blank or a quote in it is a path and nothing else)
+        cmd = [bowtie, str(base)] + shlex.split(PASSES[it][2]) + [str(threads), str(fasta)]
+        sam = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
         hit = {}
         for ln in sam.split("\n"):                                            # :50-56
             if ln and not ln.startswith("@"):

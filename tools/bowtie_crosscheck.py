@@ -34,6 +34,7 @@ itself:
 import argparse
 import os
 import re
+import shlex
 import subprocess
 import sys
 import tempfile
@@ -124,8 +125,8 @@ def main(argv=None):
             recs = [(q, q[:re.search('T{3,}$', q).start()]) for q in un if re.search('T{3,}$', q)] if it == 3 else [(q, q) for q in un]
         with open(fasta, "w") as fh:
             fh.write("".join(f">{q}\n{x}\n" for q, x in recs))
-        cmd = bowtie + " " + os.path.join(idxdir, index_basename(args.org, key, args.db)) + argstr + str(args.threads) + " " + fasta
-        out = subprocess.run(cmd, shell=True, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
+        cmd = [bowtie, os.path.join(idxdir, index_basename(args.org, key, args.db))] + shlex.split(argstr) + [str(args.threads), fasta]
+        out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stdout
         ref_hit = {}
         for ln in out.split("\n"):
             if ln and not ln.startswith("@"):
