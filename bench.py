@@ -966,6 +966,49 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["collapsed_reads_annotation_on_host"] = {"error": repr(e)[:300]}
 
+    # ---------------- SURVEY 8(f) row N2 (never `value`): the isomiR typing of the miRTop GFF3 on the sample's miRNA reads --
+    # every read of the exact-miRNA and isomiR passes through k_isotype (the reference's per-read difflib diff + list rewriting,
+    # summary.py:204-470), records back on the host; the kernel's own time from its HIP-event bracket
+    if rank == 0 and n_gpus == 1 and args.workload in ("c3", "c5") and n_pass > ISO_PASS and hasattr(sl, "mir_hairpin"):
+        try:
+            from mirge3_amd import gff
+            mir, hp = sl.libs["mirna"], sl.libs["hairpin"]
+            mseq, hseq = mir.seqs.to_list(), hp.seqs.to_list()
+            pre_of = {nm: hp.names[int(sl.mir_hairpin[k])] for k, nm in enumerate(mir.names)}
+            tabs = gff.resolve_names(mir.names, dict(zip(mir.names, mseq)), pre_of, dict(zip(hp.names, hseq)))
+            u_g = raw.collapse()
+            res_g = casc.run(u_g)
+            ps_g = res_g.fetch()[0]
+            rows_g = np.nonzero((ps_g == EXACT_PASS) | (ps_g == ISO_PASS))[0].astype(np.int64)
+            ctx.profile(True); ctx.profile_only("k_isotype"); ctx.profile_reset()
+            best_dt = None
+            for _ in range(3):
+                ctx.sync()
+                t = time.perf_counter()
+                recs_g = gff.isomir_records(casc, u_g, res_g, tabs, rows_g)
+                dt = time.perf_counter() - t
+                best_dt = dt if best_dt is None else min(best_dt, dt)
+            k_l, k_ms = 0, 0.0
+            for name, l, ms, u in ctx.profile_records():
+                if name.startswith("k_isotype") and l:
+                    k_l, k_ms = k_l + l, k_ms + ms
+            ctx.profile(False); ctx.profile_only("")
+            k_ms_call = k_ms / 3.0
+            b = ALGO_BYTES["k_isotype"] * float(rows_g.shape[0])
+            out["gff_typing"] = {
+                "mirna_reads": int(rows_g.shape[0]), "isomir_records": int((recs_g["kind"] == 2).sum()),
+                "ms_call": round(best_dt * 1e3, 3), "M_reads_per_s_call": round(rows_g.shape[0] / best_dt / 1e6, 1),
+                "k_isotype_ms": round(k_ms_call, 4), "k_isotype_launches_per_call": round(k_l / 3.0, 1),
+                "roofline": {"bound": "hbm", "algorithmic_bytes": b, "achieved": round(b / max(k_ms_call, 1e-9) / 1e6, 2), "unit": "GB/s",
+                             "peak": HBM_PEAK_GBS, "frac": round(b / max(k_ms_call, 1e-9) / 1e6 / HBM_PEAK_GBS, 6),
+                             "bytes_per_unit": "14 in + one 336-byte record out per miRNA read"},
+                "note": "mirge_isomir_type on every read the exact-miRNA / isomiR passes annotated: slot map up, kernel, 336-byte records "
+                        "back over PCIe (ms_call, best of 3); k_isotype_ms = the kernel(s) alone by HIP events; the file itself "
+                        "(mirge_gff_write, host cores) is part of cli_path when -gff is given, not of this leg"}
+            res_g.close(); u_g.close()
+        except Exception as e:  # noqa: BLE001
+            out["gff_typing"] = {"error": repr(e)[:300]}
+
     # ---------------- PCIe-inclusive rate (never `value`): host ASCII reads in, per-read annotation + counts out
     if rank == 0:
         best_dt = None

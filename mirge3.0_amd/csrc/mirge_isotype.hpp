@@ -277,3 +277,315 @@ MIRGE_HD void mirge_isotype(const char* a, int la, const char* b, int lb, const 
     o.clen = (uint16_t)(at - o.vlen);
     o.kind = 2; o.start = start; o.end = end;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same record WITHOUT per-thread arrays (round 5).  mirge_isotype above keeps its DP rows, block lists, aligned lists and
+// text in ~2 KB of per-thread scratch: on the GPU every element is a memory access of its own and a wave spends its time
+// waiting for them (11.8 ms per 0.72 M reads).  Here everything lives in registers:
+//   * a sequence is three bit planes of its letters' codes (A C G T N = 0..4), bit p = position p;
+//   * find_longest_match walks the DIAGONALS of the comparison: a[i] == b[i + d] for all i at once is five AND / shift pairs,
+//     the longest run of ones and its first start two instructions per base of the run;
+//   * the two aligned lists are bit planes over their columns (gap / canonical code / deleted / inserted / read code); Python's
+//     `del lst[lo:hi]` is a shift of the planes' upper part;
+//   * the text goes straight to where the record lives.
+// Only the matching blocks and the work list of the recursion are indexed at run time: two small arrays behind `WS` (LDS on
+// the device, the stack on the host).  Same difflib order, same tie-breaks, same list-iterator quirks; the function above
+// stays as the general path (letters beyond ACGTN, more than 64 columns, more than MIRGE_ISO_FAST_BLOCKS blocks) and as the
+// reference the tests fuzz this one against (tests/hostsim, millions of pairs).
+#define MIRGE_ISO_FAST_BLOCKS 16
+
+namespace mirge_iso {
+
+MIRGE_HD uint64_t lowmask(int n) { return n >= 64 ? ~0ull : n <= 0 ? 0ull : ((1ull << n) - 1ull); }
+MIRGE_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
+MIRGE_HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+MIRGE_HD int clz64(uint64_t x) { return __builtin_clzll(x); }
+
+struct Seq {           // letters as code bit planes
+    uint64_t c0, c1, c2;
+    int n;
+    MIRGE_HD int code(int p) const { return (int)((c0 >> p) & 1ull) | (int)(((c1 >> p) & 1ull) << 1) | (int)(((c2 >> p) & 1ull) << 2); }
+    MIRGE_HD uint64_t letter(int c) const {  // positions holding letter c
+        const uint64_t v = lowmask(n);
+        return v & ((c & 1) ? c0 : ~c0) & ((c & 2) ? c1 : ~c1) & ((c & 4) ? c2 : ~c2);
+    }
+};
+MIRGE_HD int iso_code(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 4 : -1; }
+MIRGE_HD char iso_char(int code) { return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'T' : 'N'; }
+MIRGE_HD bool seq_of_ascii(const char* s, int n, Seq& q) {
+    q.c0 = q.c1 = q.c2 = 0; q.n = n;
+    if (n > 64) return false;
+    bool ok = true;
+    for (int p = 0; p < n; p++) {
+        const int c = iso_code(s[p]);
+        ok &= c >= 0;
+        q.c0 |= (uint64_t)(c & 1) << p; q.c1 |= (uint64_t)((c >> 1) & 1) << p; q.c2 |= (uint64_t)((c >> 2) & 1) << p;
+    }
+    return ok;
+}
+
+struct Letters { uint64_t m[5]; };  // (indexed with compile-time constants only)
+MIRGE_HD void letters_of(const Seq& q, Letters& L) {
+    L.m[0] = q.letter(0); L.m[1] = q.letter(1); L.m[2] = q.letter(2); L.m[3] = q.letter(3); L.m[4] = q.letter(4);
+}
+
+// SequenceMatcher.find_longest_match(alo, ahi, blo, bhi): the longest block, then the earliest in a, then the earliest in b
+MIRGE_HD void longest_fast(const Letters& A, const Letters& B, bool any_n, int alo, int ahi, int blo, int bhi, int& bi, int& bj, int& bk) {
+    bi = alo; bj = blo; bk = 0;
+    if (alo >= ahi || blo >= bhi) return;
+    for (int d = blo - (ahi - 1); d <= (bhi - 1) - alo; d++) {  // diagonal j = i + d
+        const int lo = alo > blo - d ? alo : blo - d, hi = ahi < bhi - d ? ahi : bhi - d;
+        uint64_t M;
+        if (d >= 0) {
+            M = (A.m[0] & (B.m[0] >> d)) | (A.m[1] & (B.m[1] >> d)) | (A.m[2] & (B.m[2] >> d)) | (A.m[3] & (B.m[3] >> d));
+            if (any_n) M |= A.m[4] & (B.m[4] >> d);
+        } else {
+            M = (A.m[0] & (B.m[0] << -d)) | (A.m[1] & (B.m[1] << -d)) | (A.m[2] & (B.m[2] << -d)) | (A.m[3] & (B.m[3] << -d));
+            if (any_n) M |= A.m[4] & (B.m[4] << -d);
+        }
+        M &= lowmask(hi) & ~lowmask(lo);
+        if (!M) continue;
+        uint64_t r = M, last;
+        int k = 0;
+        do { last = r; r &= r >> 1; k++; } while (r);  // `last`: starts of the runs of the maximal length k
+        if (k < bk) continue;
+        const int i = ctz64(last), j = i + d;
+        if (k > bk || i < bi || (i == bi && j < bj)) { bi = i; bj = j; bk = k; }
+    }
+}
+
+struct Cols {  // the two aligned lists, one bit per column
+    uint64_t gap, m0, m1, m2;       // canonical list: '-' or the canonical's letter
+    uint64_t del, ins, s0, s1, s2;  // read list: '_' deleted, '+' inserted (else equal), the read's letter
+    MIRGE_HD int mcode(int k) const { return (int)((m0 >> k) & 1ull) | (int)(((m1 >> k) & 1ull) << 1) | (int)(((m2 >> k) & 1ull) << 2); }
+    MIRGE_HD int scode(int k) const { return (int)((s0 >> k) & 1ull) | (int)(((s1 >> k) & 1ull) << 1) | (int)(((s2 >> k) & 1ull) << 2); }
+};
+MIRGE_HD uint64_t cut(uint64_t x, int lo, int w) { return (x & lowmask(lo)) | ((x >> w) & ~lowmask(lo)); }  // del x[lo:lo+w]
+MIRGE_HD void del_m_fast(Cols& L, int& nm, int lo, int hi) {
+    if (lo < 0) lo = 0;
+    if (hi > nm) hi = nm;
+    if (hi <= lo) return;
+    const int w = hi - lo;
+    L.gap = cut(L.gap, lo, w); L.m0 = cut(L.m0, lo, w); L.m1 = cut(L.m1, lo, w); L.m2 = cut(L.m2, lo, w);
+    nm -= w;
+}
+MIRGE_HD void del_s_fast(Cols& L, int& ns, int lo, int hi) {
+    if (lo < 0) lo = 0;
+    if (hi > ns) hi = ns;
+    if (hi <= lo) return;
+    const int w = hi - lo;
+    L.del = cut(L.del, lo, w); L.ins = cut(L.ins, lo, w); L.s0 = cut(L.s0, lo, w); L.s1 = cut(L.s1, lo, w); L.s2 = cut(L.s2, lo, w);
+    ns -= w;
+}
+MIRGE_HD uint64_t field(uint64_t x, int from, int w, int to) { return ((x >> from) & lowmask(w)) << to; }
+
+// merge_replacements on the planes: only '-' columns of the canonical list do anything, so the walk jumps from one to the next
+MIRGE_HD void merge_replacements_fast(Cols& L, int& nm, int& ns) {
+    for (int pass = 0; pass < 2; pass++) {
+        int y = 0;
+        for (;;) {
+            const uint64_t g = L.gap & lowmask(nm) & ~lowmask(y);
+            if (!g) break;
+            y = ctz64(g);
+            const int here = y;
+            y++;  // (the iterator moves on whatever happens to the lists)
+            if (here == 0) continue;
+            if (pass == 0) {
+                if (here - 1 >= ns) continue;
+                if (!((L.del >> (here - 1)) & 1ull)) continue;
+                bool two = false;
+                if (here - 2 > 0) {
+                    if (here - 2 >= ns) continue;
+                    if ((L.del >> (here - 2)) & 1ull) {
+                        if (here + 1 >= nm) continue;
+                        two = (L.gap >> (here + 1)) & 1ull;
+                    }
+                }
+                if (two) { del_m_fast(L, nm, here, here + 2); del_s_fast(L, ns, here - 2, here); }
+                else { del_m_fast(L, nm, here, here + 1); del_s_fast(L, ns, here - 1, here); }
+            } else {
+                if (here + 1 >= ns) continue;
+                if (!((L.del >> (here + 1)) & 1ull)) continue;
+                bool two = false;
+                if (here + 2 <= ns) {
+                    if (here + 2 >= ns) continue;
+                    if ((L.del >> (here + 2)) & 1ull) {
+                        if (here + 1 >= nm) continue;
+                        two = (L.gap >> (here + 1)) & 1ull;
+                    }
+                }
+                if (two) { del_m_fast(L, nm, here, here + 2); del_s_fast(L, ns, here, here + 2); }
+                else { del_m_fast(L, nm, here, here + 1); del_s_fast(L, ns, here + 1, here + 2); }
+            }
+        }
+    }
+}
+
+struct TextOut {  // the record's text, written where it lives
+    char* t;
+    int at;
+    char last;
+    MIRGE_HD void ch(char c) { if (at < MIRGE_ISO_TEXT - 1) { t[at++] = c; last = c; } }
+    MIRGE_HD void str(const char* s) { for (int k = 0; s[k]; k++) ch(s[k]); }
+    MIRGE_HD void num(int v) {
+        if (v < 0) { ch('-'); v = -v; }
+        int div = 1;
+        while (v / div >= 10) div *= 10;
+        for (; div > 0; div /= 10) ch((char)('0' + (v / div) % 10));
+    }
+};
+
+}  // namespace mirge_iso
+
+// WS: `uint32_t& blk(int k)`, `uint32_t& que(int k)`, k < MIRGE_ISO_FAST_BLOCKS each.  Returns false -- nothing written -- when the
+// pair is not one for this path; *kind / *start / *end / *vlen / *clen and text[] are the record's fields otherwise.
+template <class WS>
+MIRGE_HD bool mirge_isotype_fast(const mirge_iso::Seq& a, const mirge_iso::Seq& b, const char* pre, int lpre, int start0, WS& ws,
+                                 int32_t* o_start, int32_t* o_end, uint8_t* o_kind, uint16_t* o_vlen, uint16_t* o_clen, char* text) {
+    using namespace mirge_iso;
+    const int la = a.n, lb = b.n;
+    if (la > MIRGE_ISO_MAXA || lb > MIRGE_ISO_MAXB || la + lb > 64 || la < 1 || lb < 1) return false;
+    int start = start0, end = start0 + la - 1;
+    TextOut o;
+    o.t = text; o.at = 0; o.last = 0;
+    if (la == lb && a.c0 == b.c0 && a.c1 == b.c1 && a.c2 == b.c2) {
+        o.str("NA");
+        const int v = o.at;
+        o.num(lb); o.ch('M');
+        *o_kind = 1; *o_start = start; *o_end = end; *o_vlen = (uint16_t)v; *o_clen = (uint16_t)(o.at - v);
+        return true;
+    }
+    // ---- matching blocks (get_matching_blocks), the recursion as a work list
+    Letters A, B;
+    letters_of(a, A); letters_of(b, B);
+    const bool any_n = (A.m[4] | B.m[4]) != 0;
+    int nb = 0, nq = 1;
+    ws.que(0) = 0u | ((uint32_t)la << 8) | (0u << 16) | ((uint32_t)lb << 24);
+    while (nq > 0) {
+        nq--;
+        const uint32_t q = ws.que(nq);
+        const int alo = q & 255, ahi = (q >> 8) & 255, blo = (q >> 16) & 255, bhi = q >> 24;
+        int i, j, k;
+        longest_fast(A, B, any_n, alo, ahi, blo, bhi, i, j, k);
+        if (!k) continue;
+        if (nb >= MIRGE_ISO_FAST_BLOCKS || nq + 2 > MIRGE_ISO_FAST_BLOCKS) return false;
+        ws.blk(nb++) = (uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)k << 16);
+        if (alo < i && blo < j) ws.que(nq++) = (uint32_t)alo | ((uint32_t)i << 8) | ((uint32_t)blo << 16) | ((uint32_t)j << 24);
+        if (i + k < ahi && j + k < bhi) ws.que(nq++) = (uint32_t)(i + k) | ((uint32_t)ahi << 8) | ((uint32_t)(j + k) << 16) | ((uint32_t)bhi << 24);
+    }
+    for (int x = 1; x < nb; x++) {  // sort by position in the canonical (blocks never share one)
+        const uint32_t t = ws.blk(x);
+        int y = x - 1;
+        while (y >= 0 && (ws.blk(y) & 255u) > (t & 255u)) { ws.blk(y + 1) = ws.blk(y); y--; }
+        ws.blk(y + 1) = t;
+    }
+    // ---- the aligned lists, a run of columns at a time
+    Cols L;
+    L.gap = L.m0 = L.m1 = L.m2 = L.del = L.ins = L.s0 = L.s1 = L.s2 = 0;
+    int n = 0, i = 0, j = 0;
+    for (int x = 0; x <= nb; x++) {
+        const uint32_t blkv = x < nb ? ws.blk(x) : ((uint32_t)la | ((uint32_t)lb << 8));
+        const int ai = blkv & 255, bjx = (blkv >> 8) & 255, size = (blkv >> 16) & 255;
+        const int da = ai - i, db = bjx - j;
+        const bool plus_first = da > 0 && db > 0 && db < da;
+        for (int pass = 0; pass < 2; pass++) {
+            const bool plus = (pass == 0) == plus_first;
+            if (plus) {
+                if (db > 0) {
+                    L.gap |= lowmask(db) << n; L.ins |= lowmask(db) << n;
+                    L.s0 |= field(b.c0, j, db, n); L.s1 |= field(b.c1, j, db, n); L.s2 |= field(b.c2, j, db, n);
+                    n += db;
+                }
+            } else if (da > 0) {
+                L.del |= lowmask(da) << n;
+                L.m0 |= field(a.c0, i, da, n); L.m1 |= field(a.c1, i, da, n); L.m2 |= field(a.c2, i, da, n);
+                n += da;
+            }
+        }
+        if (size > 0) {
+            L.m0 |= field(a.c0, ai, size, n); L.m1 |= field(a.c1, ai, size, n); L.m2 |= field(a.c2, ai, size, n);
+            L.s0 |= field(b.c0, bjx, size, n); L.s1 |= field(b.c1, bjx, size, n); L.s2 |= field(b.c2, bjx, size, n);
+            n += size;
+        }
+        i = ai + size; j = bjx + size;
+    }
+    int nm = n, ns = n;
+    merge_replacements_fast(L, nm, ns);
+    if (ns < nm) { *o_kind = 0; *o_start = 0; *o_end = 0; *o_vlen = 0; *o_clen = 0; return true; }
+    const uint64_t valid = lowmask(nm);
+    const uint64_t gap = L.gap & valid, del = L.del & valid;
+    // ---- ends: the leading / trailing columns that are '-' in the canonical list or deleted in the read list
+    const uint64_t body = ~(gap | del) & valid;
+    const int lead = body ? ctz64(body) : nm;
+    const int tail0 = body ? 64 - clz64(body) : 0;  // first column of the trailing run
+    const uint64_t lead_m = lowmask(lead), tail_m = valid & ~lowmask(tail0);
+    const int n5 = popc64(gap & lead_m), d5 = popc64(del & ~gap & lead_m);
+    const int n3 = popc64(gap & tail_m), d3 = popc64(del & ~gap & tail_m);
+    if (n5) {
+        int lo, hi;
+        py_slice(lpre, start - n5 - 1, start - 1, lo, hi);
+        if (hi - lo < n5) { o.str("iso_5p:-"); o.num(n5); o.ch(','); }
+        else {
+            int t = 0, idx = 0;
+            for (uint64_t g = gap & lead_m; g; g &= g - 1, idx++) {
+                const int k = ctz64(g);
+                if (!((del >> k) & 1ull)) t += iso_char(L.scode(k)) == pre[lo + idx];
+            }
+            if (t) { o.str("iso_5p:+"); o.num(t); o.ch(','); }
+            if (n5 - t) { o.str("iso_add5p:+"); o.num(n5 - t); o.ch(','); }
+        }
+        start -= n5;
+    }
+    if (d5) { o.str("iso_5p:+"); o.num(d5); o.ch(','); start += d5; }
+    if (n3) {
+        int lo, hi;
+        py_slice(lpre, end, end + n3, lo, hi);
+        if (hi - lo < n3) { o.str("iso_3p:+"); o.num(n3); o.ch(','); }
+        else {
+            int t = 0, idx = 0;
+            for (uint64_t g = gap & tail_m; g; g &= g - 1, idx++) {
+                const int k = ctz64(g);
+                if (!((del >> k) & 1ull)) t += iso_char(L.scode(k)) == pre[lo + idx];
+            }
+            if (t) { o.str("iso_3p:+"); o.num(t); o.ch(','); }
+            if (n3 - t) { o.str("iso_add3p:+"); o.num(n3 - t); o.ch(','); }
+        }
+        end += n3;
+    }
+    if (d3) { o.str("iso_3p:-"); o.num(d3); o.ch(','); end -= d3; }
+    // ---- substitutions: a column with a letter on both sides that is not an equal pair
+    const uint64_t differ = (L.m0 ^ L.s0) | (L.m1 ^ L.s1) | (L.m2 ^ L.s2);
+    const uint64_t sub = ~gap & ~del & valid & (L.ins | differ);
+    bool seen[5] = {false, false, false, false, false};
+    for (uint64_t g = sub; g; g &= g - 1) {
+        const int k = ctz64(g);
+        const int c = k == 7 ? 0 : (k >= 1 && k <= 6) ? 1 : (k >= 8 && k <= 12) ? 2 : (k >= 13 && k <= 17) ? 3 : 4;
+        const bool was = c == 0 ? seen[0] : c == 1 ? seen[1] : c == 2 ? seen[2] : c == 3 ? seen[3] : seen[4];
+        if (was) continue;
+        if (c == 0) seen[0] = true; else if (c == 1) seen[1] = true; else if (c == 2) seen[2] = true; else if (c == 3) seen[3] = true; else seen[4] = true;
+        o.str(c == 0 ? "iso_snv_central_offset," : c == 1 ? "iso_snv_seed," : c == 2 ? "iso_snv_central," : c == 3 ? "iso_snv_central_supp," : "iso_snv,");
+    }
+    if (o.at > 0 && o.last == ',') o.at--;
+    if (o.at == 0) o.str("iso_snv");
+    const int vlen = o.at;
+    // ---- CIGAR: 'M' for every column that is no substitution, the canonical's letter for one
+    const uint64_t any_base = sub & ~L.m2;  // (a substituted 'N' of the canonical prints as N and does not count, as in :427-463)
+    if (!any_base) { o.num(lb); o.ch('M'); }
+    else {
+        int run = 0;
+        char prev = 0;
+        for (int k = 0; k < nm; k++) {
+            const char cs = ((sub >> k) & 1ull) ? iso_char(L.mcode(k)) : 'M';
+            if (k != 0 && cs != prev) {
+                if (run != 1) o.num(run);
+                o.ch(prev);
+                run = 1;
+            } else run++;
+            prev = cs;
+        }
+        if (run != 1) o.num(run);
+        if (nm > 0) o.ch(prev);
+    }
+    *o_kind = 2; *o_start = start; *o_end = end; *o_vlen = (uint16_t)vlen; *o_clen = (uint16_t)(o.at - vlen);
+    return true;
+}

@@ -51,6 +51,8 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
     IsoTables tb;
     tb.master_of_ref = d_mof; tb.master = d_m; tb.master_off = d_moff; tb.pre_of_master = d_pom; tb.start0 = d_s0;
     tb.pre = d_p; tb.pre_off = d_poff;
+    // MIRGE_ISO_FAST=0: every read through the array form of the typing (the tests' second implementation on the device, A/B)
+    static const int32_t iso_fast = !(std::getenv("MIRGE_ISO_FAST") && std::atoi(std::getenv("MIRGE_ISO_FAST")) == 0);
     std::vector<uint32_t*> lists;  // the groups' row lists, released behind the synchronisation below
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
         const ResGroup& g = res->g[gi];
@@ -72,10 +74,10 @@ extern "C" int mirge_isomir_type(mirge_ctx* c, const mirge_reads* U, const mirge
         LaunchScope ls(c, "k_isotype", g.n);
         if (kGroupW[gi] == 1)
             hipLaunchKernelGGL(k_isotype<1>, dim3(tgrid), dim3(64), 0, c->stream, view_of<1>(rg), rg.base, (const uint32_t*)rg.orig,
-                               g.ref, tb, d_slot, d_out, (const uint32_t*)dlist, (const uint32_t*)dnlist, chunk);
+                               g.ref, tb, d_slot, d_out, (const uint32_t*)dlist, (const uint32_t*)dnlist, chunk, iso_fast);
         else
             hipLaunchKernelGGL(k_isotype<2>, dim3(tgrid), dim3(64), 0, c->stream, view_of<2>(rg), rg.base, (const uint32_t*)rg.orig,
-                               g.ref, tb, d_slot, d_out, (const uint32_t*)dlist, (const uint32_t*)dnlist, chunk);
+                               g.ref, tb, d_slot, d_out, (const uint32_t*)dlist, (const uint32_t*)dnlist, chunk, iso_fast);
     }
     if (n_rows) HIPOK(hipMemcpyAsync(records_out, d_out, (size_t)n_rows * sizeof(MirgeIsoRec), hipMemcpyDeviceToHost, c->stream));
     HIPOK(hipStreamSynchronize(c->stream));

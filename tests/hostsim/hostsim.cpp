@@ -146,3 +146,95 @@ extern "C" int hostsim_isotype(const char* a, int32_t la, const char* b, int32_t
     cigar[r.clen] = 0;
     return 0;
 }
+
+// the register-resident form of the same record (mirge_isotype_fast): -2 when the pair is not one for that path
+struct HostWs {
+    uint32_t b[MIRGE_ISO_FAST_BLOCKS], q[MIRGE_ISO_FAST_BLOCKS];
+    uint32_t& blk(int k) { return b[k]; }
+    uint32_t& que(int k) { return q[k]; }
+};
+static int isotype_fast_rec(const char* a, int32_t la, const char* b, int32_t lb, const char* pre, int32_t lpre, int32_t start0, MirgeIsoRec& r) {
+    mirge_iso::Seq sa, sb;
+    if (la > MIRGE_ISO_MAXA || lb > MIRGE_ISO_MAXB) return -1;
+    if (!mirge_iso::seq_of_ascii(a, la, sa) || !mirge_iso::seq_of_ascii(b, lb, sb)) return -2;
+    HostWs ws;
+    r.kind = 0; r.vlen = r.clen = 0; r.start = r.end = 0;
+    return mirge_isotype_fast(sa, sb, pre, lpre, start0, ws, &r.start, &r.end, &r.kind, &r.vlen, &r.clen, r.text) ? 0 : -2;
+}
+extern "C" int hostsim_isotype_fast(const char* a, int32_t la, const char* b, int32_t lb, const char* pre, int32_t lpre, int32_t start0,
+                                    int32_t* kind, int32_t* start, int32_t* end, char* variant, char* cigar) {
+    MirgeIsoRec r;
+    const int rc = isotype_fast_rec(a, la, b, lb, pre, lpre, start0, r);
+    if (rc) return rc;
+    *kind = r.kind; *start = r.start; *end = r.end;
+    for (int k = 0; k < r.vlen; k++) variant[k] = r.text[k];
+    variant[r.vlen] = 0;
+    for (int k = 0; k < r.clen; k++) cigar[k] = r.text[r.vlen + k];
+    cigar[r.clen] = 0;
+    return 0;
+}
+// n random pairs through both forms: reads made from the canonical by shifts, templated and untemplated extensions, substitutions,
+// N calls, short indels, homopolymer runs, plus unrelated reads; precursors with the canonical at the start, the end, absent, empty.
+// Returns the number of pairs the fast form took; *bad = pairs on which a field differed (first one copied out).
+extern "C" int64_t hostsim_isotype_fuzz(uint64_t seed, int64_t n, int64_t* bad, char* first_a, char* first_b, char* first_pre) {
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    auto below = [&](int m) { return (int)(rnd() % (uint64_t)m); };
+    int64_t took = 0;
+    *bad = 0;
+    char a[80], b[160], pre[200], src[200];
+    for (int64_t it = 0; it < n; it++) {
+        const int la = 14 + below(20);
+        for (int k = 0; k < la; k++) a[k] = "ACGT"[below(4)];
+        if (it % 9 == 0 && la > 12) for (int k = 6; k < 10; k++) a[k] = a[5];
+        if (it % 31 == 0) { const int per = 2 + below(2); for (int k = per; k < la; k++) a[k] = a[k - per]; }  // short tandem repeats
+        if (it % 977 == 0) a[below(la)] = 'N';
+        const int mode = (int)(it % 7);
+        const int nl = mode != 1 ? below(12) : 0, nt = mode != 2 ? below(12) : 0;
+        int ls = 0;
+        for (int k = 0; k < nl; k++) src[ls++] = "ACGT"[below(4)];
+        const int o = ls;
+        for (int k = 0; k < la; k++) src[ls++] = a[k];
+        for (int k = 0; k < nt; k++) src[ls++] = "ACGT"[below(4)];
+        int lpre = 0;
+        if (mode == 3) lpre = 0;
+        else if (mode == 4) { for (int k = 0; k < nl; k++) pre[lpre++] = src[k]; for (int k = 0; k < nt; k++) pre[lpre++] = src[o + la + k]; }
+        else { for (int k = 0; k < ls; k++) pre[lpre++] = src[k]; }
+        int start0 = 1;
+        if (lpre > 0) {  // precursor.find(canonical) + 1
+            int f = -1;
+            for (int p = 0; p + la <= lpre && f < 0; p++) { bool eq = true; for (int k = 0; k < la && eq; k++) eq = pre[p + k] == a[k]; if (eq) f = p; }
+            start0 = f + 1;
+        }
+        const int d5 = below(7) - 3, d3 = below(9) - 4;
+        int lb = 0;
+        const bool t5 = below(10) < 6, t3 = below(10) < 6;
+        for (int k = 0; k < -d5; k++) { const int p = o + d5 + k; b[lb++] = (t5 && p >= 0) ? src[p] : "ACGT"[below(4)]; }
+        for (int k = (d5 > 0 ? d5 : 0); k < la + (d3 < 0 ? d3 : 0); k++) b[lb++] = a[k];
+        for (int k = 0; k < d3; k++) { const int p = o + la + k; b[lb++] = (t3 && p < ls) ? src[p] : "ACGT"[below(4)]; }
+        const int nmut = (int)("\0\0\1\1\2\3"[below(6)]);
+        for (int m = 0; m < nmut && lb > 0; m++) b[below(lb)] = "ACGTN"[below(5)];
+        if (it % 13 == 0 && lb > 8) { const int p = 1 + below(lb - 2); for (int k = p; k + 1 < lb; k++) b[k] = b[k + 1]; lb--; }          // a deleted base
+        if (it % 17 == 0 && lb > 8 && lb < 60) { const int p = 1 + below(lb - 1); for (int k = lb; k > p; k--) b[k] = b[k - 1]; b[p] = "ACGT"[below(4)]; lb++; }  // an inserted one
+        if (it % 50 == 0) { lb = 14 + below(17); for (int k = 0; k < lb; k++) b[k] = "ACGT"[below(4)]; }
+        if (lb < 1) continue;
+        MirgeIsoRec r0, r1;
+        r0.kind = 0; r0.vlen = r0.clen = 0; r0.start = r0.end = 0;
+        mirge_isotype(a, la, b, lb, pre, lpre, start0, r0);
+        const int rc = isotype_fast_rec(a, la, b, lb, pre, lpre, start0, r1);
+        if (rc == -2) continue;
+        took++;
+        bool same = rc == 0 && r0.kind == r1.kind && r0.vlen == r1.vlen && r0.clen == r1.clen;
+        if (same && r0.kind) same = r0.start == r1.start && r0.end == r1.end;
+        for (int k = 0; same && k < r0.vlen + r0.clen; k++) same = r0.text[k] == r1.text[k];
+        if (!same) {
+            if (!*bad) {
+                std::memcpy(first_a, a, la); first_a[la] = 0;
+                std::memcpy(first_b, b, lb); first_b[lb] = 0;
+                std::memcpy(first_pre, pre, lpre); first_pre[lpre] = 0;
+            }
+            ++*bad;
+        }
+    }
+    return took;
+}

@@ -54,5 +54,10 @@ int main() {
     long hits = 0; unsigned long long sum = 0;
     for (int64_t i = 0; i < n; i++) if (ps[i] >= 0) { hits++; sum += (unsigned long long)ps[i] * 131 + (unsigned)ref[i] * 7 + (unsigned)off[i]; }
     std::printf("rc=%d reads=%ld annotated=%ld checksum=%llu\n", rc, (long)n, hits, sum);
-    return rc;
+    // the isomiR typing, both forms (mirge_isotype on arrays, mirge_isotype_fast on bit planes: shifts by run-time amounts)
+    int64_t bad = 0;
+    char fa[100], fb[200], fp[300];
+    const int64_t took = hostsim_isotype_fuzz(7, 150000, &bad, fa, fb, fp);
+    std::printf("isotype pairs=%ld differing=%ld\n", (long)took, (long)bad);
+    return rc ? rc : (bad != 0 || took < 100000);
 }

@@ -901,6 +901,9 @@ def test_bench_single_gpu_line(tmp_path):
     ca = d["collapsed_reads_annotation_on_host"]  # SURVEY 8(d)'s "collapsed reads/s" as written: annotation + tables back on the host
     assert ca["unique_reads"] == U and ca["M_collapsed_reads_per_s"] > 0 and 0 < ca["annotated"] <= U
     assert abs(ca["M_collapsed_reads_per_s"] - U / (ca["ms"] * 1e-3) / 1e6) < 0.02 * ca["M_collapsed_reads_per_s"] + 0.1
+    gt = d["gff_typing"]  # row N2 measured: every miRNA read of the sample through k_isotype
+    assert 0 < gt["isomir_records"] <= gt["mirna_reads"] <= ca["annotated"] and gt["k_isotype_ms"] > 0 and gt["ms_call"] >= gt["k_isotype_ms"]
+    assert gt["roofline"]["algorithmic_bytes"] == 350 * gt["mirna_reads"] and 0 < gt["roofline"]["frac"] < 1
     rs = d["read_sets"]
     assert rs["default_draw"]["ms_per_step"] == d["ms_per_step"] and rs["distinct"]["U_over_N"] == 1.0
     assert rs["zipf_pool"]["U_over_N"] < rs["default_draw"]["U_over_N"] < 1.0 and rs["zipf_pool"]["raw_reads"] == N
@@ -1818,6 +1821,49 @@ def test_a2i_report_equals_the_reference_files(tmp_path, case_name):
             assert t["census"][f, q - 1, 0, 2, 2, s] == c
         checked += 1
     assert checked >= 20
+
+
+def test_isotype_register_form_equals_the_array_form_on_the_device(tmp_path):
+    """k_isotype types a read in registers (mirge_isotype_fast) and keeps the form on per-thread arrays for the pairs that one
+    cannot take; MIRGE_ISO_FAST=0 sends every read through the arrays.  Both on the same 150 k-read sample (reads of both
+    width classes, N calls), in fresh processes: the record arrays are equal byte for byte, and most reads are isomiRs."""
+    import subprocess
+    import sys
+    ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "import mirge3_amd\n"
+        "from mirge3_amd import _ffi, synth, gff\n"
+        "from mirge3_amd.cascade import Cascade\n"
+        "sl = synth.make_libraries(seed=20260101, scale='small')\n"
+        "ctx = _ffi.Context(0)\n"
+        "casc = Cascade(ctx, sl.libs)\n"
+        "reads = synth.make_reads(sl, 150000, seed=5, mix=dict(exact=0.25, isomir=0.55, hairpin=0.1, random=0.1), n_frac=0.02)\n"
+        "uniq = _ffi.DeviceReads.pack(ctx, reads).collapse()\n"
+        "res = casc.run(uniq)\n"
+        "ps = res.fetch()[0]\n"
+        "mir, hp = sl.libs['mirna'], sl.libs['hairpin']\n"
+        "mseq, hseq = mir.seqs.to_list(), hp.seqs.to_list()\n"
+        "pre_of = {nm: hp.names[int(sl.mir_hairpin[k])] for k, nm in enumerate(mir.names)}\n"
+        "tabs = gff.resolve_names(mir.names, dict(zip(mir.names, mseq)), pre_of, dict(zip(hp.names, hseq)))\n"
+        "rows = np.nonzero((ps == 0) | (ps == 8))[0].astype(np.int64)\n"
+        "seqs = uniq.unpack().to_list()\n"
+        "rows = np.array(sorted(rows.tolist(), key=lambda i: seqs[i]), dtype=np.int64)  # (the collapse's output order is not the same in two runs)\n"
+        "recs = gff.isomir_records(casc, uniq, res, tabs, rows)\n"
+        "np.save(sys.argv[1], recs.view(np.uint8).reshape(len(recs), -1))\n"
+        "print('rows', len(rows), 'isomirs', int((recs['kind'] == 2).sum()))\n") % ROOT
+    outs = []
+    for fast in ("1", "0"):
+        f = str(tmp_path / f"recs{fast}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MIRGE_ISO_FAST=fast), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "rows" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+        outs.append((np.load(f), r.stdout))
+    a, b = outs[0][0], outs[1][0]
+    assert a.shape == b.shape and a.shape[0] > 3000 and a.shape[1] == 336
+    bad = np.nonzero((a != b).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], bytes(a[bad[0]]), bytes(b[bad[0]]))
+    assert int(outs[0][1].split("isomirs")[1]) > a.shape[0] // 3
 
 
 @pytest.mark.parametrize("case_name", GFF_A2I_CASES)

@@ -163,15 +163,16 @@ def test_probe_plan_covers_every_mismatch_placement():
 
 
 def test_core_arithmetic_is_asan_ubsan_clean(tmp_path):
-    """mirge_core.hpp / mirge_libbuild.hpp under AddressSanitizer + UBSan on the CPU build (the GPU
+    """mirge_core.hpp / mirge_libbuild.hpp / mirge_isotype.hpp under AddressSanitizer + UBSan on the CPU build (the GPU
     pool has no device sanitizer): random libraries with reference Ns, reads of 1..128 nt with Ns,
-    T tails and mismatches, all nine policies."""
+    T tails and mismatches, all nine policies; the isomiR typing's two forms on 150 k pairs."""
     exe = str(tmp_path / "sanitize")
     subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17",
                            "-Wno-unknown-pragmas", os.path.join(HERE, "hostsim", "sanitize_main.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "rc=0" in r.stdout and "annotated=" in r.stdout
+    assert "differing=0" in r.stdout  # mirge_isotype.hpp, both forms of the isomiR typing, 150 k pairs under the sanitizers
 
 
 def test_pure_host_functions_are_asan_ubsan_clean(tmp_path):
@@ -202,20 +203,27 @@ def test_gz_inflater_survives_damaged_files(tmp_path):
     assert " 0 inflated in parallel" not in r.stdout  # the undamaged mutants took the parallel route
 
 
-def hostsim_isotype(master: str, read: str, precursor: str):
+def hostsim_isotype(master: str, read: str, precursor: str, form: str = "arrays"):
+    """``form``: "arrays" = mirge_isotype (per-thread arrays, the general path), "registers" = mirge_isotype_fast (bit planes;
+    what k_isotype runs for every pair it can take) -- None when the pair is not one for that form"""
     so = _sim()
     kind, start, end = C.c_int32(), C.c_int32(), C.c_int32()
     var, cig = C.create_string_buffer(400), C.create_string_buffer(400)
     start0 = (precursor.find(master) + 1) if precursor != "" else 1
-    rc = so.hostsim_isotype(master.encode(), len(master), read.encode(), len(read), precursor.encode(), len(precursor), start0,
-                            C.byref(kind), C.byref(start), C.byref(end), var, cig)
+    fn = so.hostsim_isotype if form == "arrays" else so.hostsim_isotype_fast
+    rc = fn(master.encode(), len(master), read.encode(), len(read), precursor.encode(), len(precursor), start0,
+            C.byref(kind), C.byref(start), C.byref(end), var, cig)
+    if form == "registers" and rc == -2:
+        return None
     assert rc == 0
     return ({0: "none", 1: "ref_miRNA", 2: "isomiR"}[kind.value], start.value, end.value, var.value.decode(), cig.value.decode())
 
 
+@pytest.mark.parametrize("form", ["arrays", "registers"])
 @pytest.mark.parametrize("case_name", ["case4_gff_a2i", "case6_gff_a2i"])
-def test_isotype_core_equals_the_oracle_on_the_reference_lines(case_name):
-    """every line of the GFF the reference wrote (golden cases 4 and 6), through the header k_isotype is compiled from"""
+def test_isotype_core_equals_the_oracle_on_the_reference_lines(case_name, form):
+    """every line of the GFF the reference wrote (golden cases 4 and 6), through the header k_isotype is compiled from -- both
+    forms of the typing: the one on per-thread arrays and the register-resident one the kernel prefers"""
     from test_a2i_gff_oracle import _case4_gff_tables
     case, mat, pre, pre_of = _case4_gff_tables(case_name)
     n = 0
@@ -224,7 +232,7 @@ def test_isotype_core_equals_the_oracle_on_the_reference_lines(case_name):
             continue
         f = ln.rstrip("\n").split("\t")
         attrs = dict(x.split("=", 1) for x in f[8].split("; "))
-        got = hostsim_isotype(mat[f[0]], attrs["Read"], pre[pre_of[f[0]]])
+        got = hostsim_isotype(mat[f[0]], attrs["Read"], pre[pre_of[f[0]]], form)
         assert got == (f[2], int(f[3]), int(f[4]), attrs["Variant"], attrs["Cigar"]), (f[0], mat[f[0]], attrs["Read"])
         n += 1
     assert n > 650
@@ -264,6 +272,25 @@ def test_isotype_core_equals_the_oracle_on_random_pairs():
         want = oracle.gff_record(master, read, precursor)
         got = hostsim_isotype(master, read, precursor)
         assert got == want, (master, read, precursor, got, want)
+        fast = hostsim_isotype(master, read, precursor, "registers")
+        assert fast == want, (master, read, precursor, fast, want)  # (every pair here is one the register form takes)
         shapes.add(want[3].split(":")[0].split(",")[0])
         n += 1
     assert n > 5000 and len(shapes) >= 8
+
+
+def test_isotype_register_form_equals_the_array_form_on_millions_of_pairs():
+    """k_isotype's register-resident typing (mirge_isotype_fast: sequences and the aligned lists as bit planes, difflib's longest
+    match along diagonals) against the array form it replaced on the hot path, field for field, on 3 M pairs made in C++: shifted,
+    extended (templated or not), substituted, N-called, single-base indel, homopolymer, tandem-repeat and unrelated reads; the
+    canonical at the start / end of the precursor, absent from it, empty precursor."""
+    so = _sim()
+    so.hostsim_isotype_fuzz.restype = C.c_int64
+    so.hostsim_isotype_fuzz.argtypes = [C.c_uint64, C.c_int64, C.POINTER(C.c_int64), C.c_char_p, C.c_char_p, C.c_char_p]
+    bad = C.c_int64()
+    a, b, p = C.create_string_buffer(100), C.create_string_buffer(200), C.create_string_buffer(300)
+    for seed in (101, 202, 303):
+        took = so.hostsim_isotype_fuzz(seed, 1_000_000, C.byref(bad), a, b, p)
+        assert bad.value == 0, (seed, bad.value, a.value, b.value, p.value)
+        assert took > 900_000  # (the rest: more than 64 columns)
+
