@@ -521,6 +521,8 @@ def main():
     ap.add_argument("--two-calls", type=int, default=0, help="1: mirge_collapse then mirge_cascade_run instead of the one-call path")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
+    ap.add_argument("--long-frac", dest="long_frac", type=float, default=None,
+                    help="share of the sample drawn as 32-50-nt reads (synth default 0.05); a side measurement, labelled in config.workload")
     ap.add_argument("--pool", type=int, default=0,
                     help="draw the reads from this many templates with Zipf weights (SURVEY 8d 'realistic' U/N); 0 = independent draws")
     ap.add_argument("--cli-path", type=int, default=1, help="rank 0, N=1: also time the CLI's route from a FASTQ file on disk to all CSVs")
@@ -615,7 +617,7 @@ def main():
     if args.pool:
         reads = synth.make_reads(sl, args.reads, seed=1000 + rank, pool=args.pool)
     else:
-        reads = synth.make_reads_chunked(sl, args.reads, seed=1000 + rank)  # one sample per rank
+        reads = synth.make_reads_chunked(sl, args.reads, seed=1000 + rank, **({} if args.long_frac is None else {"long_frac": args.long_frac}))  # one sample per rank
     raw = _ffi.DeviceReads.pack(ctx, reads)
     n_mirna = len(sl.libs["mirna"])
     t_setup = time.perf_counter() - t_setup
@@ -758,7 +760,7 @@ def main():
                          "c5": f"C5: {args.reads / 1e6:g}M reads, collapse -> exact + <=2-mismatch isomiR passes vs the miRNA library -> count join -> "
                                "per-position variant tally"}[args.workload],
             "raw_reads_per_gpu": args.reads, "unique_reads_per_gpu": U, "library_scale": args.scale,
-            "read_templates": args.pool or None,
+            "read_templates": args.pool or None, "long_read_share": args.long_frac,
             "library_bases": {k: v.total_len for k, v in libs.items()}, "passes": n_pass,
             "sharding": f"{n_gpus} sample(s), one per GPU, no collective",
         },

@@ -102,16 +102,33 @@ MIRGE_HD int mirge_popc(uint64_t x) {
 #endif
 }
 
+#ifndef MIRGE_WIDE_SELECT
+#define MIRGE_WIDE_SELECT 1  // 0: the words of a wide read indexed at run time, as rounds 1-4 (A/B)
+#endif
 // bases [a, a+k) of a packed sequence as an integer (k <= 32), little-endian
 template <int W>
 MIRGE_HD uint64_t mirge_extract(const uint64_t* w, int a, int k) {
     // (one word: no run-time index into the read -- an index the compiler cannot fold keeps the read's words out of registers;
     // in a kernel that meant a 24-byte-per-thread copy of the read in LDS, 6 KiB per workgroup)
     if (W == 1) return (w[0] >> ((a & 31) * 2)) & mirge_lowmask2(k);
-    int q = a >> 5, s = (a & 31) * 2;
+    // (wider reads, same reason: the two words are SELECTED, one compare per word, instead of indexed -- the index had kept a
+    // 24 W-byte copy of the read in per-thread scratch in every kernel of the 32-255-nt groups)
+    const int q = a >> 5, s = (a & 31) * 2;
+#if MIRGE_WIDE_SELECT
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        lo = i == q ? w[i] : lo;
+        hi = i == q + 1 ? w[i] : hi;
+    }
+    uint64_t v = lo >> s;
+    if (s != 0) v |= hi << (64 - s);
+    return v & mirge_lowmask2(k);
+#else
     uint64_t lo = w[q] >> s;
     if (W > 1 && s != 0 && q + 1 < W) lo |= w[q + 1] << (64 - s);
     return lo & mirge_lowmask2(k);
+#endif
 }
 
 // drop `n5` bases at the 5' end (n5 < 32) and keep `newlen` bases
@@ -150,6 +167,7 @@ MIRGE_HD int mirge_t_run(const MirgeRead<W>& r) {
         const int run1 = lead >> 1;
         return run1 < r.len ? run1 : r.len;
     }
+#if !MIRGE_WIDE_SELECT
     int run = 0;
     for (int j = r.len - 1; j >= 0; j--) {
         uint64_t b = (r.w[j >> 5] >> (2 * (j & 31))) & 3ull;
@@ -158,6 +176,18 @@ MIRGE_HD int mirge_t_run(const MirgeRead<W>& r) {
         run++;
     }
     return run;
+#endif
+    // wider reads: the last base that is no T (or is an ambiguous call), word by word with compile-time indices
+    int last_other = -1;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const int nv = r.len - 32 * i;
+        const uint64_t valid = (nv <= 0 ? 0ull : mirge_lowmask2(nv < 32 ? nv : 32)) & 0x5555555555555555ull;
+        const uint64_t x = r.w[i];
+        const uint64_t other = ~(x & (x >> 1) & ~r.nm[i]) & valid;  // bit 2j: base 32 i + j is not a T
+        if (other) last_other = 32 * i + ((63 - (int)__builtin_clzll(other)) >> 1);
+    }
+    return r.len - 1 - last_other;
 }
 
 // What bowtie is handed for this read under this policy.  false: the read is not in the
