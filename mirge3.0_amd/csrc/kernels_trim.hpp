@@ -129,12 +129,87 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
     return found ? b_val : (FRONT ? 0 : n);
 }
 
+// The same search with the adapter's kind and number as RUN-TIME (wave-uniform) values: the general 3' instance of k_trim calls it from
+// its linked / best-of-two / repeated branches.  Seven inlined compile-time variants of the function above, each with its own DP
+// column, had left that instance with 139-1101 spilled registers; this is one body.
+template <int MAXM>
+__device__ __forceinline__ int adapter_cut_point_rt(const TrimOpts& o, const uint8_t* __restrict__ read, int n, const bool FRONT, const int WHICH, int* hit) {
+    constexpr bool EXACT = false;
+    const uint8_t* const o_adapter = WHICH ? o.adapter2 : o.adapter;
+    const uint8_t* const o_wild = WHICH ? o.wild2 : o.wild;
+    const int m = EXACT ? MAXM : (WHICH ? o.alen2 : o.alen);
+    // anchored (general kernel): FRONT = PrefixAdapter (flags STOP_WITHIN_SEQ2 alone: read and adapter both start at their
+    // first base, first row and column cost their index, candidates stay the last row's cells); back = SuffixAdapter
+    // (START_WITHIN_SEQ2 alone: the one candidate is the whole adapter ending at the read's last base)
+    const bool anch = !EXACT && (WHICH ? o.anch2 : o.anch) != 0;
+    uint32_t e[MAXM + 1];
+    uint8_t nw[MAXM + 1];
+    nw[0] = 0;
+    // --no-indels (general kernel): the two indel candidates of a cell are raised above every diagonal one, and a 3' adapter
+    // cannot lose bases in front of the read: rows of the first column start at cost 128 (never accepted, and 128 + 64
+    // mismatches still fit the entry's 8 cost bits)
+    const uint32_t no_indel_or = (!EXACT && o.no_indels) ? 0xFF000000u : 0u;
+#pragma unroll
+    for (int i = 0; i <= MAXM; i++) {
+        e[i] = (FRONT && !anch) ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i
+                                : (((no_indel_or && i ? 128u : (uint32_t)i) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
+        if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o_wild[i - 1] : 0));
+    }
+    int b_mat = -1, b_cost = 0, b_val = 0;
+    bool found = false, exact = false;
+    // i: adapter rows the entry has passed; j: read column it ends in (FRONT only)
+    auto consider = [&](uint32_t ent, int i, int j) {
+        const int cost = (int)(ent >> MIRGE_TRIM_COST_SHIFT), mat = (int)((ent >> 15) & 0x7F);
+        const int origin = (int)(ent & 0x7FFF) - (int)MIRGE_TRIM_ORIGIN_BIAS;
+        const int length = FRONT ? i + (origin < 0 ? origin : 0) : i;
+        if (length >= o.min_overlap && (double)cost <= (double)(length - (FRONT ? 0 : nw[i])) * o.rate &&
+            (!found || mat > b_mat || (mat == b_mat && cost < b_cost))) {
+            found = true; b_mat = mat; b_cost = cost; b_val = FRONT ? j : origin;
+        }
+    };
+    for (int j = 1; j <= n && !exact; j++) {
+        const uint8_t ch = read[j - 1] & 0xDF;
+        uint32_t diag = e[0];
+        e[0] = (uint32_t)j + MIRGE_TRIM_ORIGIN_BIAS;  // cost 0, matches 0, origin j
+        // (anchored 5': j read bases in front of the adapter cost j -- saturated at 128, beyond every budget and within the
+        // entry's 8 cost bits with the <= 64 a column can add --, origin 0)
+        if (FRONT && anch) e[0] = ((no_indel_or ? 128u : (uint32_t)(j < 128 ? j : 128)) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS;
+        uint32_t last = e[0];
+#pragma unroll
+        for (int i = 1; i <= MAXM; i++) {
+            if (EXACT || i <= m) {
+                const uint32_t left = e[i];  // previous column, same row
+                const uint32_t best3 = EXACT ? min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22))
+                                             : min(min(diag, e[i - 1] | (1u << 22) | no_indel_or), left | (2u << 22) | no_indel_or);
+                const uint32_t miss = (best3 & ~MIRGE_TRIM_CHOICE_MASK) + (1u << MIRGE_TRIM_COST_SHIFT);
+                const bool same = EXACT ? o_adapter[i - 1] == ch : (o_wild[i - 1] || o_adapter[i - 1] == ch || (o.read_wild && ch == 'N'));
+                const uint32_t v = same ? diag + MIRGE_TRIM_MATCH_ONE : miss;
+                diag = left;
+                e[i] = v;
+                if (EXACT ? i == MAXM : i == m) last = v;
+            }
+        }
+        if (FRONT || !anch || j == n) consider(last, m, j);
+        exact = found && b_cost == 0 && b_mat == m;
+    }
+    if (!exact && !FRONT && !anch) {  // the adapter may run off the read's end: every prefix of it, in the last column, longest first
+#pragma unroll                // (cutadapt: `for i in reversed(range(first_i, m + 1))` -- on equal (matches, cost) the longer prefix stays)
+        for (int i = MAXM; i >= 0; i--)
+            if (EXACT || i <= m) consider(e[i], i, n);
+    }
+    if (hit) { hit[0] = found ? 1 : 0; hit[1] = b_mat; hit[2] = b_cost; }
+    return found ? b_val : (FRONT ? 0 : n);
+}
+
 // lstart/lend: the sequence line of every record (after '\r' stripping here); qstart/qend: its quality line (FASTQ) or null.
 // vstart/vend[r * stages_out + s]: the read after modifier s (stages_out == n_mods) or after the last one.
 // flags[5] |= 1: a record whose quality line is not as long as its sequence line (dnaio raises on it; here q[i] would
 // otherwise be taken from the next record's bytes).
+// (registers: the launch is MIRGE_BLOCK threads; the general 3' instance -- four inlined DP variants -- and the exact instances of
+//  more than 40 rows may take up to 256 registers (two waves per SIMD): a DP column in scratch costs 8 x the kernel's time)
 template <int MAXM, bool EXACT, bool FRONT>
-__global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, const int64_t* __restrict__ lend,
+__global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu((!EXACT && !FRONT) || MAXM > 40 ? 2 : 4, 8)))
+k_trim(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, const int64_t* __restrict__ lend,
                        const int64_t* __restrict__ qstart, const int64_t* __restrict__ qend, uint32_t n_seq, TrimOpts o,
                        int64_t* __restrict__ vstart, int64_t* __restrict__ vend, uint32_t* __restrict__ flags) {
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_seq; r += gridDim.x * blockDim.x) {
@@ -192,14 +267,22 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
                     // in what follows the 5' match (the whole read when an optional 5' part is absent); no 3' match is still a
                     // match when that part is optional and the 5' part was found; a match removes whichever parts were found
                     for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {
-                        int h1[3], h2[3];
-                        const int v1 = adapter_cut_point<MAXM, false, true, 0>(o, s + a0, a1 - a0, h1);
-                        if (!h1[0] && o.req1) break;
-                        const int na0 = h1[0] ? a0 + v1 : a0;
-                        const int v2 = adapter_cut_point<MAXM, false, false, 1>(o, s + na0, a1 - na0, h2);
-                        if (!h2[0] && (o.req2 || !h1[0])) break;
-                        a0 = na0;
-                        if (h2[0]) a1 = na0 + v2;
+                        int h1[3] = {0, 0, 0}, h2[3] = {0, 0, 0};
+                        int na0 = a0;
+                        bool none = false;
+                        for (int part = 0; part < 2 && !none; part++) {  // (5' part, then 3' part: one copy of the search in the code)
+                            const int from = part ? na0 : a0;
+                            const int v = adapter_cut_point_rt<MAXM>(o, s + from, a1 - from, part == 0, part, part ? h2 : h1);
+                            if (part == 0) {
+                                if (!h1[0] && o.req1) none = true;
+                                else na0 = h1[0] ? a0 + v : a0;
+                            } else if (!h2[0] && (o.req2 || !h1[0])) none = true;
+                            else {
+                                a0 = na0;
+                                if (h2[0]) a1 = na0 + v;
+                            }
+                        }
+                        if (none) break;
                     }
                     done = true;
                 } else if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild || o.anch) {
@@ -207,12 +290,11 @@ __global__ void k_trim(const uint8_t* __restrict__ text, const int64_t* __restri
                     // removed, up to `times` times (AdapterCutter: `for _ in range(times): best_match ... break if None`)
                     for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {
                         int h1[3], h2[3] = {0, 0, 0};
-                        const int v1 = o.front ? adapter_cut_point<MAXM, false, true, 0>(o, s + a0, a1 - a0, h1)
-                                               : adapter_cut_point<MAXM, false, false, 0>(o, s + a0, a1 - a0, h1);
-                        int v2 = 0;
-                        if (o.alen2 > 0)
-                            v2 = o.front2 ? adapter_cut_point<MAXM, false, true, 1>(o, s + a0, a1 - a0, h2)
-                                          : adapter_cut_point<MAXM, false, false, 1>(o, s + a0, a1 - a0, h2);
+                        int v1 = 0, v2 = 0;
+                        for (int which = 0; which < (o.alen2 > 0 ? 2 : 1); which++) {  // (a loop: one copy of the search in the code)
+                            const int v = adapter_cut_point_rt<MAXM>(o, s + a0, a1 - a0, (which ? o.front2 : o.front) != 0, which, which ? h2 : h1);
+                            if (which) v2 = v; else v1 = v;
+                        }
                         const bool second = h2[0] && (!h1[0] || h2[1] > h1[1] || (h2[1] == h1[1] && h2[2] < h1[2]));
                         if (!(second ? h2[0] : h1[0])) break;
                         const bool fr = second ? o.front2 != 0 : o.front != 0;

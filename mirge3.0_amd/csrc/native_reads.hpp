@@ -294,20 +294,31 @@ static int launch_trim_exact(mirge_ctx* c, const TrimOpts& o, const uint8_t* dte
         return launch_trim_exact<M + 1>(c, o, dtext, lstart, lend, qstart, qend, n_raw, dstart, dend, dflags);
     }
 }
+// (the general instances come in two heights: the DP column of 64 + 1 entries does not fit the registers beside the rest of the
+//  kernel -- 1 101 spilled registers, 8 x the exact instance's time -- while adapters of up to 32 bases, nearly all of them, fit)
+template <bool FRONT>
+static void launch_trim_general(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, const int64_t* lstart, const int64_t* lend,
+                                const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
+    static const bool tall_only = std::getenv("MIRGE_TRIM_TALL") && std::atoi(std::getenv("MIRGE_TRIM_TALL")) != 0;  // (A/B, tests)
+    if (!tall_only && o.alen <= 32 && o.alen2 <= 32)
+        hipLaunchKernelGGL((k_trim<32, false, FRONT>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
+    else
+        hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, FRONT>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
+}
 static int launch_trim(mirge_ctx* c, const TrimOpts& o, const uint8_t* dtext, const int64_t* lstart, const int64_t* lend,
                        const int64_t* qstart, const int64_t* qend, uint32_t n_raw, int64_t* dstart, int64_t* dend, uint32_t* dflags) {
     bool wild = false;
     for (int i = 0; i < o.alen; i++) wild = wild || o.wild[i];
     if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild || o.action_none || o.anch || o.linked) {  // the general 3' instance carries these branches
-        hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
+        launch_trim_general<false>(c, o, dtext, lstart, lend, qstart, qend, n_raw, dstart, dend, dflags);
         return 0;
     }
     if (o.front) {  // a 5' adapter is the rare case: the general kernel
-        hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, true>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
+        launch_trim_general<true>(c, o, dtext, lstart, lend, qstart, qend, n_raw, dstart, dend, dflags);
         return 0;
     }
     if (o.alen >= 1 && !wild) return launch_trim_exact<1>(c, o, dtext, lstart, lend, qstart, qend, n_raw, dstart, dend, dflags);
-    hipLaunchKernelGGL((k_trim<MIRGE_TRIM_MAX_ADAPTER, false, false>), dim3(grid_for(c, n_raw)), dim3(MIRGE_BLOCK), 0, c->stream, dtext, lstart, lend, qstart, qend, n_raw, o, dstart, dend, dflags);
+    launch_trim_general<false>(c, o, dtext, lstart, lend, qstart, qend, n_raw, dstart, dend, dflags);
     return 0;
 }
 

@@ -1376,6 +1376,20 @@ def test_staged_cascade_for_every_group(hooks):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_trimming_general_instance_at_both_heights():
+    """k_trim's general instance (two adapters, -n, --no-indels, read wildcards, anchored and linked adapters) is compiled for
+    adapters of up to 32 and up to 64 bases; the launcher picks by adapter length.  MIRGE_TRIM_TALL=1 sends every such call
+    through the 64-row instance: the linked / anchored / two-adapter / repeated-removal tests of this file again, in a fresh
+    process (the default run above covers the 32-row instance with the same tests, and the 64-row one with its long adapters)."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "linked_and_anchored or two_adapters_best_match or adapter_removal_repeated"],
+                       env=dict(os.environ, MIRGE_TRIM_TALL="1"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_collapse_cascade_one_call_equals_two_calls(ctx):
     """mirge_collapse_cascade (the bulk group's passes queued behind the collapse kernels, read count taken from
     device memory) against mirge_collapse + mirge_cascade_run on the same reads: same unique reads, counts, first
