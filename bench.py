@@ -439,6 +439,37 @@ def cli_path(args, sl, libs, text, n_pass):
             sizes = {f: os.path.getsize(os.path.join(work, f)) for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv")}
             res[label] = {"wall_s": round(wall, 3), "M_reads_per_s": round(args.reads / wall / 1e6, 2),
                           "stages_s": {k: (round(v, 3) if not isinstance(v, dict) else v) for k, v in tm.items()}, "output_bytes": sizes}
+        # ---- the same sample with -gff: fetch of reads + annotation, k_isotype, sample_miRge3.gff on the host's cores
+        try:
+            mir, hp = sl.libs["mirna"], sl.libs["hairpin"]
+            os.makedirs(os.path.join(tmp, "Libs", "bench", "fasta.Libs"), exist_ok=True)
+            with open(os.path.join(tmp, "Libs", "bench", "fasta.Libs", "bench_mature_miRBase.fa"), "w") as fh:
+                fh.write("".join(f">{nm}\n{sq}\n" for nm, sq in zip(mir.names, mir.seqs.to_list())))
+            by_hp = {}
+            for k, nm in enumerate(mir.names):
+                by_hp.setdefault(int(sl.mir_hairpin[k]), []).append(nm)
+            with open(os.path.join(tmp, "Libs", "bench", "annotation.Libs", "bench_miRBase.gff3"), "w") as fh:
+                for h, names in by_hp.items():
+                    fh.write(f"chr1\t.\tmiRNA_primary_transcript\t1\t100\t.\t+\t.\tID=MI{h};Alias=MI{h};Name={hp.names[h]}\n")
+                    for nm in names:
+                        fh.write(f"chr1\t.\tmiRNA\t1\t22\t.\t+\t.\tID=MIMAT;Alias=MIMAT;Name={nm};Derives_from=MI{h}\n")
+            work = os.path.join(tmp, "gff")
+            os.makedirs(work)
+            a.gff_out = True
+            tm = {}
+            t = time.perf_counter()
+            o = fastpath.run(a, [fq], ["S1"], work, "miRBase", timings=tm)
+            wall = time.perf_counter() - t
+            for h in ("uniq", "res"):
+                o["device"][h].close()
+            res["gff_libraries_resident"] = {
+                "wall_s": round(wall, 3), "stages_s": {k: (round(v, 3) if not isinstance(v, (dict, list)) else v) for k, v in tm.items()},
+                "gff_MB": round(os.path.getsize(os.path.join(work, "sample_miRge3.gff")) / 1e6, 1),
+                "note": "the sample of libraries_resident again with -gff: sample_miRge3.gff typed by k_isotype, written by mirge_gff_write"}
+        except Exception as e:  # noqa: BLE001
+            res["gff_libraries_resident"] = {"error": repr(e)[:300]}
+        finally:
+            a.gff_out = False
         # ---- the input users hold: the same sample as sample.fastq.gz (one gzip member, level 6), libraries resident
         fq_gz = os.path.join(tmp, "S1.fastq.gz")
         gz_bytes = write_gzip_level6(text, fq_gz)

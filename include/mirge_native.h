@@ -306,11 +306,13 @@ int mirge_isomir_type(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_resul
                       const int32_t* pre_of_master, const int32_t* start0, int64_t n_master, const char* pre_ascii,
                       const int32_t* pre_off, int64_t n_pre, const int32_t* slot_of_read, int64_t n_rows, void* records_out);
 /* the GFF3 file from those records (summary.py:60-64 header, :204 / :465 lines; UID = miRgeEssential.UID), formatted on
- * the host's cores; rows with kind 0 print nothing.  read_ascii/read_off, counts[n_rows * S] are per ROW. */
+ * the host's cores; rows with kind 0 print nothing.  read_ascii/read_off, counts[.. * S] are per ROW when read_of_row is NULL;
+ * otherwise they are the caller's whole table of n_reads unique reads and row k prints entry read_of_row[k] of it. */
 int mirge_gff_write(const char* path, const char* head, const char* source, const void* records, int64_t n_rows,
                     const char* read_ascii, const int64_t* read_off, const uint32_t* counts, int32_t n_samples,
                     const int32_t* name_of_row, const char* name_data, const int64_t* name_off, int64_t n_names,
-                    const int32_t* parent_of_row, const char* parent_data, const int64_t* parent_off, int64_t n_parents);
+                    const int32_t* parent_of_row, const char* parent_data, const int64_t* parent_off, int64_t n_parents,
+                    const int64_t* read_of_row, int64_t n_reads);
 
 /* ---- measurement (bench.py): HIP events on the ctx stream ---- */
 int mirge_ctx_timer_start(mirge_ctx* ctx);

@@ -230,7 +230,10 @@ inline void uid_append(std::string& out, const char* s, size_t n) {
 extern "C" int mirge_gff_write(const char* path, const char* head, const char* source, const void* records, int64_t n_rows,
                                const char* read_ascii, const int64_t* read_off, const uint32_t* counts, int32_t S,
                                const int32_t* name_of_row, const char* name_data, const int64_t* name_off, int64_t n_names,
-                               const int32_t* parent_of_row, const char* parent_data, const int64_t* parent_off, int64_t n_parents) {
+                               const int32_t* parent_of_row, const char* parent_data, const int64_t* parent_off, int64_t n_parents,
+                               const int64_t* read_of_row, int64_t n_reads) {
+    // read_of_row (may be NULL): row k prints read and counts number read_of_row[k] of read_off / counts (n_reads of them) --
+    // the caller hands over its whole table of unique reads instead of gathering the rows' reads first; NULL: number k
     if (!path || !head || !source || n_rows < 0 || S < 1 || !read_off || !name_off || !parent_off ||
         (n_rows > 0 && (!records || !read_ascii || !counts || !name_of_row || !parent_of_row)))
         return fail(-1, "mirge_gff_write: bad argument");
@@ -249,8 +252,10 @@ extern "C" int mirge_gff_write(const char* path, const char* head, const char* s
             if (ni < 0 || ni >= n_names || pi < 0 || pi >= n_parents || (size_t)r.vlen + r.clen > MIRGE_ISO_TEXT) { bad[(size_t)t] = 1; continue; }
             const char* nm = name_data + name_off[ni];
             const size_t nl = (size_t)(name_off[ni + 1] - name_off[ni]);
-            const char* rd = read_ascii + read_off[k];
-            const size_t rl = (size_t)(read_off[k + 1] - read_off[k]);
+            const int64_t ri = read_of_row ? read_of_row[k] : k;
+            if (read_of_row && (ri < 0 || ri >= n_reads)) { bad[(size_t)t] = 1; continue; }
+            const char* rd = read_ascii + read_off[ri];
+            const size_t rl = (size_t)(read_off[ri + 1] - read_off[ri]);
             out.append(nm, nl); out.push_back('\t'); out += src; out.push_back('\t');
             out += r.kind == 1 ? "ref_miRNA" : "isomiR";
             out.push_back('\t'); out += std::to_string(r.start); out.push_back('\t'); out += std::to_string(r.end);
@@ -264,7 +269,7 @@ extern "C" int mirge_gff_write(const char* path, const char* head, const char* s
             out += "; Variant="; out.append(r.text, r.vlen);
             out += "; Cigar="; out.append(r.text + r.vlen, r.clen);
             std::string ex;
-            for (int s = 0; s < S; s++) { if (s) ex.push_back(','); csv_uint(ex, counts[(size_t)k * S + s]); }
+            for (int s = 0; s < S; s++) { if (s) ex.push_back(','); csv_uint(ex, counts[(size_t)ri * S + s]); }
             out += "; Expression="; out += ex; out += "; Filter=Pass; Hits="; out += ex; out.push_back('\n');
         }
     };

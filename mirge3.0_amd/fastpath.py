@@ -268,6 +268,7 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
         t = time.perf_counter()
         out["gff"] = write_gff(args, workDir, ref_db, base_names, casc, uniq, res, seqs, ps, ref, counts, order)
         tm["gff_s"] = time.perf_counter() - t
+        tm["gff_stages_s"] = out["gff"].get("timing", {})
     if getattr(args, "AtoI", False):  # -ai (summary.py:1034-1057)
         from .a2i import ListedGenome, a2i_report
         t = time.perf_counter()

@@ -147,30 +147,41 @@ def isomir_records(casc: Cascade, uniq, res, tables: dict, rows: np.ndarray) -> 
 def write_gff(args, workDir, ref_db, base_names, casc: Cascade, uniq, res, seqs: FlatSeqs, ps, ref, counts, order):
     """``-gff``: ``sample_miRge3.gff``, the rows in the reference's order (exact-miRNA rows of the mapped frame, then
     the isomiR rows, :50-60)."""
+    import time
+    tm = {}
+    t0 = time.perf_counter()
     lp, org = Path(args.libraries_path), args.organism_name
     mirDict = read_mature_fasta(lp / org / "fasta.Libs" / (org + "_mature_" + ref_db + ".fa"))
     pre_of = read_annotation(lp / org / "annotation.Libs" / (org + "_" + ref_db + ".gff3"), ref_db)
     tables = resolve_names(casc.libs["mirna"].names, mirDict, pre_of, precursor_dict(casc.libs["hairpin"]))
+    tm["name_tables_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     po = ps[order]
     rows = np.concatenate([order[po == EXACT_PASS], order[po == ISO_PASS]]).astype(np.int64)
     recs = isomir_records(casc, uniq, res, tables, rows)
+    tm["typing_call_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     version_db = "miRBase22" if ref_db == "miRBase" else "MirGeneDB2.0"
     head = ("# GFF3 adapted for miRNA sequencing data\n## VERSION 0.0.1\n## source-ontology: " + version_db + "\n## COLDATA: " +
             ",".join(str(nm) for nm in base_names) + "\n")
-    sub = seqs.take(rows)
+    # (the writer indexes the run's whole table of unique reads through `rows`: no gather of the rows' reads and counts here)
     names, parents = FlatSeqs.from_list(tables["printed"]), FlatSeqs.from_list(tables["parents"])
     nrow = np.ascontiguousarray(tables["name_of_ref"][ref[rows]], dtype=np.int32) if rows.size else np.zeros(1, np.int32)
     prow = np.ascontiguousarray(tables["parent_of_ref"][ref[rows]], dtype=np.int32) if rows.size else np.zeros(1, np.int32)
-    cnt = np.ascontiguousarray(counts[rows], dtype=np.uint32) if rows.size else np.zeros((1, len(base_names)), np.uint32)
-    sdata = np.ascontiguousarray(sub.data) if sub.data.size else np.zeros(1, np.uint8)
-    soff = np.ascontiguousarray(sub.offsets, dtype=np.int64)
+    cnt = np.ascontiguousarray(counts, dtype=np.uint32).reshape(len(seqs), len(base_names)) if len(seqs) else np.zeros((1, len(base_names)), np.uint32)
+    sdata = np.ascontiguousarray(seqs.data) if seqs.data.size else np.zeros(1, np.uint8)
+    soff = np.ascontiguousarray(seqs.offsets, dtype=np.int64)
     nd = np.ascontiguousarray(names.data) if names.data.size else np.zeros(1, np.uint8)
     pd_ = np.ascontiguousarray(parents.data) if parents.data.size else np.zeros(1, np.uint8)
     recs = np.ascontiguousarray(recs) if rows.size else np.zeros(1, dtype=RECORD)
+    rows_c = np.ascontiguousarray(rows, dtype=np.int64) if rows.size else np.zeros(1, np.int64)
+    tm["rows_of_the_file_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     _ffi._check(_ffi.load().mirge_gff_write(str(Path(workDir) / "sample_miRge3.gff").encode(), head.encode(), version_db.encode(),
                                             _ffi._p(recs), C.c_int64(rows.shape[0]), _ffi._p(sdata), _ffi._p(soff), _ffi._p(cnt),
                                             C.c_int32(len(base_names)), _ffi._p(nrow), _ffi._p(nd),
                                             _ffi._p(np.ascontiguousarray(names.offsets, dtype=np.int64)), C.c_int64(len(names)),
                                             _ffi._p(prow), _ffi._p(pd_), _ffi._p(np.ascontiguousarray(parents.offsets, dtype=np.int64)),
-                                            C.c_int64(len(parents))), "mirge_gff_write")
-    return dict(records=recs, rows=rows, tables=tables)
+                                            C.c_int64(len(parents)), _ffi._p(rows_c), C.c_int64(len(seqs))), "mirge_gff_write")
+    tm["write_s"] = time.perf_counter() - t0
+    return dict(records=recs, rows=rows, tables=tables, timing={k: round(v, 4) for k, v in tm.items()})

@@ -146,20 +146,38 @@ int main(int argc, char** argv) {
         }
         const std::string pg = dir + "/s.gff";
         EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "miRBase22", rec.data(), n, reads.data(), roff.data(), cnt.data(), S, name_of.data(), nblob.data(),
-                               noff.data(), 50, parent_of.data(), pblob.data(), poff.data(), 20) == 0);
+                               noff.data(), 50, parent_of.data(), pblob.data(), poff.data(), 20, nullptr, 0) == 0);
         const std::string g = slurp(pg);
         int64_t lines = 0, want = 0;
         for (char c : g) lines += c == '\n';
         for (int64_t k = 0; k < n; k++) want += rec[(size_t)k].kind != 0;
         EXPECT(lines == want + 1 && g.rfind("## head\n", 0) == 0);
+        {   // the rows' reads and counts through an index into a larger table (read_of_row): the same file; an index beyond it is refused
+            std::vector<int64_t> perm((size_t)n);
+            for (int64_t k = 0; k < n; k++) perm[(size_t)k] = n - 1 - k;
+            std::string reads2; std::vector<int64_t> roff2{0};
+            std::vector<uint32_t> cnt2((size_t)n * S);
+            for (int64_t j = 0; j < n; j++) {  // table entry j = row n-1-j
+                const int64_t k = n - 1 - j;
+                reads2.append(reads, (size_t)roff[(size_t)k], (size_t)(roff[(size_t)k + 1] - roff[(size_t)k])); roff2.push_back((int64_t)reads2.size());
+                for (int s2 = 0; s2 < S; s2++) cnt2[(size_t)j * S + s2] = cnt[(size_t)k * S + s2];
+            }
+            const std::string pg2 = dir + "/s2.gff";
+            EXPECT(mirge_gff_write(pg2.c_str(), "## head\n", "miRBase22", rec.data(), n, reads2.data(), roff2.data(), cnt2.data(), S, name_of.data(), nblob.data(),
+                                   noff.data(), 50, parent_of.data(), pblob.data(), poff.data(), 20, perm.data(), n) == 0);
+            EXPECT(slurp(pg2) == g);
+            perm[3] = n; rec[3].kind = 1;
+            EXPECT(mirge_gff_write(pg2.c_str(), "## head\n", "miRBase22", rec.data(), n, reads2.data(), roff2.data(), cnt2.data(), S, name_of.data(), nblob.data(),
+                                   noff.data(), 50, parent_of.data(), pblob.data(), poff.data(), 20, perm.data(), n) == -1);
+        }
         EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "x", rec.data(), 0, nullptr, roff.data(), nullptr, S, nullptr, nblob.data(), noff.data(), 50, nullptr,
-                               pblob.data(), poff.data(), 20) == 0 && slurp(pg) == "## head\n");
+                               pblob.data(), poff.data(), 20, nullptr, 0) == 0 && slurp(pg) == "## head\n");
         name_of[7] = 50; rec[7].kind = 1;
         EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "x", rec.data(), n, reads.data(), roff.data(), cnt.data(), S, name_of.data(), nblob.data(), noff.data(),
-                               50, parent_of.data(), pblob.data(), poff.data(), 20) == -1);
+                               50, parent_of.data(), pblob.data(), poff.data(), 20, nullptr, 0) == -1);
         name_of[7] = 0; rec[7].vlen = MIRGE_ISO_TEXT; rec[7].clen = 1;
         EXPECT(mirge_gff_write(pg.c_str(), "## head\n", "x", rec.data(), n, reads.data(), roff.data(), cnt.data(), S, name_of.data(), nblob.data(), noff.data(),
-                               50, parent_of.data(), pblob.data(), poff.data(), 20) == -1);
+                               50, parent_of.data(), pblob.data(), poff.data(), 20, nullptr, 0) == -1);
     }
 
     // ---------------- merged_library_text: the members' letters back out of their packed images, N where the image says invalid
