@@ -111,7 +111,13 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         // Forcing that by doubling B was measured slower overall: k_part_agg/k_part_scatter pay for the larger B
         // (a bucket of up to MIRGE_PART_SMALL reads + 8 sigma stays below the 2048 - 64 distinct keys that table takes)
         t.cap = (!small_part && (uint64_t)B * MIRGE_PART_SMALL >= in.n) ? 2048u : (uint32_t)MIRGE_PART_CAP;
-        const uint32_t NB1 = std::min<uint32_t>(B, MIRGE_PART_B1), NB2 = B / NB1;
+        // level-1 bins: MIRGE_PART_B1 (64) up to 8192 final buckets (~17 M reads), 128 at 16384, 256 at 32768 -- a splitter then
+        // appends to 128 final buckets at most.  Measured (round 5, interleaved): 20 M reads 2.337 -> 2.304 ms per step, 50 M reads
+        // 6.68 -> 6.49; at 10 M reads 128 bins were 1.7 % slower than 64 (k_part_agg pays for every level-1 stream it keeps open).
+        // MIRGE_PART_NB1 overrides at run time (sweeps: a power of two up to 256)
+        static const uint32_t nb1_env = std::getenv("MIRGE_PART_NB1") ? (uint32_t)std::max(1, std::min(256, std::atoi(std::getenv("MIRGE_PART_NB1")))) : 0u;
+        const uint32_t nb1_cap = nb1_env ? nb1_env : B >= 32768 ? 256u : B >= 16384 ? 128u : (uint32_t)MIRGE_PART_B1;
+        const uint32_t NB1 = std::min<uint32_t>(B, nb1_cap), NB2 = B / NB1;
         const uint32_t CS = B > 16384 ? 1024 : MIRGE_PART_CACHE;  // chunk-level LDS cache slots (16 B each)
         const int agg_lds = (int)(CS * 16 + NB1 * 4 + (NB2 > 1 ? B * 4 : 0) + 64);
         // dynamic-LDS ceilings, raised once per process and device to the largest configuration (B = 32768)
@@ -121,7 +127,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
             std::lock_guard<std::mutex> lk(attr_mu);
             if (std::find(attr_done.begin(), attr_done.end(), c->device) == attr_done.end()) {
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          1024 * 16 + MIRGE_PART_B1 * 4 + 32768 * 4 + 64));  // CS = 1024 at B = 32768; 2048 * 16 + 16384 * 4 is smaller
+                                          1024 * 16 + 256 * 4 + 32768 * 4 + 64));  // CS = 1024 at B = 32768; 2048 * 16 + 16384 * 4 is smaller
                 HIPOK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_part_dedup<MIRGE_PART_CAP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, MIRGE_PART_CAP * 16 + 4096));
                 attr_done.push_back(c->device);
@@ -134,7 +140,9 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         chunk = (chunk + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
         // the level-1 bin is the top lg1 bits of the hash, the level-2 bin the next lg - lg1 bits
         const uint32_t shift1 = 64 - lg1, shift2 = 64 - lg;
-        const uint32_t W2 = NB2 > 1 ? std::min<uint32_t>(MIRGE_PART_W2, G) : 1, RPW = (G + W2 - 1) / W2;
+        // (splitter workgroups: MIRGE_PART_W2 per level-1 bin at 64 bins = one per CU; the same 256 in all at other bin counts)
+        const uint32_t w2_want = std::max<uint32_t>(1, (uint32_t)MIRGE_PART_W2 * (uint32_t)MIRGE_PART_B1 / NB1);
+        const uint32_t W2 = NB2 > 1 ? std::min<uint32_t>(w2_want, G) : 1, RPW = (G + W2 - 1) / W2;
         // test hook: MIRGE_TEST_SMALL_REGION=1 halves the level-1 regions so that they overflow and the call falls back
         static const bool small_region = std::getenv("MIRGE_TEST_SMALL_REGION") != nullptr;
         const uint32_t cap1 = attempt == 1 ? chunk
