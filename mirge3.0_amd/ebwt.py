@@ -159,25 +159,29 @@ def read_sequences(base: str) -> Tuple[FlatSeqs, List[int]]:
     total = int(ln.sum())
     if packed.size * 4 < total:
         raise ValueError(f"{p4}: {total} bases announced by {p3}, {packed.size * 4} present")
-    # unpack the whole 2-bit stream once, then lay the stretches out with their runs of N in front
-    codes = ((packed[:, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)[None, :]) & 3).reshape(-1)[:total]
-    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    # unpack the 2-bit stream four bases at a time (one table look-up per packed byte), then lay the stretches out with their
+    # runs of N in front: the output is [off_0 x N][ln_0 bases][off_1 x N][ln_1 bases]... in record order, so one boolean mask
+    # of the output's length places every base -- no per-base index arrays (a 130 Mb index took 22 s with them, 1 s without)
+    lut = np.empty(256, dtype="<u4")
+    b4 = np.frombuffer(b"ACGT", dtype=np.uint8).astype(np.uint32)
+    v = np.arange(256, dtype=np.uint32)
+    lut[:] = b4[v & 3] | (b4[(v >> 2) & 3] << 8) | (b4[(v >> 4) & 3] << 16) | (b4[(v >> 6) & 3] << 24)
+    bases = lut[packed[:(total + 3) // 4]].view(np.uint8)[:total]
     rec_total = off + ln
     seq_id = np.cumsum(first) - 1
     n_seq = int(seq_id[-1] + 1) if nrec else 0
     seq_len = np.bincount(seq_id, weights=rec_total, minlength=n_seq).astype(np.int64) if nrec else np.zeros(0, np.int64)
     offsets = np.zeros(n_seq + 1, dtype=np.int64)
     np.cumsum(seq_len, out=offsets[1:])
-    data = np.full(int(offsets[-1]), ord("N"), dtype=np.uint8)
-    rec_start = np.zeros(nrec, dtype=np.int64)  # where each record starts in `data`
-    if nrec:
-        np.cumsum(rec_total[:-1], out=rec_start[1:])
-    src_start = np.zeros(nrec, dtype=np.int64)
-    if nrec:
-        np.cumsum(ln[:-1], out=src_start[1:])
-    rows = np.repeat(np.arange(nrec, dtype=np.int64), ln)
-    within = np.arange(total, dtype=np.int64) - src_start[rows]
-    data[rec_start[rows] + off[rows] + within] = bases
+    if nrec and not off.any():
+        data = np.ascontiguousarray(bases)  # no ambiguous stretch anywhere: the stream is the text
+    else:
+        data = np.full(int(offsets[-1]), ord("N"), dtype=np.uint8)
+        if nrec:
+            runs = np.empty(2 * nrec, dtype=np.int64)
+            runs[0::2], runs[1::2] = off, ln
+            is_base = np.repeat(np.tile(np.array([False, True]), nrec), runs)
+            data[is_base] = bases
     recs_per_seq = np.bincount(seq_id, minlength=n_seq).tolist() if nrec else []
     return FlatSeqs(data, offsets), recs_per_seq
 
