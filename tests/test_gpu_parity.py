@@ -1673,6 +1673,26 @@ def test_full_size_c3_properties(ctx):
     o = oracle.cascade(sub.data[: sub.offsets[k]], sub.offsets[: k + 1], oracle_libs_from(sl.libs), n_pass=9, indexed=True)
     for a, b in zip(o, g):
         assert np.array_equal(a.astype(np.int64), b[:k].astype(np.int64))
+    # row N2 at this size: every read of the exact-miRNA / isomiR passes (~0.7 M) typed by k_isotype; every record typed, the
+    # exact rows that equal their canonical are ref_miRNA, and 15 000 records against the oracle's difflib restatement
+    from mirge3_amd import gff
+    mir, hp = sl.libs["mirna"], sl.libs["hairpin"]
+    mseq, hseq = mir.seqs.to_list(), hp.seqs.to_list()
+    pre_seq = dict(zip(hp.names, hseq))
+    pre_of = {nm: hp.names[int(sl.mir_hairpin[q])] for q, nm in enumerate(mir.names)}
+    tabs = gff.resolve_names(mir.names, dict(zip(mir.names, mseq)), pre_of, pre_seq)
+    rows = np.nonzero((ps == 0) | (ps == 8))[0].astype(np.int64)
+    recs = gff.isomir_records(casc, uniq, res, tabs, rows)
+    assert len(recs) == len(rows) > 500000 and (recs["kind"] > 0).all()
+    for q in rng.permutation(len(rows))[:15000]:
+        i = int(rows[q])
+        read, nm = useq.get(i), mir.names[ref[i]]
+        kind, start, end, variant, cigar = oracle.gff_record(mseq[ref[i]], read, pre_seq[pre_of[nm]])
+        r = recs[q]
+        text = bytes(r["text"]).ljust(320, b"\0")
+        got = ({1: "ref_miRNA", 2: "isomiR"}[int(r["kind"])], int(r["start"]), int(r["end"]), text[:r["vlen"]].decode(),
+               text[r["vlen"]:r["vlen"] + r["clen"]].decode())
+        assert got == (kind, start, end, variant, cigar), (read, mseq[ref[i]], got, (kind, start, end, variant, cigar))
     res.close(); uniq.close(); raw.close(); casc.close()
 
 
