@@ -505,12 +505,28 @@ k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, co
         ulen[rank] = (uint8_t)L;
         ucnt[rank] = lds_cnt[s0 + i];
         ufirst[rank] = lds_min[s0 + i];
-        atomicAdd(&lds_x[32 + L], 1u);
+        if (hist) atomicAdd(&lds_x[32 + L], 1u);
         rank++;
     }
+    if (!hist) return;  // (the histogram comes from k_len_hist on the side stream: see there)
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 32; i += blockDim.x)
         if (lds_x[32 + i]) atomicAdd(&hist[i], lds_x[32 + i]);
+}
+
+// The length histogram of the partitioned path's unique reads, by a kernel of its own on the side stream (round 5).  k_part_dedup
+// counted it while it emitted: one LDS atomic per unique read on ~16 hot counters and ~16 global atomics per bucket on 16
+// addresses -- 130 k of them per sample from 8192 workgroups.  Nothing on the GPU waits for the histogram (the host reads it
+// with the counts), but the main stream waited for those atomics: k_part_dedup 0.126 -> 0.118 ms and the step -1.7 % without
+// them (profiles/README.md, round 5).  len[0 .. *n_dev): 3.8 MB per 10 M-read sample.
+__global__ void __launch_bounds__(256) k_len_hist(const uint8_t* __restrict__ len, const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[64];
+    if (threadIdx.x < 64) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = *n_dev;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&h[len[i] & 63u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
 // heads: read j is the head of its group iff it is the group's smallest index.  `first` is addressed

@@ -44,6 +44,15 @@ static uint32_t part_region_cap(double mean) {
     return ((uint32_t)c + 3u) & ~3u;
 }
 
+// the unique reads' length histogram of a group that took the partitioned path: k_len_hist on the side stream, in front of the
+// copy that takes counts and histogram to the host (k_part_dedup no longer counts it; see the kernel)
+static void part_len_hist(mirge_ctx* c, const ReadGroup& out, const CollapseTmp& t, uint32_t* dmeta, int gi) {
+    if (!t.partitioned || !out.len) return;
+    LaunchScope ls(c, "k_len_hist", 0.0);
+    hipLaunchKernelGGL(k_len_hist, dim3((unsigned)c->n_cu * 2), dim3(256), 0, c->aux, (const uint8_t*)out.len, (const uint32_t*)(dmeta + gi),
+                       dmeta + MIRGE_META_HIST);
+}
+
 // partitioned key path after k_part_agg.  `part` 1: the second radix level (k_part_split is one workgroup per CU like
 // k_part_agg: the small groups' kernels, enqueued while these run, find room beside them); 2: the per-bucket
 // de-duplication (8192 workgroups: takes the machine); 0: both.  The main queue used to idle ~0.1 ms behind
@@ -64,10 +73,10 @@ static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGro
         const uint64_t rcap = two ? t.slab : (uint64_t)t.cap1;
         if (t.cap == 2048)
             hipLaunchKernelGGL(k_part_dedup<2048>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 4096, c->cur, rec, cnt, off, R, rcap, t.NB2,
-                               out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST, dmeta + MIRGE_META_OVERFLOW);
+                               out.seq, out.len, out.counts, out.first, dmeta + gi, (uint32_t*)nullptr, dmeta + MIRGE_META_OVERFLOW);
         else
             hipLaunchKernelGGL(k_part_dedup<MIRGE_PART_CAP>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), MIRGE_PART_CAP * 16 + 4096, c->cur, rec,
-                               cnt, off, R, rcap, t.NB2, out.seq, out.len, out.counts, out.first, dmeta + gi, dmeta + MIRGE_META_HIST,
+                               cnt, off, R, rcap, t.NB2, out.seq, out.len, out.counts, out.first, dmeta + gi, (uint32_t*)nullptr,
                                dmeta + MIRGE_META_OVERFLOW);
     }
     return 0;
@@ -464,6 +473,8 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             }
             // the bulk group's count, the overflow flag and the length histogram: `aux` behind the main stream's k_part_dedup
             if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_bulk_counted, 0);
+            if (e == hipSuccess)
+                for (int gi = 0; gi < MIRGE_NGROUPS; gi++) part_len_hist(c, R->g[gi], tmp[gi], dmeta, gi);  // (a group beside the bulk one ran on `aux` itself)
             if (e == hipSuccess) e = hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->aux);
             if (e == hipSuccess) e = hipEventRecord(c->ev_meta, c->aux);
             if (e == hipSuccess) e = hipEventSynchronize(c->ev_meta);
@@ -474,6 +485,8 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             // group's count comes from k_part_dedup): on the main stream the 4 us copy sat between k_part_dedup and the bulk
             // group's cascade -- which does not need it -- with 6 + 11 us of queue gaps around it
             rc = stream_fork(c);
+            if (rc == 0)
+                for (int gi = 0; gi < MIRGE_NGROUPS; gi++) part_len_hist(c, R->g[gi], tmp[gi], dmeta, gi);
             hipError_t e = rc == 0 ? hipMemcpyAsync(c->pinned, dmeta, MIRGE_META_WORDS * 4, hipMemcpyDeviceToHost, c->aux) : hipErrorUnknown;
             if (e == hipSuccess) e = hipEventRecord(c->ev_meta, c->aux);
             if (e == hipSuccess && hook && attempt == 0 && tmp[big].partitioned) {
