@@ -160,6 +160,8 @@ __global__ void k_collapse_init(uint32_t* __restrict__ rep, uint32_t* __restrict
 #define MIRGE_PART_B1 64       // level-1 bins (and the largest one-level partition)
 #endif
 #ifndef MIRGE_PART_SMALL
+#define MIRGE_DEDUP_SHARDS 8          // output cursors of k_part_dedup (shards of its staging area)
+#define MIRGE_DEDUP_SHARD_STRIDE 1024  // words between two cursors: 4 KiB, a memory channel of its own each
 #define MIRGE_PART_SMALL 1600  // reads per bucket up to which k_part_dedup uses its 2048-slot table
 #endif
 #ifndef MIRGE_PART_W2
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(MIRGE_DEDUP_THREADS)
 k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t R,
              uint64_t rcap, uint32_t NB2, uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
              uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst, uint32_t* __restrict__ cursor,
-             uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow) {
+             uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow, uint32_t* __restrict__ shard_cur, uint32_t shard_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
     uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + CAP);
     uint32_t* lds_cnt = lds_min + CAP;
@@ -493,8 +495,25 @@ k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, co
     for (int i = 0; i < PER; i++) mine += lds_k[s0 + i] != 0ull;
     uint32_t total;
     uint32_t rank = block_excl_scan<MIRGE_DEDUP_THREADS / 64>(mine, total, lds_x + 2);
-    if (threadIdx.x == 0) lds_x[1] = total ? atomicAdd(cursor, total) : 0u;
+    // Where the bucket's unique reads go.  One global cursor for all buckets (shard_cur == nullptr) is a returning add on ONE
+    // address per bucket, and such adds are served one after the other, 11.6 ns each: 8192 buckets = 0.095 of this kernel's
+    // 0.116 ms whatever they hold (profiles/README.md, round 5).  With shards, bucket b adds to cursor b mod MIRGE_DEDUP_SHARDS
+    // (each on a line and channel of its own) and writes into that shard's stretch of a staging area; k_part_compact closes
+    // the gaps between the stretches afterwards.
+    if (threadIdx.x == 0) {
+        uint32_t at = 0;
+        if (total) {
+            if (shard_cur) {
+                const uint32_t x = blockIdx.x % MIRGE_DEDUP_SHARDS;
+                const uint32_t o = atomicAdd(&shard_cur[x * MIRGE_DEDUP_SHARD_STRIDE], total);
+                if (o + total > shard_cap) { atomicOr(overflow, 1u); at = 0xFFFFFFFFu; }  // (no room: nothing is written, the call is redone)
+                else at = x * shard_cap + o;
+            } else at = atomicAdd(cursor, total);
+        }
+        lds_x[1] = at;
+    }
     __syncthreads();
+    if (lds_x[1] == 0xFFFFFFFFu) return;
     rank += lds_x[1];
 #pragma unroll
     for (int i = 0; i < PER; i++) {
@@ -519,6 +538,26 @@ k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, co
 // addresses -- 130 k of them per sample from 8192 workgroups.  Nothing on the GPU waits for the histogram (the host reads it
 // with the counts), but the main stream waited for those atomics: k_part_dedup 0.126 -> 0.118 ms and the step -1.7 % without
 // them (profiles/README.md, round 5).  len[0 .. *n_dev): 3.8 MB per 10 M-read sample.
+// The shards' stretches of k_part_dedup's staging area, one behind the other: the group's unique reads, dense.  *n_out = their number.
+__global__ void __launch_bounds__(256) k_part_compact(const uint32_t* __restrict__ shard_cur, uint32_t shard_cap,
+                                                       const uint64_t* __restrict__ sseq, const uint8_t* __restrict__ slen,
+                                                       const uint32_t* __restrict__ scnt, const uint32_t* __restrict__ sfirst,
+                                                       uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen, uint32_t* __restrict__ ucnt,
+                                                       uint32_t* __restrict__ ufirst, uint32_t* __restrict__ n_out) {
+    uint32_t end[MIRGE_DEDUP_SHARDS];  // (compile-time indices only: registers)
+    uint32_t run = 0;
+#pragma unroll
+    for (int x = 0; x < MIRGE_DEDUP_SHARDS; x++) { run += min(shard_cur[x * MIRGE_DEDUP_SHARD_STRIDE], shard_cap); end[x] = run; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = run;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < run; e += gridDim.x * blockDim.x) {
+        uint32_t x = 0, lo = 0;
+#pragma unroll
+        for (int y = 0; y < MIRGE_DEDUP_SHARDS - 1; y++) if (e >= end[y]) { x = (uint32_t)y + 1; lo = end[y]; }
+        const size_t src = (size_t)x * shard_cap + (e - lo);
+        useq[e] = sseq[src]; ulen[e] = slen[src]; ucnt[e] = scnt[src]; ufirst[e] = sfirst[src];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_len_hist(const uint8_t* __restrict__ len, const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[64];
     if (threadIdx.x < 64) h[threadIdx.x] = 0;

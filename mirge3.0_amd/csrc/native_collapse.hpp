@@ -16,6 +16,10 @@ struct CollapseTmp {
     bool partitioned = false;
     uint4 *rec1 = nullptr, *rec2 = nullptr;
     uint32_t *cnt1 = nullptr, *cnt2 = nullptr, *off2 = nullptr, *hist = nullptr;
+    // k_part_dedup's sharded output (attempt 0): cursors, capacity of a shard's stretch, the staging arrays k_part_compact reads
+    uint32_t *shard_cur = nullptr, shard_cap = 0, *s_cnt = nullptr, *s_first = nullptr;
+    uint64_t* s_seq = nullptr;
+    uint8_t* s_len = nullptr;
     uint32_t G = 0, B = 0, NB1 = 0, NB2 = 1, W2 = 1, RPW = 0, cap1 = 0, shift2 = 0, cap = MIRGE_PART_CAP;
     uint64_t slab = 0;
 };
@@ -71,13 +75,24 @@ static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGro
         const uint32_t* off = two ? t.off2 : nullptr;
         const uint32_t R = two ? t.W2 : t.G;
         const uint64_t rcap = two ? t.slab : (uint64_t)t.cap1;
+        const bool sh = t.shard_cur != nullptr;  // the buckets write shard by shard into the staging arrays, k_part_compact makes them dense
+        uint64_t* const oseq = sh ? t.s_seq : reinterpret_cast<uint64_t*>(out.seq);
+        uint8_t* const olen = sh ? t.s_len : reinterpret_cast<uint8_t*>(out.len);
+        uint32_t* const ocnt = sh ? t.s_cnt : out.counts;
+        uint32_t* const ofirst = sh ? t.s_first : out.first;
         if (t.cap == 2048)
             hipLaunchKernelGGL(k_part_dedup<2048>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 4096, c->cur, rec, cnt, off, R, rcap, t.NB2,
-                               out.seq, out.len, out.counts, out.first, dmeta + gi, (uint32_t*)nullptr, dmeta + MIRGE_META_OVERFLOW);
+                               oseq, olen, ocnt, ofirst, dmeta + gi, (uint32_t*)nullptr, dmeta + MIRGE_META_OVERFLOW, t.shard_cur, t.shard_cap);
         else
             hipLaunchKernelGGL(k_part_dedup<MIRGE_PART_CAP>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), MIRGE_PART_CAP * 16 + 4096, c->cur, rec,
-                               cnt, off, R, rcap, t.NB2, out.seq, out.len, out.counts, out.first, dmeta + gi, (uint32_t*)nullptr,
-                               dmeta + MIRGE_META_OVERFLOW);
+                               cnt, off, R, rcap, t.NB2, oseq, olen, ocnt, ofirst, dmeta + gi, (uint32_t*)nullptr,
+                               dmeta + MIRGE_META_OVERFLOW, t.shard_cur, t.shard_cap);
+        if (sh) {
+            LaunchScope ls2(c, "k_part_compact.w1", in.n);
+            hipLaunchKernelGGL(k_part_compact, dim3((unsigned)c->n_cu * 8), dim3(256), 0, c->cur, (const uint32_t*)t.shard_cur, t.shard_cap,
+                               (const uint64_t*)t.s_seq, (const uint8_t*)t.s_len, (const uint32_t*)t.s_cnt, (const uint32_t*)t.s_first,
+                               reinterpret_cast<uint64_t*>(out.seq), reinterpret_cast<uint8_t*>(out.len), out.counts, out.first, dmeta + gi);
+        }
     }
     return 0;
 }
@@ -162,6 +177,24 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         if (part_oom && attempt == 1) return fail(-3, "hipMalloc: out of memory (MIRGE_TEST_PART_OOM)");
         CHECK(dalloc(c, &t.rec1, (size_t)NB1 * G * cap1));
         CHECK(dalloc(c, &t.cnt1, (size_t)NB1 * G));
+        // sharded output of k_part_dedup (the first attempt only): a shard's stretch holds an eighth of the reads plus an eighth of
+        // that and 64 k -- a hash that fills it sets the overflow flag.  Measured (round 5, interleaved): a sample with 3 % unique reads
+        // 0.529 -> 0.488 ms per step (the kernel 0.103 -> 0.066 + 0.008 for k_part_compact: it was waiting for the one cursor), the
+        // default draw with 42 % unique reads 1.184 -> 1.190 (0.116 -> 0.123 + 0.028: there the kernel's time is its records).  So:
+        // when the context's previous collapse found under a fifth of its reads unique -- the samples of a batch are alike; the
+        // first one takes the cursor.  MIRGE_DEDUP_SHARDED=1 / 0: always / never (tests, A/B).
+        static const int sharded_env = std::getenv("MIRGE_DEDUP_SHARDED") ? std::atoi(std::getenv("MIRGE_DEDUP_SHARDED")) : -1;
+        const bool sharded = sharded_env >= 0 ? sharded_env != 0 : (c->last_unique_share > 0.0 && c->last_unique_share < 0.2);
+        if (sharded && attempt == 0 && !small_part) {
+            t.shard_cap = in.n / MIRGE_DEDUP_SHARDS + in.n / (8 * MIRGE_DEDUP_SHARDS) + 65536u;
+            const size_t sn = (size_t)t.shard_cap * MIRGE_DEDUP_SHARDS;
+            CHECK(dalloc(c, &t.shard_cur, (size_t)MIRGE_DEDUP_SHARDS * MIRGE_DEDUP_SHARD_STRIDE));
+            CHECK(dalloc(c, &t.s_seq, sn));
+            CHECK(dalloc(c, &t.s_len, sn));
+            CHECK(dalloc(c, &t.s_cnt, sn));
+            CHECK(dalloc(c, &t.s_first, sn));
+            HIPOK(hipMemsetAsync(t.shard_cur, 0, (size_t)MIRGE_DEDUP_SHARDS * MIRGE_DEDUP_SHARD_STRIDE * 4, c->cur));  // (in front of k_part_agg: off the path)
+        }
         if (NB2 > 1) {
             CHECK(dalloc(c, &t.hist, (size_t)G * B));
             CHECK(dalloc(c, &t.rec2, (size_t)NB1 * W2 * slab));
@@ -321,6 +354,7 @@ static void collapse_tmp_release(mirge_ctx* c, CollapseTmp& t) {
     c->defer(t.rep); c->defer(t.firstj); c->defer(t.cnt); c->defer(t.slots); c->defer(t.slot_of);
     c->defer(t.flag); c->defer(t.blocksum);
     c->defer(t.rec1); c->defer(t.cnt1); c->defer(t.rec2); c->defer(t.cnt2); c->defer(t.off2); c->defer(t.hist);
+    c->defer(t.shard_cur); c->defer(t.s_seq); c->defer(t.s_len); c->defer(t.s_cnt); c->defer(t.s_first);
     t = CollapseTmp();
 }
 
@@ -515,6 +549,8 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
     if (rc == 0) {
         uint32_t U[MIRGE_NGROUPS];
         for (int gi = 0; gi < MIRGE_NGROUPS; gi++) U[gi] = c->pinned[gi];
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+            if (tmp[gi].partitioned && raw->g[gi].n) c->last_unique_share = (double)U[gi] / (double)raw->g[gi].n;
         R->total_bases = 0;
         for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
             R->len_hist[L] = (int32_t)c->pinned[MIRGE_META_HIST + L];

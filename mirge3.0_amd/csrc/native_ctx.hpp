@@ -43,6 +43,9 @@ struct mirge_ctx {
     // second stream: the small read groups (long reads, reads with N) run beside the big one.
     // cur = the stream the launch helpers currently target.
     hipStream_t aux = nullptr, cur = nullptr;
+    // unique / raw reads of the partitioned group in this context's last collapse (0: none yet): samples of a batch are alike, and
+    // k_part_dedup's sharded output pays for itself only when few reads are unique (native_collapse.hpp)
+    double last_unique_share = 0.0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_meta = nullptr, ev_meta_small = nullptr, ev_bulk_counted = nullptr;
     // the small read groups' one-launch cascades each on a stream of their own (round 3): with the bulk group's passes in one
     // launch they only get the chip when its workgroups retire, and on ONE stream three of them then ran one after the other

@@ -1393,6 +1393,19 @@ def test_trimming_general_instance_at_both_heights():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_partitioned_collapse_with_sharded_output():
+    """k_part_dedup can write its buckets' unique reads through eight cursors into a staging area that k_part_compact makes dense
+    (chosen by itself when a context's previous sample had few unique reads); MIRGE_DEDUP_SHARDED=1 makes every partitioned
+    collapse take that route: the collapse tests of this file again, in a fresh process."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "collapse_vs_oracle or partitioned_collapse_sizes or one_call_equals"],
+                       env=dict(os.environ, MIRGE_DEDUP_SHARDED="1"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_collapse_cascade_one_call_equals_two_calls(ctx):
     """mirge_collapse_cascade (the bulk group's passes queued behind the collapse kernels, read count taken from
     device memory) against mirge_collapse + mirge_cascade_run on the same reads: same unique reads, counts, first

@@ -24,7 +24,7 @@ for a in args:
     so = parts[0]
     env = dict(p.split("=", 1) for p in parts[1:] if p)
     cfgs.append((name, os.path.abspath(so) if so else "", env))
-KEYS = ("k_part_agg.w1", "k_part_split.w1", "k_part_dedup.w1", "k_cascade_bulk.w1", "k_resolve.w1", "k_cascade_fused.w2", "k_cascade_bulk.w2", "k_cascade_fused.w1")
+KEYS = ("k_part_agg.w1", "k_part_split.w1", "k_part_dedup.w1", "k_cascade_bulk.w1", "k_resolve.w1", "k_cascade_fused.w2", "k_part_compact.w1")
 res = {c[0]: [] for c in cfgs}
 ker = {c[0]: {k: [] for k in KEYS} for c in cfgs}
 for r in range(rounds):
