@@ -205,7 +205,14 @@ def bwt_align_bowtie(args, pdDataFrame, workDir, ref_db):
             if Path(str(base) + ".fa").exists() and build and Path(build).exists():
                 subprocess.run([build, "-q", str(base) + ".fa", str(base)], check=True, stdout=subprocess.DEVNULL)
             elif not Path(str(base) + ".fa").exists():  # (a stand-in bowtie may answer from <index>.fa; a real one says what it misses)
-                continue
+                # the reference's bwtAlign dies here with bowtie's CalledProcessError (manifoldAlign.py:19): a class silently
+                # missing from the count tables is the one thing a parity switch must not do.  Only the optional spike-in
+                # library (manifoldAlign.py:86-89) may be absent.
+                if it == 9:
+                    outlog.write(f"WARNING: no spike-in index {base}.1.ebwt: pass skipped\n")
+                    continue
+                outlog.close()
+                raise FileNotFoundError(f"--backend bowtie: pass {it} ({colnames[1 + it]}): neither {base}.1.ebwt nor {base}.fa exists")
         seqs = pdDataFrame.index
         if it == 0:
             recs = [(q, q) for q in seqs if len(q) < 26]                      # :93

@@ -492,7 +492,9 @@ def read_text(path: str, stream: bool = False):
             need = _gz_reserve(path)  # its memory, promised under a lock; 0: the streamed route below
             if need:
                 return ParallelGzipStream(path, reserved=need)  # inflated on all cores, parsed beside; declines like the call below
-        need = _gz_reserve(path) if (sized and _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0" and not stream) else 0
+        # (MIRGE_GZ_PARALLEL=whole with stream=True lands here too: inflated whole first, then parsed -- the route README.md
+        # documents and bench.py's `inflated_whole_then_parsed` leg measures; a stream the branch above declined does as well)
+        need = _gz_reserve(path) if (sized and _os.environ.get("MIRGE_GZ_PARALLEL", "1") != "0") else 0
         if need:
             t0 = time.perf_counter()
             raw = np.fromfile(path, dtype=np.uint8)

@@ -546,8 +546,15 @@ __global__ void __launch_bounds__(256) k_part_compact(const uint32_t* __restrict
                                                        uint32_t* __restrict__ ufirst, uint32_t* __restrict__ n_out) {
     uint32_t end[MIRGE_DEDUP_SHARDS];  // (compile-time indices only: registers)
     uint32_t run = 0;
+    bool over = false;  // a shard that overflowed was left unwritten by some buckets (k_part_dedup set the overflow flag: the call is
+                        // redone): the group is published EMPTY, so that the cascade queued behind never walks uninitialised records
 #pragma unroll
-    for (int x = 0; x < MIRGE_DEDUP_SHARDS; x++) { run += min(shard_cur[x * MIRGE_DEDUP_SHARD_STRIDE], shard_cap); end[x] = run; }
+    for (int x = 0; x < MIRGE_DEDUP_SHARDS; x++) {
+        const uint32_t cx = shard_cur[x * MIRGE_DEDUP_SHARD_STRIDE];
+        over |= cx > shard_cap;
+        run += min(cx, shard_cap); end[x] = run;
+    }
+    if (over) run = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = run;
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < run; e += gridDim.x * blockDim.x) {
         uint32_t x = 0, lo = 0;

@@ -52,9 +52,14 @@ static uint32_t part_region_cap(double mean) {
 // copy that takes counts and histogram to the host (k_part_dedup no longer counts it; see the kernel)
 static void part_len_hist(mirge_ctx* c, const ReadGroup& out, const CollapseTmp& t, uint32_t* dmeta, int gi) {
     if (!t.partitioned || !out.len) return;
-    LaunchScope ls(c, "k_len_hist", 0.0);
-    hipLaunchKernelGGL(k_len_hist, dim3((unsigned)c->n_cu * 2), dim3(256), 0, c->aux, (const uint8_t*)out.len, (const uint32_t*)(dmeta + gi),
-                       dmeta + MIRGE_META_HIST);
+    hipStream_t const was = c->cur;
+    c->cur = c->aux;  // (LaunchScope records its events on c->cur: the kernel's stream, not the caller's)
+    {
+        LaunchScope ls(c, "k_len_hist", 0.0);
+        hipLaunchKernelGGL(k_len_hist, dim3((unsigned)c->n_cu * 2), dim3(256), 0, c->aux, (const uint8_t*)out.len, (const uint32_t*)(dmeta + gi),
+                           dmeta + MIRGE_META_HIST);
+    }
+    c->cur = was;
 }
 
 // partitioned key path after k_part_agg.  `part` 1: the second radix level (k_part_split is one workgroup per CU like
@@ -468,7 +473,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
                 collapse_tmp_release(c, tmp[gi]);
                 ReadGroup& og = R->g[gi];
-                c->release(og.seq); c->release(og.len); c->release(og.counts); c->release(og.first);
+                c->release(og.seq); c->release(og.len); c->release(og.nmask); c->release(og.counts); c->release(og.first);
                 og = ReadGroup();
             }
             c->flush_deferred();  // (alloc() hands cached blocks back to the driver by itself when a request fails)
@@ -535,8 +540,9 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         if (rc == 0 && c->pinned[MIRGE_META_OVERFLOW] && attempt < 2) {
             for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
                 collapse_tmp_release(c, tmp[gi]);
-                ReadGroup& og = R->g[gi];  // outputs the partitioned attempt had allocated at capacity n
-                c->release(og.seq); c->release(og.len); c->release(og.counts); c->release(og.first);
+                ReadGroup& og = R->g[gi];  // outputs the partitioned attempt had allocated at capacity n -- and, when the small
+                // groups' phase B ran ahead of the bulk group's count (small_ready), theirs: the `N` groups' nmask among them
+                c->release(og.seq); c->release(og.len); c->release(og.nmask); c->release(og.counts); c->release(og.first);
                 og = ReadGroup();
             }
             c->flush_deferred();

@@ -371,6 +371,16 @@ def test_gz_inflate_on_all_cores_equals_zlib(tmp_path):
         assert isinstance(st, collapse.GzipRecordStream) and b"".join(st) == text + text[:5000] + text
     finally:
         os.environ.pop("MIRGE_GZ_PARALLEL")
+    # MIRGE_GZ_PARALLEL=whole with stream=True (how fastpath and bench.py's `inflated_whole_then_parsed` leg call it): the WHOLE
+    # file inflated on all cores first, then handed over -- not the streamed zlib route (round 5's advisor found it fell there)
+    os.environ["MIRGE_GZ_PARALLEL"] = "whole"
+    try:
+        del collapse.GZ_LOG[:]
+        wt = collapse.read_text(str(p1), stream=True)
+        assert isinstance(wt, np.ndarray) and wt.tobytes() == text
+        assert collapse.GZ_LOG and "parallel_inflate_s" in collapse.GZ_LOG[-1]
+    finally:
+        os.environ.pop("MIRGE_GZ_PARALLEL")
     assert _ffi.gz_inflate(p1.read_bytes() + b"junk behind the member") is None
     assert _ffi.gz_inflate(gzip.compress(text[:100000], 6)) is None  # too small to cut
     bad = bytearray(p1.read_bytes())
