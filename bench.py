@@ -318,6 +318,131 @@ def fastq_text(reads):
     return text
 
 
+def write_fastq_file(reads, path, chunk=2_000_000):
+    """the sample as a FASTQ file, built 2 M reads at a time (fastq_text takes ~0.5 KB of host memory per read: eight ranks writing
+    20 M-read samples at once would want 80 GB)"""
+    from mirge3_amd.seqio import FlatSeqs
+    off = reads.offsets
+    with open(path, "wb") as fh:
+        for a in range(0, len(reads), chunk):
+            b = min(len(reads), a + chunk)
+            fastq_text(FlatSeqs(reads.data[int(off[a]):int(off[b])], off[a:b + 1] - off[a])).tofile(fh)
+    return os.path.getsize(path)
+
+
+class _GroupDist:
+    """torch.distributed's object collectives bound to ONE process group (a gloo group with a short timeout of its own: a rank
+    that fails inside the leg must cost the bench line two minutes, not the default group's ten)"""
+    def __init__(self, dist, group):
+        self._d, self._g = dist, group
+
+    def all_gather_object(self, out, obj):
+        return self._d.all_gather_object(out, obj, group=self._g)
+
+    def gather_object(self, obj, out=None, dst=0):
+        return self._d.gather_object(obj, out, dst=dst, group=self._g)
+
+    def broadcast_object_list(self, box, src=0):
+        return self._d.broadcast_object_list(box, src=src, group=self._g)
+
+    def barrier(self):
+        return self._d.barrier(group=self._g)
+
+
+def c4_end_to_end(args, dist, rank, world, sl, casc, reads, n_pass):
+    """BASELINE configs[3] as the PRODUCT runs it (never `value`): N FASTQ files on disk, one per rank -> every output file of the
+    sharded CLI, the run's ONE mapped.csv / unmapped.csv over the sorted union of all samples included (digest.py:243,
+    mirge/__main__.py:164-173).  `value` steps collapse -> cascade -> join per rank and never merges; this leg is the wall time
+    between two barriers around what `python -m torch.distributed.run ... -m mirge3_amd.cli -s S0.fastq,...` does with the libraries
+    resident: parse, collapse + cascade + join per rank, then the tail -- round 6: every rank merges, annotates, orders, formats and
+    pwrites ITS key range of the two files (fastpath.run_sharded_ranges); for comparison the same samples with rank 0 building the
+    joint table alone (round 5's route, MIRGE_SHARD_TAIL=rank0)."""
+    import datetime
+    import shutil
+    import tempfile
+    from types import SimpleNamespace
+    from mirge3_amd import fastpath, multigpu
+    if n_pass != 9:
+        return None
+    pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=180))
+    gd = _GroupDist(dist, pg)
+    box = [tempfile.mkdtemp(prefix="mirge_c4e2e_", dir="/tmp") if rank == 0 else None]
+    gd.broadcast_object_list(box, src=0)
+    tmp = box[0]
+    out = {}
+    try:
+        if rank == 0:
+            os.makedirs(os.path.join(tmp, "Libs", "bench", "annotation.Libs"))
+            with open(os.path.join(tmp, "Libs", "bench", "annotation.Libs", "bench_merges_miRBase.csv"), "w") as fh:
+                fh.write("".join(",".join(r) + "\n" for r in sl.merges))
+        fq = os.path.join(tmp, f"S{rank}.fastq")
+        fq_bytes = write_fastq_file(reads, fq)
+        names = [f"S{i}" for i in range(world)]
+        files = [os.path.join(tmp, f"S{i}.fastq") for i in range(world)]
+        a = SimpleNamespace(libraries_path=os.path.join(tmp, "Libs"), organism_name="bench", spikeIn=False, quiet=True, minimum_length=16,
+                            crThreshold="0.1", device=casc.ctx.device, isoform_entropy=False)
+
+        def one_run(label, ranges):
+            work = os.path.join(tmp, label)
+            if rank == 0:
+                os.makedirs(work)
+            gd.barrier()
+            t0 = time.perf_counter()
+            held = {} if ranges else None
+            tb = fastpath.run_sample_tables(a, files[rank], names[rank], rank, work, "miRBase", casc, True, False, hold=held)
+            t_sample = time.perf_counter() - t0
+            tables = multigpu.gather_tables([tb], rank, world, gd)
+            tm = {}
+            if ranges:
+                tm = fastpath.run_sharded_ranges(a, held, world, names, work, casc, rank, world, gd)
+                if rank == 0:
+                    fastpath.sharded_count_tables(a, tables, work, "miRBase", casc, tm)
+            elif rank == 0:
+                o = fastpath.run_sharded_rank0(a, tables, work, "miRBase", casc, timings=tm)
+                for h in ("uniq", "res"):
+                    if o["device"].get(h) is not None:
+                        o["device"][h].close()
+            gd.barrier()
+            wall = time.perf_counter() - t0
+            every = [None] * world
+            gd.all_gather_object(every, (wall, t_sample, {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items()
+                                                         if not isinstance(v, (list, dict))}))
+            res = {"wall_s": round(max(x[0] for x in every), 4), "M_reads_per_s": round(world * args.reads / max(x[0] for x in every) / 1e6, 2),
+                   "sample_s_per_rank": [round(x[1], 4) for x in every],
+                   "tail_s": round(max(x[0] for x in every) - max(x[1] for x in every), 4)}
+            if ranges:
+                res["range_tail_per_rank"] = [x[2] for x in every]
+            else:
+                res["rank0_tail"] = every[0][2]
+            if rank == 0:
+                res["output_bytes"] = {f: os.path.getsize(os.path.join(work, f)) for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv")}
+            return res, work
+
+        first, _ = one_run("ranges_first", True)   # pays for page-locked staging, buffer-pool blocks, the page cache
+        out["ranges"], w_r = one_run("ranges", True)
+        out["ranges"]["first_run_wall_s"] = first["wall_s"]
+        one_run("rank0_first", False)
+        out["rank0_alone"], w_0 = one_run("rank0", False)
+        if rank == 0:
+            import subprocess
+            out["same_files_both_tails"] = all(subprocess.run(["cmp", "-s", os.path.join(w_r, f), os.path.join(w_0, f)]).returncode == 0
+                                               for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "annotation.report.csv"))
+        out["fastq_MB_per_sample"] = round(fq_bytes / 1e6, 1)
+        out["speedup_over_rank0_alone"] = round(out["rank0_alone"]["wall_s"] / max(out["ranges"]["wall_s"], 1e-9), 3)
+        out["note"] = ("wall time between two barriers: every rank's FASTQ file on disk -> parse + collapse + cascade + join on its GPU -> the run's "
+                       "count tables and ONE mapped.csv / unmapped.csv (sorted union of all samples, one count column each); libraries resident; "
+                       "`ranges` = every rank writes its key range of the two files, `rank0_alone` = round 5's route; second run of each (the first "
+                       "pays for page-locked staging and pool blocks); tail_s = wall - the slowest rank's own sample; never `value`")
+    finally:
+        try:
+            gd.barrier()
+        except Exception:  # noqa: BLE001
+            pass
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def write_gzip_level6(text, path, piece=4 << 20):
     """`text` as ONE gzip member at level 6, compressed in independent pieces on all cores (pigz -i's construction: every
     piece its own raw deflate stream ended with a sync flush, the last one with the final block): what a user's
@@ -564,6 +689,8 @@ def main():
                     help="rank 0, N=1: also measure the step with TWO samples in flight on two contexts (never `value`)")
     ap.add_argument("--read-sets", dest="read_sets", type=int, default=1,
                     help="rank 0, N=1, c3: also step SURVEY 8(d)'s Zipf-pool (U/N ~ 5 %%) and all-distinct (U = N) read sets (never `value`)")
+    ap.add_argument("--c4-end-to-end", dest="c4_e2e", type=int, default=1,
+                    help="N > 1: also time the sharded CLI's whole route, FASTQ files -> all output files, tail included (never `value`)")
     ap.add_argument("--pmc", type=int, default=1,
                     help="rank 0, N=1: measure the dominant kernel's HBM traffic with two child rocprofv3 --pmc passes")
     args = ap.parse_args()
@@ -950,6 +1077,16 @@ def main():
                 out["cli_path"] = {"error": repr(e)[:300]}
         del text
 
+    # ---------------- BASELINE configs[3] end to end (never `value`): all ranks, N > 1 -- the product's route with its tail
+    if dist is not None and world > 1 and args.c4_e2e and args.workload in ("c3", "c4") and not args.pool:
+        try:
+            e2e = c4_end_to_end(args, dist, rank, world, sl, casc, reads, n_pass)
+            if rank == 0 and e2e is not None:
+                out["c4_end_to_end"] = e2e
+        except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the line down
+            if rank == 0:
+                out["c4_end_to_end"] = {"error": repr(e)[:400]}
+
     # ---------------- two samples in flight (never `value`): what a batch of samples per GPU runs at -- a second context (its own
     # streams, its own copy of the libraries) steps a second sample from a second host thread; the collapse of one sample (LDS-
     # and write-bound) overlaps the cascade of the other (bound by L1 misses in flight)
@@ -1168,7 +1305,10 @@ def main():
     raw.close()
     casc.close()
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 -- the line is out; a group a secondary leg left in a timed-out state must not turn rc != 0
+            pass
 
 
 if __name__ == "__main__":

@@ -276,6 +276,30 @@ int mirge_annotation_csv_device(mirge_ctx* ctx, const mirge_reads* uniq, const m
                                 int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
                                 const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n);
 
+/* ---- the sharded run's parallel tail (round 6).  The reference's ONE mapped.csv / unmapped.csv hold the sorted union of all
+ * samples' sequences with one count column per sample (the outer join of mirge/libs/digest.py:243, written at
+ * mirge/__main__.py:164-173).  With one sample per GPU the union's key space is cut into one range per rank by the first 21
+ * bases of that order; every rank merges, annotates, orders and formats ITS stretch of the two files.
+ *   mirge_reads_range_sample   k evenly spaced quantiles of a dictionary's first-word sort keys (3 bits per base: end 0, A 1, C 2,
+ *                              G 3, N 4, T 5; 21 bases, most significant first -- Python's string order).  The ranks pool them.
+ *   mirge_reads_range_split    the dictionary as host arrays ordered by (owner range, handle index): range q =
+ *                              [splitters[q-1], splitters[q]) of that key; bounds_out[q] .. bounds_out[q+1] are its rows.
+ *                              ascii_out / off_out as mirge_reads_unpack, counts_out [n][n_samples].  n_parts <= 256.
+ *   mirge_annotation_csv_device_sizes   bytes_out[0] / [1] = bytes the listed rows take in mapped.csv / unmapped.csv.
+ *   mirge_annotation_csv_device_at      the rows' text at the given offsets of the two EXISTING files (no header, no
+ *                                       truncation): the caller created them at their final size from every rank's sizes. */
+int mirge_reads_range_sample(mirge_ctx* ctx, const mirge_reads* uniq, int32_t k, uint64_t* keys_out);
+int mirge_reads_range_split(mirge_ctx* ctx, const mirge_reads* uniq, const uint64_t* splitters, int32_t n_parts, char* ascii_out,
+                            int64_t* offsets_out, uint32_t* counts_out, int64_t* bounds_out);
+int mirge_annotation_csv_device_sizes(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, const int64_t* rows,
+                                      int64_t n_rows, int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                      const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n,
+                                      int64_t* bytes_out);
+int mirge_annotation_csv_device_at(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, const char* mapped_path,
+                                   const char* unmapped_path, int64_t mapped_off, int64_t unmapped_off, const int64_t* rows,
+                                   int64_t n_rows, int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                   const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n);
+
 /* ---- per-position variant tally / A-to-I counting core (BASELINE config 5): replaces
  * align2TargetSeq / judgeAllign / A2IEditing / mismatchCountAnalysis (mirge2_tRF_a2i.py:246-518) and the membership
  * rules of a2i_editing (:988-1016) for the reads the cascade annotated to a miRNA in exact_pass / iso_pass.

@@ -26,6 +26,7 @@ EXPORTS = [
     "mirge_reads_n_samples", "mirge_reads_group_counts", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
+    "mirge_reads_range_sample", "mirge_reads_range_split", "mirge_annotation_csv_device_sizes", "mirge_annotation_csv_device_at",
     "mirge_cascade_prepare", "mirge_cascade_walks", "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
@@ -502,6 +503,27 @@ class DeviceReads:
         _check(load().mirge_collapse_order_sorted(self.ctx._h, self._h, _p(order)), "mirge_collapse_order_sorted")
         return order
 
+    def range_sample(self, k: int = 256) -> np.ndarray:
+        """k evenly spaced quantiles of the dictionary's first-word sort keys (``mirge_reads_range_sample``): what a rank puts
+        into the pool the sharded run's range splitters are chosen from (``multigpu.choose_splitters``)"""
+        out = np.zeros(int(k), dtype=np.uint64)
+        _check(load().mirge_reads_range_sample(self.ctx._h, self._h, C.c_int32(int(k)), _p(out)), "mirge_reads_range_sample")
+        return out
+
+    def range_split(self, splitters: np.ndarray):
+        """The dictionary ordered by (owner range, handle index) -> (FlatSeqs, counts [U, S] uint32, bounds int64 [n_parts + 1]);
+        range q = keys in [splitters[q-1], splitters[q]) = rows bounds[q] .. bounds[q+1] (``mirge_reads_range_split``)."""
+        sp = np.ascontiguousarray(splitters, dtype=np.uint64)
+        n_parts = int(sp.shape[0]) + 1
+        n, S = len(self), max(self.n_samples, 1)
+        off = np.zeros(n + 1, dtype=np.int64)
+        data = np.empty(max(load().mirge_reads_total_bases(self._h), 1), dtype=np.uint8)
+        cnt = np.zeros((n, S), dtype=np.uint32)
+        bounds = np.zeros(n_parts + 1, dtype=np.int64)
+        _check(load().mirge_reads_range_split(self.ctx._h, self._h, _p(sp) if sp.size else C.c_void_p(0), C.c_int32(n_parts), _p(data),
+                                              _p(off), _p(cnt) if cnt.size else C.c_void_p(0), _p(bounds)), "mirge_reads_range_split")
+        return FlatSeqs(data[:off[-1]], off), cnt, bounds
+
     def nonzero_per_sample(self) -> np.ndarray:
         """unique reads with a count, per sample column (``mirge_collapse_nonzero``)"""
         out = np.zeros(max(self.n_samples, 1), dtype=np.int64)
@@ -691,13 +713,9 @@ def annotation_csv(mapped_path, unmapped_path, header: str, seqs: FlatSeqs, ps: 
            "mirge_annotation_csv")
 
 
-def annotation_csv_device(ctx: "Context", uniq: "DeviceReads", res: "CascadeResult", mapped_path, unmapped_path, header: str,
-                          rows: np.ndarray, col_of_pass: Sequence[int], n_name_cols: int,
-                          names_by_pass: Sequence[Optional[FlatSeqs]]) -> bool:
-    """``mapped.csv`` / ``unmapped.csv`` formatted on the GPU from the device-resident reads, counts and annotation
-    (``mirge_annotation_csv_device``).  False: a reference name needs CSV quoting -- call ``annotation_csv`` instead."""
+def _name_tables(col_of_pass, names_by_pass):
+    """ctypes views of the per-pass reference-name tables the CSV formatters take (+ the arrays that must outlive the call)"""
     n_pass = len(col_of_pass)
-    rows = np.ascontiguousarray(rows, dtype=np.int64)
     col = (C.c_int32 * n_pass)(*[int(x) for x in col_of_pass])
     keep = []
     nd, no, nn = (C.c_void_p * n_pass)(), (C.c_void_p * n_pass)(), (C.c_int64 * n_pass)()
@@ -710,6 +728,43 @@ def annotation_csv_device(ctx: "Context", uniq: "DeviceReads", res: "CascadeResu
         o = np.ascontiguousarray(fs.offsets, dtype=np.int64)
         keep += [d, o]
         nd[p], no[p], nn[p] = d.ctypes.data if d.size else None, o.ctypes.data, len(fs)
+    return n_pass, col, nd, no, nn, keep
+
+
+def annotation_csv_device_sizes(ctx: "Context", uniq: "DeviceReads", res: "CascadeResult", rows: np.ndarray, col_of_pass: Sequence[int],
+                                n_name_cols: int, names_by_pass: Sequence[Optional[FlatSeqs]]):
+    """(bytes in mapped.csv, bytes in unmapped.csv) the listed rows take (``mirge_annotation_csv_device_sizes``): a rank's stretch of
+    a sharded run's files; None when a reference name needs CSV quoting (the run then takes rank 0's host route)."""
+    n_pass, col, nd, no, nn, keep = _name_tables(col_of_pass, names_by_pass)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    out = np.zeros(2, dtype=np.int64)
+    rc = load().mirge_annotation_csv_device_sizes(ctx._h, uniq._h, res._h, _p(rows) if rows.size else C.c_void_p(0), C.c_int64(rows.shape[0]),
+                                                  C.c_int32(n_pass), col, C.c_int32(n_name_cols), nd, no, nn, _p(out))
+    if rc == -4:
+        return None
+    _check(rc, "mirge_annotation_csv_device_sizes")
+    return int(out[0]), int(out[1])
+
+
+def annotation_csv_device_at(ctx: "Context", uniq: "DeviceReads", res: "CascadeResult", mapped_path, unmapped_path, mapped_off: int,
+                             unmapped_off: int, rows: np.ndarray, col_of_pass: Sequence[int], n_name_cols: int,
+                             names_by_pass: Sequence[Optional[FlatSeqs]]):
+    """The listed rows' text at the given byte offsets of the two EXISTING files (``mirge_annotation_csv_device_at``)."""
+    n_pass, col, nd, no, nn, keep = _name_tables(col_of_pass, names_by_pass)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    _check(load().mirge_annotation_csv_device_at(ctx._h, uniq._h, res._h, str(mapped_path).encode(), str(unmapped_path).encode(),
+                                                 C.c_int64(int(mapped_off)), C.c_int64(int(unmapped_off)),
+                                                 _p(rows) if rows.size else C.c_void_p(0), C.c_int64(rows.shape[0]), C.c_int32(n_pass), col,
+                                                 C.c_int32(n_name_cols), nd, no, nn), "mirge_annotation_csv_device_at")
+
+
+def annotation_csv_device(ctx: "Context", uniq: "DeviceReads", res: "CascadeResult", mapped_path, unmapped_path, header: str,
+                          rows: np.ndarray, col_of_pass: Sequence[int], n_name_cols: int,
+                          names_by_pass: Sequence[Optional[FlatSeqs]]) -> bool:
+    """``mapped.csv`` / ``unmapped.csv`` formatted on the GPU from the device-resident reads, counts and annotation
+    (``mirge_annotation_csv_device``).  False: a reference name needs CSV quoting -- call ``annotation_csv`` instead."""
+    n_pass, col, nd, no, nn, keep = _name_tables(col_of_pass, names_by_pass)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
     enc = lambda x: None if x is None else str(x).encode()
     rc = load().mirge_annotation_csv_device(ctx._h, uniq._h, res._h, enc(mapped_path), enc(unmapped_path), header.encode(),
                                             _p(rows) if rows.size else C.c_void_p(0), C.c_int64(rows.shape[0]), C.c_int32(n_pass),

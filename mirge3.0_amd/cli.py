@@ -274,22 +274,41 @@ def main(argv=None):
             sys.exit("-spl / -rr are single-process options")
         via_files = multigpu.directory_is_shared(workDir, rank, world, dist)  # False on a node that does not see rank 0's directory
 
+        # round 6: the run's ONE mapped.csv / unmapped.csv written range by range by EVERY rank (fastpath.run_sharded_ranges) when the
+        # run allows it and every rank sees the run's directory; else rank 0 builds the joint table alone (round 5's route)
+        use_ranges = via_files and fastpath.parallel_tail_eligible(args, len(files), world, casc)
+        held = {} if use_ranges else None
+
         def process(i):  # device-resident per sample (fastpath.run_sample_tables)
             return fastpath.run_sample_tables(args, files[i], base_names[i], i, workDir, ref_db, casc, via_files,
-                                              dictionary_order=len(files) == 1)
+                                              dictionary_order=len(files) == 1, hold=held)
 
         t_shard = time.perf_counter()
         tables = multigpu.run_sharded(len(files), rank, world, process, dist)
         t_gather = time.perf_counter()
+        tm_ranges = None
+        if use_ranges:
+            tm_ranges = fastpath.run_sharded_ranges(args, held, len(files), base_names, workDir, casc, rank, world, dist)
+            every_tm = [None] * world if rank == 0 else None
+            dist.gather_object({k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm_ranges.items()}, every_tm, dst=0)
         if rank == 0:  # the same files as the one-process run: count tables, ONE mapped.csv / unmapped.csv, -gff / -ai / -ie
             tm = {}
-            fastpath.run_sharded_rank0(args, tables, workDir, ref_db, casc, timings=tm)
+            if use_ranges:
+                t_ct = time.perf_counter()
+                fastpath.sharded_count_tables(args, tables, workDir, ref_db, casc, tm)
+                tm["ranges_tail_per_rank"] = every_tm
+                tm["rank0_tail_s"] = tm_ranges["range_tail_s"] + (time.perf_counter() - t_ct)
+                tm["range_tail_s_slowest_rank"] = max(x["range_tail_s"] for x in every_tm)
+            else:
+                fastpath.run_sharded_rank0(args, tables, workDir, ref_db, casc, timings=tm)
             # where a sharded run's time goes: every rank's sample, then rank 0's serial tail
             import json
             import resource
             line = {"ranks": world, "samples": len(files), "samples_and_gather_s": round(t_gather - t_shard, 4),
                     "per_sample": [dict(t.timing or {}, name=t.name, index=t.index) for t in tables],
+                    "tail": "ranges (every rank its stretch of mapped.csv / unmapped.csv)" if use_ranges else "rank 0 alone",
                     "rank0_tail": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items() if not isinstance(v, (list, dict))},
+                    "ranges_tail_per_rank": tm.get("ranges_tail_per_rank"),
                     "rank0_peak_rss_MB": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0, 1)}
             with open(workDir / "run.log", "a+") as fh:
                 fh.write("sharded run timing: " + json.dumps(line) + "\n")

@@ -147,6 +147,40 @@ __global__ void k_lexkey(CsvTables t, const uint32_t* __restrict__ perm, uint32_
         keys[k] = key;
     }
 }
+// ------------------------------------------------------------------------------------------
+// Range partition of a dictionary by the FIRST word of that order (round 6: the sharded run's parallel tail, multigpu.py).
+// Rank q of a sharded run owns the reads whose word-0 key lies in [splitter[q-1], splitter[q]): reads that agree in their first
+// 21 bases have one owner, and the owners' ranges are consecutive stretches of the run's sorted union (digest.py:243) -- so
+// every rank can merge, annotate, order and format ITS stretch of mapped.csv / unmapped.csv (mirge/__main__.py:164-173).
+//   k_range_owner : owner[i] = number of splitters <= key[i]                       (n_split <= 255)
+//   k_invert_perm : pos[perm[k]] = k
+//   k_part_bounds : bounds[q] = first position of part q in the owner-sorted order (bounds pre-filled with n)
+//   k_scatter_rows: out[pos[base + j]][0..S) = counts[j][0..S)
+// ------------------------------------------------------------------------------------------
+__global__ void k_range_owner(const unsigned long long* __restrict__ keys, uint32_t n, const unsigned long long* __restrict__ split,
+                              int32_t n_split, uint32_t* __restrict__ owner) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        int lo = 0, hi = n_split;  // first splitter > k
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (split[mid] <= k) lo = mid + 1; else hi = mid; }
+        owner[i] = (uint32_t)lo;
+    }
+}
+__global__ void k_invert_perm(const uint32_t* __restrict__ perm, uint32_t n, uint32_t* __restrict__ pos) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) pos[perm[k]] = k;
+}
+__global__ void k_part_bounds(const uint32_t* __restrict__ owner_sorted, uint32_t n, unsigned long long* __restrict__ bounds) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t cur = owner_sorted[k];
+        const uint32_t from = k ? owner_sorted[k - 1] + 1u : 0u;
+        for (uint32_t q = from; q <= cur; q++) bounds[q] = k;  // (parts nobody falls into start where the next one does)
+    }
+}
+__global__ void k_scatter_rows(const uint32_t* __restrict__ counts, uint32_t n, int32_t S, const uint32_t* __restrict__ pos,
+                               uint32_t* __restrict__ out) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        for (int32_t s = 0; s < S; s++) out[(size_t)pos[j] * S + s] = counts[(size_t)j * S + s];
+}
 __global__ void k_iota(uint32_t* __restrict__ out, uint32_t n) {
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) out[k] = k;
 }

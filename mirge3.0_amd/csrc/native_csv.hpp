@@ -10,10 +10,44 @@
 // reads, their count matrix and the cascade's annotation where they lie; what crosses PCIe is the files' text (page-locked
 // staging kept in the ctx), written by several threads with positional writes while later chunks are still arriving.
 // Reference names that need CSV quoting are refused (-4): the caller then formats on the host (mirge_annotation_csv).
+// `mode` 0: the two files whole (created, header first).  1: only the bytes the rows would take (bytes_out[0] mapped, [1]
+// unmapped; nothing is formatted or written).  2: the rows' text at file offsets file_off[0] / [1] of files that exist
+// (no header, no truncation): ONE rank's stretch of a sharded run's files (round 6, fastpath.run_sharded_ranges) -- rank 0
+// has created them at their final size from the ranks' mode-1 answers.
+static int annotation_csv_device_impl(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const char* mapped_path,
+                                      const char* unmapped_path, const char* header, const int64_t* rows, int64_t n_rows,
+                                      int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                      const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n,
+                                      int mode, int64_t* bytes_out, const int64_t* file_off);
 extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const char* mapped_path,
                                            const char* unmapped_path, const char* header, const int64_t* rows, int64_t n_rows,
                                            int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
                                            const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n) {
+    return annotation_csv_device_impl(c, U, res, mapped_path, unmapped_path, header, rows, n_rows, n_pass, col_of_pass, n_name_cols,
+                                      name_data, name_off, name_n, 0, nullptr, nullptr);
+}
+extern "C" int mirge_annotation_csv_device_sizes(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const int64_t* rows,
+                                                 int64_t n_rows, int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                                 const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n,
+                                                 int64_t* bytes_out) {
+    if (!bytes_out) return fail(-1, "mirge_annotation_csv_device_sizes: bad argument");
+    return annotation_csv_device_impl(c, U, res, "", "", "", rows, n_rows, n_pass, col_of_pass, n_name_cols, name_data, name_off, name_n,
+                                      1, bytes_out, nullptr);
+}
+extern "C" int mirge_annotation_csv_device_at(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const char* mapped_path,
+                                              const char* unmapped_path, int64_t mapped_off, int64_t unmapped_off, const int64_t* rows,
+                                              int64_t n_rows, int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                              const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n) {
+    if (!mapped_path || !unmapped_path || mapped_off < 0 || unmapped_off < 0) return fail(-1, "mirge_annotation_csv_device_at: bad argument");
+    const int64_t off[2] = {mapped_off, unmapped_off};
+    return annotation_csv_device_impl(c, U, res, mapped_path, unmapped_path, "", rows, n_rows, n_pass, col_of_pass, n_name_cols, name_data,
+                                      name_off, name_n, 2, nullptr, off);
+}
+static int annotation_csv_device_impl(mirge_ctx* c, const mirge_reads* U, const mirge_result* res, const char* mapped_path,
+                                      const char* unmapped_path, const char* header, const int64_t* rows, int64_t n_rows,
+                                      int32_t n_pass, const int32_t* col_of_pass, int32_t n_name_cols,
+                                      const char* const* name_data, const int64_t* const* name_off, const int64_t* name_n,
+                                      int mode, int64_t* bytes_out, const int64_t* file_off) {
     if (!c || !U || !res || !header || (!rows && n_rows) || n_rows < 0 || n_pass < 1 || n_pass > MIRGE_MAX_PASSES || !col_of_pass ||
         n_name_cols < 0 || !name_data || !name_off || !name_n || U->n_samples < 1 || res->n != U->n || n_rows >= 0xFFFFFFF0ll)
         return fail(-1, "mirge_annotation_csv_device: bad argument");
@@ -102,6 +136,7 @@ extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, c
         if (hflag) { rc = fail(-1, "mirge_annotation_csv_device: pass or reference index out of range"); break; }
         bytes_m = mapped_path ? (size_t)tot[0] : 0;
         bytes_u = unmapped_path ? (size_t)tot[1] : 0;
+        if (mode == 1) { bytes_out[0] = (int64_t)tot[0]; bytes_out[1] = (int64_t)tot[1]; break; }
         if (bytes_m && (rc = dalloc(c, &out_m, bytes_m))) break;
         if (bytes_u && (rc = dalloc(c, &out_u, bytes_u))) break;
         if (n_rows && (bytes_m || bytes_u)) {
@@ -134,7 +169,7 @@ extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, c
                 e = hipMemcpyAsync(c->csv_pinned + pin0 + at, dsrc + at, nn, hipMemcpyDeviceToHost, c->stream);
                 hipEvent_t ev = c->get_evt();
                 if (e == hipSuccess) e = hipEventRecord(ev, c->stream);
-                chunks.push_back(Chunk{which, pin0 + at, hl + at, nn, ev});
+                chunks.push_back(Chunk{which, pin0 + at, (mode == 2 ? (size_t)file_off[which] : hl) + at, nn, ev});
             }
         }
         if (e != hipSuccess) { rc = fail(-2, std::string("mirge_annotation_csv_device: ") + hipGetErrorString(e)); }
@@ -142,6 +177,12 @@ extern "C" int mirge_annotation_csv_device(mirge_ctx* c, const mirge_reads* U, c
         const char* paths[2] = {mapped_path, unmapped_path};
         for (int which = 0; which < 2 && rc == 0; which++) {
             if (!paths[which]) continue;
+            if (mode == 2) {  // a stretch of a file that exists at its final size: no header, nothing truncated
+                if ((which == 0 ? bytes_m : bytes_u) == 0) continue;
+                fd[which] = ::open(paths[which], O_WRONLY, 0644);
+                if (fd[which] < 0) rc = fail(-8, std::string("cannot open ") + paths[which]);
+                continue;
+            }
             fd[which] = ::open(paths[which], O_WRONLY | O_CREAT | O_TRUNC, 0644);
             if (fd[which] < 0 || ::pwrite(fd[which], header, hl, 0) != (ssize_t)hl) rc = fail(-8, std::string("cannot write ") + paths[which]);
         }
@@ -239,6 +280,110 @@ extern "C" int mirge_collapse_order_sorted(mirge_ctx* c, const mirge_reads* U, i
     } while (0);
     (void)hipStreamSynchronize(c->stream);
     c->release(keys); c->release(keys2); c->release(perm); c->release(perm2); c->release(tmp);
+    return rc;
+}
+
+// The sharded run's parallel tail (round 6; multigpu.py, fastpath.run_sharded_ranges).  The run's ONE mapped.csv / unmapped.csv
+// hold the sorted union of all samples' sequences (digest.py:243, mirge/__main__.py:164-173); instead of rank 0 merging every
+// dictionary alone, the joint key space is cut into one range per rank by the word-0 key of that order (k_lexkey, 21 bases).
+//   mirge_reads_range_sample : k evenly spaced quantiles of this dictionary's word-0 keys (the ranks pool them: the splitters)
+//   mirge_reads_range_split  : the dictionary's reads, lengths and counts as host arrays ordered by (owner range, handle index),
+//                              bounds_out[q] .. bounds_out[q + 1] = the rows of range q -- each stretch goes to its owner
+extern "C" int mirge_reads_range_sample(mirge_ctx* c, const mirge_reads* U, int32_t k, uint64_t* keys_out) {
+    if (!c || !U || k < 1 || k > (1 << 20) || !keys_out) return fail(-1, "mirge_reads_range_sample: bad argument");
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
+    const size_t n = (size_t)U->n;
+    if (n >= 0x7FFFFFFFull) return fail(-5, "mirge_reads_range_sample: 2^31 unique reads or more");
+    if (!n) { for (int32_t i = 0; i < k; i++) keys_out[i] = ~0ull; return 0; }  // (an empty dictionary votes for nothing: see multigpu.choose_splitters)
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+        if (U->g[gi].n && U->g[gi].orig) return fail(-1, "mirge_reads_range_sample: handle is not a collapse result");
+    CsvTables t;
+    csv_tables_of(U, nullptr, t);
+    unsigned long long *keys = nullptr, *keys2 = nullptr;
+    uint32_t* perm = nullptr;
+    void* tmp = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = dalloc(c, &keys, n))) break;
+        if ((rc = dalloc(c, &keys2, n))) break;
+        if ((rc = dalloc(c, &perm, n))) break;
+        size_t tb = 0;
+        hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tb, keys, keys2, (int)n, 0, 63, c->stream);
+        if (e == hipSuccess && (rc = dalloc(c, (uint8_t**)&tmp, std::max<size_t>(tb, 16)))) break;
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, perm, (uint32_t)n);
+        hipLaunchKernelGGL(k_lexkey, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, t, perm, (uint32_t)n, 0, keys);
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(tmp, tb, keys, keys2, (int)n, 0, 63, c->stream);
+        for (int32_t i = 0; i < k && e == hipSuccess; i++) {
+            const size_t at = std::min(n - 1, (size_t)((2 * (uint64_t)i + 1) * (uint64_t)n / (2 * (uint64_t)k)));  // (n < 2^31, k small)
+            e = hipMemcpyAsync(&keys_out[i], keys2 + at, 8, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_reads_range_sample: ") + hipGetErrorString(e)); break; }
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(keys); c->release(keys2); c->release(perm); c->release(tmp);
+    return rc;
+}
+
+extern "C" int mirge_reads_range_split(mirge_ctx* c, const mirge_reads* U, const uint64_t* splitters, int32_t n_parts, char* ascii_out,
+                                       int64_t* off_out, uint32_t* counts_out, int64_t* bounds_out) {
+    if (!c || !U || n_parts < 1 || n_parts > 256 || (n_parts > 1 && !splitters) || !off_out || !bounds_out || U->n_samples < 1 ||
+        (U->n && !counts_out) || (U->total_bases > 0 && !ascii_out))
+        return fail(-1, "mirge_reads_range_split: bad argument");
+    for (int32_t q = 1; q + 1 < n_parts; q++)
+        if (splitters[q] < splitters[q - 1]) return fail(-1, "mirge_reads_range_split: splitters must ascend");
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
+    const size_t n = (size_t)U->n;
+    if (n >= 0x7FFFFFFFull) return fail(-5, "mirge_reads_range_split: 2^31 unique reads or more");
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+        if (U->g[gi].n && U->g[gi].orig) return fail(-1, "mirge_reads_range_split: handle is not a collapse result");
+    if (!n) { off_out[0] = 0; for (int32_t q = 0; q <= n_parts; q++) bounds_out[q] = 0; return 0; }
+    const int32_t S = U->n_samples;
+    CsvTables t;
+    csv_tables_of(U, nullptr, t);
+    unsigned long long *keys = nullptr, *dsplit = nullptr, *dbounds = nullptr;
+    uint32_t *iota = nullptr, *owner = nullptr, *owner2 = nullptr, *perm = nullptr, *pos = nullptr, *dcnt = nullptr;
+    void* tmp = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = dalloc(c, &keys, n))) break;
+        if ((rc = dalloc(c, &dsplit, (size_t)n_parts))) break;
+        if ((rc = dalloc(c, &dbounds, (size_t)n_parts + 1))) break;
+        if ((rc = dalloc(c, &iota, n))) break;
+        if ((rc = dalloc(c, &owner, n))) break;
+        if ((rc = dalloc(c, &owner2, n))) break;
+        if ((rc = dalloc(c, &perm, n))) break;
+        if ((rc = dalloc(c, &pos, n))) break;
+        if ((rc = dalloc(c, &dcnt, n * (size_t)S))) break;
+        int bits = 1;
+        while ((1 << bits) < n_parts) bits++;
+        size_t tb = 0;
+        hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, tb, owner, owner2, iota, perm, (int)n, 0, bits, c->stream);
+        if (e == hipSuccess && (rc = dalloc(c, (uint8_t**)&tmp, std::max<size_t>(tb, 16)))) break;
+        std::vector<unsigned long long> hb((size_t)n_parts + 1, (unsigned long long)n);
+        if (e == hipSuccess) e = hipMemcpyAsync(dbounds, hb.data(), hb.size() * 8, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && n_parts > 1) e = hipMemcpyAsync(dsplit, splitters, (size_t)(n_parts - 1) * 8, hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, iota, (uint32_t)n);
+        hipLaunchKernelGGL(k_lexkey, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, t, iota, (uint32_t)n, 0, keys);
+        hipLaunchKernelGGL(k_range_owner, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, keys, (uint32_t)n, dsplit, n_parts - 1, owner);
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, tb, owner, owner2, iota, perm, (int)n, 0, bits, c->stream);  // stable: handle order inside a part
+        hipLaunchKernelGGL(k_invert_perm, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, perm, (uint32_t)n, pos);
+        hipLaunchKernelGGL(k_part_bounds, dim3(grid_for(c, n)), dim3(MIRGE_BLOCK), 0, c->stream, owner2, (uint32_t)n, dbounds);
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+            const ReadGroup& g = U->g[gi];
+            if (g.n) hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, g.counts, g.n, S, pos + g.base, dcnt);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), dbounds, hb.size() * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(counts_out, dcnt, n * (size_t)S * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc = fail(-2, std::string("mirge_reads_range_split: ") + hipGetErrorString(e)); break; }
+        for (int32_t q = 0; q <= n_parts; q++) bounds_out[q] = (int64_t)hb[(size_t)q];
+        bounds_out[0] = 0;
+        rc = reads_unpack_impl(c, U, ascii_out, off_out, pos);
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(keys); c->release(dsplit); c->release(dbounds); c->release(iota); c->release(owner); c->release(owner2); c->release(perm);
+    c->release(pos); c->release(dcnt); c->release(tmp);
     return rc;
 }
 

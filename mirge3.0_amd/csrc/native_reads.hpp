@@ -690,9 +690,22 @@ static int launch_unpack(mirge_ctx* c, const ReadGroup& g, const int64_t* doff, 
     return 0;
 }
 
+// `dpos` (device, [n], or nullptr): read with handle index i goes to row dpos[i] of the output instead of row i (the range
+// split of a dictionary, native_csv.hpp; the handle must then be a collapse result -- no `orig` lists)
+static int reads_unpack_impl(mirge_ctx* c, const mirge_reads* R, char* ascii_out, int64_t* off_out, const uint32_t* dpos);
 extern "C" int mirge_reads_unpack(mirge_ctx* c, const mirge_reads* R, char* ascii_out, int64_t* off_out) {
     if (!c || !R || !off_out || (R->total_bases > 0 && !ascii_out)) return fail(-1, "mirge_reads_unpack: bad argument");
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
+    return reads_unpack_impl(c, R, ascii_out, off_out, nullptr);
+}
+static int reads_unpack_impl(mirge_ctx* c, const mirge_reads* R0, char* ascii_out, int64_t* off_out, const uint32_t* dpos) {
+    mirge_reads Rv = *R0;  // (a view: with dpos every group's `orig` is its stretch of the position list)
+    if (dpos)
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+            if (Rv.g[gi].n && Rv.g[gi].orig) return fail(-1, "reads_unpack_impl: a row order needs a collapse result");
+            Rv.g[gi].orig = const_cast<uint32_t*>(dpos) + Rv.g[gi].base;
+        }
+    const mirge_reads* R = &Rv;
     const int64_t n = R->n;
     int32_t* dlen = nullptr;
     CHECK(dalloc(c, &dlen, (size_t)std::max<int64_t>(n, 1)));

@@ -63,7 +63,7 @@ def names_by_pass(casc) -> list:
 
 
 def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: str, casc=None, via_files: bool = True,
-                      dictionary_order: bool = False):
+                      dictionary_order: bool = False, hold: dict = None):
     """One sample on this process's GPU, for the sharded CLI (one sample per rank, multigpu.py): device-resident parse ->
     collapse + cascade -> count join.  Returns the sample's ``SampleTables`` (a few kB: its columns of the count tables)
     with its ``SampleReads`` attached (unique reads and counts: what rank 0 needs for the run's ONE mapped.csv /
@@ -84,6 +84,13 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
     raw.close()
     cls, ex, iso = _ffi.count_join(ctx, uniq, res, EXACT_PASS, ISO_PASS, len(casc.libs["mirna"]))
     t_tail = time.perf_counter()
+    if hold is not None:
+        # the parallel tail (run_sharded_ranges): the dictionary stays on the device until the run's range splitters are known
+        out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0], iupac=bool(iupac))
+        res.close()
+        hold[index] = uniq
+        out.timing = {"sample_s": round(time.perf_counter() - t_sample, 4), "unique_reads": int(len(uniq))}
+        return out
     counts, _ = uniq.counts()
     seqs = uniq.unpack()
     cnt = counts[:, 0]
@@ -92,7 +99,7 @@ def run_sample_tables(args, file: str, name: str, index: int, workDir, ref_db: s
         # their sequences, digest.py:243): at C4's size the host-side reordering of 7.8 M ragged reads was 2.4 of a rank's 2.9 s
         order = uniq.first_appearance_order()
         seqs, cnt = seqs.take(order), cnt[order]
-    out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0])
+    out = multigpu.SampleTables(index, name, n_rec, n_trimmed, len(uniq), cls[:, 0], ex[:, 0], iso[:, 0], iupac=bool(iupac))
     # (round 5: no annotation travels -- it depends on the sequence alone, and rank 0 annotates the run's joint table on its own
     # GPU in milliseconds, which puts that table's mapped.csv / unmapped.csv on the device-formatted route; lengths as bytes
     # or 16-bit words instead of 64-bit offsets: 30 B per unique read instead of 47)
@@ -285,6 +292,24 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
     return out
 
 
+def sharded_count_tables(args, tables, workDir, ref_db: str, casc, tm: Dict[str, float]):
+    """Rank 0 of the sharded CLI: the run's count tables (miR.Counts.csv, miR.RPM.csv, annotation.report.*) from the ranks' own
+    per-sample columns (a few kB each) -- summary.py:686-798,882-901 on R x S tables; -> (finish_tables' dict, names, merges)"""
+    from . import multigpu
+    from .countjoin import finish_tables
+    t0 = time.perf_counter()
+    names, src, trimmed, uniq_n, cls, ex, iso = multigpu.merge_tables(tables)
+    merges = load_merges(str(args.libraries_path), args.organism_name, ref_db)
+    out = finish_tables(cls, ex, iso, casc.libs["mirna"], merges, names, src, trimmed, uniq_n, float(args.crThreshold),
+                        bool(args.spikeIn), workDir=Path(workDir))
+    with open(Path(workDir) / "run.log", "a+") as outlog:
+        for tb in tables:
+            if tb.iupac:
+                outlog.write(f"WARNING: {tb.name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N\n")
+    tm["count_tables_s"] = time.perf_counter() - t0
+    return out, names, merges
+
+
 def run_sharded_rank0(args, tables, workDir, ref_db: str, casc, timings: Dict[str, float] = None):
     """Rank 0 of the sharded CLI, after the gather: the count tables from the ranks' own per-sample columns, then the
     run's joint table (``merge_sample_reads``) and everything ``reports`` writes from it -- the same files, byte for byte,
@@ -293,15 +318,10 @@ def run_sharded_rank0(args, tables, workDir, ref_db: str, casc, timings: Dict[st
     so nothing per read but the dictionaries travels, and ``mapped.csv`` / ``unmapped.csv`` of the union are formatted on the
     GPU like a one-process run's (``reports``: no fetch of reads, counts or annotation, no formatting on host threads)."""
     from . import multigpu
-    from .countjoin import finish_tables
     tm = timings if timings is not None else {}
     t0 = time.perf_counter()
     workDir = Path(workDir)
-    names, src, trimmed, uniq_n, cls, ex, iso = multigpu.merge_tables(tables)
-    merges = load_merges(str(args.libraries_path), args.organism_name, ref_db)
-    out = finish_tables(cls, ex, iso, casc.libs["mirna"], merges, names, src, trimmed, uniq_n, float(args.crThreshold),
-                        bool(args.spikeIn), workDir=workDir)
-    tm["count_tables_s"] = time.perf_counter() - t0
+    out, names, merges = sharded_count_tables(args, tables, workDir, ref_db, casc, tm)
     t = time.perf_counter()
     for tb in tables:
         if isinstance(tb.reads, str):
@@ -311,10 +331,6 @@ def run_sharded_rank0(args, tables, workDir, ref_db: str, casc, timings: Dict[st
     except OSError:
         pass
     tm["load_dictionaries_s"] = time.perf_counter() - t
-    with open(workDir / "run.log", "a+") as outlog:
-        for tb in tables:
-            if tb.reads.iupac:
-                outlog.write(f"WARNING: {tb.name} holds IUPAC ambiguity codes other than N (or '.'); they are aligned -- and printed -- as N\n")
     t = time.perf_counter()
     uniq = merge_sample_reads(casc.ctx, [tb.reads for tb in tables])
     for tb in tables:
@@ -331,6 +347,116 @@ def run_sharded_rank0(args, tables, workDir, ref_db: str, casc, timings: Dict[st
     tm["reports_s"] = time.perf_counter() - t
     tm["rank0_tail_s"] = time.perf_counter() - t0
     return out
+
+
+def names_need_quoting(casc) -> bool:
+    """a reference name holds a comma, a quote or a line break: mapped.csv then takes the host formatter (mirge_annotation_csv)"""
+    for fs in names_by_pass(casc):
+        if fs is not None and len(fs) and np.isin(fs.data, np.frombuffer(b',"\n\r', dtype=np.uint8)).any():
+            return True
+    return False
+
+
+def parallel_tail_eligible(args, n_samples: int, world: int, casc) -> bool:
+    """the sharded run's files can be written range by range on every rank: several samples (one sample's frame is in dictionary
+    order, not sorted: digest.py:158-163), no per-read report that needs the joint table in one place (-gff / -ai / -ie), names that
+    print as they are.  MIRGE_SHARD_TAIL=rank0 keeps round 5's route (tests compare the two)."""
+    import os
+    if os.environ.get("MIRGE_SHARD_TAIL", "ranges") != "ranges":
+        return False
+    if world < 2 or n_samples < 2 or getattr(args, "host_csv", False):
+        return False
+    if any(getattr(args, k, False) for k in ("gff_out", "AtoI", "isoform_entropy")):
+        return False
+    return not names_need_quoting(casc)
+
+
+def run_sharded_ranges(args, held: dict, n_samples: int, base_names, workDir, casc, rank: int, world: int, dist, shard_dir=None,
+                       timings: Dict[str, float] = None):
+    """EVERY rank of the sharded CLI, after its own samples (their dictionaries still on the device, ``held`` = {sample index:
+    DeviceReads}): the run's ONE mapped.csv / unmapped.csv written range by range (multigpu.py, 'The parallel tail').
+      1. every sample's k quantile keys -> all ranks (a few kB over gloo) -> the same world - 1 splitters everywhere
+      2. every held dictionary split by owner range on the device, each stretch handed to its owner as files
+      3. this rank's range: the samples' stretches merged (weighted collapse, S columns), annotated by one cascade, ordered by
+         the device sort, its rows' bytes counted; the ranks' byte counts -> every rank's offsets in the two files
+      4. rank 0 creates the files (header, final size); every rank formats its rows on the GPU and pwrites them at its offset
+    Same bytes as the one-process run of the same samples (tests/test_gpu_parity.py, tools/sharded_c4.py)."""
+    import os
+    from . import multigpu
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
+    workDir = Path(workDir)
+    shard_dir = Path(shard_dir) if shard_dir is not None else workDir / ".mirge_shards"
+    ctx = casc.ctx
+    # ---- 1. splitters
+    t = time.perf_counter()
+    mine = [(int(i), int(len(u)), u.range_sample(multigpu.RANGE_SAMPLE_KEYS)) for i, u in sorted(held.items())]
+    pool = [None] * world
+    dist.all_gather_object(pool, mine)
+    flat = sorted((x for part in pool for x in part), key=lambda x: x[0])
+    splitters = multigpu.choose_splitters([(u, k) for _, u, k in flat], world)
+    tm["splitters_s"] = time.perf_counter() - t
+    # ---- 2. split + hand over
+    t = time.perf_counter()
+    for i, u in sorted(held.items()):
+        seqs, cnt, bounds = u.range_split(splitters)
+        multigpu.write_parts(shard_dir, i, seqs, cnt, bounds)
+        u.close()
+    held.clear()
+    tm["split_handover_s"] = time.perf_counter() - t
+    t = time.perf_counter()
+    dist.barrier()
+    tm["wait_for_all_parts_s"] = time.perf_counter() - t
+    # ---- 3. this rank's range of the joint table
+    t = time.perf_counter()
+    parts = [multigpu.read_part(shard_dir, i, rank) for i in range(n_samples)]
+    tm["load_parts_s"] = time.perf_counter() - t
+    t = time.perf_counter()
+    uniq = merge_sample_reads(ctx, parts)
+    del parts
+    ctx.sync()
+    tm["merge_sample_reads_s"] = time.perf_counter() - t
+    t = time.perf_counter()
+    res = casc.run(uniq)
+    ctx.sync()
+    tm["annotate_joint_table_s"] = time.perf_counter() - t
+    tm["joint_unique_reads_of_range"] = len(uniq)
+    t = time.perf_counter()
+    order = uniq.sorted_order()
+    tm["row_order_s"] = time.perf_counter() - t
+    t = time.perf_counter()
+    n_cols = 10 if args.spikeIn else 9
+    cols = PASS_COLUMNS[:n_cols]
+    header = (",".join(["Sequence", "annotFlag"] + cols + list(base_names)) + "\n").encode()
+    names = names_by_pass(casc)
+    passes = list(range(casc.n_pass))
+    sizes = _ffi.annotation_csv_device_sizes(ctx, uniq, res, order, passes, n_cols, names)
+    if sizes is None:
+        raise RuntimeError("a reference name needs CSV quoting (parallel_tail_eligible should have excluded this run)")
+    every = [None] * world
+    dist.all_gather_object(every, (int(sizes[0]), int(sizes[1]), len(uniq)))
+    off_m = len(header) + sum(x[0] for x in every[:rank])
+    off_u = len(header) + sum(x[1] for x in every[:rank])
+    mapped, unmapped = workDir / "mapped.csv", workDir / "unmapped.csv"
+    if rank == 0:
+        for path, total in ((mapped, sum(x[0] for x in every)), (unmapped, sum(x[1] for x in every))):
+            with open(path, "wb") as fh:
+                fh.write(header)
+                fh.truncate(len(header) + total)
+    dist.barrier()  # the files exist at their final size
+    tm["sizes_offsets_s"] = time.perf_counter() - t
+    t = time.perf_counter()
+    _ffi.annotation_csv_device_at(ctx, uniq, res, mapped, unmapped, off_m, off_u, order, passes, n_cols, names)
+    tm["format_write_s"] = time.perf_counter() - t
+    res.close(); uniq.close()
+    if rank == 0:
+        try:
+            shard_dir.rmdir()
+        except OSError:
+            pass
+    tm["joint_unique_reads"] = int(sum(x[2] for x in every))
+    tm["range_tail_s"] = time.perf_counter() - t0
+    return tm
 
 
 def mirna_frame(seqs: FlatSeqs, ps, ref, counts, order, casc, base_names):

@@ -84,6 +84,69 @@ class SampleTables:
     iso: np.ndarray         # [n_mirna]
     reads: Optional[object] = None  # SampleReads, or the stem of its files (SampleReads.to_files)
     timing: Optional[dict] = None   # the rank's own stage times for this sample (run.log of the sharded run)
+    iupac: bool = False             # the sample held IUPAC codes other than N (run.log says so)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The parallel tail (round 6).  The reference puts ONE mapped.csv / unmapped.csv over the sorted union of all samples'
+# sequences, one count column per sample (digest.py:243, mirge/__main__.py:164-173).  Until round 5 rank 0 built that table
+# alone while the other GPUs idled (1.31 s at 8 x 20 M reads against ~0.3 s for a rank's own sample).  Now the union's key
+# space is cut into one RANGE per rank: a read's owner follows from the first 21 bases of its sort key, ranges are
+# consecutive stretches of the sorted union, so rank q merges the samples' reads of range q (weighted collapse, S columns),
+# annotates them (one cascade), orders them (device sort) and formats + pwrites its stretch of the two files at the byte
+# offset the ranks' sizes give.  Hand-over: files in the run's directory (or /dev/shm), 30 B per unique read; no RCCL.
+# ---------------------------------------------------------------------------------------------------------------------
+RANGE_SAMPLE_KEYS = 512   # quantiles a sample contributes to the splitter pool (a range is then balanced to ~1/512 of a sample)
+KEY_NONE = np.uint64(0xFFFFFFFFFFFFFFFF)  # what an empty dictionary's quantiles read (mirge_reads_range_sample)
+
+
+def choose_splitters(pool, n_parts: int) -> np.ndarray:
+    """``pool`` = [(unique reads of a sample, its k quantile keys)] over ALL samples of the run -> the n_parts - 1 ascending
+    splitter keys (uint64): weighted quantiles of the pooled keys, a sample's k keys each standing for U / k of its reads.
+    Every rank computes this from the same all-gathered pool, so all agree without a broadcast."""
+    keys, wts = [], []
+    for u, k in pool:
+        k = np.asarray(k, dtype=np.uint64)
+        k = k[k != KEY_NONE]
+        if u and k.size:
+            keys.append(k)
+            wts.append(np.full(k.shape[0], float(u) / k.shape[0]))
+    if n_parts <= 1:
+        return np.zeros(0, dtype=np.uint64)
+    if not keys:
+        return np.full(n_parts - 1, np.uint64(1) << np.uint64(63), dtype=np.uint64)  # beyond every key: range 0 owns what there is
+    keys, wts = np.concatenate(keys), np.concatenate(wts)
+    o = np.argsort(keys, kind="stable")
+    keys, cum = keys[o], np.cumsum(wts[o])
+    want = cum[-1] * np.arange(1, n_parts, dtype=np.float64) / n_parts
+    at = np.minimum(np.searchsorted(cum, want, side="left"), keys.shape[0] - 1)
+    return np.ascontiguousarray(keys[at], dtype=np.uint64)
+
+
+def part_stem(directory, sample: int, part: int) -> str:
+    import os
+    return os.path.join(str(directory), f"sample{sample}.part{part}")
+
+
+def write_parts(directory, sample: int, seqs, counts: np.ndarray, bounds: np.ndarray, iupac: bool = False):
+    """the stretches of a range-split dictionary (``DeviceReads.range_split``) as one SampleReads file set per owner"""
+    import os
+    os.makedirs(str(directory), exist_ok=True)
+    off = seqs.offsets
+    ln = seqs.lengths
+    mx = int(ln.max()) if len(ln) else 0
+    ln = ln.astype(np.uint8 if mx < 256 else np.uint16 if mx < 65536 else np.int64)
+    cnt = np.ascontiguousarray(counts, dtype=np.uint32).reshape(len(ln), -1)[:, 0]
+    for q in range(len(bounds) - 1):
+        a, b = int(bounds[q]), int(bounds[q + 1])
+        stem = part_stem(directory, sample, q)
+        np.save(stem + ".data.npy", seqs.data[int(off[a]):int(off[b])])
+        np.save(stem + ".lengths.npy", ln[a:b])
+        np.save(stem + ".counts.npy", cnt[a:b])
+
+
+def read_part(directory, sample: int, part: int, remove: bool = True) -> "SampleReads":
+    return SampleReads.from_files(part_stem(directory, sample, part) + "|0", remove)
 
 
 def gather_tables(local: Sequence[SampleTables], rank: int, world: int, dist=None) -> Optional[List[SampleTables]]:

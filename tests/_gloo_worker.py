@@ -92,7 +92,78 @@ def main():
     else:
         assert tables is None
     dist.barrier()
+    range_tail(out_dir, rank, world, case, n_samples, col_of, name_of, exp)
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def range_tail(out_dir, rank, world, case, n_samples, col_of, name_of, exp):
+    """The parallel tail's host protocol (multigpu.py 'The parallel tail', fastpath.run_sharded_ranges) with numpy / Python standing in
+    for the four device steps (quantile keys, range split, merge + order, row formatting): pooled quantiles -> the same splitters on
+    every rank -> every dictionary cut by owner range and handed over as files -> each rank merges ITS range of every sample, sorts it,
+    formats its rows, the ranks' byte counts give the offsets, rank 0 creates the files, every rank pwrites its stretch.  The parent
+    compares mapped.csv / unmapped.csv with the reference's."""
+    from helpers import PASS_COLS, lex_key0
+    from mirge3_amd.seqio import FlatSeqs
+    shard = os.path.join(out_dir, ".mirge_range_shards")
+    k = 16
+    mine = {}
+    for i in multigpu.assign_samples(n_samples, world)[rank]:
+        d = [(s, int(row[col_of[i]])) for s, row in zip(case.seqs, case.counts) if int(row[col_of[i]])]
+        keys = np.array([lex_key0(s) for s, _ in d], dtype=np.uint64)
+        srt = np.sort(keys)
+        qs = srt[np.minimum(len(srt) - 1, (2 * np.arange(k) + 1) * len(srt) // (2 * k))] if len(srt) else np.full(k, multigpu.KEY_NONE)
+        mine[i] = (d, keys, qs)
+    pool = [None] * world
+    dist.all_gather_object(pool, [(i, len(v[0]), v[2]) for i, v in sorted(mine.items())])
+    flat = sorted((x for part in pool for x in part), key=lambda x: x[0])
+    assert [x[0] for x in flat] == list(range(n_samples))
+    sp = multigpu.choose_splitters([(u, q) for _, u, q in flat], world)
+    every_sp = [None] * world
+    dist.all_gather_object(every_sp, sp.tolist())
+    assert every_sp == [every_sp[0]] * world and len(sp) == world - 1  # the same cut everywhere, without a broadcast
+    for i, (d, keys, _) in mine.items():
+        owner = np.searchsorted(sp, keys, side="right")
+        o = np.argsort(owner, kind="stable")
+        bounds = np.concatenate(([0], np.cumsum(np.bincount(owner, minlength=world)))).astype(np.int64)
+        multigpu.write_parts(shard, i, FlatSeqs.from_list([d[j][0] for j in o]), np.array([d[j][1] for j in o], dtype=np.uint32), bounds)
+    dist.barrier()
+    joint = {}
+    for i in range(n_samples):
+        part = multigpu.read_part(shard, i, rank)
+        for q, c in zip(FlatSeqs(part.data, part.offsets).to_list(), part.counts):
+            joint.setdefault(q, [0] * n_samples)[i] = int(c)
+    n_cols = case.n_pass
+    rows_m, rows_u = [], []
+    for q in sorted(joint):
+        p, nm = exp[q]
+        cols = [""] * n_cols
+        if p >= 0:
+            cols[p] = nm
+        line = ",".join([q, "1" if p >= 0 else "0"] + cols + [str(c) for c in joint[q]]) + "\n"
+        (rows_m if p >= 0 else rows_u).append(line)
+    text_m, text_u = "".join(rows_m).encode(), "".join(rows_u).encode()
+    every = [None] * world
+    dist.all_gather_object(every, (len(text_m), len(text_u), max(joint) if joint else None, min(joint) if joint else None))
+    header = (",".join(["Sequence", "annotFlag"] + PASS_COLS[:n_cols] + name_of) + "\n").encode()
+    paths = [os.path.join(out_dir, f) for f in ("mapped.csv", "unmapped.csv")]
+    if rank == 0:
+        for w, path in enumerate(paths):
+            with open(path, "wb") as fh:
+                fh.write(header)
+                fh.truncate(len(header) + sum(x[w] for x in every))
+        # the ranges are consecutive stretches of the sorted union: a rank's largest read sorts before the next rank's smallest
+        held = [x for x in every if x[2] is not None]
+        assert all(a[2] < b[3] for a, b in zip(held, held[1:]))
+    dist.barrier()
+    for w, (path, text) in enumerate(zip(paths, (text_m, text_u))):
+        fd = os.open(path, os.O_WRONLY)
+        os.pwrite(fd, text, len(header) + sum(x[w] for x in every[:rank]))
+        os.close(fd)
+    dist.barrier()
+    if rank == 0:
+        assert not os.listdir(shard)
+        os.rmdir(shard)
 
 
 if __name__ == "__main__":

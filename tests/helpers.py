@@ -73,3 +73,15 @@ class GoldenCase:
 
 def oracle_libs_from(libs, n_pass=9):
     return [(libs[PASS_LIBKEY[p]].seqs.data, libs[PASS_LIBKEY[p]].seqs.offsets) for p in range(n_pass)]
+
+
+LEX_DIGIT = {"A": 1, "C": 2, "G": 3, "N": 4, "T": 5}
+
+
+def lex_key0(seq: str) -> int:
+    """the first word of the device's sort key of a read (csrc/kernels_csv.hpp, k_lexkey): 21 bases, 3 bits each (end 0, A 1, C 2,
+    G 3, N 4, T 5), most significant first -- comparing these numbers is comparing the first 21 letters as Python strings"""
+    key = 0
+    for b in range(21):
+        key = (key << 3) | (LEX_DIGIT[seq[b]] if b < len(seq) else 0)
+    return key

@@ -1581,6 +1581,110 @@ def test_cli_two_ranks_equal_one_process_at_scale(tmp_path, ci_libs):
     assert (tmp_path / "one" / "mapped.csv").stat().st_size > 20_000_000 and not (out2 / ".mirge_shards").exists()
 
 
+def test_range_sample_and_split_of_a_dictionary(ctx, ci_libs):
+    """mirge_reads_range_sample / mirge_reads_range_split (round 6: the sharded run's parallel tail): the quantile keys are
+    keys of the dictionary in ascending order; the split orders the dictionary by (owner range, handle index), every read lands in
+    the range its first 21 bases say, with its count, and the ranges are consecutive stretches of the sorted dictionary.  Reads with
+    N, 32-50-nt reads, an empty range, one range, an empty dictionary."""
+    from helpers import lex_key0
+    from mirge3_amd import multigpu
+    reads = synth.make_reads(ci_libs, 60000, seed=31, pool=9000, n_frac=0.03)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    u = raw.collapse()
+    seqs = u.unpack().to_list()
+    cnt, _ = u.counts()
+    keys = np.array([lex_key0(q) for q in seqs], dtype=np.uint64)
+    k = 64
+    qs = u.range_sample(k)
+    srt = np.sort(keys)
+    assert np.array_equal(qs, srt[np.minimum(len(srt) - 1, (2 * np.arange(k) + 1) * len(srt) // (2 * k))])
+    for n_parts in (1, 2, 5, 8):
+        sp = multigpu.choose_splitters([(len(seqs), qs)], n_parts)
+        assert sp.shape[0] == n_parts - 1 and (np.diff(sp.astype(np.int64)) >= 0).all()
+        if n_parts == 5:
+            sp[2] = sp[1]  # an empty range
+        fs, c2, bounds = u.range_split(sp)
+        got = fs.to_list()
+        owner = np.searchsorted(sp, keys, side="right")
+        assert bounds[0] == 0 and bounds[-1] == len(seqs)
+        assert np.array_equal(np.diff(bounds), np.bincount(owner, minlength=n_parts))
+        exp_order = np.argsort(owner, kind="stable")
+        assert got == [seqs[i] for i in exp_order] and np.array_equal(c2, cnt[exp_order])
+        if n_parts in (2, 8):  # balance: every range within a few 1/k of the dictionary of its share
+            assert np.abs(np.diff(bounds) - len(seqs) / n_parts).max() <= 3 * len(seqs) / k + 50
+        # consecutive stretches of the sorted dictionary: the largest sequence of a range sorts before the smallest of the next
+        prev = None
+        for q in range(n_parts):
+            part = got[int(bounds[q]):int(bounds[q + 1])]
+            if part:
+                assert prev is None or prev < min(part)
+                prev = max(part)
+    u.close(); raw.close()
+    empty = _ffi.DeviceReads.pack(ctx, FlatSeqs.from_list([])).collapse()
+    assert (empty.range_sample(8) == multigpu.KEY_NONE).all()
+    fs, c2, bounds = empty.range_split(np.array([5, 9], dtype=np.uint64))
+    assert len(fs) == 0 and list(bounds) == [0, 0, 0, 0]
+    assert np.array_equal(multigpu.choose_splitters([(0, empty.range_sample(8))], 3), np.full(2, 1 << 63, dtype=np.uint64))
+    empty.close()
+
+
+def test_cli_ranks_write_their_ranges_of_the_per_read_tables(tmp_path):
+    """The sharded CLI's parallel tail (fastpath.run_sharded_ranges): no rank builds the run's joint table alone -- every rank merges,
+    annotates, orders and formats its RANGE of the sorted union and pwrites its stretch of mapped.csv / unmapped.csv.  Golden case 2
+    (two samples, two ranks) and case 5 (three samples with the spike-in library on two ranks: rank 0 holds two samples): the
+    reference's own files, byte for byte; the run log says which tail ran."""
+    for name, port, extra in (("case2_two_samples", 29561, []), ("case5_three_samples_spikein", 29563, ["-spk"])):
+        case = GoldenCase(name)
+        d = tmp_path / name
+        d.mkdir()
+        out = _run_cli_two_ranks(d, _case_fastq_files(case, d), case, extra, port)
+        for f in ("miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv"):
+            assert (out / f).read_text() == case.text(f), (name, f)
+        _same_report_but_total_input(out, case)
+        log = (out / "run.log").read_text()
+        assert '"tail": "ranges' in log and not (out / ".mirge_shards").exists()
+
+
+def test_cli_ranges_tail_equals_rank0_tail_and_one_process(tmp_path, ci_libs):
+    """Three routes to the same files on three 0.7 M-read samples over three ranks that share the GPU: one process; the sharded run
+    with rank 0 building the joint table alone (MIRGE_SHARD_TAIL=rank0, round 5); the sharded run with every rank writing its range
+    (round 6).  Every output file byte for byte."""
+    import subprocess
+    import sys
+    from mirge3_amd.seqio import index_basename, write_fasta
+    idx = tmp_path / "Libs" / ORG / "index.Libs"
+    idx.mkdir(parents=True)
+    (tmp_path / "Libs" / ORG / "annotation.Libs").mkdir()
+    for key, lib in ci_libs.libs.items():
+        write_fasta(str(idx / (index_basename(ORG, key, "miRBase") + ".fa")), lib)
+    (tmp_path / "Libs" / ORG / "annotation.Libs" / f"{ORG}_merges_miRBase.csv").write_text("".join(",".join(r) + "\n" for r in ci_libs.merges))
+    files = []
+    for s in range(3):
+        reads = synth.make_reads_chunked(ci_libs, 700_000, seed=500 + s, n_frac=0.01)
+        p = tmp_path / f"S{s + 1}.fastq"
+        with open(p, "w") as fh:
+            fh.write("".join(f"@r\n{q}\n+\n{'I' * len(q)}\n" for q in reads.to_list()))
+        files.append(str(p))
+    libdir = str(tmp_path / "Libs")
+    _run_cli(["-s", ",".join(files), "-lib", libdir, "-on", ORG, "-db", "miRBase", "-o", str(tmp_path), "-dn", "one", "-shh"])
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    launcher = tmp_path / "run_cli.py"
+    launcher.write_text("import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()\n" % root)
+    names = ("annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv")
+    for tail, port in (("rank0", 29565), ("ranges", 29567)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(launcher), "-s", ",".join(files), "-lib", libdir, "-on", ORG, "-db", "miRBase",
+               "-o", str(tmp_path), "-dn", tail, "-shh"]
+        r = subprocess.run(cmd, env=dict(os.environ, MIRGE_SHARE_GPU="1", OMP_NUM_THREADS="2", MIRGE_SHARD_TAIL=tail), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        for f in names:
+            assert (tmp_path / "one" / f).read_bytes() == (tmp_path / tail / f).read_bytes(), (tail, f)
+        log = (tmp_path / tail / "run.log").read_text()
+        assert ('"tail": "ranges' in log) == (tail == "ranges")
+    assert (tmp_path / "one" / "mapped.csv").stat().st_size > 10_000_000
+
+
 def test_weighted_collapse_merges_dictionaries(ctx, ci_libs):
     """mirge_collapse_weighted: three samples' dictionaries (unique reads + counts) merged == the joint collapse of their
     raw reads (counts matrix; first index = first entry of the concatenated dictionaries)."""

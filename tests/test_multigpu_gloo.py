@@ -25,6 +25,9 @@ def test_two_ranks_gloo_merge_equals_reference(tmp_path):
     case = GoldenCase("case2_two_samples")
     for f in ("annotation.report.csv", "annotation.report.html", "miR.Counts.csv", "miR.RPM.csv"):
         assert (tmp_path / f).read_text() == case.text(f), f
+    # round 6: the run's ONE mapped.csv / unmapped.csv written range by range by BOTH ranks (the worker's range_tail)
+    for f in ("mapped.csv", "unmapped.csv"):
+        assert (tmp_path / f).read_text() == case.text(f), f
 
 
 def test_eight_ranks_gloo_eight_dictionaries(tmp_path):
@@ -47,6 +50,16 @@ def test_eight_ranks_gloo_eight_dictionaries(tmp_path):
         assert [g[0] for g in got] == [w[0] for w in want]
         for g, w in zip(got[1:], want[1:]):
             assert g[1:] == [w[1 + i % S] for i in range(8)], (f, g[0])
+    # round 6: the range hand-over at eight ranks -- every rank wrote its stretch of the two per-read files: the reference's rows,
+    # in the reference's (sorted) order, the case's three count columns dealt to the eight samples
+    for f in ("mapped.csv", "unmapped.csv"):
+        got = list(csv.reader((tmp_path / f).read_text().splitlines()))
+        want = list(csv.reader(case.text(f).splitlines()))
+        n_fixed = len(want[0]) - S
+        assert got[0] == want[0][:n_fixed] + [f"{want[0][n_fixed + i % S]}_{i}" for i in range(8)]
+        assert len(got) == len(want)
+        for g, w in zip(got[1:], want[1:]):
+            assert g == w[:n_fixed] + [w[n_fixed + i % S] for i in range(8)], (f, g[0])
     got = list(csv.reader((tmp_path / "annotation.report.csv").read_text().splitlines()))
     want = list(csv.reader(case.text("annotation.report.csv").splitlines()))
     assert got[0] == want[0] and len(got) == 9

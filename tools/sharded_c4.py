@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--one-process", dest="one_process", type=int, default=0)
     ap.add_argument("--port", type=int, default=29571)
     ap.add_argument("--tmp", default="/tmp")
+    ap.add_argument("--tails", default="ranges,rank0", help="which tails to run: ranges (round 6: every rank its key range), rank0 (round 5)")
     args = ap.parse_args()
     import numpy as np  # noqa: F401
     import mirge3_amd  # noqa: F401
@@ -74,29 +75,45 @@ def main():
         subprocess.run([sys.executable, launcher, "-s", files[0], "-lib", os.path.join(tmp, "Libs"), "-on", "bench", "-db", "miRBase", "-o", tmp,
                         "-shh", "-dn", "warm"], env=env, check=True, capture_output=True, text=True, timeout=1800)
         shutil.rmtree(os.path.join(tmp, "warm"), ignore_errors=True)
-        t = time.perf_counter()
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.ranks), "--master-addr",
-                            "127.0.0.1", "--master-port", str(args.port), launcher] + base + ["-dn", "sharded"], env=env, capture_output=True,
-                           text=True, timeout=3600)
-        wall = time.perf_counter() - t
-        if r.returncode != 0:
-            say("sharded run FAILED:\n" + r.stderr[-3000:])
-            return 1
-        log = open(os.path.join(tmp, "sharded", "run.log")).read()
-        line = [ln for ln in log.splitlines() if ln.startswith("sharded run timing: ")][-1]
-        d = json.loads(line[len("sharded run timing: "):])
-        say(f"sharded run, {args.ranks} ranks on one GPU: {wall:.2f} s wall (process start-up, libraries from their cache and probe tables included)")
-        say(f"  ranks' samples + gather: {d['samples_and_gather_s']:.3f} s")
-        say("  per sample (its rank's own clock; eight ranks share the GPU here): "
-            + ", ".join(f"{p['name']} {p.get('sample_s', 0):.2f} s (hand-over {p.get('handover_s', 0):.2f}, U {p.get('unique_reads', 0) / 1e6:.2f} M)" for p in d["per_sample"]))
-        say("  rank 0's tail:")
-        for k, v in d["rank0_tail"].items():
-            say(f"    {k:34s} {v}")
-        say(f"  rank 0 peak host memory: {d['rank0_peak_rss_MB']:.0f} MB")
-        for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv"):
-            say(f"  {f}: {os.path.getsize(os.path.join(tmp, 'sharded', f)) / 1e6:.1f} MB")
-        slowest = max(p.get("sample_s", 0) for p in d["per_sample"])
-        say(f"  rank 0's tail {d['rank0_tail'].get('rank0_tail_s', 0):.2f} s against the slowest rank's sample {slowest:.2f} s")
+        tails = [x for x in args.tails.split(",") if x]
+        for ti, tail in enumerate(tails):
+            dn = "sharded" if ti == 0 else "sharded_" + tail
+            t = time.perf_counter()
+            r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.ranks), "--master-addr",
+                                "127.0.0.1", "--master-port", str(args.port + ti), launcher] + base + ["-dn", dn],
+                               env=dict(env, MIRGE_SHARD_TAIL=tail), capture_output=True, text=True, timeout=3600)
+            wall = time.perf_counter() - t
+            if r.returncode != 0:
+                say(f"sharded run ({tail}) FAILED:\n" + r.stderr[-3000:])
+                return 1
+            log = open(os.path.join(tmp, dn, "run.log")).read()
+            line = [ln for ln in log.splitlines() if ln.startswith("sharded run timing: ")][-1]
+            d = json.loads(line[len("sharded run timing: "):])
+            say(f"sharded run, tail = {d.get('tail', tail)}, {args.ranks} ranks on one GPU: {wall:.2f} s wall (process start-up, libraries from their "
+                "cache and probe tables included)")
+            say(f"  ranks' samples + gather: {d['samples_and_gather_s']:.3f} s")
+            say("  per sample (its rank's own clock; the ranks share the GPU here): "
+                + ", ".join(f"{p['name']} {p.get('sample_s', 0):.2f} s (hand-over {p.get('handover_s', 0):.2f}, U {p.get('unique_reads', 0) / 1e6:.2f} M)" for p in d["per_sample"]))
+            say("  rank 0's tail:")
+            for k, v in d["rank0_tail"].items():
+                say(f"    {k:34s} {v}")
+            if d.get("ranges_tail_per_rank"):
+                say("  every rank's range tail (its own clock; on one shared GPU the device steps of the ranks queue behind each other):")
+                keys = [k for k in d["ranges_tail_per_rank"][0] if k != "joint_unique_reads"]
+                say("    " + " ".join(f"{k[:22]:>22s}" for k in ["rank"] + keys))
+                for q, row in enumerate(d["ranges_tail_per_rank"]):
+                    say("    " + " ".join(f"{str(v)[:22]:>22s}" for v in [q] + [row.get(k) for k in keys]))
+            say(f"  rank 0 peak host memory: {d['rank0_peak_rss_MB']:.0f} MB")
+            for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv"):
+                say(f"  {f}: {os.path.getsize(os.path.join(tmp, dn, f)) / 1e6:.1f} MB")
+            slowest = max(p.get("sample_s", 0) for p in d["per_sample"])
+            say(f"  rank 0's tail {d['rank0_tail'].get('rank0_tail_s', 0):.2f} s against the slowest rank's sample {slowest:.2f} s")
+            if ti > 0:
+                for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "annotation.report.csv"):
+                    a, b = os.path.join(tmp, "sharded", f), os.path.join(tmp, dn, f)
+                    same = os.path.getsize(a) == os.path.getsize(b) and subprocess.run(["cmp", "-s", a, b]).returncode == 0
+                    say(f"  {f}: {'identical to the first tail' if same else 'DIFFERS from the first tail'}")
+                shutil.rmtree(os.path.join(tmp, dn), ignore_errors=True)
         if args.one_process:
             t = time.perf_counter()
             r1 = subprocess.run([sys.executable, launcher] + base + ["-dn", "one"], env=env, capture_output=True, text=True, timeout=3600)
