@@ -520,6 +520,80 @@ def secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, I
     return res
 
 
+def repeat_rich_leg(args, ctx, _ffi, synth, Cascade, PASSES, n_mirna, EXACT_PASS, ISO_PASS, default_ms):
+    """The step on libraries with the repeat structure real ones have (never `value`; round 5's review: every number so far is on
+    uniform-random libraries, the best case for a k-mer index): `synth.make_libraries(repeats=True)` -- poly-A tails on 60 % of the
+    mRNAs, five 300-nt Alu-like families at 5-15 % divergence in 10 % of the transcripts, simple repeats in ncRNA and mRNA, tRNA
+    isodecoder families -- and `synth.REPEAT_MIX` reads (15 % poly-A / poly-T / simple-repeat / Alu-derived reads with 0-2 errors).
+    Reports the step, the bulk cascade kernel's own time, how unevenly its workgroups finished (one read whose probe bucket holds 10^5
+    positions is scanned by ONE wave), and the oracle's verdict on a 40 k-read sample of the same set."""
+    import oracle
+    t0 = time.perf_counter()
+    sl_r = synth.make_libraries(seed=20260101, scale=args.scale, repeats=True)
+    casc_r = Cascade(ctx, sl_r.libs, n_pass=9)
+    n = args.reads
+    reads_r = synth.make_reads_chunked(sl_r, n, seed=4000, mix=synth.REPEAT_MIX)
+    raw_r = _ffi.DeviceReads.pack(ctx, reads_r)
+    setup_s = time.perf_counter() - t0
+    u_n = [0]
+
+    def one():
+        uq, rs = casc_r.collapse_and_run(raw_r)
+        _ffi.count_join(ctx, uq, rs, EXACT_PASS, ISO_PASS, n_mirna)
+        u_n[0] = len(uq)
+        rs.close(); uq.close()
+    t1 = time.perf_counter()
+    one()
+    first_step_s = time.perf_counter() - t1  # probe tables of these libraries are built here
+    for _ in range(2):
+        one()
+    ctx.profile(True); ctx.profile_only("k_cascade_bulk"); ctx.profile_reset()
+    for _ in range(3):
+        one()
+    recs = [r for r in ctx.profile_records() if r[0].startswith("k_cascade_bulk") and r[1]]
+    wg = _ffi.cascade_wg_times(ctx)
+    ctx.profile(False); ctx.profile_only("")
+    bulk_ms = max((ms / l for _, l, ms, _ in recs), default=None)
+    k = 0
+    t = time.perf_counter()
+    while k < 10 or time.perf_counter() - t < 0.3:
+        one(); k += 1
+    dt = (time.perf_counter() - t) / k
+    out = {"raw_reads": n, "unique_reads": u_n[0], "U_over_N": round(u_n[0] / n, 4), "steps": k, "ms_per_step": round(dt * 1e3, 4),
+           "M_raw_reads_per_s": round(n / dt / 1e6, 1), "M_collapsed_reads_per_s": round(u_n[0] / dt / 1e6, 1),
+           "vs_default_draw_step": round(dt * 1e3 / default_ms, 3), "k_cascade_bulk_ms": None if bulk_ms is None else round(bulk_ms, 4),
+           "setup_s": round(setup_s, 1), "first_step_s": round(first_step_s, 3),
+           "library_bases": {kk: v.total_len for kk, v in sl_r.libs.items()},
+           "note": "libraries with poly-A tails, Alu-like families, simple repeats and tRNA isodecoder families + 15 % repeat-derived reads; "
+                   "vs_default_draw_step = this step / the uniform libraries' step of `value`"}
+    if wg is not None and len(wg):
+        out["bulk_workgroups_ms"] = {"n": int(len(wg)), "median": round(float(np.median(wg)), 4), "p99": round(float(np.percentile(wg, 99)), 4),
+                                     "max": round(float(wg.max()), 4),
+                                     "longest_share_of_launch": None if not bulk_ms else round(float(wg.max()) / bulk_ms, 3),
+                                     "note": "constant-rate clock, first to last instruction of every workgroup of the last bracketed launch: max / median "
+                                             "near 1 = the fixed segments finished together; a long tail = one segment's reads held the launch"}
+    # the oracle on a 40 k-read sample of the same set (brute-force semantics, k-mer variant), per read and per class
+    try:
+        m = min(40_000, n)
+        sub = reads_r.take(np.arange(m))
+        r2 = _ffi.DeviceReads.pack(ctx, sub)
+        u2 = r2.collapse()
+        res2 = casc_r.run(u2)
+        g = res2.fetch()
+        useq = u2.unpack()
+        libs_o = [(sl_r.libs[PASSES[p][1]].seqs.data, sl_r.libs[PASSES[p][1]].seqs.offsets) for p in range(9)]
+        t = time.perf_counter()
+        o = oracle.cascade(useq.data, useq.offsets, libs_o, n_pass=9, indexed=True, threads=min(os.cpu_count() or 1, 64))
+        out["oracle_parity_on_sample"] = {"raw_reads": m, "unique_reads": len(u2), "oracle_s": round(time.perf_counter() - t, 2),
+                                          "identical": bool(all(np.array_equal(a.astype(np.int64), b.astype(np.int64)) for a, b in zip(o, g))),
+                                          "annotated": int((g[0] >= 0).sum())}
+        res2.close(); u2.close(); r2.close()
+    except Exception as e:  # noqa: BLE001
+        out["oracle_parity_on_sample"] = {"error": repr(e)[:300]}
+    raw_r.close(); casc_r.close()
+    return out
+
+
 def cli_path(args, sl, libs, text, n_pass):
     """FASTQ file -> all CSVs through the CLI's device-resident route, wall-clock: a first run (libraries read from
     their directory, packed, indexed: what a one-sample invocation pays) and a second one in the same process
@@ -991,6 +1065,13 @@ def main():
             out["read_sets"] = secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, ISO_PASS, out)
         except Exception as e:  # noqa: BLE001
             out["read_sets"] = {"error": repr(e)[:300]}
+
+    if rank == 0 and n_gpus == 1 and args.read_sets and args.workload == "c3" and not args.pool:
+        try:
+            out.setdefault("read_sets", {})["repeat_rich"] = repeat_rich_leg(args, ctx, _ffi, synth, Cascade, PASSES, n_mirna, EXACT_PASS, ISO_PASS,
+                                                                              out["ms_per_step"])
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("read_sets", {})["repeat_rich"] = {"error": repr(e)[:300]}
 
     # ---------------- the same from the FILE's text (never `value`): FASTQ bytes in host memory -> records parsed,
     # filtered, packed on the GPU -> collapse -> cascade -> count tables on the host

@@ -232,6 +232,10 @@ int mirge_cascade_prepare(mirge_ctx* ctx, const mirge_reads* reads, const mirge_
  * ("-v 0", or "-n 0" inside the seed, over a small library: manifoldAlign.py:85 passes 0 and 3) that ride in another pass's
  * walk, walks[2] = passes in all.  Nothing in the reference corresponds to it: diagnostics for tests and bench.py. */
 int mirge_cascade_walks(mirge_ctx* ctx, int32_t* walks);
+/* Test / measurement aid: the constant-rate clock ticks every workgroup of the last PROFILED bulk-cascade launch took (its
+ * segment of the reads through all passes), ticks_out[0 .. min(cap, *grid_out)), and the clock's rate in kHz: the longest
+ * workgroup's share of the launch says whether one read's candidate list is what the launch waited for. */
+int mirge_cascade_wg_times(mirge_ctx* ctx, uint32_t* ticks_out, int32_t cap, int32_t* grid_out, int32_t* khz_out);
 /* mirge_collapse followed by mirge_cascade_run for ONE sample, as one call: the bulk read group's passes are queued on
  * the GPU behind the collapse kernels before the host has read the unique counts back (the kernels take the count
  * from device memory), so the GPU does not idle across the collapse's host synchronisation.  Same results; falls

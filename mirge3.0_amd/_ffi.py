@@ -27,7 +27,7 @@ EXPORTS = [
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_reads_range_sample", "mirge_reads_range_split", "mirge_annotation_csv_device_sizes", "mirge_annotation_csv_device_at",
-    "mirge_cascade_prepare", "mirge_cascade_walks", "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
+    "mirge_cascade_prepare", "mirge_cascade_walks", "mirge_cascade_wg_times", "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]
 
 
@@ -607,6 +607,17 @@ def cascade_walks(ctx: "Context"):
     w = (C.c_int32 * 3)()
     _check(load().mirge_cascade_walks(ctx._h, w), "mirge_cascade_walks")
     return int(w[0]), int(w[1]), int(w[2])
+
+
+def cascade_wg_times(ctx: "Context"):
+    """milliseconds every workgroup of the last profiled bulk-cascade launch took (``mirge_cascade_wg_times``), or None"""
+    g, khz = C.c_int32(0), C.c_int32(0)
+    _check(load().mirge_cascade_wg_times(ctx._h, None, 0, C.byref(g), C.byref(khz)), "mirge_cascade_wg_times")
+    if g.value <= 0:
+        return None
+    t = np.zeros(g.value, dtype=np.uint32)
+    _check(load().mirge_cascade_wg_times(ctx._h, _p(t), C.c_int32(g.value), C.byref(g), C.byref(khz)), "mirge_cascade_wg_times")
+    return t.astype(np.float64) / max(khz.value, 1)
 
 
 def collapse_cascade(ctx: Context, raw: DeviceReads, libs: Sequence[Optional[DeviceLibrary]],

@@ -754,6 +754,9 @@ k_cascade_bulk(const BulkWalks* __restrict__ walks, GroupView<W> g, uint32_t* __
     const int nwalks = walks->n;
     const size_t seg = (size_t)blockIdx.x * cap;
     size_t seg_r = seg;
+    // (round 6) when the workgroup started and ended, on the constant-rate clock, in the two rows behind the survivor counts: what
+    // says whether ONE workgroup's segment -- a read whose probe bucket holds 10^5 positions -- is what the launch waited for
+    if (threadIdx.x == 0) seg_n[(size_t)(MIRGE_MAX_PASSES_K + 1) * gridDim.x + blockIdx.x] = (uint32_t)wall_clock64();
     uint32_t n_in = first_pass_share(g.n, n_dev, cap, seg_r);
     const uint32_t* act_in = nullptr;
     uint32_t* act_out = actA;
@@ -777,6 +780,7 @@ k_cascade_bulk(const BulkWalks* __restrict__ walks, GroupView<W> g, uint32_t* __
         act_in = act_out;
         act_out = (act_out == actA) ? actB : actA;
     }
+    if (threadIdx.x == 0) seg_n[(size_t)(MIRGE_MAX_PASSES_K + 2) * gridDim.x + blockIdx.x] = (uint32_t)wall_clock64();
     // (k_resolve stays a launch of its own: done here, for the workgroup's own reads, it is a chain of dependent loads with
     // four waves to hide it -- the kernel grew by 0.04 ms to save a 0.046 ms launch that the whole chip runs at once)
 }

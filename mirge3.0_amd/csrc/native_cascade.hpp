@@ -131,7 +131,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     uint32_t *actA = nullptr, *actB = nullptr, *seg_n = nullptr;
     CHECK(dalloc(c, &actA, (size_t)grid * cap));
     CHECK(dalloc(c, &actB, (size_t)grid * cap));
-    CHECK(dalloc(c, &seg_n, (size_t)grid * (MIRGE_MAX_PASSES + 1)));
+    CHECK(dalloc(c, &seg_n, (size_t)grid * (MIRGE_MAX_PASSES + 3)));  // (+ 2 rows: the workgroups' start / end clocks, k_cascade_bulk)
     if (steps.empty()) {  // no pass runs: nothing will write the "unannotated" marks
         HIPOK(hipMemsetAsync(out.pass, 0xFF, n, c->cur));
         HIPOK(hipMemsetAsync(out.mm, 0xFF, n, c->cur));
@@ -160,6 +160,17 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
             hipLaunchKernelGGL((k_cascade_bulk<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos,
                                out.mm, n_dev);
         stage = (int)steps.size();
+        if (c->profiling && W == 1) {  // the workgroups' clocks of this launch, for mirge_cascade_wg_times (stream-ordered copy)
+            if (c->wg_pinned_words < 2 * (size_t)grid) {
+                if (c->wg_pinned) (void)hipHostFree(c->wg_pinned);
+                c->wg_pinned = nullptr; c->wg_pinned_words = 0;
+                if (hipHostMalloc((void**)&c->wg_pinned, 2 * (size_t)grid * 4, hipHostMallocDefault) == hipSuccess) c->wg_pinned_words = 2 * (size_t)grid;
+            }
+            if (c->wg_pinned_words >= 2 * (size_t)grid) {
+                HIPOK(hipMemcpyAsync(c->wg_pinned, seg_n + (size_t)grid * (MIRGE_MAX_PASSES + 1), 2 * (size_t)grid * 4, hipMemcpyDeviceToHost, c->cur));
+                c->wg_grid = grid;
+            }
+        }
     } else
     for (const PassStep& st : steps) {
         const int32_t p = st.p0;
@@ -555,6 +566,19 @@ extern "C" int mirge_cascade_prepare(mirge_ctx* c, const mirge_reads* R, const m
     reads_lengths_present(R, hist);
     CHECK(cascade_config(c, libs, pol, n_pass, hist, R->long_max > 0));
     HIPOK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ticks_out[b] = constant-rate clock ticks workgroup b of the LAST profiled k_cascade_bulk launch (one-word bulk group) took,
+// *khz_out = that clock's rate; returns the grid in *grid_out (0: no such launch yet).  Profiling must have been on.
+extern "C" int mirge_cascade_wg_times(mirge_ctx* c, uint32_t* ticks_out, int32_t cap, int32_t* grid_out, int32_t* khz_out) {
+    if (!c || !grid_out) return fail(-1, "mirge_cascade_wg_times: bad argument");
+    CHECK(mirge_ctx_sync(c));
+    *grid_out = (int32_t)c->wg_grid;
+    int khz = 100000;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
+    if (khz_out) *khz_out = khz;
+    for (uint32_t b = 0; ticks_out && b < c->wg_grid && (int32_t)b < cap; b++) ticks_out[b] = c->wg_pinned[c->wg_grid + b] - c->wg_pinned[b];
     return 0;
 }
 

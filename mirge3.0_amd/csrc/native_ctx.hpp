@@ -82,6 +82,10 @@ struct mirge_ctx {
     // page-locked staging of mirge_annotation_csv_device (the text of mapped.csv + unmapped.csv), kept between samples
     uint8_t* csv_pinned = nullptr;
     size_t csv_pinned_bytes = 0;
+    // start / end clocks of the workgroups of the last profiled k_cascade_bulk launch (mirge_cascade_wg_times)
+    uint32_t* wg_pinned = nullptr;
+    size_t wg_pinned_words = 0;
+    uint32_t wg_grid = 0;
     // the count join's device tables, kept between calls and cleared right AFTER a call's read-back: the next sample's
     // k_join starts behind its cascade without two fill kernels and their launch gaps in front of it
     unsigned long long* join_dev = nullptr;
@@ -302,6 +306,7 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->prof_pinned) (void)hipHostFree(c->prof_pinned);
     if (c->join_pinned) (void)hipHostFree(c->join_pinned);
     if (c->csv_pinned) (void)hipHostFree(c->csv_pinned);
+    if (c->wg_pinned) (void)hipHostFree(c->wg_pinned);
     if (c->join_dev) (void)hipFree(c->join_dev);
     for (auto& e : c->plans) (void)hipFree(e.dplan);
     for (auto& e : c->fused) (void)hipFree(e.dev);

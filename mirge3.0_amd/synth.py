@@ -51,10 +51,60 @@ class SynthLibs:
     # where each mature miRNA sits in its hairpin (for templated isomiRs)
     mir_hairpin: np.ndarray
     mir_hairpin_off: np.ndarray
+    # repeats=True: the consensus sequences of the Alu-like families and the simple-repeat units written into the libraries
+    repeat_families: List[str] = None
+    repeat_units: List[str] = None
 
 
-def make_libraries(seed: int = 20260101, scale: str = "small") -> SynthLibs:
+REPEAT_UNITS = ["CA", "GT", "AT", "AAT", "CAG", "GGAA", "TTTA", "A", "T"]
+
+
+def _mutated_copy(rng, cons: np.ndarray, div: float) -> np.ndarray:
+    """a copy of ``cons`` with a share ``div`` of its bases substituted"""
+    out = cons.copy()
+    hit = np.nonzero(rng.random(out.shape[0]) < div)[0]
+    code = np.searchsorted(ACGT, out[hit])
+    out[hit] = ACGT[(code + rng.integers(1, 4, size=hit.shape[0])) % 4]
+    return out
+
+
+def _add_repeat_structure(rng, libs: Dict[str, Library]):
+    """The repeat structure real libraries have and uniform draws lack (round 5's review, 'missing 4'; the reference's libraries
+    are Ensembl transcripts and ncRNA, mirge/libs/bamFmt.py:13,34): poly-A tails on most mRNAs, a few 300-nt Alu-like families at
+    5-15 % divergence in ~10 % of the transcripts, simple repeats ((CA)n, (GT)n, (AAT)n ...) in ncRNA and mRNA.  In place, lengths
+    unchanged (stretches are overwritten); -> (family consensus sequences, repeat units)."""
+    fams = [ACGT[rng.integers(0, 4, size=300, dtype=np.uint8)] for _ in range(5)]
+    # Alu-likes share a poly-A linker and an A-rich tail, as the real ones do
+    for f in fams:
+        f[120:135] = ord("A")
+        f[280:300] = ord("A")
+    for key in ("mrna", "ncrna_others"):
+        fs = libs[key].seqs
+        lens = fs.lengths
+        n = len(fs)
+        if key == "mrna":  # poly-A tails: 60 % of the transcripts, 20-150 nt
+            for i in np.nonzero(rng.random(n) < 0.6)[0]:
+                t = int(min(rng.integers(20, 151), lens[i] // 3))
+                fs.data[fs.offsets[i + 1] - t:fs.offsets[i + 1]] = ord("A")
+        for i in np.nonzero((rng.random(n) < 0.10) & (lens >= 360))[0]:  # one Alu-like element, 5-15 % diverged
+            cp = _mutated_copy(rng, fams[int(rng.integers(0, len(fams)))], float(rng.uniform(0.05, 0.15)))
+            at = int(fs.offsets[i] + rng.integers(10, lens[i] - 320))
+            fs.data[at:at + 300] = cp
+        share = 0.05 if key == "ncrna_others" else 0.03
+        for i in np.nonzero((rng.random(n) < share) & (lens >= 300))[0]:  # a simple repeat of 30-200 nt
+            unit = np.frombuffer(REPEAT_UNITS[int(rng.integers(0, 7))].encode(), dtype=np.uint8)
+            t = int(min(rng.integers(30, 201), lens[i] // 2))
+            at = int(fs.offsets[i] + rng.integers(5, lens[i] - t - 5))
+            fs.data[at:at + t] = np.resize(unit, t)
+    return ["".join(chr(c) for c in f) for f in fams], list(REPEAT_UNITS)
+
+
+def make_libraries(seed: int = 20260101, scale: str = "small", repeats: bool = False) -> SynthLibs:
+    """``repeats=True``: the same libraries with the repeat structure of real ones written in (``_add_repeat_structure``; tRNA
+    isodecoder families: identical bodies, 1-3 differing bases).  Drawn from a generator of its own: ``repeats=False`` is byte for
+    byte what it always was."""
     rng = np.random.Generator(np.random.PCG64(seed))
+    rng_r = np.random.Generator(np.random.PCG64([seed, 0x7265]))
     spec = SCALES[scale]
     libs: Dict[str, Library] = {}
 
@@ -104,6 +154,16 @@ def make_libraries(seed: int = 20260101, scale: str = "small") -> SynthLibs:
     mt = _rand_flat(rng, t_lens)
     for i in range(n_t):
         mt.data[mt.offsets[i + 1] - 3:mt.offsets[i + 1]] = np.frombuffer(b"CCA", dtype=np.uint8)
+    if repeats:  # isodecoder families of ~6: the body of the family's first member, 1-3 bases changed, 'CCA' kept
+        for i in range(n_t):
+            head = i - i % 6
+            if i == head:
+                continue
+            L = int(min(t_lens[i], t_lens[head]))
+            mt.data[mt.offsets[i]:mt.offsets[i] + L - 3] = mt.data[mt.offsets[head]:mt.offsets[head] + L - 3]
+            for p in rng_r.integers(0, L - 3, size=int(rng_r.integers(1, 4))):
+                old = mt.data[mt.offsets[i] + p]
+                mt.data[mt.offsets[i] + p] = ACGT[(int(np.searchsorted(ACGT, old)) + int(rng_r.integers(1, 4))) % 4]
     libs["mature_trna"] = Library([f"tRNA-{i + 1}-mature" for i in range(n_t)], mt)
     pre_seqs = []
     mts = mt.to_list()
@@ -152,12 +212,19 @@ def make_libraries(seed: int = 20260101, scale: str = "small") -> SynthLibs:
     for f in range(n_fam):
         a, b = names[2 * f], names[2 * f + 1]
         merges.append([f"{a}/{b.split('-', 2)[-1]}", a, b])
-    return SynthLibs(libs, merges, mir_hp, mir_off)
+    fams = units = None
+    if repeats:
+        fams, units = _add_repeat_structure(rng_r, libs)
+    return SynthLibs(libs, merges, mir_hp, mir_off, fams, units)
 
 
 # class mix of the raw reads
 DEFAULT_MIX = dict(exact=0.45, isomir=0.15, hairpin=0.03, mature_trna=0.08, pre_trna=0.01,
                    snorna=0.04, rrna=0.08, ncrna_others=0.03, mrna=0.05, random=0.08)
+# the same sample from repeat-rich libraries (make_libraries(repeats=True)): 15 % of the reads are what such libraries attract --
+# poly-A / poly-T, simple-repeat and Alu-derived reads, each with 0-2 errors
+REPEAT_MIX = dict(exact=0.40, isomir=0.13, hairpin=0.02, mature_trna=0.08, pre_trna=0.01, snorna=0.03, rrna=0.07, ncrna_others=0.03,
+                  mrna=0.04, random=0.04, poly=0.06, simple=0.03, alu=0.06)
 MAXLEN = 50
 
 
@@ -263,6 +330,25 @@ def make_reads(sl: SynthLibs, n: int, seed: int = 1, mix: Dict[str, float] | Non
             ln = rng.integers(16, 31, size=m)
             mat = ACGT[rng.integers(0, 4, size=(m, MAXLEN), dtype=np.uint8)]
             mat[np.arange(MAXLEN)[None, :] >= ln[:, None]] = 0
+        elif key in ("poly", "simple"):  # homopolymer / simple-repeat reads with 0-2 errors (REPEAT_MIX)
+            ln = rng.integers(16, 31, size=m)
+            units = ["A", "A", "A", "T"] if key == "poly" else [u for u in (sl.repeat_units or REPEAT_UNITS) if len(u) > 1]
+            which = rng.integers(0, len(units), size=m)
+            phase = rng.integers(0, 4, size=m)
+            mat = np.zeros((m, MAXLEN), dtype=np.uint8)
+            cols = np.arange(MAXLEN, dtype=np.int64)[None, :]
+            for ui, u in enumerate(units):
+                rows = np.nonzero(which == ui)[0]
+                ub = np.frombuffer(u.encode(), dtype=np.uint8)
+                mat[rows] = ub[(cols + phase[rows][:, None]) % len(u)]
+            mat[cols >= ln[:, None]] = 0
+            _mutate(rng, mat, ln, rng.choice([0, 1, 2], size=m, p=[0.5, 0.3, 0.2]))
+        elif key == "alu":  # reads out of the Alu-like families' consensus sequences, 0-2 errors on top of the copies' divergence
+            fams = sl.repeat_families or ["".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=300))]
+            cons = FlatSeqs.from_list(fams)
+            want = rng.integers(16, 31, size=m)
+            mat, ln = _substrings(rng, Library([f"alu{i}" for i in range(len(fams))], cons), m, want)
+            _mutate(rng, mat, ln, rng.choice([0, 1, 2], size=m, p=[0.4, 0.35, 0.25]))
         else:
             lib = L[key]
             if key == "hairpin":

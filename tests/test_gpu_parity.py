@@ -814,6 +814,11 @@ def test_bench_two_ranks_share_the_gpu(tmp_path):
     assert "rccl_ranks_seen" in d and d["rccl_ranks_seen"] is None  # gloo carried the barrier: RCCL was not probed
     assert d["barrier_backend"] == "gloo" and d["timing"]["timed_seconds"] >= 0.5 and d["timing"]["regions"] >= 1  # --min-seconds 0.5 below
     assert d["timing"]["timed_steps"] == d["timing"]["regions"] * 2
+    # round 6: the product's route end to end (FASTQ files -> all files, tail included), both tails, the same files
+    e2e = d["c4_end_to_end"]
+    assert "error" not in e2e, e2e
+    assert e2e["same_files_both_tails"] is True and e2e["ranges"]["wall_s"] > 0 and e2e["rank0_alone"]["wall_s"] > 0
+    assert len(e2e["ranges"]["range_tail_per_rank"]) == 2 and e2e["ranges"]["output_bytes"]["mapped.csv"] > 1_000_000
     # the RCCL guard: when RCCL cannot come up (here: made to fail; on this box two ranks on one GPU would fail by themselves)
     # every rank falls back to gloo together and the line says which backend carried the barrier
     env2 = dict(os.environ, MIRGE_BENCH_SHARE_GPU="1", MIRGE_BENCH_FORCE_NCCL_FAIL="1", OMP_NUM_THREADS="4")
