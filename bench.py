@@ -480,7 +480,47 @@ def secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, I
                             "note": "`value`: every read drawn independently from the class mix"}}
     n = args.reads
 
-    def leg(reads_fs, note):
+    from mirge3_amd.cascade import Cascade as _Cascade
+
+    def in_flight(reads_fs, one_ms, counts=(2, 4)):
+        """the same sample stepped by k contexts side by side (k host threads, k sets of HIP streams, k copies of the libraries): what
+        a batch of such samples per GPU runs at -- on the default draw the chip is full and two contexts only contend (0.83-0.86 x);
+        this set leaves it mostly idle"""
+        import threading
+        res, extra = {"1": {"ms_per_sample": round(one_ms, 4)}}, []
+        try:
+            for _ in range(max(counts) - 1):
+                c2 = _ffi.Context(casc.ctx.device)
+                k2 = _Cascade(c2, casc.libs, n_pass=9)
+                extra.append((c2, k2, _ffi.DeviceReads.pack(c2, reads_fs)))
+            r0 = _ffi.DeviceReads.pack(ctx, reads_fs)
+            workers = [(ctx, casc, r0)] + extra
+
+            def stepper(w, reps):
+                cx, kc, rw = w
+                for _ in range(reps):
+                    uq, rs = kc.collapse_and_run(rw)
+                    _ffi.count_join(cx, uq, rs, EXACT_PASS, ISO_PASS, n_mirna)
+                    rs.close(); uq.close()
+            for w in workers:
+                stepper(w, 3)
+            reps = max(20, min(400, int(0.3 / max(one_ms * 1e-3, 1e-6))))
+            for kk in counts:
+                th = [threading.Thread(target=stepper, args=(w, reps)) for w in workers[:kk]]
+                t = time.perf_counter()
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                per = (time.perf_counter() - t) / (kk * reps)
+                res[str(kk)] = {"ms_per_sample": round(per * 1e3, 4), "speedup": round(one_ms / (per * 1e3), 3)}
+            r0.close()
+        finally:
+            for c2, k2, rw in extra:
+                rw.close(); k2.close(); c2.close()
+        return res
+
+    def leg(reads_fs, note, flights=None):
         raw_s = _ffi.DeviceReads.pack(ctx, reads_fs)
         u_n = [0]
 
@@ -497,13 +537,19 @@ def secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, I
             one(); k += 1
         dt = (time.perf_counter() - t0) / k
         raw_s.close()
-        return {"raw_reads": len(reads_fs), "unique_reads": u_n[0], "U_over_N": round(u_n[0] / len(reads_fs), 4), "steps": k,
-                "ms_per_step": round(dt * 1e3, 4), "M_raw_reads_per_s": round(len(reads_fs) / dt / 1e6, 1),
-                "M_collapsed_reads_per_s": round(u_n[0] / dt / 1e6, 1), "note": note}
+        out_l = {"raw_reads": len(reads_fs), "unique_reads": u_n[0], "U_over_N": round(u_n[0] / len(reads_fs), 4), "steps": k,
+                 "ms_per_step": round(dt * 1e3, 4), "M_raw_reads_per_s": round(len(reads_fs) / dt / 1e6, 1),
+                 "M_collapsed_reads_per_s": round(u_n[0] / dt / 1e6, 1), "note": note}
+        if flights:
+            try:
+                out_l["samples_in_flight"] = in_flight(reads_fs, dt * 1e3, flights)
+            except Exception as e:  # noqa: BLE001
+                out_l["samples_in_flight"] = {"error": repr(e)[:300]}
+        return out_l
 
     pool = max(1000, n // 8)
     res["zipf_pool"] = leg(synth.make_reads(sl, n, seed=2000, pool=pool),
-                           f"Zipf(s = 1.1) duplication over {pool} templates of the same class mix: SURVEY 8(d)'s 'realistic' set")
+                           f"Zipf(s = 1.1) duplication over {pool} templates of the same class mix: SURVEY 8(d)'s 'realistic' set", flights=(2, 4))
     # all distinct: the default class mix without its duplicated exact-miRNA class, collapsed once on the GPU, its unique reads
     # taken as the raw reads of the leg (every read once)
     mix = dict(synth.DEFAULT_MIX, exact=0.01)
@@ -547,13 +593,15 @@ def repeat_rich_leg(args, ctx, _ffi, synth, Cascade, PASSES, n_mirna, EXACT_PASS
     first_step_s = time.perf_counter() - t1  # probe tables of these libraries are built here
     for _ in range(2):
         one()
-    ctx.profile(True); ctx.profile_only("k_cascade_bulk"); ctx.profile_reset()
+    ctx.profile(True); ctx.profile_only(""); ctx.profile_reset()
     for _ in range(3):
         one()
-    recs = [r for r in ctx.profile_records() if r[0].startswith("k_cascade_bulk") and r[1]]
+    recs_all = [r for r in ctx.profile_records() if r[1]]
+    recs = [r for r in recs_all if r[0].startswith("k_cascade_bulk")]
     wg = _ffi.cascade_wg_times(ctx)
     ctx.profile(False); ctx.profile_only("")
     bulk_ms = max((ms / l for _, l, ms, _ in recs), default=None)
+    top = sorted(((nm, ms / l) for nm, l, ms, _ in recs_all), key=lambda x: -x[1])[:6]
     k = 0
     t = time.perf_counter()
     while k < 10 or time.perf_counter() - t < 0.3:
@@ -562,7 +610,7 @@ def repeat_rich_leg(args, ctx, _ffi, synth, Cascade, PASSES, n_mirna, EXACT_PASS
     out = {"raw_reads": n, "unique_reads": u_n[0], "U_over_N": round(u_n[0] / n, 4), "steps": k, "ms_per_step": round(dt * 1e3, 4),
            "M_raw_reads_per_s": round(n / dt / 1e6, 1), "M_collapsed_reads_per_s": round(u_n[0] / dt / 1e6, 1),
            "vs_default_draw_step": round(dt * 1e3 / default_ms, 3), "k_cascade_bulk_ms": None if bulk_ms is None else round(bulk_ms, 4),
-           "setup_s": round(setup_s, 1), "first_step_s": round(first_step_s, 3),
+           "setup_s": round(setup_s, 1), "first_step_s": round(first_step_s, 3), "longest_kernels_ms": {nm: round(v, 4) for nm, v in top},
            "library_bases": {kk: v.total_len for kk, v in sl_r.libs.items()},
            "note": "libraries with poly-A tails, Alu-like families, simple repeats and tRNA isodecoder families + 15 % repeat-derived reads; "
                    "vs_default_draw_step = this step / the uniform libraries' step of `value`"}

@@ -20,6 +20,19 @@
 #define MIRGE_LIGHT_MAX 16
 #endif
 #define MIRGE_COOP_UNROLL 1
+#ifndef MIRGE_SORTED_EXIT
+#define MIRGE_SORTED_EXIT 1   // heavy buckets are position-sorted at build time (native_lib.hpp): scans may stop at a 0-mismatch hit
+#endif
+#ifndef MIRGE_ADAPTIVE_LIGHT
+#define MIRGE_ADAPTIVE_LIGHT 1  // many lanes with long lists (Alu-like families): the lanes walk their own lists side by side
+#endif
+#ifndef MIRGE_MIN_BUCKET
+#define MIRGE_MIN_BUCKET 1    // exact-seed policies: a read whose probe bucket is heavy takes the rarest k-mer of its seed instead
+#endif
+// k_cascade_heavy: a workgroup of 1024 threads per read, four windows per thread in flight: a bucket of 2 M windows is 512 trips
+#define MIRGE_HEAVY_THREADS 1024
+#define MIRGE_HEAVY_UNROLL 4
+#define MIRGE_HEAVY_RETRY 64  // windows in an exact-seed probe's bucket from which the other k-mers of the seed are asked
 #ifndef MIRGE_LDS_PLAN
 #define MIRGE_LDS_PLAN 1
 #endif
@@ -200,6 +213,33 @@ __device__ __forceinline__ bool probe_setup(const MirgeLibView& lib, const PlanS
     return true;
 }
 
+// The k-mer of the read's seed region [0, S) with the fewest windows in table tb, if one has fewer than `have` (the count of the
+// k-mer at offset 0): {lo, hi, its offset a > 0, inl = the bucket holds one window and lo IS its position}; a = 0: none.  A call,
+// not inlined: the branch is rare (a read out of a repeat), and inlined its temporaries cost k_cascade_bulk seven more spilled
+// vector registers on every read's path.
+struct RareKmer { uint32_t lo, hi; int32_t a; uint32_t inl; };
+template <int W>
+__device__ __attribute__((noinline)) RareKmer rarest_kmer(MirgeKTable tb, MirgeRead<W> r, int S, int k, uint32_t have) {
+    RareKmer out{0u, 0u, 0, 0u};
+    gptr_u32 bits = (gptr_u32)tb.bits;
+    for (int a2 = 1; a2 + k <= S; a2++) {
+        if (mirge_extract<W>(r.nm, a2, k)) continue;
+        const uint64_t key2 = mirge_extract<W>(r.w, a2, k);
+        uint32_t lo2 = 0, hi2 = 0, inl = 0;
+        if (!bits) {
+            const uint64_t e = ((gptr_u64)tb.bucket)[key2];
+            lo2 = (uint32_t)e; hi2 = lo2 + (uint32_t)(e >> 32);
+            inl = (uint32_t)(e >> 32) == 1u ? 1u : 0u;
+        } else if ((bits[key2 >> 5] >> (key2 & 31)) & 1u) {
+            const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key2);
+            lo2 = bd.a; hi2 = bd.b;
+        }
+        if (hi2 - lo2 < have) { have = hi2 - lo2; out.lo = lo2; out.hi = hi2; out.a = a2; out.inl = inl; }
+        if (have < MIRGE_HEAVY_RETRY) break;
+    }
+    return out;
+}
+
 // long candidate lists (repeats, poly-A), one at a time by the whole wave: the owner's read is broadcast, the 64 lanes
 // stride through the bucket (coalesced pos[] loads), the few lanes that found a valid window are read back
 template <int W>
@@ -222,12 +262,18 @@ __device__ __forceinline__ void verify_heavy(const MirgeLibView& lib, const Mirg
         const int ba = __builtin_amdgcn_readlane(a, src);
         gptr_u32 bpos = (gptr_u32)readlane_u64((uint64_t)pos, src);
         uint64_t lbest = MIRGE_NO_HIT;
-        for (uint32_t c0 = blo + lane; c0 < bhi; c0 += 64 * MIRGE_COOP_UNROLL) {
+        for (uint32_t c0 = blo + lane; c0 - lane < bhi; c0 += 64 * MIRGE_COOP_UNROLL) {  // (wave-uniform trip count: the ballot below)
             uint32_t c[MIRGE_COOP_UNROLL];
 #pragma unroll
             for (int u = 0; u < MIRGE_COOP_UNROLL; u++) c[u] = c0 + 64 * u;
             const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, mi, rr, bpos, c, bhi, ba);
             if (cand < lbest) lbest = cand;
+#if MIRGE_SORTED_EXIT
+            // (round 6) the list ascends (k_table_heavy_list + the segmented sort): candidates rank by (class, mismatches, position),
+            // class and position only grow from here, so a window without a mismatch is final -- the scan of a poly-A bucket of 10^6
+            // windows ends at the first tail that holds the read
+            if (__ballot(cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u)) break;
+#endif
         }
         // almost every candidate fails verification: instead of a shuffle tree, visit the few
         // lanes that hold a hit (v_readlane -> scalar min)
@@ -250,7 +296,21 @@ __device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const Mirg
     // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
     // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
     // per list and many such lanes per probe the lane-serial batches are several times cheaper)
-    const bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
+    bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
+#if MIRGE_ADAPTIVE_LIGHT
+    // (round 6) A hand-over serves ONE lane's list at a time: 64 lanes that each hold a list of 300 windows (reads out of an
+    // Alu-like family with 800 diverged copies) cost the wave 64 x 5 trips, while the lanes walking their own lists side by side
+    // cost it 300 / MIRGE_LIGHT = 75.  So: with the wave's heavy lists summing to n windows the cooperative route takes n / 64 trips,
+    // and a lane whose own list is no longer than that (times MIRGE_LIGHT) may as well walk it itself; the truly long lists -- a
+    // poly-A bucket -- stay with the whole wave.
+    const unsigned long long hb0 = __ballot(heavy);
+    if (hb0 & (hb0 - 1)) {  // two heavy lanes or more
+        uint32_t tot = heavy ? hi - lo : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
+        if (heavy && (hi - lo) <= (tot >> 4)) heavy = false;
+    }
+#endif
     if (!heavy) {
         for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
             uint32_t c[MIRGE_LIGHT];
@@ -258,6 +318,9 @@ __device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const Mirg
             for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
             const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a, best);
             if (cand < best) best = cand;
+#if MIRGE_SORTED_EXIT
+            if (hi - lo > MIRGE_LIGHT_MAX && cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u) break;  // (a sorted list: see verify_heavy)
+#endif
         }
     }
     verify_heavy<W>(lib, pol, mi, r, pos, lo, hi, a, heavy, best);
@@ -273,6 +336,11 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
     const int np = active ? (int)(LDS ? ps.l->np[r.len] : ps.g->np[r.len]) : 0;
     // wave-uniform bound on the probe count: (mm+1) plain segments or (mm+1)^2 recursive probes
     const int npmax = (pol.mm >= 1 && pol.mm <= 2) ? (pol.mm + 1) * (pol.mm + 1) : pol.mm + 1;
+    // (round 6) pol.reserved > 0: a read that meets a bucket of more windows than that is not aligned by this wave -- one such list
+    // (a poly-A bucket of the mRNA library: 2 M windows) kept ONE wave busy for 20 ms while the chip idled.  It is answered
+    // MIRGE_DEFER and taken by k_cascade_heavy: a whole workgroup per read, its lists strided by 256 threads.
+    const uint32_t big_t = (uint32_t)pol.reserved;
+    bool defer = false;
 #pragma unroll 1
     for (int q = 0; q < npmax; q++) {
         uint32_t lo = 0, hi = 0;
@@ -296,12 +364,99 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
                 hi = bd.b;
             }
             a = pr.a1;
+#if MIRGE_MIN_BUCKET
+            // (round 6) An exact-seed policy (mm = 0: mRNA, spike-in) admits no mismatch inside the seed, so ANY k-mer of the seed
+            // filters completely -- the plan takes the first.  A read out of a repeat with a sequencing error (poly-A with one G) whose
+            // first k-mer misses the error lands in a bucket of 10^5 .. 10^6 windows none of which can verify; a k-mer that holds the
+            // error is rare.  So a read whose bucket is heavy asks the other k-mers of its seed for their counts and takes the rarest.
+            if (pol.mm == 0 && pr.k2 == 0 && (hi - lo) >= MIRGE_HEAVY_RETRY) {
+                const RareKmer rk = rarest_kmer<W>(tb, r, mirge_seed_region(pol, r.len), pr.k1, hi - lo);
+                if (rk.a > 0) { lo = rk.lo; hi = rk.hi; a = rk.a; pos = rk.inl ? nullptr : (gptr_u32)tb.pos; }
+            }
+#endif
+            if (big_t && (hi - lo) > big_t) { defer = true; active = false; lo = hi = 0; }  // (its other probes need not be looked at either)
         }
         verify_lists<W>(lib, pol, mi, r, pos, lo, hi, a, best);
         // a 0-mismatch window (of the first member library) is in probe 0's bucket and buckets ascend:
         // nothing later can beat it
         if (q == 0 && (best >> 32) == 0) active = false;
     }
+    if (defer) best = MIRGE_DEFER;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cascade_heavy (round 6): the reads align_hybrid answered MIRGE_DEFER for -- one of their probe buckets holds more windows
+// than a wave should walk alone (poly-A, Alu-like and simple-repeat buckets of real libraries: 10^4 .. 10^6 windows) -- with ONE
+// WORKGROUP per read: every step of the cascade from the first on (the answer depends on the read alone, so redoing the passes
+// that found nothing costs a few lookups and changes nothing), every candidate list strided by all 256 threads, two windows per
+// thread in flight, the scan of a position-sorted list ended by the first window without a mismatch.  Same probes, same
+// verification, same minimum as align_hybrid: same answers.  heavy_cnt[0] = reads in heavy_list (appended by the cascade kernels
+// of this group), heavy_cnt[1] = workgroups done: the last one resets both for the next launch.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wg_min_u64(uint64_t v, unsigned long long* s_best) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t t = ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        if (t < v) v = t;
+    }
+    if (threadIdx.x == 0) *s_best = MIRGE_NO_HIT;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) atomicMin(s_best, (unsigned long long)v);
+    __syncthreads();
+    const uint64_t m = *s_best;
+    __syncthreads();  // (everybody has read it before the next reduction resets it)
+    return m;
+}
+
+template <int W>
+__device__ __forceinline__ uint64_t align_wg(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
+                                             const MirgePlanTable* __restrict__ plan, const MirgeRead<W>& r, unsigned long long* s_best) {
+    uint64_t best = MIRGE_NO_HIT;  // this thread's; the workgroup's minimum at the end
+    const int np = (int)plan->np[r.len];
+    for (int q = 0; q < np; q++) {  // everything up to the scan is uniform over the workgroup: one read
+        const MirgeProbe pr = plan->pr[r.len][q];
+        uint64_t key;
+        if (!mirge_probe_key<W>(r, pr, key)) continue;
+        const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
+        gptr_u32 bits = (gptr_u32)tb.bits;
+        uint32_t lo = 0, hi = 0;
+        gptr_u32 pos = nullptr;
+        if (!bits) {
+            const uint64_t e = ((gptr_u64)tb.bucket)[key];
+            const uint32_t cnt = (uint32_t)(e >> 32);
+            lo = (uint32_t)e; hi = lo + cnt;
+            pos = cnt == 1 ? nullptr : (gptr_u32)tb.pos;
+        } else if ((bits[key >> 5] >> (key & 31)) & 1u) {
+            const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key);
+            pos = (gptr_u32)tb.pos; lo = bd.a; hi = bd.b;
+        }
+        int a = pr.a1;
+#if MIRGE_MIN_BUCKET
+        if (pol.mm == 0 && pr.k2 == 0 && (hi - lo) >= MIRGE_HEAVY_RETRY) {
+            const RareKmer rk = rarest_kmer<W>(tb, r, mirge_seed_region(pol, r.len), pr.k1, hi - lo);
+            if (rk.a > 0) { lo = rk.lo; hi = rk.hi; a = rk.a; pos = rk.inl ? nullptr : (gptr_u32)tb.pos; }
+        }
+#endif
+        const bool sorted = (hi - lo) > MIRGE_LIGHT_MAX;  // (what k_table_heavy_list lists)
+        for (uint32_t c0 = lo + threadIdx.x; c0 - threadIdx.x < hi; c0 += MIRGE_HEAVY_UNROLL * MIRGE_HEAVY_THREADS) {
+            uint32_t c[MIRGE_HEAVY_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MIRGE_HEAVY_UNROLL; u++) c[u] = c0 + u * MIRGE_HEAVY_THREADS;
+            const uint64_t cand = eval_batch<W, MIRGE_HEAVY_UNROLL>(lib, pol, mi, r, pos, c, hi, a);
+            if (cand < best) best = cand;
+            if (MIRGE_SORTED_EXIT && sorted && __syncthreads_or(cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u)) break;
+        }
+        // a 0-mismatch window of the first member library is in probe 0's bucket: nothing later can beat it
+        if (q == 0 && np > 1 && (wg_min_u64(best, s_best) >> 32) == 0) break;
+    }
+    return wg_min_u64(best, s_best);
+}
+
+// a deferred read: marked (the heavy kernel overwrites the mark), listed
+__device__ __forceinline__ void defer_read(uint32_t idx, uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list,
+                                           int8_t* __restrict__ res_pass, int8_t* __restrict__ res_mm) {
+    res_pass[idx] = -2; res_mm[idx] = -1;
+    heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -334,7 +489,8 @@ template <int W, bool LDSP, bool COHERENT, bool HASN = true>
 __device__ __forceinline__ void pass_segment(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const PlanSrc<LDSP>& psrc,
                                              const GroupView<W>& g, const uint32_t* act_in, uint32_t n_in, size_t seg, size_t seg_r,
                                              uint32_t* __restrict__ act_out, int32_t pass_id, int8_t* __restrict__ res_pass,
-                                             uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, uint32_t* s_count) {
+                                             uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, uint32_t* s_count,
+                                             uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
     const int lane = threadIdx.x & 63;
     for (uint32_t base = 0; base < n_in; base += MIRGE_BLOCK) {
         const uint32_t t = base + threadIdx.x;
@@ -359,6 +515,10 @@ __device__ __forceinline__ void pass_segment(const MirgeLibView& lib, const Mirg
         }
         uint64_t best;
         align_hybrid<W, LDSP>(lib, pol, mi, psrc, r2, elig, best);
+        if (elig && best == MIRGE_DEFER) {  // a bucket no wave should walk alone: k_cascade_heavy answers for this read
+            defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm);
+            survivor = false;
+        } else
         if (elig && best != MIRGE_NO_HIT) {
             const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
             res_pass[idx] = (int8_t)(pass_id + cls);
@@ -399,7 +559,7 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
        const uint32_t* __restrict__ act_in,
        const uint32_t* __restrict__ seg_n_in, uint32_t* __restrict__ act_out, uint32_t* __restrict__ seg_n_out,
        uint32_t cap, int32_t pass_id, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
-       int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
+       int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
     __shared__ uint32_t s_count;
     constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
     __shared__ __attribute__((aligned(16))) unsigned char s_plan_raw[LDSP ? sizeof(LdsPlan) : 16];
@@ -412,7 +572,8 @@ k_pass(MirgeLibView lib, MirgePolicy pol, MergeInfo mi, const MirgePlanTable* __
     const size_t seg = (size_t)blockIdx.x * cap;  // the workgroup's slice of the survivor arrays
     size_t seg_r = seg;
     const uint32_t n_in = act_in ? seg_n_in[blockIdx.x] : first_pass_share(g.n, n_dev, cap, seg_r);
-    pass_segment<W, LDSP, false>(lib, pol, mi, psrc, g, act_in, n_in, seg, seg_r, act_out, pass_id, res_pass, res_pos, res_mm, &s_count);
+    pass_segment<W, LDSP, false>(lib, pol, mi, psrc, g, act_in, n_in, seg, seg_r, act_out, pass_id, res_pass, res_pos, res_mm, &s_count,
+                                 heavy_cnt, heavy_list);
     __syncthreads();
     if (threadIdx.x == 0) seg_n_out[blockIdx.x] = s_count;
 }
@@ -633,7 +794,8 @@ template <int W, bool LDSP, bool COHERENT, bool HASN>
 __device__ __forceinline__ void walk_segment(const BulkWalk& wk, const PlanSrc<LDSP>& psrc, const GroupView<W>& g, const uint32_t* act_in,
                                              uint32_t n_in, size_t seg, size_t seg_r, uint32_t* __restrict__ act_out,
                                              int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm,
-                                             uint32_t* s_count, uint32_t* s_open) {
+                                             uint32_t* s_count, uint32_t* s_open, uint32_t* __restrict__ heavy_cnt,
+                                             uint32_t* __restrict__ heavy_list) {
     const int lane = threadIdx.x & 63;
     const bool has_main = wk.has_main != 0;
     if (W == 1 && !has_main) {  // a walk of exact steps only: its own short loop, nothing of the alignment's registers alive
@@ -704,6 +866,10 @@ __device__ __forceinline__ void walk_segment(const BulkWalk& wk, const PlanSrc<L
             const bool elig = open && mirge_effective_read<W>(r2, wk.main.pol);  // (a policy `post` follows leaves r2 as it was)
             uint64_t best;
             align_hybrid<W, LDSP>(wk.main.lib, wk.main.pol, wk.main.mi, psrc, r2, elig, best);
+            if (elig && best == MIRGE_DEFER) {  // a bucket no wave should walk alone: k_cascade_heavy answers for this read
+                defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm);
+                open = false;
+            } else
             if (elig && best != MIRGE_NO_HIT) {
                 const int cls = (int)(best >> 40);  // member library of a merged pass (0 otherwise)
                 res_pass[idx] = (int8_t)(wk.main.pass_id + cls);
@@ -745,7 +911,8 @@ template <int W, bool HASN>
 __global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(W == 1 ? MIRGE_BULK_WAVES : 1, 8)))  // one-word reads: 6 workgroups per CU must be resident (80 VGPRs; k_pass: 77); wider reads keep their registers
 k_cascade_bulk(const BulkWalks* __restrict__ walks, GroupView<W> g, uint32_t* __restrict__ actA, uint32_t* __restrict__ actB,
                uint32_t* __restrict__ seg_n, uint32_t cap, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
-               int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev) {
+               int8_t* __restrict__ res_mm, const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ heavy_cnt,
+               uint32_t* __restrict__ heavy_list) {
     __shared__ uint32_t s_count;
     __shared__ uint32_t s_open[2];  // reads still open behind the walk's pre step / behind its main pass
     constexpr bool LDSP = (W == 1) && MIRGE_LDS_PLAN;
@@ -767,7 +934,8 @@ k_cascade_bulk(const BulkWalks* __restrict__ walks, GroupView<W> g, uint32_t* __
         __syncthreads();
         PlanSrc<LDSP> psrc;
         psrc.g = wk.main.plan; psrc.l = LDSP ? s_plan : nullptr;
-        walk_segment<W, LDSP, !MIRGE_SURV_PLAIN_LOADS, HASN>(wk, psrc, g, act_in, n_in, seg, seg_r, act_out, res_pass, res_pos, res_mm, &s_count, s_open);
+        walk_segment<W, LDSP, !MIRGE_SURV_PLAIN_LOADS, HASN>(wk, psrc, g, act_in, n_in, seg, seg_r, act_out, res_pass, res_pos, res_mm, &s_count, s_open,
+                                                             heavy_cnt, heavy_list);
         __syncthreads();  // the survivors are written (and visible to this workgroup at L2), the plan is free again
         n_in = s_count;
         if (threadIdx.x == 0) {  // seg_n[step][workgroup] = reads still open behind that pass (= handed to the next one)
@@ -812,7 +980,7 @@ template <int W, bool HASN>
 __global__ void __launch_bounds__(MIRGE_BLOCK)
 k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView<W> g, int8_t* __restrict__ res_pass,
                 uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref,
-                int32_t* __restrict__ res_off) {
+                int32_t* __restrict__ res_off, uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
     const uint32_t nrounds = (g.n + MIRGE_BLOCK - 1) / MIRGE_BLOCK;
     const int nsteps = steps->n;
     for (uint32_t round = blockIdx.x; round < nrounds; round += gridDim.x) {
@@ -837,6 +1005,11 @@ k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
             PlanSrc<false> psrc;
             psrc.g = st.plan; psrc.l = nullptr;
             align_hybrid<W, false>(st.lib, st.pol, st.mi, psrc, r2, elig, best);
+            if (elig && best == MIRGE_DEFER) {  // k_cascade_heavy answers for this read (and writes all five of its fields)
+                o_pass = -2;
+                heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
+                open = false;
+            } else
             if (elig && best != MIRGE_NO_HIT) {
                 const int cls = (int)(best >> 40);
                 o_pass = (int8_t)(st.pass_id + cls);
@@ -854,5 +1027,49 @@ k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
             res_pass[idx] = o_pass; res_pos[idx] = o_pos; res_mm[idx] = o_mm;
             res_ref[idx] = ref; res_off[idx] = off;
         }
+    }
+}
+
+// (the reads align_hybrid deferred: see align_wg above)
+template <int W, bool HASN>
+__global__ void __launch_bounds__(MIRGE_HEAVY_THREADS)
+k_cascade_heavy(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView<W> g, uint32_t* __restrict__ heavy_cnt,
+                const uint32_t* __restrict__ heavy_list, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
+                int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off) {
+    __shared__ unsigned long long s_best;
+    const uint32_t n = __hip_atomic_load(&heavy_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nsteps = steps->n;
+    for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        const uint32_t idx = heavy_list[item];
+        MirgeRead<W> r0;
+        load_read<W, HASN>(g, idx, r0);
+        int8_t o_pass = -1, o_mm = -1;
+        uint32_t o_pos = 0;
+        for (int si = 0; si < nsteps && o_pass < 0; si++) {
+            const FusedStep& st = steps->s[si];
+            MirgeRead<W> r2 = r0;
+            if (!mirge_effective_read<W>(r2, st.pol)) continue;
+            const uint64_t best = align_wg<W>(st.lib, st.pol, st.mi, st.plan, r2, &s_best);
+            if (best != MIRGE_NO_HIT) {
+                const int cls = (int)(best >> 40);
+                o_pass = (int8_t)(st.pass_id + cls);
+                uint32_t b0 = 0;
+#pragma unroll
+                for (int i = 1; i < 4; i++) if (i == cls) b0 = st.mi.bound[i];
+                o_pos = (uint32_t)best - b0;
+                o_mm = (int8_t)((best >> 32) & 0xFF);
+            }
+        }
+        if (threadIdx.x == 0) {
+            int32_t ref = -1, off = -1;
+            if (o_pass >= 0) resolve_one(tb, o_pass, o_pos, ref, off);
+            res_pass[idx] = o_pass; res_pos[idx] = o_pos; res_mm[idx] = o_mm;
+            if (res_ref) { res_ref[idx] = ref; res_off[idx] = off; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&heavy_cnt[1], 1u) == gridDim.x - 1) {
+        __hip_atomic_store(&heavy_cnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&heavy_cnt[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

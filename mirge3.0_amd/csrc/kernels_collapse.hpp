@@ -216,7 +216,7 @@ __device__ __forceinline__ uint32_t region_prefix(const uint32_t* __restrict__ c
 __global__ void __launch_bounds__(MIRGE_PART_THREADS)
 k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uint32_t chunk, uint32_t shift1, uint32_t NB1,
            uint32_t bshift, uint32_t B, uint32_t CS, uint32_t cap1, uint4* __restrict__ rec1, uint32_t* __restrict__ cnt1,
-           uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow) {
+           uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow, uint32_t* __restrict__ n_records) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_a[];  // [CS] keys | [CS] minj | [CS] cnt | [NB1] cursors | [B] hist
     uint32_t* c_min = reinterpret_cast<uint32_t*>(lds_a + CS);
     uint32_t* c_cnt = c_min + CS;
@@ -343,6 +343,9 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
         const uint32_t n = cur[b];
         cnt1[(size_t)b * G + blockIdx.x] = min(n, cap1);
         if (n > cap1) atomicOr(overflow, 1u);
+        // (round 6) the sample's record count: what k_part_dedup chooses its output mode from -- on the device, for THIS sample
+        // (until round 5 the host chose from the context's previous sample)
+        atomicAdd(n_records, min(n, cap1));
     }
     if (hist) for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[(size_t)blockIdx.x * B + b] = lds_h[b];
 }
@@ -415,7 +418,15 @@ __global__ void __launch_bounds__(MIRGE_DEDUP_THREADS)
 k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t R,
              uint64_t rcap, uint32_t NB2, uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen,
              uint32_t* __restrict__ ucnt, uint32_t* __restrict__ ufirst, uint32_t* __restrict__ cursor,
-             uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow, uint32_t* __restrict__ shard_cur, uint32_t shard_cap) {
+             uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow, uint32_t* __restrict__ shard_cur_in, uint32_t shard_cap,
+             const uint32_t* __restrict__ n_records, uint32_t rec_thresh, uint64_t* __restrict__ sseq, uint8_t* __restrict__ slen, uint32_t* __restrict__ scnt,
+             uint32_t* __restrict__ sfirst) {
+    // Output mode, chosen HERE from the sample's record count (*n_records, written by k_part_agg; a line of its own): few records = few unique reads =
+    // the kernel's time is the one global cursor's returning adds (11.6 ns each, one per bucket) -> eight cursors into the staging
+    // arrays (s*), k_part_compact closes the gaps; many records = the kernel's time is its records -> the one cursor, straight into
+    // the output arrays (and k_part_compact returns at once).  Uniform over the launch: every workgroup reads the same word.
+    uint32_t* const shard_cur = (shard_cur_in && *n_records < rec_thresh) ? shard_cur_in : nullptr;
+    if (shard_cur) { useq = sseq; ulen = slen; ucnt = scnt; ufirst = sfirst; }
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
     uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + CAP);
     uint32_t* lds_cnt = lds_min + CAP;
@@ -543,7 +554,9 @@ __global__ void __launch_bounds__(256) k_part_compact(const uint32_t* __restrict
                                                        const uint64_t* __restrict__ sseq, const uint8_t* __restrict__ slen,
                                                        const uint32_t* __restrict__ scnt, const uint32_t* __restrict__ sfirst,
                                                        uint64_t* __restrict__ useq, uint8_t* __restrict__ ulen, uint32_t* __restrict__ ucnt,
-                                                       uint32_t* __restrict__ ufirst, uint32_t* __restrict__ n_out) {
+                                                       uint32_t* __restrict__ ufirst, uint32_t* __restrict__ n_out,
+                                                       const uint32_t* __restrict__ n_rec, uint32_t rec_thresh) {
+    if (!(*n_rec < rec_thresh)) return;  // k_part_dedup took the one cursor: the output is dense already, *n_out is that cursor
     uint32_t end[MIRGE_DEDUP_SHARDS];  // (compile-time indices only: registers)
     uint32_t run = 0;
     bool over = false;  // a shard that overflowed was left unwritten by some buckets (k_part_dedup set the overflow flag: the call is

@@ -123,6 +123,33 @@ __global__ void k_table_pass(const uint64_t* __restrict__ T, const uint64_t* __r
     }
 }
 
+// Round 6: the position list of every bucket the wave-cooperative scan takes (more than MIRGE_LIGHT_MAX = 16 windows) in ASCENDING
+// order.  With real libraries -- poly-A tails, Alu-derived elements, simple repeats -- such a bucket holds 10^3 .. 10^6 windows,
+// and a scan in position order may stop at the first window nothing later can beat (verify_heavy: a hit without a mismatch is final,
+// since candidates rank by class, mismatches, position and both class and position only grow from there).  The counting sort's
+// fill leaves a bucket in the order its atomics happened to be served: the heavy buckets are listed here (begin / end into pos[])
+// and sorted by one segmented radix sort per table.
+__global__ void k_table_heavy_list(const uint32_t* __restrict__ bucket, uint64_t nb, uint32_t min_count, uint32_t* __restrict__ n_heavy,
+                                   uint32_t cap, uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_end, uint32_t outlier_min) {
+    for (uint64_t k = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; k < nb; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t lo = bucket[k], hi = bucket[k + 1];
+        if (hi - lo < min_count) continue;
+        const uint32_t at = atomicAdd(n_heavy, 1u);
+        if (at < cap) { seg_begin[at] = lo; seg_end[at] = hi; }
+        // the fullest OUTLIER bucket -- far above what a uniform text of this size puts into a bucket of this table (a table of
+        // 1- or 2-base keys holds 10^4 windows per bucket by construction; a poly-A bucket of a 15-base table holds 10^6 because
+        // the library repeats itself): what decides whether reads may be deferred to k_cascade_heavy (mirge_lib::max_bucket)
+        if (hi - lo >= outlier_min) atomicMax(n_heavy + 1, hi - lo);
+    }
+}
+// sorted stretches back into the table's own list (the segmented sort writes to a second array and leaves what lies outside the
+// listed segments unwritten): one workgroup per segment in turn, coalesced
+__global__ void k_table_heavy_copy(const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end, uint32_t n_seg,
+                                   const uint32_t* __restrict__ sorted, uint32_t* __restrict__ pos) {
+    for (uint32_t sg = blockIdx.x; sg < n_seg; sg += gridDim.x)
+        for (uint32_t i = seg_begin[sg] + threadIdx.x; i < seg_end[sg]; i += blockDim.x) pos[i] = sorted[i];
+}
+
 // CSR bounds + position list -> self-contained entries (MirgeKTable): {count, the position itself | list start}
 __global__ void k_table_entries(const uint32_t* __restrict__ bucket, const uint32_t* __restrict__ pos, uint64_t nb,
                                 uint64_t* __restrict__ entry) {

@@ -30,6 +30,9 @@
 #endif
 #define MIRGE_MAX_READ_LEN 255   // the four TEMPLATED width classes of 1 / 2 / 4 / 8 words, whose length is a byte (longer: kernels_long.hpp)
 #define MIRGE_NO_HIT 0xFFFFFFFFFFFFFFFFull
+// align_hybrid's answer for a read one of whose probe buckets holds more windows than the pass's MirgePolicy::reserved (> 0): not
+// aligned here -- the read goes to k_cascade_heavy, one workgroup per read (kernels_cascade.hpp, round 6)
+#define MIRGE_DEFER 0xFFFFFFFFFFFFFFFEull
 
 // Cascade policy of one pass: the restated bowtie-1 argument string
 // (reference: mirge/libs/manifoldAlign.py:85).

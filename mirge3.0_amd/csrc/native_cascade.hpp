@@ -88,6 +88,29 @@ static int prepare_tables(mirge_lib* lib, const mirge_policy& pol, const int32_t
     return lib_prepare_shapes(lib, wanted);
 }
 
+// the two counters k_cascade_heavy works with (reads listed, workgroups done; zero between launches: the kernel's last workgroup
+// resets them) for the group with this tag, or nullptr when no library of the configuration holds a bucket beyond casc_big_t
+static uint32_t* heavy_counters(mirge_ctx* c, const char* gtag) {
+    if (!c->casc_big_t || !c->heavy_cnt) return nullptr;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+        if (std::strcmp(group_tag(gi), gtag) == 0) return c->heavy_cnt + 2 * gi;
+    return c->heavy_cnt;
+}
+template <int W>
+static void launch_heavy(mirge_ctx* c, const ReadGroup& rg, const ResGroup& out, const FusedSteps* dsteps, const ResolveTable& rt, const char* gtag,
+                         uint32_t* hcnt, const uint32_t* hlist, const GroupView<W>& v, bool with_resolve) {
+    char name[40];
+    std::snprintf(name, sizeof(name), "k_cascade_heavy%s", gtag);
+    LaunchScope ls(c, name, 0.0);
+    const uint32_t grid = (uint32_t)c->n_cu * 2u;  // two 1024-thread workgroups per CU
+    int32_t* rr = with_resolve ? out.ref : nullptr;
+    int32_t* ro = with_resolve ? out.off : nullptr;
+    if (rg.nmask)
+        hipLaunchKernelGGL((k_cascade_heavy<W, true>), dim3(grid), dim3(MIRGE_HEAVY_THREADS), 0, c->cur, dsteps, rt, v, hcnt, hlist, out.pass, out.pos, out.mm, rr, ro);
+    else
+        hipLaunchKernelGGL((k_cascade_heavy<W, false>), dim3(grid), dim3(MIRGE_HEAVY_THREADS), 0, c->cur, dsteps, rt, v, hcnt, hlist, out.pass, out.pos, out.mm, rr, ro);
+}
+
 template <int W>
 static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const std::vector<PassStep>& steps,
                          const mirge_policy* pol, const ResolveTable& rt, const char* gtag,
@@ -129,6 +152,10 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     uint32_t cap = (n + grid - 1) / grid;
     cap = (cap + MIRGE_BLOCK - 1) / MIRGE_BLOCK * MIRGE_BLOCK;
     uint32_t *actA = nullptr, *actB = nullptr, *seg_n = nullptr;
+    // (round 6) reads whose probe bucket no wave should walk alone go to k_cascade_heavy: their list, this group's counters
+    uint32_t* const hcnt = heavy_counters(c, gtag);
+    uint32_t* hlist = nullptr;
+    if (hcnt) CHECK(dalloc(c, &hlist, (size_t)n));
     CHECK(dalloc(c, &actA, (size_t)grid * cap));
     CHECK(dalloc(c, &actB, (size_t)grid * cap));
     CHECK(dalloc(c, &seg_n, (size_t)grid * (MIRGE_MAX_PASSES + 3)));  // (+ 2 rows: the workgroups' start / end clocks, k_cascade_bulk)
@@ -155,10 +182,10 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         // (a group without ambiguous calls runs the build of the kernel in which the N masks are compile-time zeros)
         if (rg.nmask)
             hipLaunchKernelGGL((k_cascade_bulk<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos,
-                               out.mm, n_dev);
+                               out.mm, n_dev, hcnt, hlist);
         else
             hipLaunchKernelGGL((k_cascade_bulk<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos,
-                               out.mm, n_dev);
+                               out.mm, n_dev, hcnt, hlist);
         stage = (int)steps.size();
         if (c->profiling && W == 1) {  // the workgroups' clocks of this launch, for mirge_cascade_wg_times (stream-ordered copy)
             if (c->wg_pinned_words < 2 * (size_t)grid) {
@@ -176,6 +203,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         const int32_t p = st.p0;
         MirgePolicy mp;
         std::memcpy(&mp, &pol[p], sizeof(mp));
+        mp.reserved = hcnt ? (int32_t)c->casc_big_t : 0;
         {
             if (st.np > 1) std::snprintf(name, sizeof(name), "k_pass[%d-%d]%s", (int)p, (int)(p + st.np - 1), gtag);
             else std::snprintf(name, sizeof(name), "k_pass[%d]%s", (int)p, gtag);
@@ -185,7 +213,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
             uint32_t* sn_out = seg_n + (size_t)grid * stage;
 #define MIRGE_LAUNCH_PASS(SLOT)                                                                                       \
     hipLaunchKernelGGL((k_pass<W, SLOT>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, st.lib->view(), mp, st.mi, st.dplan, v, act_in, \
-                       sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm, n_dev)
+                       sn_in, act_out, sn_out, cap, p, out.pass, out.pos, out.mm, n_dev, hcnt, hlist)
             switch (p) {
                 case 0: MIRGE_LAUNCH_PASS(0); break;
                 case 1: MIRGE_LAUNCH_PASS(1); break;
@@ -205,6 +233,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         act_out = (act_out == actA) ? actB : actA;
         stage++;
     }
+    if (hcnt && stage > 0) launch_heavy<W>(c, rg, out, c->casc_dsteps, rt, gtag, hcnt, hlist, v, false);  // (k_resolve follows for every read)
     {
         std::snprintf(name, sizeof(name), "k_resolve%s", gtag);
         LaunchScope ls(c, name, n);
@@ -220,7 +249,7 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
             c->prof_used += words;
         }
     }
-    c->defer(actA); c->defer(actB); c->defer(seg_n);
+    c->defer(actA); c->defer(actB); c->defer(seg_n); c->defer(hlist);
     return 0;
 }
 
@@ -236,16 +265,23 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     CHECK(dalloc(c, &out.mm, n));
     CHECK(dalloc(c, &out.ref, n));
     CHECK(dalloc(c, &out.off, n));
+    uint32_t* const hcnt = heavy_counters(c, gtag);
+    uint32_t* hlist = nullptr;
+    if (hcnt) CHECK(dalloc(c, &hlist, (size_t)n));
     char name[32];
     std::snprintf(name, sizeof(name), "k_cascade_fused%s", gtag);
-    LaunchScope ls(c, name, n);
-    const uint32_t grid = std::min<uint32_t>((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (uint32_t)c->n_cu * 8);
-    if (rg.nmask)
-        hipLaunchKernelGGL((k_cascade_fused<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
-                           out.pos, out.mm, out.ref, out.off);
-    else  // no ambiguous calls in the group: the build whose N masks are compile-time zeros
-        hipLaunchKernelGGL((k_cascade_fused<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
-                           out.pos, out.mm, out.ref, out.off);
+    {
+        LaunchScope ls(c, name, n);
+        const uint32_t grid = std::min<uint32_t>((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (uint32_t)c->n_cu * 8);
+        if (rg.nmask)
+            hipLaunchKernelGGL((k_cascade_fused<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
+                               out.pos, out.mm, out.ref, out.off, hcnt, hlist);
+        else  // no ambiguous calls in the group: the build whose N masks are compile-time zeros
+            hipLaunchKernelGGL((k_cascade_fused<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
+                               out.pos, out.mm, out.ref, out.off, hcnt, hlist);
+    }
+    if (hcnt) launch_heavy<W>(c, rg, out, dsteps, rt, gtag, hcnt, hlist, view_of<W>(rg), true);
+    c->defer(hlist);
     return 0;
 }
 
@@ -334,6 +370,17 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         }
         st.dplan = dp;
     }
+    // (round 6) Does any library of this configuration hold a probe bucket beyond MIRGE_BIG_T windows (default 8192; 0: never defer)?
+    // Then the steps carry that threshold (MirgePolicy::reserved): a read that meets such a bucket is answered by k_cascade_heavy, a
+    // workgroup per read.  Uniform-random libraries hold none: their cascades run as before, without the extra launch.
+    static const uint32_t big_t_env = std::getenv("MIRGE_BIG_T") ? (uint32_t)std::strtoul(std::getenv("MIRGE_BIG_T"), nullptr, 10) : 8192u;
+    c->casc_big_t = 0;
+    for (auto& st : steps)
+        if (big_t_env && st.lib->max_bucket > big_t_env) c->casc_big_t = big_t_env;
+    if (c->casc_big_t && !c->heavy_cnt) {
+        HIPOK(hipMalloc((void**)&c->heavy_cnt, 2 * MIRGE_NGROUPS * 4));
+        HIPOK(hipMemset(c->heavy_cnt, 0, 2 * MIRGE_NGROUPS * 4));
+    }
     // the step list of the fused small-group kernel lives in device memory; uploaded when it changes
     auto fs = std::make_unique<FusedSteps>();
     std::memset(fs.get(), 0, sizeof(FusedSteps));
@@ -342,6 +389,7 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         FusedStep& f = fs->s[i];
         f.lib = steps[i].lib->view();
         std::memcpy(&f.pol, &pol[steps[i].p0], sizeof(MirgePolicy));
+        f.pol.reserved = (int32_t)c->casc_big_t;
         f.mi = steps[i].mi;
         f.plan = steps[i].dplan;
         f.pass_id = steps[i].p0;

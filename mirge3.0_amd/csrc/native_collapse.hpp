@@ -17,7 +17,7 @@ struct CollapseTmp {
     uint4 *rec1 = nullptr, *rec2 = nullptr;
     uint32_t *cnt1 = nullptr, *cnt2 = nullptr, *off2 = nullptr, *hist = nullptr;
     // k_part_dedup's sharded output (attempt 0): cursors, capacity of a shard's stretch, the staging arrays k_part_compact reads
-    uint32_t *shard_cur = nullptr, shard_cap = 0, *s_cnt = nullptr, *s_first = nullptr;
+    uint32_t *shard_cur = nullptr, shard_cap = 0, *s_cnt = nullptr, *s_first = nullptr, rec_thresh = 0;
     uint64_t* s_seq = nullptr;
     uint8_t* s_len = nullptr;
     uint32_t G = 0, B = 0, NB1 = 0, NB2 = 1, W2 = 1, RPW = 0, cap1 = 0, shift2 = 0, cap = MIRGE_PART_CAP;
@@ -34,7 +34,11 @@ struct CollapseTmp {
 #define MIRGE_META_OVERFLOW 10
 #define MIRGE_META_LONG_BASES 12
 #define MIRGE_META_HIST 16
-#define MIRGE_META_WORDS (MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1)
+// [MIRGE_META_RECORDS] records k_part_agg emitted -- on a 256-byte line of its own: every k_part_dedup workgroup reads it while the
+// buckets' returning adds hammer the cursor in word 0..9; on the cursor's line those reads queued behind the adds (k_part_dedup
+// 0.117 -> 0.175 ms on the default draw, measured)
+#define MIRGE_META_RECORDS (((MIRGE_META_HIST + MIRGE_MAX_READ_LEN + 1 + 63) & ~63) + 64)
+#define MIRGE_META_WORDS (MIRGE_META_RECORDS + 64)
 
 static const char* group_tag(int gi) {
     static const char* t[MIRGE_NGROUPS] = {".w1", ".w2", ".w4", ".w8", ".wl", ".w1n", ".w2n", ".w4n", ".w8n", ".wln"};
@@ -80,23 +84,25 @@ static int collapse_part_rest(mirge_ctx* c, int gi, const ReadGroup& in, ReadGro
         const uint32_t* off = two ? t.off2 : nullptr;
         const uint32_t R = two ? t.W2 : t.G;
         const uint64_t rcap = two ? t.slab : (uint64_t)t.cap1;
-        const bool sh = t.shard_cur != nullptr;  // the buckets write shard by shard into the staging arrays, k_part_compact makes them dense
-        uint64_t* const oseq = sh ? t.s_seq : reinterpret_cast<uint64_t*>(out.seq);
-        uint8_t* const olen = sh ? t.s_len : reinterpret_cast<uint8_t*>(out.len);
-        uint32_t* const ocnt = sh ? t.s_cnt : out.counts;
-        uint32_t* const ofirst = sh ? t.s_first : out.first;
+        // (round 6) with the staging arrays there (t.shard_cur) the kernel itself chooses, from the sample's record count, between
+        // eight cursors into them -- k_part_compact then makes the output dense -- and the one cursor into the output arrays
+        const bool sh = t.shard_cur != nullptr;
+        uint64_t* const oseq = reinterpret_cast<uint64_t*>(out.seq);
+        uint8_t* const olen = reinterpret_cast<uint8_t*>(out.len);
         if (t.cap == 2048)
             hipLaunchKernelGGL(k_part_dedup<2048>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), 2048 * 16 + 4096, c->cur, rec, cnt, off, R, rcap, t.NB2,
-                               oseq, olen, ocnt, ofirst, dmeta + gi, (uint32_t*)nullptr, dmeta + MIRGE_META_OVERFLOW, t.shard_cur, t.shard_cap);
+                               oseq, olen, out.counts, out.first, dmeta + gi, (uint32_t*)nullptr, dmeta + MIRGE_META_OVERFLOW, t.shard_cur, t.shard_cap,
+                               (const uint32_t*)(dmeta + MIRGE_META_RECORDS), t.rec_thresh, t.s_seq, t.s_len, t.s_cnt, t.s_first);
         else
             hipLaunchKernelGGL(k_part_dedup<MIRGE_PART_CAP>, dim3(t.B), dim3(MIRGE_DEDUP_THREADS), MIRGE_PART_CAP * 16 + 4096, c->cur, rec,
-                               cnt, off, R, rcap, t.NB2, oseq, olen, ocnt, ofirst, dmeta + gi, (uint32_t*)nullptr,
-                               dmeta + MIRGE_META_OVERFLOW, t.shard_cur, t.shard_cap);
+                               cnt, off, R, rcap, t.NB2, oseq, olen, out.counts, out.first, dmeta + gi, (uint32_t*)nullptr,
+                               dmeta + MIRGE_META_OVERFLOW, t.shard_cur, t.shard_cap, (const uint32_t*)(dmeta + MIRGE_META_RECORDS), t.rec_thresh,
+                               t.s_seq, t.s_len, t.s_cnt, t.s_first);
         if (sh) {
             LaunchScope ls2(c, "k_part_compact.w1", in.n);
             hipLaunchKernelGGL(k_part_compact, dim3((unsigned)c->n_cu * 8), dim3(256), 0, c->cur, (const uint32_t*)t.shard_cur, t.shard_cap,
                                (const uint64_t*)t.s_seq, (const uint8_t*)t.s_len, (const uint32_t*)t.s_cnt, (const uint32_t*)t.s_first,
-                               reinterpret_cast<uint64_t*>(out.seq), reinterpret_cast<uint8_t*>(out.len), out.counts, out.first, dmeta + gi);
+                               oseq, olen, out.counts, out.first, dmeta + gi, (const uint32_t*)(dmeta + MIRGE_META_RECORDS), t.rec_thresh);
         }
     }
     return 0;
@@ -188,8 +194,15 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         // default draw with 42 % unique reads 1.184 -> 1.190 (0.116 -> 0.123 + 0.028: there the kernel's time is its records).  So:
         // when the context's previous collapse found under a fifth of its reads unique -- the samples of a batch are alike; the
         // first one takes the cursor.  MIRGE_DEDUP_SHARDED=1 / 0: always / never (tests, A/B).
+        // Round 6: the choice is made ON THE DEVICE, per sample, from the record count k_part_agg leaves behind the overflow flag --
+        // a sample whose chunks merge into few records (Zipf over 1.25 M templates: 0.33 records per raw read) has few unique reads,
+        // the default draw (0.61) does not; the staging arrays are there either way (pool blocks, 19 B per raw read).  Until round 5
+        // the host chose from the context's PREVIOUS sample: a batch's first sample, or alternating kinds, got the other mode.
+        // MIRGE_DEDUP_SHARDED=1 / 0: always / never (tests, A/B); MIRGE_DEDUP_REC_SHARE: the threshold (records per raw read).
         static const int sharded_env = std::getenv("MIRGE_DEDUP_SHARDED") ? std::atoi(std::getenv("MIRGE_DEDUP_SHARDED")) : -1;
-        const bool sharded = sharded_env >= 0 ? sharded_env != 0 : (c->last_unique_share > 0.0 && c->last_unique_share < 0.2);
+        static const double rec_share = std::getenv("MIRGE_DEDUP_REC_SHARE") ? std::atof(std::getenv("MIRGE_DEDUP_REC_SHARE")) : 0.45;
+        const bool sharded = sharded_env != 0;
+        t.rec_thresh = sharded_env > 0 ? 0xFFFFFFFFu : (uint32_t)std::min<double>(4.0e9, rec_share * (double)in.n);
         if (sharded && attempt == 0 && !small_part) {
             t.shard_cap = in.n / MIRGE_DEDUP_SHARDS + in.n / (8 * MIRGE_DEDUP_SHARDS) + 65536u;
             const size_t sn = (size_t)t.shard_cap * MIRGE_DEDUP_SHARDS;
@@ -216,7 +229,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         {
             LaunchScope ls(c, "k_part_agg.w1", in.n);
             hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_PART_THREADS), agg_lds, c->cur, v1, in.orig, in.base, chunk, shift1, NB1,
-                               shift2, B, CS, cap1, t.rec1, t.cnt1, t.hist, dmeta + MIRGE_META_OVERFLOW);
+                               shift2, B, CS, cap1, t.rec1, t.cnt1, t.hist, dmeta + MIRGE_META_OVERFLOW, dmeta + MIRGE_META_RECORDS);
         }
         t.G = G; t.B = B; t.NB1 = NB1; t.NB2 = NB2; t.W2 = W2; t.RPW = RPW; t.cap1 = cap1; t.slab = slab; t.shift2 = shift2;
         if (stage == 1) return collapse_part_rest(c, gi, in, out, t, dmeta, 1);
@@ -555,8 +568,6 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
     if (rc == 0) {
         uint32_t U[MIRGE_NGROUPS];
         for (int gi = 0; gi < MIRGE_NGROUPS; gi++) U[gi] = c->pinned[gi];
-        for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
-            if (tmp[gi].partitioned && raw->g[gi].n) c->last_unique_share = (double)U[gi] / (double)raw->g[gi].n;
         R->total_bases = 0;
         for (int L = 0; L <= MIRGE_MAX_READ_LEN; L++) {
             R->len_hist[L] = (int32_t)c->pinned[MIRGE_META_HIST + L];

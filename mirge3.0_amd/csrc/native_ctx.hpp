@@ -43,9 +43,6 @@ struct mirge_ctx {
     // second stream: the small read groups (long reads, reads with N) run beside the big one.
     // cur = the stream the launch helpers currently target.
     hipStream_t aux = nullptr, cur = nullptr;
-    // unique / raw reads of the partitioned group in this context's last collapse (0: none yet): samples of a batch are alike, and
-    // k_part_dedup's sharded output pays for itself only when few reads are unique (native_collapse.hpp)
-    double last_unique_share = 0.0;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_meta = nullptr, ev_meta_small = nullptr, ev_bulk_counted = nullptr;
     // the small read groups' one-launch cascades each on a stream of their own (round 3): with the bulk group's passes in one
     // launch they only get the chip when its workgroups retire, and on ONE stream three of them then ran one after the other
@@ -83,6 +80,10 @@ struct mirge_ctx {
     uint8_t* csv_pinned = nullptr;
     size_t csv_pinned_bytes = 0;
     // start / end clocks of the workgroups of the last profiled k_cascade_bulk launch (mirge_cascade_wg_times)
+    // k_cascade_heavy (kernels_cascade.hpp): per read group {reads listed, workgroups done}, zero between launches; the threshold the
+    // current configuration's steps carry (0: no library holds a bucket that large -- no deferral, no extra launch)
+    uint32_t* heavy_cnt = nullptr;
+    uint32_t casc_big_t = 0;
     uint32_t* wg_pinned = nullptr;
     size_t wg_pinned_words = 0;
     uint32_t wg_grid = 0;
@@ -307,6 +308,7 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->join_pinned) (void)hipHostFree(c->join_pinned);
     if (c->csv_pinned) (void)hipHostFree(c->csv_pinned);
     if (c->wg_pinned) (void)hipHostFree(c->wg_pinned);
+    if (c->heavy_cnt) (void)hipFree(c->heavy_cnt);
     if (c->join_dev) (void)hipFree(c->join_dev);
     for (auto& e : c->plans) (void)hipFree(e.dplan);
     for (auto& e : c->fused) (void)hipFree(e.dev);

@@ -20,6 +20,7 @@ struct mirge_lib {
     std::mutex mu;
     int64_t n_refs = 0;
     int kmax = 8;
+    uint32_t max_bucket = 0;  // windows in the fullest bucket of any probe table built so far (k_table_heavy_list): > casc_big_t = reads may be deferred
     // whole-read tables of the exact passes (kernels_cascade.hpp, ExactStep), by the set of lengths they hold (bit l of the key)
     struct ExactTab { uint64_t* slots = nullptr; uint32_t mask = 0; uint64_t windows = 0; };
     std::map<uint32_t, ExactTab> exact;
@@ -159,6 +160,20 @@ static int lib_build_shapes(mirge_lib* L, const std::vector<ShapeJob>& jobs) {
     if (e == hipSuccess) e = hipMalloc(&tmp, std::max<size_t>(tmp_cap, 16));
     if (e == hipSuccess && nb_scratch) e = hipMalloc((void**)&A_scratch, (nb_scratch + 2) * 4);
     const int grid = c->n_cu * 8;
+    // (round 6) the heavy buckets' position lists in ascending order: their list, the segmented sort's second array and work area
+    const uint32_t heavy_cap = (uint32_t)std::min<uint64_t>(L->h.total / (MIRGE_LIGHT_MAX + 1) + 16, 0x7FFFFFF0ull);
+    uint32_t *seg_begin = nullptr, *seg_end = nullptr, *n_heavy = nullptr, *pos_sorted = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_cap = 0;
+    const bool sort_heavy = true;  // (not a switch: verify_heavy's early exit and k_cascade_heavy rely on ascending lists)
+    int pos_bits = 1;
+    while (pos_bits < 32 && (1ull << pos_bits) < L->h.total + 1) pos_bits++;
+    if (e == hipSuccess && sort_heavy && !jobs.empty()) {
+        e = hipMalloc((void**)&seg_begin, (size_t)heavy_cap * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&seg_end, (size_t)heavy_cap * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&n_heavy, 64);
+        if (e == hipSuccess) e = hipMalloc((void**)&pos_sorted, std::max<size_t>((size_t)L->h.total, 1) * 4);
+    }
     for (size_t k = 0; k < jobs.size() && e == hipSuccess; k++) {
         const ShapeJob& j = jobs[k];
         Built t{mirge_shape_id(j.k1, j.gap, j.k2), 1ull << (2 * (j.k1 + j.k2)), nullptr, nullptr, nullptr, nullptr};
@@ -180,6 +195,40 @@ static int lib_build_shapes(mirge_lib* L, const std::vector<ShapeJob>& jobs) {
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_table_pass<true>, dim3(grid), dim3(MIRGE_BLOCK), 0, c->stream, L->dT, L->dinv, L->h.total, j.k1,
                            j.gap, j.k2, A, t.dpos);
+        if (sort_heavy && L->h.total > MIRGE_LIGHT_MAX) {
+            // buckets of more than MIRGE_LIGHT_MAX windows (what verify_heavy scans): listed, sorted by position, written back.
+            // One host wait per table for the number of segments (a launch over every possible segment would be 8 M workgroups
+            // for the human mRNA table): ~56 tables, a few ms per process on top of the tables' 40.
+            uint32_t nh = 0;
+            e = hipMemsetAsync(n_heavy, 0, 8, c->stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(k_table_heavy_list, dim3(grid_for(c, (size_t)std::min<uint64_t>(nb, 1ull << 24))), dim3(MIRGE_BLOCK), 0, c->stream,
+                               (const uint32_t*)A, nb, (uint32_t)MIRGE_LIGHT_MAX + 1u, n_heavy, heavy_cap, seg_begin, seg_end,
+                               (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, std::max<uint64_t>(1024, 32 * (L->h.total / nb + 1))));
+            uint32_t nh2[2] = {0, 0};
+            e = hipMemcpyAsync(nh2, n_heavy, 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) break;
+            nh = std::min(nh2[0], heavy_cap);
+            L->max_bucket = std::max(L->max_bucket, nh2[1]);
+            if (nh) {
+                size_t need = 0;
+                e = hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, need, (const uint32_t*)t.dpos, pos_sorted, (int)std::min<uint64_t>(L->h.total, 0x7FFFFFFFull),
+                                                               (int)nh, seg_begin, seg_end, 0, pos_bits, c->stream);
+                if (e == hipSuccess && need > sort_tmp_cap) {
+                    (void)hipFree(sort_tmp); sort_tmp = nullptr; sort_tmp_cap = 0;
+                    e = hipMalloc(&sort_tmp, need + need / 4 + 256);
+                    if (e == hipSuccess) sort_tmp_cap = need + need / 4 + 256;
+                }
+                size_t tb2 = sort_tmp_cap;
+                if (e == hipSuccess)
+                    e = hipcub::DeviceSegmentedRadixSort::SortKeys(sort_tmp, tb2, (const uint32_t*)t.dpos, pos_sorted, (int)std::min<uint64_t>(L->h.total, 0x7FFFFFFFull),
+                                                                   (int)nh, seg_begin, seg_end, 0, pos_bits, c->stream);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(k_table_heavy_copy, dim3((unsigned)std::min<uint32_t>(nh, (uint32_t)c->n_cu * 16u)), dim3(MIRGE_BLOCK), 0, c->stream,
+                                   (const uint32_t*)seg_begin, (const uint32_t*)seg_end, nh, (const uint32_t*)pos_sorted, t.dpos);
+            }
+        }
         if (!entries)  // non-empty-bucket bitmap
             hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, (size_t)((nb + 31) / 32))), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, t.dbits);
         else
@@ -190,6 +239,7 @@ static int lib_build_shapes(mirge_lib* L, const std::vector<ShapeJob>& jobs) {
     if (e == hipSuccess) e = hipGetLastError();
     (void)hipFree(tmp);
     (void)hipFree(A_scratch);
+    (void)hipFree(seg_begin); (void)hipFree(seg_end); (void)hipFree(n_heavy); (void)hipFree(pos_sorted); (void)hipFree(sort_tmp);
     if (e != hipSuccess) {
         for (auto& t : built) { (void)hipFree(t.A); (void)hipFree(t.dpos); (void)hipFree(t.dbits); (void)hipFree(t.dentry); }
         return fail(e == hipErrorOutOfMemory ? -3 : -2, std::string("probe table construction: ") + hipGetErrorString(e));

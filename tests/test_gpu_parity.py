@@ -292,6 +292,31 @@ def test_low_complexity_libraries(ctx):
     casc.close()
 
 
+def test_repeat_rich_libraries_vs_oracle(ctx):
+    """Libraries with the repeat structure real ones have (synth.make_libraries(repeats=True): poly-A tails on 60 % of the mRNAs,
+    Alu-like families at 5-15 % divergence, simple repeats, tRNA isodecoder families) and 40 k reads of synth.REPEAT_MIX (15 % poly-A /
+    poly-T / simple-repeat / Alu-derived reads with 0-2 errors): every field of every read against the oracle -- its k-mer variant on all
+    of them, brute force on 6 k -- through the one-call route and the staged one."""
+    sl = synth.make_libraries(seed=123, scale="ci", repeats=True)
+    assert sl.repeat_families and len(sl.repeat_families[0]) == 300
+    mr = sl.libs["mrna"].seqs.to_list()
+    assert sum(q.endswith("A" * 20) for q in mr) > 0.4 * len(mr)
+    reads = synth.make_reads(sl, 40000, seed=11, mix=synth.REPEAT_MIX, n_frac=0.005)
+    casc = Cascade(ctx, sl.libs)
+    raw = _ffi.DeviceReads.pack(ctx, reads)
+    uniq, res = casc.collapse_and_run(raw)
+    g = res.fetch()
+    useq = uniq.unpack()
+    o = oracle.cascade(useq.data, useq.offsets, oracle_libs_from(sl.libs), n_pass=9, indexed=True)
+    _assert_same(o, g)
+    sub = useq.take(np.arange(0, len(useq), max(1, len(useq) // 6000)))
+    _assert_same(oracle.cascade(sub.data, sub.offsets, oracle_libs_from(sl.libs), n_pass=9, indexed=False), casc.annotate(sub))
+    # the repeat-derived reads do land in the libraries that carry the repeats
+    ps = g[0]
+    assert (ps == 7).sum() > 0.03 * len(useq) and (ps >= 0).sum() > 0.5 * len(useq)
+    res.close(); uniq.close(); raw.close(); casc.close()
+
+
 def test_references_shorter_than_a_resolve_granule(ctx):
     """Position -> (reference, offset) reads one entry per 16 positions (ResolveTable); references of 0-15 nt between
     the real ones put several starts into a granule -- the entry's search branch -- and a start on every offset of one."""
