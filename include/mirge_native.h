@@ -341,6 +341,19 @@ int mirge_gff_write(const char* path, const char* head, const char* source, cons
                     const int32_t* name_of_row, const char* name_data, const int64_t* name_off, int64_t n_names,
                     const int32_t* parent_of_row, const char* parent_data, const int64_t* parent_off, int64_t n_parents,
                     const int64_t* read_of_row, int64_t n_reads);
+/* The same file from the DEVICE-resident run (round 6; what the CLI's -gff route calls): the rows are chosen (the exact-miRNA rows of
+ * the mapped frame in frame order, then its isomiR rows: summary.py:50-60), typed, measured and formatted by kernels where the reads,
+ * counts and annotation lie; only the file's text crosses PCIe.  order[k] = handle index of the read in row k of the run's frame
+ * (mirge_collapse_order / mirge_collapse_order_sorted); the typing tables as mirge_isomir_type; name_of_ref / parent_of_ref
+ * [n_mirna] index the two string tables (-1: the reference prints no line for reads of that name).  *n_lines_out = lines below
+ * the head.  Replaces create_gff's per-read loop and its writes (mirge/libs/summary.py:204-470). */
+int mirge_gff_write_device(mirge_ctx* ctx, const mirge_reads* uniq, const mirge_result* res, int32_t exact_pass, int32_t iso_pass,
+                           const int32_t* master_of_ref, int64_t n_mirna, const char* master_ascii, const int32_t* master_off,
+                           const int32_t* pre_of_master, const int32_t* start0, int64_t n_master, const char* pre_ascii,
+                           const int32_t* pre_off, int64_t n_pre, const int32_t* name_of_ref, const char* name_data,
+                           const int64_t* name_off, int64_t n_names, const int32_t* parent_of_ref, const char* parent_data,
+                           const int64_t* parent_off, int64_t n_parents, const int64_t* order, const char* path, const char* head,
+                           const char* source, int64_t* n_lines_out);
 
 /* ---- measurement (bench.py): HIP events on the ctx stream ---- */
 int mirge_ctx_timer_start(mirge_ctx* ctx);

@@ -25,7 +25,7 @@ EXPORTS = [
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
     "mirge_reads_n_samples", "mirge_reads_group_counts", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
-    "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
+    "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_gff_write_device", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_reads_range_sample", "mirge_reads_range_split", "mirge_annotation_csv_device_sizes", "mirge_annotation_csv_device_at",
     "mirge_cascade_prepare", "mirge_cascade_walks", "mirge_cascade_wg_times", "mirge_ctx_profile_only", "mirge_ctx_profile_units", "mirge_ctx_profile_reset", "mirge_ctx_profile_count", "mirge_ctx_profile_get",
 ]

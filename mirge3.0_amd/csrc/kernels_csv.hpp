@@ -193,3 +193,134 @@ __global__ void k_count_nonzero_cols(const uint32_t* __restrict__ counts, uint32
             if (bal && (threadIdx.x & 63) == (unsigned)(__ffsll(bal) - 1)) atomicAdd(&nz[s], (unsigned long long)__popcll(bal));
         }
 }
+
+// ------------------------------------------------------------------------------------------
+// The miRTop GFF3 (`-gff`, sample_miRge3.gff; create_gff, mirge/libs/summary.py:48-606) formatted on the device (round 6).  Until
+// round 5 k_isotype's 336-byte records crossed PCIe (241 MB per 0.72 M miRNA reads) and mirge_gff_write built the 160 MB of text on
+// host cores from them plus a host copy of every read, count and annotation; the file was 0.12 of a sample's 0.28 s.  Now the
+// rows are chosen, typed, measured and written where the reads, counts, annotation and records already lie:
+//   k_gff_select : frame position k -> flags "exact-miRNA row" / "isomiR row" (two exclusive scans give the file's row order:
+//                  the exact rows of the mapped frame, then its isomiR rows, summary.py:50-60)
+//   k_gff_rows   : row -> the read's handle index and its slot for k_isotype
+//   k_gff_line<false> : bytes of every line;  k_gff_line<true> : the lines, each at its offset
+// A line:  NAME \t SOURCE \t ref_miRNA|isomiR \t START \t END \t.\t+\t.\tRead=SEQ; UID=...; Name=NAME; Parent=PRE; Variant=V; Cigar=C;
+//          Expression=c0,c1,..; Filter=Pass; Hits=c0,c1,..\n      -- mirge_gff_write's bytes (native_host.hpp), which the golden files pin.
+// ------------------------------------------------------------------------------------------
+struct GffTables {
+    const int32_t* name_of_ref;     // [n_mirna] printed-name index of a miRNA reference, -1: none
+    const int32_t* parent_of_ref;   // [n_mirna]
+    const uint8_t* name_data;       // printed names back to back
+    const uint32_t* name_off;       // [n_names + 1]
+    const uint8_t* parent_data;
+    const uint32_t* parent_off;     // [n_parents + 1]
+    uint32_t n_names, n_parents, n_mirna;
+    const uint8_t* source;          // e.g. "miRBase22"
+    uint32_t source_len;
+};
+
+__global__ void k_gff_select(CsvTables t, const uint32_t* __restrict__ order, uint32_t n, int32_t exact_pass, int32_t iso_pass,
+                             uint32_t* __restrict__ f_exact, uint32_t* __restrict__ f_iso) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t j;
+        const int gi = csv_locate(t, order[k], j);
+        const int p = t.g[gi].pass[j];
+        f_exact[k] = (p == exact_pass && p >= 0) ? 1u : 0u;
+        f_iso[k] = (p == iso_pass && p >= 0) ? 1u : 0u;
+    }
+}
+__global__ void k_gff_rows(const uint32_t* __restrict__ order, uint32_t n, const uint32_t* __restrict__ f_exact, const uint32_t* __restrict__ f_iso,
+                           const uint32_t* __restrict__ p_exact, const uint32_t* __restrict__ p_iso, uint32_t n_exact,
+                           uint32_t* __restrict__ rows, int32_t* __restrict__ slot_of_read) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t read = order[k];
+        if (f_exact[k]) { rows[p_exact[k]] = read; slot_of_read[read] = (int32_t)p_exact[k]; }
+        else if (f_iso[k]) { rows[n_exact + p_iso[k]] = read; slot_of_read[read] = (int32_t)(n_exact + p_iso[k]); }
+    }
+}
+
+// a cursor that counts (WRITE = false) or writes
+template <bool WRITE>
+struct GffOut {
+    uint8_t* o;
+    uint32_t n;
+    __device__ __forceinline__ void ch(char c) { if (WRITE) o[n] = (uint8_t)c; n++; }
+    __device__ __forceinline__ void str(const char* s) { for (int k = 0; s[k]; k++) ch(s[k]); }
+    __device__ __forceinline__ void bytes(const uint8_t* s, uint32_t len) { if (WRITE) for (uint32_t k = 0; k < len; k++) o[n + k] = s[k]; n += len; }
+    __device__ __forceinline__ void uint(uint32_t v) {
+        const int nd = csv_digits(v);
+        if (WRITE) { uint32_t x = v; for (int d = nd - 1; d >= 0; d--) { o[n + d] = (uint8_t)('0' + x % 10u); x /= 10u; } }
+        n += (uint32_t)nd;
+    }
+    __device__ __forceinline__ void sint(int32_t v) { if (v < 0) { ch('-'); uint((uint32_t)(-(int64_t)v)); } else uint((uint32_t)v); }
+};
+
+// flags[0] |= 1: a name index out of range or a record's text beyond its capacity
+template <bool WRITE>
+__global__ void k_gff_line(CsvTables t, GffTables gt, const uint32_t* __restrict__ rows, uint32_t n_rows, const MirgeIsoRec* __restrict__ recs,
+                           unsigned long long* __restrict__ len_out, const unsigned long long* __restrict__ off, uint8_t* __restrict__ out,
+                           uint32_t* __restrict__ flags) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_rows; k += gridDim.x * blockDim.x) {
+        const MirgeIsoRec& r = recs[k];
+        if (r.kind == 0) { if (!WRITE) len_out[k] = 0ull; continue; }  // a name the reference has no annotation for: no line (summary.py:492)
+        uint32_t j;
+        const int gi = csv_locate(t, rows[k], j);
+        const CsvGroup& g = t.g[gi];
+        const int32_t ref = g.ref[j];
+        const int32_t ni = (ref >= 0 && (uint32_t)ref < gt.n_mirna) ? gt.name_of_ref[ref] : -1;
+        const int32_t pi = (ref >= 0 && (uint32_t)ref < gt.n_mirna) ? gt.parent_of_ref[ref] : -1;
+        if (ni < 0 || (uint32_t)ni >= gt.n_names || pi < 0 || (uint32_t)pi >= gt.n_parents || (uint32_t)r.vlen + r.clen > MIRGE_ISO_TEXT) {
+            atomicOr(&flags[0], 1u);
+            if (!WRITE) len_out[k] = 0ull;
+            continue;
+        }
+        GffOut<WRITE> w{WRITE ? out + off[k] : nullptr, 0u};
+        const uint8_t* nm = gt.name_data + gt.name_off[ni];
+        const uint32_t nl = gt.name_off[ni + 1] - gt.name_off[ni];
+        w.bytes(nm, nl); w.ch('\t'); w.bytes(gt.source, gt.source_len); w.ch('\t');
+        w.str(r.kind == 1 ? "ref_miRNA" : "isomiR");
+        w.ch('\t'); w.sint(r.start); w.ch('\t'); w.sint(r.end);
+        w.str("\t.\t+\t.\tRead=");
+        const int L = csv_len(g, j);
+        bool has_n = false;
+        for (int wd = 0; wd * 32 < L; wd++) {
+            uint64_t bits = g.seq[(size_t)wd * g.n + j];
+            uint64_t nmk = g.nmask ? g.nmask[(size_t)wd * g.n + j] : 0ull;
+            const int m = L - 32 * wd < 32 ? L - 32 * wd : 32;
+            for (int b = 0; b < m; b++) {
+                const bool isn = nmk & 1ull;
+                has_n |= isn;
+                w.ch(isn ? 'N' : "ACGT"[bits & 3ull]);
+                bits >>= 2; nmk >>= 2;
+            }
+        }
+        w.str("; UID=");
+        if (has_n) w.ch('.');
+        else {  // miRgeEssential.UID (:364-370): see uid_append (native_host.hpp)
+            w.str(r.kind == 1 ? "ref-" : "iso-"); w.uint((uint32_t)L); w.ch('-');
+            for (int at = 0; at < L; at += 5) {
+                const int kk = L - at < 5 ? L - at : 5;
+                int v = 0;
+                for (int q = 0; q < kk; q++) {
+                    const int p = at + q;
+                    v = v * 4 + (int)((g.seq[(size_t)(p >> 5) * g.n + j] >> (2 * (p & 31))) & 3ull);
+                }
+                if (kk == 5) { w.ch("BD0EF1HI2JK3LM4NO5PQ6RS7UV8WX9YZ"[v / 32]); w.ch("BD0EF1HI2JK3LM4NO5PQ6RS7UV8WX9YZ"[v % 32]); }
+                else {
+                    v += kk == 1 ? 0 : kk == 2 ? 4 : kk == 3 ? 20 : 84;
+                    if (v < 32) w.ch("BD0EF1HI2JK3LM4NO5PQ6RS7UV8WX9YZ"[v]);
+                    else { w.ch("BD0EF1HI2JK3LM4NO5PQ6RS7UV8WX9YZ"[v / 32]); w.ch("BD0EF1HI2JK3LM4NO5PQ6RS7UV8WX9YZ"[v % 32]); }
+                }
+            }
+        }
+        w.str("; Name="); w.bytes(nm, nl);
+        w.str("; Parent="); w.bytes(gt.parent_data + gt.parent_off[pi], gt.parent_off[pi + 1] - gt.parent_off[pi]);
+        w.str("; Variant="); w.bytes(reinterpret_cast<const uint8_t*>(r.text), r.vlen);
+        w.str("; Cigar="); w.bytes(reinterpret_cast<const uint8_t*>(r.text) + r.vlen, r.clen);
+        w.str("; Expression=");
+        for (int s = 0; s < t.S; s++) { if (s) w.ch(','); w.uint(g.counts[(size_t)j * t.S + s]); }
+        w.str("; Filter=Pass; Hits=");
+        for (int s = 0; s < t.S; s++) { if (s) w.ch(','); w.uint(g.counts[(size_t)j * t.S + s]); }
+        w.ch('\n');
+        if (!WRITE) len_out[k] = (unsigned long long)w.n;
+    }
+}

@@ -374,7 +374,8 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
     // Then the steps carry that threshold (MirgePolicy::reserved): a read that meets such a bucket is answered by k_cascade_heavy, a
     // workgroup per read.  Uniform-random libraries hold none: their cascades run as before, without the extra launch.
     static const uint32_t big_t_env = std::getenv("MIRGE_BIG_T") ? (uint32_t)std::strtoul(std::getenv("MIRGE_BIG_T"), nullptr, 10) : 8192u;
-    c->casc_big_t = 0;
+    static const bool big_t_forced = std::getenv("MIRGE_BIG_T") != nullptr;  // (tests: every bucket beyond the given size defers, outlier or not)
+    c->casc_big_t = big_t_forced ? big_t_env : 0;
     for (auto& st : steps)
         if (big_t_env && st.lib->max_bucket > big_t_env) c->casc_big_t = big_t_env;
     if (c->casc_big_t && !c->heavy_cnt) {

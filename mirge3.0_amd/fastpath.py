@@ -236,7 +236,10 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
     S = len(base_names)
     # ---- the per-read tables (mirge/__main__.py:164-173)
     t = time.perf_counter()
-    want_reports = any(getattr(args, k, False) for k in ("gff_out", "AtoI", "isoform_entropy"))
+    # (-gff alone needs nothing on the host since round 6: its rows are chosen, typed and formatted on the device)
+    from . import gff as _gff
+    gff_on_device = bool(getattr(args, "gff_out", False)) and ann is None and res is not None and _gff.device_route()
+    want_reports = any(getattr(args, k, False) for k in ("AtoI", "isoform_entropy")) or (bool(getattr(args, "gff_out", False)) and not gff_on_device)
     # annotation on the device, no per-read report asked for: the two files are formatted on the GPU and neither the reads
     # nor the counts nor the annotation are fetched (they are 35 B per unique read, the files' text 48 B)
     on_device = ann is None and res is not None and not getattr(args, "host_csv", False)
@@ -271,9 +274,12 @@ def reports(args, workDir, ref_db: str, base_names, casc, uniq, res, out, merges
                             list(range(casc.n_pass)), n_cols, names_by_pass(casc))
     tm["per_read_csv_s"] = time.perf_counter() - t
     if getattr(args, "gff_out", False):  # -gff (summary.py:800-837)
-        from .gff import write_gff
+        from .gff import write_gff, write_gff_device
         t = time.perf_counter()
-        out["gff"] = write_gff(args, workDir, ref_db, base_names, casc, uniq, res, seqs, ps, ref, counts, order)
+        if gff_on_device:
+            out["gff"] = write_gff_device(args, workDir, ref_db, base_names, casc, uniq, res, order)
+        else:
+            out["gff"] = write_gff(args, workDir, ref_db, base_names, casc, uniq, res, seqs, ps, ref, counts, order)
         tm["gff_s"] = time.perf_counter() - t
         tm["gff_stages_s"] = out["gff"].get("timing", {})
     if getattr(args, "AtoI", False):  # -ai (summary.py:1034-1057)

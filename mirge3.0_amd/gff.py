@@ -144,16 +144,81 @@ def isomir_records(casc: Cascade, uniq, res, tables: dict, rows: np.ndarray) -> 
     return out[:rows.shape[0]]
 
 
-def write_gff(args, workDir, ref_db, base_names, casc: Cascade, uniq, res, seqs: FlatSeqs, ps, ref, counts, order):
-    """``-gff``: ``sample_miRge3.gff``, the rows in the reference's order (exact-miRNA rows of the mapped frame, then
-    the isomiR rows, :50-60)."""
+def device_route() -> bool:
+    """the GFF3 formatted on the device (``mirge_gff_write_device``, round 6); MIRGE_GFF_DEVICE=0: records to the host and
+    ``mirge_gff_write`` on its cores (round 5's route -- the tests' second implementation)"""
+    import os
+    return os.environ.get("MIRGE_GFF_DEVICE", "1") != "0"
+
+
+def name_tables(args, ref_db, casc: Cascade) -> dict:
+    """``resolve_names`` of the run's libraries, kept with the cascade: a few thousand names, read once per process"""
+    key = (str(args.libraries_path), args.organism_name, ref_db)
+    cached = getattr(casc, "_gff_tables", None)
+    if cached is None or cached[0] != key:
+        lp, org = Path(args.libraries_path), args.organism_name
+        mirDict = read_mature_fasta(lp / org / "fasta.Libs" / (org + "_mature_" + ref_db + ".fa"))
+        pre_of = read_annotation(lp / org / "annotation.Libs" / (org + "_" + ref_db + ".gff3"), ref_db)
+        cached = (key, resolve_names(casc.libs["mirna"].names, mirDict, pre_of, precursor_dict(casc.libs["hairpin"])))
+        casc._gff_tables = cached
+    return cached[1]
+
+
+def write_gff_device(args, workDir, ref_db, base_names, casc: Cascade, uniq, res, order):
+    """``-gff`` from the device-resident run: rows chosen, typed and formatted on the GPU (``mirge_gff_write_device``); nothing per
+    read is fetched.  ``order`` = the frame's row order (handle indices)."""
+    import time
+    t0 = time.perf_counter()
+    tables = name_tables(args, ref_db, casc)
+    t_names = time.perf_counter() - t0
+    out = write_gff_device_with(tables, Path(workDir) / "sample_miRge3.gff", ref_db, base_names, casc, uniq, res, order)
+    out["timing"]["name_tables_s"] = round(t_names, 4)
+    return out
+
+
+def write_gff_device_with(tables: dict, path, ref_db, base_names, casc: Cascade, uniq, res, order):
+    """``mirge_gff_write_device`` with the name tables given (``resolve_names``)"""
     import time
     tm = {}
     t0 = time.perf_counter()
-    lp, org = Path(args.libraries_path), args.organism_name
-    mirDict = read_mature_fasta(lp / org / "fasta.Libs" / (org + "_mature_" + ref_db + ".fa"))
-    pre_of = read_annotation(lp / org / "annotation.Libs" / (org + "_" + ref_db + ".gff3"), ref_db)
-    tables = resolve_names(casc.libs["mirna"].names, mirDict, pre_of, precursor_dict(casc.libs["hairpin"]))
+    version_db = "miRBase22" if ref_db == "miRBase" else "MirGeneDB2.0"
+    head = ("# GFF3 adapted for miRNA sequencing data\n## VERSION 0.0.1\n## source-ontology: " + version_db + "\n## COLDATA: " +
+            ",".join(str(nm) for nm in base_names) + "\n")
+    m = FlatSeqs.from_list(tables["masters"])
+    p = FlatSeqs.from_list(tables["pre_seqs"])
+    names, parents = FlatSeqs.from_list(tables["printed"]), FlatSeqs.from_list(tables["parents"])
+    z8, z32 = np.zeros(1, np.uint8), np.zeros(1, np.int32)
+    moff, poff = m.offsets.astype(np.int32), p.offsets.astype(np.int32)
+    mdata = np.ascontiguousarray(m.data) if m.data.size else z8
+    pdata = np.ascontiguousarray(p.data) if p.data.size else z8
+    mof = np.ascontiguousarray(tables["master_of_ref"], dtype=np.int32)
+    pom = np.ascontiguousarray(tables["pre_of_master"], dtype=np.int32) if len(m) else z32
+    s0 = np.ascontiguousarray(tables["start0"], dtype=np.int32) if len(m) else z32
+    nof = np.ascontiguousarray(tables["name_of_ref"], dtype=np.int32)
+    pof = np.ascontiguousarray(tables["parent_of_ref"], dtype=np.int32)
+    nd = np.ascontiguousarray(names.data) if names.data.size else z8
+    pd_ = np.ascontiguousarray(parents.data) if parents.data.size else z8
+    noff = np.ascontiguousarray(names.offsets, dtype=np.int64)
+    paroff = np.ascontiguousarray(parents.offsets, dtype=np.int64)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    n_lines = C.c_int64(0)
+    _ffi._check(_ffi.load().mirge_gff_write_device(
+        casc.ctx._h, uniq._h, res._h, C.c_int32(EXACT_PASS), C.c_int32(ISO_PASS), _ffi._p(mof), C.c_int64(mof.shape[0]), _ffi._p(mdata),
+        _ffi._p(moff), _ffi._p(pom), _ffi._p(s0), C.c_int64(len(m)), _ffi._p(pdata), _ffi._p(poff), C.c_int64(len(p)), _ffi._p(nof), _ffi._p(nd),
+        _ffi._p(noff), C.c_int64(len(names)), _ffi._p(pof), _ffi._p(pd_), _ffi._p(paroff), C.c_int64(len(parents)),
+        _ffi._p(order) if order.size else C.c_void_p(0), str(path).encode(), head.encode(), version_db.encode(),
+        C.byref(n_lines)), "mirge_gff_write_device")
+    tm["device_call_s"] = time.perf_counter() - t0
+    return dict(records=None, rows=None, tables=tables, lines=int(n_lines.value), timing={k: round(v, 4) for k, v in tm.items()})
+
+
+def write_gff(args, workDir, ref_db, base_names, casc: Cascade, uniq, res, seqs: FlatSeqs, ps, ref, counts, order):
+    """``-gff``: ``sample_miRge3.gff``, the rows in the reference's order (exact-miRNA rows of the mapped frame, then
+    the isomiR rows, :50-60) -- the host route: k_isotype's records fetched, the file built by ``mirge_gff_write``."""
+    import time
+    tm = {}
+    t0 = time.perf_counter()
+    tables = name_tables(args, ref_db, casc)
     tm["name_tables_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     po = ps[order]

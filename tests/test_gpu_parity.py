@@ -1436,6 +1436,57 @@ def test_partitioned_collapse_with_sharded_output():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_dedup_output_mode_is_chosen_on_the_device(ctx):
+    """Round 6: k_part_dedup chooses between the one output cursor and the eight sharded ones ON THE DEVICE, per sample, from the
+    record count k_part_agg leaves (until round 5 the host chose from the context's previous sample).  A Zipf sample (few unique
+    reads: few records) and an all-distinct one through ONE context in alternation: the same dictionaries as the oracle's either way,
+    and k_part_compact's launch record shows the mode followed the sample, not the sample before it."""
+    sl = synth.make_libraries(seed=5, scale="ci")
+    zipf = synth.make_reads(sl, 400000, seed=21, pool=20000)
+    flat = synth.make_reads(sl, 400000, seed=22, mix=dict(synth.DEFAULT_MIX, exact=0.0, isomir=0.0))
+    for k, reads in enumerate((zipf, flat, zipf, flat)):
+        raw = _ffi.DeviceReads.pack(ctx, reads)
+        u = raw.collapse()
+        cnt, first = u.counts()
+        o_first, o_cnt, _ = oracle.collapse(reads.data, reads.offsets)
+        order = np.argsort(first, kind="stable")
+        assert np.array_equal(first[order], o_first) and np.array_equal(cnt[order, 0], o_cnt), k
+        u.close(); raw.close()
+
+
+def test_reads_with_outlier_buckets_take_the_heavy_kernel():
+    """Round 6: a read one of whose probe buckets holds more windows than MIRGE_BIG_T is not aligned by its wave (align_hybrid answers
+    MIRGE_DEFER) but by k_cascade_heavy, a workgroup per read.  With the threshold at 64 windows most repeat-derived reads of the
+    repeat-rich CI libraries -- and plenty of ordinary ones -- take that route: the oracle tests of this file again in a fresh process,
+    every field of every read, through the one-call route, the staged one and the small groups' one-launch cascades."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "repeat_rich or low_complexity or golden_cascade or cascade_vs_oracle or staged"],
+                       env=dict(os.environ, MIRGE_BIG_T="64"), capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    code = """
+import sys; sys.path.insert(0, %r)
+import numpy as np, mirge3_amd
+from mirge3_amd import _ffi, synth
+from mirge3_amd.cascade import Cascade
+ctx = _ffi.Context(0)
+sl = synth.make_libraries(seed=123, scale="ci", repeats=True)
+casc = Cascade(ctx, sl.libs)
+raw = _ffi.DeviceReads.pack(ctx, synth.make_reads(sl, 30000, seed=11, mix=synth.REPEAT_MIX))
+ctx.profile(True); ctx.profile_reset()
+u, r = casc.collapse_and_run(raw)
+ctx.sync()
+names = [n for n, l, ms, un in ctx.profile_records() if l]
+assert any(n.startswith("k_cascade_heavy") for n in names), names
+assert (r.fetch()[0] >= -1).all()  # no read is left with the 'deferred' mark
+print("OK")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MIRGE_BIG_T="64"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 def test_collapse_cascade_one_call_equals_two_calls(ctx):
     """mirge_collapse_cascade (the bulk group's passes queued behind the collapse kernels, read count taken from
     device memory) against mirge_collapse + mirge_cascade_run on the same reads: same unique reads, counts, first
@@ -2056,6 +2107,16 @@ def test_gff_equals_the_reference_file(tmp_path, case_name):
     lines: every variant class, templated and non-templated additions, the three worked examples of
     summary.py:249-283, reads with N, names without annotation)."""
     case, work, out = _case4_run(tmp_path, case_name, gff_out=True)
+    assert (work / "sample_miRge3.gff").read_text() == case.text("sample_miRge3.gff")
+    # round 6: the default route formats the file on the device (mirge_gff_write_device): no record reaches the host
+    assert out["gff"]["records"] is None and out["gff"]["lines"] == case.text("sample_miRge3.gff").count("\n") - 4
+    # ... and round 5's route (records to the host, mirge_gff_write on its cores) writes the same file
+    os.environ["MIRGE_GFF_DEVICE"] = "0"
+    try:
+        (tmp_path / "host").mkdir()
+        case, work, out = _case4_run(tmp_path / "host", case_name, gff_out=True)
+    finally:
+        os.environ.pop("MIRGE_GFF_DEVICE")
     assert (work / "sample_miRge3.gff").read_text() == case.text("sample_miRge3.gff")
     recs = out["gff"]["records"]
     assert (recs["kind"] == 2).sum() > 500 and (recs["kind"] == 1).sum() > 40 and (recs["kind"] == 0).sum() > 0
