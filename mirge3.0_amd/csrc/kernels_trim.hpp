@@ -132,19 +132,39 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
 // The same search with the adapter's kind and number as RUN-TIME (wave-uniform) values: the general 3' instance of k_trim calls it from
 // its linked / best-of-two / repeated branches.  Seven inlined compile-time variants of the function above, each with its own DP
 // column, had left that instance with 139-1101 spilled registers; this is one body.
+// (round 6) The adapter as the search reads it: for each of A C G T the rows that hold that letter, and the wildcard rows, as 64-bit
+// masks.  The rows' letters used to be compared one by one with bytes of the kernel's argument block, which the compiler kept in
+// scalar registers -- 64 + 64 bytes per adapter, two adapters: most of the general instance's thousand spilled scalar registers.  A
+// column now selects ONE mask by its read letter and a row tests its bit.
+struct AdapterMasks { uint64_t eq[4]; uint64_t wild; };
+__device__ __forceinline__ AdapterMasks adapter_masks(const uint8_t* adapter, const uint8_t* wild, int m) {
+    AdapterMasks am{{0ull, 0ull, 0ull, 0ull}, 0ull};
+    for (int i = 0; i < m && i < MIRGE_TRIM_MAX_ADAPTER; i++) {
+        const uint8_t c = adapter[i];
+        const uint64_t bit = 1ull << i;
+        if (c == 'A') am.eq[0] |= bit; else if (c == 'C') am.eq[1] |= bit; else if (c == 'G') am.eq[2] |= bit; else if (c == 'T') am.eq[3] |= bit;
+        if (wild[i]) am.wild |= bit;
+    }
+    return am;
+}
+
 template <int MAXM>
-__device__ __forceinline__ int adapter_cut_point_rt(const TrimOpts& o, const uint8_t* __restrict__ read, int n, const bool FRONT, const int WHICH, int* hit) {
+__device__ __forceinline__ int adapter_cut_point_rt(const TrimOpts& o, const AdapterMasks& am1, const AdapterMasks& am2, const uint8_t* __restrict__ read, int n,
+                                                    const bool FRONT, const int WHICH, int* hit) {
     constexpr bool EXACT = false;
     const uint8_t* const o_adapter = WHICH ? o.adapter2 : o.adapter;
-    const uint8_t* const o_wild = WHICH ? o.wild2 : o.wild;
+    const uint64_t eqA = WHICH ? am2.eq[0] : am1.eq[0], eqC = WHICH ? am2.eq[1] : am1.eq[1], eqG = WHICH ? am2.eq[2] : am1.eq[2],
+                   eqT = WHICH ? am2.eq[3] : am1.eq[3], wildm = WHICH ? am2.wild : am1.wild;
     const int m = EXACT ? MAXM : (WHICH ? o.alen2 : o.alen);
     // anchored (general kernel): FRONT = PrefixAdapter (flags STOP_WITHIN_SEQ2 alone: read and adapter both start at their
     // first base, first row and column cost their index, candidates stay the last row's cells); back = SuffixAdapter
     // (START_WITHIN_SEQ2 alone: the one candidate is the whole adapter ending at the read's last base)
     const bool anch = !EXACT && (WHICH ? o.anch2 : o.anch) != 0;
     uint32_t e[MAXM + 1];
-    uint8_t nw[MAXM + 1];
-    nw[0] = 0;
+    // (round 6) wildcard rows up to row i, which the error-rate length leaves out: only nw(m) is needed while the columns run, and the
+    // prefixes' counts come out of a running count in the last loop -- the table of MAXM + 1 of them was MAXM + 1 live scalar
+    // registers of this instance's thousand spilled ones
+    int nw_m = 0;
     // --no-indels (general kernel): the two indel candidates of a cell are raised above every diagonal one, and a 3' adapter
     // cannot lose bases in front of the read: rows of the first column start at cost 128 (never accepted, and 128 + 64
     // mismatches still fit the entry's 8 cost bits)
@@ -153,22 +173,29 @@ __device__ __forceinline__ int adapter_cut_point_rt(const TrimOpts& o, const uin
     for (int i = 0; i <= MAXM; i++) {
         e[i] = (FRONT && !anch) ? MIRGE_TRIM_ORIGIN_BIAS - (uint32_t)i
                                 : (((no_indel_or && i ? 128u : (uint32_t)i) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS);
-        if (i) nw[i] = EXACT ? (uint8_t)0 : (uint8_t)(nw[i - 1] + (i <= m ? o_wild[i - 1] : 0));
     }
+    nw_m = __popcll(wildm);
     int b_mat = -1, b_cost = 0, b_val = 0;
     bool found = false, exact = false;
     // i: adapter rows the entry has passed; j: read column it ends in (FRONT only)
-    auto consider = [&](uint32_t ent, int i, int j) {
+    auto consider = [&](uint32_t ent, int i, int j, int nw_i) {
         const int cost = (int)(ent >> MIRGE_TRIM_COST_SHIFT), mat = (int)((ent >> 15) & 0x7F);
         const int origin = (int)(ent & 0x7FFF) - (int)MIRGE_TRIM_ORIGIN_BIAS;
         const int length = FRONT ? i + (origin < 0 ? origin : 0) : i;
-        if (length >= o.min_overlap && (double)cost <= (double)(length - (FRONT ? 0 : nw[i])) * o.rate &&
+        if (length >= o.min_overlap && (double)cost <= (double)(length - (FRONT ? 0 : nw_i)) * o.rate &&
             (!found || mat > b_mat || (mat == b_mat && cost < b_cost))) {
             found = true; b_mat = mat; b_cost = cost; b_val = FRONT ? j : origin;
         }
     };
     for (int j = 1; j <= n && !exact; j++) {
         const uint8_t ch = read[j - 1] & 0xDF;
+        // the rows this column's letter matches: the letter's mask, the wildcard rows, every row for an N of the read under
+        // --match-read-wildcards; a letter that is none of A C G T (an IUPAC code in the read) is compared with the adapter's bytes
+        uint64_t eqm = ch == 'A' ? eqA : ch == 'C' ? eqC : ch == 'G' ? eqG : ch == 'T' ? eqT : 0ull;
+        if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T')
+            for (int i = 0; i < m; i++) eqm |= (uint64_t)(o_adapter[i] == ch) << i;
+        eqm |= wildm;
+        if (o.read_wild && ch == 'N') eqm = ~0ull;
         uint32_t diag = e[0];
         e[0] = (uint32_t)j + MIRGE_TRIM_ORIGIN_BIAS;  // cost 0, matches 0, origin j
         // (anchored 5': j read bases in front of the adapter cost j -- saturated at 128, beyond every budget and within the
@@ -182,20 +209,24 @@ __device__ __forceinline__ int adapter_cut_point_rt(const TrimOpts& o, const uin
                 const uint32_t best3 = EXACT ? min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22))
                                              : min(min(diag, e[i - 1] | (1u << 22) | no_indel_or), left | (2u << 22) | no_indel_or);
                 const uint32_t miss = (best3 & ~MIRGE_TRIM_CHOICE_MASK) + (1u << MIRGE_TRIM_COST_SHIFT);
-                const bool same = EXACT ? o_adapter[i - 1] == ch : (o_wild[i - 1] || o_adapter[i - 1] == ch || (o.read_wild && ch == 'N'));
+                const bool same = (eqm >> (i - 1)) & 1ull;
                 const uint32_t v = same ? diag + MIRGE_TRIM_MATCH_ONE : miss;
                 diag = left;
                 e[i] = v;
                 if (EXACT ? i == MAXM : i == m) last = v;
             }
         }
-        if (FRONT || !anch || j == n) consider(last, m, j);
+        if (FRONT || !anch || j == n) consider(last, m, j, nw_m);
         exact = found && b_cost == 0 && b_mat == m;
     }
     if (!exact && !FRONT && !anch) {  // the adapter may run off the read's end: every prefix of it, in the last column, longest first
+        int nw_i = nw_m;
 #pragma unroll                // (cutadapt: `for i in reversed(range(first_i, m + 1))` -- on equal (matches, cost) the longer prefix stays)
         for (int i = MAXM; i >= 0; i--)
-            if (EXACT || i <= m) consider(e[i], i, n);
+            if (EXACT || i <= m) {
+                consider(e[i], i, n, nw_i);
+                if (i >= 1) nw_i -= (int)((wildm >> (i - 1)) & 1ull);
+            }
     }
     if (hit) { hit[0] = found ? 1 : 0; hit[1] = b_mat; hit[2] = b_cost; }
     return found ? b_val : (FRONT ? 0 : n);
@@ -261,48 +292,46 @@ k_trim(const uint8_t* __restrict__ text, const int64_t* __restrict__ lstart, con
         if (o.alen > 0) {
             bool done = false;
             if constexpr (!EXACT && !FRONT) {
-                if (o.action_none) done = true;
-                else if (o.linked) {
-                    // ONE linked adapter (LinkedAdapter.match_to): the 5' part first; required and absent = no match; the 3' part
-                    // in what follows the 5' match (the whole read when an optional 5' part is absent); no 3' match is still a
-                    // match when that part is optional and the 5' part was found; a match removes whichever parts were found
+                // The general 3' instance (round 6: ONE copy of the search in its code -- the linked form, the best-of-two form and the
+                // plain one-adapter form each had their own, with their own DP column: 1 149 spilled scalar registers, 2.7 x the exact
+                // instance's time).  Per round up to two searches, then what the form makes of them:
+                //   linked (LinkedAdapter.match_to): the 5' part first; required and absent = no match; the 3' part in what follows
+                //     the 5' match (the whole read when an optional 5' part is absent); no 3' match is still a match when that part is
+                //     optional and the 5' part was found; a match removes whichever parts were found
+                //   otherwise (AdapterCutter: `for _ in range(times): best_match ... break if None`): one or two adapters of either
+                //     kind, the better match removed -- most matches, then fewest errors, then the first given
+                if (!o.action_none) {
+                    const AdapterMasks am1 = adapter_masks(o.adapter, o.wild, o.alen), am2 = adapter_masks(o.adapter2, o.wild2, o.alen2);
+                    const int n_search = (o.linked || o.alen2 > 0) ? 2 : 1;
                     for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {
-                        int h1[3] = {0, 0, 0}, h2[3] = {0, 0, 0};
+                        int f1 = 0, m1 = 0, c1 = 0, v1 = 0, f2 = 0, m2 = 0, c2 = 0, v2 = 0;
                         int na0 = a0;
                         bool none = false;
-                        for (int part = 0; part < 2 && !none; part++) {  // (5' part, then 3' part: one copy of the search in the code)
-                            const int from = part ? na0 : a0;
-                            const int v = adapter_cut_point_rt<MAXM>(o, s + from, a1 - from, part == 0, part, part ? h2 : h1);
-                            if (part == 0) {
-                                if (!h1[0] && o.req1) none = true;
-                                else na0 = h1[0] ? a0 + v : a0;
-                            } else if (!h2[0] && (o.req2 || !h1[0])) none = true;
-                            else {
-                                a0 = na0;
-                                if (h2[0]) a1 = na0 + v;
+                        for (int k = 0; k < n_search && !none; k++) {
+                            const int from = (o.linked && k) ? na0 : a0;
+                            const bool fr = o.linked ? k == 0 : (k ? o.front2 : o.front) != 0;
+                            int hh[3] = {0, 0, 0};
+                            const int v = adapter_cut_point_rt<MAXM>(o, am1, am2, s + from, a1 - from, fr, k, hh);
+                            if (k) { f2 = hh[0]; m2 = hh[1]; c2 = hh[2]; v2 = v; } else { f1 = hh[0]; m1 = hh[1]; c1 = hh[2]; v1 = v; }
+                            if (o.linked && k == 0) {
+                                if (!f1 && o.req1) none = true;
+                                else na0 = f1 ? a0 + v1 : a0;
                             }
                         }
-                        if (none) break;
-                    }
-                    done = true;
-                } else if (o.alen2 > 0 || o.times > 1 || o.no_indels || o.read_wild || o.anch) {
-                    // the general form (this kernel instance only): one or two adapters of either kind, the better match
-                    // removed, up to `times` times (AdapterCutter: `for _ in range(times): best_match ... break if None`)
-                    for (int it = 0; it < (o.times > 1 ? o.times : 1); it++) {
-                        int h1[3], h2[3] = {0, 0, 0};
-                        int v1 = 0, v2 = 0;
-                        for (int which = 0; which < (o.alen2 > 0 ? 2 : 1); which++) {  // (a loop: one copy of the search in the code)
-                            const int v = adapter_cut_point_rt<MAXM>(o, s + a0, a1 - a0, (which ? o.front2 : o.front) != 0, which, which ? h2 : h1);
-                            if (which) v2 = v; else v1 = v;
+                        if (o.linked) {
+                            if (none || (!f2 && (o.req2 || !f1))) break;
+                            a0 = na0;
+                            if (f2) a1 = na0 + v2;
+                        } else {
+                            const bool second = f2 && (!f1 || m2 > m1 || (m2 == m1 && c2 < c1));
+                            if (!(second ? f2 : f1)) break;
+                            const bool fr = second ? o.front2 != 0 : o.front != 0;
+                            const int v = second ? v2 : v1;
+                            if (fr) a0 = a0 + v; else a1 = a0 + v;
                         }
-                        const bool second = h2[0] && (!h1[0] || h2[1] > h1[1] || (h2[1] == h1[1] && h2[2] < h1[2]));
-                        if (!(second ? h2[0] : h1[0])) break;
-                        const bool fr = second ? o.front2 != 0 : o.front != 0;
-                        const int v = second ? v2 : v1;
-                        if (fr) a0 = a0 + v; else a1 = a0 + v;
                     }
-                    done = true;
                 }
+                done = true;
             }
             if (!done) {
                 if (FRONT) a0 = a0 + adapter_cut_point<MAXM, EXACT, true>(o, s + a0, a1 - a0);
