@@ -42,6 +42,25 @@
 typedef const __attribute__((address_space(1))) uint32_t* gptr_u32;
 typedef const __attribute__((address_space(1))) uint64_t* gptr_u64;
 
+#ifndef MIRGE_PRESENCE_FILTER
+// Round 6 experiment (round 5's review, item 5): a 1-bit "bucket is non-empty" filter in front of the self-contained 8-byte entries
+// of the large tables too (k > 10: human mRNA k = 15: 128 MB, the ncRNA shapes 2-32 MB each), so that a probe nothing answers -- most
+// probes of an unmappable read -- costs a bit out of the Infinity Cache instead of a random HBM sector.  The table's `bits` pointer
+// carries bit 0 as the mark "entries behind a filter".  0: off (what is shipped unless profiles/README.md round 6 says otherwise).
+#define MIRGE_PRESENCE_FILTER 0
+#endif
+// the filter / bitmap pointer of a table without its mark, and whether the table holds self-contained entries
+__device__ __forceinline__ gptr_u32 table_bits(const MirgeKTable& tb, bool& entries) {
+#if MIRGE_PRESENCE_FILTER
+    const uint64_t raw = (uint64_t)tb.bits;
+    entries = raw == 0ull || (raw & 1ull);
+    return (gptr_u32)(raw & ~3ull);
+#else
+    entries = tb.bits == nullptr;
+    return (gptr_u32)tb.bits;
+#endif
+}
+
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
     uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src);
     uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
@@ -221,18 +240,21 @@ struct RareKmer { uint32_t lo, hi; int32_t a; uint32_t inl; };
 template <int W>
 __device__ __attribute__((noinline)) RareKmer rarest_kmer(MirgeKTable tb, MirgeRead<W> r, int S, int k, uint32_t have) {
     RareKmer out{0u, 0u, 0, 0u};
-    gptr_u32 bits = (gptr_u32)tb.bits;
+    bool entries;
+    gptr_u32 bits = table_bits(tb, entries);
     for (int a2 = 1; a2 + k <= S; a2++) {
         if (mirge_extract<W>(r.nm, a2, k)) continue;
         const uint64_t key2 = mirge_extract<W>(r.w, a2, k);
         uint32_t lo2 = 0, hi2 = 0, inl = 0;
-        if (!bits) {
-            const uint64_t e = ((gptr_u64)tb.bucket)[key2];
-            lo2 = (uint32_t)e; hi2 = lo2 + (uint32_t)(e >> 32);
-            inl = (uint32_t)(e >> 32) == 1u ? 1u : 0u;
-        } else if ((bits[key2 >> 5] >> (key2 & 31)) & 1u) {
-            const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key2);
-            lo2 = bd.a; hi2 = bd.b;
+        if (!bits || ((bits[key2 >> 5] >> (key2 & 31)) & 1u)) {
+            if (entries) {
+                const uint64_t e = ((gptr_u64)tb.bucket)[key2];
+                lo2 = (uint32_t)e; hi2 = lo2 + (uint32_t)(e >> 32);
+                inl = (uint32_t)(e >> 32) == 1u ? 1u : 0u;
+            } else {
+                const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key2);
+                lo2 = bd.a; hi2 = bd.b;
+            }
         }
         if (hi2 - lo2 < have) { have = hi2 - lo2; out.lo = lo2; out.hi = hi2; out.a = a2; out.inl = inl; }
         if (have < MIRGE_HEAVY_RETRY) break;
@@ -350,6 +372,24 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
         MirgeKTable tb;
         uint64_t key;
         if (probe_setup<W, LDS>(lib, ps, r, q, np, active, pr, tb, key)) {  // no ambiguous call inside the probe
+#if MIRGE_PRESENCE_FILTER
+            bool entries;
+            gptr_u32 bits = table_bits(tb, entries);
+            if (!bits || ((bits[key >> 5] >> (key & 31)) & 1u)) {
+                if (entries) {  // large table: one self-contained entry, a single window inline
+                    const uint64_t e = ((gptr_u64)tb.bucket)[key];
+                    const uint32_t cnt = (uint32_t)(e >> 32);
+                    lo = (uint32_t)e;
+                    hi = lo + cnt;
+                    pos = cnt == 1 ? nullptr : (gptr_u32)tb.pos;  // one window: `lo` is its position
+                } else {  // small table: CSR bounds behind its L2-resident "bucket is non-empty" bit
+                    const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key);
+                    pos = (gptr_u32)tb.pos;
+                    lo = bd.a;
+                    hi = bd.b;
+                }
+            }
+#else
             gptr_u32 bits = (gptr_u32)tb.bits;
             if (!bits) {  // large table: one self-contained entry, a single window inline
                 const uint64_t e = ((gptr_u64)tb.bucket)[key];
@@ -363,6 +403,7 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
                 lo = bd.a;
                 hi = bd.b;
             }
+#endif
             a = pr.a1;
 #if MIRGE_MIN_BUCKET
             // (round 6) An exact-seed policy (mm = 0: mRNA, spike-in) admits no mismatch inside the seed, so ANY k-mer of the seed
@@ -418,17 +459,20 @@ __device__ __forceinline__ uint64_t align_wg(const MirgeLibView& lib, const Mirg
         uint64_t key;
         if (!mirge_probe_key<W>(r, pr, key)) continue;
         const MirgeKTable tb = lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
-        gptr_u32 bits = (gptr_u32)tb.bits;
+        bool entries;
+        gptr_u32 bits = table_bits(tb, entries);
         uint32_t lo = 0, hi = 0;
         gptr_u32 pos = nullptr;
-        if (!bits) {
-            const uint64_t e = ((gptr_u64)tb.bucket)[key];
-            const uint32_t cnt = (uint32_t)(e >> 32);
-            lo = (uint32_t)e; hi = lo + cnt;
-            pos = cnt == 1 ? nullptr : (gptr_u32)tb.pos;
-        } else if ((bits[key >> 5] >> (key & 31)) & 1u) {
-            const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key);
-            pos = (gptr_u32)tb.pos; lo = bd.a; hi = bd.b;
+        if (!bits || ((bits[key >> 5] >> (key & 31)) & 1u)) {
+            if (entries) {
+                const uint64_t e = ((gptr_u64)tb.bucket)[key];
+                const uint32_t cnt = (uint32_t)(e >> 32);
+                lo = (uint32_t)e; hi = lo + cnt;
+                pos = cnt == 1 ? nullptr : (gptr_u32)tb.pos;
+            } else {
+                const PairU32 bd = load_pair32((gptr_u32)tb.bucket + key);
+                pos = (gptr_u32)tb.pos; lo = bd.a; hi = bd.b;
+            }
         }
         int a = pr.a1;
 #if MIRGE_MIN_BUCKET

@@ -251,8 +251,10 @@ __global__ void k_cascade_long(const FusedSteps* __restrict__ steps, ResolveTabl
                 const MirgeKTable t = st.lib.tables[mirge_shape_id(pr.k1, pr.gap, pr.k2)];
                 uint32_t lo, cnt;
                 bool inl = false;
-                if (t.bits) {
-                    if (!((t.bits[key >> 5] >> (key & 31)) & 1u)) continue;
+                bool entries;
+                gptr_u32 tbits = table_bits(t, entries);  // (MIRGE_PRESENCE_FILTER: the pointer may carry the "entries behind a filter" mark)
+                if (tbits && !((tbits[key >> 5] >> (key & 31)) & 1u)) continue;
+                if (!entries) {
                     const uint32_t* b = static_cast<const uint32_t*>(t.bucket);
                     lo = b[key]; cnt = b[key + 1] - lo;
                 } else {

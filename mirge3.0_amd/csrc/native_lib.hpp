@@ -124,7 +124,7 @@ extern "C" void mirge_lib_destroy(mirge_lib* L) {
     (void)hipSetDevice(L->ctx->device);
     (void)hipStreamSynchronize(L->ctx->stream);
     (void)hipFree(L->dT); (void)hipFree(L->dinv); (void)hipFree(L->dref_start); (void)hipFree(L->dcoarse); (void)hipFree(L->dtables);
-    for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); (void)hipFree((void*)t.bits); }
+    for (auto& t : L->htables) { (void)hipFree((void*)t.bucket); (void)hipFree((void*)t.pos); (void)hipFree((void*)((uintptr_t)t.bits & ~(uintptr_t)3)); }
     for (auto& e : L->exact) (void)hipFree(e.second.slots);
     delete L;
 }
@@ -182,7 +182,7 @@ static int lib_build_shapes(mirge_lib* L, const std::vector<ShapeJob>& jobs) {
         if (!entries) e = hipMalloc((void**)&t.A, (nb + 2) * 4);
         // pos[] for every position of the text: the exact number (a few k-mers short of it) is only known after the scan
         if (e == hipSuccess) e = hipMalloc((void**)&t.dpos, std::max<size_t>((size_t)L->h.total, 1) * 4);
-        if (e == hipSuccess && !entries) e = hipMalloc((void**)&t.dbits, (size_t)((nb + 31) / 32) * 4);
+        if (e == hipSuccess && (!entries || MIRGE_PRESENCE_FILTER)) e = hipMalloc((void**)&t.dbits, (size_t)((nb + 31) / 32) * 4);
         if (e == hipSuccess && entries) e = hipMalloc((void**)&t.dentry, nb * 8);
         built.push_back(t);  // (whatever was allocated is freed below on failure)
         uint32_t* A = entries ? A_scratch : t.A;
@@ -229,9 +229,9 @@ static int lib_build_shapes(mirge_lib* L, const std::vector<ShapeJob>& jobs) {
                                    (const uint32_t*)seg_begin, (const uint32_t*)seg_end, nh, (const uint32_t*)pos_sorted, t.dpos);
             }
         }
-        if (!entries)  // non-empty-bucket bitmap
+        if (!entries || MIRGE_PRESENCE_FILTER)  // non-empty-bucket bitmap (MIRGE_PRESENCE_FILTER: in front of the entries of a large table too)
             hipLaunchKernelGGL(k_table_bits, dim3(grid_for(c, (size_t)((nb + 31) / 32))), dim3(MIRGE_BLOCK), 0, c->stream, A, nb, t.dbits);
-        else
+        if (entries)
             hipLaunchKernelGGL(k_table_entries, dim3(grid_for(c, nb)), dim3(MIRGE_BLOCK), 0, c->stream, A, t.dpos, nb, t.dentry);
     }
     // tables complete; no kernel may be reading the registry while it changes
@@ -248,7 +248,7 @@ static int lib_build_shapes(mirge_lib* L, const std::vector<ShapeJob>& jobs) {
         L->device_bytes += (t.dentry ? t.nb * 8 : (t.nb + 2) * 4) + (size_t)L->h.total * 4 + (t.dbits ? (size_t)((t.nb + 31) / 32) * 4 : 0);
         L->htables[t.sid].bucket = t.dentry ? (const void*)t.dentry : (const void*)t.A;
         L->htables[t.sid].pos = t.dpos;
-        L->htables[t.sid].bits = t.dbits;
+        L->htables[t.sid].bits = (t.dentry && t.dbits) ? (const uint32_t*)((uintptr_t)t.dbits | 1u) : t.dbits;  // (the mark: entries behind a filter)
     }
     if (!built.empty())
         HIPOK(hipMemcpy(L->dtables, L->htables.data(), sizeof(MirgeKTable) * MIRGE_SHAPE_SLOTS, hipMemcpyHostToDevice));
