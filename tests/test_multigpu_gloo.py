@@ -16,6 +16,33 @@ def test_assign_samples():
     assert multigpu.assign_samples(1, 4) == [[0], [], [], []]
 
 
+def test_choose_splitters_and_part_files(tmp_path):
+    """multigpu.choose_splitters / write_parts / read_part (round 6, the parallel tail's host side; no GPU): weighted quantiles of the
+    pooled keys -- a sample's k keys each stand for U / k of its reads --, ascending, the same whatever order the pool is handed
+    over in; empty dictionaries vote for nothing; a dictionary cut by bounds comes back stretch by stretch."""
+    import numpy as np
+    from mirge3_amd.seqio import FlatSeqs
+    rng = np.random.default_rng(3)
+    big = np.sort(rng.integers(0, 1 << 60, size=512).astype(np.uint64))
+    small = np.sort(rng.integers(0, 1 << 40, size=512).astype(np.uint64))      # a sample whose reads all sort low
+    empty = np.full(512, multigpu.KEY_NONE, dtype=np.uint64)
+    sp = multigpu.choose_splitters([(1_000_000, big), (1_000, small), (0, empty)], 8)
+    assert sp.shape == (7,) and sp.dtype == np.uint64 and (np.diff(sp.astype(np.float64)) >= 0).all()
+    assert np.array_equal(sp, multigpu.choose_splitters([(0, empty), (1_000, small), (1_000_000, big)], 8))
+    # the big sample carries 1000 x the weight: the cuts are (nearly) its own octiles, the small sample's keys hardly move them
+    assert np.abs(np.searchsorted(big, sp) - 64 * np.arange(1, 8)).max() <= 2
+    assert multigpu.choose_splitters([(5, big)], 1).shape == (0,)
+    assert (multigpu.choose_splitters([(0, empty)], 4) == np.uint64(1) << np.uint64(63)).all()
+    seqs = ["ACGT" * 5, "T" * 17, "GGGCCCAAATTTGGGC", "A" * 300, "CCCCCCCCCCCCCCCCCC"]
+    fs = FlatSeqs.from_list(seqs)
+    cnt = np.array([[3], [1], [7], [2], [9]], dtype=np.uint32)
+    multigpu.write_parts(tmp_path, 4, fs, cnt, np.array([0, 2, 2, 5], dtype=np.int64))
+    got = [multigpu.read_part(tmp_path, 4, q) for q in range(3)]
+    assert [FlatSeqs(p.data, p.offsets).to_list() for p in got] == [seqs[:2], [], seqs[2:]]
+    assert [p.counts.tolist() for p in got] == [[3, 1], [], [7, 2, 9]] and got[2].lengths.dtype == np.uint16
+    assert not list(tmp_path.iterdir())  # read_part removes what it has read
+
+
 def test_two_ranks_gloo_merge_equals_reference(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
