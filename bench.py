@@ -82,7 +82,7 @@ def rocprof_symbol(rec_name):
     if base.startswith("k_pass["):
         return f"k_pass<{w}, {int(base[7:-1].split('-')[0])}>"  # a merged run 'k_pass[4-6]' is launched as slot 4
     if base in ("k_cascade_fused", "k_cascade_bulk"):  # <W, HASN>: the record's 'n' suffix is the group with N masks
-        return f"{base}<{w}, {'true' if rec_name.endswith('n') else 'false'}>"
+        return f"{base}<{w}, {'true' if rec_name.endswith('n') else 'false'},"  # (<W, HASN, REP>: either build of the group's kernel)
     if base in ("k_collapse_insert", "k_collapse_scatter"):
         return f"{base}<{w}>"
     if base == "k_part_dedup":  # k_part_dedup<2048> / <4096>: one of them per sample size

@@ -264,7 +264,7 @@ __device__ __attribute__((noinline)) RareKmer rarest_kmer(MirgeKTable tb, MirgeR
 
 // long candidate lists (repeats, poly-A), one at a time by the whole wave: the owner's read is broadcast, the 64 lanes
 // stride through the bucket (coalesced pos[] loads), the few lanes that found a valid window are read back
-template <int W>
+template <int W, bool REP>
 __device__ __forceinline__ void verify_heavy(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const MirgeRead<W>& r,
                                              gptr_u32 pos, uint32_t lo, uint32_t hi, int a, bool heavy, uint64_t& best) {
     const int lane = threadIdx.x & 63;
@@ -290,12 +290,12 @@ __device__ __forceinline__ void verify_heavy(const MirgeLibView& lib, const Mirg
             for (int u = 0; u < MIRGE_COOP_UNROLL; u++) c[u] = c0 + 64 * u;
             const uint64_t cand = eval_batch<W, MIRGE_COOP_UNROLL>(lib, pol, mi, rr, bpos, c, bhi, ba);
             if (cand < lbest) lbest = cand;
-#if MIRGE_SORTED_EXIT
+            if constexpr (REP && MIRGE_SORTED_EXIT) {
             // (round 6) the list ascends (k_table_heavy_list + the segmented sort): candidates rank by (class, mismatches, position),
             // class and position only grow from here, so a window without a mismatch is final -- the scan of a poly-A bucket of 10^6
             // windows ends at the first tail that holds the read
             if (__ballot(cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u)) break;
-#endif
+            }
         }
         // almost every candidate fails verification: instead of a shuffle tree, visit the few
         // lanes that hold a hit (v_readlane -> scalar min)
@@ -312,14 +312,14 @@ __device__ __forceinline__ void verify_heavy(const MirgeLibView& lib, const Mirg
 }
 
 // the candidate list [lo, hi) of one probe, verified: short lists by their own lane, long ones by the whole wave
-template <int W>
+template <int W, bool REP>
 __device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi, const MirgeRead<W>& r,
                                              gptr_u32 pos, uint32_t lo, uint32_t hi, int a, uint64_t& best) {
     // lists of up to MIRGE_LIGHT_MAX windows are verified by their own lane, MIRGE_LIGHT per batch
     // (a cooperative hand-over costs the whole wave ~150 instructions per list; with 5-15 windows
     // per list and many such lanes per probe the lane-serial batches are several times cheaper)
     bool heavy = (hi - lo) > MIRGE_LIGHT_MAX;
-#if MIRGE_ADAPTIVE_LIGHT
+    if constexpr (REP && MIRGE_ADAPTIVE_LIGHT) {
     // (round 6) A hand-over serves ONE lane's list at a time: 64 lanes that each hold a list of 300 windows (reads out of an
     // Alu-like family with 800 diverged copies) cost the wave 64 x 5 trips, while the lanes walking their own lists side by side
     // cost it 300 / MIRGE_LIGHT = 75.  So: with the wave's heavy lists summing to n windows the cooperative route takes n / 64 trips,
@@ -332,7 +332,7 @@ __device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const Mirg
         for (int o = 32; o > 0; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o, 64);
         if (heavy && (hi - lo) <= (tot >> 4)) heavy = false;
     }
-#endif
+    }
     if (!heavy) {
         for (uint32_t c0 = lo; c0 < hi; c0 += MIRGE_LIGHT) {
             uint32_t c[MIRGE_LIGHT];
@@ -340,15 +340,18 @@ __device__ __forceinline__ void verify_lists(const MirgeLibView& lib, const Mirg
             for (int u = 0; u < MIRGE_LIGHT; u++) c[u] = c0 + u;
             const uint64_t cand = eval_batch<W, MIRGE_LIGHT>(lib, pol, mi, r, pos, c, hi, a, best);
             if (cand < best) best = cand;
-#if MIRGE_SORTED_EXIT
-            if (hi - lo > MIRGE_LIGHT_MAX && cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u) break;  // (a sorted list: see verify_heavy)
-#endif
+            if constexpr (REP && MIRGE_SORTED_EXIT)
+                if (hi - lo > MIRGE_LIGHT_MAX && cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u) break;  // (a sorted list: see verify_heavy)
         }
     }
-    verify_heavy<W>(lib, pol, mi, r, pos, lo, hi, a, heavy, best);
+    verify_heavy<W, REP>(lib, pol, mi, r, pos, lo, hi, a, heavy, best);
 }
 
-template <int W, bool LDS>
+// REP (round 6): the build for configurations whose libraries repeat themselves (an outlier bucket: mirge_lib::max_bucket) -- sorted
+// exits, the lane-serial walk of many heavy lists, the rarest k-mer of an exact seed, deferral to k_cascade_heavy.  REP = false is the
+// kernel as it was for libraries that hold no such bucket: each of those four costs the uniform-library step 0.5-0.8 % in registers
+// and issue slots for nothing it could gain (profiles/r06_ab_rep_features.txt).
+template <int W, bool LDS, bool REP>
 __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const MirgePolicy& pol, const MergeInfo& mi,
                                              const PlanSrc<LDS>& ps, const MirgeRead<W>& r, bool active, uint64_t& best) {
     best = MIRGE_NO_HIT;
@@ -361,7 +364,7 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
     // (round 6) pol.reserved > 0: a read that meets a bucket of more windows than that is not aligned by this wave -- one such list
     // (a poly-A bucket of the mRNA library: 2 M windows) kept ONE wave busy for 20 ms while the chip idled.  It is answered
     // MIRGE_DEFER and taken by k_cascade_heavy: a whole workgroup per read, its lists strided by 256 threads.
-    const uint32_t big_t = (uint32_t)pol.reserved;
+    const uint32_t big_t = REP ? (uint32_t)pol.reserved : 0u;
     bool defer = false;
 #pragma unroll 1
     for (int q = 0; q < npmax; q++) {
@@ -405,7 +408,7 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
             }
 #endif
             a = pr.a1;
-#if MIRGE_MIN_BUCKET
+            if constexpr (REP && MIRGE_MIN_BUCKET) {
             // (round 6) An exact-seed policy (mm = 0: mRNA, spike-in) admits no mismatch inside the seed, so ANY k-mer of the seed
             // filters completely -- the plan takes the first.  A read out of a repeat with a sequencing error (poly-A with one G) whose
             // first k-mer misses the error lands in a bucket of 10^5 .. 10^6 windows none of which can verify; a k-mer that holds the
@@ -414,15 +417,15 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
                 const RareKmer rk = rarest_kmer<W>(tb, r, mirge_seed_region(pol, r.len), pr.k1, hi - lo);
                 if (rk.a > 0) { lo = rk.lo; hi = rk.hi; a = rk.a; pos = rk.inl ? nullptr : (gptr_u32)tb.pos; }
             }
-#endif
-            if (big_t && (hi - lo) > big_t) { defer = true; active = false; lo = hi = 0; }  // (its other probes need not be looked at either)
+            }
+            if (REP && big_t && (hi - lo) > big_t) { defer = true; active = false; lo = hi = 0; }  // (its other probes need not be looked at either)
         }
-        verify_lists<W>(lib, pol, mi, r, pos, lo, hi, a, best);
+        verify_lists<W, REP>(lib, pol, mi, r, pos, lo, hi, a, best);
         // a 0-mismatch window (of the first member library) is in probe 0's bucket and buckets ascend:
         // nothing later can beat it
         if (q == 0 && (best >> 32) == 0) active = false;
     }
-    if (defer) best = MIRGE_DEFER;
+    if (REP && defer) best = MIRGE_DEFER;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -558,7 +561,7 @@ __device__ __forceinline__ void pass_segment(const MirgeLibView& lib, const Mirg
             r2.len = 0;
         }
         uint64_t best;
-        align_hybrid<W, LDSP>(lib, pol, mi, psrc, r2, elig, best);
+        align_hybrid<W, LDSP, true>(lib, pol, mi, psrc, r2, elig, best);  // (the staged route: the repeat-aware build always)
         if (elig && best == MIRGE_DEFER) {  // a bucket no wave should walk alone: k_cascade_heavy answers for this read
             defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm);
             survivor = false;
@@ -834,7 +837,7 @@ __device__ __forceinline__ void count_open(bool open, uint32_t* ctr) {
 }
 
 // pass_segment for a walk: per read pre -> main -> post, in the cascade's order
-template <int W, bool LDSP, bool COHERENT, bool HASN>
+template <int W, bool LDSP, bool COHERENT, bool HASN, bool REP>
 __device__ __forceinline__ void walk_segment(const BulkWalk& wk, const PlanSrc<LDSP>& psrc, const GroupView<W>& g, const uint32_t* act_in,
                                              uint32_t n_in, size_t seg, size_t seg_r, uint32_t* __restrict__ act_out,
                                              int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm,
@@ -909,8 +912,8 @@ __device__ __forceinline__ void walk_segment(const BulkWalk& wk, const PlanSrc<L
         if (has_main) {
             const bool elig = open && mirge_effective_read<W>(r2, wk.main.pol);  // (a policy `post` follows leaves r2 as it was)
             uint64_t best;
-            align_hybrid<W, LDSP>(wk.main.lib, wk.main.pol, wk.main.mi, psrc, r2, elig, best);
-            if (elig && best == MIRGE_DEFER) {  // a bucket no wave should walk alone: k_cascade_heavy answers for this read
+            align_hybrid<W, LDSP, REP>(wk.main.lib, wk.main.pol, wk.main.mi, psrc, r2, elig, best);
+            if (REP && elig && best == MIRGE_DEFER) {  // a bucket no wave should walk alone: k_cascade_heavy answers for this read
                 defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm);
                 open = false;
             } else
@@ -951,7 +954,7 @@ __device__ __forceinline__ void walk_segment(const BulkWalk& wk, const PlanSrc<L
 
 // HASN = false: the build for a group without ambiguous calls -- its N masks are compile-time zeros and fold away in everything
 // inlined behind the load (7 fewer spilled scalar registers, -2 % kernel time on the bulk group)
-template <int W, bool HASN>
+template <int W, bool HASN, bool REP>
 __global__ void __launch_bounds__(MIRGE_BLOCK) __attribute__((amdgpu_waves_per_eu(W == 1 ? MIRGE_BULK_WAVES : 1, 8)))  // one-word reads: 6 workgroups per CU must be resident (80 VGPRs; k_pass: 77); wider reads keep their registers
 k_cascade_bulk(const BulkWalks* __restrict__ walks, GroupView<W> g, uint32_t* __restrict__ actA, uint32_t* __restrict__ actB,
                uint32_t* __restrict__ seg_n, uint32_t cap, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
@@ -978,7 +981,7 @@ k_cascade_bulk(const BulkWalks* __restrict__ walks, GroupView<W> g, uint32_t* __
         __syncthreads();
         PlanSrc<LDSP> psrc;
         psrc.g = wk.main.plan; psrc.l = LDSP ? s_plan : nullptr;
-        walk_segment<W, LDSP, !MIRGE_SURV_PLAIN_LOADS, HASN>(wk, psrc, g, act_in, n_in, seg, seg_r, act_out, res_pass, res_pos, res_mm, &s_count, s_open,
+        walk_segment<W, LDSP, !MIRGE_SURV_PLAIN_LOADS, HASN, REP>(wk, psrc, g, act_in, n_in, seg, seg_r, act_out, res_pass, res_pos, res_mm, &s_count, s_open,
                                                              heavy_cnt, heavy_list);
         __syncthreads();  // the survivors are written (and visible to this workgroup at L2), the plan is free again
         n_in = s_count;
@@ -1020,7 +1023,7 @@ __global__ void k_resolve(ResolveTable tb, const int8_t* __restrict__ res_pass, 
 // every step; a read that is annotated simply stops being eligible (no compaction: the group is small).
 // Same device functions as k_pass, so the same answers.
 // ------------------------------------------------------------------------------------------
-template <int W, bool HASN>
+template <int W, bool HASN, bool REP>
 __global__ void __launch_bounds__(MIRGE_BLOCK)
 k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView<W> g, int8_t* __restrict__ res_pass,
                 uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref,
@@ -1048,8 +1051,8 @@ k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
             uint64_t best;
             PlanSrc<false> psrc;
             psrc.g = st.plan; psrc.l = nullptr;
-            align_hybrid<W, false>(st.lib, st.pol, st.mi, psrc, r2, elig, best);
-            if (elig && best == MIRGE_DEFER) {  // k_cascade_heavy answers for this read (and writes all five of its fields)
+            align_hybrid<W, false, REP>(st.lib, st.pol, st.mi, psrc, r2, elig, best);
+            if (REP && elig && best == MIRGE_DEFER) {  // k_cascade_heavy answers for this read (and writes all five of its fields)
                 o_pass = -2;
                 heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
                 open = false;

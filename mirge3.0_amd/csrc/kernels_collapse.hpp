@@ -216,7 +216,8 @@ __device__ __forceinline__ uint32_t region_prefix(const uint32_t* __restrict__ c
 __global__ void __launch_bounds__(MIRGE_PART_THREADS)
 k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uint32_t chunk, uint32_t shift1, uint32_t NB1,
            uint32_t bshift, uint32_t B, uint32_t CS, uint32_t cap1, uint4* __restrict__ rec1, uint32_t* __restrict__ cnt1,
-           uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow, uint32_t* __restrict__ n_records) {
+           uint32_t* __restrict__ hist, uint32_t* __restrict__ overflow, uint32_t* __restrict__ n_records, uint32_t* __restrict__ shard_cur) {
+    if (shard_cur && blockIdx.x == 0 && threadIdx.x < MIRGE_DEDUP_SHARDS) shard_cur[threadIdx.x * MIRGE_DEDUP_SHARD_STRIDE] = 0u;  // k_part_dedup's cursors
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_a[];  // [CS] keys | [CS] minj | [CS] cnt | [NB1] cursors | [B] hist
     uint32_t* c_min = reinterpret_cast<uint32_t*>(lds_a + CS);
     uint32_t* c_cnt = c_min + CS;
@@ -343,9 +344,15 @@ k_part_agg(GroupView<1> g, const uint32_t* __restrict__ orig, uint32_t base, uin
         const uint32_t n = cur[b];
         cnt1[(size_t)b * G + blockIdx.x] = min(n, cap1);
         if (n > cap1) atomicOr(overflow, 1u);
-        // (round 6) the sample's record count: what k_part_dedup chooses its output mode from -- on the device, for THIS sample
-        // (until round 5 the host chose from the context's previous sample)
-        atomicAdd(n_records, min(n, cap1));
+    }
+    // (round 6) the sample's record count: what k_part_dedup chooses its output mode from -- on the device, for THIS sample (until
+    // round 5 the host chose from the context's previous sample).  ONE add per workgroup: an add per level-1 bin was 16 384 adds on one
+    // address, served one after the other at 11.6 ns -- 0.19 ms of atomic traffic that was still draining under k_part_split and
+    // k_part_dedup, whose own cursor adds queued behind it (k_part_dedup 0.116 -> 0.130 ms).
+    if (threadIdx.x == 0) {
+        uint32_t mine = 0;
+        for (uint32_t b = 0; b < NB1; b++) mine += min(cur[b], cap1);
+        atomicAdd(n_records, mine);
     }
     if (hist) for (uint32_t b = threadIdx.x; b < B; b += blockDim.x) hist[(size_t)blockIdx.x * B + b] = lds_h[b];
 }
@@ -425,8 +432,16 @@ k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, co
     // the kernel's time is the one global cursor's returning adds (11.6 ns each, one per bucket) -> eight cursors into the staging
     // arrays (s*), k_part_compact closes the gaps; many records = the kernel's time is its records -> the one cursor, straight into
     // the output arrays (and k_part_compact returns at once).  Uniform over the launch: every workgroup reads the same word.
-    uint32_t* const shard_cur = (shard_cur_in && *n_records < rec_thresh) ? shard_cur_in : nullptr;
-    if (shard_cur) { useq = sseq; ulen = slen; ucnt = scnt; ufirst = sfirst; }
+    // (the word is ASKED FOR here and LOOKED AT behind the table's read-out, where the output range is reserved: a workgroup is a
+    // latency chain of ~12 us and eight rounds of them fill the chip -- waiting for this load at the top cost the kernel 13 us)
+    // ... and asked for with a VECTOR load (an address the compiler cannot prove uniform): a scalar load would be waited for at the
+    // kernel's first `s_waitcnt lgkmcnt(0)` -- scalar loads and LDS operations share that counter --, i.e. at the top after all; the
+    // vector load is in flight together with the bucket's first records.
+    // ... by ONE thread of the workgroup (every lane asking was 65 k requests for one address per launch: a hot spot on one L2 channel).
+    uint32_t lane_zero = 0u;
+    asm volatile("" : "+v"(lane_zero));  // (a zero in a vector register the compiler cannot see through)
+    uint32_t n_rec_now = 0u;
+    if (threadIdx.x == 0 && shard_cur_in) n_rec_now = n_records[lane_zero];
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds_k[];  // [CAP] keys, then [CAP] minj, [CAP] cnt
     uint32_t* lds_min = reinterpret_cast<uint32_t*>(lds_k + CAP);
     uint32_t* lds_cnt = lds_min + CAP;
@@ -506,6 +521,7 @@ k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, co
     for (int i = 0; i < PER; i++) mine += lds_k[s0 + i] != 0ull;
     uint32_t total;
     uint32_t rank = block_excl_scan<MIRGE_DEDUP_THREADS / 64>(mine, total, lds_x + 2);
+    uint32_t* const shard_cur = (shard_cur_in && n_rec_now < rec_thresh) ? shard_cur_in : nullptr;  // (thread 0's: it reserves the range)
     // Where the bucket's unique reads go.  One global cursor for all buckets (shard_cur == nullptr) is a returning add on ONE
     // address per bucket, and such adds are served one after the other, 11.6 ns each: 8192 buckets = 0.095 of this kernel's
     // 0.116 ms whatever they hold (profiles/README.md, round 5).  With shards, bucket b adds to cursor b mod MIRGE_DEDUP_SHARDS
@@ -522,9 +538,11 @@ k_part_dedup(const uint4* __restrict__ rec, const uint32_t* __restrict__ cnt, co
             } else at = atomicAdd(cursor, total);
         }
         lds_x[1] = at;
+        lds_x[18] = shard_cur ? 1u : 0u;  // (the mode, for the other threads: [2..17] is the scan's scratch, [32..63] the lengths)
     }
     __syncthreads();
     if (lds_x[1] == 0xFFFFFFFFu) return;
+    if (lds_x[18]) { useq = sseq; ulen = slen; ucnt = scnt; ufirst = sfirst; }
     rank += lds_x[1];
 #pragma unroll
     for (int i = 0; i < PER; i++) {

@@ -140,8 +140,10 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
     if (!wg_per_cu[W]) {
         int nb = 0;
         hipFuncAttributes fa;
-        HIPOK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_pass<W, 15>), MIRGE_BLOCK, 0));
-        HIPOK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_pass<W, 15>)));
+        // (the bulk kernel's own attributes -- until round 6 k_pass<W, 15>'s stood in for them; that kernel is now always the repeat-aware
+        //  build and may take a few registers more than the attribute-capped bulk kernel)
+        HIPOK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_cascade_bulk<W, false, true>), MIRGE_BLOCK, 0));
+        HIPOK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_cascade_bulk<W, false, true>)));
         const int by_regs = 512 / std::max(16, (fa.numRegs + 15) / 16 * 16);  // waves per SIMD = 4-wave workgroups per CU
         wg_per_cu[W] = std::max(1, std::min({nb, by_regs, W == 1 ? MIRGE_BULK_WAVES : 6}));
         if (std::getenv("MIRGE_WG_PER_CU")) wg_per_cu[W] = std::max(1, std::atoi(std::getenv("MIRGE_WG_PER_CU")));
@@ -180,12 +182,13 @@ static int cascade_group(mirge_ctx* c, const ReadGroup& rg, ResGroup& out, const
         if (ls.rec >= 0)
             for (size_t k = 0; k < steps.size(); k++) stage_of_pass.emplace_back(ls.rec, (int)k);  // units = reads handed to every pass
         // (a group without ambiguous calls runs the build of the kernel in which the N masks are compile-time zeros)
-        if (rg.nmask)
-            hipLaunchKernelGGL((k_cascade_bulk<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos,
-                               out.mm, n_dev, hcnt, hlist);
-        else
-            hipLaunchKernelGGL((k_cascade_bulk<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos,
-                               out.mm, n_dev, hcnt, hlist);
+        // (REP: the repeat-aware build, for configurations with an outlier bucket -- align_hybrid)
+#define MIRGE_LAUNCH_BULK(HASN_, REP_)                                                                                                              \
+    hipLaunchKernelGGL((k_cascade_bulk<W, HASN_, REP_>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dwalks, v, actA, actB, seg_n, cap, out.pass, out.pos, \
+                       out.mm, n_dev, hcnt, hlist)
+        if (rg.nmask) { if (c->casc_rep) MIRGE_LAUNCH_BULK(true, true); else MIRGE_LAUNCH_BULK(true, false); }
+        else { if (c->casc_rep) MIRGE_LAUNCH_BULK(false, true); else MIRGE_LAUNCH_BULK(false, false); }
+#undef MIRGE_LAUNCH_BULK
         stage = (int)steps.size();
         if (c->profiling && W == 1) {  // the workgroups' clocks of this launch, for mirge_cascade_wg_times (stream-ordered copy)
             if (c->wg_pinned_words < 2 * (size_t)grid) {
@@ -273,12 +276,13 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     {
         LaunchScope ls(c, name, n);
         const uint32_t grid = std::min<uint32_t>((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (uint32_t)c->n_cu * 8);
-        if (rg.nmask)
-            hipLaunchKernelGGL((k_cascade_fused<W, true>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
-                               out.pos, out.mm, out.ref, out.off, hcnt, hlist);
-        else  // no ambiguous calls in the group: the build whose N masks are compile-time zeros
-            hipLaunchKernelGGL((k_cascade_fused<W, false>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass,
-                               out.pos, out.mm, out.ref, out.off, hcnt, hlist);
+        // (HASN = false: no ambiguous calls in the group: the build whose N masks are compile-time zeros; REP: see align_hybrid)
+#define MIRGE_LAUNCH_FUSED(HASN_, REP_)                                                                                                        \
+    hipLaunchKernelGGL((k_cascade_fused<W, HASN_, REP_>), dim3(grid), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), out.pass, out.pos, \
+                       out.mm, out.ref, out.off, hcnt, hlist)
+        if (rg.nmask) { if (c->casc_rep) MIRGE_LAUNCH_FUSED(true, true); else MIRGE_LAUNCH_FUSED(true, false); }
+        else { if (c->casc_rep) MIRGE_LAUNCH_FUSED(false, true); else MIRGE_LAUNCH_FUSED(false, false); }
+#undef MIRGE_LAUNCH_FUSED
     }
     if (hcnt) launch_heavy<W>(c, rg, out, dsteps, rt, gtag, hcnt, hlist, view_of<W>(rg), true);
     c->defer(hlist);
@@ -375,9 +379,16 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
     // workgroup per read.  Uniform-random libraries hold none: their cascades run as before, without the extra launch.
     static const uint32_t big_t_env = std::getenv("MIRGE_BIG_T") ? (uint32_t)std::strtoul(std::getenv("MIRGE_BIG_T"), nullptr, 10) : 8192u;
     static const bool big_t_forced = std::getenv("MIRGE_BIG_T") != nullptr;  // (tests: every bucket beyond the given size defers, outlier or not)
+    // MIRGE_CASCADE_REP=1 / 0: the repeat-aware build of the cascade kernels always / never (tests, A/B); by itself: when a library holds an
+    // outlier bucket (>= 1024 windows and 32 x what a uniform text would put there)
+    static const int rep_env = std::getenv("MIRGE_CASCADE_REP") ? std::atoi(std::getenv("MIRGE_CASCADE_REP")) : -1;
     c->casc_big_t = big_t_forced ? big_t_env : 0;
-    for (auto& st : steps)
+    c->casc_rep = rep_env > 0 || big_t_forced;
+    for (auto& st : steps) {
+        if (st.lib->max_bucket > 0 && rep_env != 0) c->casc_rep = true;
         if (big_t_env && st.lib->max_bucket > big_t_env) c->casc_big_t = big_t_env;
+    }
+    if (!c->casc_rep) c->casc_big_t = 0;  // (only the repeat-aware build defers)
     if (c->casc_big_t && !c->heavy_cnt) {
         HIPOK(hipMalloc((void**)&c->heavy_cnt, 2 * MIRGE_NGROUPS * 4));
         HIPOK(hipMemset(c->heavy_cnt, 0, 2 * MIRGE_NGROUPS * 4));

@@ -211,7 +211,8 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
             CHECK(dalloc(c, &t.s_len, sn));
             CHECK(dalloc(c, &t.s_cnt, sn));
             CHECK(dalloc(c, &t.s_first, sn));
-            HIPOK(hipMemsetAsync(t.shard_cur, 0, (size_t)MIRGE_DEDUP_SHARDS * MIRGE_DEDUP_SHARD_STRIDE * 4, c->cur));  // (in front of k_part_agg: off the path)
+            // (the eight cursors are zeroed by k_part_agg's first workgroup: a memset in front of it was a launch of its own, 2 us of
+            //  kernel behind 17 us of queue gap at the head of every step)
         }
         if (NB2 > 1) {
             CHECK(dalloc(c, &t.hist, (size_t)G * B));
@@ -229,7 +230,7 @@ static int collapse_phase_a(mirge_ctx* c, int gi, const ReadGroup& in, ReadGroup
         {
             LaunchScope ls(c, "k_part_agg.w1", in.n);
             hipLaunchKernelGGL(k_part_agg, dim3(G), dim3(MIRGE_PART_THREADS), agg_lds, c->cur, v1, in.orig, in.base, chunk, shift1, NB1,
-                               shift2, B, CS, cap1, t.rec1, t.cnt1, t.hist, dmeta + MIRGE_META_OVERFLOW, dmeta + MIRGE_META_RECORDS);
+                               shift2, B, CS, cap1, t.rec1, t.cnt1, t.hist, dmeta + MIRGE_META_OVERFLOW, dmeta + MIRGE_META_RECORDS, t.shard_cur);
         }
         t.G = G; t.B = B; t.NB1 = NB1; t.NB2 = NB2; t.W2 = W2; t.RPW = RPW; t.cap1 = cap1; t.slab = slab; t.shift2 = shift2;
         if (stage == 1) return collapse_part_rest(c, gi, in, out, t, dmeta, 1);

@@ -84,6 +84,7 @@ struct mirge_ctx {
     // current configuration's steps carry (0: no library holds a bucket that large -- no deferral, no extra launch)
     uint32_t* heavy_cnt = nullptr;
     uint32_t casc_big_t = 0;
+    bool casc_rep = false;  // the configuration's libraries repeat themselves: the cascade kernels' repeat-aware build (align_hybrid<.., REP>)
     uint32_t* wg_pinned = nullptr;
     size_t wg_pinned_words = 0;
     uint32_t wg_grid = 0;
