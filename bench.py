@@ -418,10 +418,16 @@ def c4_end_to_end(args, dist, rank, world, sl, casc, reads, n_pass):
                 res["output_bytes"] = {f: os.path.getsize(os.path.join(work, f)) for f in ("mapped.csv", "unmapped.csv", "miR.Counts.csv")}
             return res, work
 
-        first, _ = one_run("ranges_first", True)   # pays for page-locked staging, buffer-pool blocks, the page cache
+        def drop(work):  # (a run's two per-read files are GBs at C4's size: only the two runs that are compared stay side by side)
+            gd.barrier()
+            if rank == 0:
+                shutil.rmtree(work, ignore_errors=True)
+        first, w_f = one_run("ranges_first", True)   # pays for page-locked staging, buffer-pool blocks, the page cache
+        drop(w_f)
         out["ranges"], w_r = one_run("ranges", True)
         out["ranges"]["first_run_wall_s"] = first["wall_s"]
-        one_run("rank0_first", False)
+        _, w_f0 = one_run("rank0_first", False)
+        drop(w_f0)
         out["rank0_alone"], w_0 = one_run("rank0", False)
         if rank == 0:
             import subprocess
