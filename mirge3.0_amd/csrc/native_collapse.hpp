@@ -459,10 +459,14 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
                     if (gi != big && gi != largest && raw->g[gi].n) small_stream[gi] = n_spread++ % MIRGE_N_XAUX;
             if (n_spread && rc == 0) rc = xaux_fork(c);
         }
+        // MIRGE_DEDUP_FIRST=1 (round 6 experiment): the bulk group's k_part_dedup enqueued with its first two kernels, ahead of the small
+        // groups' launches, instead of behind them
+        static const bool dedup_first = std::getenv("MIRGE_DEDUP_FIRST") && std::atoi(std::getenv("MIRGE_DEDUP_FIRST")) == 1;
         for (int k = -1; k <= MIRGE_NGROUPS && rc == 0; k++) {
             const int gi = (k < 0 || k == MIRGE_NGROUPS) ? big : k;
             if (k >= 0 && k < MIRGE_NGROUPS && gi == big) continue;
-            const int stage = k < 0 ? 1 : (k == MIRGE_NGROUPS ? 2 : 0);
+            if (dedup_first && k == MIRGE_NGROUPS) continue;
+            const int stage = k < 0 ? (dedup_first ? 0 : 1) : (k == MIRGE_NGROUPS ? 2 : 0);
             c->cur = gi == big ? c->stream : (small_stream[gi] >= 0 ? c->xaux[small_stream[gi]] : c->aux);
             if (is_long_group(gi)) rc = collapse_phase_a_long(c, gi, raw->g[gi], tmp[gi], dsample, S, dmeta, stage, dweight);
             else MIRGE_BY_WIDTH(gi, rc, collapse_phase_a<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], dsample, S, dmeta, attempt, stage, dweight));
