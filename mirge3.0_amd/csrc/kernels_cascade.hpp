@@ -29,9 +29,9 @@
 #ifndef MIRGE_MIN_BUCKET
 #define MIRGE_MIN_BUCKET 1    // exact-seed policies: a read whose probe bucket is heavy takes the rarest k-mer of its seed instead
 #endif
-// k_cascade_heavy: a workgroup of 1024 threads per read, four windows per thread in flight: a bucket of 2 M windows is 512 trips
+// k_cascade_heavy: a workgroup of 1024 threads per read, eight windows per thread in flight: a bucket of 2 M windows is 256 trips
 #define MIRGE_HEAVY_THREADS 1024
-#define MIRGE_HEAVY_UNROLL 4
+#define MIRGE_HEAVY_UNROLL 8
 #define MIRGE_HEAVY_RETRY 64  // windows in an exact-seed probe's bucket from which the other k-mers of the seed are asked
 #ifndef MIRGE_LDS_PLAN
 #define MIRGE_LDS_PLAN 1
@@ -431,9 +431,8 @@ __device__ __forceinline__ void align_hybrid(const MirgeLibView& lib, const Mirg
 // ------------------------------------------------------------------------------------------
 // k_cascade_heavy (round 6): the reads align_hybrid answered MIRGE_DEFER for -- one of their probe buckets holds more windows
 // than a wave should walk alone (poly-A, Alu-like and simple-repeat buckets of real libraries: 10^4 .. 10^6 windows) -- with ONE
-// WORKGROUP per read: every step of the cascade from the first on (the answer depends on the read alone, so redoing the passes
-// that found nothing costs a few lookups and changes nothing), every candidate list strided by all 256 threads, two windows per
-// thread in flight, the scan of a position-sorted list ended by the first window without a mismatch.  Same probes, same
+// WORKGROUP per read: every step of the cascade from the one that deferred it on (its mark names the pass; the passes before it found
+// nothing), every candidate list strided by all 1 024 threads, four windows per thread in flight, the scan of a position-sorted list ended by the first window without a mismatch.  Same probes, same
 // verification, same minimum as align_hybrid: same answers.  heavy_cnt[0] = reads in heavy_list (appended by the cascade kernels
 // of this group), heavy_cnt[1] = workgroups done: the last one resets both for the next launch.
 // ------------------------------------------------------------------------------------------
@@ -485,13 +484,18 @@ __device__ __forceinline__ uint64_t align_wg(const MirgeLibView& lib, const Mirg
         }
 #endif
         const bool sorted = (hi - lo) > MIRGE_LIGHT_MAX;  // (what k_table_heavy_list lists)
+        // the exit is looked for every eighth trip only: a barrier per trip made every wave wait for the slowest wave's loads, trip after
+        // trip -- a list of 2 M windows was 512 trips of 4.7 us; between two checks the waves run ahead of each other
+        bool seen_exact = false;
+        uint32_t trip = 0;
         for (uint32_t c0 = lo + threadIdx.x; c0 - threadIdx.x < hi; c0 += MIRGE_HEAVY_UNROLL * MIRGE_HEAVY_THREADS) {
             uint32_t c[MIRGE_HEAVY_UNROLL];
 #pragma unroll
             for (int u = 0; u < MIRGE_HEAVY_UNROLL; u++) c[u] = c0 + u * MIRGE_HEAVY_THREADS;
             const uint64_t cand = eval_batch<W, MIRGE_HEAVY_UNROLL>(lib, pol, mi, r, pos, c, hi, a);
             if (cand < best) best = cand;
-            if (MIRGE_SORTED_EXIT && sorted && __syncthreads_or(cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u)) break;
+            seen_exact |= cand != MIRGE_NO_HIT && ((cand >> 32) & 0xFFu) == 0u;
+            if (MIRGE_SORTED_EXIT && sorted && (++trip & 7u) == 0u && __syncthreads_or(seen_exact)) break;
         }
         // a 0-mismatch window of the first member library is in probe 0's bucket: nothing later can beat it
         if (q == 0 && np > 1 && (wg_min_u64(best, s_best) >> 32) == 0) break;
@@ -500,9 +504,10 @@ __device__ __forceinline__ uint64_t align_wg(const MirgeLibView& lib, const Mirg
 }
 
 // a deferred read: marked (the heavy kernel overwrites the mark), listed
+// (the mark names the pass that deferred the read, -2 - pass: the passes before it found nothing and k_cascade_heavy resumes there)
 __device__ __forceinline__ void defer_read(uint32_t idx, uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list,
-                                           int8_t* __restrict__ res_pass, int8_t* __restrict__ res_mm) {
-    res_pass[idx] = -2; res_mm[idx] = -1;
+                                           int8_t* __restrict__ res_pass, int8_t* __restrict__ res_mm, int32_t pass_id) {
+    res_pass[idx] = (int8_t)(-2 - pass_id); res_mm[idx] = -1;
     heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
 }
 
@@ -563,7 +568,7 @@ __device__ __forceinline__ void pass_segment(const MirgeLibView& lib, const Mirg
         uint64_t best;
         align_hybrid<W, LDSP, true>(lib, pol, mi, psrc, r2, elig, best);  // (the staged route: the repeat-aware build always)
         if (elig && best == MIRGE_DEFER) {  // a bucket no wave should walk alone: k_cascade_heavy answers for this read
-            defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm);
+            defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm, pass_id);
             survivor = false;
         } else
         if (elig && best != MIRGE_NO_HIT) {
@@ -914,7 +919,7 @@ __device__ __forceinline__ void walk_segment(const BulkWalk& wk, const PlanSrc<L
             uint64_t best;
             align_hybrid<W, LDSP, REP>(wk.main.lib, wk.main.pol, wk.main.mi, psrc, r2, elig, best);
             if (REP && elig && best == MIRGE_DEFER) {  // a bucket no wave should walk alone: k_cascade_heavy answers for this read
-                defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm);
+                defer_read(idx, heavy_cnt, heavy_list, res_pass, res_mm, wk.main.pass_id);
                 open = false;
             } else
             if (elig && best != MIRGE_NO_HIT) {
@@ -1053,7 +1058,7 @@ k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
             psrc.g = st.plan; psrc.l = nullptr;
             align_hybrid<W, false, REP>(st.lib, st.pol, st.mi, psrc, r2, elig, best);
             if (REP && elig && best == MIRGE_DEFER) {  // k_cascade_heavy answers for this read (and writes all five of its fields)
-                o_pass = -2;
+                o_pass = (int8_t)(-2 - st.pass_id);  // (see defer_read)
                 heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
                 open = false;
             } else
@@ -1090,10 +1095,13 @@ k_cascade_heavy(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
         const uint32_t idx = heavy_list[item];
         MirgeRead<W> r0;
         load_read<W, HASN>(g, idx, r0);
+        const int from_pass = -2 - (int)res_pass[idx];  // the pass that deferred the read: those before it found nothing
+        __syncthreads();  // (every thread has read the mark before thread 0 overwrites it with the answer)
         int8_t o_pass = -1, o_mm = -1;
         uint32_t o_pos = 0;
         for (int si = 0; si < nsteps && o_pass < 0; si++) {
             const FusedStep& st = steps->s[si];
+            if (st.pass_id < from_pass) continue;
             MirgeRead<W> r2 = r0;
             if (!mirge_effective_read<W>(r2, st.pol)) continue;
             const uint64_t best = align_wg<W>(st.lib, st.pol, st.mi, st.plan, r2, &s_best);
