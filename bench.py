@@ -554,6 +554,56 @@ def secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, I
         return out_l
 
     pool = max(1000, n // 8)
+
+    def multi_sample(S=4):
+        """SEVERAL samples in one process and ONE launch set (never `value`): what the CLI runs for `-s S1.fastq,S2.fastq,...` -- every sample
+        collapsed by itself, the dictionaries merged on the device (mirge_collapse_merge, round 6), one cascade and one count join over the
+        union with S count columns -- against round 5's route (mirge_collapse with sample ids over the samples' raw reads: the general,
+        global-atomic path) and against S separate steps.  Four samples of the Zipf kind."""
+        smp = [synth.make_reads(sl, n, seed=2000 + s, pool=pool) for s in range(S)]
+        raws = [_ffi.DeviceReads.pack(ctx, x) for x in smp]
+        del smp
+        sid = np.repeat(np.arange(S, dtype=np.int32), [len(r) for r in raws])
+        nu = [0]
+
+        def merged():
+            dicts = [r.collapse() for r in raws]
+            u = _ffi.DeviceReads.merge(ctx, dicts)
+            for d in dicts:
+                d.close()
+            rs = casc.run(u)
+            _ffi.count_join(ctx, u, rs, EXACT_PASS, ISO_PASS, n_mirna)
+            nu[0] = len(u)
+            rs.close(); u.close()
+
+        def joint_raw():
+            allr = _ffi.DeviceReads.concat(ctx, raws)
+            u = allr.collapse(sid, S)
+            rs = casc.run(u)
+            _ffi.count_join(ctx, u, rs, EXACT_PASS, ISO_PASS, n_mirna)
+            rs.close(); u.close(); allr.close()
+
+        def separate():
+            for r in raws:
+                u, rs = casc.collapse_and_run(r)
+                _ffi.count_join(ctx, u, rs, EXACT_PASS, ISO_PASS, n_mirna)
+                rs.close(); u.close()
+        out_m = {}
+        for name, f in (("merged_dictionaries", merged), ("joint_collapse_of_raw_reads", joint_raw), ("separate_steps", separate)):
+            f(); f()
+            k, t0 = 0, time.perf_counter()
+            while k < 5 or time.perf_counter() - t0 < 0.3:
+                f(); k += 1
+            dt = (time.perf_counter() - t0) / k
+            out_m[name] = {"ms_per_run": round(dt * 1e3, 4), "ms_per_sample": round(dt * 1e3 / S, 4), "M_raw_reads_per_s": round(S * n / dt / 1e6, 1)}
+        for r in raws:
+            r.close()
+        out_m.update(samples=S, raw_reads_per_sample=n, unique_reads_of_the_union=nu[0],
+                     note="S samples, one process: merged_dictionaries = the CLI's route since round 6 (per-sample partitioned collapses + "
+                          "mirge_collapse_merge + one cascade + one S-column join); joint_collapse_of_raw_reads = its route until round 5; "
+                          "separate_steps = S times the step of `value` (S dictionaries, S cascades, no union)")
+        return out_m
+
     res["zipf_pool"] = leg(synth.make_reads(sl, n, seed=2000, pool=pool),
                            f"Zipf(s = 1.1) duplication over {pool} templates of the same class mix: SURVEY 8(d)'s 'realistic' set", flights=(2, 4))
     # all distinct: the default class mix without its duplicated exact-miRNA class, collapsed once on the GPU, its unique reads
@@ -567,6 +617,10 @@ def secondary_read_sets(args, sl, ctx, casc, _ffi, synth, n_mirna, EXACT_PASS, I
     del cand
     if len(distinct) > n:
         distinct = distinct.take(np.arange(n))
+    try:
+        res["multi_sample_run"] = multi_sample(4)
+    except Exception as e:  # noqa: BLE001
+        res["multi_sample_run"] = {"error": repr(e)[:300]}
     res["distinct"] = leg(distinct, "every read exactly once (U = N): SURVEY 8(d)'s 'stress' set -- the class mix minus its duplicated exact-miRNA "
                                     "reads, de-duplicated; every read goes through the cascade")
     return res

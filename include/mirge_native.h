@@ -197,6 +197,11 @@ int mirge_collapse(mirge_ctx* ctx, const mirge_reads* raw, const int32_t* sample
  * without expanding them.  first indices refer to the raw set as given. */
 int mirge_collapse_weighted(mirge_ctx* ctx, const mirge_reads* raw, const int32_t* sample_ids, int32_t n_samples,
                             const uint32_t* weights, mirge_reads** uniq, int64_t* n_uniq);
+/* The sample matrix of several samples from their per-sample dictionaries, entirely on the device (round 6; what the CLI's route for
+ * several files calls): parts[s] = the collapse result of sample s alone (one count column); -> the unique reads of the union with an
+ * n_parts-column count matrix, as mirge_collapse with sample ids over the samples' raw reads would give -- the outer join of
+ * mirge/libs/digest.py:243 -- without putting the raw reads of all samples through one table.  The parts stay valid. */
+int mirge_collapse_merge(mirge_ctx* ctx, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** uniq, int64_t* n_uniq);
 /* counts_out[U * n_samples] (row-major), first_index_out[U] (index of the first raw read, may be NULL) */
 int mirge_collapse_fetch(mirge_ctx* ctx, const mirge_reads* uniq, uint32_t* counts_out,
                          int64_t* first_index_out);

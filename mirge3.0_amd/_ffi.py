@@ -23,7 +23,7 @@ EXPORTS = [
     "mirge_last_error", "mirge_device_count", "mirge_gz_inflate", "mirge_gz_inflate_progress", "mirge_ctx_create", "mirge_ctx_destroy", "mirge_ctx_sync",
     "mirge_lib_create", "mirge_lib_create_packed", "mirge_lib_packed_sizes", "mirge_lib_packed_copy", "mirge_lib_destroy", "mirge_lib_n_refs", "mirge_lib_device_bytes", "mirge_lib_prepare",
     "mirge_reads_pack", "mirge_reads_parse", "mirge_reads_parse_trim", "mirge_reads_parse_umi", "mirge_reads_concat", "mirge_reads_destroy", "mirge_reads_count", "mirge_reads_total_bases",
-    "mirge_reads_n_samples", "mirge_reads_group_counts", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
+    "mirge_reads_n_samples", "mirge_reads_group_counts", "mirge_reads_iupac_seen", "mirge_reads_unpack", "mirge_collapse", "mirge_collapse_weighted", "mirge_collapse_merge", "mirge_collapse_fetch", "mirge_collapse_order", "mirge_collapse_order_sorted", "mirge_collapse_nonzero",
     "mirge_reads_set_counts", "mirge_cascade_run", "mirge_collapse_cascade", "mirge_result_fetch", "mirge_result_destroy",
     "mirge_count_join", "mirge_count_join_host", "mirge_annotation_csv", "mirge_annotation_csv_device", "mirge_variant_tally", "mirge_isomir_type", "mirge_gff_write", "mirge_gff_write_device", "mirge_ctx_timer_start", "mirge_ctx_timer_stop", "mirge_ctx_profile_enable",
     "mirge_reads_range_sample", "mirge_reads_range_split", "mirge_annotation_csv_device_sizes", "mirge_annotation_csv_device_at",
@@ -457,6 +457,15 @@ class DeviceReads:
     def iupac_seen(self) -> bool:
         """some read held an IUPAC ambiguity code other than N (packed and printed as N)"""
         return load().mirge_reads_iupac_seen(self._h) == 1
+
+    @staticmethod
+    def merge(ctx: "Context", parts: Sequence["DeviceReads"]) -> "DeviceReads":
+        """The sample matrix of several samples from their per-sample dictionaries (``mirge_collapse_merge``): unique reads of the
+        union, one count column per part, all on the device."""
+        arr = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        h, nu = C.c_void_p(), C.c_int64()
+        _check(load().mirge_collapse_merge(ctx._h, arr, C.c_int32(len(parts)), C.byref(h), C.byref(nu)), "mirge_collapse_merge")
+        return DeviceReads(ctx, h)
 
     def unpack(self) -> FlatSeqs:
         n = len(self)

@@ -706,3 +706,13 @@ __global__ void k_collapse_scatter(GroupView<W> g, const uint32_t* __restrict__ 
         }
     }
 }
+
+// mirge_collapse_merge (round 6): entry j of a per-sample dictionary's group becomes "read" number at + j of the joint set with its
+// sample's index and its count as the weight (what mirge_collapse_weighted takes from the host, built where the dictionaries lie)
+__global__ void k_merge_fill(const uint32_t* __restrict__ counts, uint32_t n, uint32_t at, int32_t sample, int32_t* __restrict__ dsample,
+                             uint32_t* __restrict__ dweight) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        dsample[at + j] = sample;
+        dweight[at + j] = counts[j];
+    }
+}

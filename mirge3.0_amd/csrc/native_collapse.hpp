@@ -392,7 +392,8 @@ struct CollapseHook {
 };
 
 static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S, mirge_reads** uniq,
-                         int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights = nullptr);
+                         int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights = nullptr, int32_t* dsample_in = nullptr,
+                         uint32_t* dweight_in = nullptr);
 
 extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
                               mirge_reads** uniq, int64_t* n_uniq) {
@@ -405,20 +406,22 @@ extern "C" int mirge_collapse_weighted(mirge_ctx* c, const mirge_reads* raw, con
     return collapse_impl(c, raw, sample_ids, S, uniq, n_uniq, nullptr, weights);
 }
 
+// dsample_in / dweight_in (device, [raw->n], pool blocks this call releases): sample ids and weights that are on the device already
+// (mirge_collapse_merge) instead of the host arrays
 static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S, mirge_reads** uniq,
-                         int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights) {
+                         int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights, int32_t* dsample_in, uint32_t* dweight_in) {
     HostClock hc("collapse");
-    if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids)) return fail(-1, "mirge_collapse: bad argument");
+    if (!c || !raw || !uniq || S < 1 || (S > 1 && !sample_ids && !dsample_in)) return fail(-1, "mirge_collapse: bad argument");
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
-    int32_t* dsample = nullptr;
-    if (sample_ids && raw->n) {
+    int32_t* dsample = dsample_in;
+    if (!dsample_in && sample_ids && raw->n) {
         for (int64_t i = 0; i < raw->n; i++)
             if (sample_ids[i] < 0 || sample_ids[i] >= S) return fail(-1, "sample id out of range");
         CHECK(dalloc(c, &dsample, (size_t)raw->n));
         HIPOK(hipMemcpyAsync(dsample, sample_ids, (size_t)raw->n * 4, hipMemcpyHostToDevice, c->stream));
     }
-    uint32_t* dweight = nullptr;
-    if (weights && raw->n) {
+    uint32_t* dweight = dweight_in;
+    if (!dweight_in && weights && raw->n) {
         CHECK(dalloc(c, &dweight, (size_t)raw->n));
         HIPOK(hipMemcpyAsync(dweight, weights, (size_t)raw->n * 4, hipMemcpyHostToDevice, c->stream));
     }
@@ -605,6 +608,42 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
     if (n_uniq) *n_uniq = base;
     hc.lap("phase B + release");
     return 0;
+}
+
+// The sample matrix of SEVERAL samples from their per-sample dictionaries, all on the device (round 6).  The reference joins the samples'
+// dictionaries on their sequences (the outer join of digest.py:243); mirge_collapse with sample ids does the same from the RAW reads
+// of all samples through the general (global-atomic) path -- 40 M raw reads of four samples: 18-37 ms, the hot sequences of real
+// samples contending for their table cells -- while each sample alone takes the partitioned path in 0.3 ms.  So a run of several
+// samples collapses every sample by itself and merges the dictionaries here: their entries appended (mirge_reads_concat), sample
+// index and count of every entry as sample id and weight (k_merge_fill), one weighted collapse over S x U entries in which no
+// sequence occurs more than S times.  parts[s] = the collapse result of sample s (one count column each); the parts stay valid.
+extern "C" int mirge_collapse_merge(mirge_ctx* c, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** uniq, int64_t* n_uniq) {
+    if (!c || !parts || n_parts < 1 || !uniq) return fail(-1, "mirge_collapse_merge: bad argument");
+    HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
+    for (int p = 0; p < n_parts; p++) {
+        if (!parts[p] || parts[p]->ctx != c || parts[p]->n_samples != 1) return fail(-1, "mirge_collapse_merge: every part must be a one-sample collapse result of this context");
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+            if (parts[p]->g[gi].n && (parts[p]->g[gi].orig || !parts[p]->g[gi].counts)) return fail(-1, "mirge_collapse_merge: a part is not a collapse result");
+    }
+    mirge_reads* all = nullptr;
+    CHECK(reads_concat_impl(c, parts, n_parts, &all, true));
+    int32_t* dsample = nullptr;
+    uint32_t* dweight = nullptr;
+    int rc = dalloc(c, &dsample, (size_t)std::max<int64_t>(all->n, 1));
+    if (rc == 0) rc = dalloc(c, &dweight, (size_t)std::max<int64_t>(all->n, 1));
+    if (rc) { c->release(dsample); mirge_reads_destroy(all); return rc; }
+    uint32_t before = 0;
+    for (int p = 0; p < n_parts; p++) {
+        for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
+            const ReadGroup& g = parts[p]->g[gi];
+            if (g.n) hipLaunchKernelGGL(k_merge_fill, dim3(grid_for(c, g.n)), dim3(MIRGE_BLOCK), 0, c->stream, (const uint32_t*)g.counts, g.n,
+                                        before + g.base, (int32_t)p, dsample, dweight);
+        }
+        before += (uint32_t)parts[p]->n;
+    }
+    rc = collapse_impl(c, all, nullptr, n_parts, uniq, n_uniq, nullptr, nullptr, dsample, dweight);  // (releases dsample / dweight)
+    mirge_reads_destroy(all);
+    return rc;
 }
 
 extern "C" int mirge_collapse_fetch(mirge_ctx* c, const mirge_reads* U, uint32_t* counts_out, int64_t* first_out) {

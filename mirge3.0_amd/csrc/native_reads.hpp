@@ -78,13 +78,18 @@ extern "C" void mirge_reads_destroy(mirge_reads* r) {
 }
 // Several raw read sets (the samples of a run, each parsed from its own file) as one, in the order given: read j of
 // part p gets handle index (reads of the parts before p) + j.  No count matrices; the parts stay valid.
+static int reads_concat_impl(mirge_ctx* c, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out, bool collapsed_ok);
 extern "C" int mirge_reads_concat(mirge_ctx* c, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out) {
+    return reads_concat_impl(c, parts, n_parts, out, false);
+}
+// collapsed_ok: the parts may be collapse results (mirge_collapse_merge: their entries appended as reads; the counts stay behind)
+static int reads_concat_impl(mirge_ctx* c, const mirge_reads* const* parts, int32_t n_parts, mirge_reads** out, bool collapsed_ok) {
     if (!c || !parts || n_parts < 1 || !out) return fail(-1, "mirge_reads_concat: bad argument");
     HIPOK(hipSetDevice(c->device)); CHECK(join_pending_now(c));
     int64_t total = 0;
     for (int p = 0; p < n_parts; p++) {
         if (!parts[p] || parts[p]->ctx != c) return fail(-1, "mirge_reads_concat: foreign or NULL read set");
-        if (parts[p]->n_samples) return fail(-1, "mirge_reads_concat: collapsed read sets cannot be appended");
+        if (parts[p]->n_samples && !collapsed_ok) return fail(-1, "mirge_reads_concat: collapsed read sets cannot be appended");
         total += parts[p]->n;
     }
     if (total >= 0xFFFFFFF0ll) return fail(-5, "more than 2^32 reads in one set is not supported");

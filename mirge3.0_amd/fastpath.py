@@ -196,11 +196,9 @@ def run(args, files: List[str], base_names: List[str], workDir, ref_db: str, tim
     t = time.perf_counter()
     if S == 1:
         uniq, res = casc.collapse_and_run(parsed[0])
-    else:
-        allr = _ffi.DeviceReads.concat(ctx, parsed)
-        sid = np.repeat(np.arange(S, dtype=np.int32), [len(p) for p in parsed])
-        uniq = allr.collapse(sid, S)
-        allr.close()
+    else:  # (round 6: every sample collapsed by itself, the dictionaries merged on the device -- collapse.collapse_parsed_samples)
+        from .collapse import collapse_parsed_samples
+        uniq = collapse_parsed_samples(ctx, parsed)
         res = casc.run(uniq)
     for p in parsed:
         p.close()

@@ -1766,6 +1766,35 @@ def test_cli_ranges_tail_equals_rank0_tail_and_one_process(tmp_path, ci_libs):
     assert (tmp_path / "one" / "mapped.csv").stat().st_size > 10_000_000
 
 
+def test_collapse_merge_equals_the_joint_collapse_of_the_raw_reads(ctx, ci_libs):
+    """mirge_collapse_merge (round 6: what a run of several samples in one process calls): per-sample dictionaries merged on the device ==
+    mirge_collapse with sample ids over the samples' concatenated raw reads (the route until round 5) == Python's Counters: the same
+    unique reads, the same count matrix.  Samples of different kinds and sizes, one of them empty, reads with N and of 32-50 nt; and the
+    CLI's files by either route (MIRGE_JOINT_COLLAPSE=raw) are the golden case's."""
+    samples = [synth.make_reads(ci_libs, 150000, seed=41, pool=4000, n_frac=0.02), synth.make_reads_chunked(ci_libs, 90000, seed=42),
+               FlatSeqs.from_list([]), synth.make_reads(ci_libs, 70000, seed=43, n_frac=0.05, long_frac=0.3)]
+    raws = [_ffi.DeviceReads.pack(ctx, smp) for smp in samples]
+    dicts = [r.collapse() for r in raws]
+    merged = _ffi.DeviceReads.merge(ctx, dicts)
+    allr = _ffi.DeviceReads.concat(ctx, raws)
+    sid = np.repeat(np.arange(len(raws), dtype=np.int32), [len(r) for r in raws])
+    joint = allr.collapse(sid, len(raws))
+    assert len(merged) == len(joint) and merged.n_samples == joint.n_samples == 4
+
+    def table(u):
+        cnt, _ = u.counts()
+        return dict(zip(u.unpack().to_list(), map(tuple, cnt.tolist())))
+    tm, tj = table(merged), table(joint)
+    assert tm == tj
+    exp = [Counter(smp.to_list()) for smp in samples]
+    assert set(tm) == set().union(*[set(c) for c in exp])
+    for q, row in list(tm.items())[:3000]:
+        assert list(row) == [c.get(q, 0) for c in exp]
+    assert np.array_equal(merged.nonzero_per_sample(), [len(c) for c in exp])
+    for h in dicts + raws + [merged, joint, allr]:
+        h.close()
+
+
 def test_weighted_collapse_merges_dictionaries(ctx, ci_libs):
     """mirge_collapse_weighted: three samples' dictionaries (unique reads + counts) merged == the joint collapse of their
     raw reads (counts matrix; first index = first entry of the concatenated dictionaries)."""

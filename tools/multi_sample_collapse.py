@@ -50,18 +50,37 @@ def main():
             nu = len(u)
             res.close(); u.close(); allr.close()
             return t2 - t1, nu
-        for f in (per_sample, joint):
+        def merged():
+            t1 = time.perf_counter()
+            dicts = [r.collapse() for r in raws]
+            u = _ffi.DeviceReads.merge(ctx, dicts)
+            ctx.sync()
+            t2 = time.perf_counter()
+            for d in dicts:
+                d.close()
+            res = casc.run(u)
+            _ffi.count_join(ctx, u, res, EXACT_PASS, ISO_PASS, n_mirna)
+            nu = len(u)
+            res.close(); u.close()
+            return t2 - t1, nu
+        for f in (per_sample, joint, merged):
             f(); f()
         t = time.perf_counter(); k = 0
         while k < 5 or time.perf_counter() - t < 0.5:
             per_sample(); k += 1
         a = (time.perf_counter() - t) / k
-        t = time.perf_counter(); k = 0; tc = 0.0
+        t = time.perf_counter(); kj = 0; tc = 0.0
+        while kj < 5 or time.perf_counter() - t < 0.5:
+            cj, nu = joint(); tc += cj; kj += 1
+        b = (time.perf_counter() - t) / kj
+        t = time.perf_counter(); k = 0; tm = 0.0
         while k < 5 or time.perf_counter() - t < 0.5:
-            c, nu = joint(); tc += c; k += 1
-        b = (time.perf_counter() - t) / k
+            cm, num = merged(); tm += cm; k += 1
+        m = (time.perf_counter() - t) / k
+        assert num == nu, (num, nu)
+        print(f"{label:8s} merged dictionaries (mirge_collapse_merge): run {m * 1e3:.3f} ms ({m * 1e3 / S:.3f} per sample; per-sample collapses + merge {tm / k * 1e3:.3f} ms)", flush=True)
         print(f"{label:8s} {S} samples x {args.reads / 1e6:g} M reads: per-sample steps {a * 1e3:.3f} ms ({a * 1e3 / S:.3f} per sample); joint run {b * 1e3:.3f} ms "
-              f"({b * 1e3 / S:.3f} per sample; its collapse {tc / k * 1e3:.3f} ms, {nu / 1e6:.2f} M unique reads of the union)", flush=True)
+              f"({b * 1e3 / S:.3f} per sample; its collapse {tc / kj * 1e3:.3f} ms, {nu / 1e6:.2f} M unique reads of the union)", flush=True)
         for r in raws:
             r.close()
 
