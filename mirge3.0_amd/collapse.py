@@ -741,18 +741,16 @@ def collapse_samples(ctx: _ffi.Context, samples: Sequence[FlatSeqs]):
     matrix); the route for callers that hold sequences, not files (``baking`` parses the files' text on the GPU)."""
     S = len(samples)
     if S == 1:
-        allr, sid = samples[0], None
-    else:
-        data = np.concatenate([s.data for s in samples])
-        lens = np.concatenate([s.lengths for s in samples])
-        off = np.zeros(lens.shape[0] + 1, dtype=np.int64)
-        np.cumsum(lens, out=off[1:])
-        allr = FlatSeqs(data, off)
-        sid = np.repeat(np.arange(S, dtype=np.int32), [len(s) for s in samples])
-    raw = _ffi.DeviceReads.pack(ctx, allr)
-    uniq = raw.collapse(sid, S)
-    raw.close()
-    return uniq
+        raw = _ffi.DeviceReads.pack(ctx, samples[0])
+        uniq = raw.collapse()
+        raw.close()
+        return uniq
+    packed = [_ffi.DeviceReads.pack(ctx, s) for s in samples]  # (round 6: per-sample collapses, merged on the device)
+    try:
+        return collapse_parsed_samples(ctx, packed)
+    finally:
+        for r in packed:
+            r.close()
 
 
 def umi_from_args(args):
