@@ -1726,6 +1726,37 @@ def test_cli_ranks_write_their_ranges_of_the_per_read_tables(tmp_path):
         assert '"tail": "ranges' in log and not (out / ".mirge_shards").exists()
 
 
+def test_cli_ranges_tail_with_an_empty_range_and_an_idle_rank(tmp_path):
+    """The parallel tail's corners: two samples that hold ONE sequence between them on three ranks -- one rank has no sample, the
+    splitters coincide, two of the three key ranges are empty -- and a run whose samples share nothing.  The files are the
+    one-process run's."""
+    import subprocess
+    import sys
+    case = GoldenCase("case2_two_samples")
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    launcher = tmp_path / "run_cli.py"
+    launcher.write_text("import sys; sys.path.insert(0, %r); import mirge3_amd; from mirge3_amd.cli import main; main()\n" % root)
+    one = case.seqs[0]
+    sets = {"same": ([one] * 40, [one] * 25), "disjoint": (case.seqs[:30], case.seqs[30:70])}
+    for tag, (a, b) in sets.items():
+        d = tmp_path / tag
+        d.mkdir()
+        files = []
+        for nm, seqs in (("S1", a), ("S2", b)):
+            p = d / f"{nm}.fastq"
+            p.write_text("".join(f"@r\n{q}\n+\n{'I' * len(q)}\n" for q in seqs))
+            files.append(str(p))
+        common = ["-s", ",".join(files), "-lib", case.libdir, "-on", ORG, "-db", "miRBase", "-o", str(d), "-shh"]
+        _run_cli(common + ["-dn", "one"])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+               "--master-port", "29569" if tag == "same" else "29573", str(launcher)] + common + ["-dn", "ranks"]
+        r = subprocess.run(cmd, env=dict(os.environ, MIRGE_SHARE_GPU="1", OMP_NUM_THREADS="2"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        for f in ("annotation.report.csv", "miR.Counts.csv", "miR.RPM.csv", "mapped.csv", "unmapped.csv"):
+            assert (d / "one" / f).read_bytes() == (d / "ranks" / f).read_bytes(), (tag, f)
+        assert '"tail": "ranges' in (d / "ranks" / "run.log").read_text()
+
+
 def test_cli_ranges_tail_equals_rank0_tail_and_one_process(tmp_path, ci_libs):
     """Three routes to the same files on three 0.7 M-read samples over three ranks that share the GPU: one process; the sharded run
     with rank 0 building the joint table alone (MIRGE_SHARD_TAIL=rank0, round 5); the sharded run with every rank writing its range
