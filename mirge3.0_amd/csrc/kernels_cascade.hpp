@@ -1082,6 +1082,72 @@ k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_cascade_spec + k_cascade_pick (round 6): the cascade of a TINY read group (a few hundred to a few thousand reads: the groups with an
+// ambiguous call) with all of its passes AT ONCE.  In k_cascade_fused a wave takes its 64 reads through the passes one after the other:
+// nine dependent chains of lookups, 35-65 us for a group of 40-700 reads whatever the chip is doing -- and on a sample with few unique
+// reads those chains are what the step waits for once the bulk kernel has retired (profiles/r06_timeline_zipf.txt).  A pass's answer for
+// a read depends on the read alone (its own subset rule and alignment); the cascade only says which answer COUNTS: the first pass, in
+// order, that has one.  So block (x = round of 256 reads, y = step) computes step y's answer for every read of its round as if the read
+// were still open -- nine times the work of a group that is a thousandth of the sample -- and k_cascade_pick takes, per read, the first
+// step with an answer (or hands the read to k_cascade_heavy when a step that comes before any answer deferred it).  Same device
+// functions, same answers.
+// ------------------------------------------------------------------------------------------
+template <int W, bool HASN, bool REP>
+__global__ void __launch_bounds__(MIRGE_BLOCK)
+k_cascade_spec(const FusedSteps* __restrict__ steps, GroupView<W> g, unsigned long long* __restrict__ answers /*[nsteps][n]*/) {
+    const int si = blockIdx.y;
+    const FusedStep& st = steps->s[si];
+    const uint32_t idx = blockIdx.x * MIRGE_BLOCK + threadIdx.x;
+    const bool valid = idx < g.n;
+    MirgeRead<W> r2;
+    if (valid) load_read<W, HASN>(g, idx, r2);
+    else {
+#pragma unroll
+        for (int w = 0; w < W; w++) { r2.w[w] = 0; r2.nm[w] = 0; }
+        r2.len = 0;
+    }
+    const bool elig = valid && mirge_effective_read<W>(r2, st.pol);
+    uint64_t best;
+    PlanSrc<false> psrc;
+    psrc.g = st.plan; psrc.l = nullptr;
+    align_hybrid<W, false, REP>(st.lib, st.pol, st.mi, psrc, r2, elig, best);
+    if (valid) answers[(size_t)si * g.n + idx] = elig ? best : MIRGE_NO_HIT;
+}
+
+template <int W>
+__global__ void k_cascade_pick(const FusedSteps* __restrict__ steps, ResolveTable tb, uint32_t n, const unsigned long long* __restrict__ answers,
+                               int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref,
+                               int32_t* __restrict__ res_off, uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
+    const int nsteps = steps->n;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        int8_t o_pass = -1, o_mm = -1;
+        uint32_t o_pos = 0;
+        for (int si = 0; si < nsteps; si++) {
+            const uint64_t best = answers[(size_t)si * n + idx];
+            if (best == MIRGE_NO_HIT) continue;
+            const FusedStep& st = steps->s[si];
+            if (best == MIRGE_DEFER) {  // (see defer_read: the mark names the pass)
+                o_pass = (int8_t)(-2 - st.pass_id);
+                heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
+                break;
+            }
+            const int cls = (int)(best >> 40);
+            o_pass = (int8_t)(st.pass_id + cls);
+            uint32_t b0 = 0;
+#pragma unroll
+            for (int i = 1; i < 4; i++) if (i == cls) b0 = st.mi.bound[i];
+            o_pos = (uint32_t)best - b0;
+            o_mm = (int8_t)((best >> 32) & 0xFF);
+            break;
+        }
+        int32_t ref = -1, off = -1;
+        if (o_pass >= 0) resolve_one(tb, o_pass, o_pos, ref, off);
+        res_pass[idx] = o_pass; res_pos[idx] = o_pos; res_mm[idx] = o_mm;
+        res_ref[idx] = ref; res_off[idx] = off;
+    }
+}
+
 // (the reads align_hybrid deferred: see align_wg above)
 template <int W, bool HASN>
 __global__ void __launch_bounds__(MIRGE_HEAVY_THREADS)

@@ -272,6 +272,29 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     uint32_t* hlist = nullptr;
     if (hcnt) CHECK(dalloc(c, &hlist, (size_t)n));
     char name[32];
+    // (round 6) a tiny group: all passes at once (k_cascade_spec), then the first answer per read (k_cascade_pick).  MIRGE_SPEC_MAX: the
+    // largest group (reads) that takes this route, 0 = never (tests, A/B)
+    static const uint32_t spec_max = std::getenv("MIRGE_SPEC_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_SPEC_MAX"), nullptr, 10) : 4096u;
+    const int nsteps = (int)c->casc_steps.size();
+    if (n <= spec_max && nsteps > 1) {
+        unsigned long long* answers = nullptr;
+        CHECK(dalloc(c, &answers, (size_t)nsteps * n));
+        const dim3 grid((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (unsigned)nsteps);
+        {
+            std::snprintf(name, sizeof(name), "k_cascade_spec%s", gtag);
+            LaunchScope ls(c, name, n);
+#define MIRGE_LAUNCH_SPEC(HASN_, REP_) \
+    hipLaunchKernelGGL((k_cascade_spec<W, HASN_, REP_>), grid, dim3(MIRGE_BLOCK), 0, c->cur, dsteps, view_of<W>(rg), answers)
+            if (rg.nmask) { if (c->casc_rep) MIRGE_LAUNCH_SPEC(true, true); else MIRGE_LAUNCH_SPEC(true, false); }
+            else { if (c->casc_rep) MIRGE_LAUNCH_SPEC(false, true); else MIRGE_LAUNCH_SPEC(false, false); }
+#undef MIRGE_LAUNCH_SPEC
+            hipLaunchKernelGGL(k_cascade_pick<W>, dim3((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, n,
+                               (const unsigned long long*)answers, out.pass, out.pos, out.mm, out.ref, out.off, hcnt, hlist);
+        }
+        if (hcnt) launch_heavy<W>(c, rg, out, dsteps, rt, gtag, hcnt, hlist, view_of<W>(rg), true);
+        c->defer(hlist); c->defer(answers);
+        return 0;
+    }
     std::snprintf(name, sizeof(name), "k_cascade_fused%s", gtag);
     {
         LaunchScope ls(c, name, n);

@@ -1390,14 +1390,18 @@ def test_long_reads_under_a_length_rule_beyond_255(ctx, ci_libs):
     res.close(); dr.close(); lib.close()
 
 
-@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0"), dict(MIRGE_EXACT_WALKS="0")])
+@pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0"), dict(MIRGE_EXACT_WALKS="0"),
+                                   dict(MIRGE_SPEC_MAX="0"), dict(MIRGE_SPEC_MAX="100000000", MIRGE_CASCADE_REP="1")])
 def test_staged_cascade_for_every_group(hooks):
     """Small read groups normally take k_cascade_fused (one launch for the whole cascade, no compaction); MIRGE_FUSED_MAX=0
     sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch), or
     with MIRGE_BULK_FUSED=0 one k_pass launch per pass.  All must agree with the oracle: the oracle parity tests of this
     file, the one-call route (full cascade and the one-pass C2 cascade) and the cascade fuzz are re-run in a fresh process with
     the hooks set.  With MIRGE_FUSED_MAX=0 the small groups of one-word reads WITH ambiguous calls also walk with the exact
-    steps of round 5 (the build with N masks); MIRGE_EXACT_WALKS=0 is round 4's one walk per pass, no whole-read tables."""
+    steps of round 5 (the build with N masks); MIRGE_EXACT_WALKS=0 is round 4's one walk per pass, no whole-read tables.
+    Round 6: tiny groups take k_cascade_spec + k_cascade_pick (all passes at once, the first answer per read) -- MIRGE_SPEC_MAX=0
+    sends them through k_cascade_fused as before, a huge MIRGE_SPEC_MAX every small group through the speculative form, here
+    together with the repeat-aware build of the kernels (MIRGE_CASCADE_REP=1) that uniform libraries do not launch by themselves."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
