@@ -274,7 +274,7 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     char name[32];
     // (round 6) a tiny group: all passes at once (k_cascade_spec), then the first answer per read (k_cascade_pick).  MIRGE_SPEC_MAX: the
     // largest group (reads) that takes this route, 0 = never (tests, A/B)
-    static const uint32_t spec_max = std::getenv("MIRGE_SPEC_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_SPEC_MAX"), nullptr, 10) : 4096u;
+    static const uint32_t spec_max = std::getenv("MIRGE_SPEC_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_SPEC_MAX"), nullptr, 10) : 32768u;
     const int nsteps = (int)c->casc_steps.size();
     if (n <= spec_max && nsteps > 1) {
         unsigned long long* answers = nullptr;
