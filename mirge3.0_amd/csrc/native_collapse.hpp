@@ -395,6 +395,26 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
                          int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights = nullptr, int32_t* dsample_in = nullptr,
                          uint32_t* dweight_in = nullptr);
 
+// Which extra stream the one-launch cascade of every small read group takes (cascade_launch_groups assigns them this way): the groups
+// other than `big` by size, largest first; one slot each for those that take the one-launch route, when there is more than one; -1:
+// the second stream.  n[gi] = reads of group gi.
+static void small_group_slots(const uint32_t* n, int big, int* slot) {
+    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
+    static const bool xaux_on = !(std::getenv("MIRGE_XAUX") && std::atoi(std::getenv("MIRGE_XAUX")) == 0);
+    int order[MIRGE_NGROUPS], no = 0;
+    for (int gi = 0; gi < MIRGE_NGROUPS; gi++) { slot[gi] = -1; if (gi != big) order[no++] = gi; }
+    std::stable_sort(order, order + no, [&](int a, int b) { return n[a] > n[b]; });
+    int n_small = 0;
+    for (int k = 0; k < no; k++) if (n[order[k]] && n[order[k]] <= fused_max) n_small++;
+    if (!xaux_on || n_small <= 1) return;
+    int next = 0;
+    for (int k = 0; k < no; k++) {
+        const int gi = order[k];
+        if (is_long_group(gi) || !n[gi] || n[gi] > fused_max) continue;
+        slot[gi] = next++ % MIRGE_N_XAUX;
+    }
+}
+
 extern "C" int mirge_collapse(mirge_ctx* c, const mirge_reads* raw, const int32_t* sample_ids, int32_t S,
                               mirge_reads** uniq, int64_t* n_uniq) {
     return collapse_impl(c, raw, sample_ids, S, uniq, n_uniq, nullptr);
@@ -522,9 +542,21 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
             }
             if (e == hipSuccess && hooked) e = hipEventSynchronize(c->ev_meta_small);
             if (e == hipSuccess && hooked) {
+                // (round 6) a small group's scatter kernel goes on the extra stream its one-launch cascade will take (small_ready ->
+                // cascade_launch_groups): the three scatters ran one after the other on the second stream (74 us on a sample with few
+                // unique reads) and every cascade then started a cross-stream hop (~22 us) behind the LAST of them -- now each group's
+                // scatter and cascade are neighbours on one stream and the groups run side by side.  MIRGE_SCATTER_ON_XAUX=0: as before.
+                static const bool scatter_x = !(std::getenv("MIRGE_SCATTER_ON_XAUX") && std::atoi(std::getenv("MIRGE_SCATTER_ON_XAUX")) == 0);
+                int xslot[MIRGE_NGROUPS];
+                uint32_t n_small_u[MIRGE_NGROUPS];
+                for (int gi = 0; gi < MIRGE_NGROUPS; gi++) n_small_u[gi] = gi == big ? 0u : small[gi];
+                small_group_slots(n_small_u, big, xslot);
+                bool any_x = false;
+                for (int gi = 0; gi < MIRGE_NGROUPS; gi++) any_x |= scatter_x && xslot[gi] >= 0;
+                if (any_x) rc = xaux_fork(c);
                 for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
                     if (gi == big) continue;
-                    c->cur = c->aux;
+                    c->cur = (scatter_x && xslot[gi] >= 0) ? c->xaux[xslot[gi]] : c->aux;
                     if (is_long_group(gi)) rc = collapse_phase_b_long(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, small[gi], 0u, dmeta);
                     else MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, small[gi], 0u, dmeta));
                 }
