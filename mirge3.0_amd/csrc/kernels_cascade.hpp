@@ -1093,9 +1093,48 @@ k_cascade_fused(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView
 // step with an answer (or hands the read to k_cascade_heavy when a step that comes before any answer deferred it).  Same device
 // functions, same answers.
 // ------------------------------------------------------------------------------------------
+// one read's place in the cascade from its per-step answers (answers[si * stride + idx]): the first step with one
+__device__ __forceinline__ void spec_pick_one(const FusedSteps* __restrict__ steps, const ResolveTable& tb, size_t stride, uint32_t idx,
+                                              const unsigned long long* __restrict__ answers, int8_t* __restrict__ res_pass,
+                                              uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref,
+                                              int32_t* __restrict__ res_off, uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
+    const int nsteps = steps->n;
+    int8_t o_pass = -1, o_mm = -1;
+    uint32_t o_pos = 0;
+    for (int si = 0; si < nsteps; si++) {
+        const uint64_t best = answers[(size_t)si * stride + idx];
+        if (best == MIRGE_NO_HIT) continue;
+        const FusedStep& st = steps->s[si];
+        if (best == MIRGE_DEFER) {  // (see defer_read: the mark names the pass)
+            o_pass = (int8_t)(-2 - st.pass_id);
+            heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
+            break;
+        }
+        const int cls = (int)(best >> 40);
+        o_pass = (int8_t)(st.pass_id + cls);
+        uint32_t b0 = 0;
+#pragma unroll
+        for (int i = 1; i < 4; i++) if (i == cls) b0 = st.mi.bound[i];
+        o_pos = (uint32_t)best - b0;
+        o_mm = (int8_t)((best >> 32) & 0xFF);
+        break;
+    }
+    int32_t ref = -1, off = -1;
+    if (o_pass >= 0) resolve_one(tb, o_pass, o_pos, ref, off);
+    res_pass[idx] = o_pass; res_pos[idx] = o_pos; res_mm[idx] = o_mm;
+    res_ref[idx] = ref; res_off[idx] = off;
+}
+
+// `tickets` (one counter per round of 256 reads, zero between launches) = the pick in the same launch: the workgroup that finishes a
+// round's LAST step picks for that round's reads (its ticket is the count of steps before it) and puts the counter back to zero.
+// nullptr: the answers only, k_cascade_pick follows.  `stride` = the answers' row length (a multiple of 256: no two rounds share a line).
 template <int W, bool HASN, bool REP>
 __global__ void __launch_bounds__(MIRGE_BLOCK)
-k_cascade_spec(const FusedSteps* __restrict__ steps, GroupView<W> g, unsigned long long* __restrict__ answers /*[nsteps][n]*/) {
+k_cascade_spec(const FusedSteps* __restrict__ steps, ResolveTable tb, GroupView<W> g, unsigned long long* __restrict__ answers /*[nsteps][stride]*/,
+               uint32_t stride, uint32_t* __restrict__ tickets, int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos,
+               int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref, int32_t* __restrict__ res_off, uint32_t* __restrict__ heavy_cnt,
+               uint32_t* __restrict__ heavy_list) {
+    __shared__ uint32_t s_last;
     const int si = blockIdx.y;
     const FusedStep& st = steps->s[si];
     const uint32_t idx = blockIdx.x * MIRGE_BLOCK + threadIdx.x;
@@ -1112,40 +1151,28 @@ k_cascade_spec(const FusedSteps* __restrict__ steps, GroupView<W> g, unsigned lo
     PlanSrc<false> psrc;
     psrc.g = st.plan; psrc.l = nullptr;
     align_hybrid<W, false, REP>(st.lib, st.pol, st.mi, psrc, r2, elig, best);
-    if (valid) answers[(size_t)si * g.n + idx] = elig ? best : MIRGE_NO_HIT;
+    if (valid) answers[(size_t)si * stride + idx] = elig ? best : MIRGE_NO_HIT;
+    if (!tickets) return;
+    __threadfence();  // this workgroup's answers are out (agent scope) before its ticket is drawn
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.y - 1 ? 1u : 0u;
+        if (s_last) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();  // ... and the other steps' answers are read behind theirs
+    if (valid) spec_pick_one(steps, tb, stride, idx, answers, res_pass, res_pos, res_mm, res_ref, res_off, heavy_cnt, heavy_list);
 }
 
 template <int W>
-__global__ void k_cascade_pick(const FusedSteps* __restrict__ steps, ResolveTable tb, uint32_t n, const unsigned long long* __restrict__ answers,
+__global__ void k_cascade_pick(const FusedSteps* __restrict__ steps, ResolveTable tb, uint32_t n, uint32_t stride,
+                               const unsigned long long* __restrict__ answers,
                                int8_t* __restrict__ res_pass, uint32_t* __restrict__ res_pos, int8_t* __restrict__ res_mm, int32_t* __restrict__ res_ref,
                                int32_t* __restrict__ res_off, uint32_t* __restrict__ heavy_cnt, uint32_t* __restrict__ heavy_list) {
-    const int nsteps = steps->n;
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-        int8_t o_pass = -1, o_mm = -1;
-        uint32_t o_pos = 0;
-        for (int si = 0; si < nsteps; si++) {
-            const uint64_t best = answers[(size_t)si * n + idx];
-            if (best == MIRGE_NO_HIT) continue;
-            const FusedStep& st = steps->s[si];
-            if (best == MIRGE_DEFER) {  // (see defer_read: the mark names the pass)
-                o_pass = (int8_t)(-2 - st.pass_id);
-                heavy_list[atomicAdd(&heavy_cnt[0], 1u)] = idx;
-                break;
-            }
-            const int cls = (int)(best >> 40);
-            o_pass = (int8_t)(st.pass_id + cls);
-            uint32_t b0 = 0;
-#pragma unroll
-            for (int i = 1; i < 4; i++) if (i == cls) b0 = st.mi.bound[i];
-            o_pos = (uint32_t)best - b0;
-            o_mm = (int8_t)((best >> 32) & 0xFF);
-            break;
-        }
-        int32_t ref = -1, off = -1;
-        if (o_pass >= 0) resolve_one(tb, o_pass, o_pos, ref, off);
-        res_pass[idx] = o_pass; res_pos[idx] = o_pos; res_mm[idx] = o_mm;
-        res_ref[idx] = ref; res_off[idx] = off;
-    }
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x)
+        spec_pick_one(steps, tb, stride, idx, answers, res_pass, res_pos, res_mm, res_ref, res_off, heavy_cnt, heavy_list);
 }
 
 // (the reads align_hybrid deferred: see align_wg above)

@@ -278,18 +278,31 @@ static int cascade_group_fused(mirge_ctx* c, const ReadGroup& rg, ResGroup& out,
     const int nsteps = (int)c->casc_steps.size();
     if (n <= spec_max && nsteps > 1) {
         unsigned long long* answers = nullptr;
-        CHECK(dalloc(c, &answers, (size_t)nsteps * n));
-        const dim3 grid((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, (unsigned)nsteps);
+        const uint32_t rounds = (n + MIRGE_BLOCK - 1) / MIRGE_BLOCK, stride = rounds * MIRGE_BLOCK;
+        CHECK(dalloc(c, &answers, (size_t)nsteps * stride));
+        const dim3 grid(rounds, (unsigned)nsteps);
+        // MIRGE_SPEC_TICKETS=1 (round 6 experiment, OFF by default): the pick in the same launch (the workgroup that ends a round's last
+        // step does it: `tickets`, k_cascade_spec) -- one kernel less in a chain of launches the step's end waits for on a sample with few
+        // unique reads.  Measured WORSE (profiles/r06_ab_spec_tickets.txt): 0.539 vs 0.408 ms on that sample, 1.259 vs 1.190 ms on the
+        // default draw -- the two agent-scope fences per workgroup write back and invalidate the XCD's L2 under the bulk kernel that runs
+        // beside it (its own launch time: 0.84 vs 0.78 ms); a kernel boundary is the cheaper fence here.
+        static const bool tickets_on = std::getenv("MIRGE_SPEC_TICKETS") && std::atoi(std::getenv("MIRGE_SPEC_TICKETS")) == 1;
+        uint32_t* tickets = nullptr;
+        if (tickets_on && c->spec_tickets && rounds <= MIRGE_SPEC_TICKET_ROUNDS)
+            for (int gi = 0; gi < MIRGE_NGROUPS; gi++)
+                if (std::strcmp(group_tag(gi), gtag) == 0) tickets = c->spec_tickets + (size_t)gi * MIRGE_SPEC_TICKET_ROUNDS;
         {
             std::snprintf(name, sizeof(name), "k_cascade_spec%s", gtag);
             LaunchScope ls(c, name, n);
-#define MIRGE_LAUNCH_SPEC(HASN_, REP_) \
-    hipLaunchKernelGGL((k_cascade_spec<W, HASN_, REP_>), grid, dim3(MIRGE_BLOCK), 0, c->cur, dsteps, view_of<W>(rg), answers)
+#define MIRGE_LAUNCH_SPEC(HASN_, REP_)                                                                                                          \
+    hipLaunchKernelGGL((k_cascade_spec<W, HASN_, REP_>), grid, dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, view_of<W>(rg), answers, stride, tickets, \
+                       out.pass, out.pos, out.mm, out.ref, out.off, hcnt, hlist)
             if (rg.nmask) { if (c->casc_rep) MIRGE_LAUNCH_SPEC(true, true); else MIRGE_LAUNCH_SPEC(true, false); }
             else { if (c->casc_rep) MIRGE_LAUNCH_SPEC(false, true); else MIRGE_LAUNCH_SPEC(false, false); }
 #undef MIRGE_LAUNCH_SPEC
-            hipLaunchKernelGGL(k_cascade_pick<W>, dim3((n + MIRGE_BLOCK - 1) / MIRGE_BLOCK), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, n,
-                               (const unsigned long long*)answers, out.pass, out.pos, out.mm, out.ref, out.off, hcnt, hlist);
+            if (!tickets)
+                hipLaunchKernelGGL(k_cascade_pick<W>, dim3(rounds), dim3(MIRGE_BLOCK), 0, c->cur, dsteps, rt, n, stride,
+                                   (const unsigned long long*)answers, out.pass, out.pos, out.mm, out.ref, out.off, hcnt, hlist);
         }
         if (hcnt) launch_heavy<W>(c, rg, out, dsteps, rt, gtag, hcnt, hlist, view_of<W>(rg), true);
         c->defer(hlist); c->defer(answers);
@@ -412,6 +425,10 @@ static int cascade_prepare(mirge_ctx* c, const mirge_lib* const* libs, const mir
         if (big_t_env && st.lib->max_bucket > big_t_env) c->casc_big_t = big_t_env;
     }
     if (!c->casc_rep) c->casc_big_t = 0;  // (only the repeat-aware build defers)
+    if (!c->spec_tickets) {  // (k_cascade_spec's per-round counters, one row per read group; zero between launches)
+        HIPOK(hipMalloc((void**)&c->spec_tickets, (size_t)MIRGE_NGROUPS * MIRGE_SPEC_TICKET_ROUNDS * 4));
+        HIPOK(hipMemset(c->spec_tickets, 0, (size_t)MIRGE_NGROUPS * MIRGE_SPEC_TICKET_ROUNDS * 4));
+    }
     if (c->casc_big_t && !c->heavy_cnt) {
         HIPOK(hipMalloc((void**)&c->heavy_cnt, 2 * MIRGE_NGROUPS * 4));
         HIPOK(hipMemset(c->heavy_cnt, 0, 2 * MIRGE_NGROUPS * 4));
@@ -591,7 +608,7 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
             continue;
         }
         if (gi != big && R->g[gi].n <= fused_max) {
-            if (spread && R->g[gi].n) c->cur = c->xaux[slot++ % MIRGE_N_XAUX];
+            if (spread && R->g[gi].n) c->cur = c->xaux[xaux_slot_of(slot++)];
             MIRGE_BY_WIDTH(gi, rc, cascade_group_fused<W>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi)));
             continue;
         }

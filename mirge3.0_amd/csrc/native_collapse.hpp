@@ -398,6 +398,15 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
 // Which extra stream the one-launch cascade of every small read group takes (cascade_launch_groups assigns them this way): the groups
 // other than `big` by size, largest first; one slot each for those that take the one-launch route, when there is more than one; -1:
 // the second stream.  n[gi] = reads of group gi.
+// How many of the extra streams the small groups are dealt over (MIRGE_XAUX_SLOTS, default 2).  The runtime maps this context's streams
+// onto four hardware queues: a third extra stream shares a queue with the second, and two streams taking turns on one queue pay a
+// dependency packet per turn (~12 us, profiles/r06_timeline_zipf.txt).  Two: 0.382 vs 0.409 ms on the sample with few unique reads,
+// 1.197 vs 1.195 ms on the default draw (profiles/r06_ab_xaux_slots.txt; largest group alone on a stream, the others chained: the same).
+static int xaux_slots() {
+    static const int v = std::getenv("MIRGE_XAUX_SLOTS") ? std::max(1, std::min(MIRGE_N_XAUX, std::atoi(std::getenv("MIRGE_XAUX_SLOTS")))) : 2;
+    return v;
+}
+static int xaux_slot_of(int k) { return k % xaux_slots(); }  // the k-th small group by size, 0 = the largest
 static void small_group_slots(const uint32_t* n, int big, int* slot) {
     static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
     static const bool xaux_on = !(std::getenv("MIRGE_XAUX") && std::atoi(std::getenv("MIRGE_XAUX")) == 0);
@@ -411,7 +420,7 @@ static void small_group_slots(const uint32_t* n, int big, int* slot) {
     for (int k = 0; k < no; k++) {
         const int gi = order[k];
         if (is_long_group(gi) || !n[gi] || n[gi] > fused_max) continue;
-        slot[gi] = next++ % MIRGE_N_XAUX;
+        slot[gi] = xaux_slot_of(next++);
     }
 }
 

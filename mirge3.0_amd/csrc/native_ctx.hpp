@@ -48,6 +48,7 @@ struct mirge_ctx {
     // launch they only get the chip when its workgroups retire, and on ONE stream three of them then ran one after the other
     // (56 + 69 + 49 us behind the bulk kernel, with the join waiting); side by side they take what the longest takes
 #define MIRGE_N_XAUX 3
+#define MIRGE_SPEC_TICKET_ROUNDS 8192  // groups of up to 2 M reads pick inside k_cascade_spec
     hipStream_t xaux[MIRGE_N_XAUX] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_xfork = nullptr, ev_xjoin[MIRGE_N_XAUX] = {nullptr, nullptr, nullptr};
     bool xaux_used = false;
@@ -83,6 +84,7 @@ struct mirge_ctx {
     // k_cascade_heavy (kernels_cascade.hpp): per read group {reads listed, workgroups done}, zero between launches; the threshold the
     // current configuration's steps carry (0: no library holds a bucket that large -- no deferral, no extra launch)
     uint32_t* heavy_cnt = nullptr;
+    uint32_t* spec_tickets = nullptr;  // [MIRGE_NGROUPS][MIRGE_SPEC_TICKET_ROUNDS], see k_cascade_spec
     uint32_t casc_big_t = 0;
     bool casc_rep = false;  // the configuration's libraries repeat themselves: the cascade kernels' repeat-aware build (align_hybrid<.., REP>)
     uint32_t* wg_pinned = nullptr;
@@ -310,6 +312,7 @@ extern "C" void mirge_ctx_destroy(mirge_ctx* c) {
     if (c->csv_pinned) (void)hipHostFree(c->csv_pinned);
     if (c->wg_pinned) (void)hipHostFree(c->wg_pinned);
     if (c->heavy_cnt) (void)hipFree(c->heavy_cnt);
+    if (c->spec_tickets) (void)hipFree(c->spec_tickets);
     if (c->join_dev) (void)hipFree(c->join_dev);
     for (auto& e : c->plans) (void)hipFree(e.dplan);
     for (auto& e : c->fused) (void)hipFree(e.dev);
