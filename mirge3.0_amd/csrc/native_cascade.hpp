@@ -596,7 +596,7 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
     for (int k = 0; k < MIRGE_NGROUPS; k++)
         if (order[k] != skip && order[k] != big && R->g[order[k]].n && R->g[order[k]].n <= fused_max) n_small++;
     const bool spread = xaux_on && n_small > 1;
-    if (spread) CHECK(xaux_fork(c));
+    if (spread && !c->xaux_forked) CHECK(xaux_fork(c));
     // (the same assignment as small_group_slots, native_collapse.hpp: a small group's scatter kernel was put on the stream its cascade takes)
     int slot = 0;
     for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {

@@ -549,28 +549,35 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
                 rc = hook->pre_sync(R.get(), tmp, dmeta, big);
                 hooked = rc == 0;
             }
+            static const bool scatter_x = !(std::getenv("MIRGE_SCATTER_ON_XAUX") && std::atoi(std::getenv("MIRGE_SCATTER_ON_XAUX")) == 0);
             if (e == hipSuccess && hooked) e = hipEventSynchronize(c->ev_meta_small);
             if (e == hipSuccess && hooked) {
                 // (round 6) a small group's scatter kernel goes on the extra stream its one-launch cascade will take (small_ready ->
                 // cascade_launch_groups): the three scatters ran one after the other on the second stream (74 us on a sample with few
                 // unique reads) and every cascade then started a cross-stream hop (~22 us) behind the LAST of them -- now each group's
                 // scatter and cascade are neighbours on one stream and the groups run side by side.  MIRGE_SCATTER_ON_XAUX=0: as before.
-                static const bool scatter_x = !(std::getenv("MIRGE_SCATTER_ON_XAUX") && std::atoi(std::getenv("MIRGE_SCATTER_ON_XAUX")) == 0);
                 int xslot[MIRGE_NGROUPS];
                 uint32_t n_small_u[MIRGE_NGROUPS];
                 for (int gi = 0; gi < MIRGE_NGROUPS; gi++) n_small_u[gi] = gi == big ? 0u : small[gi];
                 small_group_slots(n_small_u, big, xslot);
-                bool any_x = false;
-                for (int gi = 0; gi < MIRGE_NGROUPS; gi++) any_x |= scatter_x && xslot[gi] >= 0;
-                if (any_x) rc = xaux_fork(c);
+                bool forked = false;
+                for (int gi = 0; gi < MIRGE_NGROUPS; gi++) forked |= scatter_x && xslot[gi] >= 0;
+                // The extra streams take over from `aux` here, once, for the scatter kernels AND the cascades (cascade_launch_groups skips
+                // its own fork: four runtime calls less in front of the cascades).  Queued BEFORE the host's wait instead -- the calls off
+                // the chain -- it was slower: 0.403 vs 0.378 ms on the sample with few unique reads, 1.235 vs 1.217 ms on the default draw
+                // (profiles/r06_ab_fork_early.txt): two more queues holding an unsatisfied dependency packet beside k_part_dedup /
+                // k_part_compact cost those kernels 15 % / 60 % of their time.
+                if (forked) rc = xaux_fork(c);
                 for (int gi = 0; gi < MIRGE_NGROUPS && rc == 0; gi++) {
                     if (gi == big) continue;
-                    c->cur = (scatter_x && xslot[gi] >= 0) ? c->xaux[xslot[gi]] : c->aux;
+                    c->cur = (forked && xslot[gi] >= 0) ? c->xaux[xslot[gi]] : c->aux;
                     if (is_long_group(gi)) rc = collapse_phase_b_long(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, small[gi], 0u, dmeta);
                     else MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, small[gi], 0u, dmeta));
                 }
                 c->cur = c->stream;
+                c->xaux_forked = forked;  // (cascade_launch_groups: the extra streams already stand behind `aux`)
                 if (rc == 0) { rc = hook->small_ready(R.get(), big); small_done = rc == 0; }
+                c->xaux_forked = false;
             }
             // the bulk group's count, the overflow flag and the length histogram: `aux` behind the main stream's k_part_dedup
             if (e == hipSuccess) e = hipStreamWaitEvent(c->aux, c->ev_bulk_counted, 0);

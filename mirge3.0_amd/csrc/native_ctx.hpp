@@ -84,6 +84,7 @@ struct mirge_ctx {
     // k_cascade_heavy (kernels_cascade.hpp): per read group {reads listed, workgroups done}, zero between launches; the threshold the
     // current configuration's steps carry (0: no library holds a bucket that large -- no deferral, no extra launch)
     uint32_t* heavy_cnt = nullptr;
+    bool xaux_forked = false;  // collapse_impl -> cascade_launch_groups: the extra streams were put behind `aux` for the scatter kernels
     uint32_t* spec_tickets = nullptr;  // [MIRGE_NGROUPS][MIRGE_SPEC_TICKET_ROUNDS], see k_cascade_spec
     uint32_t casc_big_t = 0;
     bool casc_rep = false;  // the configuration's libraries repeat themselves: the cascade kernels' repeat-aware build (align_hybrid<.., REP>)
