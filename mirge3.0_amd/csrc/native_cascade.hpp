@@ -597,7 +597,7 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
         if (order[k] != skip && order[k] != big && R->g[order[k]].n && R->g[order[k]].n <= fused_max) n_small++;
     const bool spread = xaux_on && n_small > 1;
     if (spread && !c->xaux_forked) CHECK(xaux_fork(c));
-    // (the same assignment as small_group_slots, native_collapse.hpp: a small group's scatter kernel was put on the stream its cascade takes)
+    // (the same assignment as small_group_slots, native_collapse.hpp; with `xaux_forked` the caller's own: small_slot)
     int slot = 0;
     for (int k = 0; k < MIRGE_NGROUPS && rc == 0; k++) {
         const int gi = order[k];
@@ -608,11 +608,23 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
             continue;
         }
         if (gi != big && R->g[gi].n <= fused_max) {
-            if (spread && R->g[gi].n) c->cur = c->xaux[xaux_slot_of(slot++)];
+            if (c->xaux_forked) { if (c->small_slot[gi] >= 0) c->cur = c->xaux[c->small_slot[gi]]; }  // behind its own scatter kernel
+            else if (spread && R->g[gi].n) c->cur = c->xaux[xaux_slot_of(slot++)];
             MIRGE_BY_WIDTH(gi, rc, cascade_group_fused<W>(c, R->g[gi], res->g[gi], dsteps, rt, group_tag(gi)));
             continue;
         }
         MIRGE_BY_WIDTH(gi, rc, cascade_group<W>(c, R->g[gi], res->g[gi], steps, pol, rt, group_tag(gi), nullptr, 0, c->casc_dwalks[W == 1 ? 0 : 1]));
+    }
+    // (round 6, the mirge_collapse_cascade route) extra stream 0 collects the other extra streams now, behind its own last cascade: the
+    // join then has ONE stream to wait for (stream_join)
+    c->x0_gathered = false;
+    if (rc == 0 && c->xaux_forked && c->xaux_used) {
+        hipError_t e = hipSuccess;
+        for (int k = 1; k < xaux_slots() && e == hipSuccess; k++) {  // (the streams small_slot names)
+            e = hipEventRecord(c->ev_xjoin[k], c->xaux[k]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->xaux[0], c->ev_xjoin[k], 0);
+        }
+        c->x0_gathered = e == hipSuccess;
     }
     // no join here: the next entry point that needs one makes it (join_pending_now); mirge_count_join puts the bulk
     // group's part of its work in front of it
@@ -745,6 +757,7 @@ extern "C" int mirge_collapse_cascade(mirge_ctx* c, const mirge_reads* raw, cons
         c->overlap_mode = false;
         c->join_pending = false;  // (everything has drained: nothing is left to join)
         c->xaux_used = false;
+        c->x0_gathered = c->aux_drained = false;
         for (int gi = 0; gi < MIRGE_NGROUPS; gi++) {
             if (gi != hooked_group && !res->g[gi].pass) continue;
             ResGroup& g = res->g[gi];

@@ -575,7 +575,9 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
                     else MIRGE_BY_WIDTH(gi, rc, collapse_phase_b<W>(c, gi, raw->g[gi], R->g[gi], tmp[gi], S, small[gi], 0u, dmeta));
                 }
                 c->cur = c->stream;
-                c->xaux_forked = forked;  // (cascade_launch_groups: the extra streams already stand behind `aux`)
+                c->xaux_forked = forked;  // (cascade_launch_groups: the extra streams already stand behind `aux`, and where each group went)
+                static_assert(MIRGE_NGROUPS <= 16, "mirge_ctx::small_slot");
+                for (int gi = 0; gi < MIRGE_NGROUPS; gi++) c->small_slot[gi] = forked ? xslot[gi] : -1;
                 if (rc == 0) { rc = hook->small_ready(R.get(), big); small_done = rc == 0; }
                 c->xaux_forked = false;
             }
@@ -643,6 +645,7 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
         c->cur = c->stream;
         // (with the small groups' cascades already on their streams the join is the caller's: mirge_count_join puts work in front of it)
         if (!small_done) { int jr = stream_join(c); if (rc == 0) rc = jr; }
+        else c->aux_drained = rc == 0;  // (the host waited for ev_meta, the last thing queued on `aux`; the loop above put nothing there)
     }
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) collapse_tmp_release(c, tmp[gi]);
     c->flush_deferred();

@@ -84,7 +84,12 @@ struct mirge_ctx {
     // k_cascade_heavy (kernels_cascade.hpp): per read group {reads listed, workgroups done}, zero between launches; the threshold the
     // current configuration's steps carry (0: no library holds a bucket that large -- no deferral, no extra launch)
     uint32_t* heavy_cnt = nullptr;
-    bool xaux_forked = false;  // collapse_impl -> cascade_launch_groups: the extra streams were put behind `aux` for the scatter kernels
+    // (round 6) the join of a mirge_collapse_cascade step: extra stream 0 collected the other extra streams when the cascades were queued
+    // (x0_gathered), and the host has since waited for the last thing queued on `aux` (aux_drained): the main stream then waits for
+    // extra stream 0 alone -- one dependency packet and four runtime calls instead of two and eight in the step's tail
+    bool x0_gathered = false, aux_drained = false;
+    bool xaux_forked = false;  // collapse_impl -> cascade_launch_groups: the extra streams were put behind `aux` for the scatter kernels,
+    int small_slot[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // ... group gi's on extra stream small_slot[gi] (-1: on `aux`): its cascade goes there too
     uint32_t* spec_tickets = nullptr;  // [MIRGE_NGROUPS][MIRGE_SPEC_TICKET_ROUNDS], see k_cascade_spec
     uint32_t casc_big_t = 0;
     bool casc_rep = false;  // the configuration's libraries repeat themselves: the cascade kernels' repeat-aware build (align_hybrid<.., REP>)
@@ -217,6 +222,17 @@ static int stream_join(mirge_ctx* c) {
     c->cur = c->stream;
     hipError_t e = hipSuccess;
     const bool x = c->xaux_used;
+    static const bool short_join = !(std::getenv("MIRGE_SHORT_JOIN") && std::atoi(std::getenv("MIRGE_SHORT_JOIN")) == 0);  // A/B
+    const bool only_x0 = short_join && x && c->x0_gathered && c->aux_drained;
+    c->x0_gathered = c->aux_drained = false;
+    if (only_x0) {
+        c->xaux_used = false;
+        e = hipEventRecord(c->ev_xjoin[0], c->xaux[0]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_xjoin[0], 0);
+        c->flush_deferred();
+        if (e != hipSuccess) return fail(-2, std::string("stream join: ") + hipGetErrorString(e));
+        return 0;
+    }
     if (x) {
         // Every wait is a barrier packet its queue works through in order (~7 us each even when already satisfied), and a wait
         // that is NOT yet satisfied costs a queue-to-queue hop (~15 us) once it is.  `aux` (idle by then) collects the extra
