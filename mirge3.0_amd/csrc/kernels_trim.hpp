@@ -65,10 +65,7 @@ template <int MAXM, bool EXACT, bool FRONT, int WHICH = 0>
 __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_t* __restrict__ read, int n, int* hit = nullptr) {
     const uint8_t* const o_adapter = WHICH ? o.adapter2 : o.adapter;
     const uint8_t* const o_wild = WHICH ? o.wild2 : o.wild;
-    // (m is the same for every lane -- said so: the row loop's `i > m` is then a scalar compare and a branch per row; without it the
-    // compiler kept 2 x MAXM lane masks for `i <= m` / `i == m` alive across the column loop, most of them spilled and read back with two
-    // v_readlane per row and column)
-    const int m = EXACT ? MAXM : __builtin_amdgcn_readfirstlane(WHICH ? o.alen2 : o.alen);
+    const int m = EXACT ? MAXM : (WHICH ? o.alen2 : o.alen);
     // anchored (general kernel): FRONT = PrefixAdapter (flags STOP_WITHIN_SEQ2 alone: read and adapter both start at their
     // first base, first row and column cost their index, candidates stay the last row's cells); back = SuffixAdapter
     // (START_WITHIN_SEQ2 alone: the one candidate is the whole adapter ending at the read's last base)
@@ -106,9 +103,15 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
         // entry's 8 cost bits with the <= 64 a column can add --, origin 0)
         if (FRONT && anch) e[0] = ((no_indel_or ? 128u : (uint32_t)(j < 128 ? j : 128)) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS;
         uint32_t last = e[0];
+        // (round 6) m is the same number in every lane and every column; hidden from the optimiser per column, `i <= mj` is one scalar
+        // compare and a branch per row INSIDE the column loop, and the column's last row computed is row m.  Left to itself the compiler
+        // kept 2 x MAXM lane masks for `i <= m` / `i == m` alive across the column loop, most of them spilled and read back with two
+        // v_readlane per row and column.
+        int mj = m;
+        if (!EXACT) asm volatile("" : "+s"(mj));
 #pragma unroll
         for (int i = 1; i <= MAXM; i++) {
-            if (EXACT || i <= m) {
+            if (EXACT || i <= mj) {
                 const uint32_t left = e[i];  // previous column, same row
                 const uint32_t best3 = EXACT ? min(min(diag, e[i - 1] | (1u << 22)), left | (2u << 22))
                                              : min(min(diag, e[i - 1] | (1u << 22) | no_indel_or), left | (2u << 22) | no_indel_or);
@@ -117,7 +120,7 @@ __device__ __forceinline__ int adapter_cut_point(const TrimOpts& o, const uint8_
                 const uint32_t v = same ? diag + MIRGE_TRIM_MATCH_ONE : miss;
                 diag = left;
                 e[i] = v;
-                if (EXACT ? i == MAXM : i == m) last = v;
+                last = v;
             }
         }
         if (FRONT || !anch || j == n) consider(last, m, j);
@@ -205,8 +208,8 @@ __device__ __forceinline__ int adapter_cut_point_rt(const TrimOpts& o, const Ada
         // entry's 8 cost bits with the <= 64 a column can add --, origin 0)
         if (FRONT && anch) e[0] = ((no_indel_or ? 128u : (uint32_t)(j < 128 ? j : 128)) << MIRGE_TRIM_COST_SHIFT) | MIRGE_TRIM_ORIGIN_BIAS;
         uint32_t last = e[0];
-        int mj = m;  // (the same number every column, hidden from the optimiser: `i <= mj` stays one scalar compare per row INSIDE the
-        asm volatile("" : "+s"(mj));  // column loop instead of MAXM lane masks computed in front of it and kept in scalar registers)
+        int mj = m;  // (as in adapter_cut_point: one scalar compare per row inside the column loop, no lane masks kept across it)
+        asm volatile("" : "+s"(mj));
 #pragma unroll
         for (int i = 1; i <= MAXM; i++) {
             if (EXACT || i <= mj) {  // (rows run 1..m: the last one computed is row m)
