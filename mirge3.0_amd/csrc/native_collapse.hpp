@@ -407,8 +407,12 @@ static int xaux_slots() {
     return v;
 }
 static int xaux_slot_of(int k) { return k % xaux_slots(); }  // the k-th small group by size, 0 = the largest
+static uint32_t small_fused_max() {  // (cascade_launch_groups: the largest group that takes the one-launch cascade)
+    static const uint32_t v = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
+    return v;
+}
 static void small_group_slots(const uint32_t* n, int big, int* slot) {
-    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
+    const uint32_t fused_max = small_fused_max();
     static const bool xaux_on = !(std::getenv("MIRGE_XAUX") && std::atoi(std::getenv("MIRGE_XAUX")) == 0);
     int order[MIRGE_NGROUPS], no = 0;
     for (int gi = 0; gi < MIRGE_NGROUPS; gi++) { slot[gi] = -1; if (gi != big) order[no++] = gi; }
@@ -562,6 +566,15 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
                 small_group_slots(n_small_u, big, xslot);
                 bool forked = false;
                 for (int gi = 0; gi < MIRGE_NGROUPS; gi++) forked |= scatter_x && xslot[gi] >= 0;
+                // Not when a small group is large enough for the staged cascade (beyond MIRGE_FUSED_MAX unique reads: a 20 M-read sample's
+                // 32-64-nt group): its k_cascade_bulk<2> is a grid of resident workgroups like the bulk group's own, and whichever of the
+                // two is resident first keeps the other's remaining workgroups waiting until it retires.  With the scatter kernels one
+                // after the other on `aux` the bulk group's kernel has ~55 us of head start and is resident first in 83 of 87 steps; with
+                // them side by side in 55 of 79, and a step that loses the race takes 2.85 instead of 2.33 ms (20 M reads: 2.65 vs 2.26 ms
+                // per step on average, profiles/r06_ab_c4_shape.txt).  MIRGE_SCATTER_ON_XAUX=2: side by side regardless.
+                static const bool scatter_always = std::getenv("MIRGE_SCATTER_ON_XAUX") && std::atoi(std::getenv("MIRGE_SCATTER_ON_XAUX")) == 2;
+                for (int gi = 0; gi < MIRGE_NGROUPS && !scatter_always; gi++)
+                    if (gi != big && !is_long_group(gi) && small[gi] > small_fused_max()) forked = false;
                 // The extra streams take over from `aux` here, once, for the scatter kernels AND the cascades (cascade_launch_groups skips
                 // its own fork: four runtime calls less in front of the cascades).  Queued BEFORE the host's wait instead -- the calls off
                 // the chain -- it was slower: 0.403 vs 0.378 ms on the sample with few unique reads, 1.235 vs 1.217 ms on the default draw

@@ -289,12 +289,16 @@ extern "C" int mirge_ctx_create(int device, void* hip_stream, mirge_ctx** out) {
     hipDeviceProp_t prop;
     HIPOK(hipGetDeviceProperties(&prop, device));
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // MIRGE_STREAM_PRIORITY=1 (round 6 experiment): the main stream at the device's highest stream priority, the side streams at its lowest
+    static const bool prio = std::getenv("MIRGE_STREAM_PRIORITY") && std::atoi(std::getenv("MIRGE_STREAM_PRIORITY")) == 1;
+    int p_low = 0, p_high = 0;
+    if (prio) HIPOK(hipDeviceGetStreamPriorityRange(&p_low, &p_high));
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; }
-    else { HIPOK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    else { HIPOK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p_high)); c->own_stream = true; }
     c->cur = c->stream;
-    HIPOK(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    HIPOK(hipStreamCreateWithPriority(&c->aux, hipStreamNonBlocking, p_low));
     for (int k = 0; k < MIRGE_N_XAUX; k++) {
-        HIPOK(hipStreamCreateWithFlags(&c->xaux[k], hipStreamNonBlocking));
+        HIPOK(hipStreamCreateWithPriority(&c->xaux[k], hipStreamNonBlocking, p_low));
         HIPOK(hipEventCreateWithFlags(&c->ev_xjoin[k], hipEventDisableTiming));
     }
     HIPOK(hipEventCreateWithFlags(&c->ev_xfork, hipEventDisableTiming));
