@@ -578,7 +578,7 @@ static int cascade_launch_groups(mirge_ctx* c, const mirge_reads* R, mirge_resul
     const FusedSteps* dsteps = c->casc_dsteps;
     // MIRGE_FUSED_MAX: largest group (reads) that takes the one-launch path; 0 = always staged (tests).  Beyond ~0.5 M reads
     // the staged passes' compaction pays for their launches (20 M-read sample, 0.7 M reads of 32-64 nt: 3.17 -> 3.08 ms)
-    static const uint32_t fused_max = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
+    const uint32_t fused_max = small_fused_max();  // (native_collapse.hpp: the one reading of the variable)
     int rc = 0;
     const int big = big_is >= 0 ? big_is : largest_group(R);  // (big_is: the bulk group of a read set whose bulk count is not known yet)
     CHECK(stream_fork(c));

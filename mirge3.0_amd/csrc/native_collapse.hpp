@@ -395,9 +395,6 @@ static int collapse_impl(mirge_ctx* c, const mirge_reads* raw, const int32_t* sa
                          int64_t* n_uniq, CollapseHook* hook, const uint32_t* weights = nullptr, int32_t* dsample_in = nullptr,
                          uint32_t* dweight_in = nullptr);
 
-// Which extra stream the one-launch cascade of every small read group takes (cascade_launch_groups assigns them this way): the groups
-// other than `big` by size, largest first; one slot each for those that take the one-launch route, when there is more than one; -1:
-// the second stream.  n[gi] = reads of group gi.
 // How many of the extra streams the small groups are dealt over (MIRGE_XAUX_SLOTS, default 2).  The runtime maps this context's streams
 // onto four hardware queues: a third extra stream shares a queue with the second, and two streams taking turns on one queue pay a
 // dependency packet per turn (~12 us, profiles/r06_timeline_zipf.txt).  Two: 0.382 vs 0.409 ms on the sample with few unique reads,
@@ -411,6 +408,9 @@ static uint32_t small_fused_max() {  // (cascade_launch_groups: the largest grou
     static const uint32_t v = std::getenv("MIRGE_FUSED_MAX") ? (uint32_t)std::strtoul(std::getenv("MIRGE_FUSED_MAX"), nullptr, 10) : (1u << 19);
     return v;
 }
+// Which extra stream the one-launch cascade of every small read group takes (cascade_launch_groups assigns them this way): the groups
+// other than `big` by size, largest first; one slot each for those that take the one-launch route, when there is more than one; -1:
+// the second stream.  n[gi] = reads of group gi.
 static void small_group_slots(const uint32_t* n, int big, int* slot) {
     const uint32_t fused_max = small_fused_max();
     static const bool xaux_on = !(std::getenv("MIRGE_XAUX") && std::atoi(std::getenv("MIRGE_XAUX")) == 0);
