@@ -1392,7 +1392,8 @@ def test_long_reads_under_a_length_rule_beyond_255(ctx, ci_libs):
 
 @pytest.mark.parametrize("hooks", [dict(MIRGE_FUSED_MAX="0"), dict(MIRGE_FUSED_MAX="0", MIRGE_BULK_FUSED="0"), dict(MIRGE_EXACT_WALKS="0"),
                                    dict(MIRGE_SPEC_MAX="0"), dict(MIRGE_SPEC_MAX="100000000", MIRGE_CASCADE_REP="1"),
-                                   dict(MIRGE_SPEC_MAX="100000000", MIRGE_SPEC_TICKETS="1", MIRGE_XAUX_SLOTS="3")])
+                                   dict(MIRGE_SPEC_MAX="100000000", MIRGE_SPEC_TICKETS="1", MIRGE_XAUX_SLOTS="3"),
+                                   dict(MIRGE_SCATTER_ON_XAUX="2", MIRGE_FUSED_MAX="2000", MIRGE_STREAM_PRIORITY="1")])
 def test_staged_cascade_for_every_group(hooks):
     """Small read groups normally take k_cascade_fused (one launch for the whole cascade, no compaction); MIRGE_FUSED_MAX=0
     sends every group through the staged form with survivor lists instead -- k_cascade_bulk (all passes in one launch), or
@@ -1404,7 +1405,9 @@ def test_staged_cascade_for_every_group(hooks):
     sends them through k_cascade_fused as before, a huge MIRGE_SPEC_MAX every small group through the speculative form, here
     together with the repeat-aware build of the kernels (MIRGE_CASCADE_REP=1) that uniform libraries do not launch by themselves;
     MIRGE_SPEC_TICKETS=1 is the measured-and-left-off form with the pick inside k_cascade_spec (the workgroup that ends a round's
-    last step), MIRGE_XAUX_SLOTS=3 the small groups over three extra streams instead of two."""
+    last step), MIRGE_XAUX_SLOTS=3 the small groups over three extra streams instead of two.  The last set: groups beyond 2 000 reads
+    staged (so staged and one-launch small groups meet in one sample), the small groups' scatter kernels side by side regardless
+    (MIRGE_SCATTER_ON_XAUX=2: by itself only without a staged small group), streams with priorities (measured, off)."""
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
